@@ -1,0 +1,138 @@
+/*
+ * dfepe.h — C ABI of libdfepe_hip.so: the MI355X (gfx950) weighted-8-point hot path of deepFEPE.
+ *
+ * The reference (eric-yyjau/pytorch-deepFEPE) is pure Python and has no FFI layer; the drop-in
+ * boundary is therefore its Python call surface.  Each entry point below replaces
+ * the arithmetic of the cited reference function; the Python mirror of that surface
+ * (pytorch-deepfepe_amd/compat) binds these symbols with ctypes.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.  Every pointer is a DEVICE pointer to
+ *     contiguous fp32 (or int32 where stated) memory owned by the caller; nothing is allocated,
+ *     freed or retained by the library; there is no global mutable state (re-entrant).
+ *   - `stream` is a hipStream_t (NULL = default stream); work is enqueued asynchronously on it.
+ *     The caller has made the owning device current (PyTorch does).
+ *   - Return value: DFEPE_OK (0) or a negative DFEPE_ERR_* code; never throws.
+ *   - Layouts follow the reference tensors: points [B,N,3] row-major, matrices [.,3,3] row-major
+ *     flattened to 9, per-layer stacks [L,B,...].
+ *   - Convention of F: x2^T F x1 = 0 (deepFEPE/models/DeepFNet.py:203-205).
+ */
+#ifndef DFEPE_H
+#define DFEPE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFEPE_VERSION 100 /* 0.1.0 */
+
+#define DFEPE_OK 0
+#define DFEPE_ERR_INVALID_ARG (-1) /* null pointer, non-positive size, bad flag combination   */
+#define DFEPE_ERR_HIP (-2)         /* a HIP runtime call failed (launch, attribute)            */
+#define DFEPE_ERR_UNSUPPORTED (-3) /* valid request this build cannot serve (e.g. N too large) */
+
+/* floats per pair in the `save` buffer handed from dfepe_w8pt_fwd to dfepe_w8pt_bwd */
+#define DFEPE_SAVE_FLOATS 128
+
+/* flags for dfepe_w8pt_fwd / dfepe_w8pt_bwd */
+#define DFEPE_W8PT_RAW_MATCHES 1u /* `pts1` is matches_xy_ori [B,N,4] in pixels, `pts2` unused (may be NULL);
+                                     the image-size normalisation of NormalizeAndExpand_HW is fused in   */
+
+int dfepe_version(void);
+const char *dfepe_strerror(int code);
+int dfepe_save_floats(void);
+
+/*
+ * Weighted normalised 8-point fit, forward.
+ * Replaces: Fit.forward / Fit.weighted_svd / Fit.normalize (deepFEPE/models/DeepFNet.py:148-179,181-257,278-295),
+ *           with DFEPE_W8PT_RAW_MATCHES also NormalizeAndExpand_HW (DeepFNet.py:93-120),
+ *           and, when epi_res != NULL, utils_F.compute_epi_residual(pts1, pts2, out, clamp_at)
+ *           (deepFEPE/dsac_tools/utils_F.py:400-413) as called in the recurrent loop (DeepFNet.py:479).
+ *
+ *   pts1, pts2 [B,N,3]  homogeneous points (pts*[:,:,2] is used exactly like the reference does), or
+ *   pts1       [B,N,4]  pixel matches when DFEPE_W8PT_RAW_MATCHES (image_w/image_h = W,H of image_size)
+ *   weights    [B,N]    (the reference's [B,1,N])
+ *   F_out      [B,9]    T2^T F' T1                          (reference `out`)
+ *   residual   [B,N]    X f/|f|                             (reference `residual`)
+ *   epi_res    [B,N]    or NULL
+ *   save       [B,DFEPE_SAVE_FLOATS] or NULL (needed for backward)
+ * Sign gauge: the reference inherits LAPACK's arbitrary sign of f; here f is oriented so that its
+ * largest-magnitude component is positive (F_out and residual flip together, everything downstream is
+ * sign-invariant).
+ */
+int dfepe_w8pt_fwd(const float *pts1, const float *pts2, const float *weights, int B, int N,
+                   unsigned flags, float image_w, float image_h, float clamp_at,
+                   float *F_out, float *residual, float *epi_res, float *save, void *stream);
+
+/*
+ * Backward of dfepe_w8pt_fwd w.r.t. the weights (analytic eigenvector / rank-2 / epipolar-residual
+ * adjoints; replaces torch.autograd through the per-sample torch.svd calls, DeepFNet.py:232-256).
+ *   g_F [B,9], g_residual [B,N], g_epi [B,N]: upstream gradients, each may be NULL (= zero)
+ *   F_out: the forward output (needed when g_epi != NULL)
+ *   g_weights [B,N]: written (not accumulated)
+ */
+int dfepe_w8pt_bwd(const float *pts1, const float *pts2, const float *weights, int B, int N,
+                   unsigned flags, float image_w, float image_h, float clamp_at,
+                   const float *save, const float *F_out,
+                   const float *g_F, const float *g_residual, const float *g_epi,
+                   float *g_weights, void *stream);
+
+/*
+ * F-loss and E-from-F over all layers.
+ * Replaces: the per-layer body of get_all_loss_DeepF (deepFEPE/train_good_utils.py:325-358):
+ *   pts*_eval = T* virt*^T ; losses = compute_epi_residual(pts1_eval, pts2_eval, F_layer, clamp_at) ;
+ *   E_layer = K^T T2^T F_layer T1 K.
+ *   F_layers [L,B,9]; T1,T2 [B,9] (t_stride = 9) or a single [9] shared by the batch (t_stride = 0);
+ *   K [B,9]; virt1, virt2 [B,M,3]
+ *   loss_sum [L,B]  = sum over the M virtual points of the clamped residual (caller divides by M / B)
+ *   E_layers [L,B,9] or NULL
+ */
+int dfepe_floss_fwd(const float *F_layers, int L, int B, const float *T1, const float *T2, int t_stride,
+                    const float *K, const float *virt1, const float *virt2, int M, float clamp_at,
+                    float *loss_sum, float *E_layers, void *stream);
+
+/*  g_loss_sum [L,B] or NULL, g_E [L,B,9] or NULL  ->  g_F_layers [L,B,9] (written) */
+int dfepe_floss_bwd(const float *F_layers, int L, int B, const float *T1, const float *T2, int t_stride,
+                    const float *K, const float *virt1, const float *virt2, int M, float clamp_at,
+                    const float *g_loss_sum, const float *g_E, float *g_F_layers, void *stream);
+
+/*
+ * Pose loss: decompose E^T into the two rotations / two translations, compare with the ground truth.
+ * Replaces: the per-layer, per-sample loop of get_Rt_loss (deepFEPE/train_good_utils.py:96-239):
+ *   utils_F._get_M2s (utils_F.py:478-498), utils_geo._R_to_q (utils_geo.py:58-86), _l2_error (:165-167),
+ *   strict-'<' candidate selection (:160-168), rot12_to_angle_error (:150-155), vector_angle (:175-179).
+ *   E_layers [L,B,9]; q_gt [B,4] (qs_cam); t_gt [B,3] (ts_cam, normalised inside); R_gt [B,9] = inv(delta)[:3,:3]
+ *   q_l2, t_l2 [L,B]; R_deg, t_deg [L,B] (may be NULL); sel [L,B] int32 (bit0: R candidate, bit1: t candidate; may be NULL)
+ */
+int dfepe_pose_fwd(const float *E_layers, int L, int B, const float *q_gt, const float *t_gt, const float *R_gt,
+                   float *q_l2, float *t_l2, float *R_deg, float *t_deg, int *sel, void *stream);
+
+/*  g_q_l2, g_t_l2 [L,B] (either may be NULL) -> g_E [L,B,9] (written) */
+int dfepe_pose_bwd(const float *E_layers, int L, int B, const float *q_gt, const float *t_gt,
+                   const float *g_q_l2, const float *g_t_l2, float *g_E, void *stream);
+
+/*
+ * Cheirality-checked pose from E.
+ * Replaces: utils_F._E_to_M_train (deepFEPE/dsac_tools/utils_F.py:679-763): the four candidates of _get_M2s in
+ * the order (R1,t),(R1,-t),(R2,t),(R2,-t), linear triangulation of every correspondence (the reference calls
+ * cv2.triangulatePoints), count of points with 0 < Z < depth_thres in both cameras, first arg-max wins.
+ *   E [B,9]; K [B,9]; matches [B,N,4] pixels
+ *   Rt_cam [B,12]  inverse (camera motion) of the winner, zeros when no candidate has a valid point
+ *   winner [B] int32 (-1 when none); counts [B,4] int32
+ */
+int dfepe_cheirality(const float *E, const float *K, const float *matches, int B, int N, float depth_thres,
+                     float *Rt_cam, int *winner, int *counts, void *stream);
+
+/*
+ * Epipolar metrics of dsac_tools.utils_F (utils_F.py:291-361) on homogeneous-or-not 2-D points.
+ *   kind: 0 = _sym_epi_dist (squared, eps 1e-10 as in the batched branch), 1 = _sampson_dist,
+ *         2 = _epi_distance (writes 3 planes: mean, d1, d2)
+ *   F [B,9]; X, Y [B,N,2]; out [B,N] (kind 0,1) or [3,B,N] (kind 2); clamp_at <= 0 means no clamp (kind 0 only)
+ */
+int dfepe_epi_metrics(int kind, const float *F, const float *X, const float *Y, int B, int N, float clamp_at,
+                      float eps, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFEPE_H */

@@ -1,0 +1,62 @@
+"""ctypes binding of libdfepe_hip.so (the C ABI declared in include/dfepe.h).
+
+The library is the product: there is no CPU fallback.  `lib()` raises if the shared object is
+missing, so a GPU box without the HIP extension fails loudly instead of silently running something else.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_uint, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdfepe_hip.so")
+
+OK = 0
+W8PT_RAW_MATCHES = 1
+
+_P = c_void_p
+_SIGNATURES = {
+    "dfepe_version": (c_int, []),
+    "dfepe_strerror": (c_char_p, [c_int]),
+    "dfepe_save_floats": (c_int, []),
+    "dfepe_w8pt_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_uint, c_float, c_float, c_float, _P, _P, _P, _P, _P]),
+    "dfepe_w8pt_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_uint, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "dfepe_floss_fwd": (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, c_float, _P, _P, _P]),
+    "dfepe_floss_bwd": (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, c_float, _P, _P, _P, _P]),
+    "dfepe_pose_fwd": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dfepe_pose_bwd": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "dfepe_cheirality": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P, _P]),
+    "dfepe_epi_metrics": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_float, c_float, _P, _P]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class DfepeError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the HIP library; raises DfepeError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DfepeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python pytorch-deepfepe_amd/build.py` or `__graft_entry__.build()`); there is no CPU fallback"
+            )
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != OK:
+        msg = lib().dfepe_strerror(code).decode()
+        raise DfepeError(f"{what} failed: {msg} (code {code})")

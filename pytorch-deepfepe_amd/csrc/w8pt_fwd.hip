@@ -1,0 +1,436 @@
+// w8pt_fwd — weighted normalised 8-point fit, forward.  One wavefront (64 lanes) per image pair.
+//
+// Restates (not from the reference source) the arithmetic of
+//   NormalizeAndExpand_HW   deepFEPE/models/DeepFNet.py:93-120   (fused when RAW)
+//   Fit.normalize           deepFEPE/models/DeepFNet.py:148-179  (Hartley, unit weights, literal 1.4142)
+//   Fit.weighted_svd        deepFEPE/models/DeepFNet.py:181-257
+//   compute_epi_residual    deepFEPE/dsac_tools/utils_F.py:400-413
+//
+// Phases (all wave-synchronous, no block barrier; the 4 waves of a block are independent pairs):
+//   0  coalesced global -> LDS copy of the pair's correspondences (+ weights), coordinate sums
+//   1  mean distance to the centroid  -> Hartley scale                      (wave reductions, fp64)
+//   2  rows p/|p| * w, 45 upper-triangular sums of X^T X per lane in fp64   (exact products of fp32 data)
+//   3  recursive-halving reduce-scatter of the 45 sums across the wave -> 9x9 A in LDS (both triangles)
+//   4  parallel-ordering two-sided Jacobi on A (fp64, 4 disjoint rotations per round, 9 rounds per sweep),
+//      eigenvectors accumulated in V (LDS); wave-uniform convergence test per sweep
+//   5  f = eigenvector of the smallest eigenvalue; 3x3 SVD; F' = F - s3 u3 v3^T; out = T2^T F' T1
+//   6  residual_i = X_i . f and the symmetric epipolar residual per correspondence (coalesced stores)
+// No MFMA: the only contraction (X^T X, 9xN by Nx9) is far too skinny; the rest is eigen work.
+#include "dfepe_common.h"
+
+namespace {
+
+__constant__ unsigned char kTriI[45] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2,
+                                        2, 3, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 6, 6, 6, 7, 7, 8};
+__constant__ unsigned char kTriJ[45] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 1, 2, 3, 4, 5, 6, 7, 8, 2, 3, 4, 5, 6, 7,
+                                        8, 3, 4, 5, 6, 7, 8, 4, 5, 6, 7, 8, 5, 6, 7, 8, 6, 7, 8, 7, 8, 8};
+
+// X^T X = sum_i k_i^2 (b b^T) (x) (a a^T) with a = (x1~,y1~,z1), b = (x2~,y2~,1): only 6 x 6 = 36 distinct sums.
+// pair tables for the 6 distinct entries of a symmetric 3x3 outer product
+__constant__ unsigned char kSymR[6] = {0, 0, 0, 1, 1, 2};
+__constant__ unsigned char kSymC[6] = {0, 1, 2, 1, 2, 2};
+
+constexpr int kWsDoubles = 216;  // per-wave fp64 workspace in LDS: A[81] V[81] CS[18] + pad  (1728 B, 16-B multiple)
+constexpr int kMaxSweeps = 12;
+constexpr double kJacobiTol = 1e-26;  // stop when off(A)^2 <= tol * diag(A)^2
+
+struct Pt {
+  float x1, y1, z1, x2, y2, z2;
+};
+
+template <bool RAW>
+__device__ __forceinline__ Pt lds_point(const float* P, int i, int npad) {
+  Pt p;
+  if (RAW) {
+    const float4 m = reinterpret_cast<const float4*>(P)[i];
+    p.x1 = m.x; p.y1 = m.y; p.z1 = 1.0f; p.x2 = m.z; p.y2 = m.w; p.z2 = 1.0f;
+  } else {
+    const float* a = P + 3 * i;
+    const float* b = P + 3 * npad + 3 * i;
+    p.x1 = a[0]; p.y1 = a[1]; p.z1 = a[2]; p.x2 = b[0]; p.y2 = b[1]; p.z2 = b[2];
+  }
+  return p;
+}
+
+// Row of the design matrix for one correspondence: X = w * p / max(|p|, 1e-12), fp64.
+__device__ __forceinline__ void design_row(const Pt& p, double w, double s1, double c1x, double c1y, double s2,
+                                           double c2x, double c2y, double* X) {
+  const double z1 = p.z1;
+  const double a0 = s1 * ((double)p.x1 - c1x * z1), a1 = s1 * ((double)p.y1 - c1y * z1), a2 = z1;
+  const double z2 = p.z2;
+  const double b0 = s2 * ((double)p.x2 - c2x * z2), b1 = s2 * ((double)p.y2 - c2y * z2);
+  X[0] = b0 * a0; X[1] = b0 * a1; X[2] = b0 * a2;
+  X[3] = b1 * a0; X[4] = b1 * a1; X[5] = b1 * a2;
+  X[6] = a0;      X[7] = a1;      X[8] = a2;
+  double n2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) n2 += X[k] * X[k];
+  // NaN/Inf rows are dropped (the reference scrubs NaN in X on its default path, models/model_utils.py:5-15)
+  const bool ok = (n2 < 1e300) && (fabs(w) < 1e300);
+  const double sc = ok ? w / fmax(sqrt(n2), 1e-12) : 0.0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) X[k] = ok ? X[k] * sc : 0.0;
+}
+
+// One halving step of the reduce-scatter: CNT live values per lane -> (CNT+1)/2.
+template <int CNT>
+__device__ __forceinline__ void halve(double* a, bool upper, int mask) {
+  constexpr int H = (CNT + 1) / 2;
+#pragma unroll
+  for (int k = 0; k < H; ++k) {
+    const double lo = a[k];
+    const double hi = (k + H < CNT) ? a[k + H] : 0.0;
+    const double send = upper ? lo : hi;
+    const double keep = upper ? hi : lo;
+    a[k] = keep + __shfl_xor(send, mask, WAVE);
+  }
+}
+
+template <bool RAW>
+__global__ void __launch_bounds__(256, 4)
+w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, const float* __restrict__ wts,
+                int B, int N, int npad, int wave_bytes, float hw_sx, float hw_sy, float clamp_at,
+                float* __restrict__ F_out, float* __restrict__ residual, float* __restrict__ epi_res,
+                float* __restrict__ save) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int pair = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (pair >= B) return;  // whole wave leaves; there is no block-level barrier in this kernel
+
+  unsigned char* base = smem + (size_t)wave * wave_bytes;
+  double* A = reinterpret_cast<double*>(base);
+  double* V = A + 81;
+  double* CS = V + 81;
+  float* P = reinterpret_cast<float*>(base + kWsDoubles * sizeof(double));
+  float* W = P + (RAW ? 4 : 6) * npad;
+
+  // ---- phase 0: stage the pair in LDS, coordinate sums ------------------------------------------
+  double sx1 = 0, sy1 = 0, sx2 = 0, sy2 = 0;
+  const float* wsrc = wts + (size_t)pair * N;
+  if (RAW) {
+    const float4* src = reinterpret_cast<const float4*>(pts1) + (size_t)pair * N;
+    for (int i = lane; i < N; i += WAVE) {
+      float4 m = src[i];
+      m.x = fmaf(m.x, hw_sx, -1.0f);
+      m.y = fmaf(m.y, hw_sy, -1.0f);
+      m.z = fmaf(m.z, hw_sx, -1.0f);
+      m.w = fmaf(m.w, hw_sy, -1.0f);
+      reinterpret_cast<float4*>(P)[i] = m;
+      W[i] = wsrc[i];
+      sx1 += m.x; sy1 += m.y; sx2 += m.z; sy2 += m.w;
+    }
+  } else {
+    const float* s1p = pts1 + (size_t)pair * N * 3;
+    const float* s2p = pts2 + (size_t)pair * N * 3;
+    for (int t = lane; t < 3 * N; t += WAVE) {
+      P[t] = s1p[t];
+      P[3 * npad + t] = s2p[t];
+    }
+    for (int i = lane; i < N; i += WAVE) W[i] = wsrc[i];
+    wave_sync();
+    for (int i = lane; i < N; i += WAVE) {
+      const Pt p = lds_point<false>(P, i, npad);
+      sx1 += p.x1; sy1 += p.y1; sx2 += p.x2; sy2 += p.y2;
+    }
+  }
+  const double invN = 1.0 / (double)N;
+  const double c1x = to_sgpr(wave_sum(sx1) * invN), c1y = to_sgpr(wave_sum(sy1) * invN);
+  const double c2x = to_sgpr(wave_sum(sx2) * invN), c2y = to_sgpr(wave_sum(sy2) * invN);
+  wave_sync();
+
+  // ---- phase 1: Hartley scale -------------------------------------------------------------------
+  double d1 = 0, d2 = 0;
+  for (int i = lane; i < N; i += WAVE) {
+    const Pt p = lds_point<RAW>(P, i, npad);
+    const double ax = (double)p.x1 - c1x, ay = (double)p.y1 - c1y;
+    const double bx = (double)p.x2 - c2x, by = (double)p.y2 - c2y;
+    d1 += sqrt(ax * ax + ay * ay);
+    d2 += sqrt(bx * bx + by * by);
+  }
+  const double s1 = to_sgpr(1.4142 / (wave_sum(d1) * invN));  // the reference uses the literal, not sqrt(2) (DeepFNet.py:168)
+  const double s2 = to_sgpr(1.4142 / (wave_sum(d2) * invN));
+
+  // ---- phase 2: X^T X as 36 distinct fp64 sums per lane (exact products of fp32-derived factors) ---------
+  double acc[36];
+#pragma unroll
+  for (int e = 0; e < 36; ++e) acc[e] = 0.0;
+  for (int i = lane; i < N; i += WAVE) {
+    const Pt p = lds_point<RAW>(P, i, npad);
+    const double w = (double)W[i];
+    const double z1 = p.z1, z2 = p.z2;
+    const double a0 = s1 * ((double)p.x1 - c1x * z1), a1 = s1 * ((double)p.y1 - c1y * z1), a2 = z1;
+    const double b0 = s2 * ((double)p.x2 - c2x * z2), b1 = s2 * ((double)p.y2 - c2y * z2);
+    const double n2 = (a0 * a0 + a1 * a1 + a2 * a2) * (b0 * b0 + b1 * b1 + 1.0);  // |p|^2
+    const bool ok = (n2 < 1e300) && (fabs(w) < 1e150);
+    const double k2 = ok ? (w * w) / fmax(n2, 1e-24) : 0.0;                        // (w / max(|p|,1e-12))^2
+    const double aa[6] = {a0 * a0, a0 * a1, a0 * a2, a1 * a1, a1 * a2, a2 * a2};
+    const double bb[6] = {k2 * b0 * b0, k2 * b0 * b1, k2 * b0, k2 * b1 * b1, k2 * b1, k2};
+    if (ok) {
+#pragma unroll
+      for (int u = 0; u < 6; ++u)
+#pragma unroll
+        for (int v = 0; v < 6; ++v) acc[6 * u + v] += bb[u] * aa[v];
+    }
+  }
+
+  // ---- phase 3: reduce-scatter across the wave; lane ends up owning (at most) one distinct sum -------------
+  halve<36>(acc, lane & 32, 32);
+  halve<18>(acc, lane & 16, 16);
+  halve<9>(acc, lane & 8, 8);
+  halve<5>(acc, lane & 4, 4);
+  halve<3>(acc, lane & 2, 2);
+  halve<2>(acc, lane & 1, 1);
+  {
+    // mirror the fixed halving schedule 36 -> 18 -> 9 -> 5 -> 3 -> 2 -> 1: `idx` is the distinct sum this lane
+    // ends up owning, `cnt` how many of its slots were real data (<= 0: the lane holds padding)
+    int cnt = 36, idx = 0, width = 36;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const int h = (width + 1) / 2;
+      if (lane & m) { idx += h; cnt -= h; } else { cnt = (cnt < h) ? cnt : h; }
+      width = h;
+    }
+    if (cnt >= 1) {
+      // sum (u,v) is A[3r+c][3r'+c'] for (r,r') = sym pair u, (c,c') = sym pair v, and its 3 index swaps
+      const int u = idx / 6, v = idx % 6;
+      const int r0 = kSymR[u], r1 = kSymC[u], q0 = kSymR[v], q1 = kSymC[v];
+      const double val = acc[0];
+      const int i00 = 3 * r0 + q0, i01 = 3 * r0 + q1, i10 = 3 * r1 + q0, i11 = 3 * r1 + q1;
+      A[i00 * 9 + i11] = val; A[i11 * 9 + i00] = val;
+      A[i01 * 9 + i10] = val; A[i10 * 9 + i01] = val;
+    }
+    V[lane] = (lane % 10 == 0) ? 1.0 : 0.0;  // identity: element e is diagonal iff e % 10 == 0
+    if (lane < 17) V[lane + 64] = ((lane + 64) % 10 == 0) ? 1.0 : 0.0;
+  }
+  wave_sync();
+
+  // ---- phase 4: two-sided Jacobi, round-robin parallel ordering ------------------------------------
+  // round r pairs index i with (2r - i) mod 9; index r sits out.  A' = J^T A J, V' = V J with, for the
+  // pair (p<q):  J_pp = J_qq = c, J_pq = s, J_qp = -s.  Per index k we keep (c_k, sh_k) where
+  // sh_p = -s and sh_q = +s, so that  col_k' = c_k col_k + sh_k col_partner(k)  (and the same for rows).
+  const int ti = (lane < 45) ? kTriI[lane] : 0;
+  const int tj = (lane < 45) ? kTriJ[lane] : 0;
+  const int vi0 = lane / 9, vj0 = lane % 9;
+  const int vi1 = (lane + 64) / 9, vj1 = (lane + 64) % 9;
+  for (int sweep = 0; sweep < ((clamp_at < 0.f) ? 0 : kMaxSweeps); ++sweep) {  // DEBUG: negative hw_sx skips Jacobi
+    double off = 0.0, dg = 0.0;
+    if (lane < 45) {
+      const double a = A[ti * 9 + tj];
+      if (ti == tj) dg = a * a; else off = a * a;
+    }
+    off = wave_sum(off);
+    dg = wave_sum(dg);
+    if (!(off > kJacobiTol * dg)) break;  // wave-uniform (also leaves on NaN)
+    for (int r = 0; r < 9; ++r) {
+      if (lane < 9) {
+        const int i = lane;
+        const int j = (2 * r + 9 - i) % 9;
+        double c = 1.0, sh = 0.0;
+        if (j != i) {
+          const int p = (i < j) ? i : j, q = (i < j) ? j : i;
+          const double app = A[p * 10], aqq = A[q * 10], apq = A[p * 9 + q];
+          if (apq != 0.0) {
+            const double th = (aqq - app) / (2.0 * apq);
+            const double t = copysign(1.0, th) / (fabs(th) + sqrt(th * th + 1.0));
+            c = 1.0 / sqrt(t * t + 1.0);
+            const double s = t * c;
+            sh = (i == p) ? -s : s;
+          }
+        }
+        CS[2 * i] = c;
+        CS[2 * i + 1] = sh;
+      }
+      wave_sync();
+      double anew = 0.0;
+      if (lane < 45) {
+        const int ip = (2 * r + 9 - ti) % 9, jp = (2 * r + 9 - tj) % 9;
+        const double ci = CS[2 * ti], si = CS[2 * ti + 1], cj = CS[2 * tj], sj = CS[2 * tj + 1];
+        const double a00 = A[ti * 9 + tj], a01 = A[ti * 9 + jp], a10 = A[ip * 9 + tj], a11 = A[ip * 9 + jp];
+        anew = ci * (cj * a00 + sj * a01) + si * (cj * a10 + sj * a11);
+      }
+      double v0, v1 = 0.0;
+      {
+        const int jp = (2 * r + 9 - vj0) % 9;
+        v0 = CS[2 * vj0] * V[vi0 * 9 + vj0] + CS[2 * vj0 + 1] * V[vi0 * 9 + jp];
+      }
+      if (lane < 17) {
+        const int jp = (2 * r + 9 - vj1) % 9;
+        v1 = CS[2 * vj1] * V[vi1 * 9 + vj1] + CS[2 * vj1 + 1] * V[vi1 * 9 + jp];
+      }
+      wave_sync();
+      if (lane < 45) {
+        A[ti * 9 + tj] = anew;
+        A[tj * 9 + ti] = anew;
+      }
+      V[lane] = v0;
+      if (lane < 17) V[lane + 64] = v1;
+      wave_sync();
+    }
+  }
+
+  // ---- phase 5: smallest eigenpair, rank-2 projection, de-normalisation (wave-uniform arithmetic) ---
+  // torch.svd(X)[2][:, -1] is the right singular vector of the smallest of the min(N,9) singular values
+  // (DeepFNet.py:232-233): for N >= 9 the smallest eigenvalue of X^T X; for N < 9 the reduced SVD has only N
+  // columns, so the reference takes the smallest of the N *non-null* directions.  `skip` = 9 - min(N,9)
+  // eigenvalues are passed over (ascending order, index as tie-break) to mirror that.
+  double lam[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) lam[k] = A[k * 10];
+  const int skip = (N < 9) ? 9 - N : 0;
+  int kmin = 0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) rank += (lam[j] < lam[k] || (lam[j] == lam[k] && j < k)) ? 1 : 0;
+    if (rank == skip) kmin = k;
+  }
+  double f[9];
+  double fn2 = 0.0;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    f[c] = V[c * 9 + kmin];
+    fn2 += f[c] * f[c];
+  }
+  // orientation: largest-magnitude component positive (first one on ties)
+  double big = f[0];
+#pragma unroll
+  for (int c = 1; c < 9; ++c)
+    if (fabs(f[c]) > fabs(big)) big = f[c];
+  const double sgn = (big < 0.0) ? -1.0 : 1.0;
+  const double fscale = sgn / sqrt(fn2);
+#pragma unroll
+  for (int c = 0; c < 9; ++c) f[c] *= fscale;
+
+  float Ff[9], U3[9], S3[3], V3[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) Ff[c] = (float)f[c];
+  svd3<float>(Ff, U3, S3, V3);
+  // s3 = u3^T F v3 in fp64 (stationary w.r.t. first-order errors of u3, v3), F' = F - s3 u3 v3^T
+  double s3 = 0.0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s3 += (double)U3[3 * r + 2] * f[3 * r + c] * (double)V3[3 * c + 2];
+  double Fp[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Fp[3 * r + c] = f[3 * r + c] - s3 * (double)U3[3 * r + 2] * (double)V3[3 * c + 2];
+  // out = T2^T F' T1,  T = [[s,0,-s cx],[0,s,-s cy],[0,0,1]]
+  double Mx[9], out[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    Mx[3 * r + 0] = s1 * Fp[3 * r + 0];
+    Mx[3 * r + 1] = s1 * Fp[3 * r + 1];
+    Mx[3 * r + 2] = Fp[3 * r + 2] - s1 * (c1x * Fp[3 * r + 0] + c1y * Fp[3 * r + 1]);
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    out[c] = s2 * Mx[c];
+    out[3 + c] = s2 * Mx[3 + c];
+    out[6 + c] = Mx[6 + c] - s2 * (c2x * Mx[c] + c2y * Mx[3 + c]);
+  }
+  float of[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) of[c] = (float)out[c];
+  if (lane == 0) {
+    float* dst = F_out + (size_t)pair * 9;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) dst[c] = of[c];
+  }
+  if (save != nullptr) {
+    float* sv = save + (size_t)pair * DFEPE_SAVE_FLOATS;
+    {
+      const int k = lane / 9, c = lane % 9;
+      sv[SV_Q + lane] = (clamp_at < 0.f) ? (float)A[lane] : (float)V[c * 9 + k];
+    }
+    if (lane < 17) {
+      const int e = lane + 64, k = e / 9, c = e % 9;
+      sv[SV_Q + e] = (clamp_at < 0.f) ? (float)A[e] : (float)V[c * 9 + k];
+    }
+    if (lane < 9) sv[SV_LAM + lane] = (float)A[lane * 10];
+    if (lane == 0) {
+      sv[SV_T1 + 0] = (float)s1; sv[SV_T1 + 1] = (float)c1x; sv[SV_T1 + 2] = (float)c1y;
+      sv[SV_T2 + 0] = (float)s2; sv[SV_T2 + 1] = (float)c2x; sv[SV_T2 + 2] = (float)c2y;
+      sv[SV_KMIN] = (float)kmin;
+      sv[SV_SIGN] = (float)sgn;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) { sv[SV_U3 + c] = U3[c]; sv[SV_V3 + c] = V3[c]; }
+      sv[SV_S3 + 0] = S3[0]; sv[SV_S3 + 1] = S3[1]; sv[SV_S3 + 2] = (float)s3;
+#pragma unroll
+      for (int c = 119; c < DFEPE_SAVE_FLOATS; ++c) sv[c] = 0.0f;
+    }
+  }
+
+  // ---- phase 6: per-correspondence outputs ----------------------------------------------------------
+  float* rdst = residual + (size_t)pair * N;
+  float* edst = (epi_res != nullptr) ? epi_res + (size_t)pair * N : nullptr;
+  for (int i = lane; i < N; i += WAVE) {
+    const Pt p = lds_point<RAW>(P, i, npad);
+    double X[9];
+    design_row(p, (double)W[i], s1, c1x, c1y, s2, c2x, c2y, X);
+    double r = 0.0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) r += X[c] * f[c];
+    rdst[i] = (float)r;
+    if (edst != nullptr) {
+      // l1 = F^T x2 (row form x2 F), l2 = F x1, dd = x2^T F x1 = x1 . l1     (utils_F.py:402-411), fp32 like the reference
+      const float l1x = fmaf(p.x2, of[0], fmaf(p.y2, of[3], p.z2 * of[6]));
+      const float l1y = fmaf(p.x2, of[1], fmaf(p.y2, of[4], p.z2 * of[7]));
+      const float l1z = fmaf(p.x2, of[2], fmaf(p.y2, of[5], p.z2 * of[8]));
+      const float l2x = fmaf(p.x1, of[0], fmaf(p.y1, of[1], p.z1 * of[2]));
+      const float l2y = fmaf(p.x1, of[3], fmaf(p.y1, of[4], p.z1 * of[5]));
+      const float dd = fmaf(p.x1, l1x, fmaf(p.y1, l1y, p.z1 * l1z));
+      const float n1 = sqrtf(fmaf(l1x, l1x, l1y * l1y)) + 1e-6f;
+      const float n2 = sqrtf(fmaf(l2x, l2x, l2y * l2y)) + 1e-6f;
+      const float d = fabsf(dd) * (1.0f / n1 + 1.0f / n2);
+      edst[i] = fminf(d, clamp_at);
+    }
+  }
+}
+
+}  // namespace
+
+// host-side launcher ------------------------------------------------------------------------------------
+extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float* weights, int B, int N,
+                              unsigned flags, float image_w, float image_h, float clamp_at, float* F_out,
+                              float* residual, float* epi_res, float* save, void* stream) {
+  const bool raw = (flags & DFEPE_W8PT_RAW_MATCHES) != 0;
+  if (B < 0 || N <= 0) return DFEPE_ERR_INVALID_ARG;
+  if (B == 0) return DFEPE_OK;
+  if (!pts1 || (!raw && !pts2) || !weights || !F_out || !residual) return DFEPE_ERR_INVALID_ARG;
+  if (raw && !(image_w > 0.f && image_h > 0.f)) return DFEPE_ERR_INVALID_ARG;
+  if (raw && (reinterpret_cast<uintptr_t>(pts1) & 15u)) return DFEPE_ERR_INVALID_ARG;  // float4 loads
+
+  const int npad = (N + 3) & ~3;
+  const int wave_bytes = kWsDoubles * (int)sizeof(double) + (raw ? 5 : 7) * npad * (int)sizeof(float);
+  int waves = 4;
+  const int lds_cap = 160 * 1024;
+  while (waves > 1 && waves * wave_bytes > lds_cap) waves >>= 1;
+  if (waves * wave_bytes > lds_cap) return DFEPE_ERR_UNSUPPORTED;  // N > ~8000 (raw) / ~5800 (pts): not staged in LDS yet
+  const size_t lds = (size_t)waves * wave_bytes;
+  const dim3 grid((B + waves - 1) / waves), block(64 * waves);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const float hw_sx = raw ? 2.0f / image_w : 0.f, hw_sy = raw ? 2.0f / image_h : 0.f;
+  hipError_t err;
+  if (raw) {
+    if (lds > 64 * 1024) {
+      err = hipFuncSetAttribute(reinterpret_cast<const void*>(&w8pt_fwd_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (err != hipSuccess) return DFEPE_ERR_HIP;
+    }
+    hipLaunchKernelGGL(w8pt_fwd_kernel<true>, grid, block, lds, st, pts1, pts2, weights, B, N, npad, wave_bytes,
+                       hw_sx, hw_sy, clamp_at, F_out, residual, epi_res, save);
+  } else {
+    if (lds > 64 * 1024) {
+      err = hipFuncSetAttribute(reinterpret_cast<const void*>(&w8pt_fwd_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (err != hipSuccess) return DFEPE_ERR_HIP;
+    }
+    hipLaunchKernelGGL(w8pt_fwd_kernel<false>, grid, block, lds, st, pts1, pts2, weights, B, N, npad, wave_bytes,
+                       hw_sx, hw_sy, clamp_at, F_out, residual, epi_res, save);
+  }
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
