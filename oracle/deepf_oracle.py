@@ -215,7 +215,7 @@ def f_loss(outs: Dict[str, object], pts1_virt: Tensor, pts2_virt: Tensor, Ks: Te
         "loss_min_batch": per_pair.min(dim=0)[0],  # (:376)
         "loss_per_pair": per_pair,
     }
-    if depth > 1:  # (:429-438) logged only
+    if depth > 1 and len(outs.get("epi_res_layers", [])) > 0:  # (:429-438) logged only
         l = [(e * w).mean() for e, w in zip(outs["epi_res_layers"], outs["weights_layers"])]
         losses["loss_epi_res_layers"] = l
         losses["loss_epi_res"] = sum(l) / len(l)

@@ -50,6 +50,48 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// One correspondence in image-size-normalised homogeneous coordinates.
+struct Pt {
+  float x1, y1, z1, x2, y2, z2;
+};
+
+template <bool RAW>
+__device__ __forceinline__ Pt global_point(const float* __restrict__ pts1, const float* __restrict__ pts2, size_t pair,
+                                           int i, int N, float hw_sx, float hw_sy) {
+  Pt p;
+  if (RAW) {
+    const float4 m = reinterpret_cast<const float4*>(pts1)[pair * N + i];
+    p.x1 = fmaf(m.x, hw_sx, -1.0f); p.y1 = fmaf(m.y, hw_sy, -1.0f); p.z1 = 1.0f;
+    p.x2 = fmaf(m.z, hw_sx, -1.0f); p.y2 = fmaf(m.w, hw_sy, -1.0f); p.z2 = 1.0f;
+  } else {
+    const float* a = pts1 + (pair * N + i) * 3;
+    const float* b = pts2 + (pair * N + i) * 3;
+    p.x1 = a[0]; p.y1 = a[1]; p.z1 = a[2]; p.x2 = b[0]; p.y2 = b[1]; p.z2 = b[2];
+  }
+  return p;
+}
+
+// Unit row of the design matrix: ph = p / max(|p|, 1e-12) with p = [x2~ a, y2~ a, a], a = (x1~, y1~, z1)
+// (DeepFNet.py:203-212), fp64.  Returns false (and a zero row) for non-finite rows.
+__device__ __forceinline__ bool unit_row(const Pt& p, double s1, double c1x, double c1y, double s2, double c2x,
+                                         double c2y, double* ph) {
+  const double z1 = p.z1, z2 = p.z2;
+  const double a0 = s1 * ((double)p.x1 - c1x * z1), a1 = s1 * ((double)p.y1 - c1y * z1), a2 = z1;
+  const double b0 = s2 * ((double)p.x2 - c2x * z2), b1 = s2 * ((double)p.y2 - c2y * z2);
+  const double n2 = (a0 * a0 + a1 * a1 + a2 * a2) * (b0 * b0 + b1 * b1 + 1.0);
+  const bool ok = n2 < 1e300;
+  const double inv = ok ? 1.0 / fmax(sqrt(n2), 1e-12) : 0.0;
+  const double ia0 = ok ? a0 * inv : 0.0, ia1 = ok ? a1 * inv : 0.0, ia2 = ok ? a2 * inv : 0.0;
+  ph[0] = b0 * ia0; ph[1] = b0 * ia1; ph[2] = b0 * ia2;
+  ph[3] = b1 * ia0; ph[4] = b1 * ia1; ph[5] = b1 * ia2;
+  ph[6] = ia0;      ph[7] = ia1;      ph[8] = ia2;
+  if (!ok) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ph[k] = 0.0;
+  }
+  return ok;
+}
+
 // 3x3 helpers on row-major arrays -------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void mat3_mul(const T* A, const T* B, T* C) {  // C = A B

@@ -1,0 +1,172 @@
+// floss_fwd / floss_bwd — epipolar "F-loss" on the virtual correspondences for all layers, and E-from-F.
+//
+// Restates the per-layer body of get_all_loss_DeepF (deepFEPE/train_good_utils.py:325-358):
+//   pts*_eval = T* virt*^T                                            (:325-326)
+//   losses_l  = compute_epi_residual(pts1_eval, pts2_eval, F_l, clamp) (:340-342, utils_F.py:400-413)
+//   E_l       = K^T T2^T F_l T1 K                                      (:356-358)
+// One wavefront per image pair: lanes stride over the M virtual points (each point is transformed once and
+// reused for every layer), per-layer sums are wave-reduced; lanes 0..L-1 then form the L essential matrices.
+// The means over M and over the batch are left to the caller (a [L,B] tensor; under data parallelism the
+// batch mean is the all-reduced sum), exactly the quantities get_all_loss_DeepF derives from `losses`.
+#include "dfepe_common.h"
+
+namespace {
+
+constexpr int kMaxLayers = 16;
+
+struct Epi {
+  double d, dd, n1, n2, i1, i2;
+  double l1[3], l2[3];
+};
+
+__device__ __forceinline__ Epi epi_terms(const double* x1, const double* x2, const double* o) {
+  Epi e;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) e.l1[c] = x2[0] * o[c] + x2[1] * o[3 + c] + x2[2] * o[6 + c];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) e.l2[r] = o[3 * r] * x1[0] + o[3 * r + 1] * x1[1] + o[3 * r + 2] * x1[2];
+  e.dd = x1[0] * e.l1[0] + x1[1] * e.l1[1] + x1[2] * e.l1[2];
+  e.n1 = sqrt(e.l1[0] * e.l1[0] + e.l1[1] * e.l1[1]);
+  e.n2 = sqrt(e.l2[0] * e.l2[0] + e.l2[1] * e.l2[1]);
+  e.i1 = 1.0 / (e.n1 + 1e-6);
+  e.i2 = 1.0 / (e.n2 + 1e-6);
+  e.d = fabs(e.dd) * (e.i1 + e.i2);
+  return e;
+}
+
+__device__ __forceinline__ void load9(const float* p, double* m) {
+#pragma unroll
+  for (int c = 0; c < 9; ++c) m[c] = (double)p[c];
+}
+
+__device__ __forceinline__ void eval_point(const float* v, const double* T, double* x) {
+  const double a = v[0], b = v[1], c = v[2];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) x[r] = T[3 * r] * a + T[3 * r + 1] * b + T[3 * r + 2] * c;
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(256)
+floss_kernel(const float* __restrict__ F_layers, int L, int B, const float* __restrict__ T1, const float* __restrict__ T2,
+             int t_stride, const float* __restrict__ K, const float* __restrict__ virt1, const float* __restrict__ virt2,
+             int M, float clamp_at, float* __restrict__ loss_sum, float* __restrict__ E_layers,
+             const float* __restrict__ g_loss_sum, const float* __restrict__ g_E, float* __restrict__ g_F_layers) {
+  const int lane = threadIdx.x & 63;
+  const size_t pair = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (pair >= (size_t)B) return;
+  double t1[9], t2[9];
+  load9(T1 + pair * t_stride, t1);
+  load9(T2 + pair * t_stride, t2);
+  const float* v1 = virt1 + pair * M * 3;
+  const float* v2 = virt2 + pair * M * 3;
+
+  for (int l = 0; l < L; ++l) {
+    double o[9];
+    load9(F_layers + ((size_t)l * B + pair) * 9, o);
+    if (!BWD) {
+      double acc = 0.0;
+      for (int i = lane; i < M; i += WAVE) {
+        double x1[3], x2[3];
+        eval_point(v1 + 3 * i, t1, x1);
+        eval_point(v2 + 3 * i, t2, x2);
+        const Epi e = epi_terms(x1, x2, o);
+        acc += fmin(e.d, (double)clamp_at);
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) loss_sum[(size_t)l * B + pair] = (float)acc;
+    } else {
+      double go[9];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) go[c] = 0.0;
+      const double gl = (g_loss_sum != nullptr) ? (double)g_loss_sum[(size_t)l * B + pair] : 0.0;
+      if (g_loss_sum != nullptr) {
+        for (int i = lane; i < M; i += WAVE) {
+          double x1[3], x2[3];
+          eval_point(v1 + 3 * i, t1, x1);
+          eval_point(v2 + 3 * i, t2, x2);
+          const Epi e = epi_terms(x1, x2, o);
+          if (e.d <= (double)clamp_at) {
+            const double S = e.i1 + e.i2, ad = fabs(e.dd);
+            const double sg = (e.dd > 0.0) ? 1.0 : ((e.dd < 0.0) ? -1.0 : 0.0);
+            const double k1 = (e.n1 > 0.0) ? ad * e.i1 * e.i1 / e.n1 : 0.0;
+            const double k2 = (e.n2 > 0.0) ? ad * e.i2 * e.i2 / e.n2 : 0.0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                double t = sg * S * x2[r] * x1[c];
+                if (c < 2) t -= k1 * e.l1[c] * x2[r];
+                if (r < 2) t -= k2 * e.l2[r] * x1[c];
+                go[3 * r + c] += t;
+              }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) go[c] = gl * wave_sum(go[c]);
+      }
+      if (g_E != nullptr) {
+        // E = (T2 K)^T F (T1 K)  ->  g_F += (T2 K) g_E (T1 K)^T
+        double k[9], a[9], cmat[9], ge[9], tmp[9], add[9];
+        load9(K + pair * 9, k);
+        load9(g_E + ((size_t)l * B + pair) * 9, ge);
+        mat3_mul(t2, k, a);
+        mat3_mul(t1, k, cmat);
+        mat3_mul(a, ge, tmp);
+        mat3_mul_nt(tmp, cmat, add);
+#pragma unroll
+        for (int c = 0; c < 9; ++c) go[c] += add[c];
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) g_F_layers[((size_t)l * B + pair) * 9 + c] = (float)go[c];
+      }
+    }
+  }
+  if (!BWD && E_layers != nullptr && lane < L) {
+    double o[9], k[9], a[9], cmat[9], tmp[9], e[9];
+    load9(F_layers + ((size_t)lane * B + pair) * 9, o);
+    load9(K + pair * 9, k);
+    mat3_mul(t2, k, a);
+    mat3_mul(t1, k, cmat);
+    mat3_mul_tn(a, o, tmp);
+    mat3_mul(tmp, cmat, e);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) E_layers[((size_t)lane * B + pair) * 9 + c] = (float)e[c];
+  }
+}
+
+int check_common(const float* F_layers, int L, int B, const float* T1, const float* T2, int t_stride, const float* K,
+                 const float* virt1, const float* virt2, int M) {
+  if (L <= 0 || L > kMaxLayers || B < 0 || M <= 0) return DFEPE_ERR_INVALID_ARG;
+  if (t_stride != 0 && t_stride != 9) return DFEPE_ERR_INVALID_ARG;
+  if (B > 0 && (!F_layers || !T1 || !T2 || !K || !virt1 || !virt2)) return DFEPE_ERR_INVALID_ARG;
+  return DFEPE_OK;
+}
+
+}  // namespace
+
+extern "C" int dfepe_floss_fwd(const float* F_layers, int L, int B, const float* T1, const float* T2, int t_stride,
+                               const float* K, const float* virt1, const float* virt2, int M, float clamp_at,
+                               float* loss_sum, float* E_layers, void* stream) {
+  const int rc = check_common(F_layers, L, B, T1, T2, t_stride, K, virt1, virt2, M);
+  if (rc != DFEPE_OK) return rc;
+  if (B == 0) return DFEPE_OK;
+  if (!loss_sum) return DFEPE_ERR_INVALID_ARG;
+  const dim3 grid((B + 3) / 4), block(256);
+  hipLaunchKernelGGL(floss_kernel<false>, grid, block, 0, static_cast<hipStream_t>(stream), F_layers, L, B, T1, T2,
+                     t_stride, K, virt1, virt2, M, clamp_at, loss_sum, E_layers, nullptr, nullptr, nullptr);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+extern "C" int dfepe_floss_bwd(const float* F_layers, int L, int B, const float* T1, const float* T2, int t_stride,
+                               const float* K, const float* virt1, const float* virt2, int M, float clamp_at,
+                               const float* g_loss_sum, const float* g_E, float* g_F_layers, void* stream) {
+  const int rc = check_common(F_layers, L, B, T1, T2, t_stride, K, virt1, virt2, M);
+  if (rc != DFEPE_OK) return rc;
+  if (B == 0) return DFEPE_OK;
+  if (!g_F_layers) return DFEPE_ERR_INVALID_ARG;
+  const dim3 grid((B + 3) / 4), block(256);
+  hipLaunchKernelGGL(floss_kernel<true>, grid, block, 0, static_cast<hipStream_t>(stream), F_layers, L, B, T1, T2,
+                     t_stride, K, virt1, virt2, M, clamp_at, nullptr, nullptr, g_loss_sum, g_E, g_F_layers);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}

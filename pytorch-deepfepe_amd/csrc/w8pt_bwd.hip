@@ -1,0 +1,189 @@
+// w8pt_bwd — analytic adjoint of w8pt_fwd with respect to the weights.  One wavefront per image pair.
+//
+// Replaces torch.autograd's replay of the per-sample torch.svd calls of Fit.weighted_svd
+// (deepFEPE/models/DeepFNet.py:232-256) with closed forms:
+//   epipolar residual  d_i(out)            -> g_out      (only when g_epi is given)
+//   out = T2^T F' T1                        -> g_F' = T2 g_out T1^T
+//   F' = F - s3 u3 v3^T  (rank-2 projection) -> g_F    (3x3 SVD adjoint restricted to the dropped triplet)
+//   F = reshape(f), r = X f                 -> g_f = vec(g_F) + X^T g_r
+//   f = eigenvector of X^T X                -> u = sum_k q_k (q_k . g_f) / (lam_f - lam_k)
+//   X_i = w_i ph_i                          -> g_w_i = 2 w_i (ph_i.f)(ph_i.u) + g_r_i (ph_i.f)
+// All nine eigenpairs come from the forward Jacobi (the `save` record), so the cost is O(9 N) per pair:
+// two streaming passes over the correspondences (the second one hits L2) and a few hundred uniform flops.
+#include "dfepe_common.h"
+
+namespace {
+
+__device__ __forceinline__ double guard_den(double d) {
+  // keep the sign, floor the magnitude: repeated eigen/singular values give a large-but-finite gradient, never NaN
+  const double lim = 1e-30;
+  return (fabs(d) < lim) ? ((d < 0.0) ? -lim : lim) : d;
+}
+
+template <bool RAW>
+__global__ void __launch_bounds__(256)
+w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, const float* __restrict__ wts, int B,
+                int N, float hw_sx, float hw_sy, float clamp_at, const float* __restrict__ save,
+                const float* __restrict__ F_out, const float* __restrict__ g_F, const float* __restrict__ g_res,
+                const float* __restrict__ g_epi, float* __restrict__ g_w) {
+  const int lane = threadIdx.x & 63;
+  const size_t pair = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (pair >= (size_t)B) return;
+
+  const float* sv = save + pair * DFEPE_SAVE_FLOATS;
+  const double s1 = sv[SV_T1], c1x = sv[SV_T1 + 1], c1y = sv[SV_T1 + 2];
+  const double s2 = sv[SV_T2], c2x = sv[SV_T2 + 1], c2y = sv[SV_T2 + 2];
+  const int ksel = (int)sv[SV_KMIN];
+  const double sgn = sv[SV_SIGN];
+  double f[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) f[c] = sgn * (double)sv[SV_Q + ksel * 9 + c];
+
+  // ---- pass A: X^T g_r  and  sum_i g_epi_i d(d_i)/d(out) ---------------------------------------------
+  double gx[9], go[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) { gx[c] = 0.0; go[c] = 0.0; }
+  double o[9];
+  if (g_epi != nullptr) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) o[c] = (double)F_out[pair * 9 + c];
+  }
+  const float* wsrc = wts + pair * N;
+  for (int i = lane; i < N; i += WAVE) {
+    const Pt p = global_point<RAW>(pts1, pts2, pair, i, N, hw_sx, hw_sy);
+    if (g_res != nullptr) {
+      double ph[9];
+      const double w = (double)wsrc[i];
+      const bool ok = unit_row(p, s1, c1x, c1y, s2, c2x, c2y, ph) && (fabs(w) < 1e150);
+      const double gw = ok ? (double)g_res[pair * N + i] * w : 0.0;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) gx[c] += gw * ph[c];
+    }
+    if (g_epi != nullptr) {
+      const double x1[3] = {p.x1, p.y1, p.z1}, x2[3] = {p.x2, p.y2, p.z2};
+      double l1[3], l2[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) l1[c] = x2[0] * o[c] + x2[1] * o[3 + c] + x2[2] * o[6 + c];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) l2[r] = o[3 * r] * x1[0] + o[3 * r + 1] * x1[1] + o[3 * r + 2] * x1[2];
+      const double dd = x1[0] * l1[0] + x1[1] * l1[1] + x1[2] * l1[2];
+      const double n1 = sqrt(l1[0] * l1[0] + l1[1] * l1[1]), n2 = sqrt(l2[0] * l2[0] + l2[1] * l2[1]);
+      const double i1 = 1.0 / (n1 + 1e-6), i2 = 1.0 / (n2 + 1e-6);
+      const double S = i1 + i2, ad = fabs(dd);
+      const double d = ad * S;
+      const double g = (d <= (double)clamp_at) ? (double)g_epi[pair * N + i] : 0.0;  // clamp(max=) passes the gradient up to and including the bound
+      const double sg = (dd > 0.0) ? 1.0 : ((dd < 0.0) ? -1.0 : 0.0);
+      const double k1 = (n1 > 0.0) ? ad * i1 * i1 / n1 : 0.0;
+      const double k2 = (n2 > 0.0) ? ad * i2 * i2 / n2 : 0.0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          double t = sg * S * x2[r] * x1[c];
+          if (c < 2) t -= k1 * l1[c] * x2[r];
+          if (r < 2) t -= k2 * l2[r] * x1[c];
+          go[3 * r + c] += g * t;
+        }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    gx[c] = (g_res != nullptr) ? wave_sum(gx[c]) : 0.0;
+    go[c] = (g_epi != nullptr) ? wave_sum(go[c]) : 0.0;
+  }
+  if (g_F != nullptr) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) go[c] += (double)g_F[pair * 9 + c];
+  }
+
+  // ---- uniform part ---------------------------------------------------------------------------------
+  // g_F' = T2 g_out T1^T
+  double t1[9] = {s1, 0.0, -s1 * c1x, 0.0, s1, -s1 * c1y, 0.0, 0.0, 1.0};
+  double t2[9] = {s2, 0.0, -s2 * c2x, 0.0, s2, -s2 * c2y, 0.0, 0.0, 1.0};
+  double tmp[9], G[9];
+  mat3_mul(t2, go, tmp);
+  mat3_mul_nt(tmp, t1, G);
+  // rank-2 projection adjoint
+  double U[9], V[9], S[3];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) { U[c] = sv[SV_U3 + c]; V[c] = sv[SV_V3 + c]; }
+  S[0] = sv[SV_S3]; S[1] = sv[SV_S3 + 1]; S[2] = sv[SV_S3 + 2];
+  double UtGV[9];  // (U^T G V)[a][b] = u_a^T G v_b
+  mat3_mul_tn(U, G, tmp);
+  mat3_mul(tmp, V, UtGV);
+  double gFm[9];
+  {
+    const double a33 = UtGV[8];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gFm[3 * r + c] = G[3 * r + c] - a33 * U[3 * r + 2] * V[3 * c + 2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const double coef = S[2] / guard_den(S[2] * S[2] - S[k] * S[k]);
+      const double ak3 = UtGV[3 * k + 2];  // u_k^T G v_3
+      const double a3k = UtGV[6 + k];      // u_3^T G v_k
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const double ukv3 = U[3 * r + k] * V[3 * c + 2], u3vk = U[3 * r + 2] * V[3 * c + k];
+          gFm[3 * r + c] -= coef * (ak3 * (S[2] * ukv3 + S[k] * u3vk) + a3k * (S[2] * u3vk + S[k] * ukv3));
+        }
+    }
+  }
+  // g_f and the eigenvector adjoint
+  double gf[9], u[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) { gf[c] = gFm[c] + gx[c]; u[c] = 0.0; }
+  const double lsel = sv[SV_LAM + ksel];
+  for (int k = 0; k < 9; ++k) {
+    if (k == ksel) continue;
+    double dot = 0.0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) dot += (double)sv[SV_Q + k * 9 + c] * gf[c];
+    const double ck = dot / guard_den(lsel - (double)sv[SV_LAM + k]);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) u[c] += ck * (double)sv[SV_Q + k * 9 + c];
+  }
+
+  // ---- pass B: g_w --------------------------------------------------------------------------------------
+  float* dst = g_w + pair * N;
+  for (int i = lane; i < N; i += WAVE) {
+    const Pt p = global_point<RAW>(pts1, pts2, pair, i, N, hw_sx, hw_sy);
+    double ph[9];
+    const double w = (double)wsrc[i];
+    const bool ok = unit_row(p, s1, c1x, c1y, s2, c2x, c2y, ph) && (fabs(w) < 1e150);
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { a += ph[c] * f[c]; b += ph[c] * u[c]; }
+    const double gr = (g_res != nullptr) ? (double)g_res[pair * N + i] : 0.0;
+    dst[i] = ok ? (float)(2.0 * w * a * b + gr * a) : 0.0f;
+  }
+}
+
+}  // namespace
+
+extern "C" int dfepe_w8pt_bwd(const float* pts1, const float* pts2, const float* weights, int B, int N, unsigned flags,
+                              float image_w, float image_h, float clamp_at, const float* save, const float* F_out,
+                              const float* g_F, const float* g_residual, const float* g_epi, float* g_weights,
+                              void* stream) {
+  const bool raw = (flags & DFEPE_W8PT_RAW_MATCHES) != 0;
+  if (B < 0 || N <= 0) return DFEPE_ERR_INVALID_ARG;
+  if (B == 0) return DFEPE_OK;
+  if (!pts1 || (!raw && !pts2) || !weights || !save || !g_weights) return DFEPE_ERR_INVALID_ARG;
+  if (g_epi && !F_out) return DFEPE_ERR_INVALID_ARG;
+  if (raw && !(image_w > 0.f && image_h > 0.f)) return DFEPE_ERR_INVALID_ARG;
+  if (raw && (reinterpret_cast<uintptr_t>(pts1) & 15u)) return DFEPE_ERR_INVALID_ARG;
+  const int waves = 4;
+  const dim3 grid((B + waves - 1) / waves), block(64 * waves);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const float hw_sx = raw ? 2.0f / image_w : 0.f, hw_sy = raw ? 2.0f / image_h : 0.f;
+  if (raw)
+    hipLaunchKernelGGL(w8pt_bwd_kernel<true>, grid, block, 0, st, pts1, pts2, weights, B, N, hw_sx, hw_sy, clamp_at, save,
+                       F_out, g_F, g_residual, g_epi, g_weights);
+  else
+    hipLaunchKernelGGL(w8pt_bwd_kernel<false>, grid, block, 0, st, pts1, pts2, weights, B, N, hw_sx, hw_sy, clamp_at, save,
+                       F_out, g_F, g_residual, g_epi, g_weights);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}

@@ -34,10 +34,6 @@ constexpr int kWsDoubles = 216;  // per-wave fp64 workspace in LDS: A[81] V[81] 
 constexpr int kMaxSweeps = 12;
 constexpr double kJacobiTol = 1e-26;  // stop when off(A)^2 <= tol * diag(A)^2
 
-struct Pt {
-  float x1, y1, z1, x2, y2, z2;
-};
-
 template <bool RAW>
 __device__ __forceinline__ Pt lds_point(const float* P, int i, int npad) {
   Pt p;
@@ -50,26 +46,6 @@ __device__ __forceinline__ Pt lds_point(const float* P, int i, int npad) {
     p.x1 = a[0]; p.y1 = a[1]; p.z1 = a[2]; p.x2 = b[0]; p.y2 = b[1]; p.z2 = b[2];
   }
   return p;
-}
-
-// Row of the design matrix for one correspondence: X = w * p / max(|p|, 1e-12), fp64.
-__device__ __forceinline__ void design_row(const Pt& p, double w, double s1, double c1x, double c1y, double s2,
-                                           double c2x, double c2y, double* X) {
-  const double z1 = p.z1;
-  const double a0 = s1 * ((double)p.x1 - c1x * z1), a1 = s1 * ((double)p.y1 - c1y * z1), a2 = z1;
-  const double z2 = p.z2;
-  const double b0 = s2 * ((double)p.x2 - c2x * z2), b1 = s2 * ((double)p.y2 - c2y * z2);
-  X[0] = b0 * a0; X[1] = b0 * a1; X[2] = b0 * a2;
-  X[3] = b1 * a0; X[4] = b1 * a1; X[5] = b1 * a2;
-  X[6] = a0;      X[7] = a1;      X[8] = a2;
-  double n2 = 0.0;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) n2 += X[k] * X[k];
-  // NaN/Inf rows are dropped (the reference scrubs NaN in X on its default path, models/model_utils.py:5-15)
-  const bool ok = (n2 < 1e300) && (fabs(w) < 1e300);
-  const double sc = ok ? w / fmax(sqrt(n2), 1e-12) : 0.0;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) X[k] = ok ? X[k] * sc : 0.0;
 }
 
 // One halving step of the reduce-scatter: CNT live values per lane -> (CNT+1)/2.
@@ -369,11 +345,13 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   float* edst = (epi_res != nullptr) ? epi_res + (size_t)pair * N : nullptr;
   for (int i = lane; i < N; i += WAVE) {
     const Pt p = lds_point<RAW>(P, i, npad);
-    double X[9];
-    design_row(p, (double)W[i], s1, c1x, c1y, s2, c2x, c2y, X);
+    double ph[9];
+    const double w = (double)W[i];
+    const bool ok = unit_row(p, s1, c1x, c1y, s2, c2x, c2y, ph) && (fabs(w) < 1e150);
     double r = 0.0;
 #pragma unroll
-    for (int c = 0; c < 9; ++c) r += X[c] * f[c];
+    for (int c = 0; c < 9; ++c) r += ph[c] * f[c];
+    r = ok ? r * w : 0.0;
     rdst[i] = (float)r;
     if (edst != nullptr) {
       // l1 = F^T x2 (row form x2 F), l2 = F x1, dd = x2^T F x1 = x1 . l1     (utils_F.py:402-411), fp32 like the reference

@@ -1,0 +1,161 @@
+"""Parity of the analytic adjoints (w8pt_bwd, floss_bwd, pose_bwd) and of the whole hot-path step against
+torch.autograd of the CPU oracle run in fp64.  GPU box only."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+IMAGE_SIZE = [376, 1241, 3]
+DEV = "cuda:0"
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-300)
+
+
+@pytest.mark.parametrize("N,outl", [(100, 0.0), (100, 0.4), (257, 0.2)])
+@pytest.mark.parametrize("use_epi", [False, True])
+def test_w8pt_backward_vs_oracle_autograd(dfepe, oracle, N, outl, use_epi):
+    B = 5
+    sc = dfepe.synth.make_scene(B, N, seed=7 + N, outlier_ratio=outl)
+    g = torch.Generator().manual_seed(1)
+    m = sc["matches_xy_ori"]
+    logits = sc["logits_layers"][0]
+    GF = torch.randn(B, 3, 3, generator=g)
+    GR = torch.randn(B, N, generator=g)
+    GE = torch.randn(B, N, generator=g)
+    # ours
+    w = torch.softmax(logits, 1).to(DEV).requires_grad_(True)
+    outs = dfepe.ops.w8pt_raw(m.to(DEV), w, IMAGE_SIZE[1], IMAGE_SIZE[0], clamp_at=0.5, want_epi=True)
+    F, res, epi = outs
+    loss = (F * GF.to(DEV)).sum() + (res * GR.to(DEV)).sum()
+    if use_epi:
+        loss = loss + (epi * GE.to(DEV)).sum()
+    loss.backward()
+    # oracle (fp64 autograd), with the per-pair sign gauge of our forward applied to the sign-odd outputs
+    wo = torch.softmax(logits.double(), 1).requires_grad_(True)
+    p1, p2, _ = oracle.normalize_hw(m.double(), IMAGE_SIZE)
+    o_out, o_res, _ = oracle.fit_forward(p1, p2, wo.unsqueeze(1))
+    s = torch.sign((o_out.detach() * F.detach().cpu().double()).flatten(1).sum(1))
+    lo = (s[:, None, None] * o_out * GF.double()).sum() + (s[:, None] * o_res * GR.double()).sum()
+    if use_epi:
+        lo = lo + (oracle.compute_epi_residual(p1, p2, o_out, 0.5) * GE.double()).sum()
+    lo.backward()
+    assert relerr(w.grad.cpu().numpy(), wo.grad.numpy()) < 2e-4
+
+
+def test_floss_forward_backward(dfepe, oracle):
+    L, B, M = 5, 7, 100
+    sc = dfepe.synth.make_scene(B, 50, seed=2)
+    g = torch.Generator().manual_seed(4)
+    # F layers: ground-truth F in HW-normalised coordinates, perturbed differently per layer
+    T = oracle.hw_matrix(IMAGE_SIZE, torch.float64)
+    Tinv = torch.linalg.inv(T)
+    Fn = Tinv.T @ sc["F_gt"].double() @ Tinv
+    Fn = Fn / Fn.flatten(1).norm(dim=1)[:, None, None]
+    Fl = torch.stack([Fn + 0.003 * (l + 1) * torch.randn(B, 3, 3, generator=g, dtype=torch.float64) for l in range(L)])
+    Fl = Fl.float().double()  # both sides see the same fp32-representable F (clamp masks and sign(dd) are discontinuous)
+    GL = torch.rand(L, B, generator=g, dtype=torch.float64)
+    GEm = torch.randn(L, B, 3, 3, generator=g, dtype=torch.float64)
+    clamp = 0.02
+    # oracle
+    Fo = Fl.clone().requires_grad_(True)
+    outs = {"T1": T.expand(B, 3, 3), "T2": T.expand(B, 3, 3), "out_layers": [Fo[l] for l in range(L)], "F_est": Fo[-1],
+            "epi_res_layers": [], "weights_layers": []}
+    losses, _, _, E_layers = oracle.f_loss(outs, sc["pts1_virt_ori"].double(), sc["pts2_virt_ori"].double(), sc["Ks"].double(), L, clamp)
+    per_pair_sum = losses["loss_per_pair"] * M
+    lo = (per_pair_sum * GL).sum() + (torch.stack(E_layers) * GEm).sum()
+    lo.backward()
+    # ours
+    Fd = Fl.float().to(DEV).requires_grad_(True)
+    Td = T.float().to(DEV)
+    loss_sum, E = dfepe.ops.floss(Fd, Td, Td, sc["Ks"].to(DEV), sc["pts1_virt_ori"].to(DEV), sc["pts2_virt_ori"].to(DEV), clamp)
+    ((loss_sum * GL.float().to(DEV)).sum() + (E * GEm.float().to(DEV)).sum()).backward()
+    assert relerr(loss_sum.detach().cpu().numpy(), per_pair_sum.detach().numpy()) < 2e-5
+    assert relerr(E.detach().cpu().numpy(), torch.stack(E_layers).detach().numpy()) < 2e-6
+    assert relerr(Fd.grad.cpu().numpy(), Fo.grad.numpy()) < 2e-4
+    # per-pair transforms [B,3,3] give the same answer as the shared one
+    loss_sum2, E2 = dfepe.ops.floss(Fd.detach(), Td.expand(B, 3, 3).contiguous(), Td.expand(B, 3, 3).contiguous(), sc["Ks"].to(DEV),
+                                    sc["pts1_virt_ori"].to(DEV), sc["pts2_virt_ori"].to(DEV), clamp)
+    assert torch.equal(loss_sum2, loss_sum.detach()) and torch.equal(E2, E.detach())
+
+
+@pytest.mark.parametrize("noise", [0.05, 1e-3, 0.0])
+def test_pose_forward_backward(dfepe, oracle, noise):
+    L, B = 3, 16
+    sc = dfepe.synth.make_scene(B, 20, seed=9, dtype=torch.float64)
+    g = torch.Generator().manual_seed(2)
+    E = torch.stack([sc["E_gt"] / sc["E_gt"].flatten(1).norm(dim=1)[:, None, None] + noise * (l + 1) * torch.randn(B, 3, 3, generator=g, dtype=torch.float64) for l in range(L)])
+    E = E.float().double()  # the kernel sees fp32 inputs
+    # ground truth of a *different* pair (roll) so that the errors are away from their kink at 0
+    q_gt = torch.roll(sc["qs_cam"], 1, 0)
+    t_gt = torch.roll(sc["ts_cam"], 1, 0)
+    delta = torch.roll(sc["delta_Rtijs_4_4"], 1, 0)
+    GQ = torch.rand(L, B, generator=g, dtype=torch.float64)
+    GT = torch.rand(L, B, generator=g, dtype=torch.float64)
+    Eo = E.clone().requires_grad_(True)
+    pose = oracle.rt_loss([Eo[l] for l in range(L)], delta, q_gt, t_gt)
+    R_gt = torch.linalg.inv(delta)[:, :3, :3]
+    Ed = E.float().to(DEV).requires_grad_(True)
+    q_l2, t_l2, R_deg, t_deg, sel = dfepe.ops.pose_errors(Ed, q_gt.float().to(DEV), t_gt.float().to(DEV), R_gt.float().to(DEV))
+    np.testing.assert_allclose(q_l2.detach().cpu().numpy(), pose["q_l2"].detach().numpy(), atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(t_l2.detach().cpu().numpy(), pose["t_l2"].detach().numpy(), atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(R_deg.cpu().numpy(), pose["R_deg"], atol=2e-3, rtol=1e-4)
+    np.testing.assert_allclose(t_deg.cpu().numpy(), pose["t_deg"], atol=2e-2, rtol=1e-4)
+    ((q_l2 * GQ.float().to(DEV)).sum() + (t_l2 * GT.float().to(DEV)).sum()).backward()
+    assert torch.isfinite(Ed.grad).all()
+    if noise > 0:  # at exact essential matrices torch's svd_backward divides by s1^2 - s2^2 = 0: no autograd yard-stick there
+        ((pose["q_l2"] * GQ).sum() + (pose["t_l2"] * GT).sum()).backward()
+        assert relerr(Ed.grad.cpu().numpy(), Eo.grad.numpy()) < (2e-4 if noise > 1e-2 else 2e-2)
+    else:  # finite differences of the kernel's own forward in the direction of a random perturbation
+        D = torch.randn(L, B, 3, 3, generator=g, dtype=torch.float64)
+        eps = 1e-3
+        def f(Ex):
+            q, t, *_ = dfepe.ops.pose_errors(Ex.float().to(DEV), q_gt.float().to(DEV), t_gt.float().to(DEV), R_gt.float().to(DEV))
+            return (q.double().cpu() * GQ).sum(0) + (t.double().cpu() * GT).sum(0)
+        num = (f(E + eps * D) - f(E - eps * D)) / (2 * eps)
+        ana = (Ed.grad.double().cpu() * D).sum(dim=(0, 2, 3))
+        assert relerr(ana.numpy(), num.numpy()) < 2e-2
+
+
+@pytest.mark.parametrize("depth,qt", [(5, True), (5, False), (1, True)])
+def test_hot_path_step_matches_oracle(dfepe, oracle, depth, qt):
+    B, N = 6, 100
+    sc = dfepe.synth.make_scene(B, N, seed=21, outlier_ratio=0.2, depth_layers=depth)
+    ours = dfepe.pipeline.hot_path_step(dfepe.pipeline.scene_to_device(sc, DEV), IMAGE_SIZE, depth, 0.02, qt=qt)
+    sc64 = {k: v.double() for k, v in sc.items()}
+    ref = oracle.hot_path_step(sc64, IMAGE_SIZE, depth, 0.02, qt=qt, mode="batched")
+    assert abs(ours["loss"].item() - ref["loss"].item()) < 2e-6 * max(1.0, abs(ref["loss"].item()))
+    np.testing.assert_allclose(ours["loss_layers"].detach().cpu().numpy(), torch.stack(ref["losses"]["loss_layers"]).detach().numpy(), rtol=2e-5, atol=1e-8)
+    if qt:
+        np.testing.assert_allclose(ours["q_l2"].detach().cpu().numpy(), ref["pose"]["q_l2"].detach().numpy(), atol=2e-6, rtol=1e-5)
+        np.testing.assert_allclose(ours["t_l2"].detach().cpu().numpy(), ref["pose"]["t_l2"].detach().numpy(), atol=2e-5, rtol=1e-4)
+        np.testing.assert_allclose(ours["R_deg"].cpu().numpy(), ref["pose"]["R_deg"], atol=2e-3, rtol=1e-4)
+        np.testing.assert_allclose(ours["t_deg"].cpu().numpy(), ref["pose"]["t_deg"], atol=2e-2, rtol=1e-4)
+    assert relerr(ours["grad_logits"].cpu().numpy(), ref["grad_logits"].numpy()) < 5e-4
+
+
+def test_hot_path_step_matches_reference_golden(dfepe, golden):
+    """Same step against the reference's own fp32 run (tests/golden/pipeline.npz)."""
+    g = golden("pipeline")
+    pre = "solver_"
+    sc = {k: torch.from_numpy(g[pre + k]) for k in ("matches_xy_ori", "Ks", "delta_Rtijs_4_4", "qs_cam", "ts_cam", "pts1_virt_ori", "pts2_virt_ori", "logits_layers")}
+    dev = dfepe.pipeline.scene_to_device(sc, DEV)
+    ours = dfepe.pipeline.hot_path_step(dev, IMAGE_SIZE, 5, 0.02, qt=True, backward=False)
+    np.testing.assert_allclose(ours["loss_layers"].cpu().numpy(), g[pre + "loss_layers"], rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(ours["q_l2"].cpu().numpy(), g[pre + "q_l2_layers"], atol=2e-4, rtol=2e-3)
+    np.testing.assert_allclose(ours["t_l2"].cpu().numpy(), g[pre + "t_l2_layers"], atol=3e-3, rtol=3e-3)
+    np.testing.assert_allclose(ours["t_deg"].cpu().numpy(), g[pre + "t_angle_layers"], atol=0.2, rtol=3e-3)
+    for l in range(5):
+        np.testing.assert_allclose(ours["epi_res_layers"][l].cpu().numpy()[:, None, :] if l < 4 else 0, g[pre + "epi_res_layers"][l] if l < 4 else 0, atol=5e-4, rtol=5e-3)
+    # gradients of the two reference training losses w.r.t. the logits
+    for key, qt_only in (("grad_logits_lossF", False), ("grad_logits_lossQT", True)):
+        logits = dev["logits_layers"].clone().requires_grad_(True)
+        out = dfepe.pipeline.hot_path_forward(dev["matches_xy_ori"], logits, dev["Ks"], dev["pts1_virt_ori"], dev["pts2_virt_ori"],
+                                              dev["qs_cam"], dev["ts_cam"], dev["R_gt"], IMAGE_SIZE, 0.02, qt=True)
+        (out["loss_qt"] if qt_only else out["loss_F"]).backward()
+        ref = g[pre + key]
+        ours_g = logits.grad.cpu().numpy()
+        cos = (ours_g * ref).sum() / (np.linalg.norm(ours_g) * np.linalg.norm(ref))
+        assert cos > 0.999 and relerr(ours_g, ref) < 5e-2
