@@ -9,11 +9,13 @@
 // Phases (all wave-synchronous, no block barrier; the 4 waves of a block are independent pairs):
 //   0  coalesced global -> LDS copy of the pair's correspondences (+ weights), coordinate sums
 //   1  mean distance to the centroid  -> Hartley scale                      (wave reductions, fp64)
-//   2  rows p/|p| * w, 45 upper-triangular sums of X^T X per lane in fp64   (exact products of fp32 data)
-//   3  recursive-halving reduce-scatter of the 45 sums across the wave -> 9x9 A in LDS (both triangles)
-//   4  parallel-ordering two-sided Jacobi on A (fp64, 4 disjoint rotations per round, 9 rounds per sweep),
-//      eigenvectors accumulated in V (LDS); wave-uniform convergence test per sweep
-//   5  f = eigenvector of the smallest eigenvalue; 3x3 SVD; F' = F - s3 u3 v3^T; out = T2^T F' T1
+//   2  rows p/|p| * w, the 36 distinct sums of X^T X per lane in fp64        (Kronecker structure of the rows)
+//   3  recursive-halving reduce-scatter of the 36 distinct sums across the wave -> 9x9 M in LDS (fp64)
+//   4  all nine eigenpairs of M/trace(M) by a parallel-ordering two-sided Jacobi in fp32 (systolic form: the
+//      four rotation pairs always sit at positions (0,1)(2,3)(4,5)(6,7), the data is permuted between rounds,
+//      so every LDS address is loop-invariant); then the one eigenvector the solver needs is polished in fp64
+//      against the fp64 M by residual correction in the Jacobi basis (converges to fp64 accuracy)
+//   5  f = that eigenvector; 3x3 SVD; F' = F - s3 u3 v3^T; out = T2^T F' T1
 //   6  residual_i = X_i . f and the symmetric epipolar residual per correspondence (coalesced stores)
 // No MFMA: the only contraction (X^T X, 9xN by Nx9) is far too skinny; the rest is eigen work.
 #include "dfepe_common.h"
@@ -30,9 +32,13 @@ __constant__ unsigned char kTriJ[45] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 1, 2, 3, 4, 5
 __constant__ unsigned char kSymR[6] = {0, 0, 0, 1, 1, 2};
 __constant__ unsigned char kSymC[6] = {0, 1, 2, 1, 2, 2};
 
-constexpr int kWsDoubles = 216;  // per-wave fp64 workspace in LDS: A[81] V[81] CS[18] + pad  (1728 B, 16-B multiple)
-constexpr int kMaxSweeps = 12;
-constexpr double kJacobiTol = 1e-26;  // stop when off(A)^2 <= tol * diag(A)^2
+// seat permutation of the round-robin tournament: position p moves to kPerm[p] after every round
+__constant__ unsigned char kPerm[9] = {8, 3, 0, 5, 2, 7, 4, 6, 1};
+
+constexpr int kWsDoubles = 216;  // per-wave workspace in LDS (1728 B, 16-B multiple): see the carve in the kernel
+constexpr int kMaxSweeps = 10;
+constexpr float kJacobiTol = 1e-13f;  // fp32 sweeps stop when off(A)^2 <= tol (A is scaled to unit trace)
+constexpr int kRefineIters = 12;  // upper bound; the loop leaves as soon as the fp64 residual is at round-off level
 
 template <bool RAW>
 __device__ __forceinline__ Pt lds_point(const float* P, int i, int npad) {
@@ -46,6 +52,13 @@ __device__ __forceinline__ Pt lds_point(const float* P, int i, int npad) {
     p.x1 = a[0]; p.y1 = a[1]; p.z1 = a[2]; p.x2 = b[0]; p.y2 = b[1]; p.z2 = b[2];
   }
   return p;
+}
+
+__device__ __forceinline__ double pick9(const double* v, int c) {  // v[c] for a register array (no scratch)
+  double r = v[0];
+#pragma unroll
+  for (int k = 1; k < 9; ++k) r = (c == k) ? v[k] : r;
+  return r;
 }
 
 // One halving step of the reduce-scatter: CNT live values per lane -> (CNT+1)/2.
@@ -75,9 +88,11 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   if (pair >= B) return;  // whole wave leaves; there is no block-level barrier in this kernel
 
   unsigned char* base = smem + (size_t)wave * wave_bytes;
-  double* A = reinterpret_cast<double*>(base);
-  double* V = A + 81;
-  double* CS = V + 81;
+  double* M64 = reinterpret_cast<double*>(base);            // [81] X^T X, fp64, natural index order      0..648
+  double* SCR = M64 + 81;                                   // [32] exchange scratch for the refinement  648..904
+  float* A32 = reinterpret_cast<float*>(base + 904);        // [81] Jacobi iterate (position space)       904..1228
+  float* V32 = A32 + 81;                                    // [81] accumulated rotations                1228..1552
+  float2* CS = reinterpret_cast<float2*>(base + 1552);      // [9]  (c, signed s) per position           1552..1624
   float* P = reinterpret_cast<float*>(base + kWsDoubles * sizeof(double));
   float* W = P + (RAW ? 4 : 6) * npad;
 
@@ -168,107 +183,167 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
       width = h;
     }
     if (cnt >= 1) {
-      // sum (u,v) is A[3r+c][3r'+c'] for (r,r') = sym pair u, (c,c') = sym pair v, and its 3 index swaps
+      // sum (u,v) is M[3r+c][3r'+c'] for (r,r') = sym pair u, (c,c') = sym pair v, and its 3 index swaps
       const int u = idx / 6, v = idx % 6;
       const int r0 = kSymR[u], r1 = kSymC[u], q0 = kSymR[v], q1 = kSymC[v];
       const double val = acc[0];
       const int i00 = 3 * r0 + q0, i01 = 3 * r0 + q1, i10 = 3 * r1 + q0, i11 = 3 * r1 + q1;
-      A[i00 * 9 + i11] = val; A[i11 * 9 + i00] = val;
-      A[i01 * 9 + i10] = val; A[i10 * 9 + i01] = val;
+      M64[i00 * 9 + i11] = val; M64[i11 * 9 + i00] = val;
+      M64[i01 * 9 + i10] = val; M64[i10 * 9 + i01] = val;
     }
-    V[lane] = (lane % 10 == 0) ? 1.0 : 0.0;  // identity: element e is diagonal iff e % 10 == 0
-    if (lane < 17) V[lane + 64] = ((lane + 64) % 10 == 0) ? 1.0 : 0.0;
   }
   wave_sync();
 
-  // ---- phase 4: two-sided Jacobi, round-robin parallel ordering ------------------------------------
-  // round r pairs index i with (2r - i) mod 9; index r sits out.  A' = J^T A J, V' = V J with, for the
-  // pair (p<q):  J_pp = J_qq = c, J_pq = s, J_qp = -s.  Per index k we keep (c_k, sh_k) where
-  // sh_p = -s and sh_q = +s, so that  col_k' = c_k col_k + sh_k col_partner(k)  (and the same for rows).
+  // ---- phase 4a: fp32 Jacobi on M / trace(M) ----------------------------------------------------------
+  // A' = J^T A J, V' = V J with J_pp = J_qq = c, J_pq = s, J_qp = -s for the pairs (p,q) = (0,1),(2,3),(4,5),(6,7)
+  // of *positions*; position 8 sits out.  Per position k we keep (c_k, sh_k), sh_p = -s, sh_q = +s, so that
+  // col_k' = c_k col_k + sh_k col_(k^1).  The result of the round is stored through the seat permutation kPerm,
+  // which realises the round-robin schedule (9 rounds = all 36 pairs once).  Eigenpairs come out in seat order,
+  // which is irrelevant: (A32[k][k], V32[:,k]) is a consistent pair for every k.
+  double tr = 0.0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) tr += M64[k * 10];
+  const double inv_tr = (tr > 0.0) ? 1.0 / tr : 1.0;
+  {
+    const float a0 = (float)(M64[lane] * inv_tr);
+    A32[lane] = a0;
+    V32[lane] = (lane % 10 == 0) ? 1.0f : 0.0f;  // identity: element e is diagonal iff e % 10 == 0
+    if (lane < 17) {
+      A32[lane + 64] = (float)(M64[lane + 64] * inv_tr);
+      V32[lane + 64] = ((lane + 64) % 10 == 0) ? 1.0f : 0.0f;
+    }
+    if (lane == 8) CS[8] = make_float2(1.0f, 0.0f);
+  }
+  // loop-invariant addresses
   const int ti = (lane < 45) ? kTriI[lane] : 0;
   const int tj = (lane < 45) ? kTriJ[lane] : 0;
-  const int vi0 = lane / 9, vj0 = lane % 9;
-  const int vi1 = (lane + 64) / 9, vj1 = (lane + 64) % 9;
-  for (int sweep = 0; sweep < ((clamp_at < 0.f) ? 0 : kMaxSweeps); ++sweep) {  // DEBUG: negative hw_sx skips Jacobi
-    double off = 0.0, dg = 0.0;
-    if (lane < 45) {
-      const double a = A[ti * 9 + tj];
-      if (ti == tj) dg = a * a; else off = a * a;
+  const int tip = (ti < 8) ? (ti ^ 1) : 8, tjp = (tj < 8) ? (tj ^ 1) : 8;
+  const int a00 = ti * 9 + tj, a01 = ti * 9 + tjp, a10 = tip * 9 + tj, a11 = tip * 9 + tjp;
+  const int aw = kPerm[ti] * 9 + kPerm[tj], awt = kPerm[tj] * 9 + kPerm[ti];
+  const int vi0 = lane / 9, vj0 = lane % 9, vjp0 = (vj0 < 8) ? (vj0 ^ 1) : 8;
+  const int e1 = (lane < 17) ? lane + 64 : 0;
+  const int vi1 = e1 / 9, vj1 = e1 % 9, vjp1 = (vj1 < 8) ? (vj1 ^ 1) : 8;
+  const int vr0 = vi0 * 9 + vj0, vrp0 = vi0 * 9 + vjp0, vw0 = vi0 * 9 + kPerm[vj0];
+  const int vr1 = vi1 * 9 + vj1, vrp1 = vi1 * 9 + vjp1, vw1 = vi1 * 9 + kPerm[vj1];
+  const int pp = (lane < 8) ? (lane & ~1) : 0;  // lanes 0..7: my pair is positions (pp, pp+1)
+  wave_sync();
+  for (int sweep = 0; sweep < ((clamp_at < 0.f) ? 0 : kMaxSweeps); ++sweep) {  // DEBUG hook: negative clamp skips Jacobi
+    float off = 0.0f;
+    if (lane < 45 && ti != tj) {
+      const float a = A32[a00];
+      off = a * a;
     }
     off = wave_sum(off);
-    dg = wave_sum(dg);
-    if (!(off > kJacobiTol * dg)) break;  // wave-uniform (also leaves on NaN)
+    if (!(off > kJacobiTol)) break;  // wave-uniform (also leaves on NaN)
     for (int r = 0; r < 9; ++r) {
-      if (lane < 9) {
-        const int i = lane;
-        const int j = (2 * r + 9 - i) % 9;
-        double c = 1.0, sh = 0.0;
-        if (j != i) {
-          const int p = (i < j) ? i : j, q = (i < j) ? j : i;
-          const double app = A[p * 10], aqq = A[q * 10], apq = A[p * 9 + q];
-          if (apq != 0.0) {
-            const double th = (aqq - app) / (2.0 * apq);
-            const double t = copysign(1.0, th) / (fabs(th) + sqrt(th * th + 1.0));
-            c = 1.0 / sqrt(t * t + 1.0);
-            const double s = t * c;
-            sh = (i == p) ? -s : s;
-          }
+      if (lane < 8) {
+        const float app = A32[pp * 10], aqq = A32[pp * 10 + 10], apq = A32[pp * 9 + pp + 1];
+        float c = 1.0f, sn = 0.0f;
+        if (apq != 0.0f) {
+          const float d = aqq - app, b = 2.0f * apq;
+          const float h = __builtin_amdgcn_sqrtf(fmaf(d, d, b * b));
+          const float t = b * __builtin_amdgcn_rcpf(d + copysignf(h, d));
+          c = __builtin_amdgcn_rsqf(fmaf(t, t, 1.0f));
+          sn = t * c;
         }
-        CS[2 * i] = c;
-        CS[2 * i + 1] = sh;
+        CS[lane] = make_float2(c, (lane & 1) ? sn : -sn);
       }
       wave_sync();
-      double anew = 0.0;
+      float anew = 0.0f;
       if (lane < 45) {
-        const int ip = (2 * r + 9 - ti) % 9, jp = (2 * r + 9 - tj) % 9;
-        const double ci = CS[2 * ti], si = CS[2 * ti + 1], cj = CS[2 * tj], sj = CS[2 * tj + 1];
-        const double a00 = A[ti * 9 + tj], a01 = A[ti * 9 + jp], a10 = A[ip * 9 + tj], a11 = A[ip * 9 + jp];
-        anew = ci * (cj * a00 + sj * a01) + si * (cj * a10 + sj * a11);
+        const float2 ci = CS[ti], cj = CS[tj];
+        anew = ci.x * fmaf(cj.x, A32[a00], cj.y * A32[a01]) + ci.y * fmaf(cj.x, A32[a10], cj.y * A32[a11]);
       }
-      double v0, v1 = 0.0;
-      {
-        const int jp = (2 * r + 9 - vj0) % 9;
-        v0 = CS[2 * vj0] * V[vi0 * 9 + vj0] + CS[2 * vj0 + 1] * V[vi0 * 9 + jp];
-      }
-      if (lane < 17) {
-        const int jp = (2 * r + 9 - vj1) % 9;
-        v1 = CS[2 * vj1] * V[vi1 * 9 + vj1] + CS[2 * vj1 + 1] * V[vi1 * 9 + jp];
-      }
+      const float2 c0 = CS[vj0];
+      const float v0 = fmaf(c0.x, V32[vr0], c0.y * V32[vrp0]);
+      const float2 c1 = CS[vj1];
+      const float v1 = fmaf(c1.x, V32[vr1], c1.y * V32[vrp1]);
       wave_sync();
       if (lane < 45) {
-        A[ti * 9 + tj] = anew;
-        A[tj * 9 + ti] = anew;
+        A32[aw] = anew;
+        A32[awt] = anew;
       }
-      V[lane] = v0;
-      if (lane < 17) V[lane + 64] = v1;
+      V32[vw0] = v0;
+      if (lane < 17) V32[vw1] = v1;
       wave_sync();
     }
   }
 
-  // ---- phase 5: smallest eigenpair, rank-2 projection, de-normalisation (wave-uniform arithmetic) ---
+  // ---- phase 4b: pick the eigenpair the reference picks, polish it in fp64 ----------------------------
   // torch.svd(X)[2][:, -1] is the right singular vector of the smallest of the min(N,9) singular values
   // (DeepFNet.py:232-233): for N >= 9 the smallest eigenvalue of X^T X; for N < 9 the reduced SVD has only N
   // columns, so the reference takes the smallest of the N *non-null* directions.  `skip` = 9 - min(N,9)
   // eigenvalues are passed over (ascending order, index as tie-break) to mirror that.
-  double lam[9];
+  float lam32[9];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) lam[k] = A[k * 10];
+  for (int k = 0; k < 9; ++k) lam32[k] = A32[k * 10];
   const int skip = (N < 9) ? 9 - N : 0;
   int kmin = 0;
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
     int rank = 0;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) rank += (lam[j] < lam[k] || (lam[j] == lam[k] && j < k)) ? 1 : 0;
+    for (int j = 0; j < 9; ++j) rank += (lam32[j] < lam32[k] || (lam32[j] == lam32[k] && j < k)) ? 1 : 0;
     if (rank == skip) kmin = k;
   }
   double f[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) f[c] = (double)V32[c * 9 + kmin];
+  double rho = (double)lam32[kmin] * tr;
+  // residual correction: r = M f - rho f;  f += sum_{k != kmin} q_k (q_k . r) / (rho - lam_k);  renormalise.
+  // The Jacobi basis (fp32-accurate) acts as an approximate inverse of (M - rho); the fixed point is the exact
+  // fp64 eigenvector, reached at a linear rate ~ eps32 |M| / gap per iteration.
+  for (int it = 0; it < ((clamp_at < 0.f) ? 0 : kRefineIters); ++it) {
+    double fn2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) fn2 += f[c] * f[c];
+    const double fin = 1.0 / sqrt(fn2);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) f[c] *= fin;
+    // y = M f, one row per lane
+    if (lane < 9) {
+      double y = 0.0;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) y += M64[lane * 9 + c] * f[c];
+      SCR[lane] = y;
+    }
+    wave_sync();
+    double r[9];
+    rho = 0.0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { r[c] = SCR[c]; rho += r[c] * f[c]; }
+    double rn2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { r[c] -= rho * f[c]; rn2 += r[c] * r[c]; }
+    if (!(rn2 > 1e-28 * tr * tr)) break;  // |M f - rho f| <= 1e-14 trace(M): converged (wave-uniform)
+    // a_k = (q_k . r) / (rho - lam_k) for k != kmin, one k per lane
+    if (lane < 9) {
+      double dot = 0.0;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) dot += (double)V32[c * 9 + lane] * r[c];
+      double den = rho - (double)A32[lane * 10] * tr;
+      const double lim = 1e-12 * tr;
+      if (fabs(den) < lim) den = (den < 0.0) ? -lim : lim;
+      SCR[16 + lane] = (lane == kmin) ? 0.0 : dot / den;
+    }
+    wave_sync();
+    // d_c = sum_k a_k q_k[c], one component per lane; then everybody reads the new f
+    if (lane < 9) {
+      double dsum = 0.0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) dsum += SCR[16 + k] * (double)V32[lane * 9 + k];
+      SCR[lane] = dsum;
+    }
+    wave_sync();
+#pragma unroll
+    for (int c = 0; c < 9; ++c) f[c] += SCR[c];
+    wave_sync();
+  }
+
+  // ---- phase 5: rank-2 projection, de-normalisation (wave-uniform arithmetic) ------------------------------
   double fn2 = 0.0;
 #pragma unroll
-  for (int c = 0; c < 9; ++c) {
-    f[c] = V[c * 9 + kmin];
-    fn2 += f[c] * f[c];
-  }
+  for (int c = 0; c < 9; ++c) fn2 += f[c] * f[c];
   // orientation: largest-magnitude component positive (first one on ties)
   double big = f[0];
 #pragma unroll
@@ -320,13 +395,13 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     float* sv = save + (size_t)pair * DFEPE_SAVE_FLOATS;
     {
       const int k = lane / 9, c = lane % 9;
-      sv[SV_Q + lane] = (clamp_at < 0.f) ? (float)A[lane] : (float)V[c * 9 + k];
+      sv[SV_Q + lane] = (k == kmin) ? (float)(sgn * pick9(f, c)) : V32[c * 9 + k];  // the polished vector replaces its Jacobi column
     }
     if (lane < 17) {
       const int e = lane + 64, k = e / 9, c = e % 9;
-      sv[SV_Q + e] = (clamp_at < 0.f) ? (float)A[e] : (float)V[c * 9 + k];
+      sv[SV_Q + e] = (k == kmin) ? (float)(sgn * pick9(f, c)) : V32[c * 9 + k];
     }
-    if (lane < 9) sv[SV_LAM + lane] = (float)A[lane * 10];
+    if (lane < 9) sv[SV_LAM + lane] = (lane == kmin) ? (float)rho : (float)((double)A32[lane * 10] * tr);
     if (lane == 0) {
       sv[SV_T1 + 0] = (float)s1; sv[SV_T1 + 1] = (float)c1x; sv[SV_T1 + 2] = (float)c1y;
       sv[SV_T2 + 0] = (float)s2; sv[SV_T2 + 1] = (float)c2x; sv[SV_T2 + 2] = (float)c2y;
