@@ -132,6 +132,28 @@ int dfepe_cheirality(const float *E, const float *K, const float *matches, int B
 int dfepe_epi_metrics(int kind, const float *F, const float *X, const float *Y, int B, int N, float clamp_at,
                       float eps, float *out, void *stream);
 
+/*
+ * Stand-alone symmetric epipolar residual (the same arithmetic dfepe_w8pt_fwd fuses in its epilogue).
+ * Replaces: utils_F.compute_epi_residual(pts1, pts2, F, clamp_at) (deepFEPE/dsac_tools/utils_F.py:400-413).
+ *   pts1, pts2 [B,N,3]; F [B,9]; out [B,N].   bwd: g_out [B,N] -> g_F [B,9] (gradient w.r.t. F only).
+ */
+int dfepe_epi_residual_fwd(const float *pts1, const float *pts2, const float *F, int B, int N, float clamp_at,
+                           float *out, void *stream);
+int dfepe_epi_residual_bwd(const float *pts1, const float *pts2, const float *F, int B, int N, float clamp_at,
+                           const float *g_out, float *g_F, void *stream);
+
+/*
+ * Small pose-geometry helpers, batched over n items (one lane each).
+ *   kind 0  rotation -> quaternion          in0 = R [n,9]              out [n,4]   (utils_geo._R_to_q, utils_geo.py:58-86)
+ *   kind 1  rotation angle in degrees       in0 = R0 [n,9], in1 = R1   out [n]     (utils_geo.rot12_to_angle_error, :150-155)
+ *   kind 2  vector angle in degrees         in0 = v1 [n,3], in1 = v2   out [n]     (utils_geo.vector_angle, :175-179)
+ *   kind 3  singular values forced to 1,1,0 in0 = E [n,9]              out [n,9]   (utils_F._F_to_E projection, utils_F.py:457-461;
+ *                                                                                   Train_model_pipeline.py:954-964)
+ *   kind 4  four-fold decomposition         in0 = E [n,9]              out [n,21] = R1[9] R2[9] t[3]
+ *                                                                                  (utils_F._get_M2s, utils_F.py:478-498)
+ */
+int dfepe_geo_misc(int kind, const float *in0, const float *in1, int n, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,9 @@ _SIGNATURES = {
     "dfepe_pose_bwd": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "dfepe_cheirality": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P, _P]),
     "dfepe_epi_metrics": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_float, c_float, _P, _P]),
+    "dfepe_epi_residual_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P]),
+    "dfepe_epi_residual_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P]),
+    "dfepe_geo_misc": (c_int, [c_int, _P, _P, c_int, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

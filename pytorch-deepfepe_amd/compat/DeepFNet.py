@@ -1,0 +1,143 @@
+"""Mirror of deepFEPE/models/DeepFNet.py for the default training path: NormalizeAndExpand_HW (:93-120),
+Fit (:123-295) and DeepFNet (:299-554).  The solver arithmetic runs in libdfepe_hip.so; the Python here only
+orchestrates the recurrent loop exactly like DeepFNet.forward (:429-554)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib, ops
+from .ErrorEstimators import ErrorEstimator
+
+
+def _require_gpu(t, what):
+    if not t.is_cuda:
+        raise _lib.DfepeError(f"{what}: tensors must live on the GPU (there is no CPU implementation in this package)")
+
+
+class NormalizeAndExpand_HW(nn.Module):
+    """pixel (x,y) -> [-1,1]^2 homogeneous; returns pts1, pts2 [B,3,N] and T1, T2 [B,3,3] (DeepFNet.py:108-120).
+    Inside DeepFNet.forward this map is fused into the solver kernel; the module exists for API parity."""
+
+    def __init__(self, image_size, is_cuda=True, is_test=False):
+        super().__init__()
+        self.H, self.W = image_size[0], image_size[1]
+
+    def normalize(self, pts):
+        _require_gpu(pts, "NormalizeAndExpand_HW")
+        T = torch.tensor([[2.0 / self.W, 0.0, -1.0], [0.0, 2.0 / self.H, -1.0], [0.0, 0.0, 1.0]], device=pts.device,
+                         dtype=pts.dtype).unsqueeze(0).expand(pts.size(0), -1, -1)
+        ones = torch.ones(pts.size(0), pts.size(1), 1, device=pts.device, dtype=pts.dtype)
+        return T @ torch.cat((pts, ones), 2).permute(0, 2, 1), T
+
+    def forward(self, pts):
+        pts1, T1 = self.normalize(pts[:, :, :2])
+        pts2, T2 = self.normalize(pts[:, :, 2:])
+        return pts1, pts2, T1, T2
+
+
+class Fit(nn.Module):
+    """Weighted normalised 8-point fit.  forward(pts1[B,N,3], pts2[B,N,3], weights[B,1,N]) -> (out[B,3,3], residual[B,N]).
+
+    ``if_cpu_svd`` is accepted and ignored (it selected a per-sample CPU LAPACK round trip in the reference,
+    DeepFNet.py:219-230; both of its branches compute the same thing).  Gradients flow to ``weights``; gradients
+    w.r.t. the points are not produced (the reference's training path never asks for them: the points are data)."""
+
+    def __init__(self, is_cuda=True, is_test=False, if_cpu_svd=False, normalize_SVD=True):
+        super().__init__()
+        if not normalize_SVD:
+            raise NotImplementedError("normalize_SVD=False (un-normalised rows) is not built; every reference config uses True")
+        self.if_cpu_svd = if_cpu_svd
+        self.is_cuda = is_cuda
+
+    def weighted_svd(self, pts1, pts2, weights, if_print=False):
+        _require_gpu(weights, "Fit")
+        out, residual = ops.w8pt(pts1, pts2, weights)
+        return out, residual
+
+    def forward(self, pts1, pts2, weights, if_print=False, matches_good_unique_num=None):
+        return self.weighted_svd(pts1, pts2, weights, if_print=if_print)
+
+
+class DeepFNet(nn.Module):
+    """Recurrent weight-estimation / fit loop.  Same constructor and ``forward(data_batch) -> dict`` contract as the
+    reference (DeepFNet.py:300,429-554; dict keys :534-548).  Built: the default branch every shipped config uses
+    (no descriptors, no learned offsets, no triangulated depth, no image weights); the others raise."""
+
+    def __init__(self, depth, image_size, if_quality, if_img_w=False, if_goodCorresArch=False, if_tri_depth=False,
+                 if_learn_offsets=False, if_des=False, des_size=None, quality_size=0, is_cuda=True, is_test=False,
+                 if_cpu_svd=False, **params):
+        super().__init__()
+        for flag, name in ((if_goodCorresArch, "if_goodCorresArch"), (if_tri_depth, "if_tri_depth"),
+                           (if_learn_offsets, "if_learn_offsets"), (if_des, "if_des")):
+            if flag:
+                raise NotImplementedError(f"DeepFNet({name}=True) is outside the built hot path (SURVEY.md §8)")
+        if not if_quality:
+            quality_size = 0
+        self.if_quality = if_quality
+        self.if_img_w = if_img_w
+        self.image_size = image_size
+        self.depth = depth
+        self.input_weights = ErrorEstimator(4 + quality_size)
+        self.update_weights = ErrorEstimator(4 + quality_size + 3)  # + weights, epi_res, residual (DeepFNet.py:340)
+        if is_test:
+            self.input_weights.eval()
+            self.update_weights.eval()
+        self.norm_HW = NormalizeAndExpand_HW(image_size, is_cuda, is_test)
+        self.fit = Fit(is_cuda, is_test, if_cpu_svd)
+
+    def get_input(self, data_batch, offsets=None, iter=None):
+        pts = data_batch["matches_xy_ori"]
+        pts1, pts2, T1, T2 = self.norm_HW(pts)
+        pts1 = pts1.permute(0, 2, 1)
+        pts2 = pts2.permute(0, 2, 1)
+        parts = [(pts1[:, :, :2] + 1) / 2, (pts2[:, :, :2] + 1) / 2]
+        if self.if_quality:
+            parts.append(data_batch["quality"])
+        weight_in = torch.cat(parts, 2).permute(0, 2, 1)
+        return weight_in, pts1, pts2, T1, T2
+
+    def _fit(self, matches, weights_prod, want_epi):
+        H, W = float(self.image_size[0]), float(self.image_size[1])
+        return ops.w8pt_raw(matches, weights_prod, W, H, clamp_at=0.5, want_epi=want_epi)
+
+    def forward(self, data_batch):
+        matches = data_batch["matches_xy_ori"]
+        _require_gpu(matches, "DeepFNet")
+        pts_normalized_in, pts1, pts2, T1, T2 = self.get_input(data_batch)
+        logits = self.input_weights(pts_normalized_in)
+        weights_pts = F.softmax(logits, dim=2)
+        weights_prod = weights_pts * data_batch["weights_im"] if self.if_img_w else weights_pts
+        _ = data_batch["matches_good_unique_nums"]  # read like the reference does (DeepFNet.py:449,453)
+        _ = data_batch["t_scene_scale"]
+
+        out_layers, epi_res_layers, residual_layers = [], [], []
+        weights_layers, logits_layers = [weights_prod], [logits]
+        for it in range(self.depth - 1):
+            out, residual, epi = self._fit(matches, weights_prod, True)
+            out_layers.append(out)
+            residual_layers.append(residual)
+            epi_res = epi.unsqueeze(1)
+            epi_res_layers.append(epi_res)
+            net_in = torch.cat((pts_normalized_in, weights_prod, epi_res, residual.unsqueeze(1)), 1)
+            logits = self.update_weights(net_in)
+            weights_pts = F.softmax(logits, dim=2)
+            weights_prod = weights_pts * data_batch["weights_im"] if self.if_img_w else weights_pts
+            weights_layers.append(weights_prod)
+            logits_layers.append(logits)
+        out, residual = self._fit(matches, weights_prod, False)
+        residual_layers.append(residual)
+        out_layers.append(out)
+        return {
+            "logits": logits.squeeze(1),
+            "logits_layers": logits_layers,
+            "F_est": out,
+            "epi_res_layers": epi_res_layers,
+            "T1": T1,
+            "T2": T2,
+            "out_layers": out_layers,
+            "pts1": pts1,
+            "pts2": pts2,
+            "weights": weights_prod,
+            "residual_layers": residual_layers,
+            "weights_layers": weights_layers,
+        }

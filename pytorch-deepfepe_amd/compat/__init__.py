@@ -1,0 +1,13 @@
+"""Mirror of the reference's Python call surface for the hot path: same class / function names,
+argument order, defaults, return arity, tensor layouts and dict keys, backed by libdfepe_hip.so.
+
+    reference module                         this package
+    deepFEPE.models.DeepFNet            ->   compat.DeepFNet        (NormalizeAndExpand_HW, Fit, DeepFNet)
+    deepFEPE.models.ErrorEstimators     ->   compat.ErrorEstimators (stock PyTorch; not part of the hot path)
+    deepFEPE.dsac_tools.utils_F         ->   compat.utils_F
+    deepFEPE.dsac_tools.utils_geo       ->   compat.utils_geo
+    deepFEPE.train_good_utils (losses)  ->   compat.train_good_utils (get_all_loss_DeepF, get_Rt_loss)
+
+See INTEGRATION.md for how train_good.py is pointed at these.
+"""
+from . import DeepFNet, ErrorEstimators, train_good_utils, utils_F, utils_geo  # noqa: F401

@@ -1,0 +1,112 @@
+"""Mirror of the two loss functions of deepFEPE/train_good_utils.py on the hot path:
+get_all_loss_DeepF (:298-520) and get_Rt_loss (:64-295), same arguments and return structures."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib, ops
+
+
+def mean_list(lst):
+    return sum(lst) / len(lst)
+
+
+def get_unique(xs, topk, matches_good_unique_nums):
+    """top-k of the first `unique_num` entries per sample (train_good_utils.py get_unique)."""
+    out = []
+    for x, n in zip(xs, matches_good_unique_nums):
+        out.append(torch.topk(x[: int(n)], topk, dim=0)[0])
+    return torch.stack(out)
+
+
+def get_all_loss_DeepF(outs, pts1_virt_ori, pts2_virt_ori, Ks, loss_params, get_residual_summaries=True):
+    """F-loss on the virtual correspondences for every layer + E-from-F.  Returns, like the reference (:511-519),
+    (losses_dict, E_ests, F_ests, logits_softmax, residual_norm_layers, residual_norm_max_layers, E_ests_layers)."""
+    if loss_params.get("if_tri_depth", False) or loss_params.get("if_sample_loss", False):
+        raise NotImplementedError("if_tri_depth / if_sample_loss are outside the built hot path (all shipped configs disable them)")
+    logits_softmax = outs["weights"]
+    F_est_normalized, T1, T2 = outs["F_est"], outs["T1"], outs["T2"]
+    out_layers, residual_layers, weights_layers = outs["out_layers"], outs["residual_layers"], outs["weights_layers"]
+    depth = loss_params["depth"]
+    F_layers = torch.stack(list(out_layers[:depth]))  # [L,B,3,3]
+    M = pts1_virt_ori.shape[1]
+    B = F_layers.shape[1]
+    loss_sum, E_layers = ops.floss(F_layers, T1, T2, Ks, pts1_virt_ori, pts2_virt_ori, loss_params["clamp_at"])
+    per_pair = loss_sum / float(M)  # losses.mean(dim=1) per layer  [L,B]
+    loss_layers = [per_pair[i].mean() for i in range(depth)]
+    loss_F_all = sum(loss_layers) / len(loss_layers)
+    E_ests_layers = [E_layers[i] for i in range(depth)]
+    F_ests = T2.permute(0, 2, 1) @ F_est_normalized @ T1
+    E_ests = Ks.transpose(1, 2) @ F_ests @ Ks
+    losses_dict = {
+        "loss_layers": loss_layers,
+        "loss_F": loss_F_all,
+        "loss_min_layers": per_pair.min(dim=1)[0],
+        "loss_min_batch": per_pair.min(dim=0)[0],
+    }
+    loss_epi_res_all = 0.0
+    loss_epi_res_layers = []
+    if depth > 1:
+        for epi_res, weights in zip(outs["epi_res_layers"], outs["weights_layers"]):
+            loss_epi_res_layers.append((epi_res * weights).mean())
+        loss_epi_res_all = sum(loss_epi_res_layers) / len(loss_epi_res_layers)
+    losses_dict.update({"loss_epi_res_layers": loss_epi_res_layers, "loss_epi_res": loss_epi_res_all})
+
+    residual_norm_layers, residual_norm_max_layers = None, None
+    if get_residual_summaries:  # logging-only summaries (:441-509), plain tensor reductions
+        topK = loss_params["topK"]
+        nums = loss_params["matches_good_unique_nums"]
+        residual_norm_layers, residual_norm_topK_layers, residual_norm_max_layers = [], [], []
+        for residual in residual_layers:
+            norms = residual.norm(p=2, dim=1)
+            residual_norm_layers.append(norms.mean())
+            residual_norm_max_layers.append(norms.max())
+            residual_norm_topK_layers.append(get_unique(residual, topK, nums).mean())
+        regW_clip, entro, entro_topK = [], [], []
+        for w in weights_layers:
+            regW_clip.append(nn.ReLU()(w - 0.01).mean())
+            entro.append(torch.distributions.Categorical(probs=w.squeeze(1)).entropy().mean())
+            entro_topK.append(torch.distributions.Categorical(probs=get_unique(w.squeeze(1), topK, nums)).entropy().mean())
+        losses_dict.update({
+            "loss_residual": sum(residual_norm_layers) / len(residual_norm_layers),
+            "loss_residual_topK": sum(residual_norm_topK_layers) / len(residual_norm_topK_layers),
+            "loss_regW_clip": sum(regW_clip) / len(weights_layers) * 100.0,
+            "loss_regW_entro": sum(entro) / len(weights_layers),
+            "loss_regW_entro_topK": sum(entro_topK) / len(weights_layers),
+        })
+    return losses_dict, E_ests, F_ests, logits_softmax, residual_norm_layers, residual_norm_max_layers, E_ests_layers
+
+
+def get_Rt_loss(E_ests_layers, Ks_cpu, x1_cpu, x2_cpu, delta_Rtijs_4_4_cpu, qs_cam, ts_cam, device="cpu"):
+    """Pose loss from the per-layer essential matrices and the ground-truth camera motion.  Same 12-key dict as the
+    reference (:272-293).  NB the reference stacks the *translation* list under "q_l2_error_list" (:276); that slip
+    is reproduced so downstream logging sees identical values.  Ks/x1/x2 are unused, as in the reference."""
+    E_layers = torch.stack(list(E_ests_layers))  # [L,B,3,3]
+    if not E_layers.is_cuda:
+        raise _lib.DfepeError("get_Rt_loss: E_ests_layers must live on the GPU")
+    dev = E_layers.device
+    delta = torch.as_tensor(delta_Rtijs_4_4_cpu).to(dev).float()
+    R_gt = torch.linalg.inv(delta)[:, :3, :3].contiguous()
+    q_l2, t_l2, R_deg, t_deg, _ = ops.pose_errors(E_layers, torch.as_tensor(qs_cam).to(dev), torch.as_tensor(ts_cam).to(dev), R_gt)
+    L = E_layers.shape[0]
+    R_np, t_np = R_deg.cpu().numpy().astype(np.float64), t_deg.cpu().numpy().astype(np.float64)
+    t_l2_layers = [t_l2[i] for i in range(L)]
+    q_l2_layers = [q_l2[i] for i in range(L)]
+    t_means = [x.mean() for x in t_l2_layers]
+    q_means = [x.mean() for x in q_l2_layers]
+    R_means = [float(R_np[i].mean()) for i in range(L)]
+    tA_means = [float(t_np[i].mean()) for i in range(L)]
+    return {
+        "t_l2_error_mean": mean_list(t_means),
+        "q_l2_error_mean": mean_list(q_means),
+        "t_l2_error_list": torch.stack(t_means),
+        "q_l2_error_list": torch.stack(t_means),  # sic: reference train_good_utils.py:276
+        "R_angle_error_mean": mean_list(R_means),
+        "R_angle_error_list": np.array(R_means),
+        "t_angle_error_mean": mean_list(tA_means),
+        "t_angle_error_list": np.array(tA_means),
+        "R_angle_error_layers_list": [R_np[i] for i in range(L)],
+        "t_angle_error_layers_list": [t_np[i] for i in range(L)],
+        "t_l2_error_layers_list": t_l2_layers,
+        "q_l2_error_layers_list": q_l2_layers,
+    }

@@ -1,0 +1,110 @@
+"""Mirror of the hot-path functions of deepFEPE/dsac_tools/utils_F.py, evaluated by libdfepe_hip.so.
+Signatures follow the reference; tensors must live on the GPU."""
+import torch
+
+from .. import _lib, ops
+
+
+def _gpu(t, dtype=torch.float32):
+    t = torch.as_tensor(t)
+    if not t.is_cuda:
+        raise _lib.DfepeError("dsac_tools.utils_F mirror: tensors must live on the GPU (no CPU implementation here)")
+    return t.to(dtype)
+
+
+def compute_epi_residual(pts1, pts2, F, clamp_at=0.5):
+    """Symmetric epipolar residual, [B,N] (utils_F.py:400-413); differentiable w.r.t. F."""
+    return ops.epi_residual(_gpu(pts1), _gpu(pts2), _gpu(F), clamp_at)
+
+
+def _get_M2s(E):
+    """E [3,3] -> (R2s, t2s, M2s) like utils_F.py:478-498 (two rotations, +-t, the four [R|t]).
+    The candidate *set* equals the reference's; the order within each pair follows this library's SVD gauge."""
+    R1, R2, t = ops.decompose_essential(_gpu(E).reshape(1, 3, 3))
+    R2s = [R1[0], R2[0]]
+    t2s = [t[0].reshape(3, 1), -t[0].reshape(3, 1)]
+    M2s = [torch.cat((R, tt), 1) for R in R2s for tt in t2s]
+    return R2s, t2s, M2s
+
+
+def _F_to_E(F, K):
+    """E = K^T F K with singular values forced to (1,1,0) (utils_F.py:455-462)."""
+    F, K = _gpu(F), _gpu(K)
+    return ops.project_essential((K.t() @ F @ K).reshape(1, 3, 3))[0]
+
+
+def _E_to_F(E, K):
+    """F = K^-T E K^-1 (utils_F.py:464-469); 2-D or batched."""
+    E, K = _gpu(E), _gpu(K)
+    Ki = torch.linalg.inv(K)
+    return Ki.transpose(-1, -2) @ E @ Ki
+
+
+def _homo_free(F, X, Y, if_homo):
+    F, X, Y = _gpu(F), _gpu(X), _gpu(Y)
+    single = X.dim() == 2
+    if single:
+        F, X, Y = F.unsqueeze(0), X.unsqueeze(0), Y.unsqueeze(0)
+    if if_homo:  # the kernels take inhomogeneous 2-D points
+        X, Y = X[..., :2] / X[..., 2:3], Y[..., :2] / Y[..., 2:3]
+    return F, X.contiguous(), Y.contiguous(), single
+
+
+def _sym_epi_dist(F, X, Y, if_homo=False, clamp_at=None):
+    """Squared symmetric epipolar distance (utils_F.py:310-339); the 1e-10 guard only in the batched form (:329)."""
+    F, X, Y, single = _homo_free(F, X, Y, if_homo)
+    out = ops.epi_metrics(0, F, X, Y, clamp_at=0.0 if clamp_at is None else clamp_at, eps=0.0 if single else 1e-10)
+    return out[0] if single else out
+
+
+def _sampson_dist(F, X, Y, if_homo=False):
+    F, X, Y, single = _homo_free(F, X, Y, if_homo)
+    out = ops.epi_metrics(1, F, X, Y)
+    return out[0] if single else out
+
+
+def _epi_distance(F, X, Y, if_homo=False):
+    """Returns ((d1+d2)/2, d1, d2) (utils_F.py:341-361)."""
+    F, X, Y, single = _homo_free(F, X, Y, if_homo)
+    out = ops.epi_metrics(2, F, X, Y)
+    return (out[0, 0], out[1, 0], out[2, 0]) if single else (out[0], out[1], out[2])
+
+
+def _E_to_M_train(E_est_th, K, x1, x2, inlier_mask=None, delta_Rt_gt_cam=None, depth_thres=50.0, show_debug=False,
+                  show_result=True, method_name="ours"):
+    """Cheirality-checked pose (utils_F.py:679-763).  Returns (M2_list, error_Rt, Rt_cam) like the reference:
+    Rt_cam [3,4] = camera motion of the winning candidate or None; error_Rt = [R deg, t deg] when a ground truth
+    is given.  The triangulation is a linear DLT per correspondence (the reference calls cv2.triangulatePoints)."""
+    dev = E_est_th.device if torch.is_tensor(E_est_th) and E_est_th.is_cuda else torch.device("cuda")
+    E = torch.as_tensor(E_est_th, dtype=torch.float32).to(dev).reshape(1, 3, 3)
+    Kt = torch.as_tensor(K, dtype=torch.float32).to(dev).reshape(1, 3, 3)
+    x1 = torch.as_tensor(x1, dtype=torch.float32).to(dev)
+    x2 = torch.as_tensor(x2, dtype=torch.float32).to(dev)
+    if inlier_mask is not None:
+        m = torch.as_tensor(inlier_mask).to(dev)
+        x1, x2 = x1[m], x2[m]
+        if x1.shape[0] < 8:
+            print("ERROR! Less than 8 points after inlier mask!")
+            return None
+    Rt, win, cnt = ops.cheirality(E, Kt, torch.cat((x1, x2), 1).unsqueeze(0).contiguous(), depth_thres)
+    if int(win[0].item()) < 0:
+        print("ERROR! 0 of qualified [R|t] found!")
+        return [], [], None
+    Rt_cam = Rt[0]
+    error_Rt = []
+    if delta_Rt_gt_cam is not None:
+        gt = torch.as_tensor(delta_Rt_gt_cam, dtype=torch.float32).to(dev)
+        eR = ops.rot_angle_deg(Rt_cam[:, :3].reshape(1, 3, 3), gt[:3, :3].reshape(1, 3, 3))[0].item()
+        et = ops.vector_angle_deg(Rt_cam[:, 3].reshape(1, 3), gt[:3, 3].reshape(1, 3))[0].item()
+        if show_result:
+            print("Recovered by %s (camera): The rotation error (degree) %.4f, and translation error (degree) %.4f" % (method_name, eR, et))
+        error_Rt = [eR, et]
+    return [], error_Rt, Rt_cam
+
+
+def _E_from_XY(*args, **kwargs):
+    raise NotImplementedError("_E_from_XY (textbook 8-point on K^-1 points, utils_F.py:104-155) is a 'next' row of SURVEY.md §8 and is not built yet")
+
+
+def _F_from_XY(*args, **kwargs):
+    raise NotImplementedError("_F_from_XY (utils_F.py:223-275) is a 'next' row of SURVEY.md §8 and is not built yet")

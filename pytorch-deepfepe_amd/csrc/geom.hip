@@ -1,0 +1,398 @@
+// Stand-alone geometry entry points of the dsac_tools API: epipolar residual / metrics, small pose helpers,
+// cheirality-checked pose selection.  These sit on either side of the solver.
+#include "dfepe_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------
+// epipolar residual (utils_F.py:400-413), one wavefront per pair
+// ------------------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ void __launch_bounds__(256)
+epi_residual_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, const float* __restrict__ F, int B,
+                    int N, float clamp_at, float* __restrict__ out, const float* __restrict__ g_out,
+                    float* __restrict__ g_F) {
+  const int lane = threadIdx.x & 63;
+  const size_t pair = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (pair >= (size_t)B) return;
+  float o[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) o[c] = F[pair * 9 + c];
+  double go[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) go[c] = 0.0;
+  for (int i = lane; i < N; i += WAVE) {
+    const Pt p = global_point<false>(pts1, pts2, pair, i, N, 0.f, 0.f);
+    if (!BWD) {
+      const float l1x = fmaf(p.x2, o[0], fmaf(p.y2, o[3], p.z2 * o[6]));
+      const float l1y = fmaf(p.x2, o[1], fmaf(p.y2, o[4], p.z2 * o[7]));
+      const float l1z = fmaf(p.x2, o[2], fmaf(p.y2, o[5], p.z2 * o[8]));
+      const float l2x = fmaf(p.x1, o[0], fmaf(p.y1, o[1], p.z1 * o[2]));
+      const float l2y = fmaf(p.x1, o[3], fmaf(p.y1, o[4], p.z1 * o[5]));
+      const float dd = fmaf(p.x1, l1x, fmaf(p.y1, l1y, p.z1 * l1z));
+      const float n1 = sqrtf(fmaf(l1x, l1x, l1y * l1y)) + 1e-6f;
+      const float n2 = sqrtf(fmaf(l2x, l2x, l2y * l2y)) + 1e-6f;
+      out[pair * N + i] = fminf(fabsf(dd) * (1.0f / n1 + 1.0f / n2), clamp_at);
+    } else {
+      const double x1[3] = {p.x1, p.y1, p.z1}, x2[3] = {p.x2, p.y2, p.z2};
+      double l1[3], l2[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) l1[c] = x2[0] * o[c] + x2[1] * o[3 + c] + x2[2] * o[6 + c];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) l2[r] = o[3 * r] * x1[0] + o[3 * r + 1] * x1[1] + o[3 * r + 2] * x1[2];
+      const double dd = x1[0] * l1[0] + x1[1] * l1[1] + x1[2] * l1[2];
+      const double n1 = sqrt(l1[0] * l1[0] + l1[1] * l1[1]), n2 = sqrt(l2[0] * l2[0] + l2[1] * l2[1]);
+      const double i1 = 1.0 / (n1 + 1e-6), i2 = 1.0 / (n2 + 1e-6);
+      const double S = i1 + i2, ad = fabs(dd);
+      const double g = (ad * S <= (double)clamp_at) ? (double)g_out[pair * N + i] : 0.0;
+      const double sg = (dd > 0.0) ? 1.0 : ((dd < 0.0) ? -1.0 : 0.0);
+      const double k1 = (n1 > 0.0) ? ad * i1 * i1 / n1 : 0.0;
+      const double k2 = (n2 > 0.0) ? ad * i2 * i2 / n2 : 0.0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          double t = sg * S * x2[r] * x1[c];
+          if (c < 2) t -= k1 * l1[c] * x2[r];
+          if (r < 2) t -= k2 * l2[r] * x1[c];
+          go[3 * r + c] += g * t;
+        }
+    }
+  }
+  if (BWD) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) go[c] = wave_sum(go[c]);
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) g_F[pair * 9 + c] = (float)go[c];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// epipolar metrics on 2-D points (utils_F.py:291-361), one lane per correspondence
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+epi_metrics_kernel(int kind, const float* __restrict__ F, const float* __restrict__ X, const float* __restrict__ Y, int B,
+                   int N, float clamp_at, float eps, float* __restrict__ out) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)B * N) return;
+  const size_t b = idx / N;
+  double f[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) f[c] = (double)F[b * 9 + c];
+  const double x[3] = {X[idx * 2], X[idx * 2 + 1], 1.0}, y[3] = {Y[idx * 2], Y[idx * 2 + 1], 1.0};
+  double fx[3], fty[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) fx[r] = f[3 * r] * x[0] + f[3 * r + 1] * x[1] + f[3 * r + 2] * x[2];       // F x
+#pragma unroll
+  for (int c = 0; c < 3; ++c) fty[c] = f[c] * y[0] + f[3 + c] * y[1] + f[6 + c] * y[2];                    // F^T y
+  const double num = y[0] * fx[0] + y[1] * fx[1] + y[2] * fx[2];
+  const double a = fx[0] * fx[0] + fx[1] * fx[1], bq = fty[0] * fty[0] + fty[1] * fty[1];
+  if (kind == 0) {
+    double e = num * num * (1.0 / (a + (double)eps) + 1.0 / (bq + (double)eps));
+    if (clamp_at > 0.f) e = fmin(e, (double)clamp_at);
+    out[idx] = (float)e;
+  } else if (kind == 1) {
+    out[idx] = (float)(num * num / (a + bq));
+  } else {
+    const double d1 = fabs(num) / sqrt(a), d2 = fabs(num) / sqrt(bq);
+    const size_t plane = (size_t)B * N;
+    out[idx] = (float)(0.5 * (d1 + d2));
+    out[plane + idx] = (float)d1;
+    out[2 * plane + idx] = (float)d2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// small pose helpers, one lane per item
+// ------------------------------------------------------------------------------------------------------
+__device__ inline void quat_of(const double* R, double* q) {
+#define M_(i, j) R[3 * (j) + (i)]
+  double v[4], t;
+  if (M_(2, 2) < 0.0) {
+    if (M_(0, 0) > M_(1, 1)) {
+      t = 1.0 + M_(0, 0) - M_(1, 1) - M_(2, 2);
+      v[0] = M_(1, 2) - M_(2, 1); v[1] = t; v[2] = M_(0, 1) + M_(1, 0); v[3] = M_(2, 0) + M_(0, 2);
+    } else {
+      t = 1.0 - M_(0, 0) + M_(1, 1) - M_(2, 2);
+      v[0] = M_(2, 0) - M_(0, 2); v[1] = M_(0, 1) + M_(1, 0); v[2] = t; v[3] = M_(1, 2) + M_(2, 1);
+    }
+  } else {
+    if (M_(0, 0) < -M_(1, 1)) {
+      t = 1.0 - M_(0, 0) - M_(1, 1) + M_(2, 2);
+      v[0] = M_(0, 1) - M_(1, 0); v[1] = M_(2, 0) + M_(0, 2); v[2] = M_(1, 2) + M_(2, 1); v[3] = t;
+    } else {
+      t = 1.0 + M_(0, 0) + M_(1, 1) + M_(2, 2);
+      v[0] = t; v[1] = M_(1, 2) - M_(2, 1); v[2] = M_(2, 0) - M_(0, 2); v[3] = M_(0, 1) - M_(1, 0);
+    }
+  }
+#undef M_
+  double sc = 0.5 / sqrt(t);
+  if (v[0] * sc < 0.0) sc = -sc;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) q[k] = sc * v[k];
+}
+
+// the four-fold ambiguity of utils_F._get_M2s (utils_F.py:478-498): R1 = U W V^T, R2 = U W^T V^T (both negated when
+// det < 0), t = u3 / |u3|
+__device__ inline void decompose_E(const double* E, double* R1, double* R2, double* t) {
+  double U[9], S[3], V[9];
+  svd3<double>(E, U, S, V);
+  double UW[9], UWt[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    UW[3 * r + 0] = U[3 * r + 1]; UW[3 * r + 1] = -U[3 * r + 0]; UW[3 * r + 2] = U[3 * r + 2];
+    UWt[3 * r + 0] = -U[3 * r + 1]; UWt[3 * r + 1] = U[3 * r + 0]; UWt[3 * r + 2] = U[3 * r + 2];
+  }
+  mat3_mul_nt(UW, V, R1);
+  mat3_mul_nt(UWt, V, R2);
+  const double det = R1[0] * (R1[4] * R1[8] - R1[5] * R1[7]) - R1[1] * (R1[3] * R1[8] - R1[5] * R1[6]) +
+                     R1[2] * (R1[3] * R1[7] - R1[4] * R1[6]);
+  if (det < 0.0) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { R1[k] = -R1[k]; R2[k] = -R2[k]; }
+  }
+  const double un = sqrt(U[2] * U[2] + U[5] * U[5] + U[8] * U[8]);
+  t[0] = U[2] / un; t[1] = U[5] / un; t[2] = U[8] / un;
+}
+
+__global__ void __launch_bounds__(256)
+geo_misc_kernel(int kind, const float* __restrict__ in0, const float* __restrict__ in1, int n, float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n) return;
+  const double rad2deg = 57.29577951308232;
+  if (kind == 0) {
+    double R[9], q[4];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = (double)in0[i * 9 + k];
+    quat_of(R, q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[i * 4 + k] = (float)q[k];
+  } else if (kind == 1) {
+    double A[9], Bm[9], D[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { A[k] = (double)in0[i * 9 + k]; Bm[k] = (double)in1[i * 9 + k]; }
+    mat3_mul_nt(A, Bm, D);
+    const double ax = D[7] - D[5], ay = D[2] - D[6], az = D[3] - D[1];
+    out[i] = (float)(atan2(sqrt(ax * ax + ay * ay + az * az), D[0] + D[4] + D[8] - 1.0) * rad2deg);
+  } else if (kind == 2) {
+    double dot = 0.0, n1 = 0.0, n2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double a = (double)in0[i * 3 + k], b = (double)in1[i * 3 + k];
+      dot += a * b; n1 += a * a; n2 += b * b;
+    }
+    const double den = (sqrt(n1) + 1e-10) * (sqrt(n2) + 1e-10) + 1e-10;
+    out[i] = (float)(acos(fmin(fmax(dot / den, -1.0), 1.0)) * rad2deg);
+  } else if (kind == 3) {
+    double E[9], U[9], S[3], V[9], Ed[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) E[k] = (double)in0[i * 9 + k];
+    svd3<double>(E, U, S, V);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Ed[3 * r + c] = U[3 * r] * V[3 * c] + U[3 * r + 1] * V[3 * c + 1];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out[i * 9 + k] = (float)Ed[k];
+  } else {
+    double E[9], R1[9], R2[9], t[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) E[k] = (double)in0[i * 9 + k];
+    decompose_E(E, R1, R2, t);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { out[i * 21 + k] = (float)R1[k]; out[i * 21 + 9 + k] = (float)R2[k]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[i * 21 + 18 + k] = (float)t[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// cheirality (utils_F._E_to_M_train, utils_F.py:679-763), one wavefront per pair, one correspondence per lane
+// ------------------------------------------------------------------------------------------------------
+// smallest eigenvector of a symmetric 4x4 (the DLT normal matrix) by cyclic Jacobi, fp64, in registers
+__device__ inline void smallest_eigvec4(double* S /*4x4 row-major, symmetric, destroyed*/, double* x) {
+  double V[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) V[k] = (k % 5 == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 10; ++sweep) {
+    double off = 0.0, dg = 0.0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (p == q) dg += S[4 * p + q] * S[4 * p + q];
+        else if (p < q) off += S[4 * p + q] * S[4 * p + q];
+      }
+    if (!(off > 1e-30 * dg)) break;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int q = p + 1; q < 4; ++q) {
+        const double apq = S[4 * p + q];
+        if (apq != 0.0) {
+          const double d = S[4 * q + q] - S[4 * p + p], b = 2.0 * apq;
+          const double h = sqrt(d * d + b * b);
+          const double t = b / (d + copysign(h, d));
+          const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {  // columns
+            const double skp = S[4 * k + p], skq = S[4 * k + q];
+            S[4 * k + p] = c * skp - s * skq;
+            S[4 * k + q] = s * skp + c * skq;
+            const double vkp = V[4 * k + p], vkq = V[4 * k + q];
+            V[4 * k + p] = c * vkp - s * vkq;
+            V[4 * k + q] = s * vkp + c * vkq;
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {  // rows
+            const double spk = S[4 * p + k], sqk = S[4 * q + k];
+            S[4 * p + k] = c * spk - s * sqk;
+            S[4 * q + k] = s * spk + c * sqk;
+          }
+        }
+      }
+  }
+  int km = 0;
+  double lm = S[0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k)
+    if (S[5 * k] < lm) { lm = S[5 * k]; km = k; }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double v = V[4 * r];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) v = (km == k) ? V[4 * r + k] : v;
+    x[r] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+cheirality_kernel(const float* __restrict__ E, const float* __restrict__ K, const float* __restrict__ matches, int B, int N,
+                  float depth_thres, float* __restrict__ Rt_cam, int* __restrict__ winner, int* __restrict__ counts) {
+  const int lane = threadIdx.x & 63;
+  const size_t pair = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (pair >= (size_t)B) return;
+  double Ed[9], Kd[9], R[2][9], t[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { Ed[k] = (double)E[pair * 9 + k]; Kd[k] = (double)K[pair * 9 + k]; }
+  decompose_E(Ed, R[0], R[1], t);
+  int cnt[4] = {0, 0, 0, 0};
+  for (int base = 0; base < N; base += WAVE) {
+    const int i = base + lane;
+    const bool live = i < N;
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) m = reinterpret_cast<const float4*>(matches)[pair * N + i];
+#pragma unroll
+    for (int cand = 0; cand < 4; ++cand) {
+      const double* Rc = R[cand >> 1];
+      const double sg = (cand & 1) ? -1.0 : 1.0;
+      // P1 = K [I|0], P2 = K [R|t]
+      double P2[12];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) P2[4 * r + c] = Kd[3 * r] * Rc[c] + Kd[3 * r + 1] * Rc[3 + c] + Kd[3 * r + 2] * Rc[6 + c];
+        P2[4 * r + 3] = sg * (Kd[3 * r] * t[0] + Kd[3 * r + 1] * t[1] + Kd[3 * r + 2] * t[2]);
+      }
+      // DLT rows: x*P[2]-P[0], y*P[2]-P[1] for both views
+      double A[16];
+      const double x1 = m.x, y1 = m.y, x2 = m.z, y2 = m.w;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const double p1r0 = (c < 3) ? Kd[c] : 0.0, p1r1 = (c < 3) ? Kd[3 + c] : 0.0, p1r2 = (c < 3) ? Kd[6 + c] : 0.0;
+        A[c] = x1 * p1r2 - p1r0;
+        A[4 + c] = y1 * p1r2 - p1r1;
+        A[8 + c] = x2 * P2[8 + c] - P2[c];
+        A[12 + c] = y2 * P2[8 + c] - P2[4 + c];
+      }
+      double S[16];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) S[4 * r + c] = A[r] * A[c] + A[4 + r] * A[4 + c] + A[8 + r] * A[8 + c] + A[12 + r] * A[12 + c];
+      double X[4];
+      smallest_eigvec4(S, X);
+      const double z1 = X[2] / X[3];
+      const double X0 = X[0] / X[3], X1 = X[1] / X[3];
+      const double z2 = Rc[6] * X0 + Rc[7] * X1 + Rc[8] * z1 + sg * t[2];
+      const bool good = live && (z1 > 0.0) && (z1 < (double)depth_thres) && (z2 > 0.0) && (z2 < (double)depth_thres);
+      cnt[cand] += __popcll(__ballot(good));
+    }
+  }
+  int win = 0;
+#pragma unroll
+  for (int c = 1; c < 4; ++c)
+    if (cnt[c] > cnt[win]) win = c;  // first maximum, like max(enumerate(...)) (utils_F.py:730)
+  if (lane == 0) {
+    if (counts != nullptr) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) counts[pair * 4 + c] = cnt[c];
+    }
+    if (winner != nullptr) winner[pair] = (cnt[win] > 0) ? win : -1;
+    // camera motion = inverse of [R|t]: [R^T | -R^T t]   (utils_misc._inv_Rt, utils_misc.py:115-121)
+    const double* Rc = R[win >> 1];
+    const double sg = (win & 1) ? -1.0 : 1.0;
+    float* dst = Rt_cam + pair * 12;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dst[4 * r + c] = (cnt[win] > 0) ? (float)Rc[3 * c + r] : 0.0f;
+      const double tc = -(Rc[r] * t[0] + Rc[3 + r] * t[1] + Rc[6 + r] * t[2]) * sg;
+      dst[4 * r + 3] = (cnt[win] > 0) ? (float)tc : 0.0f;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int dfepe_epi_residual_fwd(const float* pts1, const float* pts2, const float* F, int B, int N, float clamp_at,
+                                      float* out, void* stream) {
+  if (B < 0 || N <= 0) return DFEPE_ERR_INVALID_ARG;
+  if (B == 0) return DFEPE_OK;
+  if (!pts1 || !pts2 || !F || !out) return DFEPE_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(epi_residual_kernel<false>, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), pts1, pts2,
+                     F, B, N, clamp_at, out, nullptr, nullptr);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+extern "C" int dfepe_epi_residual_bwd(const float* pts1, const float* pts2, const float* F, int B, int N, float clamp_at,
+                                      const float* g_out, float* g_F, void* stream) {
+  if (B < 0 || N <= 0) return DFEPE_ERR_INVALID_ARG;
+  if (B == 0) return DFEPE_OK;
+  if (!pts1 || !pts2 || !F || !g_out || !g_F) return DFEPE_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(epi_residual_kernel<true>, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), pts1, pts2,
+                     F, B, N, clamp_at, nullptr, g_out, g_F);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+extern "C" int dfepe_epi_metrics(int kind, const float* F, const float* X, const float* Y, int B, int N, float clamp_at,
+                                 float eps, float* out, void* stream) {
+  if (kind < 0 || kind > 2 || B < 0 || N <= 0) return DFEPE_ERR_INVALID_ARG;
+  if (B == 0) return DFEPE_OK;
+  if (!F || !X || !Y || !out) return DFEPE_ERR_INVALID_ARG;
+  const size_t n = (size_t)B * N;
+  hipLaunchKernelGGL(epi_metrics_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), kind,
+                     F, X, Y, B, N, clamp_at, eps, out);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+extern "C" int dfepe_geo_misc(int kind, const float* in0, const float* in1, int n, float* out, void* stream) {
+  if (kind < 0 || kind > 4 || n < 0) return DFEPE_ERR_INVALID_ARG;
+  if (n == 0) return DFEPE_OK;
+  if (!in0 || !out || ((kind == 1 || kind == 2) && !in1)) return DFEPE_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(geo_misc_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), kind, in0, in1, n, out);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+extern "C" int dfepe_cheirality(const float* E, const float* K, const float* matches, int B, int N, float depth_thres,
+                                float* Rt_cam, int* winner, int* counts, void* stream) {
+  if (B < 0 || N <= 0) return DFEPE_ERR_INVALID_ARG;
+  if (B == 0) return DFEPE_OK;
+  if (!E || !K || !matches || !Rt_cam) return DFEPE_ERR_INVALID_ARG;
+  if (reinterpret_cast<uintptr_t>(matches) & 15u) return DFEPE_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(cheirality_kernel, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), E, K, matches, B, N,
+                     depth_thres, Rt_cam, winner, counts);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}

@@ -192,3 +192,94 @@ def pose_errors(E_layers: Tensor, q_gt: Tensor, t_gt: Tensor, R_gt: Tensor):
     B = E_layers.shape[1]
     return _PoseFunction.apply(_prep(E_layers, "E_layers"), _prep(q_gt.reshape(B, 4), "q_gt"),
                                _prep(t_gt.reshape(B, 3), "t_gt"), _prep(R_gt.reshape(B, 3, 3), "R_gt"))
+
+
+# ------------------------------------------------------------------------------------------------
+# stand-alone geometry entry points
+# ------------------------------------------------------------------------------------------------
+class _EpiResidualFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pts1, pts2, F, clamp_at):
+        B, N = pts1.shape[0], pts1.shape[1]
+        out = torch.empty(B, N, device=pts1.device, dtype=torch.float32)
+        with torch.cuda.device(pts1.device):
+            rc = _lib.lib().dfepe_epi_residual_fwd(_ptr(pts1), _ptr(pts2), _ptr(F), B, N, float(clamp_at), _ptr(out), _stream())
+        _lib.check(rc, "dfepe_epi_residual_fwd")
+        ctx.save_for_backward(pts1, pts2, F)
+        ctx.clamp_at = float(clamp_at)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pts1, pts2, F = ctx.saved_tensors
+        B, N = pts1.shape[0], pts1.shape[1]
+        gF = torch.empty_like(F)
+        g = g.contiguous().float()
+        with torch.cuda.device(pts1.device):
+            rc = _lib.lib().dfepe_epi_residual_bwd(_ptr(pts1), _ptr(pts2), _ptr(F), B, N, ctx.clamp_at, _ptr(g), _ptr(gF), _stream())
+        _lib.check(rc, "dfepe_epi_residual_bwd")
+        return None, None, gF, None
+
+
+def epi_residual(pts1: Tensor, pts2: Tensor, F: Tensor, clamp_at: float = 0.5) -> Tensor:
+    """pts [B,N,3], F [B,3,3] -> [B,N]; differentiable w.r.t. F."""
+    return _EpiResidualFunction.apply(_prep(pts1, "pts1"), _prep(pts2, "pts2"), _prep(F, "F"), clamp_at)
+
+
+def epi_metrics(kind: int, F: Tensor, X: Tensor, Y: Tensor, clamp_at: float = 0.0, eps: float = 0.0) -> Tensor:
+    """kind 0 sym-epi (squared), 1 Sampson, 2 epi-distance (3 planes).  F [B,3,3], X, Y [B,N,2]."""
+    F, X, Y = _prep(F, "F"), _prep(X, "X"), _prep(Y, "Y")
+    B, N = X.shape[0], X.shape[1]
+    out = torch.empty((3, B, N) if kind == 2 else (B, N), device=X.device, dtype=torch.float32)
+    with torch.cuda.device(X.device):
+        rc = _lib.lib().dfepe_epi_metrics(int(kind), _ptr(F), _ptr(X), _ptr(Y), B, N, float(clamp_at), float(eps), _ptr(out), _stream())
+    _lib.check(rc, "dfepe_epi_metrics")
+    return out
+
+
+_GEO_OUT = {0: 4, 1: 1, 2: 1, 3: 9, 4: 21}
+
+
+def geo_misc(kind: int, in0: Tensor, in1: Optional[Tensor] = None) -> Tensor:
+    in0 = _prep(in0, "in0")
+    in1 = None if in1 is None else _prep(in1, "in1")
+    n = in0.shape[0]
+    out = torch.empty(n, _GEO_OUT[kind], device=in0.device, dtype=torch.float32)
+    with torch.cuda.device(in0.device):
+        rc = _lib.lib().dfepe_geo_misc(int(kind), _ptr(in0), _ptr(in1), n, _ptr(out), _stream())
+    _lib.check(rc, "dfepe_geo_misc")
+    return out
+
+
+def rot_to_quat(R: Tensor) -> Tensor:
+    return geo_misc(0, R.reshape(-1, 9))
+
+
+def rot_angle_deg(R0: Tensor, R1: Tensor) -> Tensor:
+    return geo_misc(1, R0.reshape(-1, 9), R1.reshape(-1, 9))[:, 0]
+
+
+def vector_angle_deg(v1: Tensor, v2: Tensor) -> Tensor:
+    return geo_misc(2, v1.reshape(-1, 3), v2.reshape(-1, 3))[:, 0]
+
+
+def project_essential(E: Tensor) -> Tensor:
+    return geo_misc(3, E.reshape(-1, 9)).reshape(-1, 3, 3)
+
+
+def decompose_essential(E: Tensor):
+    o = geo_misc(4, E.reshape(-1, 9))
+    return o[:, 0:9].reshape(-1, 3, 3), o[:, 9:18].reshape(-1, 3, 3), o[:, 18:21]
+
+
+def cheirality(E: Tensor, K: Tensor, matches: Tensor, depth_thres: float = 50.0):
+    """E, K [B,3,3], matches [B,N,4] pixels -> (Rt_cam [B,3,4], winner [B] int32, counts [B,4] int32)."""
+    E, K, m = _prep(E, "E"), _prep(K, "K"), _prep(matches, "matches")
+    B, N = m.shape[0], m.shape[1]
+    Rt = torch.empty(B, 3, 4, device=m.device, dtype=torch.float32)
+    win = torch.empty(B, device=m.device, dtype=torch.int32)
+    cnt = torch.empty(B, 4, device=m.device, dtype=torch.int32)
+    with torch.cuda.device(m.device):
+        rc = _lib.lib().dfepe_cheirality(_ptr(E), _ptr(K), _ptr(m), B, N, float(depth_thres), _ptr(Rt), _ptr(win), _ptr(cnt), _stream())
+    _lib.check(rc, "dfepe_cheirality")
+    return Rt, win, cnt

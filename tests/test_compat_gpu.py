@@ -1,0 +1,194 @@
+"""The reference-API mirror (pytorch-deepfepe_amd/compat) against golden vectors produced by the reference itself
+and against the CPU oracle.  GPU box only."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+IMAGE_SIZE = [376, 1241, 3]
+DEV = "cuda:0"
+
+
+def T(x, dt=torch.float32):
+    return torch.from_numpy(np.asarray(x)).to(dt)
+
+
+def unit_align(a, ref):
+    a = np.asarray(a, dtype=np.float64).reshape(a.shape[0], -1)
+    r = np.asarray(ref, dtype=np.float64).reshape(ref.shape[0], -1)
+    a = a / np.linalg.norm(a, axis=1, keepdims=True)
+    r = r / np.linalg.norm(r, axis=1, keepdims=True)
+    s = np.sign((a * r).sum(1, keepdims=True))
+    s[s == 0] = 1
+    return a * s, r, s[:, 0]
+
+
+def test_fit_module_matches_reference_golden(dfepe, golden):
+    g = golden("fit")
+    fit = dfepe.compat.DeepFNet.Fit(is_cuda=True, if_cpu_svd=True)
+    for kind in ("general", "outlier40", "dense1000"):
+        out, res = fit(T(g[f"{kind}_f32_pts1"]).to(DEV), T(g[f"{kind}_f32_pts2"]).to(DEV), T(g[f"{kind}_f32_weights"]).to(DEV))
+        assert out.shape == g[f"{kind}_f32_out"].shape and res.shape == g[f"{kind}_f32_residual"].shape
+        a, r, s = unit_align(out.cpu().numpy(), g[f"{kind}_f32_out"])
+        assert np.linalg.norm(a - r, axis=1).max() < 2e-5
+        np.testing.assert_allclose(res.cpu().numpy() * s[:, None], g[f"{kind}_f32_residual"], atol=3e-6, rtol=2e-3)
+    norm = dfepe.compat.DeepFNet.NormalizeAndExpand_HW(IMAGE_SIZE)
+    p1, p2, T1, T2 = norm(T(g["general_f32_matches"]).to(DEV))
+    np.testing.assert_allclose(p1.permute(0, 2, 1).cpu().numpy(), g["general_f32_pts1"], atol=2e-6)
+    np.testing.assert_allclose(T2.cpu().numpy(), g["general_f32_T_hw"], atol=1e-7)
+
+
+def test_deepfnet_full_model_matches_reference_golden(dfepe, golden):
+    """Whole recurrent model with seeded estimators (tests/golden/pipeline.npz 'net_*', depth 3): same state_dict keys,
+    same parameters (checksum), same logits / F / weights per layer, same F-loss and same parameter gradients.
+    The SVD sign gauge of the reference (LAPACK's, arbitrary) is imposed on our fit outputs so that the next
+    estimator layer sees the same `residual` channel the reference saw."""
+    g = golden("pipeline")
+    depth = 3
+    net = dfepe.compat.DeepFNet.DeepFNet(depth=depth, image_size=IMAGE_SIZE, if_quality=False, if_cpu_svd=True)
+    dfepe.synth.fill_params_deterministic(net, seed=5)
+    assert sorted(net.state_dict().keys()) == [str(k) for k in g["net_state_keys"]]
+    chk = np.array([float(p.detach().double().abs().sum()) for _, p in sorted(net.named_parameters())])
+    np.testing.assert_allclose(chk, g["net_param_checksum"], rtol=1e-6)
+    net = net.to(DEV)
+    layer = {"i": 0}
+    orig_fit = net._fit
+
+    def fit_with_reference_gauge(matches, w, want_epi):
+        outs = orig_fit(matches, w, want_epi)
+        ref = torch.from_numpy(g["net_out_layers"][layer["i"]]).to(DEV)
+        s = torch.sign((outs[0].detach() * ref).flatten(1).sum(1))
+        layer["i"] += 1
+        return (outs[0] * s[:, None, None], outs[1] * s[:, None]) + tuple(outs[2:])
+
+    net._fit = fit_with_reference_gauge
+    batch = {"matches_xy_ori": T(g["net_matches_xy_ori"]).to(DEV), "matches_good_unique_nums": None, "t_scene_scale": None}
+    outs = net(batch)
+    assert set(outs.keys()) == {"logits", "logits_layers", "F_est", "epi_res_layers", "T1", "T2", "out_layers", "pts1", "pts2",
+                                "weights", "residual_layers", "weights_layers"}
+    for l in range(depth):
+        a, r, _ = unit_align(outs["out_layers"][l].detach().cpu().numpy(), g["net_out_layers"][l])
+        assert np.linalg.norm(a - r, axis=1).max() < 1e-3, l
+        np.testing.assert_allclose(outs["logits_layers"][l].detach().cpu().numpy(), g["net_logits_layers"][l], atol=2e-2, rtol=2e-2)
+        np.testing.assert_allclose(outs["weights_layers"][l].detach().cpu().numpy(), g["net_weights_layers"][l], atol=2e-4, rtol=3e-2)
+        np.testing.assert_allclose(outs["residual_layers"][l].detach().cpu().numpy(), g["net_residual_layers"][l], atol=2e-5, rtol=2e-2)
+    for l in range(depth - 1):
+        np.testing.assert_allclose(outs["epi_res_layers"][l].detach().cpu().numpy(), g["net_epi_res_layers"][l], atol=2e-3, rtol=2e-2)
+    loss_params = {"depth": depth, "clamp_at": 0.02, "if_tri_depth": False, "if_sample_loss": False, "topK": 8, "matches_good_unique_nums": None}
+    losses, E_ests, F_ests, _, _, _, E_layers = dfepe.compat.train_good_utils.get_all_loss_DeepF(
+        outs, T(g["net_pts1_virt_ori"]).to(DEV), T(g["net_pts2_virt_ori"]).to(DEV), T(g["net_Ks"]).to(DEV), loss_params,
+        get_residual_summaries=False)
+    np.testing.assert_allclose(losses["loss_F"].item(), g["net_loss_F"], rtol=2e-2)
+    losses["loss_F"].backward()
+    gn = {n: float(p.grad.double().norm()) for n, p in net.named_parameters()}
+    ours = np.array([gn[n] for n in sorted(gn)])
+    np.testing.assert_allclose(ours, g["net_grad_norms"], rtol=0.1, atol=1e-4 * g["net_grad_norms"].max())
+    ga = net.input_weights.fw[0].weight.grad.cpu().numpy().ravel()
+    gr = g["net_grad_first_conv"].ravel()
+    assert (ga * gr).sum() / (np.linalg.norm(ga) * np.linalg.norm(gr)) > 0.995
+
+
+def test_loss_functions_match_reference_golden(dfepe, golden):
+    """get_all_loss_DeepF and get_Rt_loss fed with the reference's own per-layer F (golden 'solver_*')."""
+    g = golden("pipeline")
+    pre = "solver_"
+    L = 5
+    B = g[pre + "Ks"].shape[0]
+    Thw = torch.tensor([[2.0 / 1241, 0, -1.0], [0, 2.0 / 376, -1.0], [0, 0, 1.0]]).expand(B, 3, 3).to(DEV)
+    outs = {"weights": T(g[pre + "weights_layers"][-1]).to(DEV), "F_est": T(g[pre + "F_est"]).to(DEV), "T1": Thw, "T2": Thw,
+            "out_layers": [T(x).to(DEV) for x in g[pre + "out_layers"]], "residual_layers": [T(x).to(DEV) for x in g[pre + "residual_layers"]],
+            "weights_layers": [T(x).to(DEV) for x in g[pre + "weights_layers"]], "epi_res_layers": [T(x).to(DEV) for x in g[pre + "epi_res_layers"]]}
+    loss_params = {"depth": L, "clamp_at": 0.02, "if_tri_depth": False, "if_sample_loss": False, "topK": 8,
+                   "matches_good_unique_nums": [100] * B}
+    ret = dfepe.compat.train_good_utils.get_all_loss_DeepF(outs, T(g[pre + "pts1_virt_ori"]).to(DEV), T(g[pre + "pts2_virt_ori"]).to(DEV),
+                                                           T(g[pre + "Ks"]).to(DEV), loss_params, get_residual_summaries=True)
+    assert len(ret) == 7
+    losses, E_ests, F_ests, logits_softmax, rn, rnm, E_layers = ret
+    np.testing.assert_allclose(torch.stack(losses["loss_layers"]).cpu().numpy(), g[pre + "loss_layers"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(losses["loss_F"].item(), g[pre + "loss_F"], rtol=1e-4)
+    np.testing.assert_allclose(losses["loss_min_layers"].cpu().numpy(), g[pre + "loss_min_layers"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(losses["loss_min_batch"].cpu().numpy(), g[pre + "loss_min_batch"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(losses["loss_epi_res"].item(), g[pre + "loss_epi_res"], rtol=1e-4)
+    np.testing.assert_allclose(torch.stack(E_layers).cpu().numpy(), g[pre + "E_layers"], rtol=2e-4, atol=2e-4 * np.abs(g[pre + "E_layers"]).max())
+    np.testing.assert_allclose(E_ests.cpu().numpy(), g[pre + "E_ests"], rtol=2e-4, atol=2e-4 * np.abs(g[pre + "E_ests"]).max())
+    np.testing.assert_allclose(F_ests.cpu().numpy(), g[pre + "F_ests"], rtol=2e-4, atol=2e-4 * np.abs(g[pre + "F_ests"]).max())
+    for k in ("loss_residual", "loss_residual_topK", "loss_regW_clip", "loss_regW_entro", "loss_regW_entro_topK"):
+        assert torch.isfinite(torch.as_tensor(losses[k])).all()
+    rt = dfepe.compat.train_good_utils.get_Rt_loss([T(x).to(DEV) for x in g[pre + "E_layers"]], T(g[pre + "Ks"]), None, None,
+                                                   T(g[pre + "delta_Rtijs_4_4"]), T(g[pre + "qs_cam"]).to(DEV), T(g[pre + "ts_cam"]).to(DEV), device=DEV)
+    assert set(rt.keys()) == {"t_l2_error_mean", "q_l2_error_mean", "t_l2_error_list", "q_l2_error_list", "R_angle_error_mean",
+                              "R_angle_error_list", "t_angle_error_mean", "t_angle_error_list", "R_angle_error_layers_list",
+                              "t_angle_error_layers_list", "t_l2_error_layers_list", "q_l2_error_layers_list"}
+    np.testing.assert_allclose(torch.stack(rt["q_l2_error_layers_list"]).cpu().numpy(), g[pre + "q_l2_layers"], atol=5e-6, rtol=2e-4)
+    np.testing.assert_allclose(torch.stack(rt["t_l2_error_layers_list"]).cpu().numpy(), g[pre + "t_l2_layers"], atol=5e-5, rtol=2e-4)
+    np.testing.assert_allclose(np.stack(rt["t_angle_error_layers_list"]), g[pre + "t_angle_layers"], atol=2e-2, rtol=1e-4)
+    np.testing.assert_allclose(np.stack(rt["R_angle_error_layers_list"]), g[pre + "stubcv2_R_angle_layers"], atol=5e-3, rtol=1e-3)
+    np.testing.assert_allclose(rt["t_l2_error_mean"].item(), g[pre + "t_l2_error_mean"], rtol=2e-4)
+    np.testing.assert_allclose(rt["q_l2_error_mean"].item(), g[pre + "q_l2_error_mean"], rtol=2e-4)
+    np.testing.assert_allclose(rt["q_l2_error_list"].cpu().numpy(), g[pre + "q_l2_error_list"], rtol=2e-4)  # the reference's slip: holds the t means
+    np.testing.assert_allclose(rt["t_l2_error_list"].cpu().numpy(), g[pre + "t_l2_error_list"], rtol=2e-4)
+
+
+def test_dsac_tools_functions_match_reference_golden(dfepe, golden):
+    g = golden("geometry")
+    uF, uG = dfepe.compat.utils_F, dfepe.compat.utils_geo
+    x1, x2, F, K = T(g["x1"]).to(DEV), T(g["x2"]).to(DEV), T(g["F_in"]).to(DEV), T(g["K"]).to(DEV)
+    # golden is the reference in fp64 on fp64 pixels; here the pixels (~1e3) are fp32, so y^T F x carries ~1e-4 px of input rounding
+    np.testing.assert_allclose(uF._sym_epi_dist(F, x1, x2).cpu().numpy(), g["sym_epi_b"], rtol=2e-3, atol=3e-4)
+    np.testing.assert_allclose(uF._sym_epi_dist(F[0], x1[0], x2[0]).cpu().numpy(), g["sym_epi_2d"], rtol=2e-3, atol=3e-4)
+    np.testing.assert_allclose(uF._sampson_dist(F, x1, x2).cpu().numpy(), g["sampson_b"], rtol=2e-3, atol=3e-4)
+    np.testing.assert_allclose(torch.stack(uF._epi_distance(F, x1, x2)).cpu().numpy(), g["epi_dist_b"], rtol=2e-3, atol=3e-3)
+    a, r, _ = unit_align(uF._F_to_E(F[0], K).cpu().numpy()[None], g["F_to_E"][None])
+    assert np.abs(a - r).max() < 1e-4
+    np.testing.assert_allclose(uF._E_to_F(T(g["E_in"]).to(DEV), K.expand(8, 3, 3)).cpu().numpy().shape, (8, 3, 3))
+    for b in range(8):
+        R2s, t2s, M2s = uF._get_M2s(T(g["E_in"][b]).to(DEV))
+        assert len(R2s) == 2 and len(t2s) == 2 and len(M2s) == 4 and M2s[0].shape == (3, 4)
+        d11 = np.abs(R2s[0].cpu().numpy() - g["M2s_R1"][b]).max() + np.abs(R2s[1].cpu().numpy() - g["M2s_R2"][b]).max()
+        d12 = np.abs(R2s[0].cpu().numpy() - g["M2s_R2"][b]).max() + np.abs(R2s[1].cpu().numpy() - g["M2s_R1"][b]).max()
+        assert min(d11, d12) < 2e-5
+        assert min(np.abs(t2s[0].cpu().numpy() - g["M2s_t"][b]).max(), np.abs(t2s[1].cpu().numpy() - g["M2s_t"][b]).max()) < 2e-5
+    q = uG._R_to_q(T(g["Rq_in"]).to(DEV))
+    np.testing.assert_allclose(q.cpu().numpy(), g["Rq_q"], atol=2e-6)  # all four trace-method branches
+    assert uG._R_to_q(T(g["Rq_in"][0]).to(DEV)).shape == (4, 1)
+    for b in range(8):
+        t_cam = np.linalg.inv(g["delta_Rtijs_4_4"][b])[:3, 3]
+        assert abs(uG.vector_angle(g["M2s_t"][b], t_cam) - g["vec_angle"][b]) < 2e-2
+    with pytest.raises(NotImplementedError):
+        uF._F_from_XY(x1[0], x2[0])
+
+
+def test_compute_epi_residual_standalone(dfepe, oracle, golden):
+    g = golden("fit")
+    p1, p2, F = T(g["general_f32_pts1"]).to(DEV), T(g["general_f32_pts2"]).to(DEV), T(g["general_f32_out"]).to(DEV)
+    for c, key in ((0.5, "epi_0p5"), (0.02, "epi_0p02")):
+        np.testing.assert_allclose(dfepe.compat.utils_F.compute_epi_residual(p1, p2, F, c).cpu().numpy(), g[f"general_f32_{key}"], atol=2e-6, rtol=1e-4)
+    Fd = F.clone().requires_grad_(True)
+    G = torch.randn(8, 100, generator=torch.Generator().manual_seed(0)).to(DEV)
+    (dfepe.compat.utils_F.compute_epi_residual(p1, p2, Fd, 0.5) * G).sum().backward()
+    Fo = F.cpu().double().requires_grad_(True)
+    (oracle.compute_epi_residual(p1.cpu().double(), p2.cpu().double(), Fo, 0.5) * G.cpu().double()).sum().backward()
+    assert np.abs(Fd.grad.cpu().numpy() - Fo.grad.numpy()).max() / np.abs(Fo.grad.numpy()).max() < 1e-4
+
+
+@pytest.mark.parametrize("N", [64, 1000])
+def test_cheirality_recovers_generating_pose(dfepe, oracle, N):
+    """OpenCV's triangulation is unpinned (absent here): validate by geometric ground truth and against the oracle's DLT."""
+    B = 12
+    sc = dfepe.synth.make_scene(B, N, seed=17, noise_px=0.3, outlier_ratio=0.1)
+    E = sc["E_gt"] / sc["E_gt"].flatten(1).norm(dim=1)[:, None, None]
+    Rt, win, cnt = dfepe.ops.cheirality(E.to(DEV), sc["Ks"].to(DEV), sc["matches_xy_ori"].to(DEV), 50.0)
+    Rt, win, cnt = Rt.cpu().numpy(), win.cpu().numpy(), cnt.cpu().numpy()
+    cam = np.linalg.inv(sc["delta_Rtijs_4_4"].numpy())
+    for b in range(B):
+        assert win[b] >= 0 and cnt[b].max() == cnt[b, win[b]]
+        assert oracle.rotation_angle_deg(Rt[b, :, :3], cam[b, :3, :3]) < 0.05
+        assert oracle.vector_angle_deg(Rt[b, :, 3], cam[b, :3, 3]) < 0.5
+    for b in range(3):  # counts against the CPU DLT (same algorithm, fp64 SVD of the 4x4)
+        _, _, counts = oracle.cheirality_select(E[b].double(), sc["Ks"][b].numpy(), sc["matches_xy_ori"][b, :, :2].double().numpy(),
+                                                sc["matches_xy_ori"][b, :, 2:].double().numpy(), 50.0)
+        assert sorted(counts) == sorted(cnt[b].tolist()) or np.abs(np.sort(counts) - np.sort(cnt[b])).max() <= max(1, N // 200)
+    # compat wrapper returns the reference's triple
+    _, err, Rt_cam = dfepe.compat.utils_F._E_to_M_train(E[0].to(DEV), sc["Ks"][0].numpy(), sc["matches_xy_ori"][0, :, :2].numpy(),
+                                                        sc["matches_xy_ori"][0, :, 2:].numpy(), delta_Rt_gt_cam=cam[0], show_result=False)
+    assert Rt_cam.shape == (3, 4) and err[0] < 0.05 and err[1] < 0.5
