@@ -81,8 +81,8 @@ def main():
     H, W = float(IMAGE_SIZE[0]), float(IMAGE_SIZE[1])
     hw_T = torch.tensor([[2.0 / W, 0.0, -1.0], [0.0, 2.0 / H, -1.0], [0.0, 0.0, 1.0]], device=dev)
     logits = scene["logits_layers"][:L].clone().requires_grad_(True)
-    loss_vec = torch.zeros(8, device=dev)  # [loss, loss_F, loss_qt, sum R_deg last layer, sum t_deg last layer, count, 0, 0]
-    loss_vec[5] = float(B)
+    M_virt = scene["pts1_virt_ori"].shape[1]
+    loss_vec = torch.zeros(L + 4, device=dev, dtype=torch.float64)  # dist.pack_loss_sums layout: the ONLY data exchanged between ranks
     grad_logits = torch.zeros_like(logits)  # static destination of d loss / d logits (what an optimizer / the estimator's backward would consume)
 
     def step_body():
@@ -91,11 +91,7 @@ def main():
                                               IMAGE_SIZE, clamp_at=0.02, qt=True, hw_T=hw_T)
         g, = torch.autograd.grad(out["loss"], logits)
         grad_logits.copy_(g)
-        loss_vec[0] = out["loss"].detach()
-        loss_vec[1] = out["loss_F"].detach()
-        loss_vec[2] = out["loss_qt"].detach()
-        loss_vec[3] = out["R_deg"][-1].sum()
-        loss_vec[4] = out["t_deg"][-1].sum()
+        loss_vec.copy_(dfepe.dist.pack_loss_sums(out["loss_sum"].detach(), M_virt, out["q_l2"].detach(), out["t_l2"].detach(), 0.1, 0.5))
         return out
 
     # eager warm-up (also sizes the caching allocator), then optional graph capture of the whole step
@@ -121,7 +117,7 @@ def main():
         else:
             step_body()
         if dist is not None:
-            dist.all_reduce(loss_vec)  # the only exchange of the data-parallel path: 32 bytes over xGMI
+            dist.all_reduce(loss_vec)  # the only exchange of the data-parallel path: (L+4) doubles over RCCL/xGMI
 
     def barrier():
         if dist is not None:

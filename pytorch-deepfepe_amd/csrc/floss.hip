@@ -34,9 +34,10 @@ __device__ __forceinline__ Epi epi_terms(const double* x1, const double* x2, con
   return e;
 }
 
+// 3x3 wave-uniform matrix -> scalar registers
 __device__ __forceinline__ void load9(const float* p, double* m) {
 #pragma unroll
-  for (int c = 0; c < 9; ++c) m[c] = (double)p[c];
+  for (int c = 0; c < 9; ++c) m[c] = to_sgpr((double)p[c]);
 }
 
 __device__ __forceinline__ void eval_point(const float* v, const double* T, double* x) {
@@ -46,7 +47,7 @@ __device__ __forceinline__ void eval_point(const float* v, const double* T, doub
 }
 
 template <bool BWD>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 floss_kernel(const float* __restrict__ F_layers, int L, int B, const float* __restrict__ T1, const float* __restrict__ T2,
              int t_stride, const float* __restrict__ K, const float* __restrict__ virt1, const float* __restrict__ virt2,
              int M, float clamp_at, float* __restrict__ loss_sum, float* __restrict__ E_layers,
@@ -59,12 +60,23 @@ floss_kernel(const float* __restrict__ F_layers, int L, int B, const float* __re
   load9(T2 + pair * t_stride, t2);
   const float* v1 = virt1 + pair * M * 3;
   const float* v2 = virt2 + pair * M * 3;
+  // A = T2 K, C = T1 K (E = A^T F C), formed once per pair and parked in scalar registers
+  double Am[9], Cm[9];
+  if (K != nullptr && (BWD ? (g_E != nullptr) : (E_layers != nullptr))) {
+    double k[9], ta[9], tc[9];
+    load9(K + pair * 9, k);
+    mat3_mul(t2, k, ta);
+    mat3_mul(t1, k, tc);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { Am[c] = to_sgpr(ta[c]); Cm[c] = to_sgpr(tc[c]); }
+  }
 
   for (int l = 0; l < L; ++l) {
     double o[9];
     load9(F_layers + ((size_t)l * B + pair) * 9, o);
     if (!BWD) {
       double acc = 0.0;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
       for (int i = lane; i < M; i += WAVE) {
         double x1[3], x2[3];
         eval_point(v1 + 3 * i, t1, x1);
@@ -76,10 +88,12 @@ floss_kernel(const float* __restrict__ F_layers, int L, int B, const float* __re
       if (lane == 0) loss_sum[(size_t)l * B + pair] = (float)acc;
     } else {
       double go[9];
+      float gof[9];  // per-lane partial sums in fp32 (like the reference's backward); combined in fp64
 #pragma unroll
-      for (int c = 0; c < 9; ++c) go[c] = 0.0;
+      for (int c = 0; c < 9; ++c) { go[c] = 0.0; gof[c] = 0.0f; }
       const double gl = (g_loss_sum != nullptr) ? (double)g_loss_sum[(size_t)l * B + pair] : 0.0;
       if (g_loss_sum != nullptr) {
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
         for (int i = lane; i < M; i += WAVE) {
           double x1[3], x2[3];
           eval_point(v1 + 3 * i, t1, x1);
@@ -97,22 +111,19 @@ floss_kernel(const float* __restrict__ F_layers, int L, int B, const float* __re
                 double t = sg * S * x2[r] * x1[c];
                 if (c < 2) t -= k1 * e.l1[c] * x2[r];
                 if (r < 2) t -= k2 * e.l2[r] * x1[c];
-                go[3 * r + c] += t;
+                gof[3 * r + c] += (float)t;
               }
           }
         }
 #pragma unroll
-        for (int c = 0; c < 9; ++c) go[c] = gl * wave_sum(go[c]);
+        for (int c = 0; c < 9; ++c) go[c] = gl * (double)wave_sum(gof[c]);
       }
       if (g_E != nullptr) {
         // E = (T2 K)^T F (T1 K)  ->  g_F += (T2 K) g_E (T1 K)^T
-        double k[9], a[9], cmat[9], ge[9], tmp[9], add[9];
-        load9(K + pair * 9, k);
+        double ge[9], tmp[9], add[9];
         load9(g_E + ((size_t)l * B + pair) * 9, ge);
-        mat3_mul(t2, k, a);
-        mat3_mul(t1, k, cmat);
-        mat3_mul(a, ge, tmp);
-        mat3_mul_nt(tmp, cmat, add);
+        mat3_mul(Am, ge, tmp);
+        mat3_mul_nt(tmp, Cm, add);
 #pragma unroll
         for (int c = 0; c < 9; ++c) go[c] += add[c];
       }
@@ -123,13 +134,11 @@ floss_kernel(const float* __restrict__ F_layers, int L, int B, const float* __re
     }
   }
   if (!BWD && E_layers != nullptr && lane < L) {
-    double o[9], k[9], a[9], cmat[9], tmp[9], e[9];
-    load9(F_layers + ((size_t)lane * B + pair) * 9, o);
-    load9(K + pair * 9, k);
-    mat3_mul(t2, k, a);
-    mat3_mul(t1, k, cmat);
-    mat3_mul_tn(a, o, tmp);
-    mat3_mul(tmp, cmat, e);
+    double o[9], tmp[9], e[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) o[c] = (double)F_layers[((size_t)lane * B + pair) * 9 + c];  // per-lane layer: not uniform
+    mat3_mul_tn(Am, o, tmp);
+    mat3_mul(tmp, Cm, e);
 #pragma unroll
     for (int c = 0; c < 9; ++c) E_layers[((size_t)lane * B + pair) * 9 + c] = (float)e[c];
   }

@@ -21,6 +21,7 @@ epi_residual_kernel(const float* __restrict__ pts1, const float* __restrict__ pt
   double go[9];
 #pragma unroll
   for (int c = 0; c < 9; ++c) go[c] = 0.0;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
   for (int i = lane; i < N; i += WAVE) {
     const Pt p = global_point<false>(pts1, pts2, pair, i, N, 0.f, 0.f);
     if (!BWD) {

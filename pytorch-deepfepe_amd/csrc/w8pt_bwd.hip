@@ -21,7 +21,7 @@ __device__ __forceinline__ double guard_den(double d) {
 }
 
 template <bool RAW>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, const float* __restrict__ wts, int B,
                 int N, float hw_sx, float hw_sy, float clamp_at, const float* __restrict__ save,
                 const float* __restrict__ F_out, const float* __restrict__ g_F, const float* __restrict__ g_res,
@@ -31,24 +31,27 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   if (pair >= (size_t)B) return;
 
   const float* sv = save + pair * DFEPE_SAVE_FLOATS;
-  const double s1 = sv[SV_T1], c1x = sv[SV_T1 + 1], c1y = sv[SV_T1 + 2];
-  const double s2 = sv[SV_T2], c2x = sv[SV_T2 + 1], c2y = sv[SV_T2 + 2];
+  // wave-uniform values are parked in scalar registers (to_sgpr) to keep the VGPR budget at 4 waves/SIMD
+  const double s1 = to_sgpr((double)sv[SV_T1]), c1x = to_sgpr((double)sv[SV_T1 + 1]), c1y = to_sgpr((double)sv[SV_T1 + 2]);
+  const double s2 = to_sgpr((double)sv[SV_T2]), c2x = to_sgpr((double)sv[SV_T2 + 1]), c2y = to_sgpr((double)sv[SV_T2 + 2]);
   const int ksel = (int)sv[SV_KMIN];
   const double sgn = sv[SV_SIGN];
   double f[9];
 #pragma unroll
-  for (int c = 0; c < 9; ++c) f[c] = sgn * (double)sv[SV_Q + ksel * 9 + c];
+  for (int c = 0; c < 9; ++c) f[c] = to_sgpr(sgn * (double)sv[SV_Q + ksel * 9 + c]);
 
   // ---- pass A: X^T g_r  and  sum_i g_epi_i d(d_i)/d(out) ---------------------------------------------
-  double gx[9], go[9];
+  // partial sums in fp32 (the reference's whole backward is fp32); everything uniform downstream is fp64
+  float gxf[9], gof[9];
 #pragma unroll
-  for (int c = 0; c < 9; ++c) { gx[c] = 0.0; go[c] = 0.0; }
+  for (int c = 0; c < 9; ++c) { gxf[c] = 0.0f; gof[c] = 0.0f; }
   double o[9];
   if (g_epi != nullptr) {
 #pragma unroll
-    for (int c = 0; c < 9; ++c) o[c] = (double)F_out[pair * 9 + c];
+    for (int c = 0; c < 9; ++c) o[c] = to_sgpr((double)F_out[pair * 9 + c]);
   }
   const float* wsrc = wts + pair * N;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
   for (int i = lane; i < N; i += WAVE) {
     const Pt p = global_point<RAW>(pts1, pts2, pair, i, N, hw_sx, hw_sy);
     if (g_res != nullptr) {
@@ -57,7 +60,7 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
       const bool ok = unit_row(p, s1, c1x, c1y, s2, c2x, c2y, ph) && (fabs(w) < 1e150);
       const double gw = ok ? (double)g_res[pair * N + i] * w : 0.0;
 #pragma unroll
-      for (int c = 0; c < 9; ++c) gx[c] += gw * ph[c];
+      for (int c = 0; c < 9; ++c) gxf[c] += (float)(gw * ph[c]);
     }
     if (g_epi != nullptr) {
       const double x1[3] = {p.x1, p.y1, p.z1}, x2[3] = {p.x2, p.y2, p.z2};
@@ -82,14 +85,15 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
           double t = sg * S * x2[r] * x1[c];
           if (c < 2) t -= k1 * l1[c] * x2[r];
           if (r < 2) t -= k2 * l2[r] * x1[c];
-          go[3 * r + c] += g * t;
+          gof[3 * r + c] += (float)(g * t);
         }
     }
   }
+  double gx[9], go[9];
 #pragma unroll
   for (int c = 0; c < 9; ++c) {
-    gx[c] = (g_res != nullptr) ? wave_sum(gx[c]) : 0.0;
-    go[c] = (g_epi != nullptr) ? wave_sum(go[c]) : 0.0;
+    gx[c] = (g_res != nullptr) ? (double)wave_sum(gxf[c]) : 0.0;
+    go[c] = (g_epi != nullptr) ? (double)wave_sum(gof[c]) : 0.0;
   }
   if (g_F != nullptr) {
 #pragma unroll
@@ -147,8 +151,12 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     for (int c = 0; c < 9; ++c) u[c] += ck * (double)sv[SV_Q + k * 9 + c];
   }
 
+#pragma unroll
+  for (int c = 0; c < 9; ++c) u[c] = to_sgpr(u[c]);
+
   // ---- pass B: g_w --------------------------------------------------------------------------------------
   float* dst = g_w + pair * N;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
   for (int i = lane; i < N; i += WAVE) {
     const Pt p = global_point<RAW>(pts1, pts2, pair, i, N, hw_sx, hw_sy);
     double ph[9];

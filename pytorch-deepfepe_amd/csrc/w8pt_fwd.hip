@@ -54,13 +54,6 @@ __device__ __forceinline__ Pt lds_point(const float* P, int i, int npad) {
   return p;
 }
 
-__device__ __forceinline__ double pick9(const double* v, int c) {  // v[c] for a register array (no scratch)
-  double r = v[0];
-#pragma unroll
-  for (int k = 1; k < 9; ++k) r = (c == k) ? v[k] : r;
-  return r;
-}
-
 // One halving step of the reduce-scatter: CNT live values per lane -> (CNT+1)/2.
 template <int CNT>
 __device__ __forceinline__ void halve(double* a, bool upper, int mask) {
@@ -101,7 +94,8 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   const float* wsrc = wts + (size_t)pair * N;
   if (RAW) {
     const float4* src = reinterpret_cast<const float4*>(pts1) + (size_t)pair * N;
-    for (int i = lane; i < N; i += WAVE) {
+  #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+  for (int i = lane; i < N; i += WAVE) {
       float4 m = src[i];
       m.x = fmaf(m.x, hw_sx, -1.0f);
       m.y = fmaf(m.y, hw_sy, -1.0f);
@@ -120,7 +114,8 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     }
     for (int i = lane; i < N; i += WAVE) W[i] = wsrc[i];
     wave_sync();
-    for (int i = lane; i < N; i += WAVE) {
+  #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+  for (int i = lane; i < N; i += WAVE) {
       const Pt p = lds_point<false>(P, i, npad);
       sx1 += p.x1; sy1 += p.y1; sx2 += p.x2; sy2 += p.y2;
     }
@@ -132,6 +127,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 
   // ---- phase 1: Hartley scale -------------------------------------------------------------------
   double d1 = 0, d2 = 0;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
   for (int i = lane; i < N; i += WAVE) {
     const Pt p = lds_point<RAW>(P, i, npad);
     const double ax = (double)p.x1 - c1x, ay = (double)p.y1 - c1y;
@@ -146,6 +142,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   double acc[36];
 #pragma unroll
   for (int e = 0; e < 36; ++e) acc[e] = 0.0;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
   for (int i = lane; i < N; i += WAVE) {
     const Pt p = lds_point<RAW>(P, i, npad);
     const double w = (double)W[i];
@@ -393,13 +390,20 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   }
   if (save != nullptr) {
     float* sv = save + (size_t)pair * DFEPE_SAVE_FLOATS;
+    // the polished, oriented f replaces its Jacobi column in the record; staged through LDS so that no register
+    // array is indexed dynamically (that would push it to scratch)
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) SCR[c] = sgn * f[c];
+    }
+    wave_sync();
     {
       const int k = lane / 9, c = lane % 9;
-      sv[SV_Q + lane] = (k == kmin) ? (float)(sgn * pick9(f, c)) : V32[c * 9 + k];  // the polished vector replaces its Jacobi column
+      sv[SV_Q + lane] = (k == kmin) ? (float)SCR[c] : V32[c * 9 + k];
     }
     if (lane < 17) {
       const int e = lane + 64, k = e / 9, c = e % 9;
-      sv[SV_Q + e] = (k == kmin) ? (float)(sgn * pick9(f, c)) : V32[c * 9 + k];
+      sv[SV_Q + e] = (k == kmin) ? (float)SCR[c] : V32[c * 9 + k];
     }
     if (lane < 9) sv[SV_LAM + lane] = (lane == kmin) ? (float)rho : (float)((double)A32[lane * 10] * tr);
     if (lane == 0) {
@@ -418,6 +422,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   // ---- phase 6: per-correspondence outputs ----------------------------------------------------------
   float* rdst = residual + (size_t)pair * N;
   float* edst = (epi_res != nullptr) ? epi_res + (size_t)pair * N : nullptr;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
   for (int i = lane; i < N; i += WAVE) {
     const Pt p = lds_point<RAW>(P, i, npad);
     double ph[9];

@@ -1,0 +1,66 @@
+"""Data-parallel host logic: one process per GPU, the batch of pairs is split into contiguous shards, every pair is
+solved locally (no data-path collective: all reductions of the hot path are over correspondences *inside* a pair),
+and one small all-reduce (RCCL over xGMI; gloo in the CPU tests) turns the per-rank loss sums into global means.
+
+The reference has no distributed path (only nn.DataParallel, deepFEPE/train_good.py:311-312); this replaces it with
+the `torch.distributed` equivalent for the loss bookkeeping of get_all_loss_DeepF (train_good_utils.py:340-364) and of
+the qt loss mixing (Train_model_pipeline.py:580-586).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+Tensor = torch.Tensor
+
+
+def shard_range(B: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [start, stop) of rank's pairs; the first B % world ranks get one extra pair."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    base, rem = divmod(B, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+_PER_LAYER_KEYS = ("logits_layers",)
+
+
+def shard_scene(scene: Dict[str, Tensor], rank: int, world: int) -> Dict[str, Tensor]:
+    """Slice every per-pair tensor of a synth.make_scene() batch ([B,...], or [L,B,...] for the per-layer logits)."""
+    B = scene["matches_xy_ori"].shape[0]
+    a, b = shard_range(B, rank, world)
+    out = {}
+    for k, v in scene.items():
+        out[k] = (v[:, a:b] if k in _PER_LAYER_KEYS else v[a:b]).contiguous()
+    return out
+
+
+def pack_loss_sums(loss_sum: Tensor, M: int, q_l2: Optional[Tensor] = None, t_l2: Optional[Tensor] = None,
+                   clamp_q: float = 0.1, clamp_t: float = 0.5) -> Tensor:
+    """Local sums that make the global means: [sum_b loss_sum[l,b] for l] + [sum clamp(q), sum clamp(t), n_pairs, M]."""
+    L, B = loss_sum.shape
+    parts = [loss_sum.double().sum(dim=1)]
+    zero = loss_sum.new_zeros(1, dtype=torch.float64)
+    parts.append(torch.clamp(q_l2, 0.0, clamp_q).double().sum().reshape(1) if q_l2 is not None else zero)
+    parts.append(torch.clamp(t_l2, 0.0, clamp_t).double().sum().reshape(1) if t_l2 is not None else zero)
+    # torch.full (a fill kernel) rather than torch.tensor (a host copy) so that this is hipGraph-capturable
+    parts.append(torch.full((1,), float(B), dtype=torch.float64, device=loss_sum.device))
+    parts.append(torch.full((1,), float(M), dtype=torch.float64, device=loss_sum.device))
+    return torch.cat(parts)
+
+
+def reduce_losses(packed: Tensor, L: int, balance_q: float = 1.0, balance_t: float = 0.1, group=None) -> Dict[str, Tensor]:
+    """All-reduce(SUM) the packed vector (L+4 doubles: latency-bound, any algorithm) and derive the global-batch
+    quantities: per-layer F-loss means, loss_F, and the clamped qt loss."""
+    world_M = packed[L + 3].clone()  # M is identical on every rank; keep it out of the sum
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    n = packed[L + 2]
+    loss_layers = packed[:L] / (n * world_M)
+    loss_q = packed[L] / (n * L)
+    loss_t = packed[L + 1] / (n * L)
+    return {"loss_layers": loss_layers, "loss_F": loss_layers.mean(), "loss_q": loss_q, "loss_t": loss_t,
+            "loss_qt": loss_q * balance_q + loss_t * balance_t, "n_pairs": n}

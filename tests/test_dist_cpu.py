@@ -1,0 +1,96 @@
+"""Multi-process (gloo, world_size 2) check of the data-parallel host logic: shards partition the batch, and the
+all-reduced loss sums reproduce the single-process global means.  The per-pair arithmetic on each rank is done by
+the CPU oracle here (there is no GPU in this container); the thing under test is pytorch-deepfepe_amd/dist.py."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+IMAGE_SIZE = [376, 1241, 3]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _local_sums(dfepe, oracle, scene, depth, M):
+    outs = oracle.deepf_forward(scene["matches_xy_ori"], IMAGE_SIZE, depth, logits_layers=scene["logits_layers"][:depth])
+    losses, _, _, E_layers = oracle.f_loss(outs, scene["pts1_virt_ori"], scene["pts2_virt_ori"], scene["Ks"], depth, 0.02)
+    pose = oracle.rt_loss(E_layers, scene["delta_Rtijs_4_4"], scene["qs_cam"], scene["ts_cam"])
+    loss_sum = losses["loss_per_pair"].detach() * M
+    return loss_sum, pose["q_l2"].detach(), pose["t_l2"].detach()
+
+
+def _worker(rank, world, port, B, N, depth, q):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dfepe = importlib.import_module("pytorch-deepfepe_amd")
+    oracle = importlib.import_module("oracle.deepf_oracle")
+    full = dfepe.synth.make_scene(B, N, seed=77, outlier_ratio=0.2, depth_layers=depth, dtype=torch.float64)
+    mine = dfepe.dist.shard_scene(full, rank, world)
+    a, b = dfepe.dist.shard_range(B, rank, world)
+    assert mine["matches_xy_ori"].shape[0] == b - a and mine["logits_layers"].shape[1] == b - a
+    M = full["pts1_virt_ori"].shape[1]
+    loss_sum, q_l2, t_l2 = _local_sums(dfepe, oracle, mine, depth, M)
+    packed = dfepe.dist.pack_loss_sums(loss_sum, M, q_l2, t_l2, 0.1, 0.5)
+    red = dfepe.dist.reduce_losses(packed, depth, 1.0, 0.1)
+    if rank == 0:
+        q.put({k: v.numpy() for k, v in red.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions_every_batch():
+    sys.path.insert(0, REPO)
+    d = importlib.import_module("pytorch-deepfepe_amd")
+    for B in (0, 1, 7, 8, 4096, 32768, 10):
+        for world in (1, 2, 3, 8):
+            covered = []
+            for r in range(world):
+                a, b = d.dist.shard_range(B, r, world)
+                assert 0 <= a <= b <= B
+                covered += list(range(a, b))
+            assert covered == list(range(B))
+            sizes = [d.dist.shard_range(B, r, world)[1] - d.dist.shard_range(B, r, world)[0] for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        d.dist.shard_range(8, 2, 2)
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_loss_reduction_matches_single_process():
+    sys.path.insert(0, REPO)
+    dfepe = importlib.import_module("pytorch-deepfepe_amd")
+    oracle = importlib.import_module("oracle.deepf_oracle")
+    B, N, depth, world = 7, 40, 3, 2  # odd batch: uneven shards
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, N, depth, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full = dfepe.synth.make_scene(B, N, seed=77, outlier_ratio=0.2, depth_layers=depth, dtype=torch.float64)
+    ref = oracle.hot_path_step(full, IMAGE_SIZE, depth, 0.02, qt=True, mode="batched", backward=False)
+    np.testing.assert_allclose(got["loss_layers"], torch.stack(ref["losses"]["loss_layers"]).numpy(), rtol=1e-10)
+    np.testing.assert_allclose(got["loss_F"], ref["losses"]["loss_F"].numpy(), rtol=1e-10)
+    lqt = oracle.qt_training_loss(ref["pose"]["q_l2"], ref["pose"]["t_l2"], 0.1, 0.5, 1.0, 0.1)
+    np.testing.assert_allclose(got["loss_qt"], lqt.numpy(), rtol=1e-10)
+    assert got["n_pairs"] == B
