@@ -86,12 +86,12 @@ def main():
     grad_logits = torch.zeros_like(logits)  # static destination of d loss / d logits (what an optimizer / the estimator's backward would consume)
 
     def step_body():
-        out = dfepe.pipeline.hot_path_forward(scene["matches_xy_ori"], logits, scene["Ks"], scene["pts1_virt_ori"],
+        out = dfepe.pipeline.hot_path_fused(scene["matches_xy_ori"], logits, scene["Ks"], scene["pts1_virt_ori"],
                                               scene["pts2_virt_ori"], scene["qs_cam"], scene["ts_cam"], scene["R_gt"],
                                               IMAGE_SIZE, clamp_at=0.02, qt=True, hw_T=hw_T)
         g, = torch.autograd.grad(out["loss"], logits)
         grad_logits.copy_(g)
-        loss_vec.copy_(dfepe.dist.pack_loss_sums(out["loss_sum"].detach(), M_virt, out["q_l2"].detach(), out["t_l2"].detach(), 0.1, 0.5))
+        loss_vec.copy_(out["packed"])  # dfepe_loss_head already produced the pack_loss_sums layout
         return out
 
     # eager warm-up (also sizes the caching allocator), then optional graph capture of the whole step

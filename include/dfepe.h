@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DFEPE_VERSION 100 /* 0.1.0 */
+#define DFEPE_VERSION 110 /* 0.1.1 */
 
 #define DFEPE_OK 0
 #define DFEPE_ERR_INVALID_ARG (-1) /* null pointer, non-positive size, bad flag combination   */
@@ -37,6 +37,9 @@ extern "C" {
 /* flags for dfepe_w8pt_fwd / dfepe_w8pt_bwd */
 #define DFEPE_W8PT_RAW_MATCHES 1u /* `pts1` is matches_xy_ori [B,N,4] in pixels, `pts2` unused (may be NULL);
                                      the image-size normalisation of NormalizeAndExpand_HW is fused in   */
+#define DFEPE_W8PT_LOGITS 2u      /* `weights` holds logits [B,N]; softmax over N (F.softmax(logits, dim=2),
+                                     DeepFNet.py:443,512) is fused in and the weights are written to `weights_out`;
+                                     the backward then returns the gradient w.r.t. the logits                */
 
 int dfepe_version(void);
 const char *dfepe_strerror(int code);
@@ -56,25 +59,29 @@ int dfepe_save_floats(void);
  *   residual   [B,N]    X f/|f|                             (reference `residual`)
  *   epi_res    [B,N]    or NULL
  *   save       [B,DFEPE_SAVE_FLOATS] or NULL (needed for backward)
+ *   weights_out[B,N]    softmax(logits) when DFEPE_W8PT_LOGITS (may be NULL), ignored otherwise
  * Sign gauge: the reference inherits LAPACK's arbitrary sign of f; here f is oriented so that its
  * largest-magnitude component is positive (F_out and residual flip together, everything downstream is
  * sign-invariant).
  */
 int dfepe_w8pt_fwd(const float *pts1, const float *pts2, const float *weights, int B, int N,
                    unsigned flags, float image_w, float image_h, float clamp_at,
-                   float *F_out, float *residual, float *epi_res, float *save, void *stream);
+                   float *F_out, float *residual, float *epi_res, float *save, float *weights_out, void *stream);
 
 /*
  * Backward of dfepe_w8pt_fwd w.r.t. the weights (analytic eigenvector / rank-2 / epipolar-residual
  * adjoints; replaces torch.autograd through the per-sample torch.svd calls, DeepFNet.py:232-256).
  *   g_F [B,9], g_residual [B,N], g_epi [B,N]: upstream gradients, each may be NULL (= zero)
  *   F_out: the forward output (needed when g_epi != NULL)
+ *   g_weights_extra [B,N] or NULL: with DFEPE_W8PT_LOGITS, an upstream gradient on the `weights_out` tensor itself
+ *     (the next estimator layer reads the weights, DeepFNet.py:487); added before the softmax adjoint
+ *   with DFEPE_W8PT_LOGITS `weights` must be the forward's `weights_out` and g_weights receives d/d(logits)
  *   g_weights [B,N]: written (not accumulated)
  */
 int dfepe_w8pt_bwd(const float *pts1, const float *pts2, const float *weights, int B, int N,
                    unsigned flags, float image_w, float image_h, float clamp_at,
                    const float *save, const float *F_out,
-                   const float *g_F, const float *g_residual, const float *g_epi,
+                   const float *g_F, const float *g_residual, const float *g_epi, const float *g_weights_extra,
                    float *g_weights, void *stream);
 
 /*
@@ -91,10 +98,13 @@ int dfepe_floss_fwd(const float *F_layers, int L, int B, const float *T1, const 
                     const float *K, const float *virt1, const float *virt2, int M, float clamp_at,
                     float *loss_sum, float *E_layers, void *stream);
 
-/*  g_loss_sum [L,B] or NULL, g_E [L,B,9] or NULL  ->  g_F_layers [L,B,9] (written) */
+/*  g_loss_sum [L,B] or NULL, g_E [L,B,9] or NULL  ->  g_F_layers [L,B,9] (written).
+ *  When g_loss_sum is NULL and g_loss_coef != 0 every entry of g_loss_sum is taken to be g_loss_coef * (*g_scale)
+ *  (g_scale: device pointer to one float, NULL = 1): the adjoint of a plain mean over layers, pairs and points. */
 int dfepe_floss_bwd(const float *F_layers, int L, int B, const float *T1, const float *T2, int t_stride,
                     const float *K, const float *virt1, const float *virt2, int M, float clamp_at,
-                    const float *g_loss_sum, const float *g_E, float *g_F_layers, void *stream);
+                    const float *g_loss_sum, float g_loss_coef, const float *g_scale, const float *g_E,
+                    float *g_F_layers, void *stream);
 
 /*
  * Pose loss: decompose E^T into the two rotations / two translations, compare with the ground truth.
@@ -107,9 +117,25 @@ int dfepe_floss_bwd(const float *F_layers, int L, int B, const float *T1, const 
 int dfepe_pose_fwd(const float *E_layers, int L, int B, const float *q_gt, const float *t_gt, const float *R_gt,
                    float *q_l2, float *t_l2, float *R_deg, float *t_deg, int *sel, void *stream);
 
-/*  g_q_l2, g_t_l2 [L,B] (either may be NULL) -> g_E [L,B,9] (written) */
+/*  g_q_l2, g_t_l2 [L,B] (either may be NULL) -> g_E [L,B,9] (written).
+ *  When a gradient pointer is NULL and its coefficient is non-zero, the upstream gradient of that error is
+ *  coef * (*g_scale) where the error is <= its clamp and 0 above it: the adjoint of
+ *  clamp(stack(err), 0, clamp).mean() * balance  (deepFEPE/Train_model_pipeline.py:580-586) with coef = balance/(L*B). */
 int dfepe_pose_bwd(const float *E_layers, int L, int B, const float *q_gt, const float *t_gt,
-                   const float *g_q_l2, const float *g_t_l2, float *g_E, void *stream);
+                   const float *g_q_l2, const float *g_t_l2, float coef_q, float clamp_q, float coef_t, float clamp_t,
+                   const float *g_scale, float *g_E, void *stream);
+
+/*
+ * Loss head: reduce the per-pair sums to the scalars the training step uses.
+ * Replaces: losses.mean() per layer / loss_F (train_good_utils.py:340-364) and the clamped qt mix
+ * (Train_model_pipeline.py:580-586), plus the packed sums a data-parallel all-reduce needs.
+ *   loss_sum [L,B] (sum over the M virtual points), q_l2, t_l2 [L,B] (may be NULL: no pose loss)
+ *   packed   [L+4] doubles: sum_b loss_sum[l,b] (L), sum clamp(q), sum clamp(t), B, M
+ *   scalars  [4] floats: loss = loss_F + loss_qt, loss_F, loss_qt, 0   (local-batch means)
+ */
+int dfepe_loss_head(const float *loss_sum, const float *q_l2, const float *t_l2, int L, int B, int M,
+                    float clamp_q, float clamp_t, float balance_q, float balance_t,
+                    double *packed, float *scalars, void *stream);
 
 /*
  * Cheirality-checked pose from E.

@@ -14,18 +14,20 @@ LIB_PATH = os.path.join(_HERE, "libdfepe_hip.so")
 
 OK = 0
 W8PT_RAW_MATCHES = 1
+W8PT_LOGITS = 2
 
 _P = c_void_p
 _SIGNATURES = {
     "dfepe_version": (c_int, []),
     "dfepe_strerror": (c_char_p, [c_int]),
     "dfepe_save_floats": (c_int, []),
-    "dfepe_w8pt_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_uint, c_float, c_float, c_float, _P, _P, _P, _P, _P]),
-    "dfepe_w8pt_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_uint, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "dfepe_w8pt_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_uint, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P]),
+    "dfepe_w8pt_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_uint, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dfepe_floss_fwd": (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, c_float, _P, _P, _P]),
-    "dfepe_floss_bwd": (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, c_float, _P, _P, _P, _P]),
+    "dfepe_floss_bwd": (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, c_float, _P, c_float, _P, _P, _P, _P]),
     "dfepe_pose_fwd": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "dfepe_pose_bwd": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "dfepe_pose_bwd": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, c_float, c_float, c_float, c_float, _P, _P, _P]),
+    "dfepe_loss_head": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, _P, _P, _P]),
     "dfepe_cheirality": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P, _P]),
     "dfepe_epi_metrics": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_float, c_float, _P, _P]),
     "dfepe_epi_residual_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P]),

@@ -96,35 +96,38 @@ class DeepFNet(nn.Module):
         weight_in = torch.cat(parts, 2).permute(0, 2, 1)
         return weight_in, pts1, pts2, T1, T2
 
-    def _fit(self, matches, weights_prod, want_epi):
+    def _fit(self, matches, logits, data_batch, want_epi):
+        """logits [B,1,N] -> (out, residual[, epi], weights_prod [B,1,N]).  The softmax over N is fused into the solver
+        kernel unless per-correspondence image weights multiply it afterwards (if_img_w)."""
         H, W = float(self.image_size[0]), float(self.image_size[1])
-        return ops.w8pt_raw(matches, weights_prod, W, H, clamp_at=0.5, want_epi=want_epi)
+        if self.if_img_w:
+            weights_prod = F.softmax(logits, dim=2) * data_batch["weights_im"]
+            return ops.w8pt_raw(matches, weights_prod, W, H, clamp_at=0.5, want_epi=want_epi) + (weights_prod,)
+        outs = ops.w8pt_raw_logits(matches, logits, W, H, clamp_at=0.5, want_epi=want_epi)
+        return outs[:-1] + (outs[-1].unsqueeze(1),)
 
     def forward(self, data_batch):
         matches = data_batch["matches_xy_ori"]
         _require_gpu(matches, "DeepFNet")
         pts_normalized_in, pts1, pts2, T1, T2 = self.get_input(data_batch)
         logits = self.input_weights(pts_normalized_in)
-        weights_pts = F.softmax(logits, dim=2)
-        weights_prod = weights_pts * data_batch["weights_im"] if self.if_img_w else weights_pts
         _ = data_batch["matches_good_unique_nums"]  # read like the reference does (DeepFNet.py:449,453)
         _ = data_batch["t_scene_scale"]
 
         out_layers, epi_res_layers, residual_layers = [], [], []
-        weights_layers, logits_layers = [weights_prod], [logits]
+        weights_layers, logits_layers = [], [logits]
         for it in range(self.depth - 1):
-            out, residual, epi = self._fit(matches, weights_prod, True)
+            out, residual, epi, weights_prod = self._fit(matches, logits, data_batch, True)
+            weights_layers.append(weights_prod)
             out_layers.append(out)
             residual_layers.append(residual)
             epi_res = epi.unsqueeze(1)
             epi_res_layers.append(epi_res)
             net_in = torch.cat((pts_normalized_in, weights_prod, epi_res, residual.unsqueeze(1)), 1)
             logits = self.update_weights(net_in)
-            weights_pts = F.softmax(logits, dim=2)
-            weights_prod = weights_pts * data_batch["weights_im"] if self.if_img_w else weights_pts
-            weights_layers.append(weights_prod)
             logits_layers.append(logits)
-        out, residual = self._fit(matches, weights_prod, False)
+        out, residual, weights_prod = self._fit(matches, logits, data_batch, False)
+        weights_layers.append(weights_prod)
         residual_layers.append(residual)
         out_layers.append(out)
         return {

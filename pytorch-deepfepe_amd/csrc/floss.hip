@@ -51,7 +51,8 @@ __global__ void __launch_bounds__(256, 4)
 floss_kernel(const float* __restrict__ F_layers, int L, int B, const float* __restrict__ T1, const float* __restrict__ T2,
              int t_stride, const float* __restrict__ K, const float* __restrict__ virt1, const float* __restrict__ virt2,
              int M, float clamp_at, float* __restrict__ loss_sum, float* __restrict__ E_layers,
-             const float* __restrict__ g_loss_sum, const float* __restrict__ g_E, float* __restrict__ g_F_layers) {
+             const float* __restrict__ g_loss_sum, float g_loss_coef, const float* __restrict__ g_scale,
+             const float* __restrict__ g_E, float* __restrict__ g_F_layers) {
   const int lane = threadIdx.x & 63;
   const size_t pair = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (pair >= (size_t)B) return;
@@ -91,8 +92,10 @@ floss_kernel(const float* __restrict__ F_layers, int L, int B, const float* __re
       float gof[9];  // per-lane partial sums in fp32 (like the reference's backward); combined in fp64
 #pragma unroll
       for (int c = 0; c < 9; ++c) { go[c] = 0.0; gof[c] = 0.0f; }
-      const double gl = (g_loss_sum != nullptr) ? (double)g_loss_sum[(size_t)l * B + pair] : 0.0;
-      if (g_loss_sum != nullptr) {
+      const bool has_gl = (g_loss_sum != nullptr) || (g_loss_coef != 0.0f);
+      const double gl = (g_loss_sum != nullptr) ? (double)g_loss_sum[(size_t)l * B + pair]
+                                                : (double)g_loss_coef * ((g_scale != nullptr) ? (double)g_scale[0] : 1.0);
+      if (has_gl) {
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
         for (int i = lane; i < M; i += WAVE) {
           double x1[3], x2[3];
@@ -163,19 +166,20 @@ extern "C" int dfepe_floss_fwd(const float* F_layers, int L, int B, const float*
   if (!loss_sum) return DFEPE_ERR_INVALID_ARG;
   const dim3 grid((B + 3) / 4), block(256);
   hipLaunchKernelGGL(floss_kernel<false>, grid, block, 0, static_cast<hipStream_t>(stream), F_layers, L, B, T1, T2,
-                     t_stride, K, virt1, virt2, M, clamp_at, loss_sum, E_layers, nullptr, nullptr, nullptr);
+                     t_stride, K, virt1, virt2, M, clamp_at, loss_sum, E_layers, nullptr, 0.0f, nullptr, nullptr, nullptr);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
 extern "C" int dfepe_floss_bwd(const float* F_layers, int L, int B, const float* T1, const float* T2, int t_stride,
                                const float* K, const float* virt1, const float* virt2, int M, float clamp_at,
-                               const float* g_loss_sum, const float* g_E, float* g_F_layers, void* stream) {
+                               const float* g_loss_sum, float g_loss_coef, const float* g_scale, const float* g_E,
+                               float* g_F_layers, void* stream) {
   const int rc = check_common(F_layers, L, B, T1, T2, t_stride, K, virt1, virt2, M);
   if (rc != DFEPE_OK) return rc;
   if (B == 0) return DFEPE_OK;
   if (!g_F_layers) return DFEPE_ERR_INVALID_ARG;
   const dim3 grid((B + 3) / 4), block(256);
   hipLaunchKernelGGL(floss_kernel<true>, grid, block, 0, static_cast<hipStream_t>(stream), F_layers, L, B, T1, T2,
-                     t_stride, K, virt1, virt2, M, clamp_at, nullptr, nullptr, g_loss_sum, g_E, g_F_layers);
+                     t_stride, K, virt1, virt2, M, clamp_at, nullptr, nullptr, g_loss_sum, g_loss_coef, g_scale, g_E, g_F_layers);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }

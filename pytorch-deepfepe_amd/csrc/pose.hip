@@ -184,14 +184,17 @@ pose_fwd_kernel(const float* __restrict__ E_layers, int L, int B, const float* _
 __global__ void __launch_bounds__(256)
 pose_bwd_kernel(const float* __restrict__ E_layers, int L, int B, const float* __restrict__ q_gt,
                 const float* __restrict__ t_gt, const float* __restrict__ g_q_l2, const float* __restrict__ g_t_l2,
+                float coef_q, float clamp_q, float coef_t, float clamp_t, const float* __restrict__ g_scale,
                 float* __restrict__ g_E) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)L * B) return;
   const size_t b = idx % B;
   Pose P;
   pose_forward(E_layers + idx * 9, q_gt + b * 4, t_gt + b * 3, P);
-  const double gql = (g_q_l2 != nullptr) ? (double)g_q_l2[idx] : 0.0;
-  const double gtl = (g_t_l2 != nullptr) ? (double)g_t_l2[idx] : 0.0;
+  const double gs = (g_scale != nullptr) ? (double)g_scale[0] : 1.0;
+  // torch.clamp passes the gradient on [min, max] inclusive
+  const double gql = (g_q_l2 != nullptr) ? (double)g_q_l2[idx] : ((P.qe[P.qi] <= (double)clamp_q) ? (double)coef_q * gs : 0.0);
+  const double gtl = (g_t_l2 != nullptr) ? (double)g_t_l2[idx] : ((P.te[P.ti] <= (double)clamp_t) ? (double)coef_t * gs : 0.0);
   // d|q - q_gt| / dq
   double gq[4], gR[9];
   const Quat& qq = P.q[P.qi];
@@ -255,7 +258,71 @@ pose_bwd_kernel(const float* __restrict__ E_layers, int L, int B, const float* _
     for (int c = 0; c < 3; ++c) g_E[idx * 9 + 3 * r + c] = (float)gEc[3 * c + r];  // E = Ec^T
 }
 
+// loss head: one block, grid-stride over the L*B entries, block reduction in LDS (fp64)
+__global__ void __launch_bounds__(1024)
+loss_head_kernel(const float* __restrict__ loss_sum, const float* __restrict__ q_l2, const float* __restrict__ t_l2, int L,
+                 int B, int M, float clamp_q, float clamp_t, float balance_q, float balance_t, double* __restrict__ packed,
+                 float* __restrict__ scalars) {
+  __shared__ double red[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  double tot[3] = {0.0, 0.0, 0.0};  // sum over layers of the per-layer sums, clamped q, clamped t
+  for (int l = 0; l < L; ++l) {
+    double a = 0.0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) a += (double)loss_sum[(size_t)l * B + b];
+    a = wave_sum(a);
+    if (lane == 0) red[wave] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double s = 0.0;
+      for (int k = 0; k < nw; ++k) s += red[k];
+      packed[l] = s;
+      tot[0] += s;
+    }
+    __syncthreads();
+  }
+  double q = 0.0, t = 0.0;
+  if (q_l2 != nullptr && t_l2 != nullptr) {
+    for (size_t i = threadIdx.x; i < (size_t)L * B; i += blockDim.x) {
+      q += fmin(fmax((double)q_l2[i], 0.0), (double)clamp_q);
+      t += fmin(fmax((double)t_l2[i], 0.0), (double)clamp_t);
+    }
+  }
+  q = wave_sum(q);
+  t = wave_sum(t);
+  if (lane == 0) { red[wave] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) { double s = 0.0; for (int k = 0; k < nw; ++k) s += red[k]; tot[1] = s; }
+  __syncthreads();
+  if (lane == 0) { red[wave] = t; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int k = 0; k < nw; ++k) s += red[k];
+    tot[2] = s;
+    packed[L] = tot[1];
+    packed[L + 1] = tot[2];
+    packed[L + 2] = (double)B;
+    packed[L + 3] = (double)M;
+    const double n = (double)B;
+    const double loss_F = tot[0] / (n * (double)M * (double)L);
+    const double loss_qt = (tot[1] * (double)balance_q + tot[2] * (double)balance_t) / (n * (double)L);
+    scalars[0] = (float)(loss_F + loss_qt);
+    scalars[1] = (float)loss_F;
+    scalars[2] = (float)loss_qt;
+    scalars[3] = 0.0f;
+  }
+}
+
 }  // namespace
+
+extern "C" int dfepe_loss_head(const float* loss_sum, const float* q_l2, const float* t_l2, int L, int B, int M, float clamp_q,
+                               float clamp_t, float balance_q, float balance_t, double* packed, float* scalars, void* stream) {
+  if (L <= 0 || B <= 0 || M <= 0) return DFEPE_ERR_INVALID_ARG;
+  if (!loss_sum || !packed || !scalars || ((q_l2 == nullptr) != (t_l2 == nullptr))) return DFEPE_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(loss_head_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), loss_sum, q_l2, t_l2, L, B, M,
+                     clamp_q, clamp_t, balance_q, balance_t, packed, scalars);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
 
 extern "C" int dfepe_pose_fwd(const float* E_layers, int L, int B, const float* q_gt, const float* t_gt, const float* R_gt,
                               float* q_l2, float* t_l2, float* R_deg, float* t_deg, int* sel, void* stream) {
@@ -270,12 +337,13 @@ extern "C" int dfepe_pose_fwd(const float* E_layers, int L, int B, const float* 
 }
 
 extern "C" int dfepe_pose_bwd(const float* E_layers, int L, int B, const float* q_gt, const float* t_gt,
-                              const float* g_q_l2, const float* g_t_l2, float* g_E, void* stream) {
+                              const float* g_q_l2, const float* g_t_l2, float coef_q, float clamp_q, float coef_t,
+                              float clamp_t, const float* g_scale, float* g_E, void* stream) {
   if (L <= 0 || B < 0) return DFEPE_ERR_INVALID_ARG;
   if (B == 0) return DFEPE_OK;
   if (!E_layers || !q_gt || !t_gt || !g_E) return DFEPE_ERR_INVALID_ARG;
   const size_t n = (size_t)L * B;
   hipLaunchKernelGGL(pose_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     E_layers, L, B, q_gt, t_gt, g_q_l2, g_t_l2, g_E);
+                     E_layers, L, B, q_gt, t_gt, g_q_l2, g_t_l2, coef_q, clamp_q, coef_t, clamp_t, g_scale, g_E);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }

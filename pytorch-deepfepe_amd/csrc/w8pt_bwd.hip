@@ -25,7 +25,8 @@ __global__ void __launch_bounds__(256, 4)
 w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, const float* __restrict__ wts, int B,
                 int N, float hw_sx, float hw_sy, float clamp_at, const float* __restrict__ save,
                 const float* __restrict__ F_out, const float* __restrict__ g_F, const float* __restrict__ g_res,
-                const float* __restrict__ g_epi, float* __restrict__ g_w) {
+                const float* __restrict__ g_epi, const float* __restrict__ g_w_extra, int logits_mode,
+                float* __restrict__ g_w) {
   const int lane = threadIdx.x & 63;
   const size_t pair = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (pair >= (size_t)B) return;
@@ -156,6 +157,7 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 
   // ---- pass B: g_w --------------------------------------------------------------------------------------
   float* dst = g_w + pair * N;
+  float wg = 0.0f;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
   for (int i = lane; i < N; i += WAVE) {
     const Pt p = global_point<RAW>(pts1, pts2, pair, i, N, hw_sx, hw_sy);
@@ -166,7 +168,16 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 #pragma unroll
     for (int c = 0; c < 9; ++c) { a += ph[c] * f[c]; b += ph[c] * u[c]; }
     const double gr = (g_res != nullptr) ? (double)g_res[pair * N + i] : 0.0;
-    dst[i] = ok ? (float)(2.0 * w * a * b + gr * a) : 0.0f;
+    float gwi = ok ? (float)(2.0 * w * a * b + gr * a) : 0.0f;
+    if (g_w_extra != nullptr) gwi += g_w_extra[pair * N + i];
+    dst[i] = gwi;
+    wg += gwi * (float)w;
+  }
+  if (logits_mode) {
+    // softmax adjoint: g_logit_i = w_i (g_w_i - sum_j w_j g_w_j); dst is re-read by the lane that wrote it
+    const float s = wave_sum(wg);
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+    for (int i = lane; i < N; i += WAVE) dst[i] = wsrc[i] * (dst[i] - s);
   }
 }
 
@@ -174,9 +185,10 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 
 extern "C" int dfepe_w8pt_bwd(const float* pts1, const float* pts2, const float* weights, int B, int N, unsigned flags,
                               float image_w, float image_h, float clamp_at, const float* save, const float* F_out,
-                              const float* g_F, const float* g_residual, const float* g_epi, float* g_weights,
-                              void* stream) {
+                              const float* g_F, const float* g_residual, const float* g_epi,
+                              const float* g_weights_extra, float* g_weights, void* stream) {
   const bool raw = (flags & DFEPE_W8PT_RAW_MATCHES) != 0;
+  const int logits_mode = (flags & DFEPE_W8PT_LOGITS) ? 1 : 0;
   if (B < 0 || N <= 0) return DFEPE_ERR_INVALID_ARG;
   if (B == 0) return DFEPE_OK;
   if (!pts1 || (!raw && !pts2) || !weights || !save || !g_weights) return DFEPE_ERR_INVALID_ARG;
@@ -189,9 +201,9 @@ extern "C" int dfepe_w8pt_bwd(const float* pts1, const float* pts2, const float*
   const float hw_sx = raw ? 2.0f / image_w : 0.f, hw_sy = raw ? 2.0f / image_h : 0.f;
   if (raw)
     hipLaunchKernelGGL(w8pt_bwd_kernel<true>, grid, block, 0, st, pts1, pts2, weights, B, N, hw_sx, hw_sy, clamp_at, save,
-                       F_out, g_F, g_residual, g_epi, g_weights);
+                       F_out, g_F, g_residual, g_epi, g_weights_extra, logits_mode, g_weights);
   else
     hipLaunchKernelGGL(w8pt_bwd_kernel<false>, grid, block, 0, st, pts1, pts2, weights, B, N, hw_sx, hw_sy, clamp_at, save,
-                       F_out, g_F, g_residual, g_epi, g_weights);
+                       F_out, g_F, g_residual, g_epi, g_weights_extra, logits_mode, g_weights);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256, 4)
 w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, const float* __restrict__ wts,
                 int B, int N, int npad, int wave_bytes, float hw_sx, float hw_sy, float clamp_at,
                 float* __restrict__ F_out, float* __restrict__ residual, float* __restrict__ epi_res,
-                float* __restrict__ save) {
+                float* __restrict__ save, float* __restrict__ weights_out, int logits_mode) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -118,6 +118,26 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   for (int i = lane; i < N; i += WAVE) {
       const Pt p = lds_point<false>(P, i, npad);
       sx1 += p.x1; sy1 += p.y1; sx2 += p.x2; sy2 += p.y2;
+    }
+  }
+  if (logits_mode) {
+    // fused F.softmax(logits, dim=N) (DeepFNet.py:443,512): W holds the logits at this point
+    wave_sync();
+    float mx = -INFINITY;
+    for (int i = lane; i < N; i += WAVE) mx = fmaxf(mx, W[i]);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, WAVE));
+    float sm = 0.0f;
+    for (int i = lane; i < N; i += WAVE) {
+      const float e = expf(W[i] - mx);
+      W[i] = e;
+      sm += e;
+    }
+    const float inv = 1.0f / wave_sum(sm);
+    for (int i = lane; i < N; i += WAVE) {
+      const float w = W[i] * inv;
+      W[i] = w;
+      if (weights_out != nullptr) weights_out[(size_t)pair * N + i] = w;
     }
   }
   const double invN = 1.0 / (double)N;
@@ -224,6 +244,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   const int vr1 = vi1 * 9 + vj1, vrp1 = vi1 * 9 + vjp1, vw1 = vi1 * 9 + kPerm[vj1];
   const int pp = (lane < 8) ? (lane & ~1) : 0;  // lanes 0..7: my pair is positions (pp, pp+1)
   wave_sync();
+  int n_sweeps = 0, n_refine = 0;
   for (int sweep = 0; sweep < ((clamp_at < 0.f) ? 0 : kMaxSweeps); ++sweep) {  // DEBUG hook: negative clamp skips Jacobi
     float off = 0.0f;
     if (lane < 45 && ti != tj) {
@@ -232,6 +253,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     }
     off = wave_sum(off);
     if (!(off > kJacobiTol)) break;  // wave-uniform (also leaves on NaN)
+    ++n_sweeps;
     for (int r = 0; r < 9; ++r) {
       if (lane < 8) {
         const float app = A32[pp * 10], aqq = A32[pp * 10 + 10], apq = A32[pp * 9 + pp + 1];
@@ -313,6 +335,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 #pragma unroll
     for (int c = 0; c < 9; ++c) { r[c] -= rho * f[c]; rn2 += r[c] * r[c]; }
     if (!(rn2 > 1e-28 * tr * tr)) break;  // |M f - rho f| <= 1e-14 trace(M): converged (wave-uniform)
+    ++n_refine;
     // a_k = (q_k . r) / (rho - lam_k) for k != kmin, one k per lane
     if (lane < 9) {
       double dot = 0.0;
@@ -414,8 +437,10 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 #pragma unroll
       for (int c = 0; c < 9; ++c) { sv[SV_U3 + c] = U3[c]; sv[SV_V3 + c] = V3[c]; }
       sv[SV_S3 + 0] = S3[0]; sv[SV_S3 + 1] = S3[1]; sv[SV_S3 + 2] = (float)s3;
+      sv[119] = (float)n_sweeps;  // diagnostics: Jacobi sweeps and polish iterations actually run
+      sv[120] = (float)n_refine;
 #pragma unroll
-      for (int c = 119; c < DFEPE_SAVE_FLOATS; ++c) sv[c] = 0.0f;
+      for (int c = 121; c < DFEPE_SAVE_FLOATS; ++c) sv[c] = 0.0f;
     }
   }
 
@@ -454,8 +479,9 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 // host-side launcher ------------------------------------------------------------------------------------
 extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float* weights, int B, int N,
                               unsigned flags, float image_w, float image_h, float clamp_at, float* F_out,
-                              float* residual, float* epi_res, float* save, void* stream) {
+                              float* residual, float* epi_res, float* save, float* weights_out, void* stream) {
   const bool raw = (flags & DFEPE_W8PT_RAW_MATCHES) != 0;
+  const int logits_mode = (flags & DFEPE_W8PT_LOGITS) ? 1 : 0;
   if (B < 0 || N <= 0) return DFEPE_ERR_INVALID_ARG;
   if (B == 0) return DFEPE_OK;
   if (!pts1 || (!raw && !pts2) || !weights || !F_out || !residual) return DFEPE_ERR_INVALID_ARG;
@@ -480,7 +506,7 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
       if (err != hipSuccess) return DFEPE_ERR_HIP;
     }
     hipLaunchKernelGGL(w8pt_fwd_kernel<true>, grid, block, lds, st, pts1, pts2, weights, B, N, npad, wave_bytes,
-                       hw_sx, hw_sy, clamp_at, F_out, residual, epi_res, save);
+                       hw_sx, hw_sy, clamp_at, F_out, residual, epi_res, save, weights_out, logits_mode);
   } else {
     if (lds > 64 * 1024) {
       err = hipFuncSetAttribute(reinterpret_cast<const void*>(&w8pt_fwd_kernel<false>),
@@ -488,7 +514,7 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
       if (err != hipSuccess) return DFEPE_ERR_HIP;
     }
     hipLaunchKernelGGL(w8pt_fwd_kernel<false>, grid, block, lds, st, pts1, pts2, weights, B, N, npad, wave_bytes,
-                       hw_sx, hw_sy, clamp_at, F_out, residual, epi_res, save);
+                       hw_sx, hw_sy, clamp_at, F_out, residual, epi_res, save, weights_out, logits_mode);
   }
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }

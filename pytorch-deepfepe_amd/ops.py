@@ -34,57 +34,80 @@ def save_floats() -> int:
 # ------------------------------------------------------------------------------------------------
 # weighted 8-point fit
 # ------------------------------------------------------------------------------------------------
+def _flags(raw: bool, logits: bool) -> int:
+    return (_lib.W8PT_RAW_MATCHES if raw else 0) | (_lib.W8PT_LOGITS if logits else 0)
+
+
 def w8pt_forward(pts1: Tensor, pts2: Optional[Tensor], weights: Tensor, raw: bool, image_w: float, image_h: float,
-                 clamp_at: float, want_epi: bool, want_save: bool):
-    """Raw (non-differentiable) launch.  weights [B,N]; returns F [B,3,3], residual [B,N], epi [B,N]|None, save|None."""
+                 clamp_at: float, want_epi: bool, want_save: bool, logits: bool = False, F_out: Optional[Tensor] = None):
+    """Raw (non-differentiable) launch.  weights (or logits when ``logits``) [B,N].
+    Returns F [B,3,3], residual [B,N], epi [B,N]|None, save|None, weights_out [B,N]|None.  ``F_out`` lets the caller
+    provide the destination (e.g. one [B,3,3] slice of a per-layer stack)."""
     L = _lib.lib()
     B, N = weights.shape
-    F = torch.empty(B, 3, 3, device=weights.device, dtype=torch.float32)
-    residual = torch.empty(B, N, device=weights.device, dtype=torch.float32)
-    epi = torch.empty(B, N, device=weights.device, dtype=torch.float32) if want_epi else None
-    save = torch.empty(B, _lib.lib().dfepe_save_floats(), device=weights.device, dtype=torch.float32) if want_save else None
-    with torch.cuda.device(weights.device):
-        rc = L.dfepe_w8pt_fwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, _lib.W8PT_RAW_MATCHES if raw else 0,
-                              float(image_w), float(image_h), float(clamp_at), _ptr(F), _ptr(residual), _ptr(epi),
-                              _ptr(save), _stream())
+    dev = weights.device
+    F = torch.empty(B, 3, 3, device=dev, dtype=torch.float32) if F_out is None else F_out
+    residual = torch.empty(B, N, device=dev, dtype=torch.float32)
+    epi = torch.empty(B, N, device=dev, dtype=torch.float32) if want_epi else None
+    save = torch.empty(B, L.dfepe_save_floats(), device=dev, dtype=torch.float32) if want_save else None
+    w_out = torch.empty(B, N, device=dev, dtype=torch.float32) if logits else None
+    with torch.cuda.device(dev):
+        rc = L.dfepe_w8pt_fwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, _flags(raw, logits), float(image_w), float(image_h),
+                              float(clamp_at), _ptr(F), _ptr(residual), _ptr(epi), _ptr(save), _ptr(w_out), _stream())
     _lib.check(rc, "dfepe_w8pt_fwd")
-    return F, residual, epi, save
+    return F, residual, epi, save, w_out
+
+
+def w8pt_backward(pts1, pts2, weights, raw, image_w, image_h, clamp_at, save, F, gF, gRes, gEpi, logits=False, gW_extra=None,
+                  out: Optional[Tensor] = None):
+    """Raw launch of the adjoint; returns d/d(weights) (or d/d(logits) when ``logits``; then ``weights`` must be the
+    forward's weights_out)."""
+    L = _lib.lib()
+    B, N = weights.shape
+    gW = torch.empty_like(weights) if out is None else out
+    with torch.cuda.device(weights.device):
+        rc = L.dfepe_w8pt_bwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, _flags(raw, logits), float(image_w), float(image_h),
+                              float(clamp_at), _ptr(save), _ptr(F), _ptr(gF), _ptr(gRes), _ptr(gEpi), _ptr(gW_extra), _ptr(gW),
+                              _stream())
+    _lib.check(rc, "dfepe_w8pt_bwd")
+    return gW
+
+
+def _cf(t: Optional[Tensor]) -> Optional[Tensor]:
+    return None if t is None else t.contiguous().float()
 
 
 class _W8ptFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pts1, pts2, weights, raw, image_w, image_h, clamp_at, want_epi):
-        F, residual, epi, save = w8pt_forward(pts1, pts2, weights, raw, image_w, image_h, clamp_at, want_epi,
-                                              want_save=True)
-        ctx.save_for_backward(pts1, pts2 if pts2 is not None else pts1.new_empty(0), weights, save, F)
-        ctx.cfg = (raw, image_w, image_h, clamp_at, want_epi)
+    def forward(ctx, pts1, pts2, weights, raw, image_w, image_h, clamp_at, want_epi, logits):
+        F, residual, epi, save, w_out = w8pt_forward(pts1, pts2, weights, raw, image_w, image_h, clamp_at, want_epi,
+                                                     want_save=True, logits=logits)
+        ctx.save_for_backward(pts1, pts2 if pts2 is not None else pts1.new_empty(0), w_out if logits else weights, save, F)
+        ctx.cfg = (raw, image_w, image_h, clamp_at, want_epi, logits)
+        outs = [F, residual]
         if want_epi:
-            return F, residual, epi
-        return F, residual
+            outs.append(epi)
+        if logits:
+            outs.append(w_out)
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, gF, gRes, gEpi=None):
+    def backward(ctx, gF, gRes, *rest):
         pts1, pts2, weights, save, F = ctx.saved_tensors
-        raw, image_w, image_h, clamp_at, want_epi = ctx.cfg
-        L = _lib.lib()
-        B, N = weights.shape
-        gW = torch.empty_like(weights)
-        gF = None if gF is None else gF.contiguous().float()
-        gRes = None if gRes is None else gRes.contiguous().float()
-        gEpi = None if (gEpi is None or not want_epi) else gEpi.contiguous().float()
-        with torch.cuda.device(weights.device):
-            rc = L.dfepe_w8pt_bwd(_ptr(pts1), _ptr(pts2) if pts2.numel() else None, _ptr(weights), B, N,
-                                  _lib.W8PT_RAW_MATCHES if raw else 0, float(image_w), float(image_h), float(clamp_at),
-                                  _ptr(save), _ptr(F), _ptr(gF), _ptr(gRes), _ptr(gEpi), _ptr(gW), _stream())
-        _lib.check(rc, "dfepe_w8pt_bwd")
-        return None, None, gW, None, None, None, None, None
+        raw, image_w, image_h, clamp_at, want_epi, logits = ctx.cfg
+        rest = list(rest)
+        gEpi = rest.pop(0) if want_epi else None
+        gWout = rest.pop(0) if logits else None
+        gW = w8pt_backward(pts1, pts2 if pts2.numel() else None, weights, raw, image_w, image_h, clamp_at, save, F,
+                           _cf(gF), _cf(gRes), _cf(gEpi), logits=logits, gW_extra=_cf(gWout))
+        return None, None, gW, None, None, None, None, None, None
 
 
 def w8pt(pts1: Tensor, pts2: Tensor, weights: Tensor, clamp_at: float = 0.5, want_epi: bool = False):
     """Differentiable (w.r.t. weights) fit on homogeneous points [B,N,3]; weights [B,N] or [B,1,N]."""
     pts1, pts2 = _prep(pts1, "pts1"), _prep(pts2, "pts2")
     w = _prep(weights.reshape(weights.shape[0], -1), "weights")
-    return _W8ptFunction.apply(pts1, pts2, w, False, 0.0, 0.0, clamp_at, want_epi)
+    return _W8ptFunction.apply(pts1, pts2, w, False, 0.0, 0.0, clamp_at, want_epi, False)
 
 
 def w8pt_raw(matches: Tensor, weights: Tensor, image_w: float, image_h: float, clamp_at: float = 0.5,
@@ -92,7 +115,16 @@ def w8pt_raw(matches: Tensor, weights: Tensor, image_w: float, image_h: float, c
     """Differentiable fit straight from pixel matches [B,N,4] (image-size normalisation fused)."""
     m = _prep(matches, "matches")
     w = _prep(weights.reshape(weights.shape[0], -1), "weights")
-    return _W8ptFunction.apply(m, None, w, True, float(image_w), float(image_h), clamp_at, want_epi)
+    return _W8ptFunction.apply(m, None, w, True, float(image_w), float(image_h), clamp_at, want_epi, False)
+
+
+def w8pt_raw_logits(matches: Tensor, logits: Tensor, image_w: float, image_h: float, clamp_at: float = 0.5,
+                    want_epi: bool = True):
+    """As w8pt_raw but takes the estimator's logits and fuses F.softmax(dim=N); additionally returns the weights
+    (differentiable: the next estimator layer consumes them).  Returns (F, residual[, epi], weights)."""
+    m = _prep(matches, "matches")
+    l = _prep(logits.reshape(logits.shape[0], -1), "logits")
+    return _W8ptFunction.apply(m, None, l, True, float(image_w), float(image_h), clamp_at, want_epi, True)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -139,7 +171,7 @@ class _FlossFunction(torch.autograd.Function):
         g_E = None if g_E is None else g_E.contiguous().float()
         with torch.cuda.device(F_layers.device):
             rc = lib.dfepe_floss_bwd(_ptr(F_layers), L, B, _ptr(T1c), _ptr(T2c), st, _ptr(K), _ptr(virt1), _ptr(virt2),
-                                     virt1.shape[1], clamp_at, _ptr(g_loss_sum), _ptr(g_E), _ptr(gF), _stream())
+                                     virt1.shape[1], clamp_at, _ptr(g_loss_sum), 0.0, None, _ptr(g_E), _ptr(gF), _stream())
         _lib.check(rc, "dfepe_floss_bwd")
         return gF, None, None, None, None, None, None
 
@@ -181,7 +213,8 @@ class _PoseFunction(torch.autograd.Function):
         g_q = None if g_q is None else g_q.contiguous().float()
         g_t = None if g_t is None else g_t.contiguous().float()
         with torch.cuda.device(E_layers.device):
-            rc = lib.dfepe_pose_bwd(_ptr(E_layers), L, B, _ptr(q_gt), _ptr(t_gt), _ptr(g_q), _ptr(g_t), _ptr(gE), _stream())
+            rc = lib.dfepe_pose_bwd(_ptr(E_layers), L, B, _ptr(q_gt), _ptr(t_gt), _ptr(g_q), _ptr(g_t), 0.0, 0.0, 0.0, 0.0, None,
+                                    _ptr(gE), _stream())
         _lib.check(rc, "dfepe_pose_bwd")
         return gE, None, None, None
 

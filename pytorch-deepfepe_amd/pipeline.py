@@ -11,7 +11,7 @@ from typing import Dict, Optional, Sequence
 
 import torch
 
-from . import ops
+from . import _lib, ops
 
 Tensor = torch.Tensor
 
@@ -52,6 +52,117 @@ def hot_path_forward(matches: Tensor, logits_layers: Tensor, Ks: Tensor, virt1: 
     return out
 
 
+class _HotPathFunction(torch.autograd.Function):
+    """The whole solver-only step as ONE autograd node: 5 x w8pt_fwd (softmax fused) + floss_fwd + pose_fwd + loss_head
+    forward (8 launches), pose_bwd + floss_bwd + 5 x w8pt_bwd backward (7 launches + 1 add).  No intermediate torch
+    ops, no per-op autograd bookkeeping; every buffer is allocated once per call."""
+
+    @staticmethod
+    def forward(ctx, matches, logits_layers, Ks, virt1, virt2, q_gt, t_gt, R_gt, hw_T, cfg):
+        (H, W, clamp_at, qt, clamp_q, clamp_t, balance_q, balance_t) = cfg
+        lib = _lib.lib()
+        L, B, N = logits_layers.shape
+        dev = matches.device
+        M = virt1.shape[1]
+        F_layers = torch.empty(L, B, 3, 3, device=dev)
+        residuals = torch.empty(L, B, N, device=dev)
+        epis = torch.empty(L, B, N, device=dev)
+        weights = torch.empty(L, B, N, device=dev)
+        saves = torch.empty(L, B, lib.dfepe_save_floats(), device=dev)
+        flags = _lib.W8PT_RAW_MATCHES | _lib.W8PT_LOGITS
+        st = ops._stream()
+        with torch.cuda.device(dev):
+            for l in range(L):
+                rc = lib.dfepe_w8pt_fwd(matches.data_ptr(), None, logits_layers[l].data_ptr(), B, N, flags, W, H, 0.5,
+                                        F_layers[l].data_ptr(), residuals[l].data_ptr(), epis[l].data_ptr(), saves[l].data_ptr(),
+                                        weights[l].data_ptr(), st)
+                _lib.check(rc, "dfepe_w8pt_fwd")
+            loss_sum = torch.empty(L, B, device=dev)
+            E_layers = torch.empty(L, B, 3, 3, device=dev)
+            rc = lib.dfepe_floss_fwd(F_layers.data_ptr(), L, B, hw_T.data_ptr(), hw_T.data_ptr(), 0, Ks.data_ptr(), virt1.data_ptr(),
+                                     virt2.data_ptr(), M, clamp_at, loss_sum.data_ptr(), E_layers.data_ptr(), st)
+            _lib.check(rc, "dfepe_floss_fwd")
+            q_l2 = t_l2 = R_deg = t_deg = sel = None
+            if qt:
+                q_l2 = torch.empty(L, B, device=dev)
+                t_l2 = torch.empty(L, B, device=dev)
+                R_deg = torch.empty(L, B, device=dev)
+                t_deg = torch.empty(L, B, device=dev)
+                sel = torch.empty(L, B, device=dev, dtype=torch.int32)
+                rc = lib.dfepe_pose_fwd(E_layers.data_ptr(), L, B, q_gt.data_ptr(), t_gt.data_ptr(), R_gt.data_ptr(), q_l2.data_ptr(),
+                                        t_l2.data_ptr(), R_deg.data_ptr(), t_deg.data_ptr(), sel.data_ptr(), st)
+                _lib.check(rc, "dfepe_pose_fwd")
+            packed = torch.empty(L + 4, device=dev, dtype=torch.float64)
+            scalars = torch.empty(4, device=dev)
+            rc = lib.dfepe_loss_head(loss_sum.data_ptr(), ops._ptr(q_l2), ops._ptr(t_l2), L, B, M, clamp_q, clamp_t, balance_q,
+                                     balance_t, packed.data_ptr(), scalars.data_ptr(), st)
+            _lib.check(rc, "dfepe_loss_head")
+        ctx.save_for_backward(matches, weights, Ks, virt1, virt2, q_gt, t_gt, hw_T, F_layers, E_layers, saves)
+        ctx.cfg = cfg
+        extras = (F_layers, residuals, epis, weights, E_layers, loss_sum, packed, scalars)
+        pose = (q_l2, t_l2, R_deg, t_deg, sel) if qt else ()
+        ctx.mark_non_differentiable(*extras, *pose)
+        return (scalars[0].clone(),) + extras + pose
+
+    @staticmethod
+    def backward(ctx, g_loss, *unused):
+        matches, weights, Ks, virt1, virt2, q_gt, t_gt, hw_T, F_layers, E_layers, saves = ctx.saved_tensors
+        (H, W, clamp_at, qt, clamp_q, clamp_t, balance_q, balance_t) = ctx.cfg
+        lib = _lib.lib()
+        L, B, N = weights.shape
+        M = virt1.shape[1]
+        dev = matches.device
+        g_scale = g_loss.reshape(1).contiguous().float()
+        st = ops._stream()
+        flags = _lib.W8PT_RAW_MATCHES | _lib.W8PT_LOGITS
+        g_logits = torch.empty(L, B, N, device=dev)
+        gF = torch.empty(L, B, 3, 3, device=dev)
+        with torch.cuda.device(dev):
+            gE_ptr = None
+            if qt:
+                gE = torch.empty(L, B, 3, 3, device=dev)
+                rc = lib.dfepe_pose_bwd(E_layers.data_ptr(), L, B, q_gt.data_ptr(), t_gt.data_ptr(), None, None,
+                                        balance_q / float(L * B), clamp_q, balance_t / float(L * B), clamp_t, g_scale.data_ptr(),
+                                        gE.data_ptr(), st)
+                _lib.check(rc, "dfepe_pose_bwd")
+                gE_ptr = gE.data_ptr()
+            rc = lib.dfepe_floss_bwd(F_layers.data_ptr(), L, B, hw_T.data_ptr(), hw_T.data_ptr(), 0, Ks.data_ptr(), virt1.data_ptr(),
+                                     virt2.data_ptr(), M, clamp_at, None, 1.0 / float(L * B * M), g_scale.data_ptr(), gE_ptr,
+                                     gF.data_ptr(), st)
+            _lib.check(rc, "dfepe_floss_bwd")
+            for l in range(L):
+                rc = lib.dfepe_w8pt_bwd(matches.data_ptr(), None, weights[l].data_ptr(), B, N, flags, W, H, 0.5, saves[l].data_ptr(),
+                                        F_layers[l].data_ptr(), gF[l].data_ptr(), None, None, None, g_logits[l].data_ptr(), st)
+                _lib.check(rc, "dfepe_w8pt_bwd")
+        return None, g_logits, None, None, None, None, None, None, None, None
+
+
+def hot_path_fused(matches: Tensor, logits_layers: Tensor, Ks: Tensor, virt1: Tensor, virt2: Tensor, q_gt: Tensor,
+                   t_gt: Tensor, R_gt: Tensor, image_size: Sequence[int], clamp_at: float = 0.02, qt: bool = True,
+                   clamp_q: float = 0.1, clamp_t: float = 0.5, balance_q: float = 1.0, balance_t: float = 0.1,
+                   hw_T: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """Same contract and same numbers as hot_path_forward, 15 kernel launches instead of ~120 (loss = loss_F + loss_qt)."""
+    L, B, N = logits_layers.shape
+    H, W = float(image_size[0]), float(image_size[1])
+    dev = matches.device
+    if hw_T is None:
+        hw_T = torch.tensor([[2.0 / W, 0.0, -1.0], [0.0, 2.0 / H, -1.0], [0.0, 0.0, 1.0]], device=dev)
+    f32 = lambda t: ops._prep(t, "input")
+    cfg = (H, W, float(clamp_at), bool(qt), float(clamp_q), float(clamp_t), float(balance_q), float(balance_t))
+    res = _HotPathFunction.apply(f32(matches), f32(logits_layers), f32(Ks), f32(virt1), f32(virt2), f32(q_gt.reshape(B, 4)),
+                                 f32(t_gt.reshape(B, 3)), f32(R_gt.reshape(B, 3, 3)), f32(hw_T), cfg)
+    loss, F_layers, residuals, epis, weights, E_layers, loss_sum, packed, scalars = res[:9]
+    M = virt1.shape[1]
+    out = {"loss": loss, "F_layers": F_layers, "residual_layers": [residuals[l] for l in range(L)],
+           "epi_res_layers": [epis[l] for l in range(L)], "weights_layers": [weights[l] for l in range(L)],
+           "E_layers": E_layers, "loss_sum": loss_sum, "loss_layers": packed[:L].float() / float(B * M), "loss_F": scalars[1],
+           "packed": packed}
+    if qt:
+        q_l2, t_l2, R_deg, t_deg, sel = res[9:]
+        out.update({"q_l2": q_l2, "t_l2": t_l2, "R_deg": R_deg, "t_deg": t_deg, "sel": sel, "loss_qt": scalars[2]})
+    return out
+
+
 def scene_to_device(scene: Dict[str, Tensor], device) -> Dict[str, Tensor]:
     """Move a synth.make_scene() batch to the GPU and derive the camera-motion rotation the pose loss needs
     (R_gt = inv(delta)[:3,:3] = R^T, train_good_utils.py:134,170)."""
@@ -61,9 +172,9 @@ def scene_to_device(scene: Dict[str, Tensor], device) -> Dict[str, Tensor]:
 
 
 def hot_path_step(scene: Dict[str, Tensor], image_size: Sequence[int], depth: int, clamp_at: float = 0.02,
-                  qt: bool = True, backward: bool = True, **kw) -> Dict[str, Tensor]:
+                  qt: bool = True, backward: bool = True, fused: bool = True, **kw) -> Dict[str, Tensor]:
     logits = scene["logits_layers"][:depth].detach().clone().requires_grad_(backward)
-    out = hot_path_forward(scene["matches_xy_ori"], logits, scene["Ks"], scene["pts1_virt_ori"], scene["pts2_virt_ori"],
+    out = (hot_path_fused if fused else hot_path_forward)(scene["matches_xy_ori"], logits, scene["Ks"], scene["pts1_virt_ori"], scene["pts2_virt_ori"],
                            scene["qs_cam"], scene["ts_cam"], scene["R_gt"], image_size, clamp_at, qt, **kw)
     if backward:
         out["loss"].backward()

@@ -161,3 +161,40 @@ def test_hot_path_step_matches_reference_golden(dfepe, golden):
         ours_g = logits.grad.cpu().numpy()
         cos = (ours_g * ref).sum() / (np.linalg.norm(ours_g) * np.linalg.norm(ref))
         assert cos > 0.999 and relerr(ours_g, ref) < 5e-2
+
+
+def test_fused_step_equals_unfused_ops(dfepe):
+    """The single-node fused step (softmax fused into the fit, scalar-coefficient adjoints, loss head) and the
+    per-op autograd path are the same computation."""
+    B, N, depth = 9, 100, 4
+    sc = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(B, N, seed=33, outlier_ratio=0.3, depth_layers=depth), DEV)
+    a = dfepe.pipeline.hot_path_step(sc, IMAGE_SIZE, depth, 0.02, qt=True, fused=True)
+    b = dfepe.pipeline.hot_path_step(sc, IMAGE_SIZE, depth, 0.02, qt=True, fused=False)
+    assert abs(a["loss"].item() - b["loss"].item()) < 1e-6
+    assert (a["F_layers"] - b["F_layers"]).abs().max().item() < 2e-6 * b["F_layers"].abs().max().item()
+    np.testing.assert_allclose(a["loss_layers"].cpu().numpy(), b["loss_layers"].detach().cpu().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(a["q_l2"].cpu().numpy(), b["q_l2"].detach().cpu().numpy(), atol=1e-6)
+    for l in range(depth):
+        np.testing.assert_allclose(a["weights_layers"][l].cpu().numpy(), b["weights_layers"][l].detach().cpu().numpy(), rtol=2e-6, atol=1e-9)
+    assert relerr(a["grad_logits"].cpu().numpy(), b["grad_logits"].cpu().numpy()) < 2e-5
+    # packed sums = what dist.pack_loss_sums builds from the tensors
+    ref = dfepe.dist.pack_loss_sums(a["loss_sum"], 100, a["q_l2"], a["t_l2"], 0.1, 0.5)
+    np.testing.assert_allclose(a["packed"].cpu().numpy(), ref.cpu().numpy(), rtol=1e-6)
+
+
+def test_logits_fused_fit_matches_softmax_then_fit(dfepe):
+    B, N = 6, 100
+    sc = dfepe.synth.make_scene(B, N, seed=12, outlier_ratio=0.2)
+    g = torch.Generator().manual_seed(5)
+    m = sc["matches_xy_ori"].to(DEV)
+    GF, GR, GE, GW = (torch.randn(s, generator=g).to(DEV) for s in ((B, 3, 3), (B, N), (B, N), (B, N)))
+    la = sc["logits_layers"][0].to(DEV).requires_grad_(True)
+    F, res, epi, w = dfepe.ops.w8pt_raw_logits(m, la, 1241, 376)
+    ((F * GF).sum() + (res * GR).sum() + (epi * GE).sum() + (w * GW).sum()).backward()
+    lb = sc["logits_layers"][0].to(DEV).requires_grad_(True)
+    wb = torch.softmax(lb, dim=1)
+    F2, res2, epi2 = dfepe.ops.w8pt_raw(m, wb, 1241, 376)
+    ((F2 * GF).sum() + (res2 * GR).sum() + (epi2 * GE).sum() + (wb * GW).sum()).backward()
+    np.testing.assert_allclose(w.detach().cpu().numpy(), wb.detach().cpu().numpy(), rtol=2e-6, atol=1e-10)
+    assert (F - F2).abs().max().item() < 2e-6 * F2.abs().max().item()
+    assert relerr(la.grad.cpu().numpy(), lb.grad.cpu().numpy()) < 2e-5

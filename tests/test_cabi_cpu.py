@@ -30,7 +30,7 @@ def test_library_builds_and_exports_every_declared_symbol(dfepe):
 
 def test_version_strerror_and_save_layout(dfepe):
     L = dfepe._lib.lib()
-    assert L.dfepe_version() == 100
+    assert L.dfepe_version() == 110
     assert L.dfepe_save_floats() == 128
     assert L.dfepe_strerror(0) == b"ok"
     assert b"invalid" in L.dfepe_strerror(-1)
@@ -40,15 +40,16 @@ def test_version_strerror_and_save_layout(dfepe):
 def test_argument_validation_without_launching(dfepe):
     """Bad arguments are rejected on the host before any HIP call (safe without a GPU)."""
     L = dfepe._lib.lib()
-    assert L.dfepe_w8pt_fwd(None, None, None, 4, 100, 0, 0.0, 0.0, 0.5, None, None, None, None, None) == -1
-    assert L.dfepe_w8pt_fwd(None, None, None, -1, 100, 0, 0.0, 0.0, 0.5, None, None, None, None, None) == -1
-    assert L.dfepe_w8pt_fwd(None, None, None, 0, 100, 0, 0.0, 0.0, 0.5, None, None, None, None, None) == 0  # empty batch
-    assert L.dfepe_w8pt_bwd(None, None, None, 2, 0, 0, 0.0, 0.0, 0.5, None, None, None, None, None, None, None) == -1
+    assert L.dfepe_w8pt_fwd(None, None, None, 4, 100, 0, 0.0, 0.0, 0.5, None, None, None, None, None, None) == -1
+    assert L.dfepe_w8pt_fwd(None, None, None, -1, 100, 0, 0.0, 0.0, 0.5, None, None, None, None, None, None) == -1
+    assert L.dfepe_w8pt_fwd(None, None, None, 0, 100, 0, 0.0, 0.0, 0.5, None, None, None, None, None, None) == 0  # empty batch
+    assert L.dfepe_w8pt_bwd(None, None, None, 2, 0, 0, 0.0, 0.0, 0.5, None, None, None, None, None, None, None, None) == -1
     assert L.dfepe_floss_fwd(None, 0, 4, None, None, 0, None, None, None, 100, 0.02, None, None, None) == -1
     assert L.dfepe_floss_fwd(None, 5, 0, None, None, 0, None, None, None, 100, 0.02, None, None, None) == 0
     assert L.dfepe_floss_fwd(None, 5, 4, None, None, 3, None, None, None, 100, 0.02, None, None, None) == -1  # bad stride
     assert L.dfepe_pose_fwd(None, 5, 4, None, None, None, None, None, None, None, None, None) == -1
-    assert L.dfepe_pose_bwd(None, 5, 0, None, None, None, None, None, None) == 0
+    assert L.dfepe_pose_bwd(None, 5, 0, None, None, None, None, 0.0, 0.0, 0.0, 0.0, None, None, None) == 0
+    assert L.dfepe_loss_head(None, None, None, 5, 4, 100, 0.1, 0.5, 1.0, 0.1, None, None, None) == -1
 
 
 def test_no_cpu_fallback(dfepe):
