@@ -26,10 +26,10 @@ __device__ __forceinline__ Epi epi_terms(const double* x1, const double* x2, con
 #pragma unroll
   for (int r = 0; r < 3; ++r) e.l2[r] = o[3 * r] * x1[0] + o[3 * r + 1] * x1[1] + o[3 * r + 2] * x1[2];
   e.dd = x1[0] * e.l1[0] + x1[1] * e.l1[1] + x1[2] * e.l1[2];
-  e.n1 = sqrt(e.l1[0] * e.l1[0] + e.l1[1] * e.l1[1]);
-  e.n2 = sqrt(e.l2[0] * e.l2[0] + e.l2[1] * e.l2[1]);
-  e.i1 = 1.0 / (e.n1 + 1e-6);
-  e.i2 = 1.0 / (e.n2 + 1e-6);
+  e.n1 = fast_sqrt(e.l1[0] * e.l1[0] + e.l1[1] * e.l1[1]);
+  e.n2 = fast_sqrt(e.l2[0] * e.l2[0] + e.l2[1] * e.l2[1]);
+  e.i1 = fast_rcp(e.n1 + 1e-6);
+  e.i2 = fast_rcp(e.n2 + 1e-6);
   e.d = fabs(e.dd) * (e.i1 + e.i2);
   return e;
 }
@@ -105,8 +105,8 @@ floss_kernel(const float* __restrict__ F_layers, int L, int B, const float* __re
           if (e.d <= (double)clamp_at) {
             const double S = e.i1 + e.i2, ad = fabs(e.dd);
             const double sg = (e.dd > 0.0) ? 1.0 : ((e.dd < 0.0) ? -1.0 : 0.0);
-            const double k1 = (e.n1 > 0.0) ? ad * e.i1 * e.i1 / e.n1 : 0.0;
-            const double k2 = (e.n2 > 0.0) ? ad * e.i2 * e.i2 / e.n2 : 0.0;
+            const double k1 = (e.n1 > 0.0) ? ad * e.i1 * e.i1 * fast_rcp(e.n1) : 0.0;
+            const double k2 = (e.n2 > 0.0) ? ad * e.i2 * e.i2 * fast_rcp(e.n2) : 0.0;
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll

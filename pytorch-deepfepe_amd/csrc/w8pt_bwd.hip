@@ -71,14 +71,14 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 #pragma unroll
       for (int r = 0; r < 3; ++r) l2[r] = o[3 * r] * x1[0] + o[3 * r + 1] * x1[1] + o[3 * r + 2] * x1[2];
       const double dd = x1[0] * l1[0] + x1[1] * l1[1] + x1[2] * l1[2];
-      const double n1 = sqrt(l1[0] * l1[0] + l1[1] * l1[1]), n2 = sqrt(l2[0] * l2[0] + l2[1] * l2[1]);
-      const double i1 = 1.0 / (n1 + 1e-6), i2 = 1.0 / (n2 + 1e-6);
+      const double n1 = fast_sqrt(l1[0] * l1[0] + l1[1] * l1[1]), n2 = fast_sqrt(l2[0] * l2[0] + l2[1] * l2[1]);
+      const double i1 = fast_rcp(n1 + 1e-6), i2 = fast_rcp(n2 + 1e-6);
       const double S = i1 + i2, ad = fabs(dd);
       const double d = ad * S;
       const double g = (d <= (double)clamp_at) ? (double)g_epi[pair * N + i] : 0.0;  // clamp(max=) passes the gradient up to and including the bound
       const double sg = (dd > 0.0) ? 1.0 : ((dd < 0.0) ? -1.0 : 0.0);
-      const double k1 = (n1 > 0.0) ? ad * i1 * i1 / n1 : 0.0;
-      const double k2 = (n2 > 0.0) ? ad * i2 * i2 / n2 : 0.0;
+      const double k1 = (n1 > 0.0) ? ad * i1 * i1 * fast_rcp(n1) : 0.0;
+      const double k2 = (n2 > 0.0) ? ad * i2 * i2 * fast_rcp(n2) : 0.0;
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll

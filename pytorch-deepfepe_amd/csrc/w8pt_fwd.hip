@@ -125,8 +125,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     wave_sync();
     float mx = -INFINITY;
     for (int i = lane; i < N; i += WAVE) mx = fmaxf(mx, W[i]);
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, WAVE));
+    mx = wave_max(mx);
     float sm = 0.0f;
     for (int i = lane; i < N; i += WAVE) {
       const float e = expf(W[i] - mx);
@@ -152,8 +151,8 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     const Pt p = lds_point<RAW>(P, i, npad);
     const double ax = (double)p.x1 - c1x, ay = (double)p.y1 - c1y;
     const double bx = (double)p.x2 - c2x, by = (double)p.y2 - c2y;
-    d1 += sqrt(ax * ax + ay * ay);
-    d2 += sqrt(bx * bx + by * by);
+    d1 += fast_sqrt(ax * ax + ay * ay);
+    d2 += fast_sqrt(bx * bx + by * by);
   }
   const double s1 = to_sgpr(1.4142 / (wave_sum(d1) * invN));  // the reference uses the literal, not sqrt(2) (DeepFNet.py:168)
   const double s2 = to_sgpr(1.4142 / (wave_sum(d2) * invN));
@@ -171,7 +170,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     const double b0 = s2 * ((double)p.x2 - c2x * z2), b1 = s2 * ((double)p.y2 - c2y * z2);
     const double n2 = (a0 * a0 + a1 * a1 + a2 * a2) * (b0 * b0 + b1 * b1 + 1.0);  // |p|^2
     const bool ok = (n2 < 1e300) && (fabs(w) < 1e150);
-    const double k2 = ok ? (w * w) / fmax(n2, 1e-24) : 0.0;                        // (w / max(|p|,1e-12))^2
+    const double k2 = ok ? (w * w) * fast_rcp(fmax(n2, 1e-24)) : 0.0;                        // (w / max(|p|,1e-12))^2
     const double aa[6] = {a0 * a0, a0 * a1, a0 * a2, a1 * a1, a1 * a2, a2 * a2};
     const double bb[6] = {k2 * b0 * b0, k2 * b0 * b1, k2 * b0, k2 * b1 * b1, k2 * b1, k2};
     if (ok) {
@@ -245,39 +244,39 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   const int pp = (lane < 8) ? (lane & ~1) : 0;  // lanes 0..7: my pair is positions (pp, pp+1)
   wave_sync();
   int n_sweeps = 0, n_refine = 0;
-  for (int sweep = 0; sweep < ((clamp_at < 0.f) ? 0 : kMaxSweeps); ++sweep) {  // DEBUG hook: negative clamp skips Jacobi
+  // DEBUG hook: clamp_at = -(1+S) forces exactly S sweeps without the polish, clamp_at = -(51+S) with it
+  const bool dbg_polish = clamp_at < -50.f;
+  const int max_sweeps = (clamp_at < 0.f) ? (int)(-clamp_at) - (dbg_polish ? 51 : 1) : kMaxSweeps;
+  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     float off = 0.0f;
     if (lane < 45 && ti != tj) {
       const float a = A32[a00];
       off = a * a;
     }
     off = wave_sum(off);
-    if (!(off > kJacobiTol)) break;  // wave-uniform (also leaves on NaN)
+    if (!(off > kJacobiTol) && !(clamp_at < 0.f)) break;  // wave-uniform (also leaves on NaN)
     ++n_sweeps;
     for (int r = 0; r < 9; ++r) {
+      // every read of the round is issued up front (none of them depends on this round's rotations), so the round
+      // costs two LDS round trips plus the (c,s) exchange instead of five
+      float e00 = 0.f, e01 = 0.f, e10 = 0.f, e11 = 0.f;
+      if (lane < 45) { e00 = A32[a00]; e01 = A32[a01]; e10 = A32[a10]; e11 = A32[a11]; }
+      const float u0 = V32[vr0], u0p = V32[vrp0], u1 = V32[vr1], u1p = V32[vrp1];
       if (lane < 8) {
         const float app = A32[pp * 10], aqq = A32[pp * 10 + 10], apq = A32[pp * 9 + pp + 1];
-        float c = 1.0f, sn = 0.0f;
-        if (apq != 0.0f) {
-          const float d = aqq - app, b = 2.0f * apq;
-          const float h = __builtin_amdgcn_sqrtf(fmaf(d, d, b * b));
-          const float t = b * __builtin_amdgcn_rcpf(d + copysignf(h, d));
-          c = __builtin_amdgcn_rsqf(fmaf(t, t, 1.0f));
-          sn = t * c;
-        }
+        const float d = aqq - app, b = 2.0f * apq;
+        const float h = __builtin_amdgcn_sqrtf(fmaf(d, d, b * b));
+        const float t = b * __builtin_amdgcn_rcpf(d + copysignf(h, d));
+        float c = __builtin_amdgcn_rsqf(fmaf(t, t, 1.0f));
+        float sn = t * c;
+        if (apq == 0.0f) { c = 1.0f; sn = 0.0f; }  // also catches 0/0
         CS[lane] = make_float2(c, (lane & 1) ? sn : -sn);
       }
       wave_sync();
-      float anew = 0.0f;
-      if (lane < 45) {
-        const float2 ci = CS[ti], cj = CS[tj];
-        anew = ci.x * fmaf(cj.x, A32[a00], cj.y * A32[a01]) + ci.y * fmaf(cj.x, A32[a10], cj.y * A32[a11]);
-      }
-      const float2 c0 = CS[vj0];
-      const float v0 = fmaf(c0.x, V32[vr0], c0.y * V32[vrp0]);
-      const float2 c1 = CS[vj1];
-      const float v1 = fmaf(c1.x, V32[vr1], c1.y * V32[vrp1]);
-      wave_sync();
+      const float2 ci = CS[ti], cj = CS[tj], c0 = CS[vj0], c1 = CS[vj1];
+      const float anew = ci.x * fmaf(cj.x, e00, cj.y * e01) + ci.y * fmaf(cj.x, e10, cj.y * e11);
+      const float v0 = fmaf(c0.x, u0, c0.y * u0p);
+      const float v1 = fmaf(c1.x, u1, c1.y * u1p);
       if (lane < 45) {
         A32[aw] = anew;
         A32[awt] = anew;
@@ -312,7 +311,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   // residual correction: r = M f - rho f;  f += sum_{k != kmin} q_k (q_k . r) / (rho - lam_k);  renormalise.
   // The Jacobi basis (fp32-accurate) acts as an approximate inverse of (M - rho); the fixed point is the exact
   // fp64 eigenvector, reached at a linear rate ~ eps32 |M| / gap per iteration.
-  for (int it = 0; it < ((clamp_at < 0.f) ? 0 : kRefineIters); ++it) {
+  for (int it = 0; it < ((clamp_at < 0.f && !dbg_polish) ? 0 : kRefineIters); ++it) {
     double fn2 = 0.0;
 #pragma unroll
     for (int c = 0; c < 9; ++c) fn2 += f[c] * f[c];
@@ -377,7 +376,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   float Ff[9], U3[9], S3[3], V3[9];
 #pragma unroll
   for (int c = 0; c < 9; ++c) Ff[c] = (float)f[c];
-  svd3<float>(Ff, U3, S3, V3);
+  svd3_fast(Ff, U3, S3, V3);
   // s3 = u3^T F v3 in fp64 (stationary w.r.t. first-order errors of u3, v3), F' = F - s3 u3 v3^T
   double s3 = 0.0;
 #pragma unroll
