@@ -36,7 +36,7 @@ __constant__ unsigned char kSymC[6] = {0, 1, 2, 1, 2, 2};
 __constant__ unsigned char kPerm[9] = {8, 3, 0, 5, 2, 7, 4, 6, 1};
 
 constexpr int kWsDoubles = 216;  // per-wave workspace in LDS (1728 B, 16-B multiple): see the carve in the kernel
-constexpr int kMaxSweeps = 10;
+constexpr int kMaxSweeps = 5;  // quadratic convergence: 4-5 sweeps reach fp32 round-off; stragglers are finished by the fp64 polish
 constexpr float kJacobiTol = 1e-13f;  // fp32 sweeps stop when off(A)^2 <= tol (A is scaled to unit trace)
 constexpr int kRefineIters = 12;  // upper bound; the loop leaves as soon as the fp64 residual is at round-off level
 
