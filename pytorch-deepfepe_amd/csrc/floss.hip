@@ -14,23 +14,25 @@ namespace {
 
 constexpr int kMaxLayers = 16;
 
+// Per-point epipolar terms in fp32 (the reference computes the F-loss in fp32, train_good_utils.py:340-342) on the
+// hardware sqrt/rcp; per-lane partial sums are combined across the wave and the layers in fp64.
 struct Epi {
-  double d, dd, n1, n2, i1, i2;
-  double l1[3], l2[3];
+  float d, dd, n1, n2, i1, i2;
+  float l1[3], l2[3];
 };
 
-__device__ __forceinline__ Epi epi_terms(const double* x1, const double* x2, const double* o) {
+__device__ __forceinline__ Epi epi_terms(const float* x1, const float* x2, const float* o) {
   Epi e;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) e.l1[c] = x2[0] * o[c] + x2[1] * o[3 + c] + x2[2] * o[6 + c];
+  for (int c = 0; c < 3; ++c) e.l1[c] = fmaf(x2[0], o[c], fmaf(x2[1], o[3 + c], x2[2] * o[6 + c]));
 #pragma unroll
-  for (int r = 0; r < 3; ++r) e.l2[r] = o[3 * r] * x1[0] + o[3 * r + 1] * x1[1] + o[3 * r + 2] * x1[2];
-  e.dd = x1[0] * e.l1[0] + x1[1] * e.l1[1] + x1[2] * e.l1[2];
-  e.n1 = fast_sqrt(e.l1[0] * e.l1[0] + e.l1[1] * e.l1[1]);
-  e.n2 = fast_sqrt(e.l2[0] * e.l2[0] + e.l2[1] * e.l2[1]);
-  e.i1 = fast_rcp(e.n1 + 1e-6);
-  e.i2 = fast_rcp(e.n2 + 1e-6);
-  e.d = fabs(e.dd) * (e.i1 + e.i2);
+  for (int r = 0; r < 3; ++r) e.l2[r] = fmaf(o[3 * r], x1[0], fmaf(o[3 * r + 1], x1[1], o[3 * r + 2] * x1[2]));
+  e.dd = fmaf(x1[0], e.l1[0], fmaf(x1[1], e.l1[1], x1[2] * e.l1[2]));
+  e.n1 = __builtin_amdgcn_sqrtf(fmaf(e.l1[0], e.l1[0], e.l1[1] * e.l1[1]));
+  e.n2 = __builtin_amdgcn_sqrtf(fmaf(e.l2[0], e.l2[0], e.l2[1] * e.l2[1]));
+  e.i1 = __builtin_amdgcn_rcpf(e.n1 + 1e-6f);
+  e.i2 = __builtin_amdgcn_rcpf(e.n2 + 1e-6f);
+  e.d = fabsf(e.dd) * (e.i1 + e.i2);
   return e;
 }
 
@@ -40,10 +42,11 @@ __device__ __forceinline__ void load9(const float* p, double* m) {
   for (int c = 0; c < 9; ++c) m[c] = to_sgpr((double)p[c]);
 }
 
-__device__ __forceinline__ void eval_point(const float* v, const double* T, double* x) {
+__device__ __forceinline__ void eval_point(const float* v, const double* T, float* x) {
+  // T * pixel in fp64 (pixels ~1e3 times 2/W minus 1 cancels ~3 digits), rounded once to fp32 like the reference's pts_eval
   const double a = v[0], b = v[1], c = v[2];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) x[r] = T[3 * r] * a + T[3 * r + 1] * b + T[3 * r + 2] * c;
+  for (int r = 0; r < 3; ++r) x[r] = (float)(T[3 * r] * a + T[3 * r + 1] * b + T[3 * r + 2] * c);
 }
 
 template <bool BWD>
@@ -73,19 +76,20 @@ floss_kernel(const float* __restrict__ F_layers, int L, int B, const float* __re
   }
 
   for (int l = 0; l < L; ++l) {
-    double o[9];
-    load9(F_layers + ((size_t)l * B + pair) * 9, o);
+    float o[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) o[c] = to_sgpr(F_layers[((size_t)l * B + pair) * 9 + c]);
     if (!BWD) {
-      double acc = 0.0;
+      float accf = 0.0f;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
       for (int i = lane; i < M; i += WAVE) {
-        double x1[3], x2[3];
+        float x1[3], x2[3];
         eval_point(v1 + 3 * i, t1, x1);
         eval_point(v2 + 3 * i, t2, x2);
         const Epi e = epi_terms(x1, x2, o);
-        acc += fmin(e.d, (double)clamp_at);
+        accf += fminf(e.d, clamp_at);
       }
-      acc = wave_sum(acc);
+      const double acc = wave_sum((double)accf);
       if (lane == 0) loss_sum[(size_t)l * B + pair] = (float)acc;
     } else {
       double go[9];
@@ -98,23 +102,23 @@ floss_kernel(const float* __restrict__ F_layers, int L, int B, const float* __re
       if (has_gl) {
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
         for (int i = lane; i < M; i += WAVE) {
-          double x1[3], x2[3];
+          float x1[3], x2[3];
           eval_point(v1 + 3 * i, t1, x1);
           eval_point(v2 + 3 * i, t2, x2);
           const Epi e = epi_terms(x1, x2, o);
-          if (e.d <= (double)clamp_at) {
-            const double S = e.i1 + e.i2, ad = fabs(e.dd);
-            const double sg = (e.dd > 0.0) ? 1.0 : ((e.dd < 0.0) ? -1.0 : 0.0);
-            const double k1 = (e.n1 > 0.0) ? ad * e.i1 * e.i1 * fast_rcp(e.n1) : 0.0;
-            const double k2 = (e.n2 > 0.0) ? ad * e.i2 * e.i2 * fast_rcp(e.n2) : 0.0;
+          if (e.d <= clamp_at) {
+            const float S = e.i1 + e.i2, ad = fabsf(e.dd);
+            const float sg = (e.dd > 0.0f) ? 1.0f : ((e.dd < 0.0f) ? -1.0f : 0.0f);
+            const float k1 = (e.n1 > 0.0f) ? ad * e.i1 * e.i1 * __builtin_amdgcn_rcpf(e.n1) : 0.0f;
+            const float k2 = (e.n2 > 0.0f) ? ad * e.i2 * e.i2 * __builtin_amdgcn_rcpf(e.n2) : 0.0f;
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
               for (int c = 0; c < 3; ++c) {
-                double t = sg * S * x2[r] * x1[c];
+                float t = sg * S * x2[r] * x1[c];
                 if (c < 2) t -= k1 * e.l1[c] * x2[r];
                 if (r < 2) t -= k2 * e.l2[r] * x1[c];
-                gof[3 * r + c] += (float)t;
+                gof[3 * r + c] += t;
               }
           }
         }
