@@ -252,6 +252,9 @@ __device__ inline void svd3_fast(const float* F, float* U, float* S, float* V) {
   U[2] = sg * c0; U[5] = sg * c1; U[8] = sg * c2;
 }
 
+__device__ __forceinline__ double svd_rsqrt(double x) { return fast_rsqrt(x); }
+__device__ __forceinline__ float svd_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+
 // One-sided (Hestenes) Jacobi SVD of a 3x3 matrix: F = U diag(S) V^T, S descending, S[2] >= 0 given the
 // orientation chosen for u3.  U, V row-major with singular vectors in columns.  Straight-line code on
 // values in registers; `T` is float (forward rank-2 step, backward bookkeeping) or double (pose kernels).
@@ -273,14 +276,16 @@ __device__ inline void svd3(const T* F, T* U, T* S, T* V) {
       T al = G[p] * G[p] + G[3 + p] * G[3 + p] + G[6 + p] * G[6 + p];
       T be = G[q] * G[q] + G[3 + q] * G[3 + q] + G[6 + q] * G[6 + q];
       T ga = G[p] * G[q] + G[3 + p] * G[3 + q] + G[6 + p] * G[6 + q];
-      T lim = sqrt(al * be);
-      T rel = (lim > T(0)) ? fabs(ga) / lim : T(0);
-      worst = fmax(worst, rel);
-      if (rel > tol) {
-        T zeta = (be - al) / (T(2) * ga);
-        T t = copysign(T(1), zeta) / (fabs(zeta) + sqrt(T(1) + zeta * zeta));
-        T c = T(1) / sqrt(T(1) + t * t);
-        T s = c * t;
+      const bool rot = ga * ga > tol * tol * al * be;  // division-free skip test
+      worst = rot ? T(1) : worst;
+      if (rot) {
+        // r = 1/h, h = sqrt(d^2+b^2); x = (1 + |d|/h)/2 = cos^2; c = sqrt(x), s = sgn(d) b / (2 h c)
+        const T d = be - al, b = T(2) * ga;
+        const T rh = svd_rsqrt(d * d + b * b);
+        const T x = T(0.5) + T(0.5) * fabs(d) * rh;
+        const T y = svd_rsqrt(x);
+        const T c = x * y;
+        const T s = copysign(T(0.5), d) * b * rh * y;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
           T gp = G[3 * r + p], gq = G[3 * r + q];
@@ -292,7 +297,7 @@ __device__ inline void svd3(const T* F, T* U, T* S, T* V) {
         }
       }
     }
-    if (worst <= tol) break;
+    if (worst == T(0)) break;
   }
   T n[3];
 #pragma unroll

@@ -258,54 +258,61 @@ pose_bwd_kernel(const float* __restrict__ E_layers, int L, int B, const float* _
     for (int c = 0; c < 3; ++c) g_E[idx * 9 + 3 * r + c] = (float)gEc[3 * c + r];  // E = Ec^T
 }
 
-// loss head: one block, grid-stride over the L*B entries, block reduction in LDS (fp64)
+// loss head: one block of 1024 threads, one pass over the three [L,B] arrays with per-layer register accumulators,
+// DPP wave sums, then a 16-wave combine through LDS (two block barriers in total)
+constexpr int kHeadMaxL = 16;
 __global__ void __launch_bounds__(1024)
 loss_head_kernel(const float* __restrict__ loss_sum, const float* __restrict__ q_l2, const float* __restrict__ t_l2, int L,
                  int B, int M, float clamp_q, float clamp_t, float balance_q, float balance_t, double* __restrict__ packed,
                  float* __restrict__ scalars) {
-  __shared__ double red[16];
+  __shared__ double red[16][kHeadMaxL + 2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  double tot[3] = {0.0, 0.0, 0.0};  // sum over layers of the per-layer sums, clamped q, clamped t
-  for (int l = 0; l < L; ++l) {
-    double a = 0.0;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) a += (double)loss_sum[(size_t)l * B + b];
-    a = wave_sum(a);
-    if (lane == 0) red[wave] = a;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double s = 0.0;
-      for (int k = 0; k < nw; ++k) s += red[k];
-      packed[l] = s;
-      tot[0] += s;
-    }
-    __syncthreads();
-  }
-  double q = 0.0, t = 0.0;
-  if (q_l2 != nullptr && t_l2 != nullptr) {
-    for (size_t i = threadIdx.x; i < (size_t)L * B; i += blockDim.x) {
-      q += fmin(fmax((double)q_l2[i], 0.0), (double)clamp_q);
-      t += fmin(fmax((double)t_l2[i], 0.0), (double)clamp_t);
+  float acc[kHeadMaxL];
+#pragma unroll
+  for (int l = 0; l < kHeadMaxL; ++l) acc[l] = 0.0f;
+  float q = 0.0f, t = 0.0f;
+  const bool pose = (q_l2 != nullptr);
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+#pragma unroll
+    for (int l = 0; l < kHeadMaxL; ++l) {
+      if (l < L) {
+        acc[l] += loss_sum[(size_t)l * B + b];
+        if (pose) {
+          q += fminf(fmaxf(q_l2[(size_t)l * B + b], 0.0f), clamp_q);
+          t += fminf(fmaxf(t_l2[(size_t)l * B + b], 0.0f), clamp_t);
+        }
+      }
     }
   }
-  q = wave_sum(q);
-  t = wave_sum(t);
-  if (lane == 0) { red[wave] = q; }
+#pragma unroll
+  for (int l = 0; l < kHeadMaxL; ++l) {
+    if (l < L) {
+      const double s = wave_sum((double)acc[l]);
+      if (lane == 0) red[wave][l] = s;
+    }
+  }
+  {
+    const double sq = wave_sum((double)q), stt = wave_sum((double)t);
+    if (lane == 0) { red[wave][kHeadMaxL] = sq; red[wave][kHeadMaxL + 1] = stt; }
+  }
   __syncthreads();
-  if (threadIdx.x == 0) { double s = 0.0; for (int k = 0; k < nw; ++k) s += red[k]; tot[1] = s; }
-  __syncthreads();
-  if (lane == 0) { red[wave] = t; }
+  if (threadIdx.x < kHeadMaxL + 2) {
+    double s = 0.0;
+    for (int k = 0; k < nw; ++k) s += red[k][threadIdx.x];
+    red[0][threadIdx.x] = s;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double s = 0.0;
-    for (int k = 0; k < nw; ++k) s += red[k];
-    tot[2] = s;
-    packed[L] = tot[1];
-    packed[L + 1] = tot[2];
+    double totF = 0.0;
+    for (int l = 0; l < L; ++l) { packed[l] = red[0][l]; totF += red[0][l]; }
+    const double tq = red[0][kHeadMaxL], tt = red[0][kHeadMaxL + 1];
+    packed[L] = tq;
+    packed[L + 1] = tt;
     packed[L + 2] = (double)B;
     packed[L + 3] = (double)M;
     const double n = (double)B;
-    const double loss_F = tot[0] / (n * (double)M * (double)L);
-    const double loss_qt = (tot[1] * (double)balance_q + tot[2] * (double)balance_t) / (n * (double)L);
+    const double loss_F = totF / (n * (double)M * (double)L);
+    const double loss_qt = (tq * (double)balance_q + tt * (double)balance_t) / (n * (double)L);
     scalars[0] = (float)(loss_F + loss_qt);
     scalars[1] = (float)loss_F;
     scalars[2] = (float)loss_qt;
@@ -317,7 +324,7 @@ loss_head_kernel(const float* __restrict__ loss_sum, const float* __restrict__ q
 
 extern "C" int dfepe_loss_head(const float* loss_sum, const float* q_l2, const float* t_l2, int L, int B, int M, float clamp_q,
                                float clamp_t, float balance_q, float balance_t, double* packed, float* scalars, void* stream) {
-  if (L <= 0 || B <= 0 || M <= 0) return DFEPE_ERR_INVALID_ARG;
+  if (L <= 0 || L > kHeadMaxL || B <= 0 || M <= 0) return DFEPE_ERR_INVALID_ARG;
   if (!loss_sum || !packed || !scalars || ((q_l2 == nullptr) != (t_l2 == nullptr))) return DFEPE_ERR_INVALID_ARG;
   hipLaunchKernelGGL(loss_head_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), loss_sum, q_l2, t_l2, L, B, M,
                      clamp_q, clamp_t, balance_q, balance_t, packed, scalars);

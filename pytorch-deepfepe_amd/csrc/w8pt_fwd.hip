@@ -89,6 +89,9 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   float* P = reinterpret_cast<float*>(base + kWsDoubles * sizeof(double));
   float* W = P + (RAW ? 4 : 6) * npad;
 
+  // phase timestamps (shader clock) for the diagnostics slots of the save record
+  long long tstamp[8];
+  tstamp[0] = __builtin_amdgcn_s_memtime();
   // ---- phase 0: stage the pair in LDS, coordinate sums ------------------------------------------
   double sx1 = 0, sy1 = 0, sx2 = 0, sy2 = 0;
   const float* wsrc = wts + (size_t)pair * N;
@@ -144,6 +147,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   const double c2x = to_sgpr(wave_sum(sx2) * invN), c2y = to_sgpr(wave_sum(sy2) * invN);
   wave_sync();
 
+  tstamp[1] = __builtin_amdgcn_s_memtime();
   // ---- phase 1: Hartley scale -------------------------------------------------------------------
   double d1 = 0, d2 = 0;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
@@ -157,6 +161,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   const double s1 = to_sgpr(1.4142 / (wave_sum(d1) * invN));  // the reference uses the literal, not sqrt(2) (DeepFNet.py:168)
   const double s2 = to_sgpr(1.4142 / (wave_sum(d2) * invN));
 
+  tstamp[2] = __builtin_amdgcn_s_memtime();
   // ---- phase 2: X^T X as 36 distinct fp64 sums per lane (exact products of fp32-derived factors) ---------
   double acc[36];
 #pragma unroll
@@ -181,6 +186,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     }
   }
 
+  tstamp[3] = __builtin_amdgcn_s_memtime();
   // ---- phase 3: reduce-scatter across the wave; lane ends up owning (at most) one distinct sum -------------
   halve<36>(acc, lane & 32, 32);
   halve<18>(acc, lane & 16, 16);
@@ -210,6 +216,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   }
   wave_sync();
 
+  tstamp[4] = __builtin_amdgcn_s_memtime();
   // ---- phase 4a: fp32 Jacobi on M / trace(M) ----------------------------------------------------------
   // A' = J^T A J, V' = V J with J_pp = J_qq = c, J_pq = s, J_qp = -s for the pairs (p,q) = (0,1),(2,3),(4,5),(6,7)
   // of *positions*; position 8 sits out.  Per position k we keep (c_k, sh_k), sh_p = -s, sh_q = +s, so that
@@ -287,6 +294,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     }
   }
 
+  tstamp[5] = __builtin_amdgcn_s_memtime();
   // ---- phase 4b: pick the eigenpair the reference picks, polish it in fp64 ----------------------------
   // torch.svd(X)[2][:, -1] is the right singular vector of the smallest of the min(N,9) singular values
   // (DeepFNet.py:232-233): for N >= 9 the smallest eigenvalue of X^T X; for N < 9 the reduced SVD has only N
@@ -359,6 +367,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     wave_sync();
   }
 
+  tstamp[6] = __builtin_amdgcn_s_memtime();
   // ---- phase 5: rank-2 projection, de-normalisation (wave-uniform arithmetic) ------------------------------
   double fn2 = 0.0;
 #pragma unroll
@@ -410,6 +419,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 #pragma unroll
     for (int c = 0; c < 9; ++c) dst[c] = of[c];
   }
+  tstamp[7] = __builtin_amdgcn_s_memtime();
   if (save != nullptr) {
     float* sv = save + (size_t)pair * DFEPE_SAVE_FLOATS;
     // the polished, oriented f replaces its Jacobi column in the record; staged through LDS so that no register
@@ -439,7 +449,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
       sv[119] = (float)n_sweeps;  // diagnostics: Jacobi sweeps and polish iterations actually run
       sv[120] = (float)n_refine;
 #pragma unroll
-      for (int c = 121; c < DFEPE_SAVE_FLOATS; ++c) sv[c] = 0.0f;
+      for (int c = 0; c < 7; ++c) sv[121 + c] = (float)(tstamp[c + 1] - tstamp[c]);  // cycles spent in phases 0,1,2,3,4a,4b,5
     }
   }
 
