@@ -40,6 +40,13 @@ extern "C" {
 #define DFEPE_W8PT_LOGITS 2u      /* `weights` holds logits [B,N]; softmax over N (F.softmax(logits, dim=2),
                                      DeepFNet.py:443,512) is fused in and the weights are written to `weights_out`;
                                      the backward then returns the gradient w.r.t. the logits                */
+/* variants of the textbook normalised 8-point solvers of dsac_tools (forward only):                         */
+#define DFEPE_W8PT_SQRT2 4u       /* Hartley scale sqrt(2) (utils_F._normalize_XY, utils_F.py:23) instead of the
+                                     literal 1.4142 of Fit.normalize                                         */
+#define DFEPE_W8PT_NO_ROWNORM 8u  /* rows of the design matrix are not normalised to unit length
+                                     (utils_F._E_from_XY / _F_from_XY, utils_F.py:122-130,239-247)           */
+#define DFEPE_W8PT_FORCE_110 16u  /* singular values of the 3x3 forced to (1,1,0) instead of (s1,s2,0)
+                                     (utils_F._E_from_XY, utils_F.py:148-149)                                */
 
 int dfepe_version(void);
 const char *dfepe_strerror(int code);

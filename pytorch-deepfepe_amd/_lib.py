@@ -15,6 +15,9 @@ LIB_PATH = os.path.join(_HERE, "libdfepe_hip.so")
 OK = 0
 W8PT_RAW_MATCHES = 1
 W8PT_LOGITS = 2
+W8PT_SQRT2 = 4
+W8PT_NO_ROWNORM = 8
+W8PT_FORCE_110 = 16
 
 _P = c_void_p
 _SIGNATURES = {

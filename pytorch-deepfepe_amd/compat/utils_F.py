@@ -102,9 +102,34 @@ def _E_to_M_train(E_est_th, K, x1, x2, inlier_mask=None, delta_Rt_gt_cam=None, d
     return [], error_Rt, Rt_cam
 
 
-def _E_from_XY(*args, **kwargs):
-    raise NotImplementedError("_E_from_XY (textbook 8-point on K^-1 points, utils_F.py:104-155) is a 'next' row of SURVEY.md §8 and is not built yet")
+def _diag_weights(W, N):
+    """The reference left-multiplies the design matrix by a dense W [N,N] (utils_F.py:129-130); its callers pass
+    torch.diag(w) (train_good_utils.get_E_ests).  Only diagonal W is built: it is a per-correspondence weight."""
+    if W is None:
+        return None
+    W = _gpu(W)
+    if W.dim() == 1:
+        return W
+    off = W - torch.diag(torch.diagonal(W))
+    if float(off.abs().max()) != 0.0:
+        raise NotImplementedError("dense (non-diagonal) W is not built; pass torch.diag(w) or the weight vector")
+    return torch.diagonal(W)
 
 
-def _F_from_XY(*args, **kwargs):
-    raise NotImplementedError("_F_from_XY (utils_F.py:223-275) is a 'next' row of SURVEY.md §8 and is not built yet")
+def _F_from_XY(X, Y, W=None, normalize=True, show_debug=False):
+    """Normalised 8-point fundamental matrix from X, Y [N,2] (utils_F.py:223-275); sign follows this library's gauge."""
+    X, Y = _gpu(X), _gpu(Y)
+    w = _diag_weights(W, X.shape[0])
+    return ops.eight_point(X.unsqueeze(0), Y.unsqueeze(0), None if w is None else w.unsqueeze(0), essential=False, normalize=normalize)[0]
+
+
+def _E_from_XY(X, Y, K, W=None, if_normzliedK=False, normalize=True, show_debug=False):
+    """Normalised 8-point essential matrix (utils_F.py:104-155): K^-1 points, sqrt(2) Hartley, singular values (1,1,0)."""
+    X, Y = _gpu(X), _gpu(Y)
+    if not if_normzliedK:
+        Ki = torch.linalg.inv(_gpu(K))
+        ones = torch.ones(X.shape[0], 1, device=X.device)
+        Xh, Yh = torch.cat((X, ones), 1) @ Ki.t(), torch.cat((Y, ones), 1) @ Ki.t()
+        X, Y = Xh[:, :2] / (Xh[:, 2:3] + 1e-10), Yh[:, :2] / (Yh[:, 2:3] + 1e-10)  # _de_homo (utils_misc.py:69-78)
+    w = _diag_weights(W, X.shape[0])
+    return ops.eight_point(X.unsqueeze(0), Y.unsqueeze(0), None if w is None else w.unsqueeze(0), essential=True, normalize=normalize)[0]

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256, 4)
 w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, const float* __restrict__ wts,
                 int B, int N, int npad, int wave_bytes, float hw_sx, float hw_sy, float clamp_at,
                 float* __restrict__ F_out, float* __restrict__ residual, float* __restrict__ epi_res,
-                float* __restrict__ save, float* __restrict__ weights_out, int logits_mode) {
+                float* __restrict__ save, float* __restrict__ weights_out, int logits_mode, unsigned variant) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -158,8 +158,10 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     d1 += fast_sqrt(ax * ax + ay * ay);
     d2 += fast_sqrt(bx * bx + by * by);
   }
-  const double s1 = to_sgpr(1.4142 / (wave_sum(d1) * invN));  // the reference uses the literal, not sqrt(2) (DeepFNet.py:168)
-  const double s2 = to_sgpr(1.4142 / (wave_sum(d2) * invN));
+  // Fit.normalize uses the literal 1.4142, not sqrt(2) (DeepFNet.py:168); utils_F._normalize_XY uses np.sqrt(2)
+  const double hscale = (variant & DFEPE_W8PT_SQRT2) ? 1.4142135623730951 : 1.4142;
+  const double s1 = to_sgpr(hscale / (wave_sum(d1) * invN));
+  const double s2 = to_sgpr(hscale / (wave_sum(d2) * invN));
 
   tstamp[2] = __builtin_amdgcn_s_memtime();
   // ---- phase 2: X^T X as 36 distinct fp64 sums per lane (exact products of fp32-derived factors) ---------
@@ -175,7 +177,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     const double b0 = s2 * ((double)p.x2 - c2x * z2), b1 = s2 * ((double)p.y2 - c2y * z2);
     const double n2 = (a0 * a0 + a1 * a1 + a2 * a2) * (b0 * b0 + b1 * b1 + 1.0);  // |p|^2
     const bool ok = (n2 < 1e300) && (fabs(w) < 1e150);
-    const double k2 = ok ? (w * w) * fast_rcp(fmax(n2, 1e-24)) : 0.0;                        // (w / max(|p|,1e-12))^2
+    const double k2 = ok ? ((variant & DFEPE_W8PT_NO_ROWNORM) ? (w * w) : (w * w) * fast_rcp(fmax(n2, 1e-24))) : 0.0;                        // (w / max(|p|,1e-12))^2
     const double aa[6] = {a0 * a0, a0 * a1, a0 * a2, a1 * a1, a1 * a2, a2 * a2};
     const double bb[6] = {k2 * b0 * b0, k2 * b0 * b1, k2 * b0, k2 * b1 * b1, k2 * b1, k2};
     if (ok) {
@@ -397,6 +399,13 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int c = 0; c < 3; ++c) Fp[3 * r + c] = f[3 * r + c] - s3 * (double)U3[3 * r + 2] * (double)V3[3 * c + 2];
+  if (variant & DFEPE_W8PT_FORCE_110) {  // E' = U diag(1,1,0) V^T = u1 v1^T + u2 v2^T  (utils_F.py:148-149)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        Fp[3 * r + c] = (double)U3[3 * r] * (double)V3[3 * c] + (double)U3[3 * r + 1] * (double)V3[3 * c + 1];
+  }
   // out = T2^T F' T1,  T = [[s,0,-s cx],[0,s,-s cy],[0,0,1]]
   double Mx[9], out[9];
 #pragma unroll
@@ -491,7 +500,9 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
                               float* residual, float* epi_res, float* save, float* weights_out, void* stream) {
   const bool raw = (flags & DFEPE_W8PT_RAW_MATCHES) != 0;
   const int logits_mode = (flags & DFEPE_W8PT_LOGITS) ? 1 : 0;
+  const unsigned variant = flags & (DFEPE_W8PT_SQRT2 | DFEPE_W8PT_NO_ROWNORM | DFEPE_W8PT_FORCE_110);
   if (B < 0 || N <= 0) return DFEPE_ERR_INVALID_ARG;
+  if (variant && save) return DFEPE_ERR_UNSUPPORTED;  // the textbook variants are forward-only
   if (B == 0) return DFEPE_OK;
   if (!pts1 || (!raw && !pts2) || !weights || !F_out || !residual) return DFEPE_ERR_INVALID_ARG;
   if (raw && !(image_w > 0.f && image_h > 0.f)) return DFEPE_ERR_INVALID_ARG;
@@ -499,10 +510,16 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
 
   const int npad = (N + 3) & ~3;
   const int wave_bytes = kWsDoubles * (int)sizeof(double) + (raw ? 5 : 7) * npad * (int)sizeof(float);
-  int waves = 4;
+  // waves per block: 4 when at least 16 wavefronts fit a CU's 160 KiB anyway, otherwise whichever of {4,2,1} keeps the
+  // most wavefronts resident (at N = 1000 a pair needs 21.7 KB: 1-wave blocks give 7 per CU, 4-wave blocks only 4)
   const int lds_cap = 160 * 1024;
-  while (waves > 1 && waves * wave_bytes > lds_cap) waves >>= 1;
-  if (waves * wave_bytes > lds_cap) return DFEPE_ERR_UNSUPPORTED;  // N > ~8000 (raw) / ~5800 (pts): not staged in LDS yet
+  if (wave_bytes > lds_cap) return DFEPE_ERR_UNSUPPORTED;  // N > ~8000 (raw) / ~5800 (pts): not staged in LDS yet
+  int waves = 4, best = 0;
+  for (int wv = 4; wv >= 1; wv >>= 1) {
+    const int resident = (lds_cap / (wv * wave_bytes)) * wv;
+    if (resident >= 16) { waves = wv; break; }
+    if (resident > best) { best = resident; waves = wv; }
+  }
   const size_t lds = (size_t)waves * wave_bytes;
   const dim3 grid((B + waves - 1) / waves), block(64 * waves);
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -515,7 +532,7 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
       if (err != hipSuccess) return DFEPE_ERR_HIP;
     }
     hipLaunchKernelGGL(w8pt_fwd_kernel<true>, grid, block, lds, st, pts1, pts2, weights, B, N, npad, wave_bytes,
-                       hw_sx, hw_sy, clamp_at, F_out, residual, epi_res, save, weights_out, logits_mode);
+                       hw_sx, hw_sy, clamp_at, F_out, residual, epi_res, save, weights_out, logits_mode, variant);
   } else {
     if (lds > 64 * 1024) {
       err = hipFuncSetAttribute(reinterpret_cast<const void*>(&w8pt_fwd_kernel<false>),
@@ -523,7 +540,7 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
       if (err != hipSuccess) return DFEPE_ERR_HIP;
     }
     hipLaunchKernelGGL(w8pt_fwd_kernel<false>, grid, block, lds, st, pts1, pts2, weights, B, N, npad, wave_bytes,
-                       hw_sx, hw_sy, clamp_at, F_out, residual, epi_res, save, weights_out, logits_mode);
+                       hw_sx, hw_sy, clamp_at, F_out, residual, epi_res, save, weights_out, logits_mode, variant);
   }
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }

@@ -73,6 +73,28 @@ def w8pt_backward(pts1, pts2, weights, raw, image_w, image_h, clamp_at, save, F,
     return gW
 
 
+def eight_point(X: Tensor, Y: Tensor, w: Optional[Tensor], essential: bool, normalize: bool = True) -> Tensor:
+    """Textbook normalised 8-point on 2-D points X, Y [B,N,2] with optional per-correspondence weights [B,N]
+    (utils_F._F_from_XY / _E_from_XY after the K^-1 step): sqrt(2) Hartley, unnormalised rows, S3 -> 0 or (1,1,0)."""
+    if not normalize:
+        raise NotImplementedError("normalize=False is not built")
+    X, Y = _prep(X, "X"), _prep(Y, "Y")
+    B, N = X.shape[0], X.shape[1]
+    ones = torch.ones(B, N, 1, device=X.device)
+    p1 = torch.cat((X, ones), 2).contiguous()
+    p2 = torch.cat((Y, ones), 2).contiguous()
+    wt = torch.ones(B, N, device=X.device) if w is None else _prep(w.reshape(B, N), "w")
+    L = _lib.lib()
+    F = torch.empty(B, 3, 3, device=X.device)
+    residual = torch.empty(B, N, device=X.device)
+    flags = _lib.W8PT_SQRT2 | _lib.W8PT_NO_ROWNORM | (_lib.W8PT_FORCE_110 if essential else 0)
+    with torch.cuda.device(X.device):
+        rc = L.dfepe_w8pt_fwd(_ptr(p1), _ptr(p2), _ptr(wt), B, N, flags, 0.0, 0.0, 0.5, _ptr(F), _ptr(residual), None, None, None,
+                              _stream())
+    _lib.check(rc, "dfepe_w8pt_fwd")
+    return F
+
+
 def _cf(t: Optional[Tensor]) -> Optional[Tensor]:
     return None if t is None else t.contiguous().float()
 

@@ -154,8 +154,14 @@ def test_dsac_tools_functions_match_reference_golden(dfepe, golden):
     for b in range(8):
         t_cam = np.linalg.inv(g["delta_Rtijs_4_4"][b])[:3, 3]
         assert abs(uG.vector_angle(g["M2s_t"][b], t_cam) - g["vec_angle"][b]) < 2e-2
+    # textbook 8-point variants (same kernel, flags): fp32 inputs vs the reference's fp64 run
+    Kd = K.double()
+    for ours, key in ((uF._F_from_XY(x1[0], x2[0]), "F_from_XY"), (uF._E_from_XY(x1[0], x2[0], K), "E_from_XY"),
+                      (uF._E_from_XY(x1[0], x2[0], K, W=torch.diag(T(g["W_diag"]).to(DEV))), "E_from_XY_W")):
+        a, r, _ = unit_align(ours.cpu().numpy()[None], g[key][None])
+        assert np.abs(a - r).max() < 5e-4, (key, np.abs(a - r).max())
     with pytest.raises(NotImplementedError):
-        uF._F_from_XY(x1[0], x2[0])
+        uF._F_from_XY(x1[0], x2[0], W=torch.ones(64, 64, device=DEV))
 
 
 def test_compute_epi_residual_standalone(dfepe, oracle, golden):
