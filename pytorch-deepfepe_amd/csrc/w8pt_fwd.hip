@@ -83,9 +83,9 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   unsigned char* base = smem + (size_t)wave * wave_bytes;
   double* M64 = reinterpret_cast<double*>(base);            // [81] X^T X, fp64, natural index order      0..648
   double* SCR = M64 + 81;                                   // [32] exchange scratch for the refinement  648..904
-  float* A32 = reinterpret_cast<float*>(base + 904);        // [81] Jacobi iterate (position space)       904..1228
-  float* V32 = A32 + 81;                                    // [81] accumulated rotations                1228..1552
-  float2* CS = reinterpret_cast<float2*>(base + 1552);      // [9]  (c, signed s) per position           1552..1624
+  float* A32 = reinterpret_cast<float*>(base + 904);        // [9][10] Jacobi iterate (position space, row stride 10) 904..1264
+  float* V32 = A32 + 90;                                    // [9][10] accumulated rotations                        1264..1624
+  float2* CS = reinterpret_cast<float2*>(base + 1624);      // [9]  (c, signed s) per position                      1624..1696
   float* P = reinterpret_cast<float*>(base + kWsDoubles * sizeof(double));
   float* W = P + (RAW ? 4 : 6) * npad;
 
@@ -229,27 +229,35 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 #pragma unroll
   for (int k = 0; k < 9; ++k) tr += M64[k * 10];
   const double inv_tr = (tr > 0.0) ? 1.0 / tr : 1.0;
-  {
-    const float a0 = (float)(M64[lane] * inv_tr);
-    A32[lane] = a0;
-    V32[lane] = (lane % 10 == 0) ? 1.0f : 0.0f;  // identity: element e is diagonal iff e % 10 == 0
-    if (lane < 17) {
-      A32[lane + 64] = (float)(M64[lane + 64] * inv_tr);
-      V32[lane + 64] = ((lane + 64) % 10 == 0) ? 1.0f : 0.0f;
+  // A32/V32 are stored with a row stride of 10 floats so that the column pair (2m, 2m+1) of any row is one aligned
+  // 8-byte word: one ds_read_b64 fetches an element together with its rotation partner.
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e = lane + 64 * k;
+    if (e < 90) {
+      const int i = e / 10, j = e % 10;
+      A32[e] = (j < 9) ? (float)(M64[i * 9 + j] * inv_tr) : 0.0f;
+      V32[e] = (i == j) ? 1.0f : 0.0f;
     }
-    if (lane == 8) CS[8] = make_float2(1.0f, 0.0f);
   }
-  // loop-invariant addresses
-  const int ti = (lane < 45) ? kTriI[lane] : 0;
-  const int tj = (lane < 45) ? kTriJ[lane] : 0;
-  const int tip = (ti < 8) ? (ti ^ 1) : 8, tjp = (tj < 8) ? (tj ^ 1) : 8;
-  const int a00 = ti * 9 + tj, a01 = ti * 9 + tjp, a10 = tip * 9 + tj, a11 = tip * 9 + tjp;
-  const int aw = kPerm[ti] * 9 + kPerm[tj], awt = kPerm[tj] * 9 + kPerm[ti];
-  const int vi0 = lane / 9, vj0 = lane % 9, vjp0 = (vj0 < 8) ? (vj0 ^ 1) : 8;
-  const int e1 = (lane < 17) ? lane + 64 : 0;
-  const int vi1 = e1 / 9, vj1 = e1 % 9, vjp1 = (vj1 < 8) ? (vj1 ^ 1) : 8;
-  const int vr0 = vi0 * 9 + vj0, vrp0 = vi0 * 9 + vjp0, vw0 = vi0 * 9 + kPerm[vj0];
-  const int vr1 = vi1 * 9 + vj1, vrp1 = vi1 * 9 + vjp1, vw1 = vi1 * 9 + kPerm[vj1];
+  if (lane == 8) CS[8] = make_float2(1.0f, 0.0f);  // position 8 sits out: identity rotation
+  // Work items of a round.  Slot 1: V elements 0..63 (one per lane).  Slot 2: the 45 upper-triangular A elements on
+  // lanes 0..44 and the 17 remaining V elements on lanes 45..61 -- a V element is the special case (c_i, s_i) = (1, 0)
+  // of the two-sided update, so both kinds run the same instruction stream.  All addresses are loop-invariant.
+  const bool is_a = lane < 45, is_v2 = (lane >= 45 && lane < 62);
+  const int ti = is_a ? kTriI[lane] : (is_v2 ? (lane + 19) / 9 : 0);   // V element e = 64 + (lane - 45) = lane + 19
+  const int tj = is_a ? kTriJ[lane] : (is_v2 ? (lane + 19) % 9 : 0);
+  const int tip = (ti < 8) ? (ti ^ 1) : 8;
+  const int mat2 = is_a ? 0 : 90;                       // slot-2 matrix base (A32 or V32), in floats from A32
+  const int rd_own = mat2 + ti * 10 + (tj & ~1);         // float2 {even column, odd column} of my row
+  const int rd_par = is_a ? tip * 10 + (tj & ~1) : rd_own;  // same column pair in the partner row (A only)
+  const bool odd2 = (tj & 1) != 0;
+  const int ci_idx = is_a ? ti : 8;                      // V items: identity row rotation
+  const int wr2 = is_a ? kPerm[ti] * 10 + kPerm[tj] : mat2 + ti * 10 + kPerm[tj];
+  const int wr2t = kPerm[tj] * 10 + kPerm[ti];           // mirror (A items only)
+  const int vi0 = lane / 9, vj0 = lane % 9;
+  const int rd_v = vi0 * 10 + (vj0 & ~1), wr_v = vi0 * 10 + kPerm[vj0];
+  const bool odd1 = (vj0 & 1) != 0;
   const int pp = (lane < 8) ? (lane & ~1) : 0;  // lanes 0..7: my pair is positions (pp, pp+1)
   wave_sync();
   int n_sweeps = 0, n_refine = 0;
@@ -258,40 +266,40 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   const int max_sweeps = (clamp_at < 0.f) ? (int)(-clamp_at) - (dbg_polish ? 51 : 1) : kMaxSweeps;
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     float off = 0.0f;
-    if (lane < 45 && ti != tj) {
-      const float a = A32[a00];
+    if (is_a && ti != tj) {
+      const float a = A32[ti * 10 + tj];
       off = a * a;
     }
     off = wave_sum(off);
     if (!(off > kJacobiTol) && !(clamp_at < 0.f)) break;  // wave-uniform (also leaves on NaN)
     ++n_sweeps;
     for (int r = 0; r < 9; ++r) {
-      // every read of the round is issued up front (none of them depends on this round's rotations), so the round
-      // costs two LDS round trips plus the (c,s) exchange instead of five
-      float e00 = 0.f, e01 = 0.f, e10 = 0.f, e11 = 0.f;
-      if (lane < 45) { e00 = A32[a00]; e01 = A32[a01]; e10 = A32[a10]; e11 = A32[a11]; }
-      const float u0 = V32[vr0], u0p = V32[vrp0], u1 = V32[vr1], u1p = V32[vrp1];
+      // every read of the round is issued up front (none depends on this round's rotations): 4 x ds_read_b64 + the
+      // rotation inputs, then the (c,s) exchange through CS, then 3-4 ds_write_b32
+      const float2 own = *reinterpret_cast<const float2*>(A32 + rd_own);
+      const float2 par = *reinterpret_cast<const float2*>(A32 + rd_par);
+      const float2 vv = *reinterpret_cast<const float2*>(V32 + rd_v);
       if (lane < 8) {
-        const float app = A32[pp * 10], aqq = A32[pp * 10 + 10], apq = A32[pp * 9 + pp + 1];
-        const float d = aqq - app, b = 2.0f * apq;
+        const float2 pq = *reinterpret_cast<const float2*>(A32 + pp * 11);  // {A[p][p], A[p][p+1]}
+        const float aqq = A32[pp * 11 + 11];
+        const float d = aqq - pq.x, b = 2.0f * pq.y;
         const float h = __builtin_amdgcn_sqrtf(fmaf(d, d, b * b));
         const float t = b * __builtin_amdgcn_rcpf(d + copysignf(h, d));
         float c = __builtin_amdgcn_rsqf(fmaf(t, t, 1.0f));
         float sn = t * c;
-        if (apq == 0.0f) { c = 1.0f; sn = 0.0f; }  // also catches 0/0
+        if (pq.y == 0.0f) { c = 1.0f; sn = 0.0f; }  // also catches 0/0
         CS[lane] = make_float2(c, (lane & 1) ? sn : -sn);
       }
       wave_sync();
-      const float2 ci = CS[ti], cj = CS[tj], c0 = CS[vj0], c1 = CS[vj1];
-      const float anew = ci.x * fmaf(cj.x, e00, cj.y * e01) + ci.y * fmaf(cj.x, e10, cj.y * e11);
+      const float2 ci = CS[ci_idx], cj = CS[tj], c0 = CS[vj0];
+      const float e00 = odd2 ? own.y : own.x, e01 = odd2 ? own.x : own.y;
+      const float e10 = odd2 ? par.y : par.x, e11 = odd2 ? par.x : par.y;
+      const float new2 = ci.x * fmaf(cj.x, e00, cj.y * e01) + ci.y * fmaf(cj.x, e10, cj.y * e11);
+      const float u0 = odd1 ? vv.y : vv.x, u0p = odd1 ? vv.x : vv.y;
       const float v0 = fmaf(c0.x, u0, c0.y * u0p);
-      const float v1 = fmaf(c1.x, u1, c1.y * u1p);
-      if (lane < 45) {
-        A32[aw] = anew;
-        A32[awt] = anew;
-      }
-      V32[vw0] = v0;
-      if (lane < 17) V32[vw1] = v1;
+      if (is_a || is_v2) A32[wr2] = new2;
+      if (is_a) A32[wr2t] = new2;
+      V32[wr_v] = v0;
       wave_sync();
     }
   }
@@ -304,7 +312,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   // eigenvalues are passed over (ascending order, index as tie-break) to mirror that.
   float lam32[9];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) lam32[k] = A32[k * 10];
+  for (int k = 0; k < 9; ++k) lam32[k] = A32[k * 11];
   const int skip = (N < 9) ? 9 - N : 0;
   int kmin = 0;
 #pragma unroll
@@ -316,7 +324,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   }
   double f[9];
 #pragma unroll
-  for (int c = 0; c < 9; ++c) f[c] = (double)V32[c * 9 + kmin];
+  for (int c = 0; c < 9; ++c) f[c] = (double)V32[c * 10 + kmin];
   double rho = (double)lam32[kmin] * tr;
   // residual correction: r = M f - rho f;  f += sum_{k != kmin} q_k (q_k . r) / (rho - lam_k);  renormalise.
   // The Jacobi basis (fp32-accurate) acts as an approximate inverse of (M - rho); the fixed point is the exact
@@ -349,8 +357,8 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     if (lane < 9) {
       double dot = 0.0;
 #pragma unroll
-      for (int c = 0; c < 9; ++c) dot += (double)V32[c * 9 + lane] * r[c];
-      double den = rho - (double)A32[lane * 10] * tr;
+      for (int c = 0; c < 9; ++c) dot += (double)V32[c * 10 + lane] * r[c];
+      double den = rho - (double)A32[lane * 11] * tr;
       const double lim = 1e-12 * tr;
       if (fabs(den) < lim) den = (den < 0.0) ? -lim : lim;
       SCR[16 + lane] = (lane == kmin) ? 0.0 : dot / den;
@@ -360,7 +368,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     if (lane < 9) {
       double dsum = 0.0;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) dsum += SCR[16 + k] * (double)V32[lane * 9 + k];
+      for (int k = 0; k < 9; ++k) dsum += SCR[16 + k] * (double)V32[lane * 10 + k];
       SCR[lane] = dsum;
     }
     wave_sync();
@@ -440,13 +448,13 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     wave_sync();
     {
       const int k = lane / 9, c = lane % 9;
-      sv[SV_Q + lane] = (k == kmin) ? (float)SCR[c] : V32[c * 9 + k];
+      sv[SV_Q + lane] = (k == kmin) ? (float)SCR[c] : V32[c * 10 + k];
     }
     if (lane < 17) {
       const int e = lane + 64, k = e / 9, c = e % 9;
-      sv[SV_Q + e] = (k == kmin) ? (float)SCR[c] : V32[c * 9 + k];
+      sv[SV_Q + e] = (k == kmin) ? (float)SCR[c] : V32[c * 10 + k];
     }
-    if (lane < 9) sv[SV_LAM + lane] = (lane == kmin) ? (float)rho : (float)((double)A32[lane * 10] * tr);
+    if (lane < 9) sv[SV_LAM + lane] = (lane == kmin) ? (float)rho : (float)((double)A32[lane * 11] * tr);
     if (lane == 0) {
       sv[SV_T1 + 0] = (float)s1; sv[SV_T1 + 1] = (float)c1x; sv[SV_T1 + 2] = (float)c1y;
       sv[SV_T2 + 0] = (float)s2; sv[SV_T2 + 1] = (float)c2x; sv[SV_T2 + 2] = (float)c2y;
