@@ -54,8 +54,11 @@ __device__ __forceinline__ Pt lds_point(const float* P, int i, int npad) {
   return p;
 }
 
-// One halving step of the reduce-scatter: CNT live values per lane -> (CNT+1)/2.
-template <int CNT>
+// One halving step of the reduce-scatter: CNT live values per lane -> (CNT+1)/2.  The partner is lane^MASK through
+// ds_bpermute for the two cross-row steps (MASK 32, 16) and a DPP reflection / quad permute inside a 16-lane row
+// (row_mirror pairs k with 15-k, row_half_mirror k with 7-k, quad_perm for xor 2 and xor 1): any pairing works as long
+// as the two partners sit on opposite sides of the decision bit, which all of these do.
+template <int CNT, int DPP_CTRL>
 __device__ __forceinline__ void halve(double* a, bool upper, int mask) {
   constexpr int H = (CNT + 1) / 2;
 #pragma unroll
@@ -64,7 +67,8 @@ __device__ __forceinline__ void halve(double* a, bool upper, int mask) {
     const double hi = (k + H < CNT) ? a[k + H] : 0.0;
     const double send = upper ? lo : hi;
     const double keep = upper ? hi : lo;
-    a[k] = keep + __shfl_xor(send, mask, WAVE);
+    const double got = (DPP_CTRL == 0) ? __shfl_xor(send, mask, WAVE) : dpp_f64<(DPP_CTRL == 0) ? 0xB1 : DPP_CTRL>(send);
+    a[k] = keep + got;
   }
 }
 
@@ -160,8 +164,8 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   }
   // Fit.normalize uses the literal 1.4142, not sqrt(2) (DeepFNet.py:168); utils_F._normalize_XY uses np.sqrt(2)
   const double hscale = (variant & DFEPE_W8PT_SQRT2) ? 1.4142135623730951 : 1.4142;
-  const double s1 = to_sgpr(hscale / (wave_sum(d1) * invN));
-  const double s2 = to_sgpr(hscale / (wave_sum(d2) * invN));
+  const double s1 = to_sgpr(hscale * fast_rcp(wave_sum(d1) * invN));
+  const double s2 = to_sgpr(hscale * fast_rcp(wave_sum(d2) * invN));
 
   tstamp[2] = __builtin_amdgcn_s_memtime();
   // ---- phase 2: X^T X as 36 distinct fp64 sums per lane (exact products of fp32-derived factors) ---------
@@ -190,12 +194,12 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 
   tstamp[3] = __builtin_amdgcn_s_memtime();
   // ---- phase 3: reduce-scatter across the wave; lane ends up owning (at most) one distinct sum -------------
-  halve<36>(acc, lane & 32, 32);
-  halve<18>(acc, lane & 16, 16);
-  halve<9>(acc, lane & 8, 8);
-  halve<5>(acc, lane & 4, 4);
-  halve<3>(acc, lane & 2, 2);
-  halve<2>(acc, lane & 1, 1);
+  halve<36, 0>(acc, lane & 32, 32);
+  halve<18, 0>(acc, lane & 16, 16);
+  halve<9, 0x140>(acc, lane & 8, 8);   // row_mirror
+  halve<5, 0x141>(acc, lane & 4, 4);   // row_half_mirror
+  halve<3, 0x4E>(acc, lane & 2, 2);    // quad_perm [2,3,0,1]
+  halve<2, 0xB1>(acc, lane & 1, 1);    // quad_perm [1,0,3,2]
   {
     // mirror the fixed halving schedule 36 -> 18 -> 9 -> 5 -> 3 -> 2 -> 1: `idx` is the distinct sum this lane
     // ends up owning, `cnt` how many of its slots were real data (<= 0: the lane holds padding)
@@ -228,7 +232,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   double tr = 0.0;
 #pragma unroll
   for (int k = 0; k < 9; ++k) tr += M64[k * 10];
-  const double inv_tr = (tr > 0.0) ? 1.0 / tr : 1.0;
+  const double inv_tr = (tr > 0.0) ? fast_rcp(tr) : 1.0;
   // A32/V32 are stored with a row stride of 10 floats so that the column pair (2m, 2m+1) of any row is one aligned
   // 8-byte word: one ds_read_b64 fetches an element together with its rotation partner.
 #pragma unroll
@@ -333,7 +337,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     double fn2 = 0.0;
 #pragma unroll
     for (int c = 0; c < 9; ++c) fn2 += f[c] * f[c];
-    const double fin = 1.0 / sqrt(fn2);
+    const double fin = fast_rsqrt(fn2);
 #pragma unroll
     for (int c = 0; c < 9; ++c) f[c] *= fin;
     // y = M f, one row per lane
@@ -361,7 +365,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
       double den = rho - (double)A32[lane * 11] * tr;
       const double lim = 1e-12 * tr;
       if (fabs(den) < lim) den = (den < 0.0) ? -lim : lim;
-      SCR[16 + lane] = (lane == kmin) ? 0.0 : dot / den;
+      SCR[16 + lane] = (lane == kmin) ? 0.0 : dot * fast_rcp(den);
     }
     wave_sync();
     // d_c = sum_k a_k q_k[c], one component per lane; then everybody reads the new f
@@ -388,7 +392,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   for (int c = 1; c < 9; ++c)
     if (fabs(f[c]) > fabs(big)) big = f[c];
   const double sgn = (big < 0.0) ? -1.0 : 1.0;
-  const double fscale = sgn / sqrt(fn2);
+  const double fscale = sgn * fast_rsqrt(fn2);
 #pragma unroll
   for (int c = 0; c < 9; ++c) f[c] *= fscale;
 
