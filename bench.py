@@ -82,16 +82,15 @@ def main():
     hw_T = torch.tensor([[2.0 / W, 0.0, -1.0], [0.0, 2.0 / H, -1.0], [0.0, 0.0, 1.0]], device=dev)
     logits = scene["logits_layers"][:L].clone().requires_grad_(True)
     M_virt = scene["pts1_virt_ori"].shape[1]
-    loss_vec = torch.zeros(L + 4, device=dev, dtype=torch.float64)  # dist.pack_loss_sums layout: the ONLY data exchanged between ranks
-    grad_logits = torch.zeros_like(logits)  # static destination of d loss / d logits (what an optimizer / the estimator's backward would consume)
+    state = {}  # tensors produced inside the captured graph are static: replays rewrite them in place
 
     def step_body():
         out = dfepe.pipeline.hot_path_fused(scene["matches_xy_ori"], logits, scene["Ks"], scene["pts1_virt_ori"],
                                               scene["pts2_virt_ori"], scene["qs_cam"], scene["ts_cam"], scene["R_gt"],
                                               IMAGE_SIZE, clamp_at=0.02, qt=True, hw_T=hw_T)
         g, = torch.autograd.grad(out["loss"], logits)
-        grad_logits.copy_(g)
-        loss_vec.copy_(out["packed"])  # dfepe_loss_head already produced the pack_loss_sums layout
+        state["grad_logits"] = g          # d loss / d logits: what the estimator's backward / an optimizer consumes
+        state["loss_vec"] = out["packed"]  # dist.pack_loss_sums layout (L+4 doubles): the ONLY data exchanged between ranks
         return out
 
     # eager warm-up (also sizes the caching allocator), then optional graph capture of the whole step
@@ -117,7 +116,7 @@ def main():
         else:
             step_body()
         if dist is not None:
-            dist.all_reduce(loss_vec)  # the only exchange of the data-parallel path: (L+4) doubles over RCCL/xGMI
+            dist.all_reduce(state["loss_vec"])  # the only exchange of the data-parallel path: (L+4) doubles over RCCL/xGMI
 
     def barrier():
         if dist is not None:

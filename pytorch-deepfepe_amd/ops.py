@@ -102,6 +102,7 @@ def _cf(t: Optional[Tensor]) -> Optional[Tensor]:
 class _W8ptFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pts1, pts2, weights, raw, image_w, image_h, clamp_at, want_epi, logits):
+        ctx.set_materialize_grads(False)  # unused outputs (e.g. the last layer's epi) must not cost a zero-fill
         F, residual, epi, save, w_out = w8pt_forward(pts1, pts2, weights, raw, image_w, image_h, clamp_at, want_epi,
                                                      want_save=True, logits=logits)
         ctx.save_for_backward(pts1, pts2 if pts2 is not None else pts1.new_empty(0), w_out if logits else weights, save, F)
@@ -120,6 +121,8 @@ class _W8ptFunction(torch.autograd.Function):
         rest = list(rest)
         gEpi = rest.pop(0) if want_epi else None
         gWout = rest.pop(0) if logits else None
+        if gF is None and gRes is None and gEpi is None and gWout is None:
+            return (None,) * 9
         gW = w8pt_backward(pts1, pts2 if pts2.numel() else None, weights, raw, image_w, image_h, clamp_at, save, F,
                            _cf(gF), _cf(gRes), _cf(gEpi), logits=logits, gW_extra=_cf(gWout))
         return None, None, gW, None, None, None, None, None, None

@@ -60,6 +60,7 @@ class _HotPathFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, matches, logits_layers, Ks, virt1, virt2, q_gt, t_gt, R_gt, hw_T, cfg):
         (H, W, clamp_at, qt, clamp_q, clamp_t, balance_q, balance_t) = cfg
+        ctx.set_materialize_grads(False)  # 13 auxiliary outputs: do not let autograd zero-fill [L,B,N] gradients for them
         lib = _lib.lib()
         L, B, N = logits_layers.shape
         dev = matches.device
@@ -102,7 +103,7 @@ class _HotPathFunction(torch.autograd.Function):
         extras = (F_layers, residuals, epis, weights, E_layers, loss_sum, packed, scalars)
         pose = (q_l2, t_l2, R_deg, t_deg, sel) if qt else ()
         ctx.mark_non_differentiable(*extras, *pose)
-        return (scalars[0].clone(),) + extras + pose
+        return (scalars[0:1].view(()),) + extras + pose
 
     @staticmethod
     def backward(ctx, g_loss, *unused):
@@ -112,6 +113,8 @@ class _HotPathFunction(torch.autograd.Function):
         L, B, N = weights.shape
         M = virt1.shape[1]
         dev = matches.device
+        if g_loss is None:
+            return (None,) * 10
         g_scale = g_loss.reshape(1).contiguous().float()
         st = ops._stream()
         flags = _lib.W8PT_RAW_MATCHES | _lib.W8PT_LOGITS
