@@ -49,7 +49,7 @@ __device__ __forceinline__ void eval_point(const float* v, const double* T, floa
   for (int r = 0; r < 3; ++r) x[r] = (float)(T[3 * r] * a + T[3 * r + 1] * b + T[3 * r + 2] * c);
 }
 
-template <bool BWD>
+template <bool BWD, bool CACHED>
 __global__ void __launch_bounds__(256, 4)
 floss_kernel(const float* __restrict__ F_layers, int L, int B, const float* __restrict__ T1, const float* __restrict__ T2,
              int t_stride, const float* __restrict__ K, const float* __restrict__ virt1, const float* __restrict__ virt2,
@@ -75,19 +75,44 @@ floss_kernel(const float* __restrict__ F_layers, int L, int B, const float* __re
     for (int c = 0; c < 9; ++c) { Am[c] = to_sgpr(ta[c]); Cm[c] = to_sgpr(tc[c]); }
   }
 
+  // M <= 128 (the reference uses a 10x10 grid): the (at most two) transformed points of a lane are formed once and kept
+  // in registers for all layers
+  float cx1[2][3], cx2[2][3];
+  if (CACHED) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = lane + WAVE * k;
+      if (i < M) {
+        eval_point(v1 + 3 * i, t1, cx1[k]);
+        eval_point(v2 + 3 * i, t2, cx2[k]);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { cx1[k][c] = 0.0f; cx2[k][c] = 0.0f; }
+      }
+    }
+  }
+
   for (int l = 0; l < L; ++l) {
     float o[9];
 #pragma unroll
     for (int c = 0; c < 9; ++c) o[c] = to_sgpr(F_layers[((size_t)l * B + pair) * 9 + c]);
     if (!BWD) {
       float accf = 0.0f;
+      if (CACHED) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const Epi e = epi_terms(cx1[k], cx2[k], o);
+          accf += (lane + WAVE * k < M) ? fminf(e.d, clamp_at) : 0.0f;
+        }
+      } else {
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-      for (int i = lane; i < M; i += WAVE) {
-        float x1[3], x2[3];
-        eval_point(v1 + 3 * i, t1, x1);
-        eval_point(v2 + 3 * i, t2, x2);
-        const Epi e = epi_terms(x1, x2, o);
-        accf += fminf(e.d, clamp_at);
+        for (int i = lane; i < M; i += WAVE) {
+          float x1[3], x2[3];
+          eval_point(v1 + 3 * i, t1, x1);
+          eval_point(v2 + 3 * i, t2, x2);
+          const Epi e = epi_terms(x1, x2, o);
+          accf += fminf(e.d, clamp_at);
+        }
       }
       const double acc = wave_sum((double)accf);
       if (lane == 0) loss_sum[(size_t)l * B + pair] = (float)acc;
@@ -100,13 +125,9 @@ floss_kernel(const float* __restrict__ F_layers, int L, int B, const float* __re
       const double gl = (g_loss_sum != nullptr) ? (double)g_loss_sum[(size_t)l * B + pair]
                                                 : (double)g_loss_coef * ((g_scale != nullptr) ? (double)g_scale[0] : 1.0);
       if (has_gl) {
-#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-        for (int i = lane; i < M; i += WAVE) {
-          float x1[3], x2[3];
-          eval_point(v1 + 3 * i, t1, x1);
-          eval_point(v2 + 3 * i, t2, x2);
+        auto point_grad = [&](const float* x1, const float* x2, bool live) {
           const Epi e = epi_terms(x1, x2, o);
-          if (e.d <= clamp_at) {
+          if (live && e.d <= clamp_at) {
             const float S = e.i1 + e.i2, ad = fabsf(e.dd);
             const float sg = (e.dd > 0.0f) ? 1.0f : ((e.dd < 0.0f) ? -1.0f : 0.0f);
             const float k1 = (e.n1 > 0.0f) ? ad * e.i1 * e.i1 * __builtin_amdgcn_rcpf(e.n1) : 0.0f;
@@ -120,6 +141,18 @@ floss_kernel(const float* __restrict__ F_layers, int L, int B, const float* __re
                 if (r < 2) t -= k2 * e.l2[r] * x1[c];
                 gof[3 * r + c] += t;
               }
+          }
+        };
+        if (CACHED) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) point_grad(cx1[k], cx2[k], lane + WAVE * k < M);
+        } else {
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+          for (int i = lane; i < M; i += WAVE) {
+            float x1[3], x2[3];
+            eval_point(v1 + 3 * i, t1, x1);
+            eval_point(v2 + 3 * i, t2, x2);
+            point_grad(x1, x2, true);
           }
         }
 #pragma unroll
@@ -169,8 +202,12 @@ extern "C" int dfepe_floss_fwd(const float* F_layers, int L, int B, const float*
   if (B == 0) return DFEPE_OK;
   if (!loss_sum) return DFEPE_ERR_INVALID_ARG;
   const dim3 grid((B + 3) / 4), block(256);
-  hipLaunchKernelGGL(floss_kernel<false>, grid, block, 0, static_cast<hipStream_t>(stream), F_layers, L, B, T1, T2,
-                     t_stride, K, virt1, virt2, M, clamp_at, loss_sum, E_layers, nullptr, 0.0f, nullptr, nullptr, nullptr);
+  if (M <= 2 * WAVE)
+    hipLaunchKernelGGL((floss_kernel<false, true>), grid, block, 0, static_cast<hipStream_t>(stream), F_layers, L, B, T1, T2,
+                       t_stride, K, virt1, virt2, M, clamp_at, loss_sum, E_layers, nullptr, 0.0f, nullptr, nullptr, nullptr);
+  else
+    hipLaunchKernelGGL((floss_kernel<false, false>), grid, block, 0, static_cast<hipStream_t>(stream), F_layers, L, B, T1, T2,
+                       t_stride, K, virt1, virt2, M, clamp_at, loss_sum, E_layers, nullptr, 0.0f, nullptr, nullptr, nullptr);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
@@ -183,7 +220,11 @@ extern "C" int dfepe_floss_bwd(const float* F_layers, int L, int B, const float*
   if (B == 0) return DFEPE_OK;
   if (!g_F_layers) return DFEPE_ERR_INVALID_ARG;
   const dim3 grid((B + 3) / 4), block(256);
-  hipLaunchKernelGGL(floss_kernel<true>, grid, block, 0, static_cast<hipStream_t>(stream), F_layers, L, B, T1, T2,
-                     t_stride, K, virt1, virt2, M, clamp_at, nullptr, nullptr, g_loss_sum, g_loss_coef, g_scale, g_E, g_F_layers);
+  if (M <= 2 * WAVE)
+    hipLaunchKernelGGL((floss_kernel<true, true>), grid, block, 0, static_cast<hipStream_t>(stream), F_layers, L, B, T1, T2,
+                       t_stride, K, virt1, virt2, M, clamp_at, nullptr, nullptr, g_loss_sum, g_loss_coef, g_scale, g_E, g_F_layers);
+  else
+    hipLaunchKernelGGL((floss_kernel<true, false>), grid, block, 0, static_cast<hipStream_t>(stream), F_layers, L, B, T1, T2,
+                       t_stride, K, virt1, virt2, M, clamp_at, nullptr, nullptr, g_loss_sum, g_loss_coef, g_scale, g_E, g_F_layers);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }

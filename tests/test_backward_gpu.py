@@ -198,3 +198,20 @@ def test_logits_fused_fit_matches_softmax_then_fit(dfepe):
     np.testing.assert_allclose(w.detach().cpu().numpy(), wb.detach().cpu().numpy(), rtol=2e-6, atol=1e-10)
     assert (F - F2).abs().max().item() < 2e-6 * F2.abs().max().item()
     assert relerr(la.grad.cpu().numpy(), lb.grad.cpu().numpy()) < 2e-5
+
+
+def test_floss_many_virtual_points_generic_path(dfepe, oracle):
+    """M > 128 takes the non-cached code path of floss: same answer as the oracle."""
+    L, B, M = 2, 3, 300
+    sc = dfepe.synth.make_scene(B, 20, seed=8, M_virt=M)
+    T = oracle.hw_matrix(IMAGE_SIZE, torch.float64)
+    Tinv = torch.linalg.inv(T)
+    Fn = Tinv.T @ sc["F_gt"].double() @ Tinv
+    Fn = Fn / Fn.flatten(1).norm(dim=1)[:, None, None]
+    g = torch.Generator().manual_seed(1)
+    Fl = torch.stack([Fn + 0.004 * (l + 1) * torch.randn(B, 3, 3, generator=g, dtype=torch.float64) for l in range(L)]).float().double()
+    outs = {"T1": T.expand(B, 3, 3), "T2": T.expand(B, 3, 3), "out_layers": [Fl[l] for l in range(L)], "F_est": Fl[-1]}
+    losses, _, _, E_layers = oracle.f_loss(outs, sc["pts1_virt_ori"].double(), sc["pts2_virt_ori"].double(), sc["Ks"].double(), L, 0.02)
+    loss_sum, E = dfepe.ops.floss(Fl.float().to(DEV), T.float().to(DEV), T.float().to(DEV), sc["Ks"].to(DEV), sc["pts1_virt_ori"].to(DEV), sc["pts2_virt_ori"].to(DEV), 0.02)
+    assert relerr(loss_sum.cpu().numpy(), (losses["loss_per_pair"] * M).numpy()) < 5e-5
+    assert relerr(E.cpu().numpy(), torch.stack(E_layers).numpy()) < 2e-6
