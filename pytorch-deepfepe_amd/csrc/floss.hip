@@ -57,7 +57,7 @@ floss_kernel(const float* __restrict__ F_layers, int L, int B, const float* __re
              const float* __restrict__ g_loss_sum, float g_loss_coef, const float* __restrict__ g_scale,
              const float* __restrict__ g_E, float* __restrict__ g_F_layers) {
   const int lane = threadIdx.x & 63;
-  const size_t pair = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const size_t pair = (size_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
   if (pair >= (size_t)B) return;
   double t1[9], t2[9];
   load9(T1 + pair * t_stride, t1);

@@ -13,7 +13,7 @@ epi_residual_kernel(const float* __restrict__ pts1, const float* __restrict__ pt
                     int N, float clamp_at, float* __restrict__ out, const float* __restrict__ g_out,
                     float* __restrict__ g_F) {
   const int lane = threadIdx.x & 63;
-  const size_t pair = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const size_t pair = (size_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
   if (pair >= (size_t)B) return;
   float o[9];
 #pragma unroll
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256)
 cheirality_kernel(const float* __restrict__ E, const float* __restrict__ K, const float* __restrict__ matches, int B, int N,
                   float depth_thres, float* __restrict__ Rt_cam, int* __restrict__ winner, int* __restrict__ counts) {
   const int lane = threadIdx.x & 63;
-  const size_t pair = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const size_t pair = (size_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
   if (pair >= (size_t)B) return;
   double Ed[9], Kd[9], R[2][9], t[3];
 #pragma unroll

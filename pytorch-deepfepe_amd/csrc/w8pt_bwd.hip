@@ -28,7 +28,7 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
                 const float* __restrict__ g_epi, const float* __restrict__ g_w_extra, int logits_mode,
                 float* __restrict__ g_w) {
   const int lane = threadIdx.x & 63;
-  const size_t pair = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const size_t pair = (size_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
   if (pair >= (size_t)B) return;
 
   const float* sv = save + pair * DFEPE_SAVE_FLOATS;

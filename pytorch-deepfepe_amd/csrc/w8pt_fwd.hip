@@ -80,7 +80,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
                 float* __restrict__ save, float* __restrict__ weights_out, int logits_mode, unsigned variant) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
   const int pair = blockIdx.x * (blockDim.x >> 6) + wave;
   if (pair >= B) return;  // whole wave leaves; there is no block-level barrier in this kernel
 
