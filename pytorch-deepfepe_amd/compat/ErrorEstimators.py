@@ -3,6 +3,7 @@
 Stock PyTorch-ROCm (MIOpen / rocBLAS): SURVEY.md §8 row a18 keeps it outside the hand-written hot path.
 The layer stack is restated so that ``state_dict`` keys (``fw.<idx>.weight`` ...) match the reference and its
 checkpoints load unchanged."""
+import torch
 import torch.nn as nn
 
 
@@ -21,5 +22,11 @@ class ErrorEstimator(nn.Module):
         layers.append(nn.Conv1d(256, output_size, kernel_size=1, bias=not if_bn))
         self.fw = nn.Sequential(*layers)
 
+    # MIOpen's backward for this stack fails (miopenStatusUnknownError) at 4096 pairs x 100 points on ROCm 7.2; every
+    # layer acts per pair (k=1 convolutions, InstanceNorm1d), so the batch can be processed in independent chunks.
+    max_chunk = 2048
+
     def forward(self, data):
-        return self.fw(data)
+        if data.shape[0] <= self.max_chunk:
+            return self.fw(data)
+        return torch.cat([self.fw(c) for c in data.split(self.max_chunk, dim=0)], dim=0)
