@@ -110,3 +110,26 @@ def get_Rt_loss(E_ests_layers, Ks_cpu, x1_cpu, x2_cpu, delta_Rtijs_4_4_cpu, qs_c
         "t_l2_error_layers_list": t_l2_layers,
         "q_l2_error_layers_list": q_l2_layers,
     }
+
+
+def val_rt_batch(Ks, matches_xy, E_ests, delta_Rtijs_4_4, project_E=True, depth_thres=50.0):
+    """Batched GPU counterpart of the validation fan-out (Train_model_pipeline.py:954-964,1048-1061 -> val_rt :553-646 ->
+    utils_F.goodCorr_eval_nondecompose -> cv2.recoverPose): optional projection of E onto singular values (1,1,0),
+    cheirality-checked pose for every pair, rotation / translation angular errors against the ground-truth camera motion.
+    Ks, E_ests [B,3,3]; matches_xy [B,N,4] pixels; delta_Rtijs_4_4 [B,4,4] (scene motion, like the dataset).
+    Returns dict(err_R_deg [B], err_t_deg [B], Rt_cam [B,3,4], winner [B], counts [B,4]); pairs without a valid
+    candidate get the reference's failure values 180 / 90 degrees."""
+    E = E_ests.float()
+    if not E.is_cuda:
+        raise _lib.DfepeError("val_rt_batch: tensors must live on the GPU")
+    dev = E.device
+    if project_E:
+        E = ops.project_essential(E)
+    Rt, win, cnt = ops.cheirality(E, Ks.to(dev), matches_xy.to(dev), depth_thres)
+    gt = torch.linalg.inv(delta_Rtijs_4_4.to(dev).float())
+    err_R = ops.rot_angle_deg(Rt[:, :, :3].contiguous(), gt[:, :3, :3].contiguous())
+    err_t = ops.vector_angle_deg(Rt[:, :, 3].contiguous(), gt[:, :3, 3].contiguous())
+    bad = win < 0
+    err_R = torch.where(bad, torch.full_like(err_R, 180.0), err_R)
+    err_t = torch.where(bad, torch.full_like(err_t, 90.0), err_t)
+    return {"err_R_deg": err_R, "err_t_deg": err_t, "Rt_cam": Rt, "winner": win, "counts": cnt}

@@ -102,6 +102,46 @@ def _E_to_M_train(E_est_th, K, x1, x2, inlier_mask=None, delta_Rt_gt_cam=None, d
     return [], error_Rt, Rt_cam
 
 
+def _E_to_M(E_est_th, K, x1, x2, inlier_mask=None, delta_Rt_gt=None, depth_thres=50.0, show_debug=False, show_result=True,
+            method_name="ours"):
+    """utils_F._E_to_M (utils_F.py:521-677): same selection as _E_to_M_train, ground truth given as camera motion."""
+    return _E_to_M_train(E_est_th, K, x1, x2, inlier_mask=inlier_mask, delta_Rt_gt_cam=delta_Rt_gt, depth_thres=depth_thres,
+                         show_debug=show_debug, show_result=show_result, method_name=method_name)
+
+
+def goodCorr_eval_nondecompose(p1s, p2s, E_hat, delta_Rtij_inv, K, scores, if_my_decomp=False):
+    """Evaluation-time pose from E (utils_F.py:909-954): the reference calls cv2.recoverPose (cheirality inside OpenCV,
+    50-unit distance threshold), inverts the pose and measures the rotation / translation angle against the ground-truth
+    camera motion.  Here the cheirality kernel does the selection (same candidates, DLT triangulation, threshold 50).
+    Returns (np.hstack((R, t)) in the scene convention x2 ~ R x1 + t, (err_q_deg, err_t_deg)); the failure fall-backs
+    (fewer than 5 points: 180 / 90 degrees and the identity pose) follow the reference (:942-952)."""
+    import numpy as np
+
+    p1s, p2s = np.asarray(p1s), np.asarray(p2s)
+    if scores is not None:
+        scores = np.asarray(scores)
+        num_top = max(1, len(scores) // 10)
+        th = np.sort(scores)[::-1][num_top]
+        mask = scores >= th
+        p1s, p2s = p1s[mask], p2s[mask]
+    if p1s.shape[0] < 5:
+        return np.hstack((np.eye(3, dtype=np.float32), np.zeros((3, 1), np.float32))), (180.0, 90.0)
+    dev = torch.device("cuda")
+    gt = torch.as_tensor(np.asarray(delta_Rtij_inv), dtype=torch.float32, device=dev)
+    m = torch.as_tensor(np.hstack((p1s, p2s)), dtype=torch.float32, device=dev).unsqueeze(0).contiguous()
+    Rt, win, _ = ops.cheirality(torch.as_tensor(np.asarray(E_hat), dtype=torch.float32, device=dev).reshape(1, 3, 3),
+                                torch.as_tensor(np.asarray(K), dtype=torch.float32, device=dev).reshape(1, 3, 3), m, 50.0)
+    if int(win[0].item()) < 0:
+        print("Failed in evaluation")
+        return np.hstack((np.eye(3, dtype=np.float32), np.zeros((3, 1), np.float32))), (180.0, 90.0)
+    R_cam, t_cam = Rt[0, :, :3], Rt[0, :, 3]
+    err_q = ops.rot_angle_deg(R_cam.reshape(1, 3, 3), gt[:3, :3].reshape(1, 3, 3))[0].item()
+    err_t = ops.vector_angle_deg(t_cam.reshape(1, 3), gt[:3, 3].reshape(1, 3))[0].item()
+    R = R_cam.t()
+    t = -(R @ t_cam.reshape(3, 1))
+    return torch.cat((R, t), 1).cpu().numpy(), (err_q, err_t)
+
+
 def _diag_weights(W, N):
     """The reference left-multiplies the design matrix by a dense W [N,N] (utils_F.py:129-130); its callers pass
     torch.diag(w) (train_good_utils.get_E_ests).  Only diagonal W is built: it is a per-correspondence weight."""

@@ -198,3 +198,29 @@ def test_cheirality_recovers_generating_pose(dfepe, oracle, N):
     _, err, Rt_cam = dfepe.compat.utils_F._E_to_M_train(E[0].to(DEV), sc["Ks"][0].numpy(), sc["matches_xy_ori"][0, :, :2].numpy(),
                                                         sc["matches_xy_ori"][0, :, 2:].numpy(), delta_Rt_gt_cam=cam[0], show_result=False)
     assert Rt_cam.shape == (3, 4) and err[0] < 0.05 and err[1] < 0.5
+
+
+def test_validation_pose_path(dfepe, oracle):
+    """goodCorr_eval_nondecompose / val_rt_batch (the cv2.recoverPose path of the reference, unpinned): recover the
+    generating pose from the ground-truth E and from an E estimated by the solver on noisy matches."""
+    B, N = 16, 200
+    sc = dfepe.synth.make_scene(B, N, seed=23, noise_px=0.3)
+    dev = dfepe.pipeline.scene_to_device(sc, DEV)
+    out = dfepe.compat.train_good_utils.val_rt_batch(dev["Ks"], dev["matches_xy_ori"], dev["E_gt"], dev["delta_Rtijs_4_4"])
+    assert out["err_R_deg"].max().item() < 0.05 and out["err_t_deg"].max().item() < 0.5
+    assert (out["winner"] >= 0).all()
+    # E from the solver (uniform weights) on the same matches
+    w = torch.full((B, N), 1.0 / N, device=DEV)
+    F, _, _ = dfepe.ops.w8pt_raw(dev["matches_xy_ori"], w, 1241, 376)
+    T = oracle.hw_matrix(IMAGE_SIZE).to(DEV)
+    E = dev["Ks"].transpose(1, 2) @ T.t() @ F @ T @ dev["Ks"]
+    out2 = dfepe.compat.train_good_utils.val_rt_batch(dev["Ks"], dev["matches_xy_ori"], E, dev["delta_Rtijs_4_4"])
+    assert out2["err_R_deg"].median().item() < 0.5 and out2["err_t_deg"].median().item() < 10.0
+    # single-pair reference signature
+    cam = np.linalg.inv(sc["delta_Rtijs_4_4"][0].numpy())[:3]
+    M, (eq, et) = dfepe.compat.utils_F.goodCorr_eval_nondecompose(sc["matches_xy_ori"][0, :, :2].numpy(), sc["matches_xy_ori"][0, :, 2:].numpy(),
+                                                                sc["E_gt"][0].numpy().astype(np.float64), cam, sc["Ks"][0].numpy(), None)
+    assert M.shape == (3, 4) and eq < 0.05 and et < 0.5
+    np.testing.assert_allclose(M[:, :3], sc["delta_Rtijs_4_4"][0, :3, :3].numpy(), atol=2e-3)  # scene convention: x2 ~ R x1 + t
+    M2, errs = dfepe.compat.utils_F.goodCorr_eval_nondecompose(np.zeros((3, 2)), np.zeros((3, 2)), np.eye(3), cam, sc["Ks"][0].numpy(), None)
+    assert errs == (180.0, 90.0)
