@@ -233,10 +233,12 @@ __device__ inline void smallest_eigvec4(double* S /*4x4 row-major, symmetric, de
       for (int q = p + 1; q < 4; ++q) {
         const double apq = S[4 * p + q];
         if (apq != 0.0) {
+          // c = cos, s = sin of the Jacobi angle through two rsqrt's: r = 1/hypot(d,b), x = (1+|d| r)/2 = c^2
           const double d = S[4 * q + q] - S[4 * p + p], b = 2.0 * apq;
-          const double h = sqrt(d * d + b * b);
-          const double t = b / (d + copysign(h, d));
-          const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+          const double rh = fast_rsqrt(d * d + b * b);
+          const double x = 0.5 + 0.5 * fabs(d) * rh;
+          const double y = fast_rsqrt(x);
+          const double c = x * y, s = copysign(0.5, d) * b * rh * y;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {  // columns
             const double skp = S[4 * k + p], skq = S[4 * k + q];
@@ -277,27 +279,32 @@ cheirality_kernel(const float* __restrict__ E, const float* __restrict__ K, cons
   if (pair >= (size_t)B) return;
   double Ed[9], Kd[9], R[2][9], t[3];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) { Ed[k] = (double)E[pair * 9 + k]; Kd[k] = (double)K[pair * 9 + k]; }
+  for (int k = 0; k < 9; ++k) { Ed[k] = (double)E[pair * 9 + k]; Kd[k] = to_sgpr((double)K[pair * 9 + k]); }
   decompose_E(Ed, R[0], R[1], t);
+  // per-pair (wave-uniform) quantities live in scalar registers; the per-correspondence DLT owns the VGPRs
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { R[0][k] = to_sgpr(R[0][k]); R[1][k] = to_sgpr(R[1][k]); }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) t[k] = to_sgpr(t[k]);
   int cnt[4] = {0, 0, 0, 0};
   for (int base = 0; base < N; base += WAVE) {
     const int i = base + lane;
     const bool live = i < N;
     float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) m = reinterpret_cast<const float4*>(matches)[pair * N + i];
+    // One DLT per rotation: flipping t negates the 4th column of the view-2 rows, hence the 4th component of the null
+    // vector, hence both depths exactly -- candidates (R,t) and (R,-t) are counted from the same triangulation.
 #pragma unroll
-    for (int cand = 0; cand < 4; ++cand) {
-      const double* Rc = R[cand >> 1];
-      const double sg = (cand & 1) ? -1.0 : 1.0;
-      // P1 = K [I|0], P2 = K [R|t]
+    for (int rr = 0; rr < 2; ++rr) {
+      const double* Rc = R[rr];
       double P2[12];
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) P2[4 * r + c] = Kd[3 * r] * Rc[c] + Kd[3 * r + 1] * Rc[3 + c] + Kd[3 * r + 2] * Rc[6 + c];
-        P2[4 * r + 3] = sg * (Kd[3 * r] * t[0] + Kd[3 * r + 1] * t[1] + Kd[3 * r + 2] * t[2]);
+        P2[4 * r + 3] = Kd[3 * r] * t[0] + Kd[3 * r + 1] * t[1] + Kd[3 * r + 2] * t[2];
       }
-      // DLT rows: x*P[2]-P[0], y*P[2]-P[1] for both views
+      // DLT rows: x*P[2]-P[0], y*P[2]-P[1] for both views (P1 = K [I|0])
       double A[16];
       const double x1 = m.x, y1 = m.y, x2 = m.z, y2 = m.w;
 #pragma unroll
@@ -315,11 +322,14 @@ cheirality_kernel(const float* __restrict__ E, const float* __restrict__ K, cons
         for (int c = 0; c < 4; ++c) S[4 * r + c] = A[r] * A[c] + A[4 + r] * A[4 + c] + A[8 + r] * A[8 + c] + A[12 + r] * A[12 + c];
       double X[4];
       smallest_eigvec4(S, X);
-      const double z1 = X[2] / X[3];
-      const double X0 = X[0] / X[3], X1 = X[1] / X[3];
-      const double z2 = Rc[6] * X0 + Rc[7] * X1 + Rc[8] * z1 + sg * t[2];
-      const bool good = live && (z1 > 0.0) && (z1 < (double)depth_thres) && (z2 > 0.0) && (z2 < (double)depth_thres);
-      cnt[cand] += __popcll(__ballot(good));
+      const double iw = 1.0 / X[3];
+      const double X0 = X[0] * iw, X1 = X[1] * iw, z1 = X[2] * iw;
+      const double z2 = Rc[6] * X0 + Rc[7] * X1 + Rc[8] * z1 + t[2];
+      const double thr = (double)depth_thres;
+      const bool pos = live && (z1 > 0.0) && (z1 < thr) && (z2 > 0.0) && (z2 < thr);
+      const bool neg = live && (z1 < 0.0) && (z1 > -thr) && (z2 < 0.0) && (z2 > -thr);
+      cnt[2 * rr] += __popcll(__ballot(pos));
+      cnt[2 * rr + 1] += __popcll(__ballot(neg));
     }
   }
   int win = 0;
