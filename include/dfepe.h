@@ -84,12 +84,15 @@ int dfepe_w8pt_fwd(const float *pts1, const float *pts2, const float *weights, i
  *     (the next estimator layer reads the weights, DeepFNet.py:487); added before the softmax adjoint
  *   with DFEPE_W8PT_LOGITS `weights` must be the forward's `weights_out` and g_weights receives d/d(logits)
  *   g_weights [B,N]: written (not accumulated)
+ *   g_pts1, g_pts2 [B,N,3] or NULL: gradient w.r.t. the point coordinates (through the rows, the Hartley transforms and,
+ *     when g_epi is given, the residual's direct dependence); with DFEPE_W8PT_RAW_MATCHES g_pts1 is [B,N,4] (gradient
+ *     w.r.t. the pixel matches, 16-byte aligned) and g_pts2 is ignored.  NULL skips that part of the kernel.
  */
 int dfepe_w8pt_bwd(const float *pts1, const float *pts2, const float *weights, int B, int N,
                    unsigned flags, float image_w, float image_h, float clamp_at,
                    const float *save, const float *F_out,
                    const float *g_F, const float *g_residual, const float *g_epi, const float *g_weights_extra,
-                   float *g_weights, void *stream);
+                   float *g_weights, float *g_pts1, float *g_pts2, void *stream);
 
 /*
  * F-loss and E-from-F over all layers.

@@ -39,8 +39,8 @@ class Fit(nn.Module):
     """Weighted normalised 8-point fit.  forward(pts1[B,N,3], pts2[B,N,3], weights[B,1,N]) -> (out[B,3,3], residual[B,N]).
 
     ``if_cpu_svd`` is accepted and ignored (it selected a per-sample CPU LAPACK round trip in the reference,
-    DeepFNet.py:219-230; both of its branches compute the same thing).  Gradients flow to ``weights``; gradients
-    w.r.t. the points are not produced (the reference's training path never asks for them: the points are data)."""
+    DeepFNet.py:219-230; both of its branches compute the same thing).  Gradients flow to all three tensor inputs
+    (the point gradients are only computed when pts1/pts2 require grad)."""
 
     def __init__(self, is_cuda=True, is_test=False, if_cpu_svd=False, normalize_SVD=True):
         super().__init__()

@@ -20,13 +20,13 @@ __device__ __forceinline__ double guard_den(double d) {
   return (fabs(d) < lim) ? ((d < 0.0) ? -lim : lim) : d;
 }
 
-template <bool RAW>
+template <bool RAW, bool PGRAD>
 __global__ void __launch_bounds__(256, 4)
 w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, const float* __restrict__ wts, int B,
                 int N, float hw_sx, float hw_sy, float clamp_at, const float* __restrict__ save,
                 const float* __restrict__ F_out, const float* __restrict__ g_F, const float* __restrict__ g_res,
                 const float* __restrict__ g_epi, const float* __restrict__ g_w_extra, int logits_mode,
-                float* __restrict__ g_w) {
+                float* __restrict__ g_w, float* __restrict__ g_p1, float* __restrict__ g_p2) {
   const int lane = threadIdx.x & 63;
   const size_t pair = (size_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
   if (pair >= (size_t)B) return;
@@ -179,6 +179,121 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
     for (int i = lane; i < N; i += WAVE) dst[i] = wsrc[i] * (dst[i] - s);
   }
+
+  if (PGRAD) {
+    // ---- adjoint w.r.t. the point coordinates (derivation checked against autograd in scripts/proto_pts_grad.py) ----
+    // rows -> (a, b) -> points, plus the dependence of the Hartley transforms (centroid c, scale s = k / mean distance)
+    // on the points through the rows and through out = T2^T F' T1, plus the direct dependence of the epipolar residual.
+    const double kH = 1.4142;
+    double Fp[9], tA[9], gT1[9], gT2[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Fp[3 * r + c] = S[0] * U[3 * r] * V[3 * c] + S[1] * U[3 * r + 1] * V[3 * c + 1];
+    mat3_mul_tn(t2, Fp, tA);      // T2^T F'
+    mat3_mul_tn(tA, go, gT1);     // d<G, T2^T F' T1>/dT1 = (T2^T F')^T G
+    mat3_mul(Fp, t1, tA);         // F' T1
+    mat3_mul_nt(tA, go, gT2);     // d/dT2 = F' T1 G^T
+    float sums[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) sums[k] = 0.0f;
+    const int stride = RAW ? 4 : 3;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+    for (int i = lane; i < N; i += WAVE) {
+      const Pt p = global_point<RAW>(pts1, pts2, pair, i, N, hw_sx, hw_sy);
+      const double w = (double)wsrc[i];
+      const double z1 = p.z1, z2 = p.z2;
+      const double a[3] = {s1 * ((double)p.x1 - c1x * z1), s1 * ((double)p.y1 - c1y * z1), z1};
+      const double b0 = s2 * ((double)p.x2 - c2x * z2), b1 = s2 * ((double)p.y2 - c2y * z2);
+      const double n2 = (a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) * (b0 * b0 + b1 * b1 + 1.0);
+      const bool ok = (n2 < 1e300) && (n2 > 1e-24) && (fabs(w) < 1e150);
+      const double inv = ok ? fast_rsqrt(n2) : 0.0;
+      double ph[9];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { ph[k] = b0 * a[k] * inv; ph[3 + k] = b1 * a[k] * inv; ph[6 + k] = a[k] * inv; }
+      double af = 0.0, bu = 0.0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { af += ph[k] * f[k]; bu += ph[k] * u[k]; }
+      const double gr = (g_res != nullptr) ? (double)g_res[pair * N + i] : 0.0;
+      const double cu = w * w * af, cf = w * w * bu + w * gr, dotp = 2.0 * w * w * af * bu + w * gr * af;
+      double gp[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) gp[k] = (cu * u[k] + cf * f[k] - ph[k] * dotp) * inv;
+      const double ga0 = b0 * gp[0] + b1 * gp[3] + gp[6], ga1 = b0 * gp[1] + b1 * gp[4] + gp[7], ga2 = b0 * gp[2] + b1 * gp[5] + gp[8];
+      const double gb0 = a[0] * gp[0] + a[1] * gp[1] + a[2] * gp[2], gb1 = a[0] * gp[3] + a[1] * gp[4] + a[2] * gp[5];
+      double e1[3] = {0.0, 0.0, 0.0}, e2[3] = {0.0, 0.0, 0.0};
+      if (g_epi != nullptr) {  // direct dependence of d_i on x1_i, x2_i
+        const double x1[3] = {p.x1, p.y1, p.z1}, x2[3] = {p.x2, p.y2, p.z2};
+        double l1[3], l2[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) l1[c] = x2[0] * o[c] + x2[1] * o[3 + c] + x2[2] * o[6 + c];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) l2[r] = o[3 * r] * x1[0] + o[3 * r + 1] * x1[1] + o[3 * r + 2] * x1[2];
+        const double dd = x1[0] * l1[0] + x1[1] * l1[1] + x1[2] * l1[2];
+        const double n1 = fast_sqrt(l1[0] * l1[0] + l1[1] * l1[1]), nn2 = fast_sqrt(l2[0] * l2[0] + l2[1] * l2[1]);
+        const double i1 = fast_rcp(n1 + 1e-6), i2 = fast_rcp(nn2 + 1e-6);
+        const double Ss = i1 + i2, ad = fabs(dd);
+        const double g = (ad * Ss <= (double)clamp_at) ? (double)g_epi[pair * N + i] : 0.0;
+        const double sg = (dd > 0.0) ? 1.0 : ((dd < 0.0) ? -1.0 : 0.0);
+        const double k1 = (n1 > 0.0) ? ad * i1 * i1 * fast_rcp(n1) : 0.0;
+        const double k2 = (nn2 > 0.0) ? ad * i2 * i2 * fast_rcp(nn2) : 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          e1[c] = g * (sg * Ss * l1[c] - k2 * (l2[0] * o[c] + l2[1] * o[3 + c]));          // d n2 / d x1_c
+          e2[c] = g * (sg * Ss * l2[c] - k1 * (l1[0] * o[3 * c] + l1[1] * o[3 * c + 1]));  // d n1 / d x2_c
+        }
+      }
+      // provisional values; the Hartley terms are added in the fix-up pass below (same lane re-reads what it wrote)
+      const float q1x = (float)(s1 * ga0 + e1[0]), q1y = (float)(s1 * ga1 + e1[1]);
+      const float q2x = (float)(s2 * gb0 + e2[0]), q2y = (float)(s2 * gb1 + e2[1]);
+      if (RAW) {
+        reinterpret_cast<float4*>(g_p1)[pair * N + i] = make_float4(q1x, q1y, q2x, q2y);
+      } else {
+        float* d1 = g_p1 + (pair * N + i) * 3;
+        float* d2 = g_p2 + (pair * N + i) * 3;
+        d1[0] = q1x; d1[1] = q1y; d1[2] = (float)(ga2 - s1 * (c1x * ga0 + c1y * ga1) + e1[2]);
+        d2[0] = q2x; d2[1] = q2y; d2[2] = (float)(-s2 * (c2x * gb0 + c2y * gb1) + e2[2]);
+      }
+      const double dx1 = (double)p.x1 - c1x, dy1 = (double)p.y1 - c1y, dx2 = (double)p.x2 - c2x, dy2 = (double)p.y2 - c2y;
+      const double r1 = dx1 * dx1 + dy1 * dy1, r2 = dx2 * dx2 + dy2 * dy2;
+      const double ir1 = (r1 > 0.0) ? fast_rsqrt(r1) : 0.0, ir2 = (r2 > 0.0) ? fast_rsqrt(r2) : 0.0;
+      sums[0] += (float)(((double)p.x1 - c1x * z1) * ga0 + ((double)p.y1 - c1y * z1) * ga1);  // d/ds1 through the rows
+      sums[1] += (float)(-s1 * z1 * ga0);
+      sums[2] += (float)(-s1 * z1 * ga1);
+      sums[3] += (float)(((double)p.x2 - c2x * z2) * gb0 + ((double)p.y2 - c2y * z2) * gb1);
+      sums[4] += (float)(-s2 * z2 * gb0);
+      sums[5] += (float)(-s2 * z2 * gb1);
+      sums[6] += (float)(dx1 * ir1); sums[7] += (float)(dy1 * ir1);
+      sums[8] += (float)(dx2 * ir2); sums[9] += (float)(dy2 * ir2);
+    }
+    double tot[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) tot[k] = (double)wave_sum(sums[k]);
+    const double invN = 1.0 / (double)N;
+    const double Gs1 = tot[0] + gT1[0] + gT1[4] - c1x * gT1[2] - c1y * gT1[5];
+    const double Gs2 = tot[3] + gT2[0] + gT2[4] - c2x * gT2[2] - c2y * gT2[5];
+    const double Gd1 = -Gs1 * s1 * s1 / kH, Gd2 = -Gs2 * s2 * s2 / kH;   // s = k / dbar
+    const double Gc1x = (tot[1] - s1 * gT1[2] - Gd1 * invN * tot[6]) * invN, Gc1y = (tot[2] - s1 * gT1[5] - Gd1 * invN * tot[7]) * invN;
+    const double Gc2x = (tot[4] - s2 * gT2[2] - Gd2 * invN * tot[8]) * invN, Gc2y = (tot[5] - s2 * gT2[5] - Gd2 * invN * tot[9]) * invN;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+    for (int i = lane; i < N; i += WAVE) {
+      const Pt p = global_point<RAW>(pts1, pts2, pair, i, N, hw_sx, hw_sy);
+      const double dx1 = (double)p.x1 - c1x, dy1 = (double)p.y1 - c1y, dx2 = (double)p.x2 - c2x, dy2 = (double)p.y2 - c2y;
+      const double r1 = dx1 * dx1 + dy1 * dy1, r2 = dx2 * dx2 + dy2 * dy2;
+      const double ir1 = (r1 > 0.0) ? fast_rsqrt(r1) : 0.0, ir2 = (r2 > 0.0) ? fast_rsqrt(r2) : 0.0;
+      const float a1x = (float)(Gd1 * invN * dx1 * ir1 + Gc1x), a1y = (float)(Gd1 * invN * dy1 * ir1 + Gc1y);
+      const float a2x = (float)(Gd2 * invN * dx2 * ir2 + Gc2x), a2y = (float)(Gd2 * invN * dy2 * ir2 + Gc2y);
+      if (RAW) {
+        float4 q = reinterpret_cast<float4*>(g_p1)[pair * N + i];
+        q.x = (q.x + a1x) * hw_sx; q.y = (q.y + a1y) * hw_sy; q.z = (q.z + a2x) * hw_sx; q.w = (q.w + a2y) * hw_sy;
+        reinterpret_cast<float4*>(g_p1)[pair * N + i] = q;  // chain through x^ = 2x/W - 1
+      } else {
+        float* d1 = g_p1 + (pair * N + i) * 3;
+        float* d2 = g_p2 + (pair * N + i) * 3;
+        d1[0] += a1x; d1[1] += a1y; d2[0] += a2x; d2[1] += a2y;
+      }
+    }
+  }
 }
 
 }  // namespace
@@ -186,7 +301,7 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 extern "C" int dfepe_w8pt_bwd(const float* pts1, const float* pts2, const float* weights, int B, int N, unsigned flags,
                               float image_w, float image_h, float clamp_at, const float* save, const float* F_out,
                               const float* g_F, const float* g_residual, const float* g_epi,
-                              const float* g_weights_extra, float* g_weights, void* stream) {
+                              const float* g_weights_extra, float* g_weights, float* g_pts1, float* g_pts2, void* stream) {
   const bool raw = (flags & DFEPE_W8PT_RAW_MATCHES) != 0;
   const int logits_mode = (flags & DFEPE_W8PT_LOGITS) ? 1 : 0;
   if (B < 0 || N <= 0) return DFEPE_ERR_INVALID_ARG;
@@ -194,17 +309,23 @@ extern "C" int dfepe_w8pt_bwd(const float* pts1, const float* pts2, const float*
   if (B == 0) return DFEPE_OK;
   if (!pts1 || (!raw && !pts2) || !weights || !save || !g_weights) return DFEPE_ERR_INVALID_ARG;
   if (g_epi && !F_out) return DFEPE_ERR_INVALID_ARG;
+  const bool pgrad = g_pts1 != nullptr;
+  if (!raw && ((g_pts1 == nullptr) != (g_pts2 == nullptr))) return DFEPE_ERR_INVALID_ARG;
+  if (raw && pgrad && (reinterpret_cast<uintptr_t>(g_pts1) & 15u)) return DFEPE_ERR_INVALID_ARG;
   if (raw && !(image_w > 0.f && image_h > 0.f)) return DFEPE_ERR_INVALID_ARG;
   if (raw && (reinterpret_cast<uintptr_t>(pts1) & 15u)) return DFEPE_ERR_INVALID_ARG;
   const int waves = 4;
   const dim3 grid((B + waves - 1) / waves), block(64 * waves);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float hw_sx = raw ? 2.0f / image_w : 0.f, hw_sy = raw ? 2.0f / image_h : 0.f;
-  if (raw)
-    hipLaunchKernelGGL(w8pt_bwd_kernel<true>, grid, block, 0, st, pts1, pts2, weights, B, N, hw_sx, hw_sy, clamp_at, save,
-                       F_out, g_F, g_residual, g_epi, g_weights_extra, logits_mode, g_weights);
-  else
-    hipLaunchKernelGGL(w8pt_bwd_kernel<false>, grid, block, 0, st, pts1, pts2, weights, B, N, hw_sx, hw_sy, clamp_at, save,
-                       F_out, g_F, g_residual, g_epi, g_weights_extra, logits_mode, g_weights);
+#define DFEPE_LAUNCH_BWD(R, P)                                                                                              \
+  hipLaunchKernelGGL((w8pt_bwd_kernel<R, P>), grid, block, 0, st, pts1, pts2, weights, B, N, hw_sx, hw_sy, clamp_at, save,   \
+                     F_out, g_F, g_residual, g_epi, g_weights_extra, logits_mode, g_weights, g_pts1, g_pts2)
+  if (raw) {
+    if (pgrad) DFEPE_LAUNCH_BWD(true, true); else DFEPE_LAUNCH_BWD(true, false);
+  } else {
+    if (pgrad) DFEPE_LAUNCH_BWD(false, true); else DFEPE_LAUNCH_BWD(false, false);
+  }
+#undef DFEPE_LAUNCH_BWD
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }

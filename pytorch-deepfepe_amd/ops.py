@@ -59,18 +59,22 @@ def w8pt_forward(pts1: Tensor, pts2: Optional[Tensor], weights: Tensor, raw: boo
 
 
 def w8pt_backward(pts1, pts2, weights, raw, image_w, image_h, clamp_at, save, F, gF, gRes, gEpi, logits=False, gW_extra=None,
-                  out: Optional[Tensor] = None):
+                  out: Optional[Tensor] = None, want_pts: bool = False):
     """Raw launch of the adjoint; returns d/d(weights) (or d/d(logits) when ``logits``; then ``weights`` must be the
-    forward's weights_out)."""
+    forward's weights_out) and, when ``want_pts``, the gradients w.r.t. the points ([B,N,3] x 2, or [B,N,4] for raw matches)."""
     L = _lib.lib()
     B, N = weights.shape
     gW = torch.empty_like(weights) if out is None else out
+    gP1 = gP2 = None
+    if want_pts:
+        gP1 = torch.empty_like(pts1)
+        gP2 = None if raw else torch.empty_like(pts2)
     with torch.cuda.device(weights.device):
         rc = L.dfepe_w8pt_bwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, _flags(raw, logits), float(image_w), float(image_h),
                               float(clamp_at), _ptr(save), _ptr(F), _ptr(gF), _ptr(gRes), _ptr(gEpi), _ptr(gW_extra), _ptr(gW),
-                              _stream())
+                              _ptr(gP1), _ptr(gP2), _stream())
     _lib.check(rc, "dfepe_w8pt_bwd")
-    return gW
+    return (gW, gP1, gP2) if want_pts else gW
 
 
 def eight_point(X: Tensor, Y: Tensor, w: Optional[Tensor], essential: bool, normalize: bool = True) -> Tensor:
@@ -123,13 +127,18 @@ class _W8ptFunction(torch.autograd.Function):
         gWout = rest.pop(0) if logits else None
         if gF is None and gRes is None and gEpi is None and gWout is None:
             return (None,) * 9
-        gW = w8pt_backward(pts1, pts2 if pts2.numel() else None, weights, raw, image_w, image_h, clamp_at, save, F,
-                           _cf(gF), _cf(gRes), _cf(gEpi), logits=logits, gW_extra=_cf(gWout))
-        return None, None, gW, None, None, None, None, None, None
+        want_pts = ctx.needs_input_grad[0] or (not raw and ctx.needs_input_grad[1])
+        res = w8pt_backward(pts1, pts2 if pts2.numel() else None, weights, raw, image_w, image_h, clamp_at, save, F,
+                            _cf(gF), _cf(gRes), _cf(gEpi), logits=logits, gW_extra=_cf(gWout), want_pts=want_pts)
+        if want_pts:
+            gW, gP1, gP2 = res
+            return gP1, gP2, gW, None, None, None, None, None, None
+        return None, None, res, None, None, None, None, None, None
 
 
 def w8pt(pts1: Tensor, pts2: Tensor, weights: Tensor, clamp_at: float = 0.5, want_epi: bool = False):
-    """Differentiable (w.r.t. weights) fit on homogeneous points [B,N,3]; weights [B,N] or [B,1,N]."""
+    """Differentiable fit on homogeneous points [B,N,3]; weights [B,N] or [B,1,N].  Gradients flow to the weights and,
+    when the point tensors require grad, to both point sets."""
     pts1, pts2 = _prep(pts1, "pts1"), _prep(pts2, "pts2")
     w = _prep(weights.reshape(weights.shape[0], -1), "weights")
     return _W8ptFunction.apply(pts1, pts2, w, False, 0.0, 0.0, clamp_at, want_epi, False)

@@ -135,7 +135,7 @@ class _HotPathFunction(torch.autograd.Function):
             _lib.check(rc, "dfepe_floss_bwd")
             for l in range(L):
                 rc = lib.dfepe_w8pt_bwd(matches.data_ptr(), None, weights[l].data_ptr(), B, N, flags, W, H, 0.5, saves[l].data_ptr(),
-                                        F_layers[l].data_ptr(), gF[l].data_ptr(), None, None, None, g_logits[l].data_ptr(), st)
+                                        F_layers[l].data_ptr(), gF[l].data_ptr(), None, None, None, g_logits[l].data_ptr(), None, None, st)
                 _lib.check(rc, "dfepe_w8pt_bwd")
         return None, g_logits, None, None, None, None, None, None, None, None
 

@@ -215,3 +215,45 @@ def test_floss_many_virtual_points_generic_path(dfepe, oracle):
     loss_sum, E = dfepe.ops.floss(Fl.float().to(DEV), T.float().to(DEV), T.float().to(DEV), sc["Ks"].to(DEV), sc["pts1_virt_ori"].to(DEV), sc["pts2_virt_ori"].to(DEV), 0.02)
     assert relerr(loss_sum.cpu().numpy(), (losses["loss_per_pair"] * M).numpy()) < 5e-5
     assert relerr(E.cpu().numpy(), torch.stack(E_layers).numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("use_epi", [False, True])
+def test_point_gradients_vs_oracle_autograd(dfepe, oracle, use_epi):
+    """d/d(pts1), d/d(pts2) of the fit (rows, Hartley transforms, de-normalisation, residual's direct dependence) and
+    d/d(matches) of the raw-matches entry, against fp64 autograd of the oracle."""
+    B, N = 5, 100
+    sc = dfepe.synth.make_scene(B, N, seed=41, outlier_ratio=0.2)
+    g = torch.Generator().manual_seed(3)
+    GF, GR, GE = torch.randn(B, 3, 3, generator=g), torch.randn(B, N, generator=g), torch.randn(B, N, generator=g)
+    w = torch.softmax(sc["logits_layers"][0], 1)
+    p1, p2, _ = oracle.normalize_hw(sc["matches_xy_ori"], IMAGE_SIZE)
+    p1 = p1.clone(); p2 = p2.clone()
+    p1[:, :, 2] += 0.05 * torch.randn(B, N, generator=g)  # general homogeneous coordinate
+    p2[:, :, 2] += 0.05 * torch.randn(B, N, generator=g)
+    a1, a2, aw = p1.to(DEV).requires_grad_(True), p2.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    outs = dfepe.ops.w8pt(a1, a2, aw, clamp_at=0.5, want_epi=True)
+    loss = (outs[0] * GF.to(DEV)).sum() + (outs[1] * GR.to(DEV)).sum() + ((outs[2] * GE.to(DEV)).sum() if use_epi else 0.0)
+    loss.backward()
+    o1, o2, ow = p1.double().requires_grad_(True), p2.double().requires_grad_(True), w.double().requires_grad_(True)
+    o_out, o_res, _ = oracle.fit_forward(o1, o2, ow.unsqueeze(1))
+    s = torch.sign((o_out.detach() * outs[0].detach().cpu().double()).flatten(1).sum(1))
+    lo = (s[:, None, None] * o_out * GF.double()).sum() + (s[:, None] * o_res * GR.double()).sum()
+    if use_epi:
+        lo = lo + (oracle.compute_epi_residual(o1, o2, o_out, 0.5) * GE.double()).sum()
+    lo.backward()
+    assert relerr(aw.grad.cpu().numpy(), ow.grad.numpy()) < 2e-3
+    assert relerr(a1.grad.cpu().numpy(), o1.grad.numpy()) < 2e-3
+    assert relerr(a2.grad.cpu().numpy(), o2.grad.numpy()) < 2e-3
+    # raw pixel matches: chain through the image-size normalisation
+    m = sc["matches_xy_ori"].to(DEV).requires_grad_(True)
+    outs = dfepe.ops.w8pt_raw(m, w.to(DEV), 1241, 376, clamp_at=0.5, want_epi=True)
+    ((outs[0] * GF.to(DEV)).sum() + (outs[1] * GR.to(DEV)).sum() + ((outs[2] * GE.to(DEV)).sum() if use_epi else 0.0)).backward()
+    mo = sc["matches_xy_ori"].double().requires_grad_(True)
+    q1, q2, _ = oracle.normalize_hw(mo, IMAGE_SIZE)
+    o_out, o_res, _ = oracle.fit_forward(q1, q2, w.double().unsqueeze(1))
+    s = torch.sign((o_out.detach() * outs[0].detach().cpu().double()).flatten(1).sum(1))
+    lo = (s[:, None, None] * o_out * GF.double()).sum() + (s[:, None] * o_res * GR.double()).sum()
+    if use_epi:
+        lo = lo + (oracle.compute_epi_residual(q1, q2, o_out, 0.5) * GE.double()).sum()
+    lo.backward()
+    assert relerr(m.grad.cpu().numpy(), mo.grad.numpy()) < 2e-3
