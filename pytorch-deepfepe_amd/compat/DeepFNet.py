@@ -60,15 +60,15 @@ class Fit(nn.Module):
 
 class DeepFNet(nn.Module):
     """Recurrent weight-estimation / fit loop.  Same constructor and ``forward(data_batch) -> dict`` contract as the
-    reference (DeepFNet.py:300,429-554; dict keys :534-548).  Built: the default branch every shipped config uses
-    (no descriptors, no learned offsets, no triangulated depth, no image weights); the others raise."""
+    reference (DeepFNet.py:300,429-554; dict keys :534-548).  Built: the default branch every shipped config uses plus
+    if_quality, if_img_w and if_learn_offsets (the gradient reaches the offsets through the solver's d/d(matches));
+    descriptors, triangulated depth and the deprecated GoodCorresNet architecture raise."""
 
     def __init__(self, depth, image_size, if_quality, if_img_w=False, if_goodCorresArch=False, if_tri_depth=False,
                  if_learn_offsets=False, if_des=False, des_size=None, quality_size=0, is_cuda=True, is_test=False,
                  if_cpu_svd=False, **params):
         super().__init__()
-        for flag, name in ((if_goodCorresArch, "if_goodCorresArch"), (if_tri_depth, "if_tri_depth"),
-                           (if_learn_offsets, "if_learn_offsets"), (if_des, "if_des")):
+        for flag, name in ((if_goodCorresArch, "if_goodCorresArch"), (if_tri_depth, "if_tri_depth"), (if_des, "if_des")):
             if flag:
                 raise NotImplementedError(f"DeepFNet({name}=True) is outside the built hot path (SURVEY.md §8)")
         if not if_quality:
@@ -79,14 +79,21 @@ class DeepFNet(nn.Module):
         self.depth = depth
         self.input_weights = ErrorEstimator(4 + quality_size)
         self.update_weights = ErrorEstimator(4 + quality_size + 3)  # + weights, epi_res, residual (DeepFNet.py:340)
+        self.if_learn_offsets = if_learn_offsets
+        if if_learn_offsets:  # (DeepFNet.py:341-342): per-correspondence pixel offsets, no batch norm
+            self.update_offsets = ErrorEstimator(4 + quality_size + 3, output_size=4, if_bn=False)
         if is_test:
             self.input_weights.eval()
             self.update_weights.eval()
+            if if_learn_offsets:
+                self.update_offsets.eval()
         self.norm_HW = NormalizeAndExpand_HW(image_size, is_cuda, is_test)
         self.fit = Fit(is_cuda, is_test, if_cpu_svd)
 
     def get_input(self, data_batch, offsets=None, iter=None):
         pts = data_batch["matches_xy_ori"]
+        if offsets is not None:  # (DeepFNet.py:369-373)
+            pts = pts + offsets.permute(0, 2, 1)
         pts1, pts2, T1, T2 = self.norm_HW(pts)
         pts1 = pts1.permute(0, 2, 1)
         pts2 = pts2.permute(0, 2, 1)
@@ -94,7 +101,7 @@ class DeepFNet(nn.Module):
         if self.if_quality:
             parts.append(data_batch["quality"])
         weight_in = torch.cat(parts, 2).permute(0, 2, 1)
-        return weight_in, pts1, pts2, T1, T2
+        return weight_in, pts1, pts2, T1, T2, pts
 
     def _fit(self, matches, logits, data_batch, want_epi):
         """logits [B,1,N] -> (out, residual[, epi], weights_prod [B,1,N]).  The softmax over N is fused into the solver
@@ -109,13 +116,14 @@ class DeepFNet(nn.Module):
     def forward(self, data_batch):
         matches = data_batch["matches_xy_ori"]
         _require_gpu(matches, "DeepFNet")
-        pts_normalized_in, pts1, pts2, T1, T2 = self.get_input(data_batch)
+        pts_normalized_in, pts1, pts2, T1, T2, _ = self.get_input(data_batch)
         logits = self.input_weights(pts_normalized_in)
         _ = data_batch["matches_good_unique_nums"]  # read like the reference does (DeepFNet.py:449,453)
         _ = data_batch["t_scene_scale"]
 
         out_layers, epi_res_layers, residual_layers = [], [], []
         weights_layers, logits_layers = [], [logits]
+        offsets_accu = None
         for it in range(self.depth - 1):
             out, residual, epi, weights_prod = self._fit(matches, logits, data_batch, True)
             weights_layers.append(weights_prod)
@@ -124,13 +132,17 @@ class DeepFNet(nn.Module):
             epi_res = epi.unsqueeze(1)
             epi_res_layers.append(epi_res)
             net_in = torch.cat((pts_normalized_in, weights_prod, epi_res, residual.unsqueeze(1)), 1)
+            if self.if_learn_offsets:  # (DeepFNet.py:490-507): the later fits see the corrected matches
+                offsets_accu = self.update_offsets(net_in)
+                pts_normalized_in, pts1, pts2, T1, T2, matches = self.get_input(data_batch, offsets_accu, it)
+                net_in = torch.cat((pts_normalized_in, weights_prod, epi_res, residual.unsqueeze(1)), 1)
             logits = self.update_weights(net_in)
             logits_layers.append(logits)
         out, residual, weights_prod = self._fit(matches, logits, data_batch, False)
         weights_layers.append(weights_prod)
         residual_layers.append(residual)
         out_layers.append(out)
-        return {
+        preds = {
             "logits": logits.squeeze(1),
             "logits_layers": logits_layers,
             "F_est": out,
@@ -144,3 +156,6 @@ class DeepFNet(nn.Module):
             "residual_layers": residual_layers,
             "weights_layers": weights_layers,
         }
+        if self.if_learn_offsets:
+            preds["offsets"] = offsets_accu
+        return preds

@@ -224,3 +224,49 @@ def test_validation_pose_path(dfepe, oracle):
     np.testing.assert_allclose(M[:, :3], sc["delta_Rtijs_4_4"][0, :3, :3].numpy(), atol=2e-3)  # scene convention: x2 ~ R x1 + t
     M2, errs = dfepe.compat.utils_F.goodCorr_eval_nondecompose(np.zeros((3, 2)), np.zeros((3, 2)), np.eye(3), cam, sc["Ks"][0].numpy(), None)
     assert errs == (180.0, 90.0)
+
+
+def test_deepfnet_learned_offsets_branch(dfepe):
+    """if_learn_offsets (DeepFNet.py:490-507): with a zeroed offset head the model equals the plain one; the gradient of
+    the F-loss reaches the offset head through the solver's d/d(matches) and agrees with a finite difference."""
+    torch.manual_seed(0)
+    B, N, depth = 3, 100, 3
+    sc = dfepe.synth.make_scene(B, N, seed=51, outlier_ratio=0.2)
+    dev = dfepe.pipeline.scene_to_device(sc, DEV)
+    batch = {"matches_xy_ori": dev["matches_xy_ori"], "matches_good_unique_nums": None, "t_scene_scale": None}
+    plain = dfepe.compat.DeepFNet.DeepFNet(depth=depth, image_size=IMAGE_SIZE, if_quality=False).to(DEV)
+    dfepe.synth.fill_params_deterministic(plain, seed=2)
+    net = dfepe.compat.DeepFNet.DeepFNet(depth=depth, image_size=IMAGE_SIZE, if_quality=False, if_learn_offsets=True).to(DEV)
+    net.input_weights.load_state_dict(plain.input_weights.state_dict())
+    net.update_weights.load_state_dict(plain.update_weights.state_dict())
+    with torch.no_grad():
+        for p in net.update_offsets.parameters():
+            p.zero_()
+    o0, o1 = plain(batch), net(batch)
+    assert "offsets" in o1 and o1["offsets"].shape == (B, 4, N) and o1["offsets"].abs().max().item() == 0.0
+    for a, b in zip(o0["out_layers"], o1["out_layers"]):  # the stock estimator is not bit-reproducible run to run (MIOpen): ~1e-6 drift
+        assert (a - b).abs().max().item() < 1e-4 * a.abs().max().item()
+    # now a small non-zero head: analytic gradient vs central finite difference along the last bias
+    dfepe.synth.fill_params_deterministic(net.update_offsets, seed=9)
+    with torch.no_grad():
+        for p in net.update_offsets.parameters():
+            p.mul_(0.05)
+    lp = {"depth": depth, "clamp_at": 0.5, "if_tri_depth": False, "if_sample_loss": False, "topK": 8, "matches_good_unique_nums": None}
+
+    def loss_of():
+        outs = net(batch)
+        losses = dfepe.compat.train_good_utils.get_all_loss_DeepF(outs, dev["pts1_virt_ori"], dev["pts2_virt_ori"], dev["Ks"], lp, get_residual_summaries=False)[0]
+        return losses["loss_F"]
+
+    bias = net.update_offsets.fw[15].bias
+    net.zero_grad()
+    loss_of().backward()
+    g = bias.grad.clone()
+    assert torch.isfinite(g).all() and g.abs().max().item() > 0
+    d = torch.tensor([1.0, -0.5, 0.7, 0.3], device=DEV)
+    eps = 0.05  # pixels
+    with torch.no_grad():
+        bias.add_(eps * d); lp_ = loss_of().item(); bias.sub_(2 * eps * d); lm_ = loss_of().item(); bias.add_(eps * d)
+    num = (lp_ - lm_) / (2 * eps)
+    ana = (g * d).sum().item()
+    assert abs(num - ana) < 0.05 * max(abs(num), abs(ana)) + 1e-7, (num, ana)
