@@ -190,6 +190,19 @@ int dfepe_epi_residual_bwd(const float *pts1, const float *pts2, const float *F,
  */
 int dfepe_geo_misc(int kind, const float *in0, const float *in1, int n, float *out, void *stream);
 
+/*
+ * InstanceNorm1d(affine) + LeakyReLU on rows of N contiguous floats ("next" row f-1: the part of the weight estimator
+ * between its 1x1 convolutions, deepFEPE/models/ErrorEstimators.py:47-64; the convolutions themselves are GEMMs).
+ *   Y, A, gA, gY: [(c*R + r)*N + n]  (channel-major: c < C channels, r < R rows per channel, N points), 16-byte aligned;
+ *   gamma, beta [C]; stats [C*R*2] = (mean, 1/sqrt(var+eps)) per row, written by fwd and read by bwd;
+ *   row_ggamma, row_gbeta [C*R]: per-row contributions to d/d(gamma[c]), d/d(beta[c]) (sum over r is left to the caller).
+ *   N must be a multiple of 4 and <= 512 (DFEPE_ERR_UNSUPPORTED otherwise).
+ */
+int dfepe_inorm_lrelu_fwd(const float *Y, const float *gamma, const float *beta, int C, int R, int N, float eps, float slope,
+                          float *A, float *stats, void *stream);
+int dfepe_inorm_lrelu_bwd(const float *Y, const float *gA, const float *gamma, const float *beta, const float *stats,
+                          int C, int R, int N, float slope, float *gY, float *row_ggamma, float *row_gbeta, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

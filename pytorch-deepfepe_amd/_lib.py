@@ -36,6 +36,8 @@ _SIGNATURES = {
     "dfepe_epi_residual_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P]),
     "dfepe_epi_residual_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P]),
     "dfepe_geo_misc": (c_int, [c_int, _P, _P, c_int, _P, _P]),
+    "dfepe_inorm_lrelu_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P]),
+    "dfepe_inorm_lrelu_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

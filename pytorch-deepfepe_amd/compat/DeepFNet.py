@@ -6,7 +6,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib, ops
-from .ErrorEstimators import ErrorEstimator
+from .ErrorEstimators import ErrorEstimator, FusedErrorEstimator
 
 
 def _require_gpu(t, what):
@@ -77,11 +77,14 @@ class DeepFNet(nn.Module):
         self.if_img_w = if_img_w
         self.image_size = image_size
         self.depth = depth
-        self.input_weights = ErrorEstimator(4 + quality_size)
-        self.update_weights = ErrorEstimator(4 + quality_size + 3)  # + weights, epi_res, residual (DeepFNet.py:340)
+        # same parameters / state_dict as the reference's ErrorEstimator; evaluated as channel-major GEMMs + one fused
+        # InstanceNorm+LeakyReLU pass (falls back to the stock module when that layout does not apply)
+        Est = FusedErrorEstimator if params.get("fused_estimator", True) else ErrorEstimator
+        self.input_weights = Est(4 + quality_size)
+        self.update_weights = Est(4 + quality_size + 3)  # + weights, epi_res, residual (DeepFNet.py:340)
         self.if_learn_offsets = if_learn_offsets
         if if_learn_offsets:  # (DeepFNet.py:341-342): per-correspondence pixel offsets, no batch norm
-            self.update_offsets = ErrorEstimator(4 + quality_size + 3, output_size=4, if_bn=False)
+            self.update_offsets = Est(4 + quality_size + 3, output_size=4, if_bn=False)
         if is_test:
             self.input_weights.eval()
             self.update_weights.eval()

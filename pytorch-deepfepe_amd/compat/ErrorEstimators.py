@@ -30,3 +30,38 @@ class ErrorEstimator(nn.Module):
         if data.shape[0] <= self.max_chunk:
             return self.fw(data)
         return torch.cat([self.fw(c) for c in data.split(self.max_chunk, dim=0)], dim=0)
+
+
+class FusedErrorEstimator(ErrorEstimator):
+    """Same parameters / state_dict as ErrorEstimator, MI355X-shaped evaluation ("next" row f-1 of SURVEY.md §8):
+    activations live channel-major as [C, B*N], every 1x1 convolution is ONE large GEMM W[C_out,C_in] @ X[C_in, B*N]
+    (rocBLAS / hipBLASLt through torch.mm) instead of B small ones, and InstanceNorm + LeakyReLU is one fused HIP pass
+    (ops.inorm_lrelu).  The biases of the convolutions that feed an InstanceNorm cancel in the normalisation and are
+    skipped (their gradient is exactly zero in the reference too).  Falls back to the stock path for the batch-norm
+    variant and for N not a multiple of 4 or above 512."""
+
+    def forward(self, data):
+        from .. import ops
+
+        B, C0, N = data.shape
+        mods = list(self.fw)
+        if any(isinstance(m, nn.BatchNorm1d) for m in mods) or (N % 4) or N > 512 or not data.is_cuda:
+            return super().forward(data)
+        x = data.permute(1, 0, 2).reshape(C0, B * N)  # channel-major
+        i = 0
+        while i < len(mods):
+            conv = mods[i]
+            W = conv.weight[:, :, 0]
+            if i + 2 < len(mods) and isinstance(mods[i + 1], nn.InstanceNorm1d):
+                inorm, act = mods[i + 1], mods[i + 2]
+                y = torch.mm(W, x)  # bias cancels in the instance normalisation
+                a = ops.inorm_lrelu(y.view(W.shape[0], B, N), inorm.weight, inorm.bias, inorm.eps, act.negative_slope)
+                x = a.view(W.shape[0], B * N)
+                i += 3
+            else:  # last convolution
+                y = torch.mm(W, x)
+                if conv.bias is not None:
+                    y = y + conv.bias[:, None]
+                x = y
+                i += 1
+        return x.view(-1, B, N).permute(1, 0, 2)

@@ -350,3 +350,40 @@ def cheirality(E: Tensor, K: Tensor, matches: Tensor, depth_thres: float = 50.0)
         rc = _lib.lib().dfepe_cheirality(_ptr(E), _ptr(K), _ptr(m), B, N, float(depth_thres), _ptr(Rt), _ptr(win), _ptr(cnt), _stream())
     _lib.check(rc, "dfepe_cheirality")
     return Rt, win, cnt
+
+
+# ------------------------------------------------------------------------------------------------
+# InstanceNorm1d(affine) + LeakyReLU on channel-major activations (weight-estimator fusion, "next" row f-1)
+# ------------------------------------------------------------------------------------------------
+class _InormLReLUFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Y, gamma, beta, eps, slope):
+        C, R, N = Y.shape
+        A = torch.empty_like(Y)
+        stats = torch.empty(C * R, 2, device=Y.device, dtype=torch.float32)
+        with torch.cuda.device(Y.device):
+            rc = _lib.lib().dfepe_inorm_lrelu_fwd(_ptr(Y), _ptr(gamma), _ptr(beta), C, R, N, float(eps), float(slope), _ptr(A),
+                                                  _ptr(stats), _stream())
+        _lib.check(rc, "dfepe_inorm_lrelu_fwd")
+        ctx.save_for_backward(Y, gamma, beta, stats)
+        ctx.slope = float(slope)
+        return A
+
+    @staticmethod
+    def backward(ctx, gA):
+        Y, gamma, beta, stats = ctx.saved_tensors
+        C, R, N = Y.shape
+        gA = gA.contiguous()
+        gY = torch.empty_like(Y)
+        rg = torch.empty(C, R, device=Y.device, dtype=torch.float32)
+        rb = torch.empty(C, R, device=Y.device, dtype=torch.float32)
+        with torch.cuda.device(Y.device):
+            rc = _lib.lib().dfepe_inorm_lrelu_bwd(_ptr(Y), _ptr(gA), _ptr(gamma), _ptr(beta), _ptr(stats), C, R, N, ctx.slope,
+                                                  _ptr(gY), _ptr(rg), _ptr(rb), _stream())
+        _lib.check(rc, "dfepe_inorm_lrelu_bwd")
+        return gY, rg.sum(dim=1), rb.sum(dim=1), None, None
+
+
+def inorm_lrelu(Y: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, slope: float = 0.01) -> Tensor:
+    """Y [C,R,N] channel-major (contiguous) -> LeakyReLU(InstanceNorm over N with affine gamma/beta [C])."""
+    return _InormLReLUFunction.apply(_prep(Y, "Y"), _prep(gamma, "gamma"), _prep(beta, "beta"), eps, slope)

@@ -80,7 +80,8 @@ def test_deepfnet_full_model_matches_reference_golden(dfepe, golden):
         get_residual_summaries=False)
     np.testing.assert_allclose(losses["loss_F"].item(), g["net_loss_F"], rtol=2e-2)
     losses["loss_F"].backward()
-    gn = {n: float(p.grad.double().norm()) for n, p in net.named_parameters()}
+    # conv biases that feed an InstanceNorm cancel exactly; the fused estimator skips them (grad None = the reference's ~0)
+    gn = {n: (0.0 if p.grad is None else float(p.grad.double().norm())) for n, p in net.named_parameters()}
     ours = np.array([gn[n] for n in sorted(gn)])
     np.testing.assert_allclose(ours, g["net_grad_norms"], rtol=0.1, atol=1e-4 * g["net_grad_norms"].max())
     ga = net.input_weights.fw[0].weight.grad.cpu().numpy().ravel()
