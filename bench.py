@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--outliers", type=float, default=0.2)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-model", action="store_true", help="skip the secondary whole-DeepFNet measurement")
     ap.add_argument("--cpu-sample", type=int, default=256, help="pairs in the CPU-baseline sample")
     return ap.parse_args()
 
@@ -203,6 +204,42 @@ def main():
         else:
             acc = {"median_R_deg": round(R_deg_med, 5), "median_t_deg": round(t_deg_med, 5)}
 
+        # ---- secondary, informational: the whole DeepFNet step (estimator evaluated as channel-major GEMMs + fused
+        #      InstanceNorm/LeakyReLU, solver, F-loss, qt loss, backward to the estimator parameters) --------------------
+        full_model = None
+        if not args.no_full_model:
+            try:
+                net = dfepe.compat.DeepFNet.DeepFNet(depth=L, image_size=IMAGE_SIZE, if_quality=False).to(dev)
+                dfepe.synth.fill_params_deterministic(net, 1)
+                tgu = dfepe.compat.train_good_utils
+                lp = {"depth": L, "clamp_at": 0.02, "if_tri_depth": False, "if_sample_loss": False, "topK": 8, "matches_good_unique_nums": None}
+                batch = {"matches_xy_ori": scene["matches_xy_ori"], "matches_good_unique_nums": None, "t_scene_scale": None}
+
+                def full_step():
+                    net.zero_grad(set_to_none=True)
+                    outs = net(batch)
+                    losses, _, _, _, _, _, E_layers = tgu.get_all_loss_DeepF(outs, scene["pts1_virt_ori"], scene["pts2_virt_ori"], scene["Ks"], lp, get_residual_summaries=False)
+                    rt = tgu.get_Rt_loss(E_layers, None, None, None, scene["delta_Rtijs_4_4"], scene["qs_cam"], scene["ts_cam"], device=dev)
+                    lq = torch.clamp(torch.stack(rt["q_l2_error_layers_list"]), 0, 0.1).mean()
+                    lt = torch.clamp(torch.stack(rt["t_l2_error_layers_list"]), 0, 0.5).mean()
+                    (losses["loss_F"] + lq + 0.1 * lt).backward()
+
+                for _ in range(2):
+                    full_step()
+                torch.cuda.synchronize()
+                f0 = time.perf_counter()
+                nfull = 3
+                for _ in range(nfull):
+                    full_step()
+                torch.cuda.synchronize()
+                fdt = (time.perf_counter() - f0) / nfull
+                full_model = {"value": round(B / fdt, 1), "unit": "pairs/s", "ms_per_step": round(fdt * 1e3, 2),
+                              "what": "compat.DeepFNet (seeded random weights) forward + F-loss + qt loss + backward to the estimator parameters; "
+                                      "estimator = torch.mm GEMMs (fp32) + fused HIP InstanceNorm/LeakyReLU; not part of `value`"}
+                del net
+            except Exception as e:  # never let the secondary measurement break the contract line
+                full_model = {"error": repr(e)[:200]}
+
         result = {
             "metric": "image-pairs/sec (F+E+pose+loss) at B=4096 N=100; median R/t angular err vs ref",
             "value": round(value, 1),
@@ -223,6 +260,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "accuracy": acc,
+            "full_model": full_model,
         }
         print(json.dumps(result), flush=True)
     if dist is not None:

@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256, 4)
 w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, const float* __restrict__ wts,
                 int B, int N, int npad, int wave_bytes, float hw_sx, float hw_sy, float clamp_at,
                 float* __restrict__ F_out, float* __restrict__ residual, float* __restrict__ epi_res,
-                float* __restrict__ save, float* __restrict__ weights_out, int logits_mode, unsigned variant) {
+                float* __restrict__ save, float* __restrict__ weights_out, int logits_mode, unsigned variant, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
@@ -265,9 +265,10 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   const int pp = (lane < 8) ? (lane & ~1) : 0;  // lanes 0..7: my pair is positions (pp, pp+1)
   wave_sync();
   int n_sweeps = 0, n_refine = 0;
-  // DEBUG hook: clamp_at = -(1+S) forces exactly S sweeps without the polish, clamp_at = -(51+S) with it
-  const bool dbg_polish = clamp_at < -50.f;
-  const int max_sweeps = (clamp_at < 0.f) ? (int)(-clamp_at) - (dbg_polish ? 51 : 1) : kMaxSweeps;
+  // diagnostics (DFEPE_W8PT_DIAG_* bits of `flags`, see scripts/quick_time.py): dbg = 0 normal; otherwise bits 0..7 hold
+  // 1 + the exact number of sweeps to run (no convergence test) and bit 8 keeps the polish enabled
+  const bool dbg_on = dbg != 0, dbg_polish = (dbg & 0x100) != 0;
+  const int max_sweeps = dbg_on ? (dbg & 0xff) - 1 : kMaxSweeps;
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     float off = 0.0f;
     if (is_a && ti != tj) {
@@ -275,7 +276,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
       off = a * a;
     }
     off = wave_sum(off);
-    if (!(off > kJacobiTol) && !(clamp_at < 0.f)) break;  // wave-uniform (also leaves on NaN)
+    if (!(off > kJacobiTol) && !dbg_on) break;  // wave-uniform (also leaves on NaN)
     ++n_sweeps;
     for (int r = 0; r < 9; ++r) {
       // every read of the round is issued up front (none depends on this round's rotations): 4 x ds_read_b64 + the
@@ -333,7 +334,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   // residual correction: r = M f - rho f;  f += sum_{k != kmin} q_k (q_k . r) / (rho - lam_k);  renormalise.
   // The Jacobi basis (fp32-accurate) acts as an approximate inverse of (M - rho); the fixed point is the exact
   // fp64 eigenvector, reached at a linear rate ~ eps32 |M| / gap per iteration.
-  for (int it = 0; it < ((clamp_at < 0.f && !dbg_polish) ? 0 : kRefineIters); ++it) {
+  for (int it = 0; it < ((dbg_on && !dbg_polish) ? 0 : kRefineIters); ++it) {
     double fn2 = 0.0;
 #pragma unroll
     for (int c = 0; c < 9; ++c) fn2 += f[c] * f[c];
@@ -513,6 +514,7 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
   const bool raw = (flags & DFEPE_W8PT_RAW_MATCHES) != 0;
   const int logits_mode = (flags & DFEPE_W8PT_LOGITS) ? 1 : 0;
   const unsigned variant = flags & (DFEPE_W8PT_SQRT2 | DFEPE_W8PT_NO_ROWNORM | DFEPE_W8PT_FORCE_110);
+  const int dbg = (int)((flags >> 16) & 0x1ffu);  // undocumented diagnostics: forced sweep count (timing experiments only)
   if (B < 0 || N <= 0) return DFEPE_ERR_INVALID_ARG;
   if (variant && save) return DFEPE_ERR_UNSUPPORTED;  // the textbook variants are forward-only
   if (B == 0) return DFEPE_OK;
@@ -544,7 +546,7 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
       if (err != hipSuccess) return DFEPE_ERR_HIP;
     }
     hipLaunchKernelGGL(w8pt_fwd_kernel<true>, grid, block, lds, st, pts1, pts2, weights, B, N, npad, wave_bytes,
-                       hw_sx, hw_sy, clamp_at, F_out, residual, epi_res, save, weights_out, logits_mode, variant);
+                       hw_sx, hw_sy, clamp_at, F_out, residual, epi_res, save, weights_out, logits_mode, variant, dbg);
   } else {
     if (lds > 64 * 1024) {
       err = hipFuncSetAttribute(reinterpret_cast<const void*>(&w8pt_fwd_kernel<false>),
@@ -552,7 +554,7 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
       if (err != hipSuccess) return DFEPE_ERR_HIP;
     }
     hipLaunchKernelGGL(w8pt_fwd_kernel<false>, grid, block, lds, st, pts1, pts2, weights, B, N, npad, wave_bytes,
-                       hw_sx, hw_sy, clamp_at, F_out, residual, epi_res, save, weights_out, logits_mode, variant);
+                       hw_sx, hw_sy, clamp_at, F_out, residual, epi_res, save, weights_out, logits_mode, variant, dbg);
   }
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }

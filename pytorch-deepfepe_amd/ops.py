@@ -39,7 +39,8 @@ def _flags(raw: bool, logits: bool) -> int:
 
 
 def w8pt_forward(pts1: Tensor, pts2: Optional[Tensor], weights: Tensor, raw: bool, image_w: float, image_h: float,
-                 clamp_at: float, want_epi: bool, want_save: bool, logits: bool = False, F_out: Optional[Tensor] = None):
+                 clamp_at: float, want_epi: bool, want_save: bool, logits: bool = False, F_out: Optional[Tensor] = None,
+                 diag: int = 0):
     """Raw (non-differentiable) launch.  weights (or logits when ``logits``) [B,N].
     Returns F [B,3,3], residual [B,N], epi [B,N]|None, save|None, weights_out [B,N]|None.  ``F_out`` lets the caller
     provide the destination (e.g. one [B,3,3] slice of a per-layer stack)."""
@@ -52,8 +53,8 @@ def w8pt_forward(pts1: Tensor, pts2: Optional[Tensor], weights: Tensor, raw: boo
     save = torch.empty(B, L.dfepe_save_floats(), device=dev, dtype=torch.float32) if want_save else None
     w_out = torch.empty(B, N, device=dev, dtype=torch.float32) if logits else None
     with torch.cuda.device(dev):
-        rc = L.dfepe_w8pt_fwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, _flags(raw, logits), float(image_w), float(image_h),
-                              float(clamp_at), _ptr(F), _ptr(residual), _ptr(epi), _ptr(save), _ptr(w_out), _stream())
+        rc = L.dfepe_w8pt_fwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, _flags(raw, logits) | (int(diag) << 16), float(image_w),
+                              float(image_h), float(clamp_at), _ptr(F), _ptr(residual), _ptr(epi), _ptr(save), _ptr(w_out), _stream())
     _lib.check(rc, "dfepe_w8pt_fwd")
     return F, residual, epi, save, w_out
 
