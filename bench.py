@@ -179,7 +179,7 @@ def main():
         log("roofline probe done", kdur)
         # ---- CPU baseline: the oracle's reference-shaped loop on a bounded sample of the same workload -----
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # contract: CPU baseline on rank 0 at N=1 only
             oracle = importlib.import_module("oracle.deepf_oracle")
             Bc = min(args.cpu_sample, B)
             cpu_scene = {k: (v[:Bc] if k != "logits_layers" else v[:, :Bc]).cpu() for k, v in scene.items()}
@@ -207,7 +207,7 @@ def main():
         # ---- secondary, informational: the whole DeepFNet step (estimator evaluated as channel-major GEMMs + fused
         #      InstanceNorm/LeakyReLU, solver, F-loss, qt loss, backward to the estimator parameters) --------------------
         full_model = None
-        if not args.no_full_model:
+        if not args.no_full_model and world == 1:
             try:
                 net = dfepe.compat.DeepFNet.DeepFNet(depth=L, image_size=IMAGE_SIZE, if_quality=False).to(dev)
                 dfepe.synth.fill_params_deterministic(net, 1)

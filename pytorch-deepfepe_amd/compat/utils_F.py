@@ -142,6 +142,27 @@ def goodCorr_eval_nondecompose(p1s, p2s, E_hat, delta_Rtij_inv, K, scores, if_my
     return torch.cat((R, t), 1).cpu().numpy(), (err_q, err_t)
 
 
+def _get_M2s_batch(Es_batch):
+    """Batched four-fold decomposition (utils_F.py:500-519; the reference needs the external batch_svd CUDA extension).
+    Returns ([R1 [B,3,3], R2 [B,3,3]], [t [B,3,1], -t])."""
+    R1, R2, t = ops.decompose_essential(_gpu(Es_batch))
+    t = t.unsqueeze(-1)
+    return [R1, R2], [t, -t]
+
+
+def epi_distance_np(F, X, Y, if_homo=False):
+    """numpy-in / numpy-out evaluation metric (utils_F.py:363-385): returns (d1 + d2, d1, d2), not squared."""
+    import numpy as np
+
+    dev = torch.device("cuda")
+    Fm = torch.as_tensor(np.asarray(F), dtype=torch.float32, device=dev)
+    Xt = torch.as_tensor(np.asarray(X), dtype=torch.float32, device=dev)
+    Yt = torch.as_tensor(np.asarray(Y), dtype=torch.float32, device=dev)
+    _, d1, d2 = _epi_distance(Fm, Xt, Yt, if_homo=if_homo)
+    d1, d2 = d1.cpu().numpy(), d2.cpu().numpy()
+    return d1 + d2, d1, d2
+
+
 def _diag_weights(W, N):
     """The reference left-multiplies the design matrix by a dense W [N,N] (utils_F.py:129-130); its callers pass
     torch.diag(w) (train_good_utils.get_E_ests).  Only diagonal W is built: it is a per-correspondence weight."""
@@ -161,6 +182,22 @@ def _F_from_XY(X, Y, W=None, normalize=True, show_debug=False):
     X, Y = _gpu(X), _gpu(Y)
     w = _diag_weights(W, X.shape[0])
     return ops.eight_point(X.unsqueeze(0), Y.unsqueeze(0), None if w is None else w.unsqueeze(0), essential=False, normalize=normalize)[0]
+
+
+def _E_from_XY_batch(X, Y, K, W=None, if_normzliedK=False, normalize=True, show_debug=False):
+    """Batched _E_from_XY (utils_F.py:157-221): X, Y [B,N,2], K [B,3,3]; like the reference it returns the NEGATED matrix
+    (:221).  W: per-correspondence weights [B,N] (the reference takes dense [B,N,N] matrices; only diagonals are built)."""
+    X, Y = _gpu(X), _gpu(Y)
+    if not if_normzliedK:
+        Ki = torch.linalg.inv(_gpu(K))
+        ones = torch.ones(X.shape[0], X.shape[1], 1, device=X.device)
+        Xh, Yh = torch.cat((X, ones), 2) @ Ki.transpose(1, 2), torch.cat((Y, ones), 2) @ Ki.transpose(1, 2)
+        X, Y = Xh[..., :2] / (Xh[..., 2:3] + 1e-10), Yh[..., :2] / (Yh[..., 2:3] + 1e-10)
+    w = None
+    if W is not None:
+        W = _gpu(W)
+        w = torch.diagonal(W, dim1=1, dim2=2) if W.dim() == 3 else W
+    return -ops.eight_point(X.contiguous(), Y.contiguous(), w, essential=True, normalize=normalize)
 
 
 def _E_from_XY(X, Y, K, W=None, if_normzliedK=False, normalize=True, show_debug=False):

@@ -163,6 +163,16 @@ def test_dsac_tools_functions_match_reference_golden(dfepe, golden):
         assert np.abs(a - r).max() < 5e-4, (key, np.abs(a - r).max())
     with pytest.raises(NotImplementedError):
         uF._F_from_XY(x1[0], x2[0], W=torch.ones(64, 64, device=DEV))
+    # batched forms (the reference needs the external batch_svd extension for these)
+    Eb = uF._E_from_XY_batch(x1, x2, K.expand(8, 3, 3))
+    a, r, sgn = unit_align(Eb[:1].cpu().numpy(), g["E_from_XY"][None])
+    assert np.abs(a - r).max() < 5e-4
+    E1 = uF._E_from_XY(x1[0], x2[0], K)
+    assert (Eb[0] + E1).abs().max().item() < 1e-6  # the batched reference function returns the negated matrix (utils_F.py:221)
+    Rs, ts = uF._get_M2s_batch(T(g["E_in"]).to(DEV))
+    assert Rs[0].shape == (8, 3, 3) and ts[0].shape == (8, 3, 1) and (ts[0] + ts[1]).abs().max().item() == 0.0
+    d3, d1, d2 = uF.epi_distance_np(g["F_in"][0], g["x1"][0], g["x2"][0])
+    np.testing.assert_allclose(d3, 2 * g["epi_dist_b"][0][0], rtol=2e-3, atol=6e-3)
 
 
 def test_compute_epi_residual_standalone(dfepe, oracle, golden):
