@@ -318,14 +318,21 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   float lam32[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) lam32[k] = A32[k * 11];
-  const int skip = (N < 9) ? 9 - N : 0;
   int kmin = 0;
+  if (N >= 9) {  // the usual case: plain arg-min (first index on ties)
+    float lmin = lam32[0];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    int rank = 0;
+    for (int k = 1; k < 9; ++k)
+      if (lam32[k] < lmin) { lmin = lam32[k]; kmin = k; }
+  } else {       // wave-uniform branch: rank selection, skipping the 9 - N null directions
+    const int skip = 9 - N;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) rank += (lam32[j] < lam32[k] || (lam32[j] == lam32[k] && j < k)) ? 1 : 0;
-    if (rank == skip) kmin = k;
+    for (int k = 0; k < 9; ++k) {
+      int rank = 0;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) rank += (lam32[j] < lam32[k] || (lam32[j] == lam32[k] && j < k)) ? 1 : 0;
+      if (rank == skip) kmin = k;
+    }
   }
   double f[9];
 #pragma unroll
