@@ -21,7 +21,7 @@ __device__ __forceinline__ double guard_den(double d) {
 }
 
 template <bool RAW, bool PGRAD>
-__global__ void __launch_bounds__(256, 4)
+__global__ void __launch_bounds__(256, (PGRAD ? 2 : 4))  // the point-gradient variant trades occupancy for no spills
 w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, const float* __restrict__ wts, int B,
                 int N, float hw_sx, float hw_sy, float clamp_at, const float* __restrict__ save,
                 const float* __restrict__ F_out, const float* __restrict__ g_F, const float* __restrict__ g_res,
@@ -54,6 +54,7 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   const float* wsrc = wts + pair * N;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
   for (int i = lane; i < N; i += WAVE) {
+    if (g_res == nullptr && g_epi == nullptr) break;  // nothing to accumulate (fused training step: the loss depends on F only)
     const Pt p = global_point<RAW>(pts1, pts2, pair, i, N, hw_sx, hw_sy);
     if (g_res != nullptr) {
       double ph[9];
