@@ -194,13 +194,25 @@ def main():
                              "oracle/deepf_oracle.py hot_path_step(mode='loop') = per-sample torch SVD + per-sample pose loop like the reference"}
             import numpy as np
 
+            # F parity on the sample: vs the fp32 reference-shaped run above and vs the same oracle in fp64 (batched)
+            def _ferr(Fa, Fb):
+                a = Fa.reshape(Fa.shape[0], -1).double(); b = Fb.reshape(Fb.shape[0], -1).double()
+                a = a / a.norm(dim=1, keepdim=True); b = b / b.norm(dim=1, keepdim=True)
+                sgn = torch.sign((a * b).sum(1, keepdim=True))
+                return (a * sgn - b).norm(dim=1)
+            ours_F = last["F_layers"][-1][:Bc].cpu()
+            e32 = _ferr(ours_F, ref["outs"]["out_layers"][-1].detach())
+            ref64 = oracle.hot_path_step({k: v.double() for k, v in cpu_scene.items()}, IMAGE_SIZE, L, 0.02, qt=False, mode="batched", backward=False)
+            e64 = _ferr(ours_F, ref64["outs"]["out_layers"][-1])
             ours_R = last["R_deg"][-1][:Bc].cpu().numpy()
             ours_t = last["t_deg"][-1][:Bc].cpu().numpy()
             acc = {"median_R_deg": round(R_deg_med, 5), "median_t_deg": round(t_deg_med, 5),
                    "cpu_ref_median_R_deg_sample": round(float(np.median(ref["pose"]["R_deg"][-1])), 5),
                    "cpu_ref_median_t_deg_sample": round(float(np.median(ref["pose"]["t_deg"][-1])), 5),
                    "gpu_median_R_deg_sample": round(float(np.median(ours_R)), 5),
-                   "gpu_median_t_deg_sample": round(float(np.median(ours_t)), 5)}
+                   "gpu_median_t_deg_sample": round(float(np.median(ours_t)), 5),
+                   "F_fro_err_vs_fp64_oracle_sample": {"max": float(e64.max()), "median": float(e64.median())},
+                   "F_fro_err_vs_fp32_reference_shaped_sample": {"max": float(e32.max()), "median": float(e32.median())}}
         else:
             acc = {"median_R_deg": round(R_deg_med, 5), "median_t_deg": round(t_deg_med, 5)}
 
