@@ -177,6 +177,37 @@ def main():
                     "launches_per_step": L, "method": f"HIP events around {reps} back-to-back launches, median of 5"}
 
         log("roofline probe done", kdur)
+        # ---- informational: the same step with all L fits of a layer stack in ONE grid (n_weight_sets = L).  Legal for
+        # this solver-only workload because the per-layer logits are inputs; the recurrent DeepFNet cannot do it, so
+        # it is never `value`.
+        layers_batched = None
+        if world == 1 and graph is not None:
+            def body_b():
+                o = dfepe.pipeline.hot_path_fused(scene["matches_xy_ori"], logits, scene["Ks"], scene["pts1_virt_ori"],
+                                                  scene["pts2_virt_ori"], scene["qs_cam"], scene["ts_cam"], scene["R_gt"],
+                                                  IMAGE_SIZE, clamp_at=0.02, qt=True, hw_T=hw_T, layers_batched=True)
+                return torch.autograd.grad(o["loss"], logits)[0]
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                gb = body_b()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(gb, state["grad_logits"]))
+            gr_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr_b):
+                gb = body_b()
+            for _ in range(args.warmup):
+                gr_b.replay()
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for _ in range(args.steps):
+                gr_b.replay()
+            torch.cuda.synchronize()
+            tb = time.perf_counter() - tb
+            layers_batched = {"ms_per_step": round(tb * 1e3 / args.steps, 4), "pairs_per_s": round(B * args.steps / tb, 1),
+                              "grad_bit_identical_to_value_run": same,
+                              "note": "all L layers' fits in one launch; only legal with fixed logits, not `value`"}
+            log("layers-batched variant done", layers_batched)
         # ---- CPU baseline: the oracle's reference-shaped loop on a bounded sample of the same workload -----
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # contract: CPU baseline on rank 0 at N=1 only
@@ -273,6 +304,7 @@ def main():
             "cpu_baseline": cpu,
             "accuracy": acc,
             "full_model": full_model,
+            "layers_batched": layers_batched,
         }
         print(json.dumps(result), flush=True)
     if dist is not None:

@@ -61,7 +61,9 @@ int dfepe_save_floats(void);
  *
  *   pts1, pts2 [B,N,3]  homogeneous points (pts*[:,:,2] is used exactly like the reference does), or
  *   pts1       [B,N,4]  pixel matches when DFEPE_W8PT_RAW_MATCHES (image_w/image_h = W,H of image_size)
- *   weights    [B,N]    (the reference's [B,1,N])
+ *   weights    [S,B,N]  S = n_weight_sets >= 1 weightings of the SAME B pairs (the reference's [B,1,N] is S = 1; S > 1
+ *                       serves solver-only workloads that score several weightings per pair, e.g. all IRLS layers of a
+ *                       fixed-logits step in one launch); every per-pair output then has a leading S dimension
  *   F_out      [B,9]    T2^T F' T1                          (reference `out`)
  *   residual   [B,N]    X f/|f|                             (reference `residual`)
  *   epi_res    [B,N]    or NULL
@@ -71,7 +73,7 @@ int dfepe_save_floats(void);
  * largest-magnitude component is positive (F_out and residual flip together, everything downstream is
  * sign-invariant).
  */
-int dfepe_w8pt_fwd(const float *pts1, const float *pts2, const float *weights, int B, int N,
+int dfepe_w8pt_fwd(const float *pts1, const float *pts2, const float *weights, int B, int N, int n_weight_sets,
                    unsigned flags, float image_w, float image_h, float clamp_at,
                    float *F_out, float *residual, float *epi_res, float *save, float *weights_out, void *stream);
 
@@ -88,7 +90,7 @@ int dfepe_w8pt_fwd(const float *pts1, const float *pts2, const float *weights, i
  *     when g_epi is given, the residual's direct dependence); with DFEPE_W8PT_RAW_MATCHES g_pts1 is [B,N,4] (gradient
  *     w.r.t. the pixel matches, 16-byte aligned) and g_pts2 is ignored.  NULL skips that part of the kernel.
  */
-int dfepe_w8pt_bwd(const float *pts1, const float *pts2, const float *weights, int B, int N,
+int dfepe_w8pt_bwd(const float *pts1, const float *pts2, const float *weights, int B, int N, int n_weight_sets,
                    unsigned flags, float image_w, float image_h, float clamp_at,
                    const float *save, const float *F_out,
                    const float *g_F, const float *g_residual, const float *g_epi, const float *g_weights_extra,

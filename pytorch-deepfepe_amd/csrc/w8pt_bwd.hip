@@ -23,7 +23,7 @@ __device__ __forceinline__ double guard_den(double d) {
 template <bool RAW, bool PGRAD>
 __global__ void __launch_bounds__(256, (PGRAD ? 2 : 4))  // the point-gradient variant trades occupancy for no spills
 w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, const float* __restrict__ wts, int B,
-                int N, float hw_sx, float hw_sy, float clamp_at, const float* __restrict__ save,
+                int Bm, int N, float hw_sx, float hw_sy, float clamp_at, const float* __restrict__ save,
                 const float* __restrict__ F_out, const float* __restrict__ g_F, const float* __restrict__ g_res,
                 const float* __restrict__ g_epi, const float* __restrict__ g_w_extra, int logits_mode,
                 float* __restrict__ g_w, float* __restrict__ g_p1, float* __restrict__ g_p2) {
@@ -31,6 +31,7 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   const size_t pair = (size_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
   if (pair >= (size_t)B) return;
 
+  const size_t mp = pair % (size_t)Bm;  // correspondences may be shared by several weight sets
   const float* sv = save + pair * DFEPE_SAVE_FLOATS;
   // wave-uniform values are parked in scalar registers (to_sgpr) to keep the VGPR budget at 4 waves/SIMD
   const double s1 = to_sgpr((double)sv[SV_T1]), c1x = to_sgpr((double)sv[SV_T1 + 1]), c1y = to_sgpr((double)sv[SV_T1 + 2]);
@@ -55,7 +56,7 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
   for (int i = lane; i < N; i += WAVE) {
     if (g_res == nullptr && g_epi == nullptr) break;  // nothing to accumulate (fused training step: the loss depends on F only)
-    const Pt p = global_point<RAW>(pts1, pts2, pair, i, N, hw_sx, hw_sy);
+    const Pt p = global_point<RAW>(pts1, pts2, mp, i, N, hw_sx, hw_sy);
     if (g_res != nullptr) {
       double ph[9];
       const double w = (double)wsrc[i];
@@ -161,7 +162,7 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   float wg = 0.0f;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
   for (int i = lane; i < N; i += WAVE) {
-    const Pt p = global_point<RAW>(pts1, pts2, pair, i, N, hw_sx, hw_sy);
+    const Pt p = global_point<RAW>(pts1, pts2, mp, i, N, hw_sx, hw_sy);
     double ph[9];
     const double w = (double)wsrc[i];
     const bool ok = unit_row(p, s1, c1x, c1y, s2, c2x, c2y, ph) && (fabs(w) < 1e150);
@@ -201,7 +202,7 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     const int stride = RAW ? 4 : 3;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
     for (int i = lane; i < N; i += WAVE) {
-      const Pt p = global_point<RAW>(pts1, pts2, pair, i, N, hw_sx, hw_sy);
+      const Pt p = global_point<RAW>(pts1, pts2, mp, i, N, hw_sx, hw_sy);
       const double w = (double)wsrc[i];
       const double z1 = p.z1, z2 = p.z2;
       const double a[3] = {s1 * ((double)p.x1 - c1x * z1), s1 * ((double)p.y1 - c1y * z1), z1};
@@ -278,7 +279,7 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     const double Gc2x = (tot[4] - s2 * gT2[2] - Gd2 * invN * tot[8]) * invN, Gc2y = (tot[5] - s2 * gT2[5] - Gd2 * invN * tot[9]) * invN;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
     for (int i = lane; i < N; i += WAVE) {
-      const Pt p = global_point<RAW>(pts1, pts2, pair, i, N, hw_sx, hw_sy);
+      const Pt p = global_point<RAW>(pts1, pts2, mp, i, N, hw_sx, hw_sy);
       const double dx1 = (double)p.x1 - c1x, dy1 = (double)p.y1 - c1y, dx2 = (double)p.x2 - c2x, dy2 = (double)p.y2 - c2y;
       const double r1 = dx1 * dx1 + dy1 * dy1, r2 = dx2 * dx2 + dy2 * dy2;
       const double ir1 = (r1 > 0.0) ? fast_rsqrt(r1) : 0.0, ir2 = (r2 > 0.0) ? fast_rsqrt(r2) : 0.0;
@@ -299,18 +300,22 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 
 }  // namespace
 
-extern "C" int dfepe_w8pt_bwd(const float* pts1, const float* pts2, const float* weights, int B, int N, unsigned flags,
+extern "C" int dfepe_w8pt_bwd(const float* pts1, const float* pts2, const float* weights, int B, int N, int n_weight_sets,
+                              unsigned flags,
                               float image_w, float image_h, float clamp_at, const float* save, const float* F_out,
                               const float* g_F, const float* g_residual, const float* g_epi,
                               const float* g_weights_extra, float* g_weights, float* g_pts1, float* g_pts2, void* stream) {
   const bool raw = (flags & DFEPE_W8PT_RAW_MATCHES) != 0;
   const int logits_mode = (flags & DFEPE_W8PT_LOGITS) ? 1 : 0;
-  if (B < 0 || N <= 0) return DFEPE_ERR_INVALID_ARG;
+  if (B < 0 || N <= 0 || n_weight_sets < 1) return DFEPE_ERR_INVALID_ARG;
   if (flags & (DFEPE_W8PT_SQRT2 | DFEPE_W8PT_NO_ROWNORM | DFEPE_W8PT_FORCE_110)) return DFEPE_ERR_UNSUPPORTED;
   if (B == 0) return DFEPE_OK;
   if (!pts1 || (!raw && !pts2) || !weights || !save || !g_weights) return DFEPE_ERR_INVALID_ARG;
   if (g_epi && !F_out) return DFEPE_ERR_INVALID_ARG;
   const bool pgrad = g_pts1 != nullptr;
+  if (pgrad && n_weight_sets != 1) return DFEPE_ERR_UNSUPPORTED;  // point gradients of shared correspondences would need a sum over the sets
+  const int Bm = B;
+  B *= n_weight_sets;
   if (!raw && ((g_pts1 == nullptr) != (g_pts2 == nullptr))) return DFEPE_ERR_INVALID_ARG;
   if (raw && pgrad && (reinterpret_cast<uintptr_t>(g_pts1) & 15u)) return DFEPE_ERR_INVALID_ARG;
   if (raw && !(image_w > 0.f && image_h > 0.f)) return DFEPE_ERR_INVALID_ARG;
@@ -320,7 +325,7 @@ extern "C" int dfepe_w8pt_bwd(const float* pts1, const float* pts2, const float*
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float hw_sx = raw ? 2.0f / image_w : 0.f, hw_sy = raw ? 2.0f / image_h : 0.f;
 #define DFEPE_LAUNCH_BWD(R, P)                                                                                              \
-  hipLaunchKernelGGL((w8pt_bwd_kernel<R, P>), grid, block, 0, st, pts1, pts2, weights, B, N, hw_sx, hw_sy, clamp_at, save,   \
+  hipLaunchKernelGGL((w8pt_bwd_kernel<R, P>), grid, block, 0, st, pts1, pts2, weights, B, Bm, N, hw_sx, hw_sy, clamp_at, save,   \
                      F_out, g_F, g_residual, g_epi, g_weights_extra, logits_mode, g_weights, g_pts1, g_pts2)
   if (raw) {
     if (pgrad) DFEPE_LAUNCH_BWD(true, true); else DFEPE_LAUNCH_BWD(true, false);

@@ -75,7 +75,7 @@ __device__ __forceinline__ void halve(double* a, bool upper, int mask) {
 template <bool RAW>
 __global__ void __launch_bounds__(256, 4)
 w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, const float* __restrict__ wts,
-                int B, int N, int npad, int wave_bytes, float hw_sx, float hw_sy, float clamp_at,
+                int B, int Bm, int N, int npad, int wave_bytes, float hw_sx, float hw_sy, float clamp_at,
                 float* __restrict__ F_out, float* __restrict__ residual, float* __restrict__ epi_res,
                 float* __restrict__ save, float* __restrict__ weights_out, int logits_mode, unsigned variant, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -99,8 +99,9 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   // ---- phase 0: stage the pair in LDS, coordinate sums ------------------------------------------
   double sx1 = 0, sy1 = 0, sx2 = 0, sy2 = 0;
   const float* wsrc = wts + (size_t)pair * N;
+  const size_t mp = (size_t)(pair % Bm);  // several weight sets may share one set of correspondences (n_weight_sets > 1)
   if (RAW) {
-    const float4* src = reinterpret_cast<const float4*>(pts1) + (size_t)pair * N;
+    const float4* src = reinterpret_cast<const float4*>(pts1) + mp * N;
   #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
   for (int i = lane; i < N; i += WAVE) {
       float4 m = src[i];
@@ -113,8 +114,8 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
       sx1 += m.x; sy1 += m.y; sx2 += m.z; sy2 += m.w;
     }
   } else {
-    const float* s1p = pts1 + (size_t)pair * N * 3;
-    const float* s2p = pts2 + (size_t)pair * N * 3;
+    const float* s1p = pts1 + mp * N * 3;
+    const float* s2p = pts2 + mp * N * 3;
     for (int t = lane; t < 3 * N; t += WAVE) {
       P[t] = s1p[t];
       P[3 * npad + t] = s2p[t];
@@ -516,13 +517,13 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 
 // host-side launcher ------------------------------------------------------------------------------------
 extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float* weights, int B, int N,
-                              unsigned flags, float image_w, float image_h, float clamp_at, float* F_out,
+                              int n_weight_sets, unsigned flags, float image_w, float image_h, float clamp_at, float* F_out,
                               float* residual, float* epi_res, float* save, float* weights_out, void* stream) {
   const bool raw = (flags & DFEPE_W8PT_RAW_MATCHES) != 0;
   const int logits_mode = (flags & DFEPE_W8PT_LOGITS) ? 1 : 0;
   const unsigned variant = flags & (DFEPE_W8PT_SQRT2 | DFEPE_W8PT_NO_ROWNORM | DFEPE_W8PT_FORCE_110);
   const int dbg = (int)((flags >> 16) & 0x1ffu);  // undocumented diagnostics: forced sweep count (timing experiments only)
-  if (B < 0 || N <= 0) return DFEPE_ERR_INVALID_ARG;
+  if (B < 0 || N <= 0 || n_weight_sets < 1) return DFEPE_ERR_INVALID_ARG;
   if (variant && save) return DFEPE_ERR_UNSUPPORTED;  // the textbook variants are forward-only
   if (B == 0) return DFEPE_OK;
   if (!pts1 || (!raw && !pts2) || !weights || !F_out || !residual) return DFEPE_ERR_INVALID_ARG;
@@ -542,6 +543,8 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
     if (resident > best) { best = resident; waves = wv; }
   }
   const size_t lds = (size_t)waves * wave_bytes;
+  const int Bm = B;
+  B *= n_weight_sets;  // one wavefront per (weight set, pair)
   const dim3 grid((B + waves - 1) / waves), block(64 * waves);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float hw_sx = raw ? 2.0f / image_w : 0.f, hw_sy = raw ? 2.0f / image_h : 0.f;
@@ -552,7 +555,7 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (err != hipSuccess) return DFEPE_ERR_HIP;
     }
-    hipLaunchKernelGGL(w8pt_fwd_kernel<true>, grid, block, lds, st, pts1, pts2, weights, B, N, npad, wave_bytes,
+    hipLaunchKernelGGL(w8pt_fwd_kernel<true>, grid, block, lds, st, pts1, pts2, weights, B, Bm, N, npad, wave_bytes,
                        hw_sx, hw_sy, clamp_at, F_out, residual, epi_res, save, weights_out, logits_mode, variant, dbg);
   } else {
     if (lds > 64 * 1024) {
@@ -560,7 +563,7 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (err != hipSuccess) return DFEPE_ERR_HIP;
     }
-    hipLaunchKernelGGL(w8pt_fwd_kernel<false>, grid, block, lds, st, pts1, pts2, weights, B, N, npad, wave_bytes,
+    hipLaunchKernelGGL(w8pt_fwd_kernel<false>, grid, block, lds, st, pts1, pts2, weights, B, Bm, N, npad, wave_bytes,
                        hw_sx, hw_sy, clamp_at, F_out, residual, epi_res, save, weights_out, logits_mode, variant, dbg);
   }
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;

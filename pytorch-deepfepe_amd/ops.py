@@ -53,7 +53,7 @@ def w8pt_forward(pts1: Tensor, pts2: Optional[Tensor], weights: Tensor, raw: boo
     save = torch.empty(B, L.dfepe_save_floats(), device=dev, dtype=torch.float32) if want_save else None
     w_out = torch.empty(B, N, device=dev, dtype=torch.float32) if logits else None
     with torch.cuda.device(dev):
-        rc = L.dfepe_w8pt_fwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, _flags(raw, logits) | (int(diag) << 16), float(image_w),
+        rc = L.dfepe_w8pt_fwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, 1, _flags(raw, logits) | (int(diag) << 16), float(image_w),
                               float(image_h), float(clamp_at), _ptr(F), _ptr(residual), _ptr(epi), _ptr(save), _ptr(w_out), _stream())
     _lib.check(rc, "dfepe_w8pt_fwd")
     return F, residual, epi, save, w_out
@@ -71,7 +71,7 @@ def w8pt_backward(pts1, pts2, weights, raw, image_w, image_h, clamp_at, save, F,
         gP1 = torch.empty_like(pts1)
         gP2 = None if raw else torch.empty_like(pts2)
     with torch.cuda.device(weights.device):
-        rc = L.dfepe_w8pt_bwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, _flags(raw, logits), float(image_w), float(image_h),
+        rc = L.dfepe_w8pt_bwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, 1, _flags(raw, logits), float(image_w), float(image_h),
                               float(clamp_at), _ptr(save), _ptr(F), _ptr(gF), _ptr(gRes), _ptr(gEpi), _ptr(gW_extra), _ptr(gW),
                               _ptr(gP1), _ptr(gP2), _stream())
     _lib.check(rc, "dfepe_w8pt_bwd")
@@ -94,7 +94,7 @@ def eight_point(X: Tensor, Y: Tensor, w: Optional[Tensor], essential: bool, norm
     residual = torch.empty(B, N, device=X.device)
     flags = _lib.W8PT_SQRT2 | _lib.W8PT_NO_ROWNORM | (_lib.W8PT_FORCE_110 if essential else 0)
     with torch.cuda.device(X.device):
-        rc = L.dfepe_w8pt_fwd(_ptr(p1), _ptr(p2), _ptr(wt), B, N, flags, 0.0, 0.0, 0.5, _ptr(F), _ptr(residual), None, None, None,
+        rc = L.dfepe_w8pt_fwd(_ptr(p1), _ptr(p2), _ptr(wt), B, N, 1, flags, 0.0, 0.0, 0.5, _ptr(F), _ptr(residual), None, None, None,
                               _stream())
     _lib.check(rc, "dfepe_w8pt_fwd")
     return F

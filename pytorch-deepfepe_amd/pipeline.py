@@ -59,7 +59,7 @@ class _HotPathFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, matches, logits_layers, Ks, virt1, virt2, q_gt, t_gt, R_gt, hw_T, cfg):
-        (H, W, clamp_at, qt, clamp_q, clamp_t, balance_q, balance_t) = cfg
+        (H, W, clamp_at, qt, clamp_q, clamp_t, balance_q, balance_t, batched) = cfg
         ctx.set_materialize_grads(False)  # 13 auxiliary outputs: do not let autograd zero-fill [L,B,N] gradients for them
         lib = _lib.lib()
         L, B, N = logits_layers.shape
@@ -73,11 +73,17 @@ class _HotPathFunction(torch.autograd.Function):
         flags = _lib.W8PT_RAW_MATCHES | _lib.W8PT_LOGITS
         st = ops._stream()
         with torch.cuda.device(dev):
-            for l in range(L):
-                rc = lib.dfepe_w8pt_fwd(matches.data_ptr(), None, logits_layers[l].data_ptr(), B, N, flags, W, H, 0.5,
-                                        F_layers[l].data_ptr(), residuals[l].data_ptr(), epis[l].data_ptr(), saves[l].data_ptr(),
-                                        weights[l].data_ptr(), st)
+            if batched:  # the L weightings of the same pairs in ONE launch (n_weight_sets = L): no per-layer launch tails
+                rc = lib.dfepe_w8pt_fwd(matches.data_ptr(), None, logits_layers.data_ptr(), B, N, L, flags, W, H, 0.5,
+                                        F_layers.data_ptr(), residuals.data_ptr(), epis.data_ptr(), saves.data_ptr(),
+                                        weights.data_ptr(), st)
                 _lib.check(rc, "dfepe_w8pt_fwd")
+            else:
+                for l in range(L):
+                    rc = lib.dfepe_w8pt_fwd(matches.data_ptr(), None, logits_layers[l].data_ptr(), B, N, 1, flags, W, H, 0.5,
+                                            F_layers[l].data_ptr(), residuals[l].data_ptr(), epis[l].data_ptr(),
+                                            saves[l].data_ptr(), weights[l].data_ptr(), st)
+                    _lib.check(rc, "dfepe_w8pt_fwd")
             loss_sum = torch.empty(L, B, device=dev)
             E_layers = torch.empty(L, B, 3, 3, device=dev)
             rc = lib.dfepe_floss_fwd(F_layers.data_ptr(), L, B, hw_T.data_ptr(), hw_T.data_ptr(), 0, Ks.data_ptr(), virt1.data_ptr(),
@@ -108,7 +114,7 @@ class _HotPathFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, *unused):
         matches, weights, Ks, virt1, virt2, q_gt, t_gt, hw_T, F_layers, E_layers, saves = ctx.saved_tensors
-        (H, W, clamp_at, qt, clamp_q, clamp_t, balance_q, balance_t) = ctx.cfg
+        (H, W, clamp_at, qt, clamp_q, clamp_t, balance_q, balance_t, batched) = ctx.cfg
         lib = _lib.lib()
         L, B, N = weights.shape
         M = virt1.shape[1]
@@ -133,25 +139,33 @@ class _HotPathFunction(torch.autograd.Function):
                                      virt2.data_ptr(), M, clamp_at, None, 1.0 / float(L * B * M), g_scale.data_ptr(), gE_ptr,
                                      gF.data_ptr(), st)
             _lib.check(rc, "dfepe_floss_bwd")
-            for l in range(L):
-                rc = lib.dfepe_w8pt_bwd(matches.data_ptr(), None, weights[l].data_ptr(), B, N, flags, W, H, 0.5, saves[l].data_ptr(),
-                                        F_layers[l].data_ptr(), gF[l].data_ptr(), None, None, None, g_logits[l].data_ptr(), None, None, st)
+            if batched:
+                rc = lib.dfepe_w8pt_bwd(matches.data_ptr(), None, weights.data_ptr(), B, N, L, flags, W, H, 0.5, saves.data_ptr(),
+                                        F_layers.data_ptr(), gF.data_ptr(), None, None, None, g_logits.data_ptr(), None, None, st)
                 _lib.check(rc, "dfepe_w8pt_bwd")
+            else:
+                for l in range(L):
+                    rc = lib.dfepe_w8pt_bwd(matches.data_ptr(), None, weights[l].data_ptr(), B, N, 1, flags, W, H, 0.5,
+                                            saves[l].data_ptr(), F_layers[l].data_ptr(), gF[l].data_ptr(), None, None, None,
+                                            g_logits[l].data_ptr(), None, None, st)
+                    _lib.check(rc, "dfepe_w8pt_bwd")
         return None, g_logits, None, None, None, None, None, None, None, None
 
 
 def hot_path_fused(matches: Tensor, logits_layers: Tensor, Ks: Tensor, virt1: Tensor, virt2: Tensor, q_gt: Tensor,
                    t_gt: Tensor, R_gt: Tensor, image_size: Sequence[int], clamp_at: float = 0.02, qt: bool = True,
                    clamp_q: float = 0.1, clamp_t: float = 0.5, balance_q: float = 1.0, balance_t: float = 0.1,
-                   hw_T: Optional[Tensor] = None) -> Dict[str, Tensor]:
-    """Same contract and same numbers as hot_path_forward, 15 kernel launches instead of ~120 (loss = loss_F + loss_qt)."""
+                   hw_T: Optional[Tensor] = None, layers_batched: bool = False) -> Dict[str, Tensor]:
+    """Same contract and same numbers as hot_path_forward, 15 kernel launches instead of ~120 (loss = loss_F + loss_qt).
+    ``layers_batched`` fits all L weightings in one launch (legal only because the per-layer logits are given; in the
+    real recurrent model each layer's logits depend on the previous fit): 7 launches."""
     L, B, N = logits_layers.shape
     H, W = float(image_size[0]), float(image_size[1])
     dev = matches.device
     if hw_T is None:
         hw_T = torch.tensor([[2.0 / W, 0.0, -1.0], [0.0, 2.0 / H, -1.0], [0.0, 0.0, 1.0]], device=dev)
     f32 = lambda t: ops._prep(t, "input")
-    cfg = (H, W, float(clamp_at), bool(qt), float(clamp_q), float(clamp_t), float(balance_q), float(balance_t))
+    cfg = (H, W, float(clamp_at), bool(qt), float(clamp_q), float(clamp_t), float(balance_q), float(balance_t), bool(layers_batched))
     res = _HotPathFunction.apply(f32(matches), f32(logits_layers), f32(Ks), f32(virt1), f32(virt2), f32(q_gt.reshape(B, 4)),
                                  f32(t_gt.reshape(B, 3)), f32(R_gt.reshape(B, 3, 3)), f32(hw_T), cfg)
     loss, F_layers, residuals, epis, weights, E_layers, loss_sum, packed, scalars = res[:9]

@@ -13,3 +13,9 @@ tot = ph.sum(1)
 print(f"B={B} N={N}: per-wave cycles (mean / max over pairs); sum of phases mean {tot.mean():.0f} max {tot.max():.0f}")
 for k, n in enumerate(names):
     print(f"  phase {n:18s} mean {ph[:, k].mean():8.0f}  max {ph[:, k].max():8.0f}  ({100*ph[:, k].mean()/tot.mean():.1f}%)")
+import numpy as np
+t = tot.cpu().numpy()
+print("percentiles of per-wave total cycles:", {p: int(np.percentile(t, p)) for p in (1, 10, 50, 90, 99, 99.9, 100)})
+jac = ph[:, 4].cpu().numpy(); sw = sv[:, 119].cpu().numpy()
+for s_ in np.unique(sw):
+    print(f"  sweeps={int(s_)}: n={int((sw == s_).sum())} jacobi cycles mean {jac[sw == s_].mean():.0f} total mean {t[sw == s_].mean():.0f} max {t[sw == s_].max():.0f}")

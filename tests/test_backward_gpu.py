@@ -182,6 +182,25 @@ def test_fused_step_equals_unfused_ops(dfepe):
     np.testing.assert_allclose(a["packed"].cpu().numpy(), ref.cpu().numpy(), rtol=1e-6)
 
 
+def test_layers_batched_launch_is_bit_identical(dfepe):
+    """n_weight_sets = L (all layers' weightings of the same pairs in one grid) runs the same per-wave program as L
+    separate launches: every output and the logits gradient are bit-identical.  Point gradients are refused there."""
+    B, N, depth = 37, 100, 5
+    sc = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(B, N, seed=7, outlier_ratio=0.4, depth_layers=depth), DEV)
+    a = dfepe.pipeline.hot_path_step(sc, IMAGE_SIZE, depth, 0.02, qt=True, fused=True)
+    b = dfepe.pipeline.hot_path_step(sc, IMAGE_SIZE, depth, 0.02, qt=True, fused=True, layers_batched=True)
+    for k in ("F_layers", "loss_layers", "q_l2", "t_l2", "packed", "grad_logits", "R_deg", "t_deg"):
+        assert torch.equal(a[k], b[k]), k
+    for l in range(depth):
+        assert torch.equal(a["weights_layers"][l], b["weights_layers"][l])
+    L = dfepe._lib.lib()
+    m, w = sc["matches_xy_ori"], torch.softmax(sc["logits_layers"][:depth], dim=2).contiguous()
+    buf = torch.empty(depth * B * 128, device=DEV)
+    rc = L.dfepe_w8pt_bwd(m.data_ptr(), None, w.data_ptr(), B, N, depth, 1, 1241.0, 376.0, 0.5, buf.data_ptr(), buf.data_ptr(),
+                          buf.data_ptr(), None, None, None, buf.data_ptr(), buf.data_ptr(), None, None)
+    assert rc == -3  # DFEPE_ERR_UNSUPPORTED: a point gradient would have to be summed over the sets
+
+
 def test_logits_fused_fit_matches_softmax_then_fit(dfepe):
     B, N = 6, 100
     sc = dfepe.synth.make_scene(B, N, seed=12, outlier_ratio=0.2)

@@ -40,10 +40,10 @@ def test_version_strerror_and_save_layout(dfepe):
 def test_argument_validation_without_launching(dfepe):
     """Bad arguments are rejected on the host before any HIP call (safe without a GPU)."""
     L = dfepe._lib.lib()
-    assert L.dfepe_w8pt_fwd(None, None, None, 4, 100, 0, 0.0, 0.0, 0.5, None, None, None, None, None, None) == -1
-    assert L.dfepe_w8pt_fwd(None, None, None, -1, 100, 0, 0.0, 0.0, 0.5, None, None, None, None, None, None) == -1
-    assert L.dfepe_w8pt_fwd(None, None, None, 0, 100, 0, 0.0, 0.0, 0.5, None, None, None, None, None, None) == 0  # empty batch
-    assert L.dfepe_w8pt_bwd(None, None, None, 2, 0, 0, 0.0, 0.0, 0.5, None, None, None, None, None, None, None, None, None, None) == -1
+    assert L.dfepe_w8pt_fwd(None, None, None, 4, 100, 1, 0, 0.0, 0.0, 0.5, None, None, None, None, None, None) == -1
+    assert L.dfepe_w8pt_fwd(None, None, None, -1, 100, 1, 0, 0.0, 0.0, 0.5, None, None, None, None, None, None) == -1
+    assert L.dfepe_w8pt_fwd(None, None, None, 0, 100, 1, 0, 0.0, 0.0, 0.5, None, None, None, None, None, None) == 0  # empty batch
+    assert L.dfepe_w8pt_bwd(None, None, None, 2, 0, 1, 0, 0.0, 0.0, 0.5, None, None, None, None, None, None, None, None, None, None) == -1
     assert L.dfepe_floss_fwd(None, 0, 4, None, None, 0, None, None, None, 100, 0.02, None, None, None) == -1
     assert L.dfepe_floss_fwd(None, 5, 0, None, None, 0, None, None, None, 100, 0.02, None, None, None) == 0
     assert L.dfepe_floss_fwd(None, 5, 4, None, None, 3, None, None, None, 100, 0.02, None, None, None) == -1  # bad stride
