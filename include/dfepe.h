@@ -143,7 +143,7 @@ int dfepe_pose_bwd(const float *E_layers, int L, int B, const float *q_gt, const
  * (Train_model_pipeline.py:580-586), plus the packed sums a data-parallel all-reduce needs.
  *   loss_sum [L,B] (sum over the M virtual points), q_l2, t_l2 [L,B] (may be NULL: no pose loss)
  *   packed   [L+4] doubles: sum_b loss_sum[l,b] (L), sum clamp(q), sum clamp(t), B, M
- *   scalars  [4] floats: loss = loss_F + loss_qt, loss_F, loss_qt, 0   (local-batch means)
+ *   scalars  [4+L] floats: loss = loss_F + loss_qt, loss_F, loss_qt, 0, then the L per-layer means   (local batch)
  */
 int dfepe_loss_head(const float *loss_sum, const float *q_l2, const float *t_l2, int L, int B, int M,
                     float clamp_q, float clamp_t, float balance_q, float balance_t,

@@ -189,7 +189,7 @@ __device__ inline void svd3_fast(const float* F, float* U, float* S, float* V) {
   }
   const float tol2 = 1e-14f;  // (1e-7)^2: columns are orthogonal to fp32 round-off
   for (int sweep = 0; sweep < 10; ++sweep) {
-    bool any = false;
+    bool any = false, big = false;
 #pragma unroll
     for (int pq = 0; pq < 3; ++pq) {
       const int p = (pq == 2) ? 1 : 0;
@@ -197,8 +197,10 @@ __device__ inline void svd3_fast(const float* F, float* U, float* S, float* V) {
       const float al = fmaf(G[p], G[p], fmaf(G[3 + p], G[3 + p], G[6 + p] * G[6 + p]));
       const float be = fmaf(G[q], G[q], fmaf(G[3 + q], G[3 + q], G[6 + q] * G[6 + q]));
       const float ga = fmaf(G[p], G[q], fmaf(G[3 + p], G[3 + q], G[6 + p] * G[6 + q]));
-      const bool rot = ga * ga > tol2 * al * be;
+      const float gg = ga * ga, ab = al * be;
+      const bool rot = gg > tol2 * ab;
       any = any || rot;
+      big = big || (gg > 1e-9f * ab);
       const float d = be - al, b = 2.0f * ga;
       const float r = __builtin_amdgcn_rsqf(fmaf(d, d, b * b));
       const float x = fmaf(0.5f * fabsf(d), r, 0.5f);
@@ -215,7 +217,8 @@ __device__ inline void svd3_fast(const float* F, float* U, float* S, float* V) {
         V[3 * k + q] = fmaf(s, vp, c * vq);
       }
     }
-    if (!any) break;
+    // cosines below 3e-5 are squared by the sweep that just ran (quadratic convergence): nothing left above tol
+    if (!big) break;
   }
   float n2[3];
 #pragma unroll

@@ -272,14 +272,37 @@ loss_head_kernel(const float* __restrict__ loss_sum, const float* __restrict__ q
   for (int l = 0; l < kHeadMaxL; ++l) acc[l] = 0.0f;
   float q = 0.0f, t = 0.0f;
   const bool pose = (q_l2 != nullptr);
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+  if ((B & 3) == 0) {
+    // four pairs per thread and float4 loads: at B = 4096 every load of the kernel is in flight at once, so the
+    // single block pays one memory latency instead of one per 1024 pairs
+    const int B4 = B >> 2;
+    for (int b4 = threadIdx.x; b4 < B4; b4 += blockDim.x) {
 #pragma unroll
-    for (int l = 0; l < kHeadMaxL; ++l) {
-      if (l < L) {
-        acc[l] += loss_sum[(size_t)l * B + b];
-        if (pose) {
-          q += fminf(fmaxf(q_l2[(size_t)l * B + b], 0.0f), clamp_q);
-          t += fminf(fmaxf(t_l2[(size_t)l * B + b], 0.0f), clamp_t);
+      for (int l = 0; l < kHeadMaxL; ++l) {
+        if (l < L) {
+          const float4 v = reinterpret_cast<const float4*>(loss_sum + (size_t)l * B)[b4];
+          acc[l] += (v.x + v.y) + (v.z + v.w);
+          if (pose) {
+            const float4 qv = reinterpret_cast<const float4*>(q_l2 + (size_t)l * B)[b4];
+            const float4 tv = reinterpret_cast<const float4*>(t_l2 + (size_t)l * B)[b4];
+            q += (fminf(fmaxf(qv.x, 0.0f), clamp_q) + fminf(fmaxf(qv.y, 0.0f), clamp_q)) +
+                 (fminf(fmaxf(qv.z, 0.0f), clamp_q) + fminf(fmaxf(qv.w, 0.0f), clamp_q));
+            t += (fminf(fmaxf(tv.x, 0.0f), clamp_t) + fminf(fmaxf(tv.y, 0.0f), clamp_t)) +
+                 (fminf(fmaxf(tv.z, 0.0f), clamp_t) + fminf(fmaxf(tv.w, 0.0f), clamp_t));
+          }
+        }
+      }
+    }
+  } else {
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+#pragma unroll
+      for (int l = 0; l < kHeadMaxL; ++l) {
+        if (l < L) {
+          acc[l] += loss_sum[(size_t)l * B + b];
+          if (pose) {
+            q += fminf(fmaxf(q_l2[(size_t)l * B + b], 0.0f), clamp_q);
+            t += fminf(fmaxf(t_l2[(size_t)l * B + b], 0.0f), clamp_t);
+          }
         }
       }
     }
@@ -317,6 +340,7 @@ loss_head_kernel(const float* __restrict__ loss_sum, const float* __restrict__ q
     scalars[1] = (float)loss_F;
     scalars[2] = (float)loss_qt;
     scalars[3] = 0.0f;
+    for (int l = 0; l < L; ++l) scalars[4 + l] = (float)(red[0][l] / (n * (double)M));  // losses.mean() of layer l
   }
 }
 

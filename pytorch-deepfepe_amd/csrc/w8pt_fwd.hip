@@ -22,18 +22,48 @@
 
 namespace {
 
-__constant__ unsigned char kTriI[45] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2,
-                                        2, 3, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 6, 6, 6, 7, 7, 8};
-__constant__ unsigned char kTriJ[45] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 1, 2, 3, 4, 5, 6, 7, 8, 2, 3, 4, 5, 6, 7,
-                                        8, 3, 4, 5, 6, 7, 8, 4, 5, 6, 7, 8, 5, 6, 7, 8, 6, 7, 8, 7, 8, 8};
-
 // X^T X = sum_i k_i^2 (b b^T) (x) (a a^T) with a = (x1~,y1~,z1), b = (x2~,y2~,1): only 6 x 6 = 36 distinct sums.
 // pair tables for the 6 distinct entries of a symmetric 3x3 outer product
 __constant__ unsigned char kSymR[6] = {0, 0, 0, 1, 1, 2};
 __constant__ unsigned char kSymC[6] = {0, 1, 2, 1, 2, 2};
 
-// seat permutation of the round-robin tournament: position p moves to kPerm[p] after every round
-__constant__ unsigned char kPerm[9] = {8, 3, 0, 5, 2, 7, 4, 6, 1};
+// Loop-invariant addresses of a lane's two Jacobi work items (see phase 4a), one 16-byte record per lane, built at
+// compile time: one global_load_dwordx4 replaces ~150 integer instructions and four dependent table look-ups.
+struct JacLane {
+  unsigned short rd_own, rd_par, wr2, wr2t;  // slot 2 (A element or V element 64..80): float offsets from A32
+  unsigned short rd_v, wr_v;                 // slot 1 (V element = lane): float offsets from V32
+  unsigned char ci, cj, c0, flags;           // CS slots of the row / column rotation (slot 2) and of slot 1
+};
+constexpr unsigned kJacIsA = 1, kJacIsV2 = 2, kJacOdd2 = 4, kJacOdd1 = 8, kJacOffDiag = 16;
+struct JacTable { JacLane l[64]; };
+constexpr JacTable make_jac_table() {
+  constexpr int perm[9] = {8, 3, 0, 5, 2, 7, 4, 6, 1};  // seat permutation of the round-robin tournament: position p moves to perm[p] after every round
+  JacTable t{};
+  int ai = 0, aj = 0;  // walks the upper triangle row by row
+  for (int lane = 0; lane < 64; ++lane) {
+    const bool a_item = lane < 45, v_item = (lane >= 45 && lane < 62);
+    const int ti = a_item ? ai : (v_item ? (lane + 19) / 9 : 0);  // V element e = 64 + (lane - 45) = lane + 19
+    const int tj = a_item ? aj : (v_item ? (lane + 19) % 9 : 0);
+    if (a_item) { if (++aj == 9) { ++ai; aj = ai; } }
+    const int tip = (ti < 8) ? (ti ^ 1) : 8;
+    const int mat2 = a_item ? 0 : 90;                      // slot-2 matrix base (A32 or V32), in floats from A32
+    const int rd_own = mat2 + ti * 10 + (tj & ~1);         // float2 {even column, odd column} of my row
+    const int vi0 = lane / 9, vj0 = lane % 9;
+    t.l[lane].rd_own = (unsigned short)rd_own;
+    t.l[lane].rd_par = (unsigned short)(a_item ? tip * 10 + (tj & ~1) : rd_own);  // same columns, partner row (A only)
+    t.l[lane].wr2 = (unsigned short)(a_item ? perm[ti] * 10 + perm[tj] : mat2 + ti * 10 + perm[tj]);
+    t.l[lane].wr2t = (unsigned short)(perm[tj] * 10 + perm[ti]);                   // mirror (A items only)
+    t.l[lane].rd_v = (unsigned short)(vi0 * 10 + (vj0 & ~1));
+    t.l[lane].wr_v = (unsigned short)(vi0 * 10 + perm[vj0]);
+    t.l[lane].ci = (unsigned char)(a_item ? ti : 8);       // V items: identity row rotation
+    t.l[lane].cj = (unsigned char)tj;
+    t.l[lane].c0 = (unsigned char)vj0;
+    t.l[lane].flags = (unsigned char)((a_item ? kJacIsA : 0) | (v_item ? kJacIsV2 : 0) | ((tj & 1) ? kJacOdd2 : 0) |
+                                      ((vj0 & 1) ? kJacOdd1 : 0) | ((a_item && ti != tj) ? kJacOffDiag : 0));
+  }
+  return t;
+}
+__constant__ JacTable kJac = make_jac_table();
 
 constexpr int kWsDoubles = 216;  // per-wave workspace in LDS (1728 B, 16-B multiple): see the carve in the kernel
 constexpr int kMaxSweeps = 5;  // quadratic convergence: 4-5 sweeps reach fp32 round-off; stragglers are finished by the fp64 polish
@@ -227,7 +257,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   // ---- phase 4a: fp32 Jacobi on M / trace(M) ----------------------------------------------------------
   // A' = J^T A J, V' = V J with J_pp = J_qq = c, J_pq = s, J_qp = -s for the pairs (p,q) = (0,1),(2,3),(4,5),(6,7)
   // of *positions*; position 8 sits out.  Per position k we keep (c_k, sh_k), sh_p = -s, sh_q = +s, so that
-  // col_k' = c_k col_k + sh_k col_(k^1).  The result of the round is stored through the seat permutation kPerm,
+  // col_k' = c_k col_k + sh_k col_(k^1).  The result of the round is stored through the seat permutation (make_jac_table),
   // which realises the round-robin schedule (9 rounds = all 36 pairs once).  Eigenpairs come out in seat order,
   // which is irrelevant: (A32[k][k], V32[:,k]) is a consistent pair for every k.
   double tr = 0.0;
@@ -249,20 +279,14 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   // Work items of a round.  Slot 1: V elements 0..63 (one per lane).  Slot 2: the 45 upper-triangular A elements on
   // lanes 0..44 and the 17 remaining V elements on lanes 45..61 -- a V element is the special case (c_i, s_i) = (1, 0)
   // of the two-sided update, so both kinds run the same instruction stream.  All addresses are loop-invariant.
-  const bool is_a = lane < 45, is_v2 = (lane >= 45 && lane < 62);
-  const int ti = is_a ? kTriI[lane] : (is_v2 ? (lane + 19) / 9 : 0);   // V element e = 64 + (lane - 45) = lane + 19
-  const int tj = is_a ? kTriJ[lane] : (is_v2 ? (lane + 19) % 9 : 0);
-  const int tip = (ti < 8) ? (ti ^ 1) : 8;
-  const int mat2 = is_a ? 0 : 90;                       // slot-2 matrix base (A32 or V32), in floats from A32
-  const int rd_own = mat2 + ti * 10 + (tj & ~1);         // float2 {even column, odd column} of my row
-  const int rd_par = is_a ? tip * 10 + (tj & ~1) : rd_own;  // same column pair in the partner row (A only)
-  const bool odd2 = (tj & 1) != 0;
-  const int ci_idx = is_a ? ti : 8;                      // V items: identity row rotation
-  const int wr2 = is_a ? kPerm[ti] * 10 + kPerm[tj] : mat2 + ti * 10 + kPerm[tj];
-  const int wr2t = kPerm[tj] * 10 + kPerm[ti];           // mirror (A items only)
-  const int vi0 = lane / 9, vj0 = lane % 9;
-  const int rd_v = vi0 * 10 + (vj0 & ~1), wr_v = vi0 * 10 + kPerm[vj0];
-  const bool odd1 = (vj0 & 1) != 0;
+  const uint4 jw = *reinterpret_cast<const uint4*>(&kJac.l[lane]);
+  const int rd_own = jw.x & 0xffff, rd_par = jw.x >> 16, wr2 = jw.y & 0xffff, wr2t = jw.y >> 16;
+  const int rd_v = jw.z & 0xffff, wr_v = jw.z >> 16;
+  const int ci_idx = jw.w & 0xff, cj_idx = (jw.w >> 8) & 0xff, c0_idx = (jw.w >> 16) & 0xff;
+  const unsigned jfl = jw.w >> 24;
+  const bool is_a = (jfl & kJacIsA) != 0, is_v2 = (jfl & kJacIsV2) != 0, odd2 = (jfl & kJacOdd2) != 0;
+  const bool odd1 = (jfl & kJacOdd1) != 0, offdiag = (jfl & kJacOffDiag) != 0;
+  const int off_idx = rd_own + (odd2 ? 1 : 0);           // A32[ti][tj] for the A items
   const int pp = (lane < 8) ? (lane & ~1) : 0;  // lanes 0..7: my pair is positions (pp, pp+1)
   wave_sync();
   int n_sweeps = 0, n_refine = 0;
@@ -272,8 +296,8 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   const int max_sweeps = dbg_on ? (dbg & 0xff) - 1 : kMaxSweeps;
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     float off = 0.0f;
-    if (is_a && ti != tj) {
-      const float a = A32[ti * 10 + tj];
+    if (offdiag) {
+      const float a = A32[off_idx];
       off = a * a;
     }
     off = wave_sum(off);
@@ -297,7 +321,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
         CS[lane] = make_float2(c, (lane & 1) ? sn : -sn);
       }
       wave_sync();
-      const float2 ci = CS[ci_idx], cj = CS[tj], c0 = CS[vj0];
+      const float2 ci = CS[ci_idx], cj = CS[cj_idx], c0 = CS[c0_idx];
       const float e00 = odd2 ? own.y : own.x, e01 = odd2 ? own.x : own.y;
       const float e10 = odd2 ? par.y : par.x, e11 = odd2 ? par.x : par.y;
       const float new2 = ci.x * fmaf(cj.x, e00, cj.y * e01) + ci.y * fmaf(cj.x, e10, cj.y * e11);
@@ -342,6 +366,8 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   // residual correction: r = M f - rho f;  f += sum_{k != kmin} q_k (q_k . r) / (rho - lam_k);  renormalise.
   // The Jacobi basis (fp32-accurate) acts as an approximate inverse of (M - rho); the fixed point is the exact
   // fp64 eigenvector, reached at a linear rate ~ eps32 |M| / gap per iteration.
+  double rn2_prev = 0.0;
+  bool last_pass = false;
   for (int it = 0; it < ((dbg_on && !dbg_polish) ? 0 : kRefineIters); ++it) {
     double fn2 = 0.0;
 #pragma unroll
@@ -364,8 +390,13 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     double rn2 = 0.0;
 #pragma unroll
     for (int c = 0; c < 9; ++c) { r[c] -= rho * f[c]; rn2 += r[c] * r[c]; }
-    if (!(rn2 > 1e-28 * tr * tr)) break;  // |M f - rho f| <= 1e-14 trace(M): converged (wave-uniform)
+    const double rn2_tol = 1e-28 * tr * tr;
+    if (!(rn2 > rn2_tol)) break;  // |M f - rho f| <= 1e-14 trace(M): converged (wave-uniform)
     ++n_refine;
+    // the iteration contracts linearly: when the last step's factor, applied once more, lands 100x below the
+    // tolerance, this correction is the final one and the verification pass after it is skipped
+    last_pass = (it > 0) && (rn2 * rn2 < 1e-2 * rn2_tol * rn2_prev);
+    rn2_prev = rn2;
     // a_k = (q_k . r) / (rho - lam_k) for k != kmin, one k per lane
     if (lane < 9) {
       double dot = 0.0;
@@ -388,6 +419,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 #pragma unroll
     for (int c = 0; c < 9; ++c) f[c] += SCR[c];
     wave_sync();
+    if (last_pass) break;
   }
 
   tstamp[6] = __builtin_amdgcn_s_memtime();

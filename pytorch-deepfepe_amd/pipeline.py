@@ -100,7 +100,7 @@ class _HotPathFunction(torch.autograd.Function):
                                         t_l2.data_ptr(), R_deg.data_ptr(), t_deg.data_ptr(), sel.data_ptr(), st)
                 _lib.check(rc, "dfepe_pose_fwd")
             packed = torch.empty(L + 4, device=dev, dtype=torch.float64)
-            scalars = torch.empty(4, device=dev)
+            scalars = torch.empty(4 + L, device=dev)
             rc = lib.dfepe_loss_head(loss_sum.data_ptr(), ops._ptr(q_l2), ops._ptr(t_l2), L, B, M, clamp_q, clamp_t, balance_q,
                                      balance_t, packed.data_ptr(), scalars.data_ptr(), st)
             _lib.check(rc, "dfepe_loss_head")
@@ -172,7 +172,7 @@ def hot_path_fused(matches: Tensor, logits_layers: Tensor, Ks: Tensor, virt1: Te
     M = virt1.shape[1]
     out = {"loss": loss, "F_layers": F_layers, "residual_layers": [residuals[l] for l in range(L)],
            "epi_res_layers": [epis[l] for l in range(L)], "weights_layers": [weights[l] for l in range(L)],
-           "E_layers": E_layers, "loss_sum": loss_sum, "loss_layers": packed[:L].float() / float(B * M), "loss_F": scalars[1],
+           "E_layers": E_layers, "loss_sum": loss_sum, "loss_layers": scalars[4:4 + L], "loss_F": scalars[1],
            "packed": packed}
     if qt:
         q_l2, t_l2, R_deg, t_deg, sel = res[9:]
