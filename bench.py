@@ -174,7 +174,10 @@ def main():
         roofline = {"bound": "hbm", "kernel": "w8pt_fwd_kernel<raw>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                     "avg_kernel_us": round(kdur * 1e6, 2), "algorithmic_bytes_per_launch": alg_bytes,
-                    "launches_per_step": L, "method": f"HIP events around {reps} back-to-back launches, median of 5"}
+                    "launches_per_step": L,
+                    "traffic_note": "profiles/traffic.json: PMC 2*FETCH_SIZE+WRITE_SIZE of this probe launch, which (like the training "
+                                    "step) also writes the 512-B save record per pair (2.1 MB) on top of the 28N+36 algorithmic bytes",
+                    "method": f"HIP events around {reps} back-to-back launches, median of 5"}
 
         log("roofline probe done", kdur)
         # ---- informational: the same step with all L fits of a layer stack in ONE grid (n_weight_sets = L).  Legal for
