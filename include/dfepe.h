@@ -20,11 +20,13 @@
 #ifndef DFEPE_H
 #define DFEPE_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define DFEPE_VERSION 110 /* 0.1.1 */
+#define DFEPE_VERSION 111 /* 0.1.1 */
 
 #define DFEPE_OK 0
 #define DFEPE_ERR_INVALID_ARG (-1) /* null pointer, non-positive size, bad flag combination   */
@@ -47,6 +49,9 @@ extern "C" {
                                      (utils_F._E_from_XY / _F_from_XY, utils_F.py:122-130,239-247)           */
 #define DFEPE_W8PT_FORCE_110 16u  /* singular values of the 3x3 forced to (1,1,0) instead of (s1,s2,0)
                                      (utils_F._E_from_XY, utils_F.py:148-149)                                */
+
+#define DFEPE_W8PT_NO_HARTLEY 32u /* no Hartley normalisation, T1 = T2 = I (`normalize=False` of _E_from_XY /
+                                     _F_from_XY, utils_F.py:116-119,233-236)                                 */
 
 int dfepe_version(void);
 const char *dfepe_strerror(int code);
@@ -204,6 +209,38 @@ int dfepe_inorm_lrelu_fwd(const float *Y, const float *gamma, const float *beta,
                           float *A, float *stats, void *stream);
 int dfepe_inorm_lrelu_bwd(const float *Y, const float *gA, const float *gamma, const float *beta, const float *stats,
                           int C, int R, int N, float slope, float *gY, float *row_ggamma, float *row_gbeta, void *stream);
+
+/*
+ * Match construction: what produces the [B,N,4] correspondences of dfepe_w8pt_fwd.
+ * Replaces the per-pair host loop of get_matches_from_SP (deepFEPE/train_good_utils.py:683-716):
+ *   SP_tracker.nn_match_two_way(desc1.T, desc2.T, nn_thresh)  (:687-691; PointTracker of the un-vendored `superpoint`
+ *   package, eric-yyjau/pytorch-superpoint models/model_wrap.py) -> dfepe_nn_match_two_way, batched over the pairs;
+ *   xs / offsets / quality gathered through crop_or_pad_choice (:693-716) -> dfepe_gather_matches.
+ *
+ *   desc1 [B,N1,D], desc2 [B,N2,D]  unit-norm descriptors, fp32, row-major (the reference's pts_desc layout,
+ *                                   train_good_utils.py:735), 16-byte aligned; D a multiple of 32 (else UNSUPPORTED)
+ *   nn_thresh                       keep a match when its L2 distance sqrt(2 - 2 clip(d1.d2,-1,1)) is < nn_thresh
+ *                                   (negative: INVALID_ARG, the reference raises ValueError)
+ *   workspace                       dfepe_nn_match_workspace_bytes(B,N1,N2) bytes, 8-byte aligned, contents irrelevant
+ *   m_idx1, m_idx2 [B,N1] int32, score [B,N1] fp32: the first count[b] entries of row b are the matches of pair b in
+ *                                   increasing m_idx1 order (rows 0,1,2 of the reference's [3,n] array); the rest is
+ *                                   not written.   count [B] int32.
+ * dmat is never materialised: fp32 MFMA tiles (exact fp32 products, arg-min ties resolved to the first index like
+ * numpy.argmin) folded into per-row / per-column minima with 64-bit atomicMin.
+ */
+size_t dfepe_nn_match_workspace_bytes(int B, int N1, int N2);
+int dfepe_nn_match_two_way(const float *desc1, const float *desc2, int B, int N1, int N2, int D, float nn_thresh,
+                           void *workspace, int *m_idx1, int *m_idx2, float *score, int *count, void *stream);
+/*
+ *   pts1 [B,N1,2], pts2 [B,N2,2] keypoints; off1, off2 same shapes (sub-pixel offsets; both NULL with offsets NULL)
+ *   choice [B,n_out] int32         positions into the match list of each pair (crop_or_pad_choice, utils_misc.py:139-161;
+ *                                   drawn on the host from numpy's RNG like the reference); every value < count[b]
+ *   xs [B,n_out,4] = (pts1[m_idx1[c]], pts2[m_idx2[c]]); offsets [B,n_out,4] likewise (may be NULL);
+ *   quality [B,n_out] = score[c] (may be NULL)                                   (train_good_utils.py:698-716)
+ */
+int dfepe_gather_matches(const float *pts1, const float *pts2, const float *off1, const float *off2, int B, int N1, int N2,
+                         const int *m_idx1, const int *m_idx2, const float *score, const int *choice, int n_out,
+                         float *xs, float *offsets, float *quality, void *stream);
 
 #ifdef __cplusplus
 }

@@ -500,3 +500,65 @@ def hot_path_step(scene: Dict[str, Tensor], image_size, depth: int, clamp_at: fl
         loss.backward()
     return {"loss": loss.detach(), "outs": outs, "losses": losses, "E_layers": E_layers, "pose": pose,
             "grad_logits": logits.grad if backward else None}
+
+
+# --------------------------------------------------------------------------------------
+# f-3: match construction  (train_good_utils.py:649-724 get_matches_from_SP, second half)
+# --------------------------------------------------------------------------------------
+# nn_match_two_way is NOT in /root/reference: it is ``PointTracker.nn_match_two_way`` of the ``superpoint`` package
+# (https://github.com/eric-yyjau/pytorch-superpoint, models/model_wrap.py; installed unpinned from git,
+# README.md:37-40), itself the published routine of Magic Leap's SuperPoint demo.  "Parity unpinned" for this one
+# function: the restatement below follows the published algorithm and is anchored on the reference's call site
+# (train_good_utils.py:687-691: descriptors transposed to [D,N], ``nn_thresh`` from the tracker) and on the
+# reference's own consumer of its [3,n] result (:693-716), which tests/golden/make_golden_matching.py runs unmodified.
+def nn_match_two_way(desc1: np.ndarray, desc2: np.ndarray, nn_thresh: float) -> np.ndarray:
+    """desc1 [D,N1], desc2 [D,N2] unit-norm columns -> [3,n]: rows = index in 1, index in 2, L2 distance."""
+    assert desc1.shape[0] == desc2.shape[0]
+    if desc1.shape[1] == 0 or desc2.shape[1] == 0:
+        return np.zeros((3, 0))
+    if nn_thresh < 0.0:
+        raise ValueError("'nn_thresh' should be non-negative")
+    dmat = np.dot(desc1.T, desc2)
+    dmat = np.sqrt(2 - 2 * np.clip(dmat, -1, 1))       # L2 distance of unit vectors
+    idx = np.argmin(dmat, axis=1)                      # nearest neighbour in 2 of every point of 1 (first on ties)
+    scores = dmat[np.arange(dmat.shape[0]), idx]
+    keep = scores < nn_thresh
+    idx2 = np.argmin(dmat, axis=0)                     # nearest neighbour in 1 of every point of 2
+    keep = np.logical_and(keep, np.arange(len(idx)) == idx2[idx])
+    idx, scores = idx[keep], scores[keep]
+    matches = np.zeros((3, int(keep.sum())))
+    matches[0, :] = np.arange(desc1.shape[1])[keep]
+    matches[1, :] = idx
+    matches[2, :] = scores
+    return matches
+
+
+def crop_or_pad_choice(in_num_points: int, out_num_points: int, shuffle: bool = False) -> np.ndarray:
+    """Indices that crop or pad a set to a fixed size (dsac_tools/utils_misc.py:139-161); draws from np.random's
+    global state exactly like the reference (one permutation when shuffling, one choice() when padding)."""
+    choice = np.random.permutation(in_num_points) if shuffle else np.arange(in_num_points)
+    assert out_num_points > 0
+    if in_num_points >= out_num_points:
+        return choice[:out_num_points]
+    pad = np.random.choice(choice, out_num_points - in_num_points, replace=True)
+    return np.concatenate([choice, pad])
+
+
+def matches_from_sp_outputs(xs_SP, deses_SP, reses_SP, nn_thresh: float, out_num_points: int = 1000):
+    """The per-pair loop of get_matches_from_SP after the SuperPoint front-end (train_good_utils.py:679-724):
+    xs_SP / reses_SP: two tensors [B,N,2] (integer keypoints, sub-pixel offsets), deses_SP: two tensors [B,N,D]."""
+    f = lambda t: t.detach().cpu().numpy()
+    B = xs_SP[0].shape[0]
+    xs_list, off_list, q_list, n_list = [], [], [], []
+    for b in range(B):
+        m = nn_match_two_way(f(deses_SP[0][b]).transpose(), f(deses_SP[1][b]).transpose(), nn_thresh)
+        choice = crop_or_pad_choice(m.shape[1], out_num_points, shuffle=True)
+        n_list.append(m.shape[1])
+        m = m[:, choice]
+        i1, i2 = m[0].astype(int), m[1].astype(int)
+        xs_list.append(torch.cat((xs_SP[0][b][i1], xs_SP[1][b][i2]), dim=1))
+        off_list.append(torch.cat((reses_SP[0][b][i1], reses_SP[1][b][i2]), dim=1))
+        q_list.append(m[2:3].transpose())
+    return {"xs": torch.stack(xs_list), "offsets": torch.stack(off_list),
+            "quality": torch.from_numpy(np.stack(q_list)).float(), "num_matches": torch.tensor(n_list),
+            "xs_SP": [x + r for x, r in zip(xs_SP, reses_SP)]}

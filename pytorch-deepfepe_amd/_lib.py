@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_uint, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdfepe_hip.so")
@@ -18,6 +18,7 @@ W8PT_LOGITS = 2
 W8PT_SQRT2 = 4
 W8PT_NO_ROWNORM = 8
 W8PT_FORCE_110 = 16
+W8PT_NO_HARTLEY = 32
 
 _P = c_void_p
 _SIGNATURES = {
@@ -38,6 +39,9 @@ _SIGNATURES = {
     "dfepe_geo_misc": (c_int, [c_int, _P, _P, c_int, _P, _P]),
     "dfepe_inorm_lrelu_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P]),
     "dfepe_inorm_lrelu_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
+    "dfepe_nn_match_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dfepe_nn_match_two_way": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P]),
+    "dfepe_gather_matches": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

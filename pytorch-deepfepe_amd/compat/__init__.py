@@ -6,8 +6,10 @@ argument order, defaults, return arity, tensor layouts and dict keys, backed by 
     deepFEPE.models.ErrorEstimators     ->   compat.ErrorEstimators (stock PyTorch; not part of the hot path)
     deepFEPE.dsac_tools.utils_F         ->   compat.utils_F
     deepFEPE.dsac_tools.utils_geo       ->   compat.utils_geo
-    deepFEPE.train_good_utils (losses)  ->   compat.train_good_utils (get_all_loss_DeepF, get_Rt_loss)
+    deepFEPE.train_good_utils           ->   compat.train_good_utils (get_all_loss_DeepF, get_Rt_loss, get_matches_from_SP)
+    deepFEPE.dsac_tools.utils_misc      ->   compat.utils_misc      (crop_or_pad_choice)
+    superpoint.models.model_wrap        ->   compat.model_wrap      (PointTracker.nn_match_two_way only)
 
 See INTEGRATION.md for how train_good.py is pointed at these.
 """
-from . import DeepFNet, ErrorEstimators, train_good_utils, utils_F, utils_geo  # noqa: F401
+from . import DeepFNet, ErrorEstimators, model_wrap, train_good_utils, utils_F, utils_geo, utils_misc  # noqa: F401

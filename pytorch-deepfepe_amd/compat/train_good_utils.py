@@ -133,3 +133,40 @@ def val_rt_batch(Ks, matches_xy, E_ests, delta_Rtijs_4_4, project_E=True, depth_
     err_R = torch.where(bad, torch.full_like(err_R, 180.0), err_R)
     err_t = torch.where(bad, torch.full_like(err_t, 90.0), err_t)
     return {"err_R_deg": err_R, "err_t_deg": err_t, "Rt_cam": Rt, "winner": win, "counts": cnt}
+
+
+def matches_from_SP_outputs(xs_SP, deses_SP, reses_SP, nn_thresh, out_num_points=1000):
+    """The per-pair loop of get_matches_from_SP (train_good_utils.py:679-724) for the whole batch on the GPU.
+    xs_SP, reses_SP: two tensors [B,N,2] (keypoints, sub-pixel offsets); deses_SP: two tensors [B,N,D] (unit norm).
+    One matching launch for all pairs, one D2H copy of the B match counts (the crop/pad permutation is drawn on the host
+    from numpy's RNG exactly like utils_misc.crop_or_pad_choice, so seeded runs agree), one gather launch."""
+    from .utils_misc import crop_or_pad_choice
+
+    if not deses_SP[0].is_cuda:
+        raise _lib.DfepeError("matches_from_SP_outputs: tensors must live on the GPU")
+    m1, m2, sc, cnt = ops.nn_match_two_way(deses_SP[0], deses_SP[1], float(nn_thresh))
+    counts = cnt.cpu().numpy()
+    choice = np.stack([crop_or_pad_choice(int(n), out_num_points, shuffle=True) for n in counts]).astype(np.int32)
+    choice_dev = torch.from_numpy(choice).to(m1.device)
+    xs, offsets, quality = ops.gather_matches(xs_SP[0], xs_SP[1], reses_SP[0], reses_SP[1], m1, m2, sc, choice_dev)
+    xs_all = [x + r for (x, r) in zip(xs_SP, reses_SP)]
+    return {"xs": xs, "offsets": offsets, "quality": quality, "num_matches": torch.from_numpy(counts.astype(np.int64)),
+            "xs_SP": xs_all}
+
+
+def get_matches_from_SP(imgs_grey, net_SP, SP_processer, SP_tracker, out_num_points=1000, process_SP_output=None):
+    """Same call as the reference's get_matches_from_SP (train_good_utils.py:649-724).  The SuperPoint front-end stays
+    the caller's: ``net_SP`` and ``process_SP_output`` (by default the reference's own, importable when this runs inside
+    the reference tree, :665) produce keypoints / descriptors / offsets; the matching, crop/pad and gather of all pairs
+    then run as two launches instead of a per-pair numpy loop.  ``SP_tracker`` only supplies ``nn_thresh``."""
+    if process_SP_output is None:
+        from train_good_utils import process_SP_output  # the reference's module (superpoint front-end, out of scope here)
+    imgs_grey_float = [img_grey.float().cuda() / 255.0 for img_grey in imgs_grey]
+    xs_SP, deses_SP, reses_SP = [], [], []
+    for img12_grey_float in imgs_grey_float:
+        outs = net_SP(img12_grey_float.unsqueeze(-1).permute(0, 3, 1, 2))  # [batch_size, 1, H, W]
+        outs = process_SP_output(outs, SP_processer)
+        xs_SP.append(outs["pts_int"])
+        deses_SP.append(outs["pts_desc"])
+        reses_SP.append(outs["pts_offset"])
+    return matches_from_SP_outputs(xs_SP, deses_SP, reses_SP, SP_tracker.nn_thresh, out_num_points)

@@ -178,8 +178,9 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     }
   }
   const double invN = 1.0 / (double)N;
-  const double c1x = to_sgpr(wave_sum(sx1) * invN), c1y = to_sgpr(wave_sum(sy1) * invN);
-  const double c2x = to_sgpr(wave_sum(sx2) * invN), c2y = to_sgpr(wave_sum(sy2) * invN);
+  const bool hartley = (variant & DFEPE_W8PT_NO_HARTLEY) == 0;  // wave-uniform
+  const double c1x = hartley ? to_sgpr(wave_sum(sx1) * invN) : 0.0, c1y = hartley ? to_sgpr(wave_sum(sy1) * invN) : 0.0;
+  const double c2x = hartley ? to_sgpr(wave_sum(sx2) * invN) : 0.0, c2y = hartley ? to_sgpr(wave_sum(sy2) * invN) : 0.0;
   wave_sync();
 
   tstamp[1] = __builtin_amdgcn_s_memtime();
@@ -195,8 +196,8 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   }
   // Fit.normalize uses the literal 1.4142, not sqrt(2) (DeepFNet.py:168); utils_F._normalize_XY uses np.sqrt(2)
   const double hscale = (variant & DFEPE_W8PT_SQRT2) ? 1.4142135623730951 : 1.4142;
-  const double s1 = to_sgpr(hscale * fast_rcp(wave_sum(d1) * invN));
-  const double s2 = to_sgpr(hscale * fast_rcp(wave_sum(d2) * invN));
+  const double s1 = hartley ? to_sgpr(hscale * fast_rcp(wave_sum(d1) * invN)) : 1.0;
+  const double s2 = hartley ? to_sgpr(hscale * fast_rcp(wave_sum(d2) * invN)) : 1.0;
 
   tstamp[2] = __builtin_amdgcn_s_memtime();
   // ---- phase 2: X^T X as 36 distinct fp64 sums per lane (exact products of fp32-derived factors) ---------
@@ -553,7 +554,7 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
                               float* residual, float* epi_res, float* save, float* weights_out, void* stream) {
   const bool raw = (flags & DFEPE_W8PT_RAW_MATCHES) != 0;
   const int logits_mode = (flags & DFEPE_W8PT_LOGITS) ? 1 : 0;
-  const unsigned variant = flags & (DFEPE_W8PT_SQRT2 | DFEPE_W8PT_NO_ROWNORM | DFEPE_W8PT_FORCE_110);
+  const unsigned variant = flags & (DFEPE_W8PT_SQRT2 | DFEPE_W8PT_NO_ROWNORM | DFEPE_W8PT_FORCE_110 | DFEPE_W8PT_NO_HARTLEY);
   const int dbg = (int)((flags >> 16) & 0x1ffu);  // undocumented diagnostics: forced sweep count (timing experiments only)
   if (B < 0 || N <= 0 || n_weight_sets < 1) return DFEPE_ERR_INVALID_ARG;
   if (variant && save) return DFEPE_ERR_UNSUPPORTED;  // the textbook variants are forward-only

@@ -80,9 +80,8 @@ def w8pt_backward(pts1, pts2, weights, raw, image_w, image_h, clamp_at, save, F,
 
 def eight_point(X: Tensor, Y: Tensor, w: Optional[Tensor], essential: bool, normalize: bool = True) -> Tensor:
     """Textbook normalised 8-point on 2-D points X, Y [B,N,2] with optional per-correspondence weights [B,N]
-    (utils_F._F_from_XY / _E_from_XY after the K^-1 step): sqrt(2) Hartley, unnormalised rows, S3 -> 0 or (1,1,0)."""
-    if not normalize:
-        raise NotImplementedError("normalize=False is not built")
+    (utils_F._F_from_XY / _E_from_XY after the K^-1 step): sqrt(2) Hartley (none when ``normalize`` is False),
+    unnormalised rows, S3 -> 0 or (1,1,0)."""
     X, Y = _prep(X, "X"), _prep(Y, "Y")
     B, N = X.shape[0], X.shape[1]
     ones = torch.ones(B, N, 1, device=X.device)
@@ -92,7 +91,8 @@ def eight_point(X: Tensor, Y: Tensor, w: Optional[Tensor], essential: bool, norm
     L = _lib.lib()
     F = torch.empty(B, 3, 3, device=X.device)
     residual = torch.empty(B, N, device=X.device)
-    flags = _lib.W8PT_SQRT2 | _lib.W8PT_NO_ROWNORM | (_lib.W8PT_FORCE_110 if essential else 0)
+    flags = (_lib.W8PT_SQRT2 | _lib.W8PT_NO_ROWNORM | (_lib.W8PT_FORCE_110 if essential else 0) |
+             (0 if normalize else _lib.W8PT_NO_HARTLEY))
     with torch.cuda.device(X.device):
         rc = L.dfepe_w8pt_fwd(_ptr(p1), _ptr(p2), _ptr(wt), B, N, 1, flags, 0.0, 0.0, 0.5, _ptr(F), _ptr(residual), None, None, None,
                               _stream())
@@ -388,3 +388,53 @@ class _InormLReLUFunction(torch.autograd.Function):
 def inorm_lrelu(Y: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, slope: float = 0.01) -> Tensor:
     """Y [C,R,N] channel-major (contiguous) -> LeakyReLU(InstanceNorm over N with affine gamma/beta [C])."""
     return _InormLReLUFunction.apply(_prep(Y, "Y"), _prep(gamma, "gamma"), _prep(beta, "beta"), eps, slope)
+
+
+# ------------------------------------------------------------------------------------------------
+# match construction ("next" row f-3): two-way nearest-neighbour matching of descriptors + crop/pad gather
+# ------------------------------------------------------------------------------------------------
+def nn_match_two_way(desc1: Tensor, desc2: Tensor, nn_thresh: float):
+    """desc1 [B,N1,D], desc2 [B,N2,D] unit-norm descriptors -> (m_idx1 [B,N1] int32, m_idx2 [B,N1] int32, score [B,N1],
+    count [B] int32): the first count[b] entries of row b are pair b's mutual nearest neighbours closer than ``nn_thresh``
+    in increasing m_idx1 order (PointTracker.nn_match_two_way as called at train_good_utils.py:687-691, for all pairs)."""
+    if nn_thresh < 0.0:
+        raise ValueError("'nn_thresh' should be non-negative")
+    d1, d2 = _prep(desc1, "desc1"), _prep(desc2, "desc2")
+    if d1.dim() != 3 or d2.dim() != 3 or d1.shape[0] != d2.shape[0] or d1.shape[2] != d2.shape[2]:
+        raise ValueError("descriptors must be [B,N1,D] and [B,N2,D]")
+    B, N1, D = d1.shape
+    N2 = d2.shape[1]
+    L = _lib.lib()
+    dev = d1.device
+    m1 = torch.empty(B, max(N1, 1), device=dev, dtype=torch.int32)
+    m2 = torch.empty(B, max(N1, 1), device=dev, dtype=torch.int32)
+    sc = torch.empty(B, max(N1, 1), device=dev, dtype=torch.float32)
+    cnt = torch.empty(B, device=dev, dtype=torch.int32)
+    ws = torch.empty(max(int(L.dfepe_nn_match_workspace_bytes(B, N1, N2)) // 8, 1), device=dev, dtype=torch.int64)
+    with torch.cuda.device(dev):
+        rc = L.dfepe_nn_match_two_way(_ptr(d1), _ptr(d2), B, N1, N2, D, float(nn_thresh), _ptr(ws), _ptr(m1), _ptr(m2), _ptr(sc),
+                                      _ptr(cnt), _stream())
+    _lib.check(rc, "dfepe_nn_match_two_way")
+    return m1, m2, sc, cnt
+
+
+def gather_matches(pts1: Tensor, pts2: Tensor, off1: Optional[Tensor], off2: Optional[Tensor], m_idx1: Tensor, m_idx2: Tensor,
+                   score: Tensor, choice: Tensor):
+    """choice [B,n_out] int32 positions into each pair's match list -> xs [B,n_out,4], offsets [B,n_out,4] | None,
+    quality [B,n_out,1]  (train_good_utils.py:698-716)."""
+    p1, p2 = _prep(pts1, "pts1"), _prep(pts2, "pts2")
+    B, N1, N2 = p1.shape[0], p1.shape[1], p2.shape[1]
+    o1 = None if off1 is None else _prep(off1, "off1")
+    o2 = None if off2 is None else _prep(off2, "off2")
+    if m_idx1.shape != (B, N1) or m_idx1.dtype != torch.int32 or choice.dtype != torch.int32 or not choice.is_contiguous():
+        raise ValueError("m_idx1/m_idx2 must be the [B,N1] int32 outputs of nn_match_two_way and choice a contiguous int32 [B,n_out]")
+    n_out = choice.shape[1]
+    dev = p1.device
+    xs = torch.empty(B, n_out, 4, device=dev)
+    offs = torch.empty(B, n_out, 4, device=dev) if o1 is not None else None
+    q = torch.empty(B, n_out, 1, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().dfepe_gather_matches(_ptr(p1), _ptr(p2), _ptr(o1), _ptr(o2), B, N1, N2, _ptr(m_idx1), _ptr(m_idx2), _ptr(score),
+                                             _ptr(choice), n_out, _ptr(xs), _ptr(offs), _ptr(q), _stream())
+    _lib.check(rc, "dfepe_gather_matches")
+    return xs, offs, q

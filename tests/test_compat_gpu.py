@@ -130,7 +130,7 @@ def test_loss_functions_match_reference_golden(dfepe, golden):
     np.testing.assert_allclose(rt["t_l2_error_list"].cpu().numpy(), g[pre + "t_l2_error_list"], rtol=2e-4)
 
 
-def test_dsac_tools_functions_match_reference_golden(dfepe, golden):
+def test_dsac_tools_functions_match_reference_golden(dfepe, oracle, golden):
     g = golden("geometry")
     uF, uG = dfepe.compat.utils_F, dfepe.compat.utils_geo
     x1, x2, F, K = T(g["x1"]).to(DEV), T(g["x2"]).to(DEV), T(g["F_in"]).to(DEV), T(g["K"]).to(DEV)
@@ -163,6 +163,15 @@ def test_dsac_tools_functions_match_reference_golden(dfepe, golden):
         assert np.abs(a - r).max() < 5e-4, (key, np.abs(a - r).max())
     with pytest.raises(NotImplementedError):
         uF._F_from_XY(x1[0], x2[0], W=torch.ones(64, 64, device=DEV))
+    # normalize=False (no Hartley step) against the fp64 oracle on K^-1-normalised points, where it is well conditioned
+    x1n = (torch.cat((x1[0], torch.ones(x1.shape[1], 1, device=DEV)), 1) @ torch.linalg.inv(K).t())[:, :2].contiguous()
+    x2n = (torch.cat((x2[0], torch.ones(x2.shape[1], 1, device=DEV)), 1) @ torch.linalg.inv(K).t())[:, :2].contiguous()
+    for ess in (False, True):
+        ours = (uF._E_from_XY(x1n, x2n, K, if_normzliedK=True, normalize=False) if ess else uF._F_from_XY(x1n, x2n, normalize=False))
+        ref = (oracle.E_from_XY(x1n.cpu().double(), x2n.cpu().double(), Kd.cpu(), if_normzliedK=True, normalize=False) if ess
+               else oracle.F_from_XY(x1n.cpu().double(), x2n.cpu().double(), normalize=False))
+        a, r, _ = unit_align(ours.cpu().numpy()[None], ref.numpy()[None])
+        assert np.abs(a - r).max() < 2e-5, (ess, np.abs(a - r).max())
     # batched forms (the reference needs the external batch_svd extension for these)
     Eb = uF._E_from_XY_batch(x1, x2, K.expand(8, 3, 3))
     a, r, sgn = unit_align(Eb[:1].cpu().numpy(), g["E_from_XY"][None])
