@@ -13,10 +13,10 @@
 // Kernel 1 (nn_match_tile): the only GEMM-shaped op of the whole path, so it runs on the matrix cores in exact fp32
 // (v_mfma_f32_32x32x2_f32: the descriptors are fp32 and the arg-min decisions must not see bf16 rounding).  One
 // 256-thread workgroup per 128x128 tile of dmat, 2x2 wavefronts of 64x64 (2x2 MFMA tiles of 32x32, 64 accumulator
-// VGPRs), K = D in chunks of 32 staged K-major in LDS ([k][row]: a lane's MFMA operand A[i=l&31][k=l>>5] is then a
+// VGPRs), K = D in chunks of 16 staged K-major in LDS ([k][row]: a lane's MFMA operand A[i=l&31][k=l>>5] is then a
 // conflict-free ds_read_b32), double-buffered with the next chunk prefetched into registers.  dmat never reaches HBM:
-// the epilogue turns the accumulators into distances and folds them into per-row and per-column minima, packed as
-// (distance bits << 32 | index) so that one 64-bit atomicMin per row/column realises numpy's first-occurrence argmin.
+// the epilogue turns the accumulators into squared distances and folds them into per-row and per-column minima, packed
+// as (value bits << 32 | index) so that one 64-bit atomicMin per row/column realises numpy's first-occurrence argmin.
 // Kernel 2 (nn_match_finish): threshold + mutual check + order-preserving compaction (ballot / popcount).
 // Kernel 3 (gather_matches): the crop/pad gather into xs [B,N,4], offsets [B,N,4], quality [B,N].
 #include "dfepe_common.h"
@@ -27,36 +27,64 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned long long u64;
 
 constexpr int TM = 128;  // tile edge (rows of image 1 x rows of image 2)
-constexpr int TK = 32;   // K chunk
-constexpr u64 kNoKey = ~0ull;
+constexpr int TK = 16;   // K chunk: 2 x 2 x 16 x 128 floats = 32 KiB of LDS per workgroup, so four workgroups share a CU and one
+                         // workgroup's epilogue / prologue overlaps the others' MFMA phases
 constexpr unsigned kNoVal = 0xffffffffu;
 
+// Squared distance of two unit descriptors from their dot product: t = 2 - 2 clip(dot, -1, 1), bit-identical to the
+// reference's fp32 expression under the square root (one rounding).  The minima are taken over t; the reference takes
+// them over sqrt(t), which is the same arg-min except when two DIFFERENT t round to the same square root and the larger
+// one comes first -- a 1-ulp near-tie that already depends on the summation order of the BLAS behind np.dot.  Exact
+// ties (duplicated descriptors, dots clipped at 1) keep numpy's first-occurrence rule.  The score is sqrtf(t_min).
+__device__ __forceinline__ float dot_to_t(float dot) { return fmaf(-2.0f, __builtin_amdgcn_fmed3f(dot, -1.0f, 1.0f), 2.0f); }
+
 template <int CTRL>
-__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
-  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+__device__ __forceinline__ u64 exchange_u64(u64 v) {
+  union { u64 k; int i[2]; } a, r;
+  a.k = v;
+  if (CTRL == 0) {  // lane ^ 16: crosses the 16-lane DPP rows
+    r.i[0] = __shfl_xor(a.i[0], 16, 64);
+    r.i[1] = __shfl_xor(a.i[1], 16, 64);
+  } else {
+    r.i[0] = __builtin_amdgcn_update_dpp(a.i[0], a.i[0], (CTRL == 0) ? 0xB1 : CTRL, 0xf, 0xf, false);
+    r.i[1] = __builtin_amdgcn_update_dpp(a.i[1], a.i[1], (CTRL == 0) ? 0xB1 : CTRL, 0xf, 0xf, false);
+  }
+  return r.k;
 }
-// minimum over the 32 lanes that share lane>>5; every lane of the half receives it
-__device__ __forceinline__ unsigned half_min_u32(unsigned x) {
-  x = min(x, dpp_u32<0xB1>(x));   // quad_perm [1,0,3,2]
-  x = min(x, dpp_u32<0x4E>(x));   // quad_perm [2,3,0,1]
-  x = min(x, dpp_u32<0x141>(x));  // row_half_mirror
-  x = min(x, dpp_u32<0x140>(x));  // row_mirror
-  x = min(x, (unsigned)__shfl_xor((int)x, 16, 64));
-  return x;
+// One step of a transposing min-reduction over the 32 lanes of a half: CNT keys per lane -> CNT/2; the lane with the
+// decision bit set keeps the upper half of its array and hands the lower half to its partner (any partner on the other
+// side of the bit works: lane^16, row_mirror, row_half_mirror, quad_perm xor 2 / xor 1).  After the five steps lane j
+// holds the minimum over the half of key number j: 31 exchanges instead of 32 x 5.
+template <int CNT, int CTRL>
+__device__ __forceinline__ void halve_min(u64* a, bool upper) {
+  constexpr int H = CNT / 2;
+#pragma unroll
+  for (int k = 0; k < H; ++k) {
+    const u64 lo = a[k], hi = a[k + H];
+    const u64 got = exchange_u64<CTRL>(upper ? lo : hi);
+    const u64 keep = upper ? hi : lo;
+    a[k] = (got < keep) ? got : keep;
+  }
 }
 
-// distance of two unit descriptors from their dot product, exactly the reference's fp32 expression
-__device__ __forceinline__ float dot_to_dist(float dot) { return sqrtf(2.0f - 2.0f * fminf(fmaxf(dot, -1.0f), 1.0f)); }
-
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, 4)
 nn_match_tile_kernel(const float* __restrict__ desc1, const float* __restrict__ desc2, int N1, int N2, int D,
                      u64* __restrict__ rowkey, u64* __restrict__ colkey) {
-  __shared__ float lds[2][2][TK][TM];  // [buffer][image][k][row]: 64 KiB
+  __shared__ float lds[2][2][TK][TM];  // [buffer][image][k][row]: 32 KiB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int b = blockIdx.z, m0 = blockIdx.y * TM, n0 = blockIdx.x * TM;
+  // XCD-aware tile order: workgroup w runs on XCD w % 8 (round-robin dispatch), and each XCD has its own 4 MiB L2.  The
+  // tiles of one image pair share its 2 x N x D descriptors, so every XCD is given whole pairs: the workgroups an XCD
+  // has in flight (32 CUs x 4) then cover ~2 pairs = ~4 MiB of descriptors instead of a slice of 16 different pairs.
+  const int tn = (N2 + TM - 1) / TM, tm = (N1 + TM - 1) / TM;
+  const unsigned total = gridDim.x;
+  unsigned w = blockIdx.x;
+  if ((total & 7u) == 0u) w = (w & 7u) * (total >> 3) + (w >> 3);
+  const int b = (int)(w / (unsigned)(tm * tn));
+  const int trem = (int)(w % (unsigned)(tm * tn));
+  const int m0 = (trem / tn) * TM, n0 = (trem % tn) * TM;
 
-  // loader role: threads 0..127 stream one descriptor of image 1 each (128 contiguous bytes per chunk), 128..255 image 2
+  // loader role: threads 0..127 stream one descriptor of image 1 each (64 contiguous bytes per chunk), 128..255 image 2
   const int img = tid >> 7, lr = tid & 127;
   const int grow = (img ? n0 : m0) + lr;
   const bool rvalid = grow < (img ? N2 : N1);
@@ -115,32 +143,13 @@ nn_match_tile_kernel(const float* __restrict__ desc1, const float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = dot_to_dist(acc[i][j][r]);
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = dot_to_t(acc[i][j][r]);
 
   const int cg0 = n0 + wc * 64 + jl;  // global column of my element in column tile 0 (tile 1: +32)
   const int rbase = m0 + wr * 64 + 4 * h;
-  // row minima: in-lane over the two column tiles, then across the 32 lanes of the half that hold the same rows
-  u64 myrow = kNoKey;
-#pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const unsigned k0 = (cg0 < N2) ? __float_as_uint(acc[rt][0][r]) : kNoVal;
-      const unsigned k1 = (cg0 + 32 < N2) ? __float_as_uint(acc[rt][1][r]) : kNoVal;
-      const unsigned kb = min(k0, k1);
-      const unsigned cb = (k1 < k0) ? (unsigned)(cg0 + 32) : (unsigned)cg0;  // ties keep the smaller column
-      const unsigned vmin = half_min_u32(kb);
-      const unsigned cmin = half_min_u32((kb == vmin) ? cb : kNoVal);
-      if (jl == rt * 16 + r) myrow = (vmin == kNoVal) ? kNoKey : (((u64)vmin << 32) | cmin);
-    }
-  }
-  {
-    // lane jl of half h ended up with the row of (rt, r) = (jl >> 4, jl & 15)
-    const int r = jl & 15;
-    const int rg = rbase + (jl >> 4) * 32 + (r & 3) + 8 * (r >> 2);
-    if (rg < N1 && myrow != kNoKey) atomicMin(&rowkey[(size_t)b * N1 + rg], myrow);
-  }
-  // column minima: in-lane over my 32 rows (visited in increasing order: strict < keeps the first), then the two halves
+  const bool c0ok = cg0 < N2, c1ok = cg0 + 32 < N2;
+  // column minima first (they read the accumulators in place): in-lane over my 32 rows, visited in increasing order so
+  // that strict < keeps the first row, then the two halves through one 64-bit exchange
   u64 colk[2];
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
@@ -154,34 +163,54 @@ nn_match_tile_kernel(const float* __restrict__ desc1, const float* __restrict__ 
         if (k < bestv) { bestv = k; bestr = (unsigned)rg; }
       }
     }
-    u64 key = (bestv == kNoVal) ? kNoKey : (((u64)bestv << 32) | bestr);
+    const u64 key = ((u64)bestv << 32) | bestr;
     const u64 other = (u64)__shfl_xor((long long)key, 32, 64);
     colk[ct] = (other < key) ? other : key;
   }
   {
     const u64 mycol = h ? colk[1] : colk[0];
     const int cg = cg0 + 32 * h;
-    if (cg < N2 && mycol != kNoKey) atomicMin(&colkey[(size_t)b * N2 + cg], mycol);
+    if (cg < N2 && (unsigned)(mycol >> 32) != kNoVal) atomicMin(&colkey[(size_t)b * N2 + cg], mycol);
+  }
+  // row minima: in-lane over the two column tiles (ties keep the smaller column), then the transposing reduction over
+  // the 32 lanes of the half; key number q = 16 rt + r ends up in lane q of the half
+  u64 rk[32];
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const unsigned k0 = c0ok ? __float_as_uint(acc[q >> 4][0][q & 15]) : kNoVal;
+    const unsigned k1 = c1ok ? __float_as_uint(acc[q >> 4][1][q & 15]) : kNoVal;
+    const unsigned cb = (k1 < k0) ? (unsigned)(cg0 + 32) : (unsigned)cg0;
+    rk[q] = ((u64)min(k0, k1) << 32) | cb;
+  }
+  halve_min<32, 0>(rk, (lane & 16) != 0);
+  halve_min<16, 0x140>(rk, (lane & 8) != 0);  // row_mirror
+  halve_min<8, 0x141>(rk, (lane & 4) != 0);   // row_half_mirror
+  halve_min<4, 0x4E>(rk, (lane & 2) != 0);    // quad_perm [2,3,0,1]
+  halve_min<2, 0xB1>(rk, (lane & 1) != 0);    // quad_perm [1,0,3,2]
+  {
+    const int r = jl & 15;
+    const int rg = rbase + (jl >> 4) * 32 + (r & 3) + 8 * (r >> 2);
+    if (rg < N1 && (unsigned)(rk[0] >> 32) != kNoVal) atomicMin(&rowkey[(size_t)b * N1 + rg], rk[0]);
   }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 nn_match_finish_kernel(const u64* __restrict__ rowkey, const u64* __restrict__ colkey, int N1, int N2, float nn_thresh,
                        int* __restrict__ m_idx1, int* __restrict__ m_idx2, float* __restrict__ score,
                        int* __restrict__ count) {
-  __shared__ int wsum[4];
+  __shared__ int wsum[16];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int base = 0;
-  for (int i0 = 0; i0 < N1; i0 += 256) {
+  for (int i0 = 0; i0 < N1; i0 += 1024) {  // one pass for up to 1024 keypoints: a single memory latency per pair
     const int i = i0 + tid;
     bool keep = false;
     unsigned j = 0;
     float d = 0.0f;
     if (i < N1) {
       const u64 key = rowkey[(size_t)b * N1 + i];
-      if (key != kNoKey) {
+      if ((unsigned)(key >> 32) != kNoVal) {
         j = (unsigned)key;
-        d = __uint_as_float((unsigned)(key >> 32));
+        d = sqrtf(__uint_as_float((unsigned)(key >> 32)));  // the keys carry t = 2 - 2 clip(dot); the score is the distance
         // scores < nn_thresh, and the nearest neighbour of j in image 1 is i again
         keep = (d < nn_thresh) && ((unsigned)colkey[(size_t)b * N2 + j] == (unsigned)i);
       }
@@ -192,7 +221,7 @@ nn_match_finish_kernel(const u64* __restrict__ rowkey, const u64* __restrict__ c
     __syncthreads();
     int off = base, all = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < 16; ++w) {
       if (w < wave) off += wsum[w];
       all += wsum[w];
     }
@@ -247,15 +276,16 @@ extern "C" int dfepe_nn_match_two_way(const float* desc1, const float* desc2, in
     return (hipMemsetAsync(count, 0, (size_t)B * sizeof(int), st) == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
   }
   if (!desc1 || !desc2 || !workspace || !m_idx1 || !m_idx2 || !score) return DFEPE_ERR_INVALID_ARG;
-  if (D % TK != 0) return DFEPE_ERR_UNSUPPORTED;  // K is consumed in chunks of 32 (SuperPoint: D = 256)
+  if (D % 32 != 0) return DFEPE_ERR_UNSUPPORTED;  // K is consumed in 16-float chunks, two per 128-byte line (SuperPoint: D = 256)
   if (((uintptr_t)desc1 | (uintptr_t)desc2) & 15u) return DFEPE_ERR_INVALID_ARG;
   if (((uintptr_t)workspace) & 7u) return DFEPE_ERR_INVALID_ARG;
   u64* rowkey = static_cast<u64*>(workspace);
   u64* colkey = rowkey + (size_t)B * N1;
   if (hipMemsetAsync(workspace, 0xff, dfepe_nn_match_workspace_bytes(B, N1, N2), st) != hipSuccess) return DFEPE_ERR_HIP;
-  const dim3 grid((N2 + TM - 1) / TM, (N1 + TM - 1) / TM, B);
-  hipLaunchKernelGGL(nn_match_tile_kernel, grid, dim3(256), 0, st, desc1, desc2, N1, N2, D, rowkey, colkey);
-  hipLaunchKernelGGL(nn_match_finish_kernel, dim3(B), dim3(256), 0, st, rowkey, colkey, N1, N2, nn_thresh, m_idx1, m_idx2,
+  const size_t tiles = (size_t)((N2 + TM - 1) / TM) * ((N1 + TM - 1) / TM) * B;
+  if (tiles > 0x7fffffffu) return DFEPE_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(nn_match_tile_kernel, dim3((unsigned)tiles), dim3(256), 0, st, desc1, desc2, N1, N2, D, rowkey, colkey);
+  hipLaunchKernelGGL(nn_match_finish_kernel, dim3(B), dim3(1024), 0, st, rowkey, colkey, N1, N2, nn_thresh, m_idx1, m_idx2,
                      score, count);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
