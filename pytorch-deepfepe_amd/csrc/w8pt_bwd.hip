@@ -127,7 +127,7 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
       for (int c = 0; c < 3; ++c) gFm[3 * r + c] = G[3 * r + c] - a33 * U[3 * r + 2] * V[3 * c + 2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const double coef = S[2] / guard_den(S[2] * S[2] - S[k] * S[k]);
+      const double coef = S[2] * fast_rcp(guard_den(S[2] * S[2] - S[k] * S[k]));
       const double ak3 = UtGV[3 * k + 2];  // u_k^T G v_3
       const double a3k = UtGV[6 + k];      // u_3^T G v_k
 #pragma unroll
@@ -149,7 +149,7 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     double dot = 0.0;
 #pragma unroll
     for (int c = 0; c < 9; ++c) dot += (double)sv[SV_Q + k * 9 + c] * gf[c];
-    const double ck = dot / guard_den(lsel - (double)sv[SV_LAM + k]);
+    const double ck = dot * fast_rcp(guard_den(lsel - (double)sv[SV_LAM + k]));  // fp32 seed + 2 Newton steps, not a 30-instruction fp64 divide
 #pragma unroll
     for (int c = 0; c < 9; ++c) u[c] += ck * (double)sv[SV_Q + k * 9 + c];
   }
