@@ -126,6 +126,15 @@ for k in sq:
     conf = mean(x["SQ_LDS_BANK_CONFLICT"] for x in lv) / max(mean(x["SQ_LDS_IDX_ACTIVE"] for x in lv), 1.0) if lv else 0.0
     md.append(f"| `{k}` | {wv:.0f} | {g('SQ_INSTS_VALU')/wv:.0f} | {g('SQ_INSTS_LDS')/wv:.0f} | {g('SQ_INSTS_SALU')/wv:.0f} | {wc/wv:.0f} | "
               f"{100*act/wc:.0f} | {100*wait_inst/wc:.0f} | {100*wait_any/wc:.0f} | {conf:.3f} |")
+clk_ghz = None
+if os.path.exists(os.path.join(O, "pmc_clk", "p_counter_collection.csv")):
+    rows = list(csv.DictReader(open(os.path.join(O, "pmc_clk", "p_counter_collection.csv"))))
+    busy = [(float(r["Counter_Value"]) / 256.0, (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3) for r in rows
+            if r["Counter_Name"] == "SQ_BUSY_CU_CYCLES" and "w8pt_fwd" in r["Kernel_Name"]]
+    if busy:
+        clk_ghz = mean(b / d for b, d in busy) / 1e3
+        md += ["", f"Sustained shader clock during `w8pt_fwd` (SQ_BUSY_CU_CYCLES / 256 CUs / kernel duration, a lower bound because the CUs are not "
+               f"busy during the launch ramp): **{clk_ghz:.2f} GHz** (mean of {len(busy)} launches) - not the 2.4 GHz peak clock the MI355X tables quote."]
 fv = sq.get("w8pt_fwd_kernel<true>")
 if fv:
     v = fv[:-4]
@@ -134,5 +143,8 @@ if fv:
     md += ["", f"VALU-issue floor of `w8pt_fwd` at this occupancy: 4096 waves / 1024 SIMDs = 4 waves per SIMD x {valu:.0f} VALU instructions x "
            f"4 cycles = {4*valu*4:.0f} cycles = {floor_us:.1f} us at 2.4 GHz, against {fwd_avg_us:.1f} us measured: the kernel runs at "
            f"{100*floor_us/fwd_avg_us:.0f} % of the vector-issue bound of its own instruction stream; HBM is idle most of the time."]
+    if clk_ghz:
+        md[-1] += (f"  At the {clk_ghz:.2f} GHz the counters show, the same bound is {4*valu*4/clk_ghz/1e3:.1f} us, i.e. the launch runs at "
+                   f"{100*(4*valu*4/clk_ghz/1e3)/fwd_avg_us:.0f} % of it: the kernel is vector-issue bound, and only fewer instructions make it faster.")
 open(os.path.join(P, f"{tag}_rocprof_summary.md"), "w").write("\n".join(md) + "\n")
 print("\n".join(md))
