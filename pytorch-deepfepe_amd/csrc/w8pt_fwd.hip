@@ -313,11 +313,14 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
       if (lane < 8) {
         const float2 pq = *reinterpret_cast<const float2*>(A32 + pp * 11);  // {A[p][p], A[p][p+1]}
         const float aqq = A32[pp * 11 + 11];
+        // small-angle Jacobi rotation from two reciprocal square roots: cos 2t = |d| / h, c = sqrt((1 + cos 2t) / 2),
+        // s = sgn(d) b / (2 h c)   (same rotation as t = b / (d + sgn(d) h), |t| <= 1, five instructions shorter)
         const float d = aqq - pq.x, b = 2.0f * pq.y;
-        const float h = __builtin_amdgcn_sqrtf(fmaf(d, d, b * b));
-        const float t = b * __builtin_amdgcn_rcpf(d + copysignf(h, d));
-        float c = __builtin_amdgcn_rsqf(fmaf(t, t, 1.0f));
-        float sn = t * c;
+        const float r = __builtin_amdgcn_rsqf(fmaf(d, d, b * b));
+        const float x = fmaf(0.5f * fabsf(d), r, 0.5f);
+        const float y = __builtin_amdgcn_rsqf(x);
+        float c = x * y;
+        float sn = copysignf(0.5f, d) * b * r * y;
         if (pq.y == 0.0f) { c = 1.0f; sn = 0.0f; }  // also catches 0/0
         CS[lane] = make_float2(c, (lane & 1) ? sn : -sn);
       }
