@@ -165,16 +165,30 @@ def main():
         alg_bytes = B * (28 * N + 36)  # read 16N matches + 4N weights; write 36 F + 4N residual + 4N epi  
         achieved = alg_bytes / kdur / 1e9
         traffic = None
+        issue_bound = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"w8pt_fwd_B{B}_N{N}")
+                tj = json.load(open(tpath))
+                traffic = tj.get(f"w8pt_fwd_B{B}_N{N}")
+                valu = tj.get(f"w8pt_fwd_valu_insts_per_wave_B{B}_N{N}")
+                if valu:
+                    # the bound that actually limits this kernel: one wavefront per pair, 4 cycles per wave64 VALU instruction,
+                    # ceil(B / 1024 SIMDs) wavefronts per SIMD; instruction count from the committed PMC pass
+                    wps = -(-B // 1024)
+                    cyc = wps * valu * 4.0
+                    clk = tj.get("w8pt_fwd_sustained_clock_ghz")
+                    issue_bound = {"valu_insts_per_wave": valu, "waves_per_simd": wps, "cycles": round(cyc),
+                                   "floor_us_at_2.4GHz": round(cyc / 2.4e3, 2), "frac_at_2.4GHz": round(cyc / 2.4e3 / (kdur * 1e6), 3),
+                                   "sustained_clock_ghz": clk,
+                                   "frac_at_sustained_clock": (round(cyc / (clk * 1e3) / (kdur * 1e6), 3) if clk else None),
+                                   "source": "profiles/traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, SQ_BUSY_CU_CYCLES)"}
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": "w8pt_fwd_kernel<raw>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                     "avg_kernel_us": round(kdur * 1e6, 2), "algorithmic_bytes_per_launch": alg_bytes,
-                    "launches_per_step": L,
+                    "launches_per_step": L, "vector_issue_bound": issue_bound,
                     "traffic_note": "profiles/traffic.json: PMC 2*FETCH_SIZE+WRITE_SIZE of this probe launch, which (like the training "
                                     "step) also writes the 512-B save record per pair (2.1 MB) on top of the 28N+36 algorithmic bytes",
                     "method": f"HIP events around {reps} back-to-back launches, median of 5"}

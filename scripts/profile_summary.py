@@ -146,5 +146,10 @@ if fv:
     if clk_ghz:
         md[-1] += (f"  At the {clk_ghz:.2f} GHz the counters show, the same bound is {4*valu*4/clk_ghz/1e3:.1f} us, i.e. the launch runs at "
                    f"{100*(4*valu*4/clk_ghz/1e3)/fwd_avg_us:.0f} % of it: the kernel is vector-issue bound, and only fewer instructions make it faster.")
+if fv:
+    traffic[f"w8pt_fwd_valu_insts_per_wave_B{B}_N{N}"] = round(valu, 1)
+if clk_ghz:
+    traffic["w8pt_fwd_sustained_clock_ghz"] = round(clk_ghz, 3)
+json.dump(traffic, open(os.path.join(P, "traffic.json"), "w"), indent=1)
 open(os.path.join(P, f"{tag}_rocprof_summary.md"), "w").write("\n".join(md) + "\n")
 print("\n".join(md))
