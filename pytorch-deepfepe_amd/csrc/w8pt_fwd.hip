@@ -102,7 +102,12 @@ __device__ __forceinline__ void halve(double* a, bool upper, int mask) {
   }
 }
 
-template <bool RAW>
+// COOP = false: one wavefront per pair (blocks of 4, 2 or 1 independent wavefronts, no block barrier).
+// COOP = true : one 256-thread workgroup per pair, for N so large that the pair's staging area would leave a CU with
+//   fewer than 16 wavefronts: the four wavefronts share the per-correspondence phases (0, 1, 2, 6), combine their partial
+//   sums through LDS, and wavefront 0 alone runs the eigen phases (3-5) while the others wait at a barrier.
+constexpr int kCoopBytes = 1536;  // COOP: [16] centroid, [8] Hartley, [144] moment partials, [9] f, then 17 floats (max, sum, F)
+template <bool RAW, bool COOP>
 __global__ void __launch_bounds__(256, 4)
 w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, const float* __restrict__ wts,
                 int B, int Bm, int N, int npad, int wave_bytes, float hw_sx, float hw_sy, float clamp_at,
@@ -111,10 +116,12 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
-  const int pair = blockIdx.x * (blockDim.x >> 6) + wave;
-  if (pair >= B) return;  // whole wave leaves; there is no block-level barrier in this kernel
+  const int pair = COOP ? (int)blockIdx.x : (int)(blockIdx.x * (blockDim.x >> 6) + wave);
+  if (!COOP && pair >= B) return;  // whole wave leaves; the per-wavefront variant has no block-level barrier
+  constexpr int NT = COOP ? 256 : WAVE;          // threads that stride over the pair's correspondences
+  const int tid = COOP ? (int)threadIdx.x : lane;
 
-  unsigned char* base = smem + (size_t)wave * wave_bytes;
+  unsigned char* base = COOP ? smem : smem + (size_t)wave * wave_bytes;
   double* M64 = reinterpret_cast<double*>(base);            // [81] X^T X, fp64, natural index order      0..648
   double* SCR = M64 + 81;                                   // [32] exchange scratch for the refinement  648..904
   float* A32 = reinterpret_cast<float*>(base + 904);        // [9][10] Jacobi iterate (position space, row stride 10) 904..1264
@@ -122,6 +129,9 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   float2* CS = reinterpret_cast<float2*>(base + 1624);      // [9]  (c, signed s) per position                      1624..1696
   float* P = reinterpret_cast<float*>(base + kWsDoubles * sizeof(double));
   float* W = P + (RAW ? 4 : 6) * npad;
+  double* RED = reinterpret_cast<double*>(W + npad);         // COOP only: cross-wavefront exchange (kCoopBytes)
+  float* REDF = reinterpret_cast<float*>(RED + 177);
+  auto pair_sync = [&]() { if (COOP) __syncthreads(); else wave_sync(); };
 
   // phase timestamps (shader clock) for the diagnostics slots of the save record
   long long tstamp[8];
@@ -133,7 +143,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   if (RAW) {
     const float4* src = reinterpret_cast<const float4*>(pts1) + mp * N;
   #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-  for (int i = lane; i < N; i += WAVE) {
+  for (int i = tid; i < N; i += NT) {
       float4 m = src[i];
       m.x = fmaf(m.x, hw_sx, -1.0f);
       m.y = fmaf(m.y, hw_sy, -1.0f);
@@ -146,14 +156,14 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   } else {
     const float* s1p = pts1 + mp * N * 3;
     const float* s2p = pts2 + mp * N * 3;
-    for (int t = lane; t < 3 * N; t += WAVE) {
+    for (int t = tid; t < 3 * N; t += NT) {
       P[t] = s1p[t];
       P[3 * npad + t] = s2p[t];
     }
-    for (int i = lane; i < N; i += WAVE) W[i] = wsrc[i];
-    wave_sync();
+    for (int i = tid; i < N; i += NT) W[i] = wsrc[i];
+    pair_sync();
   #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-  for (int i = lane; i < N; i += WAVE) {
+  for (int i = tid; i < N; i += NT) {
       const Pt p = lds_point<false>(P, i, npad);
       sx1 += p.x1; sy1 += p.y1; sx2 += p.x2; sy2 += p.y2;
     }
@@ -162,16 +172,27 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     // fused F.softmax(logits, dim=N) (DeepFNet.py:443,512): W holds the logits at this point
     wave_sync();
     float mx = -INFINITY;
-    for (int i = lane; i < N; i += WAVE) mx = fmaxf(mx, W[i]);
+    for (int i = tid; i < N; i += NT) mx = fmaxf(mx, W[i]);
     mx = wave_max(mx);
+    if (COOP) {
+      if (lane == 0) REDF[wave] = mx;
+      __syncthreads();
+      mx = fmaxf(fmaxf(REDF[0], REDF[1]), fmaxf(REDF[2], REDF[3]));
+    }
     float sm = 0.0f;
-    for (int i = lane; i < N; i += WAVE) {
+    for (int i = tid; i < N; i += NT) {
       const float e = expf(W[i] - mx);
       W[i] = e;
       sm += e;
     }
-    const float inv = 1.0f / wave_sum(sm);
-    for (int i = lane; i < N; i += WAVE) {
+    sm = wave_sum(sm);
+    if (COOP) {
+      if (lane == 0) REDF[4 + wave] = sm;
+      __syncthreads();
+      sm = (REDF[4] + REDF[5]) + (REDF[6] + REDF[7]);
+    }
+    const float inv = 1.0f / sm;
+    for (int i = tid; i < N; i += NT) {
       const float w = W[i] * inv;
       W[i] = w;
       if (weights_out != nullptr) weights_out[(size_t)pair * N + i] = w;
@@ -179,15 +200,24 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   }
   const double invN = 1.0 / (double)N;
   const bool hartley = (variant & DFEPE_W8PT_NO_HARTLEY) == 0;  // wave-uniform
-  const double c1x = hartley ? to_sgpr(wave_sum(sx1) * invN) : 0.0, c1y = hartley ? to_sgpr(wave_sum(sy1) * invN) : 0.0;
-  const double c2x = hartley ? to_sgpr(wave_sum(sx2) * invN) : 0.0, c2y = hartley ? to_sgpr(wave_sum(sy2) * invN) : 0.0;
+  sx1 = wave_sum(sx1); sy1 = wave_sum(sy1); sx2 = wave_sum(sx2); sy2 = wave_sum(sy2);
+  if (COOP) {
+    if (lane == 0) { RED[4 * wave] = sx1; RED[4 * wave + 1] = sy1; RED[4 * wave + 2] = sx2; RED[4 * wave + 3] = sy2; }
+    __syncthreads();
+    sx1 = (RED[0] + RED[4]) + (RED[8] + RED[12]);
+    sy1 = (RED[1] + RED[5]) + (RED[9] + RED[13]);
+    sx2 = (RED[2] + RED[6]) + (RED[10] + RED[14]);
+    sy2 = (RED[3] + RED[7]) + (RED[11] + RED[15]);
+  }
+  const double c1x = hartley ? to_sgpr(sx1 * invN) : 0.0, c1y = hartley ? to_sgpr(sy1 * invN) : 0.0;
+  const double c2x = hartley ? to_sgpr(sx2 * invN) : 0.0, c2y = hartley ? to_sgpr(sy2 * invN) : 0.0;
   wave_sync();
 
   tstamp[1] = __builtin_amdgcn_s_memtime();
   // ---- phase 1: Hartley scale -------------------------------------------------------------------
   double d1 = 0, d2 = 0;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-  for (int i = lane; i < N; i += WAVE) {
+  for (int i = tid; i < N; i += NT) {
     const Pt p = lds_point<RAW>(P, i, npad);
     const double ax = (double)p.x1 - c1x, ay = (double)p.y1 - c1y;
     const double bx = (double)p.x2 - c2x, by = (double)p.y2 - c2y;
@@ -196,8 +226,15 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   }
   // Fit.normalize uses the literal 1.4142, not sqrt(2) (DeepFNet.py:168); utils_F._normalize_XY uses np.sqrt(2)
   const double hscale = (variant & DFEPE_W8PT_SQRT2) ? 1.4142135623730951 : 1.4142;
-  const double s1 = hartley ? to_sgpr(hscale * fast_rcp(wave_sum(d1) * invN)) : 1.0;
-  const double s2 = hartley ? to_sgpr(hscale * fast_rcp(wave_sum(d2) * invN)) : 1.0;
+  d1 = wave_sum(d1); d2 = wave_sum(d2);
+  if (COOP) {
+    if (lane == 0) { RED[16 + 2 * wave] = d1; RED[17 + 2 * wave] = d2; }
+    __syncthreads();
+    d1 = (RED[16] + RED[18]) + (RED[20] + RED[22]);
+    d2 = (RED[17] + RED[19]) + (RED[21] + RED[23]);
+  }
+  const double s1 = hartley ? to_sgpr(hscale * fast_rcp(d1 * invN)) : 1.0;
+  const double s2 = hartley ? to_sgpr(hscale * fast_rcp(d2 * invN)) : 1.0;
 
   tstamp[2] = __builtin_amdgcn_s_memtime();
   // ---- phase 2: X^T X as 36 distinct fp64 sums per lane (exact products of fp32-derived factors) ---------
@@ -205,7 +242,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 #pragma unroll
   for (int e = 0; e < 36; ++e) acc[e] = 0.0;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-  for (int i = lane; i < N; i += WAVE) {
+  for (int i = tid; i < N; i += NT) {
     const Pt p = lds_point<RAW>(P, i, npad);
     const double w = (double)W[i];
     const double z1 = p.z1, z2 = p.z2;
@@ -242,7 +279,12 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
       if (lane & m) { idx += h; cnt -= h; } else { cnt = (cnt < h) ? cnt : h; }
       width = h;
     }
-    if (cnt >= 1) {
+    if (COOP) {  // the four wavefronts' partial sums meet in LDS; wavefront 0 adds them up
+      if (cnt >= 1) RED[24 + 36 * wave + idx] = acc[0];
+      __syncthreads();
+      if (cnt >= 1) acc[0] = (RED[24 + idx] + RED[60 + idx]) + (RED[96 + idx] + RED[132 + idx]);
+    }
+    if (cnt >= 1 && (!COOP || wave == 0)) {
       // sum (u,v) is M[3r+c][3r'+c'] for (r,r') = sym pair u, (c,c') = sym pair v, and its 3 index swaps
       const int u = idx / 6, v = idx % 6;
       const int r0 = kSymR[u], r1 = kSymC[u], q0 = kSymR[v], q1 = kSymC[v];
@@ -255,6 +297,9 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   wave_sync();
 
   tstamp[4] = __builtin_amdgcn_s_memtime();
+  double f[9];   // the solver's eigenvector (unit norm, oriented) and the de-normalised rank-2 F: produced by phases 4-5,
+  float of[9];   // consumed by the per-correspondence outputs of phase 6
+  if (!COOP || wave == 0) {
   // ---- phase 4a: fp32 Jacobi on M / trace(M) ----------------------------------------------------------
   // A' = J^T A J, V' = V J with J_pp = J_qq = c, J_pq = s, J_qp = -s for the pairs (p,q) = (0,1),(2,3),(4,5),(6,7)
   // of *positions*; position 8 sits out.  Per position k we keep (c_k, sh_k), sh_p = -s, sh_q = +s, so that
@@ -363,7 +408,6 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
       if (rank == skip) kmin = k;
     }
   }
-  double f[9];
 #pragma unroll
   for (int c = 0; c < 9; ++c) f[c] = (double)V32[c * 10 + kmin];
   double rho = (double)lam32[kmin] * tr;
@@ -477,7 +521,6 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     out[3 + c] = s2 * Mx[3 + c];
     out[6 + c] = Mx[6 + c] - s2 * (c2x * Mx[c] + c2y * Mx[3 + c]);
   }
-  float of[9];
 #pragma unroll
   for (int c = 0; c < 9; ++c) of[c] = (float)out[c];
   if (lane == 0) {
@@ -519,11 +562,24 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     }
   }
 
+  if (COOP && lane == 0) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { RED[168 + c] = f[c]; REDF[8 + c] = of[c]; }
+  }
+  }  // eigen phases (wavefront 0 of a cooperative workgroup)
+  if (COOP) {
+    __syncthreads();
+    if (wave != 0) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) { f[c] = RED[168 + c]; of[c] = REDF[8 + c]; }
+    }
+  }
+
   // ---- phase 6: per-correspondence outputs ----------------------------------------------------------
   float* rdst = residual + (size_t)pair * N;
   float* edst = (epi_res != nullptr) ? epi_res + (size_t)pair * N : nullptr;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-  for (int i = lane; i < N; i += WAVE) {
+  for (int i = tid; i < N; i += NT) {
     const Pt p = lds_point<RAW>(P, i, npad);
     double ph[9];
     const double w = (double)W[i];
@@ -578,29 +634,34 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
     if (resident >= 16) { waves = wv; break; }
     if (resident > best) { best = resident; waves = wv; }
   }
-  const size_t lds = (size_t)waves * wave_bytes;
+  // Large N and a batch small enough to be resident at once: the per-wavefront variant is then bound by the latency of
+  // ONE wavefront walking all N correspondences four times, so four wavefronts share a pair (measured at N = 1000:
+  // B = 64: 32.5 -> 22.6 us, B = 512: 36.3 -> 27.9 us).  Larger batches keep one wavefront per pair: more pairs are in
+  // flight per CU (7 instead of 4 at N = 1000) and the eigen phases, which one wavefront runs either way, overlap better
+  // (B = 4096: 119 us against 124 us).  1024 = 256 CUs x 4 cooperative workgroups (the VGPR budget allows 16 wavefronts).
+  const bool no_coop = ((flags >> 25) & 1u) != 0;  // undocumented diagnostic: keep one wavefront per pair (timing experiments only)
+  const bool coop = !no_coop && (N >= 256) && (lds_cap / wave_bytes < 16) && (wave_bytes + kCoopBytes <= lds_cap) &&
+                    ((long long)B * n_weight_sets <= 1024);
+  if (coop) waves = 4;
+  const size_t lds = coop ? (size_t)wave_bytes + kCoopBytes : (size_t)waves * wave_bytes;
   const int Bm = B;
-  B *= n_weight_sets;  // one wavefront per (weight set, pair)
-  const dim3 grid((B + waves - 1) / waves), block(64 * waves);
+  B *= n_weight_sets;  // one wavefront (or cooperative workgroup) per (weight set, pair)
+  const dim3 grid(coop ? B : (B + waves - 1) / waves), block(64 * waves);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float hw_sx = raw ? 2.0f / image_w : 0.f, hw_sy = raw ? 2.0f / image_h : 0.f;
-  hipError_t err;
+#define DFEPE_LAUNCH_FWD(R, C)                                                                                              \
+  do {                                                                                                                      \
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&w8pt_fwd_kernel<R, C>),                      \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)          \
+      return DFEPE_ERR_HIP;                                                                                                 \
+    hipLaunchKernelGGL((w8pt_fwd_kernel<R, C>), grid, block, lds, st, pts1, pts2, weights, B, Bm, N, npad, wave_bytes, hw_sx, \
+                       hw_sy, clamp_at, F_out, residual, epi_res, save, weights_out, logits_mode, variant, dbg);            \
+  } while (0)
   if (raw) {
-    if (lds > 64 * 1024) {
-      err = hipFuncSetAttribute(reinterpret_cast<const void*>(&w8pt_fwd_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (err != hipSuccess) return DFEPE_ERR_HIP;
-    }
-    hipLaunchKernelGGL(w8pt_fwd_kernel<true>, grid, block, lds, st, pts1, pts2, weights, B, Bm, N, npad, wave_bytes,
-                       hw_sx, hw_sy, clamp_at, F_out, residual, epi_res, save, weights_out, logits_mode, variant, dbg);
+    if (coop) DFEPE_LAUNCH_FWD(true, true); else DFEPE_LAUNCH_FWD(true, false);
   } else {
-    if (lds > 64 * 1024) {
-      err = hipFuncSetAttribute(reinterpret_cast<const void*>(&w8pt_fwd_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (err != hipSuccess) return DFEPE_ERR_HIP;
-    }
-    hipLaunchKernelGGL(w8pt_fwd_kernel<false>, grid, block, lds, st, pts1, pts2, weights, B, Bm, N, npad, wave_bytes,
-                       hw_sx, hw_sy, clamp_at, F_out, residual, epi_res, save, weights_out, logits_mode, variant, dbg);
+    if (coop) DFEPE_LAUNCH_FWD(false, true); else DFEPE_LAUNCH_FWD(false, false);
   }
+#undef DFEPE_LAUNCH_FWD
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }

@@ -10,7 +10,7 @@ def t(f, n=50):
     for _ in range(n): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1000 / n
-for B, N in ((4096, 100), (4096, 1000), (512, 1000)):
+for B, N in ((4096, 100), (4096, 1000), (512, 1000), (64, 1000), (4096, 512)):
     sc = d.synth.make_scene(B, N, seed=1, outlier_ratio=0.2)
     m = sc["matches_xy_ori"].cuda(); w = torch.softmax(sc["logits_layers"][0], 1).cuda()
     full = t(lambda: d.ops.w8pt_forward(m, None, w, True, 1241., 376., 0.5, True, True))
@@ -20,5 +20,8 @@ for B, N in ((4096, 100), (4096, 1000), (512, 1000)):
             ts = t(lambda: d.ops.w8pt_forward(m, None, w, True, 1241., 376., 0.5, True, True, diag=1 + S))
             tp = t(lambda: d.ops.w8pt_forward(m, None, w, True, 1241., 376., 0.5, True, True, diag=0x100 | (1 + S)))
             print(f"   forced {S} sweeps: no polish {ts:.1f} us, with polish {tp:.1f} us")
+    if N >= 512:
+        nc = t(lambda: d.ops.w8pt_forward(m, None, w, True, 1241., 376., 0.5, True, True, diag=0x200))
+        print(f"   one wavefront per pair (cooperative workgroups off): {nc:.1f} us")
     byts = B * (28 * N + 36)
     print(f"B={B} N={N}: full {full:.1f} us, without Jacobi {nojac:.1f} us  ({B/full:.2f} Mpairs/s, {byts/full/1e3:.1f} GB/s algorithmic)")

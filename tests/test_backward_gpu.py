@@ -201,6 +201,22 @@ def test_layers_batched_launch_is_bit_identical(dfepe):
     assert rc == -3  # DFEPE_ERR_UNSUPPORTED: a point gradient would have to be summed over the sets
 
 
+@pytest.mark.parametrize("N", [448, 600])
+def test_cooperative_workgroup_path_in_the_training_step(dfepe, oracle, N):
+    """N so large that the forward switches to one 256-thread workgroup per pair (four wavefronts share the
+    per-correspondence phases): fused softmax, save record, backward and the layers-batched launch all go through it."""
+    B, depth = 5, 2
+    sc = dfepe.synth.make_scene(B, N, seed=N, outlier_ratio=0.3, depth_layers=depth)
+    dev = dfepe.pipeline.scene_to_device(sc, DEV)
+    ours = dfepe.pipeline.hot_path_step(dev, IMAGE_SIZE, depth, 0.02, qt=True)
+    ref = oracle.hot_path_step({k: v.double() for k, v in sc.items()}, IMAGE_SIZE, depth, 0.02, qt=True, mode="batched")
+    assert abs(ours["loss"].item() - ref["loss"].item()) < 1e-5
+    assert relerr(ours["grad_logits"].cpu().numpy(), ref["grad_logits"].numpy()) < 2e-3
+    b = dfepe.pipeline.hot_path_step(dev, IMAGE_SIZE, depth, 0.02, qt=True, layers_batched=True)
+    for k in ("F_layers", "packed", "grad_logits"):
+        assert torch.equal(ours[k], b[k]), k
+
+
 def test_logits_fused_fit_matches_softmax_then_fit(dfepe):
     B, N = 6, 100
     sc = dfepe.synth.make_scene(B, N, seed=12, outlier_ratio=0.2)
