@@ -212,63 +212,94 @@ geo_misc_kernel(int kind, const float* __restrict__ in0, const float* __restrict
 // ------------------------------------------------------------------------------------------------------
 // cheirality (utils_F._E_to_M_train, utils_F.py:679-763), one wavefront per pair, one correspondence per lane
 // ------------------------------------------------------------------------------------------------------
-// smallest eigenvector of a symmetric 4x4 (the DLT normal matrix) by cyclic Jacobi, fp64, in registers
-__device__ inline void smallest_eigvec4(double* S /*4x4 row-major, symmetric, destroyed*/, double* x) {
-  double V[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) V[k] = (k % 5 == 0) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 10; ++sweep) {
-    double off = 0.0, dg = 0.0;
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (p == q) dg += S[4 * p + q] * S[4 * p + q];
-        else if (p < q) off += S[4 * p + q] * S[4 * p + q];
-      }
-    if (!(off > 1e-30 * dg)) break;
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int q = p + 1; q < 4; ++q) {
-        const double apq = S[4 * p + q];
-        if (apq != 0.0) {
-          // c = cos, s = sin of the Jacobi angle through two rsqrt's: r = 1/hypot(d,b), x = (1+|d| r)/2 = c^2
-          const double d = S[4 * q + q] - S[4 * p + p], b = 2.0 * apq;
-          const double rh = fast_rsqrt(d * d + b * b);
-          const double x = 0.5 + 0.5 * fabs(d) * rh;
-          const double y = fast_rsqrt(x);
-          const double c = x * y, s = copysign(0.5, d) * b * rh * y;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {  // columns
-            const double skp = S[4 * k + p], skq = S[4 * k + q];
-            S[4 * k + p] = c * skp - s * skq;
-            S[4 * k + q] = s * skp + c * skq;
-            const double vkp = V[4 * k + p], vkq = V[4 * k + q];
-            V[4 * k + p] = c * vkp - s * vkq;
-            V[4 * k + q] = s * vkp + c * vkq;
-          }
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {  // rows
-            const double spk = S[4 * p + k], sqk = S[4 * q + k];
-            S[4 * p + k] = c * spk - s * sqk;
-            S[4 * q + k] = s * spk + c * sqk;
-          }
-        }
-      }
+// Smallest eigenvector of a symmetric positive semi-definite 4x4 (the DLT normal matrix A^T A), fp64, in registers:
+//   two Householder reflections -> tridiagonal T;  Laguerre's iteration from lam = 0 on det(T - lam I) through the
+//   three-term recurrence (for a real-rooted polynomial it climbs monotonically to the smallest root from below, cubic
+//   rate, and does not care whether the outliers' lam4 / lam3 is 1e-7 or 0.9: <= 6 steps on DLT matrices);
+//   eigenvector of T by a twisted factorisation (pivot where |gamma_r| is smallest);  back-transformation.
+// ~6x fewer instructions than the 6-7 cyclic Jacobi sweeps this replaces, same accuracy: scripts/proto_eig4.py checks
+// the algorithm against numpy.linalg.eigh on 16 000 DLT matrices with 25 % outliers (eigenvalue error 7e-16 lam_max,
+// eigenvector error x gap 7e-16, no cheirality decision changed).
+__device__ __forceinline__ double guard_piv(double z, double tiny) { return (fabs(z) < tiny) ? ((z < 0.0) ? -tiny : tiny) : z; }
+
+__device__ inline void smallest_eigvec4(const double* S /*4x4 row-major, symmetric*/, double* x) {
+  // ---- Householder 1 on (S10, S20, S30)
+  const double a0 = S[4], a1 = S[8], a2 = S[12];
+  const double alpha = (a0 < 0.0) ? fast_sqrt(a0 * a0 + a1 * a1 + a2 * a2) : -fast_sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+  const double v0 = a0 - alpha, v1 = a1, v2 = a2;
+  const double vv = v0 * v0 + v1 * v1 + v2 * v2;
+  const bool ok1 = vv > 0.0;
+  const double beta = ok1 ? 2.0 * fast_rcp(vv) : 0.0;
+  const double p0 = beta * (S[5] * v0 + S[6] * v1 + S[7] * v2);
+  const double p1 = beta * (S[6] * v0 + S[10] * v1 + S[11] * v2);
+  const double p2 = beta * (S[7] * v0 + S[11] * v1 + S[15] * v2);
+  const double kc = 0.5 * beta * (p0 * v0 + p1 * v1 + p2 * v2);
+  const double q0 = p0 - kc * v0, q1 = p1 - kc * v1, q2 = p2 - kc * v2;
+  const double B00 = S[5] - 2.0 * v0 * q0;
+  const double B01 = S[6] - v0 * q1 - q0 * v1, B02 = S[7] - v0 * q2 - q0 * v2;
+  const double B11 = S[10] - 2.0 * v1 * q1, B12 = S[11] - v1 * q2 - q1 * v2, B22 = S[15] - 2.0 * v2 * q2;
+  // ---- Householder 2 on (B10, B20)
+  const double alpha2 = (B01 < 0.0) ? fast_sqrt(B01 * B01 + B02 * B02) : -fast_sqrt(B01 * B01 + B02 * B02);
+  const double w0 = B01 - alpha2, w1 = B02;
+  const double ww = w0 * w0 + w1 * w1;
+  const bool ok2 = ww > 0.0;
+  const double beta2 = ok2 ? 2.0 * fast_rcp(ww) : 0.0;
+  const double r0 = beta2 * (B11 * w0 + B12 * w1), r1 = beta2 * (B12 * w0 + B22 * w1);
+  const double k2 = 0.5 * beta2 * (r0 * w0 + r1 * w1);
+  const double s0 = r0 - k2 * w0, s1 = r1 - k2 * w1;
+  const double d0 = S[0], d1 = B00, d2 = B11 - 2.0 * w0 * s0, d3 = B22 - 2.0 * w1 * s1;
+  const double e0 = ok1 ? alpha : a0, e1 = ok2 ? alpha2 : B01, e2 = B12 - w0 * s1 - s0 * w1;
+  const double f0 = e0 * e0, f1 = e1 * e1, f2 = e2 * e2;
+  const double scale = fmax(fmax(fabs(d0), fabs(d1)), fmax(fabs(d2), fabs(d3))) + fmax(fabs(e0), fmax(fabs(e1), fabs(e2)));
+  // ---- Laguerre from below (all roots are >= 0: the start lam = 0 is left of, or on, the smallest one)
+  double lam = 0.0;
+  bool done = false;
+  for (int it = 0; it < 12; ++it) {
+    const double c0 = d0 - lam, c1 = d1 - lam, c2 = d2 - lam, c3 = d3 - lam;
+    // p_k = c_k p_{k-1} - f_{k-1} p_{k-2} and its first two derivatives with respect to lam
+    const double P2 = c1 * c0 - f0, D2 = -c1 - c0, E2 = 2.0;
+    const double P3 = c2 * P2 - f1 * c0, D3 = c2 * D2 - P2 + f1, E3 = c2 * E2 - 2.0 * D2;
+    const double P4 = c3 * P3 - f2 * P2, D4 = c3 * D3 - P3 - f2 * D2, E4 = c3 * E3 - 2.0 * D3 - f2 * E2;
+    const bool good = (P4 > 0.0) && !done;  // p <= 0: on the root (or past it by round-off)
+    const double ip = good ? fast_rcp(P4) : 0.0;
+    const double G = D4 * ip, H = G * G - E4 * ip;
+    const double den = G - fast_sqrt(fmax(3.0 * (4.0 * H - G * G), 0.0));  // G < 0 left of the smallest root
+    const double step = (good && den < 0.0) ? -4.0 * fast_rcp(den) : 0.0;
+    const double nl = lam + step;
+    done = done || !good || !(step > 1e-16 * scale) || (nl == lam);
+    if (!done) lam = nl;
+    if (__ballot(!done) == 0ull) break;  // wave-uniform exit
   }
-  int km = 0;
-  double lm = S[0];
-#pragma unroll
-  for (int k = 1; k < 4; ++k)
-    if (S[5 * k] < lm) { lm = S[5 * k]; km = k; }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    double v = V[4 * r];
-#pragma unroll
-    for (int k = 1; k < 4; ++k) v = (km == k) ? V[4 * r + k] : v;
-    x[r] = v;
-  }
+  // ---- twisted factorisation of T - lam: forward pivots dp, backward pivots dm, gamma_r = dp_r + dm_r - (d_r - lam)
+  const double tiny = 1e-300 + 1e-30 * scale;
+  const double c0 = d0 - lam, c1 = d1 - lam, c2 = d2 - lam, c3 = d3 - lam;
+  const double dp0 = c0;
+  const double i0 = fast_rcp(guard_piv(dp0, tiny)), dp1 = c1 - f0 * i0;
+  const double i1 = fast_rcp(guard_piv(dp1, tiny)), dp2 = c2 - f1 * i1;
+  const double i2 = fast_rcp(guard_piv(dp2, tiny)), dp3 = c3 - f2 * i2;
+  const double dm3 = c3;
+  const double j3 = fast_rcp(guard_piv(dm3, tiny)), dm2 = c2 - f2 * j3;
+  const double j2 = fast_rcp(guard_piv(dm2, tiny)), dm1 = c1 - f1 * j2;
+  const double j1 = fast_rcp(guard_piv(dm1, tiny)), dm0 = c0 - f0 * j1;
+  const double g0 = fabs(dm0), g1 = fabs(dp1 + dm1 - c1), g2 = fabs(dp2 + dm2 - c2), g3 = fabs(dp3);
+  int r = 0;
+  double gm = g0;
+  if (g1 < gm) { gm = g1; r = 1; }
+  if (g2 < gm) { gm = g2; r = 2; }
+  if (g3 < gm) { gm = g3; r = 3; }
+  // y_k / y_{k+1} = u_k above the twist, y_k / y_{k-1} = l_k below it
+  const double u0 = -e0 * i0, u1 = -e1 * i1, u2 = -e2 * i2;
+  const double l1 = -e0 * j1, l2 = -e1 * j2, l3 = -e2 * j3;
+  double y0 = (r == 0) ? 1.0 : ((r == 1) ? u0 : ((r == 2) ? u0 * u1 : u0 * u1 * u2));
+  double y1 = (r == 0) ? l1 : ((r == 1) ? 1.0 : ((r == 2) ? u1 : u1 * u2));
+  double y2 = (r == 0) ? l1 * l2 : ((r == 1) ? l2 : ((r == 2) ? 1.0 : u2));
+  double y3 = (r == 0) ? l1 * l2 * l3 : ((r == 1) ? l2 * l3 : ((r == 2) ? l3 : 1.0));
+  // ---- back-transformation x = H1 H2 y
+  const double t2 = beta2 * (w0 * y2 + w1 * y3);
+  y2 -= t2 * w0; y3 -= t2 * w1;
+  const double t1 = beta * (v0 * y1 + v1 * y2 + v2 * y3);
+  y1 -= t1 * v0; y2 -= t1 * v1; y3 -= t1 * v2;
+  x[0] = y0; x[1] = y1; x[2] = y2; x[3] = y3;  // not normalised: the caller only uses ratios
 }
 
 __global__ void __launch_bounds__(256)
