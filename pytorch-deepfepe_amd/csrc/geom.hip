@@ -210,7 +210,7 @@ geo_misc_kernel(int kind, const float* __restrict__ in0, const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------------
-// cheirality (utils_F._E_to_M_train, utils_F.py:679-763), one wavefront per pair, one correspondence per lane
+// cheirality (utils_F._E_to_M_train, utils_F.py:679-763), one workgroup (4 wavefronts) per pair, one correspondence per lane
 // ------------------------------------------------------------------------------------------------------
 // Smallest eigenvector of a symmetric positive semi-definite 4x4 (the DLT normal matrix A^T A), fp64, in registers:
 //   two Householder reflections -> tridiagonal T;  Laguerre's iteration from lam = 0 on det(T - lam I) through the
@@ -305,9 +305,11 @@ __device__ inline void smallest_eigvec4(const double* S /*4x4 row-major, symmetr
 __global__ void __launch_bounds__(256)
 cheirality_kernel(const float* __restrict__ E, const float* __restrict__ K, const float* __restrict__ matches, int B, int N,
                   float depth_thres, float* __restrict__ Rt_cam, int* __restrict__ winner, int* __restrict__ counts) {
+  // one workgroup per pair; with 256 threads the four wavefronts take every fourth group of 64 correspondences and meet in LDS
+  __shared__ int wcnt[4][4];
   const int lane = threadIdx.x & 63;
-  const size_t pair = (size_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
-  if (pair >= (size_t)B) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
+  const size_t pair = blockIdx.x;
   double Ed[9], Kd[9], R[2][9], t[3];
 #pragma unroll
   for (int k = 0; k < 9; ++k) { Ed[k] = (double)E[pair * 9 + k]; Kd[k] = to_sgpr((double)K[pair * 9 + k]); }
@@ -318,7 +320,8 @@ cheirality_kernel(const float* __restrict__ E, const float* __restrict__ K, cons
 #pragma unroll
   for (int k = 0; k < 3; ++k) t[k] = to_sgpr(t[k]);
   int cnt[4] = {0, 0, 0, 0};
-  for (int base = 0; base < N; base += WAVE) {
+  const int nw = blockDim.x >> 6;  // 4 wavefronts per pair for small batches (latency), 1 for large ones (throughput)
+  for (int base = wave * WAVE; base < N; base += nw * WAVE) {
     const int i = base + lane;
     const bool live = i < N;
     float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -362,6 +365,16 @@ cheirality_kernel(const float* __restrict__ E, const float* __restrict__ K, cons
       cnt[2 * rr] += __popcll(__ballot(pos));
       cnt[2 * rr + 1] += __popcll(__ballot(neg));
     }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wcnt[wave][c] = cnt[c];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  if (nw > 1) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) cnt[c] = (wcnt[0][c] + wcnt[1][c]) + (wcnt[2][c] + wcnt[3][c]);
   }
   int win = 0;
 #pragma unroll
@@ -434,7 +447,7 @@ extern "C" int dfepe_cheirality(const float* E, const float* K, const float* mat
   if (B == 0) return DFEPE_OK;
   if (!E || !K || !matches || !Rt_cam) return DFEPE_ERR_INVALID_ARG;
   if (reinterpret_cast<uintptr_t>(matches) & 15u) return DFEPE_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(cheirality_kernel, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), E, K, matches, B, N,
+  hipLaunchKernelGGL(cheirality_kernel, dim3(B), dim3(B >= 2048 ? 64 : 256), 0, static_cast<hipStream_t>(stream), E, K, matches, B, N,
                      depth_thres, Rt_cam, winner, counts);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
