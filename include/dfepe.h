@@ -194,6 +194,9 @@ int dfepe_epi_residual_bwd(const float *pts1, const float *pts2, const float *F,
  *                                                                                   Train_model_pipeline.py:954-964)
  *   kind 4  four-fold decomposition         in0 = E [n,9]              out [n,21] = R1[9] R2[9] t[3]
  *                                                                                  (utils_F._get_M2s, utils_F.py:478-498)
+ *   kind 5  congruence A^T F A              in0 = F [n,9], in1 = A [n,9] out [n,9]  (E = K^T T2^T F T1 K with A = T K when
+ *                                                                                   T1 = T2: train_good_utils.py:356-358,366-369;
+ *                                                                                   utils_F._F_to_E's K^T F K, utils_F.py:456)
  */
 int dfepe_geo_misc(int kind, const float *in0, const float *in1, int n, float *out, void *stream);
 

@@ -197,6 +197,14 @@ geo_misc_kernel(int kind, const float* __restrict__ in0, const float* __restrict
       for (int c = 0; c < 3; ++c) Ed[3 * r + c] = U[3 * r] * V[3 * c] + U[3 * r + 1] * V[3 * c + 1];
 #pragma unroll
     for (int k = 0; k < 9; ++k) out[i * 9 + k] = (float)Ed[k];
+  } else if (kind == 5) {
+    double F[9], A[9], tmp[9], E[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { F[k] = (double)in0[i * 9 + k]; A[k] = (double)in1[i * 9 + k]; }
+    mat3_mul_tn(A, F, tmp);
+    mat3_mul(tmp, A, E);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out[i * 9 + k] = (float)E[k];
   } else {
     double E[9], R1[9], R2[9], t[3];
 #pragma unroll
@@ -434,9 +442,9 @@ extern "C" int dfepe_epi_metrics(int kind, const float* F, const float* X, const
 }
 
 extern "C" int dfepe_geo_misc(int kind, const float* in0, const float* in1, int n, float* out, void* stream) {
-  if (kind < 0 || kind > 4 || n < 0) return DFEPE_ERR_INVALID_ARG;
+  if (kind < 0 || kind > 5 || n < 0) return DFEPE_ERR_INVALID_ARG;
   if (n == 0) return DFEPE_OK;
-  if (!in0 || !out || ((kind == 1 || kind == 2) && !in1)) return DFEPE_ERR_INVALID_ARG;
+  if (!in0 || !out || ((kind == 1 || kind == 2 || kind == 5) && !in1)) return DFEPE_ERR_INVALID_ARG;
   hipLaunchKernelGGL(geo_misc_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), kind, in0, in1, n, out);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }

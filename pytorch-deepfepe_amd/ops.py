@@ -305,7 +305,7 @@ def epi_metrics(kind: int, F: Tensor, X: Tensor, Y: Tensor, clamp_at: float = 0.
     return out
 
 
-_GEO_OUT = {0: 4, 1: 1, 2: 1, 3: 9, 4: 21}
+_GEO_OUT = {0: 4, 1: 1, 2: 1, 3: 9, 4: 21, 5: 9}
 
 
 def geo_misc(kind: int, in0: Tensor, in1: Optional[Tensor] = None) -> Tensor:
@@ -333,6 +333,11 @@ def vector_angle_deg(v1: Tensor, v2: Tensor) -> Tensor:
 
 def project_essential(E: Tensor) -> Tensor:
     return geo_misc(3, E.reshape(-1, 9)).reshape(-1, 3, 3)
+
+
+def congruence(F: Tensor, A: Tensor) -> Tensor:
+    """A^T F A for batches of 3x3 matrices: E = K^T T^T F T K with A = T K (train_good_utils.py:356-358), or K^T F K."""
+    return geo_misc(5, F.reshape(-1, 9), A.reshape(-1, 9)).reshape(-1, 3, 3)
 
 
 def decompose_essential(E: Tensor):

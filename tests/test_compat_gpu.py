@@ -178,6 +178,9 @@ def test_dsac_tools_functions_match_reference_golden(dfepe, oracle, golden):
     assert np.abs(a - r).max() < 5e-4
     E1 = uF._E_from_XY(x1[0], x2[0], K)
     assert (Eb[0] + E1).abs().max().item() < 1e-6  # the batched reference function returns the negated matrix (utils_F.py:221)
+    Fb, Ab = T(g["E_in"]).to(DEV), (K.expand(8, 3, 3) + torch.arange(8, device=DEV).float().reshape(8, 1, 1) * 1e-3).contiguous()
+    np.testing.assert_allclose(dfepe.ops.congruence(Fb, Ab).cpu().numpy(),
+                               (Ab.double().transpose(1, 2) @ Fb.double() @ Ab.double()).cpu().numpy(), rtol=1e-6, atol=1e-6 * float(Ab.abs().max()) ** 2)
     Rs, ts = uF._get_M2s_batch(T(g["E_in"]).to(DEV))
     assert Rs[0].shape == (8, 3, 3) and ts[0].shape == (8, 3, 1) and (ts[0] + ts[1]).abs().max().item() == 0.0
     d3, d1, d2 = uF.epi_distance_np(g["F_in"][0], g["x1"][0], g["x2"][0])
