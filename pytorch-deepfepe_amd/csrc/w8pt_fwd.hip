@@ -102,12 +102,12 @@ __device__ __forceinline__ void halve(double* a, bool upper, int mask) {
   }
 }
 
-// COOP = false: one wavefront per pair (blocks of 4, 2 or 1 independent wavefronts, no block barrier).
-// COOP = true : one 256-thread workgroup per pair, for N so large that the pair's staging area would leave a CU with
-//   fewer than 16 wavefronts: the four wavefronts share the per-correspondence phases (0, 1, 2, 6), combine their partial
-//   sums through LDS, and wavefront 0 alone runs the eigen phases (3-5) while the others wait at a barrier.
+// WPP (wavefronts per pair) = 1: one wavefront per pair (blocks of 4, 2 or 1 independent wavefronts, no block barrier).
+// WPP = 2 or 4: one cooperative workgroup per pair, for N so large that the pair's staging area leaves a CU with few
+//   wavefronts: the wavefronts share the per-correspondence phases (0, 1, 2, 6), combine their partial sums through LDS,
+//   and wavefront 0 alone runs the eigen phases (3-5) while the others wait at a barrier.
 constexpr int kCoopBytes = 1536;  // COOP: [16] centroid, [8] Hartley, [144] moment partials, [9] f, then 17 floats (max, sum, F)
-template <bool RAW, bool COOP>
+template <bool RAW, int WPP>
 __global__ void __launch_bounds__(256, 4)
 w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, const float* __restrict__ wts,
                 int B, int Bm, int N, int npad, int wave_bytes, float hw_sx, float hw_sy, float clamp_at,
@@ -116,9 +116,10 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
+  constexpr bool COOP = WPP > 1;
   const int pair = COOP ? (int)blockIdx.x : (int)(blockIdx.x * (blockDim.x >> 6) + wave);
   if (!COOP && pair >= B) return;  // whole wave leaves; the per-wavefront variant has no block-level barrier
-  constexpr int NT = COOP ? 256 : WAVE;          // threads that stride over the pair's correspondences
+  constexpr int NT = WPP * WAVE;                 // threads that stride over the pair's correspondences
   const int tid = COOP ? (int)threadIdx.x : lane;
 
   unsigned char* base = COOP ? smem : smem + (size_t)wave * wave_bytes;
@@ -177,7 +178,9 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     if (COOP) {
       if (lane == 0) REDF[wave] = mx;
       __syncthreads();
-      mx = fmaxf(fmaxf(REDF[0], REDF[1]), fmaxf(REDF[2], REDF[3]));
+      mx = REDF[0];
+#pragma unroll
+      for (int k = 1; k < WPP; ++k) mx = fmaxf(mx, REDF[k]);
     }
     float sm = 0.0f;
     for (int i = tid; i < N; i += NT) {
@@ -189,7 +192,9 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     if (COOP) {
       if (lane == 0) REDF[4 + wave] = sm;
       __syncthreads();
-      sm = (REDF[4] + REDF[5]) + (REDF[6] + REDF[7]);
+      sm = REDF[4];
+#pragma unroll
+      for (int k = 1; k < WPP; ++k) sm += REDF[4 + k];
     }
     const float inv = 1.0f / sm;
     for (int i = tid; i < N; i += NT) {
@@ -204,10 +209,9 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   if (COOP) {
     if (lane == 0) { RED[4 * wave] = sx1; RED[4 * wave + 1] = sy1; RED[4 * wave + 2] = sx2; RED[4 * wave + 3] = sy2; }
     __syncthreads();
-    sx1 = (RED[0] + RED[4]) + (RED[8] + RED[12]);
-    sy1 = (RED[1] + RED[5]) + (RED[9] + RED[13]);
-    sx2 = (RED[2] + RED[6]) + (RED[10] + RED[14]);
-    sy2 = (RED[3] + RED[7]) + (RED[11] + RED[15]);
+    sx1 = RED[0]; sy1 = RED[1]; sx2 = RED[2]; sy2 = RED[3];
+#pragma unroll
+    for (int k = 1; k < WPP; ++k) { sx1 += RED[4 * k]; sy1 += RED[4 * k + 1]; sx2 += RED[4 * k + 2]; sy2 += RED[4 * k + 3]; }
   }
   const double c1x = hartley ? to_sgpr(sx1 * invN) : 0.0, c1y = hartley ? to_sgpr(sy1 * invN) : 0.0;
   const double c2x = hartley ? to_sgpr(sx2 * invN) : 0.0, c2y = hartley ? to_sgpr(sy2 * invN) : 0.0;
@@ -230,8 +234,9 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   if (COOP) {
     if (lane == 0) { RED[16 + 2 * wave] = d1; RED[17 + 2 * wave] = d2; }
     __syncthreads();
-    d1 = (RED[16] + RED[18]) + (RED[20] + RED[22]);
-    d2 = (RED[17] + RED[19]) + (RED[21] + RED[23]);
+    d1 = RED[16]; d2 = RED[17];
+#pragma unroll
+    for (int k = 1; k < WPP; ++k) { d1 += RED[16 + 2 * k]; d2 += RED[17 + 2 * k]; }
   }
   const double s1 = hartley ? to_sgpr(hscale * fast_rcp(d1 * invN)) : 1.0;
   const double s2 = hartley ? to_sgpr(hscale * fast_rcp(d2 * invN)) : 1.0;
@@ -282,7 +287,12 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     if (COOP) {  // the four wavefronts' partial sums meet in LDS; wavefront 0 adds them up
       if (cnt >= 1) RED[24 + 36 * wave + idx] = acc[0];
       __syncthreads();
-      if (cnt >= 1) acc[0] = (RED[24 + idx] + RED[60 + idx]) + (RED[96 + idx] + RED[132 + idx]);
+      if (cnt >= 1) {
+        double tot = RED[24 + idx];
+#pragma unroll
+        for (int k = 1; k < WPP; ++k) tot += RED[24 + 36 * k + idx];
+        acc[0] = tot;
+      }
     }
     if (cnt >= 1 && (!COOP || wave == 0)) {
       // sum (u,v) is M[3r+c][3r'+c'] for (r,r') = sym pair u, (c,c') = sym pair v, and its 3 index swaps
@@ -634,15 +644,21 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
     if (resident >= 16) { waves = wv; break; }
     if (resident > best) { best = resident; waves = wv; }
   }
-  // Large N and a batch small enough to be resident at once: the per-wavefront variant is then bound by the latency of
-  // ONE wavefront walking all N correspondences four times, so four wavefronts share a pair (measured at N = 1000:
-  // B = 64: 32.5 -> 22.6 us, B = 512: 36.3 -> 27.9 us).  Larger batches keep one wavefront per pair: more pairs are in
-  // flight per CU (7 instead of 4 at N = 1000) and the eigen phases, which one wavefront runs either way, overlap better
-  // (B = 4096: 119 us against 124 us).  1024 = 256 CUs x 4 cooperative workgroups (the VGPR budget allows 16 wavefronts).
-  const bool no_coop = ((flags >> 25) & 1u) != 0;  // undocumented diagnostic: keep one wavefront per pair (timing experiments only)
-  const bool coop = !no_coop && (N >= 256) && (lds_cap / wave_bytes < 16) && (wave_bytes + kCoopBytes <= lds_cap) &&
-                    ((long long)B * n_weight_sets <= 1024);
-  if (coop) waves = 4;
+  // Large N: the staging area limits the per-wavefront variant to few wavefronts per CU (7 at N = 1000, 3 at N = 2000),
+  // each of which walks all N correspondences four times.  A cooperative workgroup per pair shares those walks between
+  // 2 or 4 wavefronts: the smallest count that puts >= 12 wavefronts on a CU (measured, B = 4096: N = 768 96 -> 89 us,
+  // N = 1000 126 -> 110 us, N = 2000 336 -> 182 us), and 4 whenever the batch fits in one residency round of cooperative
+  // workgroups (1024 = 256 CUs x 4; only latency matters then: N = 1000, B = 512: 37 -> 28 us).
+  const unsigned force_wpp = (flags >> 25) & 3u;  // undocumented diagnostic: 1, 2 -> 2, 3 -> 4 wavefronts per pair
+  const bool can_coop = (N >= 256) && (wave_bytes + kCoopBytes <= lds_cap);
+  const int blocks_coop = can_coop ? lds_cap / (wave_bytes + kCoopBytes) : 0;
+  int wpp = 1;
+  if (can_coop && lds_cap / wave_bytes < 12) wpp = (2 * blocks_coop >= 12) ? 2 : 4;
+  if (can_coop && lds_cap / wave_bytes < 16 && (long long)B * n_weight_sets <= 1024) wpp = 4;
+  if (force_wpp) wpp = (force_wpp == 1) ? 1 : ((force_wpp == 2) ? 2 : 4);
+  if (wpp > 1 && wave_bytes + kCoopBytes > lds_cap) wpp = 1;
+  const bool coop = wpp > 1;
+  if (coop) waves = wpp;
   const size_t lds = coop ? (size_t)wave_bytes + kCoopBytes : (size_t)waves * wave_bytes;
   const int Bm = B;
   B *= n_weight_sets;  // one wavefront (or cooperative workgroup) per (weight set, pair)
@@ -658,9 +674,9 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
                        hw_sy, clamp_at, F_out, residual, epi_res, save, weights_out, logits_mode, variant, dbg);            \
   } while (0)
   if (raw) {
-    if (coop) DFEPE_LAUNCH_FWD(true, true); else DFEPE_LAUNCH_FWD(true, false);
+    if (wpp == 4) DFEPE_LAUNCH_FWD(true, 4); else if (wpp == 2) DFEPE_LAUNCH_FWD(true, 2); else DFEPE_LAUNCH_FWD(true, 1);
   } else {
-    if (coop) DFEPE_LAUNCH_FWD(false, true); else DFEPE_LAUNCH_FWD(false, false);
+    if (wpp == 4) DFEPE_LAUNCH_FWD(false, 4); else if (wpp == 2) DFEPE_LAUNCH_FWD(false, 2); else DFEPE_LAUNCH_FWD(false, 1);
   }
 #undef DFEPE_LAUNCH_FWD
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
