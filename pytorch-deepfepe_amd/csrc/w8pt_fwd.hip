@@ -65,8 +65,9 @@ constexpr JacTable make_jac_table() {
 }
 __constant__ JacTable kJac = make_jac_table();
 
-constexpr int kWsDoubles = 216;  // per-wave workspace in LDS (1728 B, 16-B multiple): see the carve in the kernel
-constexpr int kMaxSweeps = 5;  // quadratic convergence: 4-5 sweeps reach fp32 round-off; stragglers are finished by the fp64 polish
+constexpr int kWsDoubles = 224;  // per-wave workspace in LDS (1792 B, 16-B multiple): see the carve in the kernel
+constexpr float kClusterTol = 4e-6f;  // fp32 Jacobi eigenvalues (unit trace) closer than this to the selected one are re-resolved in fp64
+constexpr int kMaxSweeps = 8;  // quadratic convergence: 4-5 sweeps reach fp32 round-off; stragglers are finished by the fp64 polish
 constexpr float kJacobiTol = 1e-13f;  // fp32 sweeps stop when off(A)^2 <= tol (A is scaled to unit trace)
 constexpr int kRefineIters = 12;  // upper bound; the loop leaves as soon as the fp64 residual is at round-off level
 
@@ -128,6 +129,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   float* A32 = reinterpret_cast<float*>(base + 904);        // [9][10] Jacobi iterate (position space, row stride 10) 904..1264
   float* V32 = A32 + 90;                                    // [9][10] accumulated rotations                        1264..1624
   float2* CS = reinterpret_cast<float2*>(base + 1624);      // [9]  (c, signed s) per position                      1624..1696
+  double* LAMC = reinterpret_cast<double*>(base + 1696);    // [9]  eigenvalues in fp64 (Ritz values of the stored vectors) 1696..1768
   float* P = reinterpret_cast<float*>(base + kWsDoubles * sizeof(double));
   float* W = P + (RAW ? 4 : 6) * npad;
   double* RED = reinterpret_cast<double*>(W + npad);         // COOP only: cross-wavefront exchange (kCoopBytes)
@@ -402,14 +404,16 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   float lam32[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) lam32[k] = A32[k * 11];
+  if (lane < 9) LAMC[lane] = (double)A32[lane * 11] * tr;
+  const int skip = (N >= 9) ? 0 : 9 - N;
   int kmin = 0;
+  // provisional choice from the fp32 eigenvalues: rank `skip` in ascending order (index as tie-break)
   if (N >= 9) {  // the usual case: plain arg-min (first index on ties)
     float lmin = lam32[0];
 #pragma unroll
     for (int k = 1; k < 9; ++k)
       if (lam32[k] < lmin) { lmin = lam32[k]; kmin = k; }
   } else {       // wave-uniform branch: rank selection, skipping the 9 - N null directions
-    const int skip = 9 - N;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       int rank = 0;
@@ -418,9 +422,130 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
       if (rank == skip) kmin = k;
     }
   }
+  // The fp32 sweeps ran on X^T X, so eigenvalues closer than ~1e-6 trace -- singular values of X below ~1e-3 sigma_1,
+  // which LAPACK's SVD of X (the reference) still tells apart -- come out in arbitrary order with arbitrarily mixed
+  // vectors.  Members of such a cluster around the selected eigenvalue are re-resolved by Rayleigh-Ritz in fp64 against the
+  // exact M64: cyclic Jacobi on H = Qc^T M Qc, rotating the stored (fp32) vectors; their Ritz values are good to
+  // ~1e-14 trace, i.e. the resolution of an fp32 SVD of X.  Rare (peaked weights, near-minimal or near-planar sets);
+  // the usual case is a cluster of one and costs two dozen instructions.
+  float lsel = lam32[0];
+#pragma unroll
+  for (int k = 1; k < 9; ++k) lsel = (k == kmin) ? lam32[k] : lsel;
+  unsigned cmask = 0;
+  int below = 0;  // eigenvalues clearly below the cluster (only possible for N < 9)
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const bool in = fabsf(lam32[k] - lsel) < kClusterTol;
+    cmask |= in ? (1u << k) : 0u;
+    below += (!in && lam32[k] < lsel) ? 1 : 0;
+  }
+  wave_sync();
+  if (__popc(cmask) > 1) {  // wave-uniform
+    const double floor_h = 1e-16 * tr;
+    // purify the cluster vectors first: remove what the fp32 sweeps left in them of the directions OUTSIDE the cluster
+    // (one residual-correction step against the well-separated eigenpairs; afterwards only fp32 storage error remains)
+    for (int i = 0; i < 9; ++i) {
+      if (!((cmask >> i) & 1u)) continue;
+      if (lane < 9) {
+        double yi = 0.0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) yi += M64[lane * 9 + c] * (double)V32[c * 10 + i];
+        SCR[lane] = yi;
+      }
+      wave_sync();
+      double hii = 0.0, rr[9];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) hii += (double)V32[c * 10 + i] * SCR[c];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) rr[c] = SCR[c] - hii * (double)V32[c * 10 + i];
+      if (lane < 9) {
+        double dot = 0.0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) dot += (double)V32[c * 10 + lane] * rr[c];
+        const double den = hii - LAMC[lane];
+        SCR[16 + lane] = (((cmask >> lane) & 1u) || !(fabs(den) > 1e-7 * tr)) ? 0.0 : dot / den;
+      }
+      wave_sync();
+      if (lane < 9) {
+        double dsum = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dsum += SCR[16 + k] * (double)V32[lane * 10 + k];
+        SCR[lane] = (double)V32[lane * 10 + i] + dsum;
+      }
+      wave_sync();
+      double nn = 0.0;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) nn += SCR[c] * SCR[c];
+      const double inn = 1.0 / sqrt(nn);
+      if (lane < 9) V32[lane * 10 + i] = (float)(SCR[lane] * inn);
+      wave_sync();
+    }
+    for (int sw = 0; sw < 6; ++sw) {
+      bool rotated = false;
+      for (int i = 0; i < 8; ++i) {
+        if (!((cmask >> i) & 1u)) continue;
+        for (int j = i + 1; j < 9; ++j) {
+          if (!((cmask >> j) & 1u)) continue;
+          // y_i = M q_i, y_j = M q_j: one row per lane
+          if (lane < 9) {
+            double yi = 0.0, yj = 0.0;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+              const double mc = M64[lane * 9 + c];
+              yi += mc * (double)V32[c * 10 + i];
+              yj += mc * (double)V32[c * 10 + j];
+            }
+            SCR[lane] = yi;
+            SCR[16 + lane] = yj;
+          }
+          wave_sync();
+          double hii = 0.0, hjj = 0.0, hij = 0.0;
+#pragma unroll
+          for (int c = 0; c < 9; ++c) {
+            const double qi = (double)V32[c * 10 + i], qj = (double)V32[c * 10 + j];
+            hii += qi * SCR[c];
+            hjj += qj * SCR[16 + c];
+            hij += qi * SCR[16 + c];
+          }
+          const double dlt = hjj - hii;
+          if (fabs(hij) > floor_h && fabs(hij) > 1e-7 * fabs(dlt)) {
+            const double tau = dlt / (2.0 * hij);
+            const double t = ((tau >= 0.0) ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+            const double cs = 1.0 / sqrt(1.0 + t * t), sn = t * cs;
+            if (lane < 9) {
+              const double qi = (double)V32[lane * 10 + i], qj = (double)V32[lane * 10 + j];
+              V32[lane * 10 + i] = (float)(cs * qi - sn * qj);
+              V32[lane * 10 + j] = (float)(sn * qi + cs * qj);
+            }
+            hii -= t * hij;
+            hjj += t * hij;
+            rotated = true;
+          }
+          if (lane == 0) { LAMC[i] = hii; LAMC[j] = hjj; }
+          wave_sync();
+        }
+      }
+      if (!rotated) break;
+    }
+    // final choice inside the cluster: rank (skip - below) among its members by the fp64 Ritz values
+    const int want = skip - below;
+    int pick = kmin;
+    for (int k = 0; k < 9; ++k) {
+      if (!((cmask >> k) & 1u)) continue;
+      int rank = 0;
+      const double lk = LAMC[k];
+      for (int j = 0; j < 9; ++j) {
+        if (!((cmask >> j) & 1u)) continue;
+        const double lj = LAMC[j];
+        rank += (lj < lk || (lj == lk && j < k)) ? 1 : 0;
+      }
+      if (rank == want) pick = k;
+    }
+    kmin = pick;
+  }
 #pragma unroll
   for (int c = 0; c < 9; ++c) f[c] = (double)V32[c * 10 + kmin];
-  double rho = (double)lam32[kmin] * tr;
+  double rho = LAMC[kmin];
   // residual correction: r = M f - rho f;  f += sum_{k != kmin} q_k (q_k . r) / (rho - lam_k);  renormalise.
   // The Jacobi basis (fp32-accurate) acts as an approximate inverse of (M - rho); the fixed point is the exact
   // fp64 eigenvector, reached at a linear rate ~ eps32 |M| / gap per iteration.
@@ -460,7 +585,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
       double dot = 0.0;
 #pragma unroll
       for (int c = 0; c < 9; ++c) dot += (double)V32[c * 10 + lane] * r[c];
-      double den = rho - (double)A32[lane * 11] * tr;
+      double den = rho - LAMC[lane];
       const double lim = 1e-12 * tr;
       if (fabs(den) < lim) den = (den < 0.0) ? -lim : lim;
       SCR[16 + lane] = (lane == kmin) ? 0.0 : dot * fast_rcp(den);
@@ -556,7 +681,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
       const int e = lane + 64, k = e / 9, c = e % 9;
       sv[SV_Q + e] = (k == kmin) ? (float)SCR[c] : V32[c * 10 + k];
     }
-    if (lane < 9) sv[SV_LAM + lane] = (lane == kmin) ? (float)rho : (float)((double)A32[lane * 11] * tr);
+    if (lane < 9) sv[SV_LAM + lane] = (lane == kmin) ? (float)rho : (float)LAMC[lane];
     if (lane == 0) {
       sv[SV_T1 + 0] = (float)s1; sv[SV_T1 + 1] = (float)c1x; sv[SV_T1 + 2] = (float)c1y;
       sv[SV_T2 + 0] = (float)s2; sv[SV_T2 + 1] = (float)c2x; sv[SV_T2 + 2] = (float)c2y;

@@ -147,3 +147,32 @@ def test_full_batch_error_vs_fp64_oracle(dfepe, oracle, outl, noise):
     a, r, _ = unit_align(E_ours.numpy(), E_ref.numpy())
     assert np.linalg.norm(a - r, axis=1)[well].max() < 1e-5
     np.testing.assert_allclose((res.cpu().numpy() * s[:, None])[well], o_res.numpy()[well], atol=5e-7, rtol=1e-4)
+
+
+@pytest.mark.parametrize("N,B,scale,outl,noise", [(100, 2048, 3.0, 0.2, 0.5), (100, 2048, 4.0, 0.4, 0.5), (12, 512, 2.0, 0.2, 0.5), (300, 256, 5.0, 0.2, 2.0)])
+def test_near_degenerate_weightings_pick_the_reference_eigenvector(dfepe, oracle, N, B, scale, outl, noise):
+    """Peaked softmax weights leave fewer than nine effective correspondences: the two smallest eigenvalues of X^T X then
+    sit closer than fp32 resolves (relative gap 1e-7 ... 1e-12), although LAPACK's SVD of X -- the reference -- still
+    separates them.  The fp64 Rayleigh-Ritz step on such clusters must pick the same vector: every pair whose gap is above
+    1e-11 trace matches the fp64 oracle to 1e-4 (the error scales like 1e-15 / gap), and the bulk stays at 1e-5."""
+    sc = dfepe.synth.make_scene(B, N, seed=31 * N + int(scale), outlier_ratio=outl, noise_px=noise)
+    m = sc["matches_xy_ori"]
+    w = torch.softmax(sc["logits_layers"][0] * scale, dim=1)
+    F, res, _ = dfepe.ops.w8pt_raw(m.to(DEV), w.to(DEV), IMAGE_SIZE[1], IMAGE_SIZE[0], clamp_at=0.5, want_epi=True)
+    assert torch.isfinite(F).all() and torch.isfinite(res).all()
+    p1, p2, _ = oracle.normalize_hw(m.double(), IMAGE_SIZE)
+    o_out, _, _ = oracle.fit_forward(p1, p2, w.double().unsqueeze(1))
+    a, r, _ = unit_align(F.cpu().numpy(), o_out.numpy())
+    err = np.linalg.norm(a - r, axis=1)
+    h1, _ = oracle.hartley(p1)
+    h2, _ = oracle.hartley(p2)
+    rows = torch.cat((h2[:, :, 0:1] * h1, h2[:, :, 1:2] * h1, h1), 2)
+    rows = rows / rows.norm(dim=2, keepdim=True).clamp_min(1e-12)
+    X = rows * w.double().unsqueeze(2)
+    ev = torch.linalg.eigvalsh(X.transpose(1, 2) @ X)
+    gap = ((ev[:, 1] - ev[:, 0]) / ev[:, -1]).numpy()
+    well = gap > 1e-11
+    assert well.sum() > 0.8 * B
+    assert (gap < 1e-7).sum() > 0, "the scene is meant to contain clusters below fp32 resolution"
+    assert err[well].max() < 1e-4, (err[well].max(), gap[well][err[well].argmax()])
+    assert np.median(err) < 2e-6 and (err[well] < 1e-5).mean() > 0.97
