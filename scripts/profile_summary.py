@@ -12,7 +12,8 @@ B, N, L, M = 4096, 100, 5, 100
 
 def short(name):
     n = name.replace("void ", "").replace("(anonymous namespace)::", "")
-    return n.split("(")[0][:70]
+    n = n.split("(")[0][:70]
+    return n.replace("w8pt_fwd_kernel<true, 1>", "w8pt_fwd_kernel<true>")  # RAW, one wavefront per pair
 
 
 def counters(sub):

@@ -111,6 +111,14 @@ def test_nn_match_ties_and_edges(dfepe, oracle):
     n = int(cnt[0].item())
     assert n == ref.shape[1]
     np.testing.assert_array_equal(m2[0, :n].cpu().numpy(), ref[1].astype(np.int64))
+    # all descriptors identical: every distance is 0, first-occurrence arg-min leaves exactly the match (0, 0)
+    same = d1[:, :1].expand(1, 37, 64).contiguous().to(DEV)
+    s1, s2, ssc, scnt = dfepe.ops.nn_match_two_way(same, same[:, :29].contiguous(), 0.5)
+    refs = oracle.nn_match_two_way(same[0].cpu().numpy().T, same[0, :29].cpu().numpy().T, 0.5)
+    assert int(scnt[0].item()) == refs.shape[1] == 1 and int(s1[0, 0]) == 0 and int(s2[0, 0]) == 0
+    # a single keypoint on one side
+    o1, o2, osc, ocnt = dfepe.ops.nn_match_two_way(d1[:, 7:8].contiguous().to(DEV), d1.to(DEV), 0.5)
+    assert int(ocnt[0].item()) == 1 and int(o2[0, 0]) == 7 and float(osc[0, 0]) < 1e-3
     # threshold 0: nothing is < 0
     assert int(dfepe.ops.nn_match_two_way(d1.to(DEV), d1.to(DEV), 0.0)[3].item()) == 0
     # empty sides
