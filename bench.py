@@ -111,15 +111,21 @@ def main():
 
     log("graph captured" if graph is not None else "eager mode")
 
+    # the only exchange of the data-parallel path: (L+4) doubles over RCCL/xGMI per step, double-buffered and asynchronous
+    # so that the next replay does not wait for the small-message latency (nothing of the next step depends on it)
+    exchange = dfepe.dist.OverlappedLossExchange(L + 4, dev, depth=2) if dist is not None else None
+
     def run_step():
         if graph is not None:
             graph.replay()
         else:
             step_body()
-        if dist is not None:
-            dist.all_reduce(state["loss_vec"])  # the only exchange of the data-parallel path: (L+4) doubles over RCCL/xGMI
+        if exchange is not None:
+            exchange.exchange(state["loss_vec"])
 
     def barrier():
+        if exchange is not None:
+            exchange.drain()  # every outstanding all-reduce is part of the timed region
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()

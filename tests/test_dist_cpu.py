@@ -94,3 +94,53 @@ def test_two_rank_loss_reduction_matches_single_process():
     lqt = oracle.qt_training_loss(ref["pose"]["q_l2"], ref["pose"]["t_l2"], 0.1, 0.5, 1.0, 0.1)
     np.testing.assert_allclose(got["loss_qt"], lqt.numpy(), rtol=1e-10)
     assert got["n_pairs"] == B
+
+
+def _exchange_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    sys.path.insert(0, REPO)
+    dfepe = importlib.import_module("pytorch-deepfepe_amd")
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    ex = dfepe.dist.OverlappedLossExchange(5, "cpu", depth=2)
+    packed = torch.zeros(5, dtype=torch.float64)
+    seen = []
+    for step in range(7):
+        packed[:] = torch.arange(5, dtype=torch.float64) * (rank + 1) + step   # the producer overwrites its buffer every step
+        ex.exchange(packed)
+        if step % 3 == 2:
+            seen.append(ex.drain().clone())
+    final = ex.drain().clone()
+    dist.destroy_process_group()
+    if rank == 0:
+        q.put({"seen": [t.numpy() for t in seen], "final": final.numpy()})
+
+
+@pytest.mark.timeout(300)
+def test_overlapped_loss_exchange_two_ranks():
+    """The double-buffered asynchronous exchange bench.py uses between hipGraph replays: every step's vector is summed
+    over the ranks although the producer buffer is overwritten right away and buffers are recycled every second step."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    base = np.arange(5, dtype=np.float64)
+    expect = lambda step: base * 1 + step + base * 2 + step
+    np.testing.assert_allclose(got["seen"][0], expect(2))
+    np.testing.assert_allclose(got["seen"][1], expect(5))
+    np.testing.assert_allclose(got["final"], expect(6))
+
+
+def test_overlapped_loss_exchange_without_process_group():
+    dfepe = importlib.import_module("pytorch-deepfepe_amd")
+    ex = dfepe.dist.OverlappedLossExchange(3, "cpu")
+    assert ex.drain() is None
+    ex.exchange(torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64))
+    np.testing.assert_allclose(ex.drain().numpy(), [1.0, 2.0, 3.0])
