@@ -160,11 +160,11 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   // ---- pass B: g_w --------------------------------------------------------------------------------------
   float* dst = g_w + pair * N;
   float wg = 0.0f;
-#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-  for (int i = lane; i < N; i += WAVE) {
+  auto weight_grad = [&](int i, float& wf) -> float {
     const Pt p = global_point<RAW>(pts1, pts2, mp, i, N, hw_sx, hw_sy);
     double ph[9];
-    const double w = (double)wsrc[i];
+    wf = wsrc[i];
+    const double w = (double)wf;
     const bool ok = unit_row(p, s1, c1x, c1y, s2, c2x, c2y, ph) && (fabs(w) < 1e150);
     double a = 0.0, b = 0.0;
 #pragma unroll
@@ -172,14 +172,32 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     const double gr = (g_res != nullptr) ? (double)g_res[pair * N + i] : 0.0;
     float gwi = ok ? (float)(2.0 * w * a * b + gr * a) : 0.0f;
     if (g_w_extra != nullptr) gwi += g_w_extra[pair * N + i];
-    dst[i] = gwi;
-    wg += gwi * (float)w;
-  }
-  if (logits_mode) {
-    // softmax adjoint: g_logit_i = w_i (g_w_i - sum_j w_j g_w_j); dst is re-read by the lane that wrote it
-    const float s = wave_sum(wg);
+    return gwi;
+  };
+  if (logits_mode && N <= 2 * WAVE) {
+    // softmax adjoint g_logit_i = w_i (g_w_i - sum_j w_j g_w_j) with the (at most two) gradients of a lane kept in
+    // registers: one store per correspondence instead of store, wave sum, load, store
+    float g0 = 0.0f, g1 = 0.0f, w0 = 0.0f, w1 = 0.0f;
+    const int i1 = lane + WAVE;
+    if (lane < N) g0 = weight_grad(lane, w0);
+    if (i1 < N) g1 = weight_grad(i1, w1);
+    const float s = wave_sum(fmaf(g1, w1, g0 * w0));
+    if (lane < N) dst[lane] = w0 * (g0 - s);
+    if (i1 < N) dst[i1] = w1 * (g1 - s);
+  } else {
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-    for (int i = lane; i < N; i += WAVE) dst[i] = wsrc[i] * (dst[i] - s);
+    for (int i = lane; i < N; i += WAVE) {
+      float wf;
+      const float gwi = weight_grad(i, wf);
+      dst[i] = gwi;
+      wg += gwi * wf;
+    }
+    if (logits_mode) {
+      // dst is re-read by the lane that wrote it
+      const float s = wave_sum(wg);
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+      for (int i = lane; i < N; i += WAVE) dst[i] = wsrc[i] * (dst[i] - s);
+    }
   }
 
   if (PGRAD) {
