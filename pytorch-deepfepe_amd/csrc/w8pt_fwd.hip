@@ -175,6 +175,22 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   if (logits_mode) {
     // fused F.softmax(logits, dim=N) (DeepFNet.py:443,512): W holds the logits at this point
     wave_sync();
+    if (!COOP && N <= 2 * WAVE) {
+      // the (at most two) logits of a lane stay in registers: one LDS round trip instead of three passes over W
+      const int i1 = lane + WAVE;
+      const float l0 = (lane < N) ? W[lane] : -INFINITY, l1 = (i1 < N) ? W[i1] : -INFINITY;
+      const float mxr = wave_max(fmaxf(l0, l1));
+      const float e0 = (lane < N) ? expf(l0 - mxr) : 0.0f, e1 = (i1 < N) ? expf(l1 - mxr) : 0.0f;
+      const float invr = 1.0f / wave_sum(e0 + e1);
+      if (lane < N) {
+        W[lane] = e0 * invr;
+        if (weights_out != nullptr) weights_out[(size_t)pair * N + lane] = e0 * invr;
+      }
+      if (i1 < N) {
+        W[i1] = e1 * invr;
+        if (weights_out != nullptr) weights_out[(size_t)pair * N + i1] = e1 * invr;
+      }
+    } else {
     float mx = -INFINITY;
     for (int i = tid; i < N; i += NT) mx = fmaxf(mx, W[i]);
     mx = wave_max(mx);
@@ -204,6 +220,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
       const float w = W[i] * inv;
       W[i] = w;
       if (weights_out != nullptr) weights_out[(size_t)pair * N + i] = w;
+    }
     }
   }
   const double invN = 1.0 / (double)N;
