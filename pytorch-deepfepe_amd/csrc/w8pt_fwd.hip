@@ -55,9 +55,9 @@ constexpr JacTable make_jac_table() {
     t.l[lane].wr2t = (unsigned short)(perm[tj] * 10 + perm[ti]);                   // mirror (A items only)
     t.l[lane].rd_v = (unsigned short)(vi0 * 10 + (vj0 & ~1));
     t.l[lane].wr_v = (unsigned short)(vi0 * 10 + perm[vj0]);
-    t.l[lane].ci = (unsigned char)(a_item ? ti : 8);       // V items: identity row rotation
-    t.l[lane].cj = (unsigned char)tj;
-    t.l[lane].c0 = (unsigned char)vj0;
+    t.l[lane].ci = (unsigned char)(4 * (a_item ? ti : 8));                      // V items: identity row rotation
+    t.l[lane].cj = (unsigned char)(4 * tj + ((tj & 1) ? 2 : 0));               // odd column: swapped coefficients
+    t.l[lane].c0 = (unsigned char)(4 * vj0 + ((vj0 & 1) ? 2 : 0));
     t.l[lane].flags = (unsigned char)((a_item ? kJacIsA : 0) | (v_item ? kJacIsV2 : 0) | ((tj & 1) ? kJacOdd2 : 0) |
                                       ((vj0 & 1) ? kJacOdd1 : 0) | ((a_item && ti != tj) ? kJacOffDiag : 0));
   }
@@ -65,7 +65,7 @@ constexpr JacTable make_jac_table() {
 }
 __constant__ JacTable kJac = make_jac_table();
 
-constexpr int kWsDoubles = 224;  // per-wave workspace in LDS (1792 B, 16-B multiple): see the carve in the kernel
+constexpr int kWsDoubles = 232;  // per-wave workspace in LDS (1856 B, 16-B multiple): see the carve in the kernel
 constexpr float kClusterTol = 4e-6f;  // fp32 Jacobi eigenvalues (unit trace) closer than this to the selected one are re-resolved in fp64
 constexpr int kMaxSweeps = 8;  // safety bound only: the sweeps run until off(A)^2 <= kJacobiTol (4-5 sweeps, a 6th for ~1 % of the pairs); stopping
                                // early leaves eigenpairs too rough for the polish when the gap is a few 1e-6 (scripts/stress_parity.py)
@@ -129,8 +129,8 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   double* SCR = M64 + 81;                                   // [32] exchange scratch for the refinement  648..904
   float* A32 = reinterpret_cast<float*>(base + 904);        // [9][10] Jacobi iterate (position space, row stride 10) 904..1264
   float* V32 = A32 + 90;                                    // [9][10] accumulated rotations                        1264..1624
-  float2* CS = reinterpret_cast<float2*>(base + 1624);      // [9]  (c, signed s) per position                      1624..1696
-  double* LAMC = reinterpret_cast<double*>(base + 1696);    // [9]  eigenvalues in fp64 (Ritz values of the stored vectors) 1696..1768
+  float4* CS = reinterpret_cast<float4*>(base + 1632);      // [9]  (c, sh, sh, c) per position: .xy for an even, .zw for an odd column 1632..1776
+  double* LAMC = reinterpret_cast<double*>(base + 1776);    // [9]  eigenvalues in fp64 (Ritz values of the stored vectors) 1776..1848
   float* P = reinterpret_cast<float*>(base + kWsDoubles * sizeof(double));
   float* W = P + (RAW ? 4 : 6) * npad;
   double* RED = reinterpret_cast<double*>(W + npad);         // COOP only: cross-wavefront exchange (kCoopBytes)
@@ -351,14 +351,14 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
       V32[e] = (i == j) ? 1.0f : 0.0f;
     }
   }
-  if (lane == 8) CS[8] = make_float2(1.0f, 0.0f);  // position 8 sits out: identity rotation
+  if (lane == 8) CS[8] = make_float4(1.0f, 0.0f, 0.0f, 1.0f);  // position 8 sits out: identity rotation
   // Work items of a round.  Slot 1: V elements 0..63 (one per lane).  Slot 2: the 45 upper-triangular A elements on
   // lanes 0..44 and the 17 remaining V elements on lanes 45..61 -- a V element is the special case (c_i, s_i) = (1, 0)
   // of the two-sided update, so both kinds run the same instruction stream.  All addresses are loop-invariant.
   const uint4 jw = *reinterpret_cast<const uint4*>(&kJac.l[lane]);
   const int rd_own = jw.x & 0xffff, rd_par = jw.x >> 16, wr2 = jw.y & 0xffff, wr2t = jw.y >> 16;
   const int rd_v = jw.z & 0xffff, wr_v = jw.z >> 16;
-  const int ci_idx = jw.w & 0xff, cj_idx = (jw.w >> 8) & 0xff, c0_idx = (jw.w >> 16) & 0xff;
+  const int ci_off = jw.w & 0xff, cj_off = (jw.w >> 8) & 0xff, c0_off = (jw.w >> 16) & 0xff;  // float offsets into CS
   const unsigned jfl = jw.w >> 24;
   const bool is_a = (jfl & kJacIsA) != 0, is_v2 = (jfl & kJacIsV2) != 0, odd2 = (jfl & kJacOdd2) != 0;
   const bool odd1 = (jfl & kJacOdd1) != 0, offdiag = (jfl & kJacOffDiag) != 0;
@@ -397,15 +397,18 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
         float c = x * y;
         float sn = copysignf(0.5f, d) * b * r * y;
         if (pq.y == 0.0f) { c = 1.0f; sn = 0.0f; }  // also catches 0/0
-        CS[lane] = make_float2(c, (lane & 1) ? sn : -sn);
+        const float sh = (lane & 1) ? sn : -sn;
+        CS[lane] = make_float4(c, sh, sh, c);
       }
       wave_sync();
-      const float2 ci = CS[ci_idx], cj = CS[cj_idx], c0 = CS[c0_idx];
-      const float e00 = odd2 ? own.y : own.x, e01 = odd2 ? own.x : own.y;
-      const float e10 = odd2 ? par.y : par.x, e11 = odd2 ? par.x : par.y;
-      const float new2 = ci.x * fmaf(cj.x, e00, cj.y * e01) + ci.y * fmaf(cj.x, e10, cj.y * e11);
-      const float u0 = odd1 ? vv.y : vv.x, u0p = odd1 ? vv.x : vv.y;
-      const float v0 = fmaf(c0.x, u0, c0.y * u0p);
+      // col' = c col + sh col_partner.  A lane whose column is the odd one of its pair holds (partner, self) in its
+      // float2, so it reads the coefficients in swapped order (.zw): no per-element selects in the loop.
+      const float* CSf = reinterpret_cast<const float*>(CS);
+      const float2 ci = *reinterpret_cast<const float2*>(CSf + ci_off);
+      const float2 kj = *reinterpret_cast<const float2*>(CSf + cj_off);
+      const float2 k0 = *reinterpret_cast<const float2*>(CSf + c0_off);
+      const float new2 = ci.x * fmaf(kj.x, own.x, kj.y * own.y) + ci.y * fmaf(kj.x, par.x, kj.y * par.y);
+      const float v0 = fmaf(k0.x, vv.x, k0.y * vv.y);
       if (is_a || is_v2) A32[wr2] = new2;
       if (is_a) A32[wr2t] = new2;
       V32[wr_v] = v0;
