@@ -363,7 +363,8 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   const bool is_a = (jfl & kJacIsA) != 0, is_v2 = (jfl & kJacIsV2) != 0, odd2 = (jfl & kJacOdd2) != 0;
   const bool odd1 = (jfl & kJacOdd1) != 0, offdiag = (jfl & kJacOffDiag) != 0;
   const int off_idx = rd_own + (odd2 ? 1 : 0);           // A32[ti][tj] for the A items
-  const int pp = (lane < 8) ? (lane & ~1) : 0;  // lanes 0..7: my pair is positions (pp, pp+1)
+  const int pp = (lane < 16) ? (lane & 6) : 0;  // lanes 0..15: my pair is positions (pp, pp+1); lanes 8..15 repeat 0..7 and
+                                                // store the swapped copy (one ds_write_b64 per lane instead of a ds_write_b128)
   wave_sync();
   int n_sweeps = 0, n_refine = 0;
   // diagnostics (DFEPE_W8PT_DIAG_* bits of `flags`, see scripts/quick_time.py): dbg = 0 normal; otherwise bits 0..7 hold
@@ -385,7 +386,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
       const float2 own = *reinterpret_cast<const float2*>(A32 + rd_own);
       const float2 par = *reinterpret_cast<const float2*>(A32 + rd_par);
       const float2 vv = *reinterpret_cast<const float2*>(V32 + rd_v);
-      if (lane < 8) {
+      if (lane < 16) {
         const float2 pq = *reinterpret_cast<const float2*>(A32 + pp * 11);  // {A[p][p], A[p][p+1]}
         const float aqq = A32[pp * 11 + 11];
         // small-angle Jacobi rotation from two reciprocal square roots: cos 2t = |d| / h, c = sqrt((1 + cos 2t) / 2),
@@ -398,7 +399,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
         float sn = copysignf(0.5f, d) * b * r * y;
         if (pq.y == 0.0f) { c = 1.0f; sn = 0.0f; }  // also catches 0/0
         const float sh = (lane & 1) ? sn : -sn;
-        CS[lane] = make_float4(c, sh, sh, c);
+        reinterpret_cast<float2*>(CS)[2 * (lane & 7) + (lane >> 3)] = (lane < 8) ? make_float2(c, sh) : make_float2(sh, c);
       }
       wave_sync();
       // col' = c col + sh col_partner.  A lane whose column is the odd one of its pair holds (partner, self) in its
