@@ -146,7 +146,7 @@ if fv:
            f"{100*floor_us/fwd_avg_us:.0f} % of the vector-issue bound of its own instruction stream; HBM is idle most of the time."]
     if clk_ghz:
         md[-1] += (f"  At the {clk_ghz:.2f} GHz the counters show, the same bound is {4*valu*4/clk_ghz/1e3:.1f} us, i.e. the launch runs at "
-                   f"{100*(4*valu*4/clk_ghz/1e3)/fwd_avg_us:.0f} % of it: the kernel is vector-issue bound, and only fewer instructions make it faster.")
+                   f"{100*(4*valu*4/clk_ghz/1e3)/fwd_avg_us:.0f} % of it: the kernel is vector-issue bound, and only fewer instructions make it faster (the Jacobi rounds, which are LDS-pipe bound, excepted).")
 if fv:
     traffic[f"w8pt_fwd_valu_insts_per_wave_B{B}_N{N}"] = round(valu, 1)
 if clk_ghz:
