@@ -34,7 +34,7 @@ struct JacLane {
   unsigned short rd_v, wr_v;                 // slot 1 (V element = lane): float offsets from V32
   unsigned char ci, cj, c0, flags;           // CS slots of the row / column rotation (slot 2) and of slot 1
 };
-constexpr unsigned kJacIsA = 1, kJacIsV2 = 2, kJacOdd2 = 4, kJacOdd1 = 8, kJacOffDiag = 16;
+constexpr unsigned kJacIsA = 1, kJacIsV2 = 2, kJacOdd2 = 4, kJacOffDiag = 16;
 struct JacTable { JacLane l[64]; };
 constexpr JacTable make_jac_table() {
   constexpr int perm[9] = {8, 3, 0, 5, 2, 7, 4, 6, 1};  // seat permutation of the round-robin tournament: position p moves to perm[p] after every round
@@ -59,7 +59,7 @@ constexpr JacTable make_jac_table() {
     t.l[lane].cj = (unsigned char)(4 * tj + ((tj & 1) ? 2 : 0));               // odd column: swapped coefficients
     t.l[lane].c0 = (unsigned char)(4 * vj0 + ((vj0 & 1) ? 2 : 0));
     t.l[lane].flags = (unsigned char)((a_item ? kJacIsA : 0) | (v_item ? kJacIsV2 : 0) | ((tj & 1) ? kJacOdd2 : 0) |
-                                      ((vj0 & 1) ? kJacOdd1 : 0) | ((a_item && ti != tj) ? kJacOffDiag : 0));
+                                      ((a_item && ti != tj) ? kJacOffDiag : 0));
   }
   return t;
 }
@@ -361,7 +361,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   const int ci_off = jw.w & 0xff, cj_off = (jw.w >> 8) & 0xff, c0_off = (jw.w >> 16) & 0xff;  // float offsets into CS
   const unsigned jfl = jw.w >> 24;
   const bool is_a = (jfl & kJacIsA) != 0, is_v2 = (jfl & kJacIsV2) != 0, odd2 = (jfl & kJacOdd2) != 0;
-  const bool odd1 = (jfl & kJacOdd1) != 0, offdiag = (jfl & kJacOffDiag) != 0;
+  const bool offdiag = (jfl & kJacOffDiag) != 0;
   const int off_idx = rd_own + (odd2 ? 1 : 0);           // A32[ti][tj] for the A items
   const int pp = (lane < 16) ? (lane & 6) : 0;  // lanes 0..15: my pair is positions (pp, pp+1); lanes 8..15 repeat 0..7 and
                                                 // store the swapped copy (one ds_write_b64 per lane instead of a ds_write_b128)
@@ -381,8 +381,8 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     if (!(off > kJacobiTol) && !dbg_on) break;  // wave-uniform (also leaves on NaN)
     ++n_sweeps;
     for (int r = 0; r < 9; ++r) {
-      // every read of the round is issued up front (none depends on this round's rotations): 4 x ds_read_b64 + the
-      // rotation inputs, then the (c,s) exchange through CS, then 3-4 ds_write_b32
+      // every read of the round is issued up front (none depends on this round's rotations): 3 x ds_read_b64 + the
+      // rotation inputs of lanes 0..15, then the (c, sh) exchange through CS (3 x ds_read_b64), then 2-3 ds_write_b32
       const float2 own = *reinterpret_cast<const float2*>(A32 + rd_own);
       const float2 par = *reinterpret_cast<const float2*>(A32 + rd_par);
       const float2 vv = *reinterpret_cast<const float2*>(V32 + rd_v);
