@@ -20,16 +20,24 @@ __device__ __forceinline__ double guard_den(double d) {
   return (fabs(d) < lim) ? ((d < 0.0) ? -lim : lim) : d;
 }
 
-template <bool RAW, bool PGRAD>
+// COOP: one 256-thread workgroup per pair instead of one wavefront (large N with a batch too small to fill the GPU, like
+// w8pt_fwd's cooperative variant): the four wavefronts split the passes over the correspondences and each repeats the
+// few hundred wave-uniform instructions; their partial sums meet in LDS.  Not combined with the point gradients.
+template <bool RAW, bool PGRAD, bool COOP>
 __global__ void __launch_bounds__(256, (PGRAD ? 2 : 4))  // the point-gradient variant trades occupancy for no spills
 w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, const float* __restrict__ wts, int B,
                 int Bm, int N, float hw_sx, float hw_sy, float clamp_at, const float* __restrict__ save,
                 const float* __restrict__ F_out, const float* __restrict__ g_F, const float* __restrict__ g_res,
                 const float* __restrict__ g_epi, const float* __restrict__ g_w_extra, int logits_mode,
                 float* __restrict__ g_w, float* __restrict__ g_p1, float* __restrict__ g_p2) {
+  static_assert(!(COOP && PGRAD), "the cooperative variant does not produce point gradients");
+  __shared__ float red[4][20];  // COOP only: per-wavefront partial sums
   const int lane = threadIdx.x & 63;
-  const size_t pair = (size_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
-  if (pair >= (size_t)B) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
+  const size_t pair = COOP ? (size_t)blockIdx.x : (size_t)blockIdx.x * (blockDim.x >> 6) + wave;
+  if (!COOP && pair >= (size_t)B) return;
+  constexpr int NT = COOP ? 256 : WAVE;
+  const int tid = COOP ? (int)threadIdx.x : lane;
 
   const size_t mp = pair % (size_t)Bm;  // correspondences may be shared by several weight sets
   const float* sv = save + pair * DFEPE_SAVE_FLOATS;
@@ -54,7 +62,7 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   }
   const float* wsrc = wts + pair * N;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-  for (int i = lane; i < N; i += WAVE) {
+  for (int i = tid; i < N; i += NT) {
     if (g_res == nullptr && g_epi == nullptr) break;  // nothing to accumulate (fused training step: the loss depends on F only)
     const Pt p = global_point<RAW>(pts1, pts2, mp, i, N, hw_sx, hw_sy);
     if (g_res != nullptr) {
@@ -97,6 +105,18 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   for (int c = 0; c < 9; ++c) {
     gx[c] = (g_res != nullptr) ? (double)wave_sum(gxf[c]) : 0.0;
     go[c] = (g_epi != nullptr) ? (double)wave_sum(gof[c]) : 0.0;
+  }
+  if (COOP && (g_res != nullptr || g_epi != nullptr)) {
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) { red[wave][c] = (float)gx[c]; red[wave][9 + c] = (float)go[c]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      gx[c] = (double)((red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+      go[c] = (double)((red[0][9 + c] + red[1][9 + c]) + (red[2][9 + c] + red[3][9 + c]));
+    }
   }
   if (g_F != nullptr) {
 #pragma unroll
@@ -174,7 +194,7 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     if (g_w_extra != nullptr) gwi += g_w_extra[pair * N + i];
     return gwi;
   };
-  if (logits_mode && N <= 2 * WAVE) {
+  if (!COOP && logits_mode && N <= 2 * WAVE) {
     // softmax adjoint g_logit_i = w_i (g_w_i - sum_j w_j g_w_j) with the (at most two) gradients of a lane kept in
     // registers: one store per correspondence instead of store, wave sum, load, store
     float g0 = 0.0f, g1 = 0.0f, w0 = 0.0f, w1 = 0.0f;
@@ -186,7 +206,7 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     if (i1 < N) dst[i1] = w1 * (g1 - s);
   } else {
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-    for (int i = lane; i < N; i += WAVE) {
+    for (int i = tid; i < N; i += NT) {
       float wf;
       const float gwi = weight_grad(i, wf);
       dst[i] = gwi;
@@ -194,9 +214,14 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     }
     if (logits_mode) {
       // dst is re-read by the lane that wrote it
-      const float s = wave_sum(wg);
+      float s = wave_sum(wg);
+      if (COOP) {
+        if (lane == 0) red[wave][18] = s;
+        __syncthreads();
+        s = (red[0][18] + red[1][18]) + (red[2][18] + red[3][18]);
+      }
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-      for (int i = lane; i < N; i += WAVE) dst[i] = wsrc[i] * (dst[i] - s);
+      for (int i = tid; i < N; i += NT) dst[i] = wsrc[i] * (dst[i] - s);
     }
   }
 
@@ -339,16 +364,18 @@ extern "C" int dfepe_w8pt_bwd(const float* pts1, const float* pts2, const float*
   if (raw && !(image_w > 0.f && image_h > 0.f)) return DFEPE_ERR_INVALID_ARG;
   if (raw && (reinterpret_cast<uintptr_t>(pts1) & 15u)) return DFEPE_ERR_INVALID_ARG;
   const int waves = 4;
-  const dim3 grid((B + waves - 1) / waves), block(64 * waves);
+  // large N, batch small enough to be resident at once: one workgroup per pair (N = 1000, B = 512: see DESIGN.md)
+  const bool coop = !pgrad && N >= 256 && B <= 1024;
+  const dim3 grid(coop ? B : (B + waves - 1) / waves), block(64 * waves);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float hw_sx = raw ? 2.0f / image_w : 0.f, hw_sy = raw ? 2.0f / image_h : 0.f;
-#define DFEPE_LAUNCH_BWD(R, P)                                                                                              \
-  hipLaunchKernelGGL((w8pt_bwd_kernel<R, P>), grid, block, 0, st, pts1, pts2, weights, B, Bm, N, hw_sx, hw_sy, clamp_at, save,   \
+#define DFEPE_LAUNCH_BWD(R, P, C)                                                                                           \
+  hipLaunchKernelGGL((w8pt_bwd_kernel<R, P, C>), grid, block, 0, st, pts1, pts2, weights, B, Bm, N, hw_sx, hw_sy, clamp_at, save, \
                      F_out, g_F, g_residual, g_epi, g_weights_extra, logits_mode, g_weights, g_pts1, g_pts2)
   if (raw) {
-    if (pgrad) DFEPE_LAUNCH_BWD(true, true); else DFEPE_LAUNCH_BWD(true, false);
+    if (pgrad) DFEPE_LAUNCH_BWD(true, true, false); else if (coop) DFEPE_LAUNCH_BWD(true, false, true); else DFEPE_LAUNCH_BWD(true, false, false);
   } else {
-    if (pgrad) DFEPE_LAUNCH_BWD(false, true); else DFEPE_LAUNCH_BWD(false, false);
+    if (pgrad) DFEPE_LAUNCH_BWD(false, true, false); else if (coop) DFEPE_LAUNCH_BWD(false, false, true); else DFEPE_LAUNCH_BWD(false, false, false);
   }
 #undef DFEPE_LAUNCH_BWD
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
