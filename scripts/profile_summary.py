@@ -13,7 +13,8 @@ B, N, L, M = 4096, 100, 5, 100
 def short(name):
     n = name.replace("void ", "").replace("(anonymous namespace)::", "")
     n = n.split("(")[0][:70]
-    return n.replace("w8pt_fwd_kernel<true, 1>", "w8pt_fwd_kernel<true>")  # RAW, one wavefront per pair
+    n = n.replace("w8pt_fwd_kernel<true, 1>", "w8pt_fwd_kernel<true>")  # RAW, one wavefront per pair
+    return n.replace("w8pt_bwd_kernel<true, false, false>", "w8pt_bwd_kernel<true, false>")  # RAW, no point gradients, one wavefront per pair
 
 
 def counters(sub):
