@@ -49,6 +49,29 @@ __device__ __forceinline__ void eval_point(const float* v, const double* T, floa
   for (int r = 0; r < 3; ++r) x[r] = (float)(T[3 * r] * a + T[3 * r + 1] * b + T[3 * r + 2] * c);
 }
 
+// Sums of nine per-lane values over the wavefront, total[c] delivered in every lane whose (lane & 15) == c: four DPP
+// steps per value give the 16-lane row sums, each lane then picks the value of its own index and two cross-row exchanges
+// finish all nine at once (50 instructions instead of nine separate wave sums at ~11 each).
+__device__ __forceinline__ float wave_sum9_scattered(const float* a, int lane) {
+  float r[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    float v = a[c];
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);
+    v += dpp_f32<0x140>(v);
+    r[c] = v;
+  }
+  const int k = lane & 15;
+  float mine = r[0];
+#pragma unroll
+  for (int c = 1; c < 9; ++c) mine = (k == c) ? r[c] : mine;
+  mine += __shfl_xor(mine, 16, WAVE);
+  mine += __shfl_xor(mine, 32, WAVE);
+  return mine;
+}
+
 template <bool BWD, bool CACHED>
 __global__ void __launch_bounds__(256, 4)
 floss_kernel(const float* __restrict__ F_layers, int L, int B, const float* __restrict__ T1, const float* __restrict__ T2,
@@ -56,8 +79,10 @@ floss_kernel(const float* __restrict__ F_layers, int L, int B, const float* __re
              int M, float clamp_at, float* __restrict__ loss_sum, float* __restrict__ E_layers,
              const float* __restrict__ g_loss_sum, float g_loss_coef, const float* __restrict__ g_scale,
              const float* __restrict__ g_E, float* __restrict__ g_F_layers) {
+  __shared__ float gsum[4][kMaxLayers][9];  // BWD: per-layer sums of the point gradients, one slab per wavefront of the block
   const int lane = threadIdx.x & 63;
-  const size_t pair = (size_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
+  const size_t pair = (size_t)blockIdx.x * (blockDim.x >> 6) + wave;
   if (pair >= (size_t)B) return;
   double t1[9], t2[9];
   load9(T1 + pair * t_stride, t1);
@@ -117,13 +142,10 @@ floss_kernel(const float* __restrict__ F_layers, int L, int B, const float* __re
       const double acc = wave_sum((double)accf);
       if (lane == 0) loss_sum[(size_t)l * B + pair] = (float)acc;
     } else {
-      double go[9];
-      float gof[9];  // per-lane partial sums in fp32 (like the reference's backward); combined in fp64
+      float gof[9];  // per-lane partial sums in fp32 (like the reference's backward); scaled and combined in fp64 below
 #pragma unroll
-      for (int c = 0; c < 9; ++c) { go[c] = 0.0; gof[c] = 0.0f; }
+      for (int c = 0; c < 9; ++c) gof[c] = 0.0f;
       const bool has_gl = (g_loss_sum != nullptr) || (g_loss_coef != 0.0f);
-      const double gl = (g_loss_sum != nullptr) ? (double)g_loss_sum[(size_t)l * B + pair]
-                                                : (double)g_loss_coef * ((g_scale != nullptr) ? (double)g_scale[0] : 1.0);
       if (has_gl) {
         auto point_grad = [&](const float* x1, const float* x2, bool live) {
           const Epi e = epi_terms(x1, x2, o);
@@ -155,22 +177,34 @@ floss_kernel(const float* __restrict__ F_layers, int L, int B, const float* __re
             point_grad(x1, x2, true);
           }
         }
-#pragma unroll
-        for (int c = 0; c < 9; ++c) go[c] = gl * (double)wave_sum(gof[c]);
+        const float tot = wave_sum9_scattered(gof, lane);
+        if (lane < 9) gsum[wave][l][lane] = tot;
+      } else if (lane < 9) {
+        gsum[wave][l][lane] = 0.0f;
       }
+    }
+  }
+  if (BWD) {
+    // combine per layer, one layer per lane: g_F_l = gl_l * sums_l + (T2 K) g_E_l (T1 K)^T   (E = (T2 K)^T F (T1 K))
+    wave_sync();
+    if (lane < L) {
+      const size_t lb = (size_t)lane * B + pair;
+      const double gl = (g_loss_sum != nullptr) ? (double)g_loss_sum[lb]
+                                                : (double)g_loss_coef * ((g_scale != nullptr) ? (double)g_scale[0] : 1.0);
+      double go[9];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) go[c] = gl * (double)gsum[wave][lane][c];
       if (g_E != nullptr) {
-        // E = (T2 K)^T F (T1 K)  ->  g_F += (T2 K) g_E (T1 K)^T
         double ge[9], tmp[9], add[9];
-        load9(g_E + ((size_t)l * B + pair) * 9, ge);
+#pragma unroll
+        for (int c = 0; c < 9; ++c) ge[c] = (double)g_E[lb * 9 + c];
         mat3_mul(Am, ge, tmp);
         mat3_mul_nt(tmp, Cm, add);
 #pragma unroll
         for (int c = 0; c < 9; ++c) go[c] += add[c];
       }
-      if (lane == 0) {
 #pragma unroll
-        for (int c = 0; c < 9; ++c) g_F_layers[((size_t)l * B + pair) * 9 + c] = (float)go[c];
-      }
+      for (int c = 0; c < 9; ++c) g_F_layers[lb * 9 + c] = (float)go[c];
     }
   }
   if (!BWD && E_layers != nullptr && lane < L) {
