@@ -293,3 +293,14 @@ def test_deepfnet_learned_offsets_branch(dfepe):
     num = (lp_ - lm_) / (2 * eps)
     ana = (g * d).sum().item()
     assert abs(num - ana) < 0.05 * max(abs(num), abs(ana)) + 1e-7, (num, ana)
+
+
+def test_cheirality_batch_size_variants_agree(dfepe):
+    """B >= 2048 runs one wavefront per pair, smaller batches four (they split the correspondences): same results."""
+    B, N = 2048, 150
+    sc = dfepe.synth.make_scene(B, N, seed=21, outlier_ratio=0.3, noise_px=1.0)
+    E, K, m = sc["E_gt"].to(DEV), sc["Ks"].to(DEV), sc["matches_xy_ori"].to(DEV)
+    Rt, win, cnt = dfepe.ops.cheirality(E, K, m, 50.0)
+    Rt2, win2, cnt2 = dfepe.ops.cheirality(E[:200].contiguous(), K[:200].contiguous(), m[:200].contiguous(), 50.0)
+    assert torch.equal(win[:200], win2) and torch.equal(cnt[:200], cnt2) and torch.equal(Rt[:200], Rt2)
+    assert (win >= 0).float().mean().item() > 0.95

@@ -176,3 +176,21 @@ def test_near_degenerate_weightings_pick_the_reference_eigenvector(dfepe, oracle
     assert (gap < 1e-7).sum() > 0, "the scene is meant to contain clusters below fp32 resolution"
     assert err[well].max() < 1e-4, (err[well].max(), gap[well][err[well].argmax()])
     assert np.median(err) < 2e-6 and (err[well] < 1e-5).mean() > 0.97
+
+
+def test_two_wavefronts_per_pair_variant(dfepe, oracle):
+    """N = 800 with more than 1024 pairs selects the cooperative workgroup of TWO wavefronts per pair (the 4-wavefront
+    variant is covered by the small-batch large-N cases): same parity bar as everywhere else."""
+    B, N = 1100, 800
+    sc = dfepe.synth.make_scene(B, N, seed=4, outlier_ratio=0.2, noise_px=0.5)
+    m = sc["matches_xy_ori"]
+    w = torch.softmax(sc["logits_layers"][0], dim=1)
+    F, res, epi = dfepe.ops.w8pt_raw(m.to(DEV), w.to(DEV), IMAGE_SIZE[1], IMAGE_SIZE[0], clamp_at=0.5, want_epi=True)
+    p1, p2, _ = oracle.normalize_hw(m.double(), IMAGE_SIZE)
+    o_out, o_res, _ = oracle.fit_forward(p1, p2, w.double().unsqueeze(1))
+    a, r, s_ = unit_align(F.cpu().numpy(), o_out.numpy())
+    assert np.linalg.norm(a - r, axis=1).max() < 5e-6
+    np.testing.assert_allclose(res.cpu().numpy() * s_[:, None], o_res.numpy(), atol=1e-6, rtol=1e-4)
+    # and it is the same function as the one-wavefront-per-pair kernel (diagnostic flag bit 25 forces that variant)
+    F1 = dfepe.ops.w8pt_forward(m.to(DEV), None, w.to(DEV), True, float(IMAGE_SIZE[1]), float(IMAGE_SIZE[0]), 0.5, True, False, diag=0x200)[0]
+    assert (F1 - F).abs().max().item() < 2e-6 * F.abs().max().item()
