@@ -32,6 +32,7 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
                 float* __restrict__ g_w, float* __restrict__ g_p1, float* __restrict__ g_p2) {
   static_assert(!(COOP && PGRAD), "the cooperative variant does not produce point gradients");
   __shared__ float red[4][20];  // COOP only: per-wavefront partial sums
+  __shared__ float qlds[4][96];  // eigenvectors (81) and eigenvalues (9) of the pair, staged for the lane-parallel eigen adjoint
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
   const size_t pair = COOP ? (size_t)blockIdx.x : (size_t)blockIdx.x * (blockDim.x >> 6) + wave;
@@ -40,6 +41,16 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   const int tid = COOP ? (int)threadIdx.x : lane;
 
   const size_t mp = pair % (size_t)Bm;  // correspondences may be shared by several weight sets
+  {  // stage Q and Lambda of the save record in LDS (two coalesced loads; their latency hides behind the scalar loads below)
+    const float* svq = save + pair * DFEPE_SAVE_FLOATS;
+    float* ql = qlds[COOP ? 0 : wave];
+    if (!COOP || wave == 0) {
+      ql[lane] = svq[SV_Q + lane];
+      if (lane < 17) ql[64 + lane] = svq[SV_Q + 64 + lane];
+      if (lane < 9) ql[81 + lane] = svq[SV_LAM + lane];
+    }
+    if (COOP) __syncthreads();
+  }
   const float* sv = save + pair * DFEPE_SAVE_FLOATS;
   // wave-uniform values are parked in scalar registers (to_sgpr) to keep the VGPR budget at 4 waves/SIMD
   const double s1 = to_sgpr((double)sv[SV_T1]), c1x = to_sgpr((double)sv[SV_T1 + 1]), c1y = to_sgpr((double)sv[SV_T1 + 2]);
@@ -164,18 +175,34 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 #pragma unroll
   for (int c = 0; c < 9; ++c) { gf[c] = gFm[c] + gx[c]; u[c] = 0.0; }
   const double lsel = sv[SV_LAM + ksel];
-  for (int k = 0; k < 9; ++k) {
-    if (k == ksel) continue;
+  // lane k: coefficient c_k = (q_k . g_f) / (lam_f - lam_k); lane c: u_c = sum_k c_k q_k[c]; the nine u_c then go back to
+  // scalar registers.  ~85 vector instructions instead of eight uniform (dot, reciprocal, axpy) rounds of ~35.
+  wave_sync();
+  const float* ql = qlds[COOP ? 0 : wave];
+  double ck = 0.0, uc = 0.0;
+  if (lane < 9) {
     double dot = 0.0;
 #pragma unroll
-    for (int c = 0; c < 9; ++c) dot += (double)sv[SV_Q + k * 9 + c] * gf[c];
-    const double ck = dot * fast_rcp(guard_den(lsel - (double)sv[SV_LAM + k]));  // fp32 seed + 2 Newton steps, not a 30-instruction fp64 divide
-#pragma unroll
-    for (int c = 0; c < 9; ++c) u[c] += ck * (double)sv[SV_Q + k * 9 + c];
+    for (int c = 0; c < 9; ++c) dot += (double)ql[lane * 9 + c] * gf[c];
+    ck = (lane == ksel) ? 0.0 : dot * fast_rcp(guard_den(lsel - (double)ql[81 + lane]));
   }
-
+  {
+    union { double d; int i[2]; } a, b;
+    a.d = ck;
 #pragma unroll
-  for (int c = 0; c < 9; ++c) u[c] = to_sgpr(u[c]);
+    for (int k = 0; k < 9; ++k) {
+      b.i[0] = __builtin_amdgcn_readlane(a.i[0], k);
+      b.i[1] = __builtin_amdgcn_readlane(a.i[1], k);
+      if (lane < 9) uc += b.d * (double)ql[k * 9 + lane];
+    }
+    a.d = uc;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      b.i[0] = __builtin_amdgcn_readlane(a.i[0], c);
+      b.i[1] = __builtin_amdgcn_readlane(a.i[1], c);
+      u[c] = b.d;
+    }
+  }
 
   // ---- pass B: g_w --------------------------------------------------------------------------------------
   float* dst = g_w + pair * N;
