@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-model", action="store_true", help="skip the secondary whole-DeepFNet measurement")
-    ap.add_argument("--cpu-sample", type=int, default=256, help="pairs in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="pairs in the CPU-baseline sample (~15 s of host work)")
     ap.add_argument("--force-dist", action="store_true",
                     help="single-process smoke test of the multi-GPU code path: a 1-rank RCCL group and the overlapped exchange")
     return ap.parse_args()
