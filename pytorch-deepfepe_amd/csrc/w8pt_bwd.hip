@@ -139,8 +139,19 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   double t1[9] = {s1, 0.0, -s1 * c1x, 0.0, s1, -s1 * c1y, 0.0, 0.0, 1.0};
   double t2[9] = {s2, 0.0, -s2 * c2x, 0.0, s2, -s2 * c2y, 0.0, 0.0, 1.0};
   double tmp[9], G[9];
-  mat3_mul(t2, go, tmp);
-  mat3_mul_nt(tmp, t1, G);
+  // T = [[s,0,-s cx],[0,s,-s cy],[0,0,1]] written out (a generic 3x3 product would multiply by its zeros: no fast-math)
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    tmp[c] = s2 * (go[c] - c2x * go[6 + c]);
+    tmp[3 + c] = s2 * (go[3 + c] - c2y * go[6 + c]);
+    tmp[6 + c] = go[6 + c];
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    G[3 * r] = s1 * (tmp[3 * r] - c1x * tmp[3 * r + 2]);
+    G[3 * r + 1] = s1 * (tmp[3 * r + 1] - c1y * tmp[3 * r + 2]);
+    G[3 * r + 2] = tmp[3 * r + 2];
+  }
   // rank-2 projection adjoint
   double U[9], V[9], S[3];
 #pragma unroll
