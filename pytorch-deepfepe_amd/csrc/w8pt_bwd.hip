@@ -157,29 +157,34 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 #pragma unroll
   for (int c = 0; c < 9; ++c) { U[c] = sv[SV_U3 + c]; V[c] = sv[SV_V3 + c]; }
   S[0] = sv[SV_S3]; S[1] = sv[SV_S3 + 1]; S[2] = sv[SV_S3 + 2];
-  double UtGV[9];  // (U^T G V)[a][b] = u_a^T G v_b
-  mat3_mul_tn(U, G, tmp);
-  mat3_mul(tmp, V, UtGV);
+  // Only five entries of U^T G V enter: a_k3 = u_k^T G v_3 (k = 0,1,2) and a_3k = u_3^T G v_k (k = 0,1).  With
+  // beta_k = coef_k (a_k3 S_3 + a_3k S_k), gamma_k = coef_k (a_k3 S_k + a_3k S_3), coef_k = S_3 / (S_3^2 - S_k^2):
+  //   g_F = G - (a_33 u_3 + beta_0 u_0 + beta_1 u_1) v_3^T - u_3 (gamma_0 v_0 + gamma_1 v_1)^T
+  double Gv3[3], Gtu3[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    Gv3[r] = G[3 * r] * V[2] + G[3 * r + 1] * V[5] + G[3 * r + 2] * V[8];
+    Gtu3[r] = G[r] * U[2] + G[3 + r] * U[5] + G[6 + r] * U[8];
+  }
+  const double a33 = U[2] * Gv3[0] + U[5] * Gv3[1] + U[8] * Gv3[2];
   double gFm[9];
   {
-    const double a33 = UtGV[8];
+    double pv[3], qv[3];
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) gFm[3 * r + c] = G[3 * r + c] - a33 * U[3 * r + 2] * V[3 * c + 2];
+    for (int r = 0; r < 3; ++r) { pv[r] = a33 * U[3 * r + 2]; qv[r] = 0.0; }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const double coef = S[2] * fast_rcp(guard_den(S[2] * S[2] - S[k] * S[k]));
-      const double ak3 = UtGV[3 * k + 2];  // u_k^T G v_3
-      const double a3k = UtGV[6 + k];      // u_3^T G v_k
+      const double ak3 = U[k] * Gv3[0] + U[3 + k] * Gv3[1] + U[6 + k] * Gv3[2];      // u_k^T G v_3
+      const double a3k = Gtu3[0] * V[k] + Gtu3[1] * V[3 + k] + Gtu3[2] * V[6 + k];  // u_3^T G v_k
+      const double beta = coef * (ak3 * S[2] + a3k * S[k]), gamma = coef * (ak3 * S[k] + a3k * S[2]);
 #pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const double ukv3 = U[3 * r + k] * V[3 * c + 2], u3vk = U[3 * r + 2] * V[3 * c + k];
-          gFm[3 * r + c] -= coef * (ak3 * (S[2] * ukv3 + S[k] * u3vk) + a3k * (S[2] * u3vk + S[k] * ukv3));
-        }
+      for (int r = 0; r < 3; ++r) { pv[r] += beta * U[3 * r + k]; qv[r] += gamma * V[3 * r + k]; }
     }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gFm[3 * r + c] = G[3 * r + c] - pv[r] * V[3 * c + 2] - U[3 * r + 2] * qv[c];
   }
   // g_f and the eigenvector adjoint
   double gf[9], u[9];
