@@ -139,8 +139,8 @@ floss_kernel(const float* __restrict__ F_layers, int L, int B, const float* __re
           accf += fminf(e.d, clamp_at);
         }
       }
-      const double acc = wave_sum((double)accf);
-      if (lane == 0) loss_sum[(size_t)l * B + pair] = (float)acc;
+      const float acc = wave_sum(accf);  // <= 128 terms of at most clamp_at each: fp32 like the reference's own sum
+      if (lane == 0) loss_sum[(size_t)l * B + pair] = acc;
     } else {
       float gof[9];  // per-lane partial sums in fp32 (like the reference's backward); scaled and combined in fp64 below
 #pragma unroll
@@ -154,15 +154,18 @@ floss_kernel(const float* __restrict__ F_layers, int L, int B, const float* __re
             const float sg = (e.dd > 0.0f) ? 1.0f : ((e.dd < 0.0f) ? -1.0f : 0.0f);
             const float k1 = (e.n1 > 0.0f) ? ad * e.i1 * e.i1 * __builtin_amdgcn_rcpf(e.n1) : 0.0f;
             const float k2 = (e.n2 > 0.0f) ? ad * e.i2 * e.i2 * __builtin_amdgcn_rcpf(e.n2) : 0.0f;
+            // d d / d F[r][c] = sg S x2[r] x1[c] - k1 l1[c] x2[r] [c<2] - k2 l2[r] x1[c] [r<2]
+            //                 = x2[r] a[c] - b[r] x1[c],  a[c] = sg S x1[c] - k1 l1[c] [c<2],  b[r] = k2 l2[r] [r<2]
+            const float sS = sg * S;
+            const float a0 = fmaf(sS, x1[0], -k1 * e.l1[0]), a1 = fmaf(sS, x1[1], -k1 * e.l1[1]), a2 = sS * x1[2];
+            const float b0 = k2 * e.l2[0], b1 = k2 * e.l2[1];
+            const float av[3] = {a0, a1, a2};
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-              for (int c = 0; c < 3; ++c) {
-                float t = sg * S * x2[r] * x1[c];
-                if (c < 2) t -= k1 * e.l1[c] * x2[r];
-                if (r < 2) t -= k2 * e.l2[r] * x1[c];
-                gof[3 * r + c] += t;
-              }
+            for (int c = 0; c < 3; ++c) {
+              gof[c] += fmaf(x2[0], av[c], -b0 * x1[c]);
+              gof[3 + c] += fmaf(x2[1], av[c], -b1 * x1[c]);
+              gof[6 + c] = fmaf(x2[2], av[c], gof[6 + c]);
+            }
           }
         };
         if (CACHED) {
