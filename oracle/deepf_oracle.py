@@ -21,7 +21,7 @@ All ``file:line`` citations are into /root/reference/deepFEPE/.
 from __future__ import annotations
 
 import math
-from typing import Callable, Dict, List, Optional, Sequence, Tuple
+from typing import Callable, Dict, Optional, Sequence, Tuple
 
 import numpy as np
 import torch

@@ -3,7 +3,7 @@ The per-sample reference functions (_R_to_q :58-86, _l2_error :165-167, rot12_to
 vector_angle :175-179) are evaluated inside the pose kernel; these wrappers expose them for single matrices too."""
 import torch
 
-from .. import _lib, ops
+from .. import ops
 
 
 def _as_batch(x, shape):

@@ -2,7 +2,7 @@
 arithmetic is entirely in libdfepe_hip.so)."""
 from __future__ import annotations
 
-from typing import Optional, Sequence, Tuple
+from typing import Optional
 
 import torch
 

@@ -1,6 +1,6 @@
 """Timing of the match-construction row (nn_match_two_way + gather) against its MFMA roofline and the oracle on the host."""
 import importlib, os, sys, time
-import numpy as np, torch
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 d = importlib.import_module("pytorch-deepfepe_amd")
 oracle = importlib.import_module("oracle.deepf_oracle")

@@ -102,7 +102,6 @@ def smallest_eigvec4(S, iters=12):
 if __name__ == "__main__":
     d = importlib.import_module("pytorch-deepfepe_amd")
     oracle = importlib.import_module("oracle.deepf_oracle")
-    import torch
     sc = d.synth.make_scene(8, 1000, seed=0, outlier_ratio=0.25, noise_px=0.5)
     mats, meta = [], []
     for b in range(8):

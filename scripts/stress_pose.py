@@ -1,6 +1,6 @@
 """One-off randomized sweep of the pose loss (forward + adjoint) against the fp64 oracle for hard inputs: exact essential
 matrices (s1 = s2), noisy ones, arbitrary 3x3 matrices, tiny and huge scales."""
-import importlib, os, sys, time
+import importlib, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 d = importlib.import_module("pytorch-deepfepe_amd")

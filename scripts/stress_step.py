@@ -1,6 +1,6 @@
 """One-off randomized sweep of the whole training step (fwd + bwd) against the fp64 oracle."""
 import importlib, os, sys, time
-import numpy as np, torch
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 d = importlib.import_module("pytorch-deepfepe_amd")
 oracle = importlib.import_module("oracle.deepf_oracle")

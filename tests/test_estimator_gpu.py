@@ -1,6 +1,5 @@
 """'Next' row f-1: the fused evaluation of the weight estimator (channel-major GEMMs + one HIP pass for
 InstanceNorm+LeakyReLU) against the stock PyTorch module with the same parameters.  GPU box only."""
-import numpy as np
 import pytest
 import torch
 
