@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 
@@ -80,3 +81,32 @@ def test_synth_scene_conventions(dfepe, oracle):
     pose = oracle.rt_loss([sc["E_gt"]], sc["delta_Rtijs_4_4"], sc["qs_cam"], sc["ts_cam"])
     assert pose["q_l2"].max() < 1e-7 and pose["t_l2"].max() < 1e-7
     assert pose["R_deg"].max() < 1e-4 and pose["t_deg"].max() < 1e-2
+
+
+def test_compat_surface_without_a_gpu(dfepe):
+    """Host-side contract of the compat layer that needs no device: constructor signatures, state_dict keys, the branches
+    that are deliberately not built, argument checks that the reference also makes on the host."""
+    C = dfepe.compat
+    with pytest.raises(NotImplementedError):
+        C.DeepFNet.Fit(normalize_SVD=False)
+    for flag in ("if_goodCorresArch", "if_tri_depth", "if_des"):
+        with pytest.raises(NotImplementedError):
+            C.DeepFNet.DeepFNet(depth=2, image_size=[376, 1241, 3], if_quality=False, **{flag: True})
+    # extra keyword arguments of train_good.py (img_zoom_xy, if_img_des_to_pointnet, ...) are swallowed like in the reference
+    net = C.DeepFNet.DeepFNet(depth=3, image_size=[376, 1241, 3], if_quality=False, img_zoom_xy=(1.0, 1.0), if_img_feat=False,
+                              if_cpu_svd=True)
+    keys = list(net.state_dict().keys())
+    assert any(k.startswith("input_weights.fw.") for k in keys) and any(k.startswith("update_weights.fw.") for k in keys)
+    with pytest.raises(NotImplementedError):
+        C.train_good_utils.get_all_loss_DeepF({}, None, None, None, {"if_tri_depth": True})
+    with pytest.raises(dfepe.DfepeError):  # CPU tensors: refused, not silently computed elsewhere
+        net({"matches_xy_ori": torch.zeros(2, 16, 4), "matches_good_unique_nums": None, "t_scene_scale": None})
+    tr = C.model_wrap.PointTracker(max_length=2, nn_thresh=0.7)
+    assert tr.nn_thresh == 0.7
+    with pytest.raises(ValueError):
+        C.model_wrap.PointTracker(max_length=1)
+    assert tr.nn_match_two_way(np.zeros((8, 0)), np.zeros((8, 5)), 0.7).shape == (3, 0)   # empty side: [3,0] like the reference
+    with pytest.raises(ValueError):
+        tr.nn_match_two_way(np.ones((8, 3)), np.ones((8, 5)), -0.1)
+    with pytest.raises(AssertionError):
+        C.utils_misc.crop_or_pad_choice(5, 0)
