@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFEPE_VERSION 111 /* 0.1.1 */
+#define DFEPE_VERSION 120 /* 0.2.0 */
 
 #define DFEPE_OK 0
 #define DFEPE_ERR_INVALID_ARG (-1) /* null pointer, non-positive size, bad flag combination   */
@@ -53,9 +53,23 @@ extern "C" {
 #define DFEPE_W8PT_NO_HARTLEY 32u /* no Hartley normalisation, T1 = T2 = I (`normalize=False` of _E_from_XY /
                                      _F_from_XY, utils_F.py:116-119,233-236)                                 */
 
+#define DFEPE_W8PT_WAVE_PER_PAIR 64u /* scheduling only, same function: use the one-wavefront-per-pair kernels even where the
+                                        row-per-pair kernels (N <= DFEPE_W8PT16_MAX_N: one 16-lane DPP row per pair, four
+                                        pairs per wavefront) would be chosen; pass the same bit to dfepe_w8pt_bwd, whose
+                                        `save` record format follows the forward kernel                              */
+#define DFEPE_W8PT_ALL_FLAGS 127u   /* any other bit in `flags` is DFEPE_ERR_INVALID_ARG                              */
+#define DFEPE_W8PT16_MAX_N 128      /* largest N served by the row-per-pair kernels                                   */
+
 int dfepe_version(void);
 const char *dfepe_strerror(int code);
 int dfepe_save_floats(void);
+
+/* Self-test of the 16-lane row primitives the small-N solver kernels are built on (DPP row_newbcast / row_mirror /
+ * row_half_mirror / quad_perm; pytorch-deepfepe_amd/csrc/rowgroup.h).  One wavefront: x, y [64] doubles in,
+ * out [14][64] doubles: bcast<0>, bcast<5>, bcast<15>, row sum, sum of lanes 2..8, exchange partners 15-l, l^7, l^2, l^1,
+ * fp32 row max, int32 row sum (of (int)(16 x)), y + bcast<3>(x) y, fp32 row sum, fp32 bcast<9> + int bcast<12> + lane id.
+ * No counterpart in the reference; tests/test_rowgroup_gpu.py checks the hardware against these definitions. */
+int dfepe_selftest_rowgroup(const double *x, const double *y, double *out, void *stream);
 
 /*
  * Weighted normalised 8-point fit, forward.

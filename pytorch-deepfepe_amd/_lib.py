@@ -19,12 +19,15 @@ W8PT_SQRT2 = 4
 W8PT_NO_ROWNORM = 8
 W8PT_FORCE_110 = 16
 W8PT_NO_HARTLEY = 32
+W8PT_WAVE_PER_PAIR = 64
+W8PT16_MAX_N = 128
 
 _P = c_void_p
 _SIGNATURES = {
     "dfepe_version": (c_int, []),
     "dfepe_strerror": (c_char_p, [c_int]),
     "dfepe_save_floats": (c_int, []),
+    "dfepe_selftest_rowgroup": (c_int, [_P, _P, _P, _P]),
     "dfepe_w8pt_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_uint, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     "dfepe_w8pt_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_uint, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dfepe_floss_fwd": (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, c_float, _P, _P, _P]),

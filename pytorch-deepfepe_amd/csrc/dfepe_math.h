@@ -1,0 +1,331 @@
+// Scalar math helpers shared by the dfepe kernels: fp64 reciprocal / square root from the fp32 hardware seeds, the
+// design-matrix row of one correspondence, 3x3 products and the 3x3 Jacobi SVDs.  Pure per-lane C++: the only
+// primitives it needs are hw_rsq / hw_rcp (v_rsq_f32 / v_rcp_f32), which rowgroup.h provides.
+#pragma once
+#include <math.h>
+
+// fp64 reciprocal square root / reciprocal from the fp32 hardware approximation plus Newton-Raphson in fp64:
+// one step takes the 1e-7 seed to ~2e-14 relative, two steps to full fp64.  ~6-10 instructions instead of the ~30
+// of the IEEE sqrt/div expansions.  Arguments outside the fp32 range fall back to the exact routines.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  if (!(x > 1e-30 && x < 1e30)) return 1.0 / sqrt(x);
+  double y = (double)hw_rsq((float)x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+  const double ax = fabs(x);
+  if (!(ax > 1e-30 && ax < 1e30)) return 1.0 / x;
+  double y = (double)hw_rcp((float)x);
+  y = y * (2.0 - x * y);
+  y = y * (2.0 - x * y);
+  return y;
+}
+__device__ __forceinline__ double fast_sqrt(double x) { return (x > 0.0) ? x * fast_rsqrt(x) : 0.0; }
+
+// Branch-free variants for operands whose magnitude lies in the fp32 exponent range (everything the solver forms from
+// normalised coordinates and unit-trace matrices does): fp32 hardware seed on a clamped copy, Newton-Raphson in fp64
+// on the true operand.  STEPS = 1 gives ~1e-14 relative, 2 full fp64.  No range test, hence no divergent fall-back path:
+// outside the range the result is finite garbage (0 * seed), never NaN.
+template <int STEPS>
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = (double)hw_rsq(fminf(fmaxf((float)x, 1e-37f), 1e37f));
+#pragma unroll
+  for (int k = 0; k < STEPS; ++k) y = y * fma(-0.5 * x, y * y, 1.5);
+  return y;
+}
+template <int STEPS>
+__device__ __forceinline__ double sqrt_nr(double x) { return x * rsqrt_nr<STEPS>(x); }  // 0 for x = 0
+template <int STEPS>
+__device__ __forceinline__ double rcp_nr(double x) {
+  const float xf = (float)x;
+  double y = (double)hw_rcp(copysignf(fminf(fmaxf(fabsf(xf), 1e-37f), 1e37f), xf));
+#pragma unroll
+  for (int k = 0; k < STEPS; ++k) y = y * fma(-x, y, 2.0);
+  return y;
+}
+
+// One correspondence in image-size-normalised homogeneous coordinates.
+struct Pt {
+  float x1, y1, z1, x2, y2, z2;
+};
+
+// Unit row of the design matrix: ph = p / max(|p|, 1e-12) with p = [x2~ a, y2~ a, a], a = (x1~, y1~, z1)
+// (DeepFNet.py:203-212), fp64.  Returns false (and a zero row) for non-finite rows.
+__device__ __forceinline__ bool unit_row(const Pt& p, double s1, double c1x, double c1y, double s2, double c2x,
+                                         double c2y, double* ph) {
+  const double z1 = p.z1, z2 = p.z2;
+  const double a0 = s1 * ((double)p.x1 - c1x * z1), a1 = s1 * ((double)p.y1 - c1y * z1), a2 = z1;
+  const double b0 = s2 * ((double)p.x2 - c2x * z2), b1 = s2 * ((double)p.y2 - c2y * z2);
+  const double n2 = (a0 * a0 + a1 * a1 + a2 * a2) * (b0 * b0 + b1 * b1 + 1.0);
+  const bool ok = n2 < 1e300;
+  const double inv = ok ? ((n2 > 1e-24) ? fast_rsqrt(n2) : 1e12) : 0.0;  // 1 / max(|p|, 1e-12)
+  const double ia0 = ok ? a0 * inv : 0.0, ia1 = ok ? a1 * inv : 0.0, ia2 = ok ? a2 * inv : 0.0;
+  ph[0] = b0 * ia0; ph[1] = b0 * ia1; ph[2] = b0 * ia2;
+  ph[3] = b1 * ia0; ph[4] = b1 * ia1; ph[5] = b1 * ia2;
+  ph[6] = ia0;      ph[7] = ia1;      ph[8] = ia2;
+  if (!ok) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ph[k] = 0.0;
+  }
+  return ok;
+}
+
+// 3x3 helpers on row-major arrays -------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void mat3_mul(const T* A, const T* B, T* C) {  // C = A B
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) C[r * 3 + c] = A[r * 3] * B[c] + A[r * 3 + 1] * B[3 + c] + A[r * 3 + 2] * B[6 + c];
+}
+template <typename T>
+__device__ __forceinline__ void mat3_mul_tn(const T* A, const T* B, T* C) {  // C = A^T B
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) C[r * 3 + c] = A[r] * B[c] + A[3 + r] * B[3 + c] + A[6 + r] * B[6 + c];
+}
+template <typename T>
+__device__ __forceinline__ void mat3_mul_nt(const T* A, const T* B, T* C) {  // C = A B^T
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) C[r * 3 + c] = A[r * 3] * B[c * 3] + A[r * 3 + 1] * B[c * 3 + 1] + A[r * 3 + 2] * B[c * 3 + 2];
+}
+
+// fp32 one-sided Jacobi SVD of a 3x3 matrix on the hardware transcendentals (v_rsq_f32 / v_rcp_f32, ~1 ulp):
+// same contract as svd3<float> below, ~50 instructions per rotation with two dependent transcendentals
+// (r = rsq(d^2+b^2); x = (1+|d| r)/2; y = rsq(x); c = x y; s = sgn(d) b r y / 2) and a division-free skip test.
+// Used for the rank-2 step of the solver, where the dropped triplet is re-measured in fp64 afterwards.
+__device__ inline void svd3_fast(const float* F, float* U, float* S, float* V) {
+  float G[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    G[i] = F[i];
+    V[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+  }
+  const float tol2 = 1e-14f;  // (1e-7)^2: columns are orthogonal to fp32 round-off
+  for (int sweep = 0; sweep < 10; ++sweep) {
+    bool any = false, big = false;
+#pragma unroll
+    for (int pq = 0; pq < 3; ++pq) {
+      const int p = (pq == 2) ? 1 : 0;
+      const int q = (pq == 0) ? 1 : 2;
+      const float al = fmaf(G[p], G[p], fmaf(G[3 + p], G[3 + p], G[6 + p] * G[6 + p]));
+      const float be = fmaf(G[q], G[q], fmaf(G[3 + q], G[3 + q], G[6 + q] * G[6 + q]));
+      const float ga = fmaf(G[p], G[q], fmaf(G[3 + p], G[3 + q], G[6 + p] * G[6 + q]));
+      const float gg = ga * ga, ab = al * be;
+      const bool rot = gg > tol2 * ab;
+      any = any || rot;
+      big = big || (gg > 1e-9f * ab);
+      const float d = be - al, b = 2.0f * ga;
+      const float r = hw_rsq(fmaf(d, d, b * b));
+      const float x = fmaf(0.5f * fabsf(d), r, 0.5f);
+      const float y = hw_rsq(x);
+      const float c = rot ? x * y : 1.0f;
+      const float s = rot ? copysignf(0.5f, d) * b * r * y : 0.0f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float gp = G[3 * k + p], gq = G[3 * k + q];
+        G[3 * k + p] = fmaf(c, gp, -s * gq);
+        G[3 * k + q] = fmaf(s, gp, c * gq);
+        const float vp = V[3 * k + p], vq = V[3 * k + q];
+        V[3 * k + p] = fmaf(c, vp, -s * vq);
+        V[3 * k + q] = fmaf(s, vp, c * vq);
+      }
+    }
+    // cosines below 3e-5 are squared by the sweep that just ran (quadratic convergence): nothing left above tol
+    if (!big) break;
+  }
+  float n2[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) n2[k] = fmaf(G[k], G[k], fmaf(G[3 + k], G[3 + k], G[6 + k] * G[6 + k]));
+#define DFEPE_SWAPCOL(a, b)                                      \
+  if (n2[a] < n2[b]) {                                           \
+    float tn = n2[a]; n2[a] = n2[b]; n2[b] = tn;                 \
+    _Pragma("unroll") for (int r = 0; r < 3; ++r) {              \
+      float tg = G[3 * r + a]; G[3 * r + a] = G[3 * r + b]; G[3 * r + b] = tg; \
+      float tv = V[3 * r + a]; V[3 * r + a] = V[3 * r + b]; V[3 * r + b] = tv; \
+    }                                                            \
+  }
+  DFEPE_SWAPCOL(0, 1)
+  DFEPE_SWAPCOL(1, 2)
+  DFEPE_SWAPCOL(0, 1)
+#undef DFEPE_SWAPCOL
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float inv = hw_rsq(fmaxf(n2[k], 1e-36f));
+    U[k] = G[k] * inv; U[3 + k] = G[3 + k] * inv; U[6 + k] = G[6 + k] * inv;
+    S[k] = n2[k] * inv;
+  }
+  S[2] = (n2[2] > 0.0f) ? n2[2] * hw_rsq(n2[2]) : 0.0f;
+  {
+    const float dt = U[0] * U[1] + U[3] * U[4] + U[6] * U[7];
+    const float a0 = U[1] - dt * U[0], a1 = U[4] - dt * U[3], a2 = U[7] - dt * U[6];
+    const float inv = hw_rsq(fmaxf(a0 * a0 + a1 * a1 + a2 * a2, 1e-36f));
+    U[1] = a0 * inv; U[4] = a1 * inv; U[7] = a2 * inv;
+  }
+  const float c0 = U[3] * U[7] - U[6] * U[4];
+  const float c1 = U[6] * U[1] - U[0] * U[7];
+  const float c2 = U[0] * U[4] - U[3] * U[1];
+  const float sg = (c0 * G[2] + c1 * G[5] + c2 * G[8] < 0.0f) ? -1.0f : 1.0f;
+  U[2] = sg * c0; U[5] = sg * c1; U[8] = sg * c2;
+}
+
+__device__ __forceinline__ double svd_rsqrt(double x) { return fast_rsqrt(x); }
+__device__ __forceinline__ float svd_rsqrt(float x) { return hw_rsq(x); }
+
+// One-sided (Hestenes) Jacobi SVD of a 3x3 matrix: F = U diag(S) V^T, S descending, S[2] >= 0 given the
+// orientation chosen for u3.  U, V row-major with singular vectors in columns.  Straight-line code on
+// values in registers; `T` is float (forward rank-2 step, backward bookkeeping) or double (pose kernels).
+template <typename T>
+__device__ inline void svd3(const T* F, T* U, T* S, T* V) {
+  T G[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    G[i] = F[i];
+    V[i] = (i % 4 == 0) ? T(1) : T(0);
+  }
+  const T tol = (sizeof(T) == 4) ? T(1e-7) : T(1e-15);
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    T worst = T(0);
+#pragma unroll
+    for (int pq = 0; pq < 3; ++pq) {
+      const int p = (pq == 2) ? 1 : 0;
+      const int q = (pq == 0) ? 1 : 2;
+      T al = G[p] * G[p] + G[3 + p] * G[3 + p] + G[6 + p] * G[6 + p];
+      T be = G[q] * G[q] + G[3 + q] * G[3 + q] + G[6 + q] * G[6 + q];
+      T ga = G[p] * G[q] + G[3 + p] * G[3 + q] + G[6 + p] * G[6 + q];
+      const bool rot = ga * ga > tol * tol * al * be;  // division-free skip test
+      worst = rot ? T(1) : worst;
+      if (rot) {
+        // r = 1/h, h = sqrt(d^2+b^2); x = (1 + |d|/h)/2 = cos^2; c = sqrt(x), s = sgn(d) b / (2 h c)
+        const T d = be - al, b = T(2) * ga;
+        const T rh = svd_rsqrt(d * d + b * b);
+        const T x = T(0.5) + T(0.5) * fabs(d) * rh;
+        const T y = svd_rsqrt(x);
+        const T c = x * y;
+        const T s = copysign(T(0.5), d) * b * rh * y;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          T gp = G[3 * r + p], gq = G[3 * r + q];
+          G[3 * r + p] = c * gp - s * gq;
+          G[3 * r + q] = s * gp + c * gq;
+          T vp = V[3 * r + p], vq = V[3 * r + q];
+          V[3 * r + p] = c * vp - s * vq;
+          V[3 * r + q] = s * vp + c * vq;
+        }
+      }
+    }
+    if (worst == T(0)) break;
+  }
+  T n[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) n[k] = sqrt(G[k] * G[k] + G[3 + k] * G[3 + k] + G[6 + k] * G[6 + k]);
+  // sort columns descending (3-element network)
+#define DFEPE_SWAPCOL(a, b)                                   \
+  if (n[a] < n[b]) {                                          \
+    T tn = n[a]; n[a] = n[b]; n[b] = tn;                      \
+    _Pragma("unroll") for (int r = 0; r < 3; ++r) {           \
+      T tg = G[3 * r + a]; G[3 * r + a] = G[3 * r + b]; G[3 * r + b] = tg; \
+      T tv = V[3 * r + a]; V[3 * r + a] = V[3 * r + b]; V[3 * r + b] = tv; \
+    }                                                         \
+  }
+  DFEPE_SWAPCOL(0, 1)
+  DFEPE_SWAPCOL(1, 2)
+  DFEPE_SWAPCOL(0, 1)
+#undef DFEPE_SWAPCOL
+  const T tiny = T(1e-30);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    T inv = T(1) / fmax(n[k], tiny);
+    U[k] = G[k] * inv;
+    U[3 + k] = G[3 + k] * inv;
+    U[6 + k] = G[6 + k] * inv;
+  }
+  // u2 re-orthogonalised against u1 (matters only when s2 is tiny), u3 = u1 x u2 oriented along g3
+  {
+    T d = U[0] * U[1] + U[3] * U[4] + U[6] * U[7];
+    T a0 = U[1] - d * U[0], a1 = U[4] - d * U[3], a2 = U[7] - d * U[6];
+    T inv = T(1) / fmax(sqrt(a0 * a0 + a1 * a1 + a2 * a2), tiny);
+    U[1] = a0 * inv; U[4] = a1 * inv; U[7] = a2 * inv;
+  }
+  T c0 = U[3] * U[7] - U[6] * U[4];
+  T c1 = U[6] * U[1] - U[0] * U[7];
+  T c2 = U[0] * U[4] - U[3] * U[1];
+  T sg = (c0 * G[2] + c1 * G[5] + c2 * G[8] < T(0)) ? T(-1) : T(1);
+  U[2] = sg * c0; U[5] = sg * c1; U[8] = sg * c2;
+  S[0] = n[0]; S[1] = n[1]; S[2] = n[2];
+}
+
+// ---- smallest singular triplet of a 3x3 matrix in closed form (fp64) -----------------------------------------------
+// The rank-2 step of the solver (DeepFNet.py:236-237) only drops the smallest singular triplet: F' = F - s3 u3 v3^T.
+// v3 / u3 are the null vectors of F^T F - lam I / F F^T - lam I, lam = s3^2 the smallest root of the characteristic
+// cubic: Newton from 0 converges monotonically from below (all roots real, p > 0, p' < 0, p'' > 0 left of the smallest
+// one), and the null vector of a rank-2 symmetric 3x3 is the largest cross product of two of its rows.  s3 = u3^T F v3 is
+// stationary w.r.t. first-order errors of the vectors.  ~250 straight-line instructions instead of a Jacobi SVD.
+__device__ __forceinline__ void sym3_null_vector(double c00, double c01, double c02, double c11, double c12, double c22, double* n) {
+  // rows r0 = (c00,c01,c02), r1 = (c01,c11,c12), r2 = (c02,c12,c22)
+  const double a0 = c01 * c12 - c02 * c11, a1 = c02 * c01 - c00 * c12, a2 = c00 * c11 - c01 * c01;  // r0 x r1
+  const double b0 = c01 * c22 - c02 * c12, b1 = c02 * c02 - c00 * c22, b2 = c00 * c12 - c01 * c02;  // r0 x r2
+  const double d0 = c11 * c22 - c12 * c12, d1 = c12 * c02 - c01 * c22, d2 = c01 * c12 - c11 * c02;  // r1 x r2
+  const double na = a0 * a0 + a1 * a1 + a2 * a2, nb = b0 * b0 + b1 * b1 + b2 * b2, nd = d0 * d0 + d1 * d1 + d2 * d2;
+  double x0 = a0, x1 = a1, x2 = a2, nx = na;
+  if (nb > nx) { x0 = b0; x1 = b1; x2 = b2; nx = nb; }
+  if (nd > nx) { x0 = d0; x1 = d1; x2 = d2; nx = nd; }
+  const double inv = (nx > 0.0) ? rsqrt_nr<2>(nx) : 0.0;
+  n[0] = x0 * inv; n[1] = x1 * inv; n[2] = x2 * inv;
+  if (!(nx > 0.0)) { n[0] = 0.0; n[1] = 0.0; n[2] = 1.0; }  // the zero matrix: any unit vector
+}
+
+// F row-major, assumed O(1) in magnitude (the solver passes a unit-Frobenius F).  Returns s3 >= 0, unit u3, v3.
+__device__ __forceinline__ void smallest_singular_triplet3(const double* F, double* u3, double* v3, double& s3) {
+  // B = F^T F
+  const double b00 = F[0] * F[0] + F[3] * F[3] + F[6] * F[6], b01 = F[0] * F[1] + F[3] * F[4] + F[6] * F[7];
+  const double b02 = F[0] * F[2] + F[3] * F[5] + F[6] * F[8], b11 = F[1] * F[1] + F[4] * F[4] + F[7] * F[7];
+  const double b12 = F[1] * F[2] + F[4] * F[5] + F[7] * F[8], b22 = F[2] * F[2] + F[5] * F[5] + F[8] * F[8];
+  const double c2 = b00 + b11 + b22;
+  const double c1 = (b00 * b11 - b01 * b01) + (b00 * b22 - b02 * b02) + (b11 * b22 - b12 * b12);
+  const double c0 = b00 * (b11 * b22 - b12 * b12) - b01 * (b01 * b22 - b12 * b02) + b02 * (b01 * b12 - b11 * b02);
+  double x = 0.0;
+  for (int it = 0; it < 12; ++it) {
+    const double p = fma(fma(c2 - x, x, -c1), x, c0);            // -x^3 + c2 x^2 - c1 x + c0
+    const double dp = fma(fma(-3.0, x, 2.0 * c2), x, -c1);       // p'(x) < 0 left of the smallest root
+    const double dx = (dp < 0.0) ? -p * rcp_nr<2>(dp) : 0.0;
+    if (!(dx > 1e-17 * c2)) break;                                // also leaves on NaN; p <= 0: at (or rounded past) the root
+    x += dx;
+  }
+  sym3_null_vector(b00 - x, b01, b02, b11 - x, b12, b22 - x, v3);
+  // D = F F^T
+  const double d00 = F[0] * F[0] + F[1] * F[1] + F[2] * F[2], d01 = F[0] * F[3] + F[1] * F[4] + F[2] * F[5];
+  const double d02 = F[0] * F[6] + F[1] * F[7] + F[2] * F[8], d11 = F[3] * F[3] + F[4] * F[4] + F[5] * F[5];
+  const double d12 = F[3] * F[6] + F[4] * F[7] + F[5] * F[8], d22 = F[6] * F[6] + F[7] * F[7] + F[8] * F[8];
+  sym3_null_vector(d00 - x, d01, d02, d11 - x, d12, d22 - x, u3);
+  double s = 0.0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s += u3[r] * F[3 * r + c] * v3[c];
+  if (s < 0.0) { s = -s; u3[0] = -u3[0]; u3[1] = -u3[1]; u3[2] = -u3[2]; }
+  s3 = s;
+}
+
+// y = C^+ x for a symmetric 3x3 C (6 distinct entries) with unit null vector n: (C + n n^T)^-1 (x - n (n.x)) by the
+// adjugate.  A second (near-)null direction gives a large-but-finite result, never NaN.
+__device__ __forceinline__ void sym3_pinv_apply(double c00, double c01, double c02, double c11, double c12, double c22,
+                                                const double* n, const double* x, double* y) {
+  const double nx = n[0] * x[0] + n[1] * x[1] + n[2] * x[2];
+  const double r0 = x[0] - nx * n[0], r1 = x[1] - nx * n[1], r2 = x[2] - nx * n[2];
+  const double m00 = c00 + n[0] * n[0], m01 = c01 + n[0] * n[1], m02 = c02 + n[0] * n[2];
+  const double m11 = c11 + n[1] * n[1], m12 = c12 + n[1] * n[2], m22 = c22 + n[2] * n[2];
+  const double k00 = m11 * m22 - m12 * m12, k01 = m02 * m12 - m01 * m22, k02 = m01 * m12 - m02 * m11;
+  const double k11 = m00 * m22 - m02 * m02, k12 = m01 * m02 - m00 * m12, k22 = m00 * m11 - m01 * m01;
+  double det = m00 * k00 + m01 * k01 + m02 * k02;
+  det = (fabs(det) < 1e-30) ? ((det < 0.0) ? -1e-30 : 1e-30) : det;
+  const double idet = rcp_nr<2>(det);
+  y[0] = (k00 * r0 + k01 * r1 + k02 * r2) * idet;
+  y[1] = (k01 * r0 + k11 * r1 + k12 * r2) * idet;
+  y[2] = (k02 * r0 + k12 * r1 + k22 * r2) * idet;
+}

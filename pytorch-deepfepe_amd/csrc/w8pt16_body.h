@@ -1,0 +1,547 @@
+// w8pt16 -- weighted normalised 8-point fit with ONE 16-LANE ROW PER IMAGE PAIR (four pairs per wavefront), N <= 128.
+//
+// Same arithmetic contract as w8pt_fwd.hip (which keeps serving large N):
+//   NormalizeAndExpand_HW   deepFEPE/models/DeepFNet.py:93-120   (fused when RAW)
+//   Fit.normalize           deepFEPE/models/DeepFNet.py:148-179  (Hartley, unit weights, literal 1.4142)
+//   Fit.weighted_svd        deepFEPE/models/DeepFNet.py:181-257
+//   compute_epi_residual    deepFEPE/dsac_tools/utils_F.py:400-413
+// restated from SURVEY.md Appendix A, not from the reference source.
+//
+// Why a row: with a wavefront per pair, everything that is uniform over the pair (selection, rank-2 step, Hartley
+// bookkeeping, every scalar recurrence) was issued for 64 lanes, and the 9x9 eigenproblem went through ~41 dependent LDS
+// round trips of a systolic Jacobi.  Here
+//   * the pair's (at most 128) correspondences stay in the registers of its 16 lanes for the whole kernel: one HBM read,
+//     no LDS staging;
+//   * the 36 distinct fp64 moment sums are reduce-scattered inside the row with DPP (35 exchanges);
+//   * the solver needs ONE eigenpair of M = X^T X, so the Jacobi is replaced by an fp64 tridiagonal route with no
+//     iteration that depends on the data's conditioning:
+//       Householder tridiagonalisation (lane i holds row i of M; broadcasts are row_newbcast DPP moves),
+//       the (skip+1)-th smallest eigenvalue by 16-way multisection on the division-free Sturm sequence (every lane of the
+//       row probes its own shift: 13 rounds shrink the bracket by 17^13 ~ 1e16),
+//       its eigenvector by twisted factorisation, back-transformed through the seven reflectors;
+//     everything is fp64 (full-rate on gfx950), so there is no fp32 sweep to polish and no cluster repair;
+//   * the backward (w8pt16_bwd_pair) applies (M - lam I)^+ through the same tridiagonal form saved here.
+// The bodies are written against rowgroup.h only, so tests/emu/ runs them on the host against the oracle.
+#pragma once
+#include <type_traits>
+
+#include "dfepe.h"
+#include <rowgroup.h>  // angle brackets on purpose: tests/emu/ substitutes its host emulation through the include path
+#include "dfepe_math.h"
+
+// ---- layout of the per-pair `save` record written by w8pt16_fwd_pair (floats; DFEPE_SAVE_FLOATS = 128) ----------
+#define S16_T1 0       // Hartley transform of image 1: s, cx, cy
+#define S16_T2 3       // Hartley transform of image 2
+#define S16_F 6        // 9: the oriented unit eigenvector f (largest-magnitude component positive)
+#define S16_Z 15       // 9: z = H^T f, the eigenvector of the tridiagonal T (same orientation)
+#define S16_TWIST 24   // twist index of the factorisation (largest-residual-free row), as float
+#define S16_HV 26      // 35: reflector k = 0..6, components k+1..8, at offset 8k - k(k-1)/2
+#define S16_HB 61      // 7: beta_k  (H_k = I - beta_k v_k v_k^T)
+#define S16_TD 68      // 9 doubles: diagonal of T  (T = H^T (M / trace M) H)
+#define S16_TE 86      // 8 doubles: off-diagonal of T
+#define S16_LAM 102    // 1 double: the selected eigenvalue of M / trace M
+#define S16_U3 104     // smallest singular triplet of F = reshape(f): u3 (3 floats)
+#define S16_V3 107     //                                              v3 (3 floats)
+#define S16_S3 110     //                                              s3 >= 0
+#define S16_INVTR 125  // 1 / trace(M)
+#define S16_TAG 127    // record format tag
+#define S16_TAG_VALUE 16.0f
+
+__host__ __device__ constexpr int s16_hv_off(int k) { return 8 * k - (k * (k - 1)) / 2; }
+
+struct W8Args {
+  const float* pts1;
+  const float* pts2;
+  const float* wts;
+  int B, Bm, N;
+  float hw_sx, hw_sy, clamp_at;
+  float* F_out;
+  float* residual;
+  float* epi_res;
+  float* save;
+  float* weights_out;
+  int logits_mode;
+  unsigned variant;
+};
+
+// phase markers for scripts/isa_phases.py (hipcc -DDFEPE_ISA_MARKS -S): comments in the assembly, nothing otherwise
+#ifdef DFEPE_ISA_MARKS
+#define DFEPE_MARK(name) asm volatile("; MARK " name)
+#else
+#define DFEPE_MARK(name)
+#endif
+
+template <int I, int E, class Fn>
+__device__ __forceinline__ void static_for(Fn&& fn) {
+  if constexpr (I < E) {
+    fn(std::integral_constant<int, I>{});
+    static_for<I + 1, E>(fn);
+  }
+}
+
+// One halving step of the in-row reduce-scatter: CNT live values per lane -> (CNT+1)/2.
+template <int CNT, int STEP>
+__device__ __forceinline__ void rg_halve(double* a, bool upper) {
+  constexpr int H = (CNT + 1) / 2;
+#pragma unroll
+  for (int k = 0; k < H; ++k) {
+    const double lo = a[k];
+    const double hi = (k + H < CNT) ? a[k + H] : 0.0;
+    const double send = upper ? lo : hi;
+    const double keep = upper ? hi : lo;
+    a[k] = keep + rg_xchg<STEP>(send);
+  }
+}
+
+// Number of eigenvalues below x of the symmetric tridiagonal (td, te), te2 = te^2: sign changes of the three-term
+// recurrence p_k = (d_k - x) p_{k-1} - e_{k-1}^2 p_{k-2}.  Division-free; with a unit-trace matrix |p_k| stays within
+// [1e-150, 1].  An exact zero counts as positive: its neighbours have opposite signs, so the count is the same.
+__device__ __forceinline__ int sturm_count(const double* td, const double* te2, double x) {
+  double pm2 = 1.0, pm1 = td[0] - x;
+  int cnt = (pm1 < 0.0) ? 1 : 0;
+#pragma unroll
+  for (int k = 1; k < 9; ++k) {
+    const double p = fma(td[k] - x, pm1, -(te2[k - 1] * pm2));
+    cnt += ((p < 0.0) != (pm1 < 0.0)) ? 1 : 0;
+    pm2 = pm1;
+    pm1 = p;
+  }
+  return cnt;
+}
+
+// Factors of one row of the design matrix: p = b (x) a with a = T1 x1, b = T2 x2 (b[2] = 1), p^ = inv * p,
+// inv = 1 / max(|p|, 1e-12) = 1 / max(|a| |b|, 1e-12)  (DeepFNet.py:203-212).  Returns false (row dropped) when the row is
+// not finite.  Branch-free; bilinear forms p^ . g = inv * b^T G a replace the explicit 9-vector wherever only dot products
+// of the row are needed.
+__device__ __forceinline__ bool row_factors(const Pt& p, double s1, double c1x, double c1y, double s2, double c2x, double c2y,
+                                            double* a, double* b, double& inv) {
+  const double z1 = p.z1, z2 = p.z2;
+  a[0] = s1 * ((double)p.x1 - c1x * z1); a[1] = s1 * ((double)p.y1 - c1y * z1); a[2] = z1;
+  b[0] = s2 * ((double)p.x2 - c2x * z2); b[1] = s2 * ((double)p.y2 - c2y * z2);
+  const double n2 = (a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) * (b[0] * b[0] + b[1] * b[1] + 1.0);
+  const bool ok = n2 < 1e300;
+  inv = ok ? ((n2 > 1e-24) ? rsqrt_nr<1>(n2) : 1e12) : 0.0;
+  return ok;
+}
+__device__ __forceinline__ double row_bilinear(const double* a, const double* b, const double* g) {  // b^T reshape(g) a
+  const double t0 = fma(g[0], a[0], fma(g[1], a[1], g[2] * a[2])), t1 = fma(g[3], a[0], fma(g[4], a[1], g[5] * a[2]));
+  const double t2 = fma(g[6], a[0], fma(g[7], a[1], g[8] * a[2]));
+  return fma(b[0], t0, fma(b[1], t1, t2));
+}
+
+__device__ __forceinline__ double pivot_guard(double q) { return (fabs(q) < 1e-30) ? -1e-30 : q; }
+
+// ---- the eigen phase shared by nothing but this kernel, kept separate for readability -----------------------------
+// In: Ar = row `l` of M / trace(M) (lanes 0..8; zeros elsewhere), kth = number of eigenvalues to pass over.
+// Out (uniform over the row): f[9] unit eigenvector (unoriented), z[9] its tridiagonal-space image, twist, lam, td, te;
+//      per lane: hv[k] = component l of reflector k; hb[k] uniform.
+__device__ __forceinline__ void eig9_select(double* Ar, const int l, const int kth, double* f, double* z, int& twist,
+                                            double& lam, double* td, double* te, double* hv, double* hb) {
+  // Householder tridiagonalisation, lower form: step k annihilates column k below the sub-diagonal
+  static_for<0, 7>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    td[k] = rg_bcast<k>(Ar[k]);
+    const double xk = (l > k) ? Ar[k] : 0.0;  // A[l][k] = A[k][l] (symmetric): the column below the diagonal
+    const double x1 = rg_bcast<k + 1>(xk);
+    const double sig = rg_sum_range<k + 2, 8>(xk * xk);
+    const double nrm = sqrt_nr<2>(fma(x1, x1, sig));
+    const bool ok = sig > 0.0;  // nothing to annihilate otherwise: H_k = I
+    const double alpha = (x1 > 0.0) ? -nrm : nrm;
+    const double vk1 = x1 - alpha;
+    const double vtv = fma(vk1, vk1, sig);
+    const double beta = ok ? 2.0 * rcp_nr<2>(vtv) : 0.0;
+    te[k] = ok ? alpha : x1;
+    hb[k] = beta;
+    const double v = ok ? ((l == k + 1) ? vk1 : ((l > k + 1) ? xk : 0.0)) : 0.0;
+    hv[k] = v;
+    // p = beta A v (rows > k), K = beta/2 v^T p, w = p - K v, A -= v w^T + w v^T
+    double p = 0.0;
+    static_for<k + 1, 9>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      p = rg_fma_bcast<j>(p, v, Ar[j]);
+    });
+    p = (l > k) ? p * beta : 0.0;
+    const double K = 0.5 * beta * rg_sum_range<k + 1, 8>(v * p);
+    const double w = fma(-K, v, p);
+    const double nv = -v, nw = -w;
+    static_for<k + 1, 9>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      Ar[j] = rg_fma_bcast<j>(Ar[j], w, nv);
+      Ar[j] = rg_fma_bcast<j>(Ar[j], v, nw);
+    });
+  });
+  td[7] = rg_bcast<7>(Ar[7]);
+  td[8] = rg_bcast<8>(Ar[8]);
+  te[7] = rg_bcast<8>(Ar[7]);
+
+  DFEPE_MARK("P4b_multisection");
+  // the (kth+1)-th smallest eigenvalue: 16-way multisection, lane l probes lo + (hi - lo)(l + 1)/17
+  double te2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) te2[k] = te[k] * te[k];
+  double lo = -1e-3, hi = 1.0 + 1e-3;  // unit trace, positive semi-definite: the spectrum lies in [0, 1]
+  const double frac = (double)(l + 1) * (1.0 / 17.0);
+  for (int round = 0; round < 13; ++round) {
+    const double wdt = hi - lo;
+    const int c = sturm_count(td, te2, fma(wdt, frac, lo));
+    const int m = rg_sum((c <= kth) ? 1 : 0);  // probes still below the wanted eigenvalue (counts are monotone in l)
+    const double step = wdt * (1.0 / 17.0);
+    lo = fma(step, (double)m, lo);
+    hi = lo + step;
+  }
+  lam = 0.5 * (lo + hi);
+
+  DFEPE_MARK("P4c_twisted");
+  // eigenvector of T by twisted factorisation: pivots from the top (dp) and from the bottom (dm), twist where
+  // gamma_k = dp_k + dm_k - (d_k - lam) is smallest in magnitude
+  double dp[9], dm[9], rp[9], rm[9];
+  dp[0] = td[0] - lam;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    dp[k] = pivot_guard(dp[k]);
+    rp[k] = rcp_nr<2>(dp[k]);
+    dp[k + 1] = (td[k + 1] - lam) - te2[k] * rp[k];
+  }
+  dm[8] = td[8] - lam;
+#pragma unroll
+  for (int k = 7; k >= 0; --k) {
+    dm[k + 1] = pivot_guard(dm[k + 1]);
+    rm[k + 1] = rcp_nr<2>(dm[k + 1]);
+    dm[k] = (td[k] - lam) - te2[k] * rm[k + 1];
+  }
+  twist = 0;
+  double gbest = fabs(dp[0] + dm[0] - (td[0] - lam));
+#pragma unroll
+  for (int k = 1; k < 9; ++k) {
+    const double g = fabs(dp[k] + dm[k] - (td[k] - lam));
+    if (g < gbest) { gbest = g; twist = k; }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) z[k] = (k == twist) ? 1.0 : 0.0;
+#pragma unroll
+  for (int k = 7; k >= 0; --k) z[k] = (k < twist) ? -(te[k] * rp[k]) * z[k + 1] : z[k];
+#pragma unroll
+  for (int k = 1; k < 9; ++k) z[k] = (k > twist) ? -(te[k - 1] * rm[k]) * z[k - 1] : z[k];
+  double zn = 0.0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) zn = fma(z[k], z[k], zn);
+  zn = rsqrt_nr<2>(zn);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { z[k] *= zn; f[k] = z[k]; }
+
+  DFEPE_MARK("P4d_backtransform");
+  // f = H_0 H_1 ... H_6 z, every lane keeps the whole vector (the reflector components come in by broadcast)
+  static_for<0, 7>([&](auto kc) {
+    constexpr int k = 6 - decltype(kc)::value;
+    double s = 0.0;
+    static_for<k + 1, 9>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      s = rg_fma_bcast<j>(s, hv[k], f[j]);
+    });
+    s *= -hb[k];
+    static_for<k + 1, 9>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      f[j] = rg_fma_bcast<j>(f[j], hv[k], s);
+    });
+  });
+}
+
+// ---- forward, one pair ---------------------------------------------------------------------------------------
+// IT = ceil(N / 16) correspondences per lane, kept in registers.  xch: 36 doubles of LDS owned by this pair.
+template <int IT, bool RAW>
+__device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair, double* xch) {
+  const int l = rg_lane();
+  const int N = A.N;
+  const unsigned variant = A.variant;
+  const size_t mp = (size_t)(pair % A.Bm);  // several weight sets may share one set of correspondences
+
+  DFEPE_MARK("P0");
+  // ---- phase 0: the pair's correspondences -> registers; softmax of the logits; coordinate sums ----------------
+  Pt pt[IT];
+  float wv[IT];
+  const float* wsrc = A.wts + (size_t)pair * N;
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int i = it * 16 + l;
+    const bool valid = i < N;
+    Pt p;
+    p.x1 = p.y1 = p.x2 = p.y2 = 0.0f;
+    p.z1 = p.z2 = 1.0f;
+    float w = A.logits_mode ? -INFINITY : 0.0f;
+    if (valid) {
+      if (RAW) {
+        const float4 m = reinterpret_cast<const float4*>(A.pts1)[mp * N + i];
+        p.x1 = fmaf(m.x, A.hw_sx, -1.0f);
+        p.y1 = fmaf(m.y, A.hw_sy, -1.0f);
+        p.x2 = fmaf(m.z, A.hw_sx, -1.0f);
+        p.y2 = fmaf(m.w, A.hw_sy, -1.0f);
+      } else {
+        const float* a = A.pts1 + (mp * N + i) * 3;
+        const float* b = A.pts2 + (mp * N + i) * 3;
+        p.x1 = a[0]; p.y1 = a[1]; p.z1 = a[2];
+        p.x2 = b[0]; p.y2 = b[1]; p.z2 = b[2];
+      }
+      w = wsrc[i];
+    }
+    pt[it] = p;
+    wv[it] = w;
+  }
+  if (A.logits_mode) {
+    // fused F.softmax(logits, dim=N) (DeepFNet.py:443,512)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) mx = fmaxf(mx, wv[it]);
+    mx = rg_max(mx);
+    float sm = 0.0f;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const float e = (it * 16 + l < N) ? expf(wv[it] - mx) : 0.0f;
+      wv[it] = e;
+      sm += e;
+    }
+    const float inv = 1.0f / rg_sum(sm);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      wv[it] *= inv;
+      const int i = it * 16 + l;
+      if (A.weights_out != nullptr && i < N) A.weights_out[(size_t)pair * N + i] = wv[it];
+    }
+  }
+  const bool hartley = (variant & DFEPE_W8PT_NO_HARTLEY) == 0;
+  const double invN = 1.0 / (double)N;
+  double c1x = 0.0, c1y = 0.0, c2x = 0.0, c2y = 0.0, s1 = 1.0, s2 = 1.0;
+  if (hartley) {
+    double sx1 = 0, sy1 = 0, sx2 = 0, sy2 = 0;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {  // lanes past N hold zeros
+      sx1 += (double)pt[it].x1; sy1 += (double)pt[it].y1; sx2 += (double)pt[it].x2; sy2 += (double)pt[it].y2;
+    }
+    c1x = rg_sum(sx1) * invN; c1y = rg_sum(sy1) * invN; c2x = rg_sum(sx2) * invN; c2y = rg_sum(sy2) * invN;
+  DFEPE_MARK("P1");
+    // ---- phase 1: Hartley scale (mean distance to the centroid) -------------------------------------------------
+    double d1 = 0, d2 = 0;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const bool valid = it * 16 + l < N;
+      const double ax = (double)pt[it].x1 - c1x, ay = (double)pt[it].y1 - c1y;
+      const double bx = (double)pt[it].x2 - c2x, by = (double)pt[it].y2 - c2y;
+      d1 += valid ? sqrt_nr<1>(ax * ax + ay * ay) : 0.0;
+      d2 += valid ? sqrt_nr<1>(bx * bx + by * by) : 0.0;
+    }
+    // Fit.normalize uses the literal 1.4142, not sqrt(2) (DeepFNet.py:168); utils_F._normalize_XY uses np.sqrt(2)
+    const double hscale = (variant & DFEPE_W8PT_SQRT2) ? 1.4142135623730951 : 1.4142;
+    s1 = hscale * rcp_nr<2>(rg_sum(d1) * invN);
+    s2 = hscale * rcp_nr<2>(rg_sum(d2) * invN);
+  }
+
+  DFEPE_MARK("P2");
+  // ---- phase 2: X^T X = sum_i k_i^2 (b b^T) (x) (a a^T): 36 distinct fp64 sums per lane ---------------------------
+  double acc[36];
+#pragma unroll
+  for (int e = 0; e < 36; ++e) acc[e] = 0.0;
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const Pt p = pt[it];
+    const double w = (double)wv[it];
+    const double z1 = p.z1, z2 = p.z2;
+    const double a0 = s1 * ((double)p.x1 - c1x * z1), a1 = s1 * ((double)p.y1 - c1y * z1), a2 = z1;
+    const double b0 = s2 * ((double)p.x2 - c2x * z2), b1 = s2 * ((double)p.y2 - c2y * z2);
+    const double n2 = (a0 * a0 + a1 * a1 + a2 * a2) * (b0 * b0 + b1 * b1 + 1.0);  // |p|^2
+    const bool ok = (n2 < 1e300) && (fabs(w) < 1e150) && (it * 16 + l < N);
+    // (w / max(|p|, 1e-12))^2
+    const double k2 = ok ? ((variant & DFEPE_W8PT_NO_ROWNORM) ? (w * w) : (w * w) * rcp_nr<2>(fmax(n2, 1e-24))) : 0.0;
+    const double aa[6] = {a0 * a0, a0 * a1, a0 * a2, a1 * a1, a1 * a2, a2 * a2};
+    const double bb[6] = {k2 * b0 * b0, k2 * b0 * b1, k2 * b0, k2 * b1 * b1, k2 * b1, k2};
+    if (ok) {
+#pragma unroll
+      for (int u = 0; u < 6; ++u)
+#pragma unroll
+        for (int v = 0; v < 6; ++v) acc[6 * u + v] = fma(bb[u], aa[v], acc[6 * u + v]);
+    }
+  }
+
+  DFEPE_MARK("P3");
+  // ---- phase 3: reduce-scatter inside the row (36 -> 18 -> 9 -> 5 -> 3 values per lane), M through LDS --------------
+  rg_halve<36, 8>(acc, (l & 8) != 0);
+  rg_halve<18, 4>(acc, (l & 4) != 0);
+  rg_halve<9, 2>(acc, (l & 2) != 0);
+  rg_halve<5, 1>(acc, (l & 1) != 0);
+  {
+    int cnt = 36, idx = 0, width = 36;  // mirror of the halving schedule: this lane ends up owning sums idx .. idx+cnt-1
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) {
+      const int h = (width + 1) / 2;
+      if (l & m) { idx += h; cnt -= h; } else { cnt = (cnt < h) ? cnt : h; }
+      width = h;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (k < cnt) xch[idx + k] = acc[k];
+  }
+  rg_sync();
+  // sum (u, v) is M[3r+c][3r'+c'] for (r, r') = symmetric pair u, (c, c') = symmetric pair v.  Lane i < 9 fetches row i.
+  double Ar[9];
+  double tr;
+  {
+    const int li = (l < 9) ? l : 0;
+    const int r = li / 3, c = li - 3 * r;
+    auto sym = [](int a, int b) { const int lo = (a < b) ? a : b, hi = (a < b) ? b : a; return (lo * (5 - lo)) / 2 + hi; };
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const int rj = j / 3, cj = j % 3;
+      const double m = xch[6 * sym(r, rj) + sym(c, cj)];
+      Ar[j] = (l < 9) ? m : 0.0;
+    }
+    const double dg = xch[6 * sym(r, r) + sym(c, c)];
+    tr = rg_sum_range<0, 8>(dg);
+  }
+  const double inv_tr = (tr > 0.0) ? rcp_nr<2>(tr) : 1.0;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) Ar[j] *= inv_tr;
+
+  DFEPE_MARK("P4");
+  // ---- phase 4: the eigenpair the reference picks --------------------------------------------------------------
+  // torch.svd(X)[2][:, -1] is the right singular vector of the smallest of the min(N,9) singular values
+  // (DeepFNet.py:232-233): for N >= 9 the smallest eigenvalue of X^T X; for N < 9 the reduced SVD has only N columns,
+  // so the reference takes the smallest of the N non-null directions: 9 - N eigenvalues are passed over.
+  const int kth = (N >= 9) ? 0 : 9 - N;
+  double f[9], z[9], td[9], te[8], hv[7], hb[7], lam;
+  int twist;
+  eig9_select(Ar, l, kth, f, z, twist, lam, td, te, hv, hb);
+
+  DFEPE_MARK("P5");
+  // ---- phase 5: orientation, rank-2 projection, de-normalisation (uniform over the row) -------------------------
+  double fn2 = 0.0;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) fn2 = fma(f[c], f[c], fn2);
+  double big = f[0];  // orientation: largest-magnitude component positive (first one on ties)
+#pragma unroll
+  for (int c = 1; c < 9; ++c)
+    if (fabs(f[c]) > fabs(big)) big = f[c];
+  const double sgn = (big < 0.0) ? -1.0 : 1.0;
+  const double fscale = sgn * rsqrt_nr<2>(fn2);
+#pragma unroll
+  for (int c = 0; c < 9; ++c) f[c] *= fscale;
+
+  DFEPE_MARK("P5b_rank2");
+  // rank-2 step: F' = F - s3 u3 v3^T with the smallest singular triplet in closed form (fp64)
+  double u3[3], v3[3], s3;
+  double Fp[9];
+  if (variant & DFEPE_W8PT_FORCE_110) {  // E' = U diag(1,1,0) V^T = u1 v1^T + u2 v2^T  (utils_F.py:148-149); forward-only variant
+    float Ff[9], U3[9], S3[3], V3[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) Ff[c] = (float)f[c];
+    svd3_fast(Ff, U3, S3, V3);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        Fp[3 * r + c] = (double)U3[3 * r] * (double)V3[3 * c] + (double)U3[3 * r + 1] * (double)V3[3 * c + 1];
+    u3[0] = u3[1] = u3[2] = v3[0] = v3[1] = v3[2] = s3 = 0.0;
+  } else {
+    smallest_singular_triplet3(f, u3, v3, s3);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Fp[3 * r + c] = fma(-s3 * u3[r], v3[c], f[3 * r + c]);
+  }
+  // out = T2^T F' T1,  T = [[s,0,-s cx],[0,s,-s cy],[0,0,1]]
+  double Mx[9], out[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    Mx[3 * r + 0] = s1 * Fp[3 * r + 0];
+    Mx[3 * r + 1] = s1 * Fp[3 * r + 1];
+    Mx[3 * r + 2] = Fp[3 * r + 2] - s1 * (c1x * Fp[3 * r + 0] + c1y * Fp[3 * r + 1]);
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    out[c] = s2 * Mx[c];
+    out[3 + c] = s2 * Mx[3 + c];
+    out[6 + c] = Mx[6 + c] - s2 * (c2x * Mx[c] + c2y * Mx[3 + c]);
+  }
+  float of[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) of[c] = (float)out[c];
+  {
+    // one store per lane: lane c writes out[c]
+    float mine = of[0];
+#pragma unroll
+    for (int c = 1; c < 9; ++c) mine = (l == c) ? of[c] : mine;
+    if (l < 9) A.F_out[(size_t)pair * 9 + l] = mine;
+  }
+
+  DFEPE_MARK("P5s_save");
+  if (A.save != nullptr) {
+    float* sv = A.save + (size_t)pair * DFEPE_SAVE_FLOATS;
+    // per-lane pieces: lane c < 9 writes f[c], z[c], td[c], te[c]; every lane writes its reflector components
+    float fm = (float)f[0], zm = (float)(sgn * z[0]);
+    double tdm = td[0], tem = te[0];
+#pragma unroll
+    for (int c = 1; c < 9; ++c) {
+      fm = (l == c) ? (float)f[c] : fm;
+      zm = (l == c) ? (float)(sgn * z[c]) : zm;
+      tdm = (l == c) ? td[c] : tdm;
+      if (c < 8) tem = (l == c) ? te[c] : tem;
+    }
+    if (l < 9) {
+      sv[S16_F + l] = fm;
+      sv[S16_Z + l] = zm;
+      reinterpret_cast<double*>(sv + S16_TD)[l] = tdm;
+    }
+    if (l < 8) reinterpret_cast<double*>(sv + S16_TE)[l] = tem;
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+      if (l > k && l < 9) sv[S16_HV + s16_hv_off(k) + (l - k - 1)] = (float)hv[k];
+    {
+      float uvm = (float)u3[0], hbm = (float)hb[0];
+#pragma unroll
+      for (int c = 1; c < 7; ++c) {
+        if (c < 6) uvm = (l == c) ? (float)((c < 3) ? u3[c] : v3[c - 3]) : uvm;
+        hbm = (l == c) ? (float)hb[c] : hbm;
+      }
+      if (l < 6) sv[S16_U3 + l] = uvm;  // u3 (3), v3 (3)
+      if (l < 7) sv[S16_HB + l] = hbm;
+    }
+    if (l == 9) {
+      sv[S16_T1 + 0] = (float)s1; sv[S16_T1 + 1] = (float)c1x; sv[S16_T1 + 2] = (float)c1y;
+      sv[S16_T2 + 0] = (float)s2; sv[S16_T2 + 1] = (float)c2x; sv[S16_T2 + 2] = (float)c2y;
+    }
+    if (l == 10) {
+      sv[S16_S3] = (float)s3;
+      sv[S16_TWIST] = (float)twist;
+      sv[S16_INVTR] = (float)inv_tr;
+      sv[S16_TAG] = S16_TAG_VALUE;
+    }
+    if (l == 11) reinterpret_cast<double*>(sv + S16_LAM)[0] = lam;
+  }
+
+  DFEPE_MARK("P6");
+  // ---- phase 6: per-correspondence outputs ----------------------------------------------------------------------
+  float* rdst = A.residual + (size_t)pair * N;
+  float* edst = (A.epi_res != nullptr) ? A.epi_res + (size_t)pair * N : nullptr;
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int i = it * 16 + l;
+    if (i >= N) continue;
+    const Pt p = pt[it];
+    // residual_i = w_i p^_i . f  (DeepFNet.py:203-214,251)
+    const double w = (double)wv[it];
+    double ra[3], rb[2], inv;
+    const bool ok = row_factors(p, s1, c1x, c1y, s2, c2x, c2y, ra, rb, inv) && (fabs(w) < 1e150);
+    const double r = ok ? row_bilinear(ra, rb, f) * inv * w : 0.0;
+    rdst[i] = (float)r;
+    if (edst != nullptr) {
+      // l1 = F^T x2 (row form x2 F), l2 = F x1, dd = x2^T F x1 = x1 . l1     (utils_F.py:402-411), fp32 like the reference
+      const float l1x = fmaf(p.x2, of[0], fmaf(p.y2, of[3], p.z2 * of[6]));
+      const float l1y = fmaf(p.x2, of[1], fmaf(p.y2, of[4], p.z2 * of[7]));
+      const float l1z = fmaf(p.x2, of[2], fmaf(p.y2, of[5], p.z2 * of[8]));
+      const float l2x = fmaf(p.x1, of[0], fmaf(p.y1, of[1], p.z1 * of[2]));
+      const float l2y = fmaf(p.x1, of[3], fmaf(p.y1, of[4], p.z1 * of[5]));
+      const float dd = fmaf(p.x1, l1x, fmaf(p.y1, l1y, p.z1 * l1z));
+      const float n1 = hw_sqrt(fmaf(l1x, l1x, l1y * l1y)) + 1e-6f;  // v_sqrt_f32 / v_rcp_f32: 1 ulp, far inside the tolerance
+      const float m2 = hw_sqrt(fmaf(l2x, l2x, l2y * l2y)) + 1e-6f;
+      const float d = fabsf(dd) * (hw_rcp(n1) + hw_rcp(m2));
+      edst[i] = fminf(d, A.clamp_at);
+    }
+  }
+}

@@ -1,0 +1,465 @@
+// w8pt16 backward -- analytic adjoint of w8pt16_fwd_pair, one 16-lane row per image pair (N <= 128).
+//
+// Replaces torch.autograd's replay of the per-sample torch.svd calls of Fit.weighted_svd
+// (deepFEPE/models/DeepFNet.py:232-256) with closed forms:
+//   epipolar residual  d_i(out)            -> g_out      (only when g_epi is given)
+//   out = T2^T F' T1                        -> g_F' = T2 g_out T1^T
+//   F' = F - s3 u3 v3^T  (rank-2 projection) -> g_F    (3x3 SVD adjoint restricted to the dropped triplet)
+//   F = reshape(f), r = X f                 -> g_f = vec(g_F) + X^T g_r
+//   f = eigenvector of M = X^T X            -> u = sum_k q_k (q_k . g_f) / (lam_f - lam_k) = -(M - lam_f I)^+ g_f
+//   X_i = w_i ph_i                          -> g_w_i = 2 w_i (ph_i.f)(ph_i.u) + g_r_i (ph_i.f)
+// The pseudo-inverse is applied in the tridiagonal form the forward saved (M / trace = H T H^T):
+//   u = -(1/trace) H (T - lam I)^+ H^T g_f,
+// with (T - lam I)^+ b obtained by pinning the twist component to zero -- which splits the singular system into two
+// definite tridiagonal blocks, one Thomas sweep each -- and projecting the null vector z out before and after.  No other
+// eigenpair is needed, so nothing of the forward's work is repeated.  All of it in fp64 on values the whole row shares.
+#pragma once
+#include "w8pt16_body.h"
+
+struct W8BwdArgs {
+  const float* pts1;
+  const float* pts2;
+  const float* wts;
+  int B, Bm, N;
+  float hw_sx, hw_sy, clamp_at;
+  const float* save;
+  const float* F_out;
+  const float* g_F;
+  const float* g_res;
+  const float* g_epi;
+  const float* g_w_extra;
+  float* g_w;
+  float* g_p1;
+  float* g_p2;
+  int logits_mode;
+};
+
+__device__ __forceinline__ double guard_den16(double d) {
+  // keep the sign, floor the magnitude: repeated eigen/singular values give a large-but-finite gradient, never NaN
+  const double lim = 1e-30;
+  return (fabs(d) < lim) ? ((d < 0.0) ? -lim : lim) : d;
+}
+
+// y = (T - lam I)^+ g for the unit-trace tridiagonal (td, te), its eigenpair (lam, z) and the twist index.
+// Uniform over the row.  g is overwritten.
+__device__ __forceinline__ void tri_pinv_apply(const double* td, const double* te, double lam, const double* z, int twist,
+                                               double* g, double* y) {
+  double zg = 0.0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) zg = fma(z[k], g[k], zg);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) g[k] = fma(-zg, z[k], g[k]);
+  // Thomas elimination from the top (rows above the twist) and from the bottom (rows below it); with y_twist = 0 the
+  // two blocks decouple and each is a principal sub-matrix of the positive semi-definite T - lam I that excludes the
+  // largest component of its null vector: definite, pivots away from zero.
+  double cp[9], gp[9], cm[9], gm[9];
+  cp[0] = guard_den16(td[0] - lam);
+  gp[0] = g[0];
+#pragma unroll
+  for (int k = 1; k < 9; ++k) {
+    const double m = te[k - 1] * rcp_nr<2>(cp[k - 1]);
+    cp[k] = guard_den16((td[k] - lam) - m * te[k - 1]);
+    gp[k] = g[k] - m * gp[k - 1];
+  }
+  cm[8] = guard_den16(td[8] - lam);
+  gm[8] = g[8];
+#pragma unroll
+  for (int k = 7; k >= 0; --k) {
+    const double m = te[k] * rcp_nr<2>(cm[k + 1]);
+    cm[k] = guard_den16((td[k] - lam) - m * te[k]);
+    gm[k] = g[k] - m * gm[k + 1];
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) y[k] = 0.0;
+#pragma unroll
+  for (int k = 7; k >= 0; --k) {
+    const double yk = (gp[k] - te[k] * y[k + 1]) * rcp_nr<2>(cp[k]);
+    y[k] = (k < twist) ? yk : y[k];
+  }
+#pragma unroll
+  for (int k = 1; k < 9; ++k) {
+    const double yk = (gm[k] - te[k - 1] * y[k - 1]) * rcp_nr<2>(cm[k]);
+    y[k] = (k > twist) ? yk : y[k];
+  }
+  double zy = 0.0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) zy = fma(z[k], y[k], zy);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) y[k] = fma(-zy, z[k], y[k]);
+}
+
+template <int IT, bool RAW, bool PGRAD>
+__device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const int pair, double* /*xch*/) {
+  const int l = rg_lane();
+  const int N = A.N;
+  const size_t mp = (size_t)(pair % A.Bm);
+  const float* sv = A.save + (size_t)pair * DFEPE_SAVE_FLOATS;
+
+  // ---- the forward's record (row-uniform loads) and the pair's correspondences -------------------------------
+  const double s1 = sv[S16_T1], c1x = sv[S16_T1 + 1], c1y = sv[S16_T1 + 2];
+  const double s2 = sv[S16_T2], c2x = sv[S16_T2 + 1], c2y = sv[S16_T2 + 2];
+  double f[9], z[9], td[9], te[8], hb[7], hv[7];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) { f[c] = sv[S16_F + c]; z[c] = sv[S16_Z + c]; td[c] = reinterpret_cast<const double*>(sv + S16_TD)[c]; }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) te[c] = reinterpret_cast<const double*>(sv + S16_TE)[c];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    hb[k] = sv[S16_HB + k];
+    hv[k] = (l > k && l < 9) ? (double)sv[S16_HV + s16_hv_off(k) + (l - k - 1)] : 0.0;
+  }
+  const double lam = reinterpret_cast<const double*>(sv + S16_LAM)[0];
+  const int twist = (int)sv[S16_TWIST];
+  const double inv_tr = sv[S16_INVTR];
+  const bool good = sv[S16_TAG] == S16_TAG_VALUE;  // a record of the other forward kernel would be misread: poison instead
+
+  Pt pt[IT];
+  float wv[IT];
+  const float* wsrc = A.wts + (size_t)pair * N;
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int i = it * 16 + l;
+    Pt p;
+    p.x1 = p.y1 = p.x2 = p.y2 = 0.0f;
+    p.z1 = p.z2 = 1.0f;
+    float w = 0.0f;
+    if (i < N) {
+      if (RAW) {
+        const float4 m = reinterpret_cast<const float4*>(A.pts1)[mp * N + i];
+        p.x1 = fmaf(m.x, A.hw_sx, -1.0f);
+        p.y1 = fmaf(m.y, A.hw_sy, -1.0f);
+        p.x2 = fmaf(m.z, A.hw_sx, -1.0f);
+        p.y2 = fmaf(m.w, A.hw_sy, -1.0f);
+      } else {
+        const float* a = A.pts1 + (mp * N + i) * 3;
+        const float* b = A.pts2 + (mp * N + i) * 3;
+        p.x1 = a[0]; p.y1 = a[1]; p.z1 = a[2];
+        p.x2 = b[0]; p.y2 = b[1]; p.z2 = b[2];
+      }
+      w = wsrc[i];
+    }
+    pt[it] = p;
+    wv[it] = w;
+  }
+
+  // ---- pass A: X^T g_r  and  sum_i g_epi_i d(d_i)/d(out) ---------------------------------------------------------
+  // partial sums in fp32 (the reference's whole backward is fp32); everything uniform downstream is fp64
+  double gx[9], go[9], o[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) { gx[c] = 0.0; go[c] = 0.0; o[c] = 0.0; }
+  if (A.g_epi != nullptr) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) o[c] = (double)A.F_out[(size_t)pair * 9 + c];
+  }
+  if (A.g_res != nullptr || A.g_epi != nullptr) {
+    float gxf[9], gof[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { gxf[c] = 0.0f; gof[c] = 0.0f; }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int i = it * 16 + l;
+      if (i >= N) continue;
+      const Pt p = pt[it];
+      if (A.g_res != nullptr) {
+        const double w = (double)wv[it];
+        double ra[3], rb[2], inv;
+        const bool ok = row_factors(p, s1, c1x, c1y, s2, c2x, c2y, ra, rb, inv) && (fabs(w) < 1e150);
+        const double gw = ok ? (double)A.g_res[(size_t)pair * N + i] * w * inv : 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const double ga = gw * ra[c];
+          gxf[c] += (float)(ga * rb[0]); gxf[3 + c] += (float)(ga * rb[1]); gxf[6 + c] += (float)ga;
+        }
+      }
+      if (A.g_epi != nullptr) {
+        const double x1[3] = {p.x1, p.y1, p.z1}, x2[3] = {p.x2, p.y2, p.z2};
+        double l1[3], l2[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) l1[c] = x2[0] * o[c] + x2[1] * o[3 + c] + x2[2] * o[6 + c];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) l2[r] = o[3 * r] * x1[0] + o[3 * r + 1] * x1[1] + o[3 * r + 2] * x1[2];
+        const double dd = x1[0] * l1[0] + x1[1] * l1[1] + x1[2] * l1[2];
+        const double n1 = sqrt_nr<1>(l1[0] * l1[0] + l1[1] * l1[1]), n2 = sqrt_nr<1>(l2[0] * l2[0] + l2[1] * l2[1]);
+        const double i1 = rcp_nr<1>(n1 + 1e-6), i2 = rcp_nr<1>(n2 + 1e-6);
+        const double S = i1 + i2, ad = fabs(dd);
+        const double d = ad * S;
+        // clamp(max=) passes the gradient up to and including the bound
+        const double g = (d <= (double)A.clamp_at) ? (double)A.g_epi[(size_t)pair * N + i] : 0.0;
+        const double sg = (dd > 0.0) ? 1.0 : ((dd < 0.0) ? -1.0 : 0.0);
+        const double k1 = (n1 > 0.0) ? ad * i1 * i1 * rcp_nr<1>(n1) : 0.0;
+        const double k2 = (n2 > 0.0) ? ad * i2 * i2 * rcp_nr<1>(n2) : 0.0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            double t = sg * S * x2[r] * x1[c];
+            if (c < 2) t -= k1 * l1[c] * x2[r];
+            if (r < 2) t -= k2 * l2[r] * x1[c];
+            gof[3 * r + c] += (float)(g * t);
+          }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      if (A.g_res != nullptr) gx[c] = (double)rg_sum(gxf[c]);
+      if (A.g_epi != nullptr) go[c] = (double)rg_sum(gof[c]);
+    }
+  }
+  if (A.g_F != nullptr) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) go[c] += (double)A.g_F[(size_t)pair * 9 + c];
+  }
+
+  // ---- uniform part ------------------------------------------------------------------------------------------
+  // g_F' = T2 g_out T1^T with T = [[s,0,-s cx],[0,s,-s cy],[0,0,1]] written out
+  double tmp[9], G[9];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    tmp[c] = s2 * (go[c] - c2x * go[6 + c]);
+    tmp[3 + c] = s2 * (go[3 + c] - c2y * go[6 + c]);
+    tmp[6 + c] = go[6 + c];
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    G[3 * r] = s1 * (tmp[3 * r] - c1x * tmp[3 * r + 2]);
+    G[3 * r + 1] = s1 * (tmp[3 * r + 1] - c1y * tmp[3 * r + 2]);
+    G[3 * r + 2] = tmp[3 * r + 2];
+  }
+  // rank-2 projection adjoint with nothing but the dropped triplet (s3, u3, v3) and F = reshape(f).  With the
+  // pseudo-inverses A_u = (s3^2 I - F F^T)^+ (null vector u3) and A_v = (s3^2 I - F^T F)^+ (null vector v3), the first-order
+  // perturbation of the triplet is  d s3 = u3^T dF v3,  d u3 = A_u (s3 dF v3 + F dF^T u3),  d v3 = A_v (s3 dF^T u3 + F^T dF v3),
+  // so with p = A_u G v3, q = A_v G^T u3, a33 = u3^T G v3:
+  //   g_F = G - (a33 u3 + s3^2 p + s3 F q) v3^T - u3 (s3 F^T p + s3^2 q)^T
+  // (the same five-term expression the full-SVD form sum_k coef_k (...) u_k / v_k collapses to).
+  double u3[3], v3[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { u3[c] = sv[S16_U3 + c]; v3[c] = sv[S16_V3 + c]; }
+  const double s3 = sv[S16_S3];
+  double gf[9];
+  {
+    const double* Fm = f;
+    double Gv3[3], Gtu3[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      Gv3[r] = G[3 * r] * v3[0] + G[3 * r + 1] * v3[1] + G[3 * r + 2] * v3[2];
+      Gtu3[r] = G[r] * u3[0] + G[3 + r] * u3[1] + G[6 + r] * u3[2];
+    }
+    const double a33 = u3[0] * Gv3[0] + u3[1] * Gv3[1] + u3[2] * Gv3[2];
+    const double q2 = s3 * s3;
+    // F F^T and F^T F (6 distinct entries each)
+    const double d00 = Fm[0] * Fm[0] + Fm[1] * Fm[1] + Fm[2] * Fm[2], d01 = Fm[0] * Fm[3] + Fm[1] * Fm[4] + Fm[2] * Fm[5];
+    const double d02 = Fm[0] * Fm[6] + Fm[1] * Fm[7] + Fm[2] * Fm[8], d11 = Fm[3] * Fm[3] + Fm[4] * Fm[4] + Fm[5] * Fm[5];
+    const double d12 = Fm[3] * Fm[6] + Fm[4] * Fm[7] + Fm[5] * Fm[8], d22 = Fm[6] * Fm[6] + Fm[7] * Fm[7] + Fm[8] * Fm[8];
+    const double b00 = Fm[0] * Fm[0] + Fm[3] * Fm[3] + Fm[6] * Fm[6], b01 = Fm[0] * Fm[1] + Fm[3] * Fm[4] + Fm[6] * Fm[7];
+    const double b02 = Fm[0] * Fm[2] + Fm[3] * Fm[5] + Fm[6] * Fm[8], b11 = Fm[1] * Fm[1] + Fm[4] * Fm[4] + Fm[7] * Fm[7];
+    const double b12 = Fm[1] * Fm[2] + Fm[4] * Fm[5] + Fm[7] * Fm[8], b22 = Fm[2] * Fm[2] + Fm[5] * Fm[5] + Fm[8] * Fm[8];
+    double pt3[3], qt3[3];
+    sym3_pinv_apply(q2 - d00, -d01, -d02, q2 - d11, -d12, q2 - d22, u3, Gv3, pt3);
+    sym3_pinv_apply(q2 - b00, -b01, -b02, q2 - b11, -b12, q2 - b22, v3, Gtu3, qt3);
+    double pv[3], qv[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const double Fq = Fm[3 * r] * qt3[0] + Fm[3 * r + 1] * qt3[1] + Fm[3 * r + 2] * qt3[2];   // (F q)_r
+      const double Ftp = Fm[r] * pt3[0] + Fm[3 + r] * pt3[1] + Fm[6 + r] * pt3[2];               // (F^T p)_r
+      pv[r] = a33 * u3[r] + q2 * pt3[r] + s3 * Fq;
+      qv[r] = s3 * Ftp + q2 * qt3[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gf[3 * r + c] = G[3 * r + c] - pv[r] * v3[c] - u3[r] * qv[c] + gx[3 * r + c];
+  }
+  // eigenvector adjoint: u = -(1/trace) H (T - lam I)^+ H^T g_f.  H^T = H_6 ... H_0 (each H_k symmetric).
+  double u[9];
+  {
+    double gt[9], y[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) gt[c] = gf[c];
+    static_for<0, 7>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      double s = 0.0;
+      static_for<k + 1, 9>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        s = rg_fma_bcast<j>(s, hv[k], gt[j]);
+      });
+      s *= -hb[k];
+      static_for<k + 1, 9>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        gt[j] = rg_fma_bcast<j>(gt[j], hv[k], s);
+      });
+    });
+    tri_pinv_apply(td, te, lam, z, twist, gt, y);
+    static_for<0, 7>([&](auto kc) {
+      constexpr int k = 6 - decltype(kc)::value;
+      double s = 0.0;
+      static_for<k + 1, 9>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        s = rg_fma_bcast<j>(s, hv[k], y[j]);
+      });
+      s *= -hb[k];
+      static_for<k + 1, 9>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        y[j] = rg_fma_bcast<j>(y[j], hv[k], s);
+      });
+    });
+    const double sc = good ? -inv_tr : (double)NAN;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) u[c] = sc * y[c];
+  }
+
+  // ---- pass B: g_w ---------------------------------------------------------------------------------------------
+  float* dst = A.g_w + (size_t)pair * N;
+  float gwv[IT];
+  float wg = 0.0f;
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int i = it * 16 + l;
+    float gwi = 0.0f;
+    if (i < N) {
+      const double w = (double)wv[it];
+      double ra[3], rb[2], inv;
+      const bool ok = row_factors(pt[it], s1, c1x, c1y, s2, c2x, c2y, ra, rb, inv) && (fabs(w) < 1e150);
+      const double a = row_bilinear(ra, rb, f) * inv, b = row_bilinear(ra, rb, u) * inv;  // p^ . f, p^ . u
+      const double gr = (A.g_res != nullptr) ? (double)A.g_res[(size_t)pair * N + i] : 0.0;
+      gwi = ok ? (float)(2.0 * w * a * b + gr * a) : 0.0f;
+      if (A.g_w_extra != nullptr) gwi += A.g_w_extra[(size_t)pair * N + i];
+    }
+    gwv[it] = gwi;
+    wg = fmaf(gwi, wv[it], wg);
+  }
+  if (A.logits_mode) {
+    // softmax adjoint g_logit_i = w_i (g_w_i - sum_j w_j g_w_j)
+    const float s = rg_sum(wg);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) gwv[it] = wv[it] * (gwv[it] - s);
+  }
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int i = it * 16 + l;
+    if (i < N) dst[i] = gwv[it];
+  }
+
+  if constexpr (PGRAD) {
+    // ---- adjoint w.r.t. the point coordinates (derivation checked against autograd in scripts/proto_pts_grad.py) ----
+    // rows -> (a, b) -> points, plus the dependence of the Hartley transforms (centroid c, scale s = k / mean distance)
+    // on the points through the rows and through out = T2^T F' T1, plus the direct dependence of the epipolar residual.
+    const double kH = 1.4142;
+    const double t1[9] = {s1, 0.0, -s1 * c1x, 0.0, s1, -s1 * c1y, 0.0, 0.0, 1.0};
+    const double t2[9] = {s2, 0.0, -s2 * c2x, 0.0, s2, -s2 * c2y, 0.0, 0.0, 1.0};
+    double Fp[9], tA[9], gT1[9], gT2[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Fp[3 * r + c] = fma(-s3 * u3[r], v3[c], f[3 * r + c]);
+    mat3_mul_tn(t2, Fp, tA);      // T2^T F'
+    mat3_mul_tn(tA, go, gT1);     // d<G, T2^T F' T1>/dT1 = (T2^T F')^T G
+    mat3_mul(Fp, t1, tA);         // F' T1
+    mat3_mul_nt(tA, go, gT2);     // d/dT2 = F' T1 G^T
+    float sums[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) sums[k] = 0.0f;
+    float q1x[IT], q1y[IT], q2x[IT], q2y[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int i = it * 16 + l;
+      q1x[it] = q1y[it] = q2x[it] = q2y[it] = 0.0f;
+      if (i >= N) continue;
+      const Pt p = pt[it];
+      const double w = (double)wv[it];
+      const double z1 = p.z1, z2 = p.z2;
+      const double a[3] = {s1 * ((double)p.x1 - c1x * z1), s1 * ((double)p.y1 - c1y * z1), z1};
+      const double b0 = s2 * ((double)p.x2 - c2x * z2), b1 = s2 * ((double)p.y2 - c2y * z2);
+      const double n2 = (a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) * (b0 * b0 + b1 * b1 + 1.0);
+      const bool ok = (n2 < 1e300) && (n2 > 1e-24) && (fabs(w) < 1e150);
+      const double inv = ok ? rsqrt_nr<1>(n2) : 0.0;
+      double ph[9];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { ph[k] = b0 * a[k] * inv; ph[3 + k] = b1 * a[k] * inv; ph[6 + k] = a[k] * inv; }
+      double af = 0.0, bu = 0.0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { af += ph[k] * f[k]; bu += ph[k] * u[k]; }
+      const double gr = (A.g_res != nullptr) ? (double)A.g_res[(size_t)pair * N + i] : 0.0;
+      const double cu = w * w * af, cf = w * w * bu + w * gr, dotp = 2.0 * w * w * af * bu + w * gr * af;
+      double gp[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) gp[k] = (cu * u[k] + cf * f[k] - ph[k] * dotp) * inv;
+      const double ga0 = b0 * gp[0] + b1 * gp[3] + gp[6], ga1 = b0 * gp[1] + b1 * gp[4] + gp[7], ga2 = b0 * gp[2] + b1 * gp[5] + gp[8];
+      const double gb0 = a[0] * gp[0] + a[1] * gp[1] + a[2] * gp[2], gb1 = a[0] * gp[3] + a[1] * gp[4] + a[2] * gp[5];
+      double e1[3] = {0.0, 0.0, 0.0}, e2[3] = {0.0, 0.0, 0.0};
+      if (A.g_epi != nullptr) {  // direct dependence of d_i on x1_i, x2_i
+        const double x1[3] = {p.x1, p.y1, p.z1}, x2[3] = {p.x2, p.y2, p.z2};
+        double l1[3], l2[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) l1[c] = x2[0] * o[c] + x2[1] * o[3 + c] + x2[2] * o[6 + c];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) l2[r] = o[3 * r] * x1[0] + o[3 * r + 1] * x1[1] + o[3 * r + 2] * x1[2];
+        const double dd = x1[0] * l1[0] + x1[1] * l1[1] + x1[2] * l1[2];
+        const double n1 = sqrt_nr<1>(l1[0] * l1[0] + l1[1] * l1[1]), nn2 = sqrt_nr<1>(l2[0] * l2[0] + l2[1] * l2[1]);
+        const double i1 = rcp_nr<1>(n1 + 1e-6), i2 = rcp_nr<1>(nn2 + 1e-6);
+        const double Ss = i1 + i2, ad = fabs(dd);
+        const double g = (ad * Ss <= (double)A.clamp_at) ? (double)A.g_epi[(size_t)pair * N + i] : 0.0;
+        const double sg = (dd > 0.0) ? 1.0 : ((dd < 0.0) ? -1.0 : 0.0);
+        const double k1 = (n1 > 0.0) ? ad * i1 * i1 * rcp_nr<1>(n1) : 0.0;
+        const double k2 = (nn2 > 0.0) ? ad * i2 * i2 * rcp_nr<1>(nn2) : 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          e1[c] = g * (sg * Ss * l1[c] - k2 * (l2[0] * o[c] + l2[1] * o[3 + c]));          // d n2 / d x1_c
+          e2[c] = g * (sg * Ss * l2[c] - k1 * (l1[0] * o[3 * c] + l1[1] * o[3 * c + 1]));  // d n1 / d x2_c
+        }
+      }
+      // provisional values; the Hartley terms are added below once their sums over the pair are known
+      q1x[it] = (float)(s1 * ga0 + e1[0]); q1y[it] = (float)(s1 * ga1 + e1[1]);
+      q2x[it] = (float)(s2 * gb0 + e2[0]); q2y[it] = (float)(s2 * gb1 + e2[1]);
+      if (!RAW) {
+        A.g_p1[((size_t)pair * N + i) * 3 + 2] = (float)(ga2 - s1 * (c1x * ga0 + c1y * ga1) + e1[2]);
+        A.g_p2[((size_t)pair * N + i) * 3 + 2] = (float)(-s2 * (c2x * gb0 + c2y * gb1) + e2[2]);
+      }
+      const double dx1 = (double)p.x1 - c1x, dy1 = (double)p.y1 - c1y, dx2 = (double)p.x2 - c2x, dy2 = (double)p.y2 - c2y;
+      const double r1 = dx1 * dx1 + dy1 * dy1, r2 = dx2 * dx2 + dy2 * dy2;
+      const double ir1 = (r1 > 0.0) ? rsqrt_nr<1>(r1) : 0.0, ir2 = (r2 > 0.0) ? rsqrt_nr<1>(r2) : 0.0;
+      sums[0] += (float)(((double)p.x1 - c1x * z1) * ga0 + ((double)p.y1 - c1y * z1) * ga1);  // d/ds1 through the rows
+      sums[1] += (float)(-s1 * z1 * ga0);
+      sums[2] += (float)(-s1 * z1 * ga1);
+      sums[3] += (float)(((double)p.x2 - c2x * z2) * gb0 + ((double)p.y2 - c2y * z2) * gb1);
+      sums[4] += (float)(-s2 * z2 * gb0);
+      sums[5] += (float)(-s2 * z2 * gb1);
+      sums[6] += (float)(dx1 * ir1); sums[7] += (float)(dy1 * ir1);
+      sums[8] += (float)(dx2 * ir2); sums[9] += (float)(dy2 * ir2);
+    }
+    double tot[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) tot[k] = (double)rg_sum(sums[k]);
+    const double invN = 1.0 / (double)N;
+    const double Gs1 = tot[0] + gT1[0] + gT1[4] - c1x * gT1[2] - c1y * gT1[5];
+    const double Gs2 = tot[3] + gT2[0] + gT2[4] - c2x * gT2[2] - c2y * gT2[5];
+    const double Gd1 = -Gs1 * s1 * s1 / kH, Gd2 = -Gs2 * s2 * s2 / kH;   // s = k / dbar
+    const double Gc1x = (tot[1] - s1 * gT1[2] - Gd1 * invN * tot[6]) * invN, Gc1y = (tot[2] - s1 * gT1[5] - Gd1 * invN * tot[7]) * invN;
+    const double Gc2x = (tot[4] - s2 * gT2[2] - Gd2 * invN * tot[8]) * invN, Gc2y = (tot[5] - s2 * gT2[5] - Gd2 * invN * tot[9]) * invN;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int i = it * 16 + l;
+      if (i >= N) continue;
+      const Pt p = pt[it];
+      const double dx1 = (double)p.x1 - c1x, dy1 = (double)p.y1 - c1y, dx2 = (double)p.x2 - c2x, dy2 = (double)p.y2 - c2y;
+      const double r1 = dx1 * dx1 + dy1 * dy1, r2 = dx2 * dx2 + dy2 * dy2;
+      const double ir1 = (r1 > 0.0) ? rsqrt_nr<1>(r1) : 0.0, ir2 = (r2 > 0.0) ? rsqrt_nr<1>(r2) : 0.0;
+      const float a1x = (float)(Gd1 * invN * dx1 * ir1 + Gc1x), a1y = (float)(Gd1 * invN * dy1 * ir1 + Gc1y);
+      const float a2x = (float)(Gd2 * invN * dx2 * ir2 + Gc2x), a2y = (float)(Gd2 * invN * dy2 * ir2 + Gc2y);
+      if (RAW) {
+        float4 q;  // chain through x^ = 2x/W - 1
+        q.x = (q1x[it] + a1x) * A.hw_sx; q.y = (q1y[it] + a1y) * A.hw_sy; q.z = (q2x[it] + a2x) * A.hw_sx; q.w = (q2y[it] + a2y) * A.hw_sy;
+        reinterpret_cast<float4*>(A.g_p1)[(size_t)pair * N + i] = q;
+      } else {
+        float* d1 = A.g_p1 + ((size_t)pair * N + i) * 3;
+        float* d2 = A.g_p2 + ((size_t)pair * N + i) * 3;
+        d1[0] = q1x[it] + a1x; d1[1] = q1y[it] + a1y; d2[0] = q2x[it] + a2x; d2[1] = q2y[it] + a2y;
+      }
+    }
+  }
+}
+
+template <int IT, bool RAW>
+__device__ __forceinline__ void w8pt16_bwd_pair(const W8BwdArgs& A, const int pair, double* xch) {
+  if (A.g_p1 != nullptr) w8pt16_bwd_pair_impl<IT, RAW, true>(A, pair, xch);
+  else w8pt16_bwd_pair_impl<IT, RAW, false>(A, pair, xch);
+}

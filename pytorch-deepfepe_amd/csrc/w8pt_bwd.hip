@@ -11,6 +11,9 @@
 // All nine eigenpairs come from the forward Jacobi (the `save` record), so the cost is O(9 N) per pair:
 // two streaming passes over the correspondences (the second one hits L2) and a few hundred uniform flops.
 #include "dfepe_common.h"
+#include "w8pt16_bwd_body.h"  // W8BwdArgs
+
+int dfepe_w8pt16_bwd_launch(const W8BwdArgs& A, bool raw, hipStream_t st);  // w8pt16.hip
 
 namespace {
 
@@ -406,6 +409,16 @@ extern "C" int dfepe_w8pt_bwd(const float* pts1, const float* pts2, const float*
   if (raw && pgrad && (reinterpret_cast<uintptr_t>(g_pts1) & 15u)) return DFEPE_ERR_INVALID_ARG;
   if (raw && !(image_w > 0.f && image_h > 0.f)) return DFEPE_ERR_INVALID_ARG;
   if (raw && (reinterpret_cast<uintptr_t>(pts1) & 15u)) return DFEPE_ERR_INVALID_ARG;
+  if (flags & ~DFEPE_W8PT_ALL_FLAGS) return DFEPE_ERR_INVALID_ARG;
+  if (N <= DFEPE_W8PT16_MAX_N && !(flags & DFEPE_W8PT_WAVE_PER_PAIR)) {  // same rule as dfepe_w8pt_fwd: the record formats differ
+    W8BwdArgs A;
+    A.pts1 = pts1; A.pts2 = pts2; A.wts = weights;
+    A.Bm = Bm; A.B = B; A.N = N;
+    A.hw_sx = raw ? 2.0f / image_w : 0.f; A.hw_sy = raw ? 2.0f / image_h : 0.f; A.clamp_at = clamp_at;
+    A.save = save; A.F_out = F_out; A.g_F = g_F; A.g_res = g_residual; A.g_epi = g_epi; A.g_w_extra = g_weights_extra;
+    A.g_w = g_weights; A.g_p1 = g_pts1; A.g_p2 = g_pts2; A.logits_mode = logits_mode;
+    return dfepe_w8pt16_bwd_launch(A, raw, static_cast<hipStream_t>(stream));
+  }
   const int waves = 4;
   // large N, batch small enough to be resident at once: one workgroup per pair (N = 1000, B = 512: see DESIGN.md)
   const bool coop = !pgrad && N >= 256 && B <= 1024;

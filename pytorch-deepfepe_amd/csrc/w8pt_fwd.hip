@@ -19,6 +19,9 @@
 //   6  residual_i = X_i . f and the symmetric epipolar residual per correspondence (coalesced stores)
 // No MFMA: the only contraction (X^T X, 9xN by Nx9) is far too skinny; the rest is eigen work.
 #include "dfepe_common.h"
+#include "w8pt16_body.h"  // W8Args
+
+int dfepe_w8pt16_fwd_launch(const W8Args& A, bool raw, hipStream_t st);  // w8pt16.hip
 
 namespace {
 
@@ -114,7 +117,7 @@ __global__ void __launch_bounds__(256, 4)
 w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, const float* __restrict__ wts,
                 int B, int Bm, int N, int npad, int wave_bytes, float hw_sx, float hw_sy, float clamp_at,
                 float* __restrict__ F_out, float* __restrict__ residual, float* __restrict__ epi_res,
-                float* __restrict__ save, float* __restrict__ weights_out, int logits_mode, unsigned variant, int dbg) {
+                float* __restrict__ save, float* __restrict__ weights_out, int logits_mode, unsigned variant) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
@@ -137,9 +140,6 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   float* REDF = reinterpret_cast<float*>(RED + 177);
   auto pair_sync = [&]() { if (COOP) __syncthreads(); else wave_sync(); };
 
-  // phase timestamps (shader clock) for the diagnostics slots of the save record
-  long long tstamp[8];
-  tstamp[0] = __builtin_amdgcn_s_memtime();
   // ---- phase 0: stage the pair in LDS, coordinate sums ------------------------------------------
   double sx1 = 0, sy1 = 0, sx2 = 0, sy2 = 0;
   const float* wsrc = wts + (size_t)pair * N;
@@ -237,7 +237,6 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   const double c2x = hartley ? to_sgpr(sx2 * invN) : 0.0, c2y = hartley ? to_sgpr(sy2 * invN) : 0.0;
   wave_sync();
 
-  tstamp[1] = __builtin_amdgcn_s_memtime();
   // ---- phase 1: Hartley scale -------------------------------------------------------------------
   double d1 = 0, d2 = 0;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
@@ -261,7 +260,6 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   const double s1 = hartley ? to_sgpr(hscale * fast_rcp(d1 * invN)) : 1.0;
   const double s2 = hartley ? to_sgpr(hscale * fast_rcp(d2 * invN)) : 1.0;
 
-  tstamp[2] = __builtin_amdgcn_s_memtime();
   // ---- phase 2: X^T X as 36 distinct fp64 sums per lane (exact products of fp32-derived factors) ---------
   double acc[36];
 #pragma unroll
@@ -286,7 +284,6 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     }
   }
 
-  tstamp[3] = __builtin_amdgcn_s_memtime();
   // ---- phase 3: reduce-scatter across the wave; lane ends up owning (at most) one distinct sum -------------
   halve<36, 0>(acc, lane & 32, 32);
   halve<18, 0>(acc, lane & 16, 16);
@@ -326,7 +323,6 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   }
   wave_sync();
 
-  tstamp[4] = __builtin_amdgcn_s_memtime();
   double f[9];   // the solver's eigenvector (unit norm, oriented) and the de-normalised rank-2 F: produced by phases 4-5,
   float of[9];   // consumed by the per-correspondence outputs of phase 6
   if (!COOP || wave == 0) {
@@ -366,20 +362,14 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   const int pp = (lane < 16) ? (lane & 6) : 0;  // lanes 0..15: my pair is positions (pp, pp+1); lanes 8..15 repeat 0..7 and
                                                 // store the swapped copy (one ds_write_b64 per lane instead of a ds_write_b128)
   wave_sync();
-  int n_sweeps = 0, n_refine = 0;
-  // diagnostics (DFEPE_W8PT_DIAG_* bits of `flags`, see scripts/quick_time.py): dbg = 0 normal; otherwise bits 0..7 hold
-  // 1 + the exact number of sweeps to run (no convergence test) and bit 8 keeps the polish enabled
-  const bool dbg_on = dbg != 0, dbg_polish = (dbg & 0x100) != 0;
-  const int max_sweeps = dbg_on ? (dbg & 0xff) - 1 : kMaxSweeps;
-  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+  for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
     float off = 0.0f;
     if (offdiag) {
       const float a = A32[off_idx];
       off = a * a;
     }
     off = wave_sum(off);
-    if (!(off > kJacobiTol) && !dbg_on) break;  // wave-uniform (also leaves on NaN)
-    ++n_sweeps;
+    if (!(off > kJacobiTol)) break;  // wave-uniform (also leaves on NaN)
     for (int r = 0; r < 9; ++r) {
       // every read of the round is issued up front (none depends on this round's rotations): 3 x ds_read_b64 + the
       // rotation inputs of lanes 0..15, then the (c, sh) exchange through CS (3 x ds_read_b64), then 2-3 ds_write_b32
@@ -417,7 +407,6 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     }
   }
 
-  tstamp[5] = __builtin_amdgcn_s_memtime();
   // ---- phase 4b: pick the eigenpair the reference picks, polish it in fp64 ----------------------------
   // torch.svd(X)[2][:, -1] is the right singular vector of the smallest of the min(N,9) singular values
   // (DeepFNet.py:232-233): for N >= 9 the smallest eigenvalue of X^T X; for N < 9 the reduced SVD has only N
@@ -573,7 +562,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
   // fp64 eigenvector, reached at a linear rate ~ eps32 |M| / gap per iteration.
   double rn2_prev = 0.0;
   bool last_pass = false;
-  for (int it = 0; it < ((dbg_on && !dbg_polish) ? 0 : kRefineIters); ++it) {
+  for (int it = 0; it < kRefineIters; ++it) {
     double fn2 = 0.0;
 #pragma unroll
     for (int c = 0; c < 9; ++c) fn2 += f[c] * f[c];
@@ -597,7 +586,6 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     for (int c = 0; c < 9; ++c) { r[c] -= rho * f[c]; rn2 += r[c] * r[c]; }
     const double rn2_tol = 1e-28 * tr * tr;
     if (!(rn2 > rn2_tol)) break;  // |M f - rho f| <= 1e-14 trace(M): converged (wave-uniform)
-    ++n_refine;
     // the iteration contracts linearly: when the last step's factor, applied once more, lands 100x below the
     // tolerance, this correction is the final one and the verification pass after it is skipped
     last_pass = (it > 0) && (rn2 * rn2 < 1e-2 * rn2_tol * rn2_prev);
@@ -627,7 +615,6 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     if (last_pass) break;
   }
 
-  tstamp[6] = __builtin_amdgcn_s_memtime();
   // ---- phase 5: rank-2 projection, de-normalisation (wave-uniform arithmetic) ------------------------------
   double fn2 = 0.0;
 #pragma unroll
@@ -685,7 +672,6 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 #pragma unroll
     for (int c = 0; c < 9; ++c) dst[c] = of[c];
   }
-  tstamp[7] = __builtin_amdgcn_s_memtime();
   if (save != nullptr) {
     float* sv = save + (size_t)pair * DFEPE_SAVE_FLOATS;
     // the polished, oriented f replaces its Jacobi column in the record; staged through LDS so that no register
@@ -712,10 +698,7 @@ w8pt_fwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 #pragma unroll
       for (int c = 0; c < 9; ++c) { sv[SV_U3 + c] = U3[c]; sv[SV_V3 + c] = V3[c]; }
       sv[SV_S3 + 0] = S3[0]; sv[SV_S3 + 1] = S3[1]; sv[SV_S3 + 2] = (float)s3;
-      sv[119] = (float)n_sweeps;  // diagnostics: Jacobi sweeps and polish iterations actually run
-      sv[120] = (float)n_refine;
-#pragma unroll
-      for (int c = 0; c < 7; ++c) sv[121 + c] = (float)(tstamp[c + 1] - tstamp[c]);  // cycles spent in phases 0,1,2,3,4a,4b,5
+      sv[127] = 64.0f;  // record format tag: wavefront-per-pair kernel (the row-per-pair kernels write 16)
     }
   }
 
@@ -771,7 +754,6 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
   const bool raw = (flags & DFEPE_W8PT_RAW_MATCHES) != 0;
   const int logits_mode = (flags & DFEPE_W8PT_LOGITS) ? 1 : 0;
   const unsigned variant = flags & (DFEPE_W8PT_SQRT2 | DFEPE_W8PT_NO_ROWNORM | DFEPE_W8PT_FORCE_110 | DFEPE_W8PT_NO_HARTLEY);
-  const int dbg = (int)((flags >> 16) & 0x1ffu);  // undocumented diagnostics: forced sweep count (timing experiments only)
   if (B < 0 || N <= 0 || n_weight_sets < 1) return DFEPE_ERR_INVALID_ARG;
   if (variant && save) return DFEPE_ERR_UNSUPPORTED;  // the textbook variants are forward-only
   if (B == 0) return DFEPE_OK;
@@ -779,6 +761,17 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
   if (raw && !(image_w > 0.f && image_h > 0.f)) return DFEPE_ERR_INVALID_ARG;
   if (raw && (reinterpret_cast<uintptr_t>(pts1) & 15u)) return DFEPE_ERR_INVALID_ARG;  // float4 loads
 
+  if (flags & ~DFEPE_W8PT_ALL_FLAGS) return DFEPE_ERR_INVALID_ARG;  // unknown flag bits are rejected, not ignored
+  if (N <= DFEPE_W8PT16_MAX_N && !(flags & DFEPE_W8PT_WAVE_PER_PAIR)) {
+    // small N: one 16-lane row per pair, correspondences in registers, fp64 tridiagonal eigen-solver (w8pt16.hip)
+    W8Args A;
+    A.pts1 = pts1; A.pts2 = pts2; A.wts = weights;
+    A.Bm = B; A.B = B * n_weight_sets; A.N = N;
+    A.hw_sx = raw ? 2.0f / image_w : 0.f; A.hw_sy = raw ? 2.0f / image_h : 0.f; A.clamp_at = clamp_at;
+    A.F_out = F_out; A.residual = residual; A.epi_res = epi_res; A.save = save; A.weights_out = weights_out;
+    A.logits_mode = logits_mode; A.variant = variant;
+    return dfepe_w8pt16_fwd_launch(A, raw, static_cast<hipStream_t>(stream));
+  }
   const int npad = (N + 3) & ~3;
   const int wave_bytes = kWsDoubles * (int)sizeof(double) + (raw ? 5 : 7) * npad * (int)sizeof(float);
   // waves per block: 4 when at least 16 wavefronts fit a CU's 160 KiB anyway, otherwise whichever of {4,2,1} keeps the
@@ -796,7 +789,7 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
   // 2 or 4 wavefronts: the smallest count that puts >= 12 wavefronts on a CU (measured, B = 4096: N = 768 96 -> 89 us,
   // N = 1000 126 -> 110 us, N = 2000 336 -> 182 us), and 4 whenever the batch fits in one residency round of cooperative
   // workgroups (1024 = 256 CUs x 4; only latency matters then: N = 1000, B = 512: 37 -> 28 us).
-  const unsigned force_wpp = (flags >> 25) & 3u;  // undocumented diagnostic: 1, 2 -> 2, 3 -> 4 wavefronts per pair
+  const unsigned force_wpp = (flags & DFEPE_W8PT_WAVE_PER_PAIR) ? 1u : 0u;  // one wavefront per pair, never a cooperative workgroup
   const bool can_coop = (N >= 256) && (wave_bytes + kCoopBytes <= lds_cap);
   const int blocks_coop = can_coop ? lds_cap / (wave_bytes + kCoopBytes) : 0;
   int wpp = 1;
@@ -818,7 +811,7 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)          \
       return DFEPE_ERR_HIP;                                                                                                 \
     hipLaunchKernelGGL((w8pt_fwd_kernel<R, C>), grid, block, lds, st, pts1, pts2, weights, B, Bm, N, npad, wave_bytes, hw_sx, \
-                       hw_sy, clamp_at, F_out, residual, epi_res, save, weights_out, logits_mode, variant, dbg);            \
+                       hw_sy, clamp_at, F_out, residual, epi_res, save, weights_out, logits_mode, variant);            \
   } while (0)
   if (raw) {
     if (wpp == 4) DFEPE_LAUNCH_FWD(true, 4); else if (wpp == 2) DFEPE_LAUNCH_FWD(true, 2); else DFEPE_LAUNCH_FWD(true, 1);

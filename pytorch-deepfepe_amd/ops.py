@@ -34,16 +34,18 @@ def save_floats() -> int:
 # ------------------------------------------------------------------------------------------------
 # weighted 8-point fit
 # ------------------------------------------------------------------------------------------------
-def _flags(raw: bool, logits: bool) -> int:
-    return (_lib.W8PT_RAW_MATCHES if raw else 0) | (_lib.W8PT_LOGITS if logits else 0)
+def _flags(raw: bool, logits: bool, wave_per_pair: bool = False) -> int:
+    return ((_lib.W8PT_RAW_MATCHES if raw else 0) | (_lib.W8PT_LOGITS if logits else 0) |
+            (_lib.W8PT_WAVE_PER_PAIR if wave_per_pair else 0))
 
 
 def w8pt_forward(pts1: Tensor, pts2: Optional[Tensor], weights: Tensor, raw: bool, image_w: float, image_h: float,
                  clamp_at: float, want_epi: bool, want_save: bool, logits: bool = False, F_out: Optional[Tensor] = None,
-                 diag: int = 0):
+                 wave_per_pair: bool = False):
     """Raw (non-differentiable) launch.  weights (or logits when ``logits``) [B,N].
     Returns F [B,3,3], residual [B,N], epi [B,N]|None, save|None, weights_out [B,N]|None.  ``F_out`` lets the caller
-    provide the destination (e.g. one [B,3,3] slice of a per-layer stack)."""
+    provide the destination (e.g. one [B,3,3] slice of a per-layer stack).  ``wave_per_pair`` forces the one-wavefront-per-pair
+    kernel where the row-per-pair kernel (N <= 128) would run; the matching backward call must pass the same value."""
     L = _lib.lib()
     B, N = weights.shape
     dev = weights.device
@@ -53,14 +55,14 @@ def w8pt_forward(pts1: Tensor, pts2: Optional[Tensor], weights: Tensor, raw: boo
     save = torch.empty(B, L.dfepe_save_floats(), device=dev, dtype=torch.float32) if want_save else None
     w_out = torch.empty(B, N, device=dev, dtype=torch.float32) if logits else None
     with torch.cuda.device(dev):
-        rc = L.dfepe_w8pt_fwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, 1, _flags(raw, logits) | (int(diag) << 16), float(image_w),
+        rc = L.dfepe_w8pt_fwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, 1, _flags(raw, logits, wave_per_pair), float(image_w),
                               float(image_h), float(clamp_at), _ptr(F), _ptr(residual), _ptr(epi), _ptr(save), _ptr(w_out), _stream())
     _lib.check(rc, "dfepe_w8pt_fwd")
     return F, residual, epi, save, w_out
 
 
 def w8pt_backward(pts1, pts2, weights, raw, image_w, image_h, clamp_at, save, F, gF, gRes, gEpi, logits=False, gW_extra=None,
-                  out: Optional[Tensor] = None, want_pts: bool = False):
+                  out: Optional[Tensor] = None, want_pts: bool = False, wave_per_pair: bool = False):
     """Raw launch of the adjoint; returns d/d(weights) (or d/d(logits) when ``logits``; then ``weights`` must be the
     forward's weights_out) and, when ``want_pts``, the gradients w.r.t. the points ([B,N,3] x 2, or [B,N,4] for raw matches)."""
     L = _lib.lib()
@@ -71,7 +73,7 @@ def w8pt_backward(pts1, pts2, weights, raw, image_w, image_h, clamp_at, save, F,
         gP1 = torch.empty_like(pts1)
         gP2 = None if raw else torch.empty_like(pts2)
     with torch.cuda.device(weights.device):
-        rc = L.dfepe_w8pt_bwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, 1, _flags(raw, logits), float(image_w), float(image_h),
+        rc = L.dfepe_w8pt_bwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, 1, _flags(raw, logits, wave_per_pair), float(image_w), float(image_h),
                               float(clamp_at), _ptr(save), _ptr(F), _ptr(gF), _ptr(gRes), _ptr(gEpi), _ptr(gW_extra), _ptr(gW),
                               _ptr(gP1), _ptr(gP2), _stream())
     _lib.check(rc, "dfepe_w8pt_bwd")

@@ -1,0 +1,171 @@
+"""The row-per-pair HIP kernel bodies (csrc/w8pt16_body.h, csrc/w8pt16_bwd_body.h), compiled for the HOST against the
+row-group emulation of tests/emu/ and compared with the oracle.  Runs without a GPU: it checks the arithmetic of the
+kernels' own source (every phase, the save record, the analytic adjoint), not the DPP encodings -- those are covered on
+the GPU box by tests/test_rowgroup_gpu.py.  The emulation library is test infrastructure; the product never loads it."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+EMU_DIR = os.path.join(REPO, "tests", "emu")
+IMAGE_SIZE = [376, 1241, 3]
+RAW, LOGITS = 1, 2
+
+
+@pytest.fixture(scope="session")
+def emu():
+    out = os.path.join(EMU_DIR, "_build")
+    os.makedirs(out, exist_ok=True)
+    lib = os.path.join(out, "libemu_w8pt16.so")
+    srcs = [os.path.join(EMU_DIR, "emu_w8pt16.cpp"), os.path.join(EMU_DIR, "rowgroup.h")] + [
+        os.path.join(REPO, "pytorch-deepfepe_amd", "csrc", f) for f in ("w8pt16_body.h", "w8pt16_bwd_body.h", "dfepe_math.h")]
+    if not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", f"-I{EMU_DIR}", f"-I{REPO}/pytorch-deepfepe_amd/csrc",
+                        f"-I{REPO}/include", srcs[0], "-o", lib], check=True)
+    L = ctypes.CDLL(lib)
+    P, I, U, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_float
+    L.emu_w8pt16_fwd.restype = I
+    L.emu_w8pt16_fwd.argtypes = [P, P, P, I, I, I, U, F, F, F, P, P, P, P, P]
+    L.emu_w8pt16_bwd.restype = I
+    L.emu_w8pt16_bwd.argtypes = [P, P, P, I, I, I, U, F, F, F, P, P, P, P, P, P, P, P, P]
+    return L
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def emu_fwd(L, pts1, pts2, w, flags, want_epi=True, want_save=True, clamp_at=0.5):
+    B, N = w.shape
+    F = torch.empty(B, 3, 3)
+    res = torch.empty(B, N)
+    epi = torch.empty(B, N) if want_epi else None
+    save = torch.zeros(B, 128) if want_save else None
+    wout = torch.empty(B, N) if flags & LOGITS else None
+    rc = L.emu_w8pt16_fwd(_p(pts1), _p(pts2), _p(w), B, N, 1, flags, float(IMAGE_SIZE[1]), float(IMAGE_SIZE[0]), clamp_at,
+                          _p(F), _p(res), _p(epi), _p(save), _p(wout))
+    assert rc == 0
+    return F, res, epi, save, wout
+
+
+def emu_bwd(L, pts1, pts2, w, flags, save, F, gF, gRes, gEpi, want_pts=False, clamp_at=0.5):
+    B, N = w.shape
+    gW = torch.empty(B, N)
+    gP1 = torch.empty_like(pts1) if want_pts else None
+    gP2 = torch.empty_like(pts2) if (want_pts and pts2 is not None) else None
+    rc = L.emu_w8pt16_bwd(_p(pts1), _p(pts2), _p(w), B, N, 1, flags, float(IMAGE_SIZE[1]), float(IMAGE_SIZE[0]), clamp_at,
+                          _p(save), _p(F), _p(gF), _p(gRes), _p(gEpi), None, _p(gW), _p(gP1), _p(gP2))
+    assert rc == 0
+    return gW, gP1, gP2
+
+
+def unit_align(a, ref):
+    a = a.reshape(a.shape[0], -1).double()
+    r = ref.reshape(ref.shape[0], -1).double()
+    a = a / a.norm(dim=1, keepdim=True)
+    r = r / r.norm(dim=1, keepdim=True)
+    s = torch.sign((a * r).sum(1, keepdim=True))
+    s[s == 0] = 1
+    return a * s, r, s[:, 0]
+
+
+@pytest.mark.parametrize("B,N,outl,noise", [(24, 100, 0.2, 0.5), (8, 100, 0.4, 0.5), (8, 100, 0.0, 0.0), (6, 128, 0.2, 0.5),
+                                            (6, 113, 0.2, 0.5), (6, 64, 0.2, 0.5), (6, 17, 0.2, 0.5), (6, 16, 0.2, 0.5),
+                                            (6, 12, 0.2, 0.5), (6, 9, 0.2, 0.5), (6, 8, 0.2, 0.5), (4, 5, 0.2, 0.5)])
+def test_forward_body_matches_fp64_oracle(emu, dfepe, oracle, B, N, outl, noise):
+    sc = dfepe.synth.make_scene(B, N, seed=7 * N + B, outlier_ratio=outl, noise_px=noise)
+    m = sc["matches_xy_ori"].contiguous()
+    logits = sc["logits_layers"][0].contiguous()
+    w = torch.softmax(logits, dim=1)
+    F, res, epi, save, wout = emu_fwd(emu, m, None, logits, RAW | LOGITS)
+    np.testing.assert_allclose(wout.numpy(), w.numpy(), rtol=2e-6, atol=1e-9)
+    p1, p2, _ = oracle.normalize_hw(m.double(), IMAGE_SIZE)
+    o_out, o_res, _ = oracle.fit_forward(p1, p2, wout.double().unsqueeze(1))
+    a, r, s = unit_align(F, o_out)
+    tol = 1e-5 if N < 12 else 1e-6  # near-minimal systems are ill-conditioned
+    assert (a - r).norm(dim=1).max().item() < 2 * tol  # the fp32 image-size normalisation x^ = 2x/W - 1 differs by 1 ulp
+    np.testing.assert_allclose((res * s[:, None]).numpy(), o_res.numpy(), atol=5e-7, rtol=1e-4)
+    o_epi = oracle.compute_epi_residual(p1, p2, o_out, 0.5).numpy()
+    np.testing.assert_allclose(epi.numpy(), o_epi, atol=5e-5, rtol=1e-3)
+    # same function through the homogeneous-points entry with plain weights
+    p1f, p2f, _ = oracle.normalize_hw(m, IMAGE_SIZE)
+    F2, res2, _, _, _ = emu_fwd(emu, p1f.contiguous(), p2f.contiguous(), wout, 0)
+    o2, _, _ = oracle.fit_forward(p1f.double(), p2f.double(), wout.double().unsqueeze(1))  # same fp32-rounded points
+    a2, r2, _ = unit_align(F2, o2)
+    assert (a2 - r2).norm(dim=1).max().item() < tol
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-300)
+
+
+@pytest.mark.parametrize("N,outl", [(100, 0.0), (100, 0.4), (128, 0.2), (20, 0.2), (9, 0.0)])
+@pytest.mark.parametrize("use_res,use_epi", [(False, False), (True, False), (True, True)])
+def test_backward_body_vs_oracle_autograd(emu, dfepe, oracle, N, outl, use_res, use_epi):
+    """d/d(logits) of <F, GF> + <residual, GR> + <epi, GE> through the emulated w8pt16 forward + backward bodies against
+    fp64 autograd of the oracle (same sign gauge).  Tolerance: the save record carries f, z, the reflectors and the 3x3
+    SVD in fp32 (relative 1e-7, no gap amplification); T and lambda travel in fp64."""
+    B = 5
+    sc = dfepe.synth.make_scene(B, N, seed=7 + N, outlier_ratio=outl)
+    g = torch.Generator().manual_seed(1)
+    m = sc["matches_xy_ori"].contiguous()
+    logits = sc["logits_layers"][0].contiguous()
+    GF = torch.randn(B, 3, 3, generator=g)
+    GR = torch.randn(B, N, generator=g) if use_res else None
+    GE = torch.randn(B, N, generator=g) if use_epi else None
+    F, res, epi, save, wout = emu_fwd(emu, m, None, logits, RAW | LOGITS)
+    assert (save[:, 127] == 16.0).all()
+    gL, _, _ = emu_bwd(emu, m, None, wout, RAW | LOGITS, save, F, GF, GR, GE)
+    lo_in = logits.double().requires_grad_(True)
+    wo = torch.softmax(lo_in, 1)
+    p1, p2, _ = oracle.normalize_hw(m.double(), IMAGE_SIZE)
+    o_out, o_res, _ = oracle.fit_forward(p1, p2, wo.unsqueeze(1))
+    s = torch.sign((o_out.detach() * F.double()).flatten(1).sum(1))
+    lo = (s[:, None, None] * o_out * GF.double()).sum()
+    if use_res:
+        lo = lo + (s[:, None] * o_res * GR.double()).sum()
+    if use_epi:
+        lo = lo + (oracle.compute_epi_residual(p1, p2, o_out, 0.5) * GE.double()).sum()
+    lo.backward()
+    assert relerr(gL.numpy(), lo_in.grad.numpy()) < (2e-4 if N >= 20 else 2e-3)
+
+
+@pytest.mark.parametrize("raw", [True, False])
+def test_point_gradients_body_vs_oracle_autograd(emu, dfepe, oracle, raw):
+    B, N = 4, 60
+    sc = dfepe.synth.make_scene(B, N, seed=21, outlier_ratio=0.2)
+    g = torch.Generator().manual_seed(3)
+    m = sc["matches_xy_ori"].contiguous()
+    w = torch.softmax(sc["logits_layers"][0], 1).contiguous()
+    GF = torch.randn(B, 3, 3, generator=g)
+    GR = torch.randn(B, N, generator=g)
+    GE = torch.randn(B, N, generator=g)
+    if raw:
+        F, res, epi, save, _ = emu_fwd(emu, m, None, w, RAW)
+        gW, gP1, _ = emu_bwd(emu, m, None, w, RAW, save, F, GF, GR, GE, want_pts=True)
+        mo = m.double().requires_grad_(True)
+        p1, p2, _ = oracle.normalize_hw(mo, IMAGE_SIZE)
+    else:
+        p1f, p2f, _ = oracle.normalize_hw(m, IMAGE_SIZE)
+        p1f, p2f = p1f.contiguous(), p2f.contiguous()
+        F, res, epi, save, _ = emu_fwd(emu, p1f, p2f, w, 0)
+        gW, gP1, gP2 = emu_bwd(emu, p1f, p2f, w, 0, save, F, GF, GR, GE, want_pts=True)
+        p1 = p1f.double().requires_grad_(True)
+        p2 = p2f.double().requires_grad_(True)
+    wo = w.double().requires_grad_(True)
+    o_out, o_res, _ = oracle.fit_forward(p1, p2, wo.unsqueeze(1))
+    s = torch.sign((o_out.detach() * F.double()).flatten(1).sum(1))
+    lo = (s[:, None, None] * o_out * GF.double()).sum() + (s[:, None] * o_res * GR.double()).sum()
+    lo = lo + (oracle.compute_epi_residual(p1, p2, o_out, 0.5) * GE.double()).sum()
+    lo.backward()
+    assert relerr(gW.numpy(), wo.grad.numpy()) < 2e-4
+    if raw:
+        assert relerr(gP1.numpy(), mo.grad.numpy()) < 5e-4
+    else:
+        assert relerr(gP1[:, :, :2].numpy(), p1.grad[:, :, :2].numpy()) < 5e-4
+        assert relerr(gP2[:, :, :2].numpy(), p2.grad[:, :, :2].numpy()) < 5e-4

@@ -191,6 +191,6 @@ def test_two_wavefronts_per_pair_variant(dfepe, oracle):
     a, r, s_ = unit_align(F.cpu().numpy(), o_out.numpy())
     assert np.linalg.norm(a - r, axis=1).max() < 5e-6
     np.testing.assert_allclose(res.cpu().numpy() * s_[:, None], o_res.numpy(), atol=1e-6, rtol=1e-4)
-    # and it is the same function as the one-wavefront-per-pair kernel (diagnostic flag bit 25 forces that variant)
-    F1 = dfepe.ops.w8pt_forward(m.to(DEV), None, w.to(DEV), True, float(IMAGE_SIZE[1]), float(IMAGE_SIZE[0]), 0.5, True, False, diag=0x200)[0]
+    # and it is the same function as the one-wavefront-per-pair kernel (DFEPE_W8PT_WAVE_PER_PAIR forces that variant)
+    F1 = dfepe.ops.w8pt_forward(m.to(DEV), None, w.to(DEV), True, float(IMAGE_SIZE[1]), float(IMAGE_SIZE[0]), 0.5, True, False, wave_per_pair=True)[0]
     assert (F1 - F).abs().max().item() < 2e-6 * F.abs().max().item()
