@@ -104,6 +104,9 @@ int dfepe_w8pt_fwd(const float *pts1, const float *pts2, const float *weights, i
  *   g_weights_extra [B,N] or NULL: with DFEPE_W8PT_LOGITS, an upstream gradient on the `weights_out` tensor itself
  *     (the next estimator layer reads the weights, DeepFNet.py:487); added before the softmax adjoint
  *   with DFEPE_W8PT_LOGITS `weights` must be the forward's `weights_out` and g_weights receives d/d(logits)
+ *   g_scale: device pointer to ONE float that multiplies the three upstream gradients (NULL = 1): the upstream gradient of a
+ *     scalar loss whose d loss / d F was formed with unit upstream (dfepe_loss_tail), applied here because everything
+ *     downstream of g_F, g_residual, g_epi is linear in them
  *   g_weights [B,N]: written (not accumulated)
  *   g_pts1, g_pts2 [B,N,3] or NULL: gradient w.r.t. the point coordinates (through the rows, the Hartley transforms and,
  *     when g_epi is given, the residual's direct dependence); with DFEPE_W8PT_RAW_MATCHES g_pts1 is [B,N,4] (gradient
@@ -113,7 +116,7 @@ int dfepe_w8pt_bwd(const float *pts1, const float *pts2, const float *weights, i
                    unsigned flags, float image_w, float image_h, float clamp_at,
                    const float *save, const float *F_out,
                    const float *g_F, const float *g_residual, const float *g_epi, const float *g_weights_extra,
-                   float *g_weights, float *g_pts1, float *g_pts2, void *stream);
+                   const float *g_scale, float *g_weights, float *g_pts1, float *g_pts2, void *stream);
 
 /*
  * F-loss and E-from-F over all layers.
@@ -167,6 +170,29 @@ int dfepe_pose_bwd(const float *E_layers, int L, int B, const float *q_gt, const
 int dfepe_loss_head(const float *loss_sum, const float *q_l2, const float *t_l2, int L, int B, int M,
                     float clamp_q, float clamp_t, float balance_q, float balance_t,
                     double *packed, float *scalars, void *stream);
+
+/*
+ * The whole loss tail of the hot-path step in ONE launch (one 16-lane row per pair): dfepe_floss_fwd + E-from-F +
+ * dfepe_pose_fwd + dfepe_loss_head, and -- when g_F_layers != NULL -- dfepe_pose_bwd + dfepe_floss_bwd for
+ *     loss = balance_F * mean_{l,b,m}(F-loss) + balance_q * mean_{l,b}(clamp(q_l2, 0, clamp_q)) + balance_t * mean_{l,b}(clamp(t_l2, 0, clamp_t))
+ * with unit upstream gradient (every coefficient of such a loss is a constant: the adjoint of a term is formed where its
+ * forward value is).  Replaces: get_all_loss_DeepF's per-layer body (deepFEPE/train_good_utils.py:325-358), get_Rt_loss's
+ * loop (:96-239) and the loss mixing of Train_model_pipeline.py:580-587 (which uses balance_F = 0 when if_qt_loss).
+ *   arguments as in dfepe_floss_fwd / dfepe_pose_fwd / dfepe_loss_head; M <= 128 (else DFEPE_ERR_UNSUPPORTED: use those)
+ *   q_gt == NULL: no pose part (then t_gt, q_l2, t_l2, R_deg, t_deg, sel are ignored)
+ *   grad_pairs: number of pairs the means run over in the gradient coefficients (B, or the global batch under data parallelism)
+ *   g_F_layers [L,B,9] or NULL; feed it to dfepe_w8pt_bwd with g_scale = the upstream gradient of the loss
+ *   packed [L+4] doubles, scalars [4+L] floats: as dfepe_loss_head, scalars[0] = balance_F * loss_F + loss_qt
+ *   workspace: dfepe_loss_tail_workspace_bytes(B) bytes, 8-byte aligned, its first 4 bytes ZERO before the first launch
+ *     (the kernel leaves them zero); batch sums are combined in a fixed order (no floating-point atomics): deterministic
+ */
+size_t dfepe_loss_tail_workspace_bytes(int B);
+int dfepe_loss_tail(const float *F_layers, int L, int B, const float *T1, const float *T2, int t_stride, const float *K,
+                    const float *virt1, const float *virt2, int M, float clamp_at,
+                    const float *q_gt, const float *t_gt, const float *R_gt, float clamp_q, float clamp_t,
+                    float balance_F, float balance_q, float balance_t, double grad_pairs,
+                    float *loss_sum, float *E_layers, float *q_l2, float *t_l2, float *R_deg, float *t_deg, int *sel,
+                    float *g_F_layers, double *packed, float *scalars, void *workspace, void *stream);
 
 /*
  * Cheirality-checked pose from E.

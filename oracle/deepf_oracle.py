@@ -484,14 +484,16 @@ def unit_frobenius(A: Tensor) -> Tensor:
 
 def hot_path_step(scene: Dict[str, Tensor], image_size, depth: int, clamp_at: float, qt: bool, mode: str,
                   clamp_q: float = 0.1, clamp_t: float = 0.5, balance_q: float = 1.0, balance_t: float = 0.1,
-                  backward: bool = True):
+                  backward: bool = True, balance_F: float = 1.0):
     """One pass of the hot path the way bench.py times it: depth fits with fixed per-layer logits,
     F-loss, E-from-F, pose loss, and (optionally) backward to the logits.  ``mode='loop'`` is the
     reference-shaped per-sample structure (DeepFNet.py:232-240, train_good_utils.py:106-239)."""
     logits = scene["logits_layers"][:depth].clone().requires_grad_(backward)
     outs = deepf_forward(scene["matches_xy_ori"], image_size, depth, logits_layers=logits, mode=mode)
     losses, E_ests, F_ests, E_layers = f_loss(outs, scene["pts1_virt_ori"], scene["pts2_virt_ori"], scene["Ks"], depth, clamp_at)
-    loss = losses["loss_F"]
+    # Train_model_pipeline.py:580-587 drops the F-loss from the objective when if_qt_loss (`loss += loss_F*balance_F` is
+    # commented out): that is balance_F = 0; the solver-only benchmark step keeps both terms (balance_F = 1)
+    loss = losses["loss_F"] * balance_F
     pose = None
     if qt:
         pose = rt_loss(E_layers, scene["delta_Rtijs_4_4"], scene["qs_cam"], scene["ts_cam"])

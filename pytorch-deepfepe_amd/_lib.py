@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdfepe_hip.so")
@@ -29,12 +29,15 @@ _SIGNATURES = {
     "dfepe_save_floats": (c_int, []),
     "dfepe_selftest_rowgroup": (c_int, [_P, _P, _P, _P]),
     "dfepe_w8pt_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_uint, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P]),
-    "dfepe_w8pt_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_uint, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dfepe_w8pt_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_uint, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dfepe_floss_fwd": (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, c_float, _P, _P, _P]),
     "dfepe_floss_bwd": (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, c_float, _P, c_float, _P, _P, _P, _P]),
     "dfepe_pose_fwd": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dfepe_pose_bwd": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, c_float, c_float, c_float, c_float, _P, _P, _P]),
     "dfepe_loss_head": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, _P, _P, _P]),
+    "dfepe_loss_tail_workspace_bytes": (c_size_t, [c_int]),
+    "dfepe_loss_tail": (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, c_float, _P, _P, _P, c_float, c_float, c_float, c_float,
+                                c_float, c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dfepe_cheirality": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P, _P]),
     "dfepe_epi_metrics": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_float, c_float, _P, _P]),
     "dfepe_epi_residual_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P]),

@@ -31,8 +31,9 @@ __device__ __forceinline__ double fast_sqrt(double x) { return (x > 0.0) ? x * f
 template <int STEPS>
 __device__ __forceinline__ double rsqrt_nr(double x) {
   double y = (double)hw_rsq(fminf(fmaxf((float)x, 1e-37f), 1e37f));
+  const double h = -0.5 * x;
 #pragma unroll
-  for (int k = 0; k < STEPS; ++k) y = y * fma(-0.5 * x, y * y, 1.5);
+  for (int k = 0; k < STEPS; ++k) y = fma(y, fma(h, y * y, 0.5), y);  // y (1.5 - x y^2 / 2) with inline constants only
   return y;
 }
 template <int STEPS>
@@ -42,7 +43,7 @@ __device__ __forceinline__ double rcp_nr(double x) {
   const float xf = (float)x;
   double y = (double)hw_rcp(copysignf(fminf(fmaxf(fabsf(xf), 1e-37f), 1e37f), xf));
 #pragma unroll
-  for (int k = 0; k < STEPS; ++k) y = y * fma(-x, y, 2.0);
+  for (int k = 0; k < STEPS; ++k) y = fma(y, fma(-x, y, 1.0), y);  // y (2 - x y)
   return y;
 }
 

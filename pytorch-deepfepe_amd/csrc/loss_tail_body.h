@@ -1,0 +1,199 @@
+// loss_tail -- the whole loss tail of the hot-path step for one image pair, forward AND backward, in one 16-lane row:
+//   F-loss on the virtual points for every layer      get_all_loss_DeepF, deepFEPE/train_good_utils.py:325-358
+//   E_l = K^T T2^T F_l T1 K                            train_good_utils.py:356-358
+//   pose errors / metrics of every layer               get_Rt_loss, train_good_utils.py:96-239 (pose_math.h)
+//   d loss / d F_l  for  loss = balance_F mean(F-loss) + balance_q mean(clamp q_l2) + balance_t mean(clamp t_l2)
+// Every gradient coefficient of such a loss is a constant known before the launch (means and clamps only), so the adjoint
+// of each term is formed right where its forward value is: the epipolar terms of a virtual point are computed once and feed
+// both the loss sum and the gradient sum; the pose adjoint follows the pose errors in the same lane.  This replaces five
+// launches (floss_fwd, pose_fwd, loss_head, pose_bwd, floss_bwd: ~47 us of mostly launch latency and dependent global loads
+// at B = 4096) by one.  Lanes stride over the M <= 128 virtual points (transformed once, kept in registers for all layers);
+// lane l < L owns layer l for the 3x3 work (E, pose forward + adjoint).  Written against rowgroup.h only (tests/emu/).
+#pragma once
+#include <rowgroup.h>  // angle brackets on purpose: tests/emu/ substitutes its host emulation through the include path
+
+#include "dfepe.h"
+#include "dfepe_math.h"
+#include "pose_math.h"
+
+constexpr int kTailMaxLayers = 16;
+constexpr int kTailLdsFloats = 2 * kTailMaxLayers * 9;  // per pair: F of every layer, then the pose part of d loss / d F
+constexpr int kTailParts = 3 * kTailMaxLayers;          // per pair: loss_sum[l], clamp(q_l2[l]), clamp(t_l2[l])
+
+struct TailArgs {
+  const float* F_layers;  // [L,B,9]
+  int L, B, M, t_stride;
+  const float* T1;
+  const float* T2;
+  const float* K;
+  const float* virt1;
+  const float* virt2;
+  float clamp_at;
+  const float* q_gt;  // nullptr: no pose part
+  const float* t_gt;
+  const float* R_gt;  // may be nullptr (no R_deg)
+  float clamp_q, clamp_t;
+  float coef_F, coef_q, coef_t;  // d loss / d loss_sum[l,b], d loss / d clamp(q_l2[l,b]), d loss / d clamp(t_l2[l,b])
+  float* loss_sum;    // [L,B]
+  float* E_layers;    // [L,B,9]
+  float* q_l2;        // [L,B] ...
+  float* t_l2;
+  float* R_deg;
+  float* t_deg;
+  int* sel;
+  float* g_F;         // [L,B,9] or nullptr (forward only)
+};
+
+// Per-point epipolar terms in fp32 (the reference computes the F-loss in fp32, train_good_utils.py:340-342; utils_F.py:402-411)
+struct TailEpi {
+  float d, dd, n1, n2, i1, i2;
+  float l1[3], l2[3];
+};
+__device__ __forceinline__ TailEpi tail_epi_terms(const float* x1, const float* x2, const float* o) {
+  TailEpi e;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) e.l1[c] = fmaf(x2[0], o[c], fmaf(x2[1], o[3 + c], x2[2] * o[6 + c]));
+#pragma unroll
+  for (int r = 0; r < 3; ++r) e.l2[r] = fmaf(o[3 * r], x1[0], fmaf(o[3 * r + 1], x1[1], o[3 * r + 2] * x1[2]));
+  e.dd = fmaf(x1[0], e.l1[0], fmaf(x1[1], e.l1[1], x1[2] * e.l1[2]));
+  e.n1 = hw_sqrt(fmaf(e.l1[0], e.l1[0], e.l1[1] * e.l1[1]));
+  e.n2 = hw_sqrt(fmaf(e.l2[0], e.l2[0], e.l2[1] * e.l2[1]));
+  e.i1 = hw_rcp(e.n1 + 1e-6f);
+  e.i2 = hw_rcp(e.n2 + 1e-6f);
+  e.d = fabsf(e.dd) * (e.i1 + e.i2);
+  return e;
+}
+
+// T * pixel in fp64 (pixels ~1e3 times 2/W minus 1 cancels ~3 digits), rounded once to fp32 like the reference's pts_eval
+__device__ __forceinline__ void tail_eval_point(const float* v, const double* T, float* x) {
+  const double a = v[0], b = v[1], c = v[2];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) x[r] = (float)(T[3 * r] * a + T[3 * r + 1] * b + T[3 * r + 2] * c);
+}
+
+// lds: kTailLdsFloats floats, part: kTailParts doubles (zero-initialised by the caller), both private to this pair's row
+template <int IT>
+__device__ __forceinline__ void loss_tail_pair(const TailArgs& A, const int pair, float* lds, double* part) {
+  const int l = rg_lane();
+  const int L = A.L, B = A.B, M = A.M;
+  float* ldsF = lds;                       // [L][9] F of every layer
+  float* ldsG = lds + kTailMaxLayers * 9;  // [L][9] pose part of d loss / d F
+  double t1[9], t2[9], Am[9], Cm[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) { t1[c] = A.T1[(size_t)pair * A.t_stride + c]; t2[c] = A.T2[(size_t)pair * A.t_stride + c]; }
+  {
+    double k[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) k[c] = A.K[(size_t)pair * 9 + c];
+    mat3_mul(t2, k, Am);  // A = T2 K, C = T1 K:  E = A^T F C
+    mat3_mul(t1, k, Cm);
+  }
+  // the pair's virtual points, transformed once (unconditional loads, index clamped, masked afterwards)
+  float x1[IT][3], x2[IT][3], vm[IT];
+  const float* v1 = A.virt1 + (size_t)pair * M * 3;
+  const float* v2 = A.virt2 + (size_t)pair * M * 3;
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int i = it * 16 + l;
+    const int ic = (i < M) ? i : M - 1;
+    tail_eval_point(v1 + 3 * ic, t1, x1[it]);
+    tail_eval_point(v2 + 3 * ic, t2, x2[it]);
+    vm[it] = (i < M) ? 1.0f : 0.0f;
+  }
+  for (int e = l; e < L * 9; e += 16) {
+    const int ly = e / 9, c = e - 9 * ly;
+    ldsF[e] = A.F_layers[((size_t)ly * B + pair) * 9 + c];
+    ldsG[e] = 0.0f;
+  }
+  rg_sync();
+
+  // ---- lane l < L: E of layer l, its pose errors and their adjoint ---------------------------------------------
+  if (l < L) {
+    const size_t lb = (size_t)l * B + pair;
+    double o[9], tmp[9], e[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) o[c] = (double)ldsF[l * 9 + c];
+    mat3_mul_tn(Am, o, tmp);
+    mat3_mul(tmp, Cm, e);
+    float Ef[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { Ef[c] = (float)e[c]; A.E_layers[lb * 9 + c] = Ef[c]; }
+    if (A.q_gt != nullptr) {
+      Pose P;
+      pose_forward(Ef, A.q_gt + (size_t)pair * 4, A.t_gt + (size_t)pair * 3, P);  // on the fp32 E, like dfepe_pose_fwd on E_layers
+      const double qe = P.qe[P.qi], te = P.te[P.ti];
+      A.q_l2[lb] = (float)qe;
+      A.t_l2[lb] = (float)te;
+      if (A.sel != nullptr) A.sel[lb] = P.qi | (P.ti << 1);
+      if (A.R_deg != nullptr && A.R_gt != nullptr) A.R_deg[lb] = (float)pose_R_deg(P, A.R_gt + (size_t)pair * 9);
+      if (A.t_deg != nullptr) A.t_deg[lb] = (float)pose_t_deg(P);
+      part[kTailMaxLayers + l] = (double)fminf(fmaxf((float)qe, 0.0f), A.clamp_q);
+      part[2 * kTailMaxLayers + l] = (double)fminf(fmaxf((float)te, 0.0f), A.clamp_t);
+      if (A.g_F != nullptr) {
+        // torch.clamp passes the gradient on [min, max] inclusive
+        const double gql = ((float)qe <= A.clamp_q) ? (double)A.coef_q : 0.0;
+        const double gtl = ((float)te <= A.clamp_t) ? (double)A.coef_t : 0.0;
+        double gE[9], add[9];
+        pose_backward(P, A.q_gt + (size_t)pair * 4, gql, gtl, gE);
+        // through dfepe_pose_bwd's fp32 g_E, then E = A^T F C:  g_F += A g_E C^T
+#pragma unroll
+        for (int c = 0; c < 9; ++c) gE[c] = (double)(float)gE[c];
+        mat3_mul(Am, gE, tmp);
+        mat3_mul_nt(tmp, Cm, add);
+#pragma unroll
+        for (int c = 0; c < 9; ++c) ldsG[l * 9 + c] = (float)add[c];
+      }
+    }
+  }
+  rg_sync();
+
+  // ---- F-loss of every layer over the virtual points, with its gradient ---------------------------------------------
+  const bool grad = A.g_F != nullptr;
+  for (int ly = 0; ly < L; ++ly) {
+    float o[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) o[c] = ldsF[ly * 9 + c];
+    float accf = 0.0f;
+    float gof[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) gof[c] = 0.0f;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const TailEpi e = tail_epi_terms(x1[it], x2[it], o);
+      accf = fmaf(vm[it], fminf(e.d, A.clamp_at), accf);
+      if (grad) {
+        // d d / d F[r][c] = sg S x2[r] x1[c] - k1 l1[c] x2[r] [c<2] - k2 l2[r] x1[c] [r<2]
+        //                 = x2[r] a[c] - b[r] x1[c],  a[c] = sg S x1[c] - k1 l1[c] [c<2],  b[r] = k2 l2[r] [r<2]
+        const float mk = (e.d <= A.clamp_at) ? vm[it] : 0.0f;  // clamp(max=) passes the gradient up to and including the bound
+        const float S = e.i1 + e.i2, ad = fabsf(e.dd);
+        const float sg = (e.dd > 0.0f) ? mk : ((e.dd < 0.0f) ? -mk : 0.0f);
+        const float k1 = (e.n1 > 0.0f) ? mk * ad * e.i1 * e.i1 * hw_rcp(e.n1) : 0.0f;
+        const float k2 = (e.n2 > 0.0f) ? mk * ad * e.i2 * e.i2 * hw_rcp(e.n2) : 0.0f;
+        const float sS = sg * S;
+        const float a0 = fmaf(sS, x1[it][0], -k1 * e.l1[0]), a1 = fmaf(sS, x1[it][1], -k1 * e.l1[1]), a2 = sS * x1[it][2];
+        const float b0 = k2 * e.l2[0], b1 = k2 * e.l2[1];
+        const float av[3] = {a0, a1, a2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          gof[c] += fmaf(x2[it][0], av[c], -b0 * x1[it][c]);
+          gof[3 + c] += fmaf(x2[it][1], av[c], -b1 * x1[it][c]);
+          gof[6 + c] = fmaf(x2[it][2], av[c], gof[6 + c]);
+        }
+      }
+    }
+    const float acc = rg_sum(accf);  // <= 128 terms of at most clamp_at each: fp32 like the reference's own sum
+    if (l == 0) {
+      A.loss_sum[(size_t)ly * B + pair] = acc;
+      part[ly] = (double)acc;
+    }
+    if (grad) {
+      float mine = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        const float tot = rg_sum(gof[c]);
+        mine = (l == c) ? tot : mine;
+      }
+      if (l < 9) A.g_F[((size_t)ly * B + pair) * 9 + l] = fmaf(A.coef_F, mine, ldsG[ly * 9 + l]);
+    }
+  }
+}

@@ -11,13 +11,13 @@ namespace {
 
 constexpr int kPairsPerBlock = 16;
 
-template <int IT, bool RAW>
+template <int IT, bool RAW, bool PLAIN>
 __global__ void __launch_bounds__(256) w8pt16_fwd_kernel(const W8Args A) {
   __shared__ double xch[kPairsPerBlock * 36];
   const int row = (int)(threadIdx.x >> 4);
   const int pair = (int)blockIdx.x * kPairsPerBlock + row;
   if (pair >= A.B) return;  // a whole row leaves; rows never wait for each other
-  w8pt16_fwd_pair<IT, RAW>(A, pair, xch + row * 36);
+  w8pt16_fwd_pair<IT, RAW, PLAIN>(A, pair, xch + row * 36);
 }
 
 template <int IT, bool RAW, bool PGRAD>
@@ -28,15 +28,15 @@ __global__ void __launch_bounds__(256) w8pt16_bwd_kernel(const W8BwdArgs A) {
   w8pt16_bwd_pair_impl<IT, RAW, PGRAD>(A, pair, nullptr);
 }
 
-template <bool RAW>
+template <bool RAW, bool PLAIN>
 void launch_fwd(const W8Args& A, hipStream_t st) {
   const dim3 grid((A.B + kPairsPerBlock - 1) / kPairsPerBlock), block(256);
   const int N = A.N;
-  if (N <= 16) hipLaunchKernelGGL((w8pt16_fwd_kernel<1, RAW>), grid, block, 0, st, A);
-  else if (N <= 32) hipLaunchKernelGGL((w8pt16_fwd_kernel<2, RAW>), grid, block, 0, st, A);
-  else if (N <= 64) hipLaunchKernelGGL((w8pt16_fwd_kernel<4, RAW>), grid, block, 0, st, A);
-  else if (N <= 112) hipLaunchKernelGGL((w8pt16_fwd_kernel<7, RAW>), grid, block, 0, st, A);
-  else hipLaunchKernelGGL((w8pt16_fwd_kernel<8, RAW>), grid, block, 0, st, A);
+  if (N <= 16) hipLaunchKernelGGL((w8pt16_fwd_kernel<1, RAW, PLAIN>), grid, block, 0, st, A);
+  else if (N <= 32) hipLaunchKernelGGL((w8pt16_fwd_kernel<2, RAW, PLAIN>), grid, block, 0, st, A);
+  else if (N <= 64) hipLaunchKernelGGL((w8pt16_fwd_kernel<4, RAW, PLAIN>), grid, block, 0, st, A);
+  else if (N <= 112) hipLaunchKernelGGL((w8pt16_fwd_kernel<7, RAW, PLAIN>), grid, block, 0, st, A);
+  else hipLaunchKernelGGL((w8pt16_fwd_kernel<8, RAW, PLAIN>), grid, block, 0, st, A);
 }
 
 template <bool RAW, bool PGRAD>
@@ -54,7 +54,9 @@ void launch_bwd(const W8BwdArgs& A, hipStream_t st) {
 
 // Called by dfepe_w8pt_fwd / dfepe_w8pt_bwd (w8pt_fwd.hip / w8pt_bwd.hip) after argument validation, for N <= DFEPE_W8PT16_MAX_N.
 int dfepe_w8pt16_fwd_launch(const W8Args& A, bool raw, hipStream_t st) {
-  if (raw) launch_fwd<true>(A, st); else launch_fwd<false>(A, st);
+  const bool plain = A.variant == 0;
+  if (raw) { if (plain) launch_fwd<true, true>(A, st); else launch_fwd<true, false>(A, st); }
+  else { if (plain) launch_fwd<false, true>(A, st); else launch_fwd<false, false>(A, st); }
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 

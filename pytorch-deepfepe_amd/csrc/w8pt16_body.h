@@ -44,6 +44,7 @@
 #define S16_V3 107     //                                              v3 (3 floats)
 #define S16_S3 110     //                                              s3 >= 0
 #define S16_INVTR 125  // 1 / trace(M)
+#define S16_SCRATCH 126 // written with garbage (branch-free stores of the lanes that have nothing to contribute)
 #define S16_TAG 127    // record format tag
 #define S16_TAG_VALUE 16.0f
 
@@ -110,8 +111,7 @@ __device__ __forceinline__ int sturm_count(const double* td, const double* te2, 
 }
 
 // Factors of one row of the design matrix: p = b (x) a with a = T1 x1, b = T2 x2 (b[2] = 1), p^ = inv * p,
-// inv = 1 / max(|p|, 1e-12) = 1 / max(|a| |b|, 1e-12)  (DeepFNet.py:203-212).  Returns false (row dropped) when the row is
-// not finite.  Branch-free; bilinear forms p^ . g = inv * b^T G a replace the explicit 9-vector wherever only dot products
+// inv = 1 / max(|p|, 1e-12) = 1 / max(|a| |b|, 1e-12)  (DeepFNet.py:203-212).  Branch-free; bilinear forms p^ . g = inv * b^T G a replace the explicit 9-vector wherever only dot products
 // of the row are needed.
 __device__ __forceinline__ bool row_factors(const Pt& p, double s1, double c1x, double c1y, double s2, double c2x, double c2y,
                                             double* a, double* b, double& inv) {
@@ -119,9 +119,8 @@ __device__ __forceinline__ bool row_factors(const Pt& p, double s1, double c1x, 
   a[0] = s1 * ((double)p.x1 - c1x * z1); a[1] = s1 * ((double)p.y1 - c1y * z1); a[2] = z1;
   b[0] = s2 * ((double)p.x2 - c2x * z2); b[1] = s2 * ((double)p.y2 - c2y * z2);
   const double n2 = (a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) * (b[0] * b[0] + b[1] * b[1] + 1.0);
-  const bool ok = n2 < 1e300;
-  inv = ok ? ((n2 > 1e-24) ? rsqrt_nr<1>(n2) : 1e12) : 0.0;
-  return ok;
+  inv = fmin(rsqrt_nr<1>(n2), 1e12);  // n2 is finite: the callers drop non-finite correspondences when they load them
+  return true;
 }
 __device__ __forceinline__ double row_bilinear(const double* a, const double* b, const double* g) {  // b^T reshape(g) a
   const double t0 = fma(g[0], a[0], fma(g[1], a[1], g[2] * a[2])), t1 = fma(g[3], a[0], fma(g[4], a[1], g[5] * a[2]));
@@ -248,43 +247,54 @@ __device__ __forceinline__ void eig9_select(double* Ar, const int l, const int k
 
 // ---- forward, one pair ---------------------------------------------------------------------------------------
 // IT = ceil(N / 16) correspondences per lane, kept in registers.  xch: 36 doubles of LDS owned by this pair.
-template <int IT, bool RAW>
+// PLAIN: none of the textbook-solver variant flags is set (the hot instantiation carries no test for them).
+template <int IT, bool RAW, bool PLAIN>
 __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair, double* xch) {
   const int l = rg_lane();
   const int N = A.N;
-  const unsigned variant = A.variant;
+  const unsigned variant = PLAIN ? 0u : A.variant;
   const size_t mp = (size_t)(pair % A.Bm);  // several weight sets may share one set of correspondences
 
   DFEPE_MARK("P0");
   // ---- phase 0: the pair's correspondences -> registers; softmax of the logits; coordinate sums ----------------
+  // Loads are unconditional (index clamped into the pair, value masked afterwards): no branch per correspondence, all of a
+  // lane's loads are in flight together.  A correspondence with a non-finite coordinate or weight is dropped here, once
+  // (zero row of X, like the reference's NaN scrub, models/model_utils.py:5-15), so that no later phase needs a guard.
   Pt pt[IT];
   float wv[IT];
+  bool kept[IT];
   const float* wsrc = A.wts + (size_t)pair * N;
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
     const int i = it * 16 + l;
     const bool valid = i < N;
+    const int ic = valid ? i : N - 1;
     Pt p;
-    p.x1 = p.y1 = p.x2 = p.y2 = 0.0f;
     p.z1 = p.z2 = 1.0f;
-    float w = A.logits_mode ? -INFINITY : 0.0f;
-    if (valid) {
-      if (RAW) {
-        const float4 m = reinterpret_cast<const float4*>(A.pts1)[mp * N + i];
-        p.x1 = fmaf(m.x, A.hw_sx, -1.0f);
-        p.y1 = fmaf(m.y, A.hw_sy, -1.0f);
-        p.x2 = fmaf(m.z, A.hw_sx, -1.0f);
-        p.y2 = fmaf(m.w, A.hw_sy, -1.0f);
-      } else {
-        const float* a = A.pts1 + (mp * N + i) * 3;
-        const float* b = A.pts2 + (mp * N + i) * 3;
-        p.x1 = a[0]; p.y1 = a[1]; p.z1 = a[2];
-        p.x2 = b[0]; p.y2 = b[1]; p.z2 = b[2];
-      }
-      w = wsrc[i];
+    if (RAW) {
+      const float4 m = reinterpret_cast<const float4*>(A.pts1)[mp * N + ic];
+      p.x1 = fmaf(m.x, A.hw_sx, -1.0f);
+      p.y1 = fmaf(m.y, A.hw_sy, -1.0f);
+      p.x2 = fmaf(m.z, A.hw_sx, -1.0f);
+      p.y2 = fmaf(m.w, A.hw_sy, -1.0f);
+    } else {
+      const float* a = A.pts1 + (mp * N + ic) * 3;
+      const float* b = A.pts2 + (mp * N + ic) * 3;
+      p.x1 = a[0]; p.y1 = a[1]; p.z1 = a[2];
+      p.x2 = b[0]; p.y2 = b[1]; p.z2 = b[2];
     }
+    float w = wsrc[ic];
+    // one comparison: the sum of magnitudes is below the bound only if every coordinate is finite and of sane size
+    float mag = (fabsf(p.x1) + fabsf(p.y1)) + (fabsf(p.x2) + fabsf(p.y2));
+    if (!RAW) mag += fabsf(p.z1) + fabsf(p.z2);
+    const bool keep = valid && (mag < 1e18f);  // false for NaN
+    p.x1 = keep ? p.x1 : 0.0f; p.y1 = keep ? p.y1 : 0.0f; p.x2 = keep ? p.x2 : 0.0f; p.y2 = keep ? p.y2 : 0.0f;
+    if (!RAW) { p.z1 = keep ? p.z1 : 1.0f; p.z2 = keep ? p.z2 : 1.0f; }
+    if (A.logits_mode) w = valid ? w : -INFINITY;
+    else w = (keep && fabsf(w) < 3e38f) ? w : 0.0f;
     pt[it] = p;
     wv[it] = w;
+    kept[it] = keep;
   }
   if (A.logits_mode) {
     // fused F.softmax(logits, dim=N) (DeepFNet.py:443,512)
@@ -295,7 +305,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     float sm = 0.0f;
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-      const float e = (it * 16 + l < N) ? expf(wv[it] - mx) : 0.0f;
+      const float e = expf(wv[it] - mx);  // padding lanes hold -inf: exactly 0
       wv[it] = e;
       sm += e;
     }
@@ -305,6 +315,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
       wv[it] *= inv;
       const int i = it * 16 + l;
       if (A.weights_out != nullptr && i < N) A.weights_out[(size_t)pair * N + i] = wv[it];
+      wv[it] = kept[it] ? wv[it] : 0.0f;  // a dropped correspondence keeps its softmax weight in weights_out, not in X
     }
   }
   const bool hartley = (variant & DFEPE_W8PT_NO_HARTLEY) == 0;
@@ -322,11 +333,11 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     double d1 = 0, d2 = 0;
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-      const bool valid = it * 16 + l < N;
+      const double vm = (it * 16 + l < N) ? 1.0 : 0.0;  // arithmetic mask: no branch around the square roots
       const double ax = (double)pt[it].x1 - c1x, ay = (double)pt[it].y1 - c1y;
       const double bx = (double)pt[it].x2 - c2x, by = (double)pt[it].y2 - c2y;
-      d1 += valid ? sqrt_nr<1>(ax * ax + ay * ay) : 0.0;
-      d2 += valid ? sqrt_nr<1>(bx * bx + by * by) : 0.0;
+      d1 = fma(vm, sqrt_nr<1>(ax * ax + ay * ay), d1);
+      d2 = fma(vm, sqrt_nr<1>(bx * bx + by * by), d2);
     }
     // Fit.normalize uses the literal 1.4142, not sqrt(2) (DeepFNet.py:168); utils_F._normalize_XY uses np.sqrt(2)
     const double hscale = (variant & DFEPE_W8PT_SQRT2) ? 1.4142135623730951 : 1.4142;
@@ -346,18 +357,15 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     const double z1 = p.z1, z2 = p.z2;
     const double a0 = s1 * ((double)p.x1 - c1x * z1), a1 = s1 * ((double)p.y1 - c1y * z1), a2 = z1;
     const double b0 = s2 * ((double)p.x2 - c2x * z2), b1 = s2 * ((double)p.y2 - c2y * z2);
-    const double n2 = (a0 * a0 + a1 * a1 + a2 * a2) * (b0 * b0 + b1 * b1 + 1.0);  // |p|^2
-    const bool ok = (n2 < 1e300) && (fabs(w) < 1e150) && (it * 16 + l < N);
-    // (w / max(|p|, 1e-12))^2
-    const double k2 = ok ? ((variant & DFEPE_W8PT_NO_ROWNORM) ? (w * w) : (w * w) * rcp_nr<2>(fmax(n2, 1e-24))) : 0.0;
+    const double n2 = (a0 * a0 + a1 * a1 + a2 * a2) * (b0 * b0 + b1 * b1 + 1.0);  // |p|^2, finite (phase 0 dropped the rest)
+    // (w / max(|p|, 1e-12))^2; a dropped or padding correspondence has w = 0 and contributes exact zeros
+    const double k2 = (variant & DFEPE_W8PT_NO_ROWNORM) ? (w * w) : (w * w) * rcp_nr<2>(fmax(n2, 1e-24));
     const double aa[6] = {a0 * a0, a0 * a1, a0 * a2, a1 * a1, a1 * a2, a2 * a2};
     const double bb[6] = {k2 * b0 * b0, k2 * b0 * b1, k2 * b0, k2 * b1 * b1, k2 * b1, k2};
-    if (ok) {
 #pragma unroll
-      for (int u = 0; u < 6; ++u)
+    for (int u = 0; u < 6; ++u)
 #pragma unroll
-        for (int v = 0; v < 6; ++v) acc[6 * u + v] = fma(bb[u], aa[v], acc[6 * u + v]);
-    }
+      for (int v = 0; v < 6; ++v) acc[6 * u + v] = fma(bb[u], aa[v], acc[6 * u + v]);
   }
 
   DFEPE_MARK("P3");
@@ -490,8 +498,8 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     }
     if (l < 8) reinterpret_cast<double*>(sv + S16_TE)[l] = tem;
 #pragma unroll
-    for (int k = 0; k < 7; ++k)
-      if (l > k && l < 9) sv[S16_HV + s16_hv_off(k) + (l - k - 1)] = (float)hv[k];
+    for (int k = 0; k < 7; ++k)  // lanes that hold no component of reflector k write a scratch slot: no branch per reflector
+      sv[(l > k && l < 9) ? S16_HV + s16_hv_off(k) + (l - k - 1) : S16_SCRATCH] = (float)hv[k];
     {
       float uvm = (float)u3[0], hbm = (float)hb[0];
 #pragma unroll
@@ -522,26 +530,24 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
     const int i = it * 16 + l;
-    if (i >= N) continue;
     const Pt p = pt[it];
-    // residual_i = w_i p^_i . f  (DeepFNet.py:203-214,251)
-    const double w = (double)wv[it];
+    // residual_i = w_i p^_i . f  (DeepFNet.py:203-214,251); straight-line, only the stores are guarded
     double ra[3], rb[2], inv;
-    const bool ok = row_factors(p, s1, c1x, c1y, s2, c2x, c2y, ra, rb, inv) && (fabs(w) < 1e150);
-    const double r = ok ? row_bilinear(ra, rb, f) * inv * w : 0.0;
-    rdst[i] = (float)r;
-    if (edst != nullptr) {
-      // l1 = F^T x2 (row form x2 F), l2 = F x1, dd = x2^T F x1 = x1 . l1     (utils_F.py:402-411), fp32 like the reference
-      const float l1x = fmaf(p.x2, of[0], fmaf(p.y2, of[3], p.z2 * of[6]));
-      const float l1y = fmaf(p.x2, of[1], fmaf(p.y2, of[4], p.z2 * of[7]));
-      const float l1z = fmaf(p.x2, of[2], fmaf(p.y2, of[5], p.z2 * of[8]));
-      const float l2x = fmaf(p.x1, of[0], fmaf(p.y1, of[1], p.z1 * of[2]));
-      const float l2y = fmaf(p.x1, of[3], fmaf(p.y1, of[4], p.z1 * of[5]));
-      const float dd = fmaf(p.x1, l1x, fmaf(p.y1, l1y, p.z1 * l1z));
-      const float n1 = hw_sqrt(fmaf(l1x, l1x, l1y * l1y)) + 1e-6f;  // v_sqrt_f32 / v_rcp_f32: 1 ulp, far inside the tolerance
-      const float m2 = hw_sqrt(fmaf(l2x, l2x, l2y * l2y)) + 1e-6f;
-      const float d = fabsf(dd) * (hw_rcp(n1) + hw_rcp(m2));
-      edst[i] = fminf(d, A.clamp_at);
+    row_factors(p, s1, c1x, c1y, s2, c2x, c2y, ra, rb, inv);
+    const float r = (float)(row_bilinear(ra, rb, f) * inv * (double)wv[it]);
+    // l1 = F^T x2 (row form x2 F), l2 = F x1, dd = x2^T F x1 = x1 . l1     (utils_F.py:402-411), fp32 like the reference
+    const float l1x = fmaf(p.x2, of[0], fmaf(p.y2, of[3], p.z2 * of[6]));
+    const float l1y = fmaf(p.x2, of[1], fmaf(p.y2, of[4], p.z2 * of[7]));
+    const float l1z = fmaf(p.x2, of[2], fmaf(p.y2, of[5], p.z2 * of[8]));
+    const float l2x = fmaf(p.x1, of[0], fmaf(p.y1, of[1], p.z1 * of[2]));
+    const float l2y = fmaf(p.x1, of[3], fmaf(p.y1, of[4], p.z1 * of[5]));
+    const float dd = fmaf(p.x1, l1x, fmaf(p.y1, l1y, p.z1 * l1z));
+    const float n1 = hw_sqrt(fmaf(l1x, l1x, l1y * l1y)) + 1e-6f;  // v_sqrt_f32 / v_rcp_f32: 1 ulp, far inside the tolerance
+    const float m2 = hw_sqrt(fmaf(l2x, l2x, l2y * l2y)) + 1e-6f;
+    const float d = fminf(fabsf(dd) * (hw_rcp(n1) + hw_rcp(m2)), A.clamp_at);
+    if (i < N) {
+      rdst[i] = r;
+      if (edst != nullptr) edst[i] = d;
     }
   }
 }

@@ -28,6 +28,7 @@ struct W8BwdArgs {
   const float* g_res;
   const float* g_epi;
   const float* g_w_extra;
+  const float* g_scale;  // one float scaling g_F, g_res, g_epi (nullptr = 1)
   float* g_w;
   float* g_p1;
   float* g_p2;
@@ -52,33 +53,33 @@ __device__ __forceinline__ void tri_pinv_apply(const double* td, const double* t
   // Thomas elimination from the top (rows above the twist) and from the bottom (rows below it); with y_twist = 0 the
   // two blocks decouple and each is a principal sub-matrix of the positive semi-definite T - lam I that excludes the
   // largest component of its null vector: definite, pivots away from zero.
-  double cp[9], gp[9], cm[9], gm[9];
-  cp[0] = guard_den16(td[0] - lam);
+  double rp[9], gp[9], rm[9], gm[9];  // reciprocal pivots, eliminated right-hand sides
+  rp[0] = rcp_nr<2>(guard_den16(td[0] - lam));
   gp[0] = g[0];
 #pragma unroll
   for (int k = 1; k < 9; ++k) {
-    const double m = te[k - 1] * rcp_nr<2>(cp[k - 1]);
-    cp[k] = guard_den16((td[k] - lam) - m * te[k - 1]);
+    const double m = te[k - 1] * rp[k - 1];
+    rp[k] = rcp_nr<2>(guard_den16((td[k] - lam) - m * te[k - 1]));
     gp[k] = g[k] - m * gp[k - 1];
   }
-  cm[8] = guard_den16(td[8] - lam);
+  rm[8] = rcp_nr<2>(guard_den16(td[8] - lam));
   gm[8] = g[8];
 #pragma unroll
   for (int k = 7; k >= 0; --k) {
-    const double m = te[k] * rcp_nr<2>(cm[k + 1]);
-    cm[k] = guard_den16((td[k] - lam) - m * te[k]);
+    const double m = te[k] * rm[k + 1];
+    rm[k] = rcp_nr<2>(guard_den16((td[k] - lam) - m * te[k]));
     gm[k] = g[k] - m * gm[k + 1];
   }
 #pragma unroll
   for (int k = 0; k < 9; ++k) y[k] = 0.0;
 #pragma unroll
   for (int k = 7; k >= 0; --k) {
-    const double yk = (gp[k] - te[k] * y[k + 1]) * rcp_nr<2>(cp[k]);
+    const double yk = (gp[k] - te[k] * y[k + 1]) * rp[k];
     y[k] = (k < twist) ? yk : y[k];
   }
 #pragma unroll
   for (int k = 1; k < 9; ++k) {
-    const double yk = (gm[k] - te[k - 1] * y[k - 1]) * rcp_nr<2>(cm[k]);
+    const double yk = (gm[k] - te[k - 1] * y[k - 1]) * rm[k];
     y[k] = (k > twist) ? yk : y[k];
   }
   double zy = 0.0;
@@ -95,6 +96,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
   const size_t mp = (size_t)(pair % A.Bm);
   const float* sv = A.save + (size_t)pair * DFEPE_SAVE_FLOATS;
 
+  DFEPE_MARK("B0_load");
   // ---- the forward's record (row-uniform loads) and the pair's correspondences -------------------------------
   const double s1 = sv[S16_T1], c1x = sv[S16_T1 + 1], c1y = sv[S16_T1 + 2];
   const double s2 = sv[S16_T2], c2x = sv[S16_T2 + 1], c2y = sv[S16_T2 + 2];
@@ -113,35 +115,42 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
   const double inv_tr = sv[S16_INVTR];
   const bool good = sv[S16_TAG] == S16_TAG_VALUE;  // a record of the other forward kernel would be misread: poison instead
 
+  // same unconditional loads and the same drop rule as the forward (w8pt16_fwd_pair, phase 0)
   Pt pt[IT];
-  float wv[IT];
+  float wv[IT];   // the weight (softmax output in logits mode); 0 on padding lanes
+  bool kept[IT];  // false: the forward dropped this correspondence from X
   const float* wsrc = A.wts + (size_t)pair * N;
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
     const int i = it * 16 + l;
+    const bool valid = i < N;
+    const int ic = valid ? i : N - 1;
     Pt p;
-    p.x1 = p.y1 = p.x2 = p.y2 = 0.0f;
     p.z1 = p.z2 = 1.0f;
-    float w = 0.0f;
-    if (i < N) {
-      if (RAW) {
-        const float4 m = reinterpret_cast<const float4*>(A.pts1)[mp * N + i];
-        p.x1 = fmaf(m.x, A.hw_sx, -1.0f);
-        p.y1 = fmaf(m.y, A.hw_sy, -1.0f);
-        p.x2 = fmaf(m.z, A.hw_sx, -1.0f);
-        p.y2 = fmaf(m.w, A.hw_sy, -1.0f);
-      } else {
-        const float* a = A.pts1 + (mp * N + i) * 3;
-        const float* b = A.pts2 + (mp * N + i) * 3;
-        p.x1 = a[0]; p.y1 = a[1]; p.z1 = a[2];
-        p.x2 = b[0]; p.y2 = b[1]; p.z2 = b[2];
-      }
-      w = wsrc[i];
+    if (RAW) {
+      const float4 m = reinterpret_cast<const float4*>(A.pts1)[mp * N + ic];
+      p.x1 = fmaf(m.x, A.hw_sx, -1.0f);
+      p.y1 = fmaf(m.y, A.hw_sy, -1.0f);
+      p.x2 = fmaf(m.z, A.hw_sx, -1.0f);
+      p.y2 = fmaf(m.w, A.hw_sy, -1.0f);
+    } else {
+      const float* a = A.pts1 + (mp * N + ic) * 3;
+      const float* b = A.pts2 + (mp * N + ic) * 3;
+      p.x1 = a[0]; p.y1 = a[1]; p.z1 = a[2];
+      p.x2 = b[0]; p.y2 = b[1]; p.z2 = b[2];
     }
+    const float w = wsrc[ic];
+    float mag = (fabsf(p.x1) + fabsf(p.y1)) + (fabsf(p.x2) + fabsf(p.y2));
+    if (!RAW) mag += fabsf(p.z1) + fabsf(p.z2);
+    const bool keep = valid && (mag < 1e18f) && (fabsf(w) < 3e38f);
+    p.x1 = keep ? p.x1 : 0.0f; p.y1 = keep ? p.y1 : 0.0f; p.x2 = keep ? p.x2 : 0.0f; p.y2 = keep ? p.y2 : 0.0f;
+    if (!RAW) { p.z1 = keep ? p.z1 : 1.0f; p.z2 = keep ? p.z2 : 1.0f; }
     pt[it] = p;
-    wv[it] = w;
+    wv[it] = (valid && fabsf(w) < 3e38f) ? w : 0.0f;
+    kept[it] = keep;
   }
 
+  DFEPE_MARK("B1_passA");
   // ---- pass A: X^T g_r  and  sum_i g_epi_i d(d_i)/d(out) ---------------------------------------------------------
   // partial sums in fp32 (the reference's whole backward is fp32); everything uniform downstream is fp64
   double gx[9], go[9], o[9];
@@ -163,8 +172,8 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
       if (A.g_res != nullptr) {
         const double w = (double)wv[it];
         double ra[3], rb[2], inv;
-        const bool ok = row_factors(p, s1, c1x, c1y, s2, c2x, c2y, ra, rb, inv) && (fabs(w) < 1e150);
-        const double gw = ok ? (double)A.g_res[(size_t)pair * N + i] * w * inv : 0.0;
+        row_factors(p, s1, c1x, c1y, s2, c2x, c2y, ra, rb, inv);
+        const double gw = kept[it] ? (double)A.g_res[(size_t)pair * N + i] * w * inv : 0.0;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const double ga = gw * ra[c];
@@ -209,7 +218,13 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
 #pragma unroll
     for (int c = 0; c < 9; ++c) go[c] += (double)A.g_F[(size_t)pair * 9 + c];
   }
+  const double gsc = (A.g_scale != nullptr) ? (double)A.g_scale[0] : 1.0;  // everything downstream is linear in the three gradients
+  if (A.g_scale != nullptr) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { go[c] *= gsc; gx[c] *= gsc; }
+  }
 
+  DFEPE_MARK("B2_uniform");
   // ---- uniform part ------------------------------------------------------------------------------------------
   // g_F' = T2 g_out T1^T with T = [[s,0,-s cx],[0,s,-s cy],[0,0,1]] written out
   double tmp[9], G[9];
@@ -225,6 +240,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
     G[3 * r + 1] = s1 * (tmp[3 * r + 1] - c1y * tmp[3 * r + 2]);
     G[3 * r + 2] = tmp[3 * r + 2];
   }
+  DFEPE_MARK("B3_rank2");
   // rank-2 projection adjoint with nothing but the dropped triplet (s3, u3, v3) and F = reshape(f).  With the
   // pseudo-inverses A_u = (s3^2 I - F F^T)^+ (null vector u3) and A_v = (s3^2 I - F^T F)^+ (null vector v3), the first-order
   // perturbation of the triplet is  d s3 = u3^T dF v3,  d u3 = A_u (s3 dF v3 + F dF^T u3),  d v3 = A_v (s3 dF^T u3 + F^T dF v3),
@@ -269,6 +285,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
 #pragma unroll
       for (int c = 0; c < 3; ++c) gf[3 * r + c] = G[3 * r + c] - pv[r] * v3[c] - u3[r] * qv[c] + gx[3 * r + c];
   }
+  DFEPE_MARK("B4_eigadj");
   // eigenvector adjoint: u = -(1/trace) H (T - lam I)^+ H^T g_f.  H^T = H_6 ... H_0 (each H_k symmetric).
   double u[9];
   {
@@ -288,6 +305,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
         gt[j] = rg_fma_bcast<j>(gt[j], hv[k], s);
       });
     });
+  DFEPE_MARK("B5_tripinv");
     tri_pinv_apply(td, te, lam, z, twist, gt, y);
     static_for<0, 7>([&](auto kc) {
       constexpr int k = 6 - decltype(kc)::value;
@@ -307,6 +325,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
     for (int c = 0; c < 9; ++c) u[c] = sc * y[c];
   }
 
+  DFEPE_MARK("B6_passB");
   // ---- pass B: g_w ---------------------------------------------------------------------------------------------
   float* dst = A.g_w + (size_t)pair * N;
   float gwv[IT];
@@ -318,9 +337,10 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
     if (i < N) {
       const double w = (double)wv[it];
       double ra[3], rb[2], inv;
-      const bool ok = row_factors(pt[it], s1, c1x, c1y, s2, c2x, c2y, ra, rb, inv) && (fabs(w) < 1e150);
+      row_factors(pt[it], s1, c1x, c1y, s2, c2x, c2y, ra, rb, inv);
+      const bool ok = kept[it];
       const double a = row_bilinear(ra, rb, f) * inv, b = row_bilinear(ra, rb, u) * inv;  // p^ . f, p^ . u
-      const double gr = (A.g_res != nullptr) ? (double)A.g_res[(size_t)pair * N + i] : 0.0;
+      const double gr = (A.g_res != nullptr) ? gsc * (double)A.g_res[(size_t)pair * N + i] : 0.0;
       gwi = ok ? (float)(2.0 * w * a * b + gr * a) : 0.0f;
       if (A.g_w_extra != nullptr) gwi += A.g_w_extra[(size_t)pair * N + i];
     }
@@ -370,7 +390,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
       const double a[3] = {s1 * ((double)p.x1 - c1x * z1), s1 * ((double)p.y1 - c1y * z1), z1};
       const double b0 = s2 * ((double)p.x2 - c2x * z2), b1 = s2 * ((double)p.y2 - c2y * z2);
       const double n2 = (a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) * (b0 * b0 + b1 * b1 + 1.0);
-      const bool ok = (n2 < 1e300) && (n2 > 1e-24) && (fabs(w) < 1e150);
+      const bool ok = kept[it] && (n2 > 1e-24);
       const double inv = ok ? rsqrt_nr<1>(n2) : 0.0;
       double ph[9];
 #pragma unroll
@@ -378,7 +398,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
       double af = 0.0, bu = 0.0;
 #pragma unroll
       for (int k = 0; k < 9; ++k) { af += ph[k] * f[k]; bu += ph[k] * u[k]; }
-      const double gr = (A.g_res != nullptr) ? (double)A.g_res[(size_t)pair * N + i] : 0.0;
+      const double gr = (A.g_res != nullptr) ? gsc * (double)A.g_res[(size_t)pair * N + i] : 0.0;
       const double cu = w * w * af, cf = w * w * bu + w * gr, dotp = 2.0 * w * w * af * bu + w * gr * af;
       double gp[9];
 #pragma unroll
@@ -397,7 +417,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
         const double n1 = sqrt_nr<1>(l1[0] * l1[0] + l1[1] * l1[1]), nn2 = sqrt_nr<1>(l2[0] * l2[0] + l2[1] * l2[1]);
         const double i1 = rcp_nr<1>(n1 + 1e-6), i2 = rcp_nr<1>(nn2 + 1e-6);
         const double Ss = i1 + i2, ad = fabs(dd);
-        const double g = (ad * Ss <= (double)A.clamp_at) ? (double)A.g_epi[(size_t)pair * N + i] : 0.0;
+        const double g = (ad * Ss <= (double)A.clamp_at) ? gsc * (double)A.g_epi[(size_t)pair * N + i] : 0.0;
         const double sg = (dd > 0.0) ? 1.0 : ((dd < 0.0) ? -1.0 : 0.0);
         const double k1 = (n1 > 0.0) ? ad * i1 * i1 * rcp_nr<1>(n1) : 0.0;
         const double k2 = (nn2 > 0.0) ? ad * i2 * i2 * rcp_nr<1>(nn2) : 0.0;

@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256, (PGRAD ? 2 : 4))  // the point-gradient v
 w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, const float* __restrict__ wts, int B,
                 int Bm, int N, float hw_sx, float hw_sy, float clamp_at, const float* __restrict__ save,
                 const float* __restrict__ F_out, const float* __restrict__ g_F, const float* __restrict__ g_res,
-                const float* __restrict__ g_epi, const float* __restrict__ g_w_extra, int logits_mode,
+                const float* __restrict__ g_epi, const float* __restrict__ g_w_extra, const float* __restrict__ g_scale, int logits_mode,
                 float* __restrict__ g_w, float* __restrict__ g_p1, float* __restrict__ g_p2) {
   static_assert(!(COOP && PGRAD), "the cooperative variant does not produce point gradients");
   __shared__ float red[4][20];  // COOP only: per-wavefront partial sums
@@ -136,6 +136,11 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 #pragma unroll
     for (int c = 0; c < 9; ++c) go[c] += (double)g_F[pair * 9 + c];
   }
+  const double gsc = (g_scale != nullptr) ? (double)g_scale[0] : 1.0;  // scales all three upstream gradients (linear downstream)
+  if (g_scale != nullptr) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { go[c] *= gsc; gx[c] *= gsc; }
+  }
 
   // ---- uniform part ---------------------------------------------------------------------------------
   // g_F' = T2 g_out T1^T
@@ -235,7 +240,7 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
     double a = 0.0, b = 0.0;
 #pragma unroll
     for (int c = 0; c < 9; ++c) { a += ph[c] * f[c]; b += ph[c] * u[c]; }
-    const double gr = (g_res != nullptr) ? (double)g_res[pair * N + i] : 0.0;
+    const double gr = (g_res != nullptr) ? gsc * (double)g_res[pair * N + i] : 0.0;
     float gwi = ok ? (float)(2.0 * w * a * b + gr * a) : 0.0f;
     if (g_w_extra != nullptr) gwi += g_w_extra[pair * N + i];
     return gwi;
@@ -305,7 +310,7 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
       double af = 0.0, bu = 0.0;
 #pragma unroll
       for (int k = 0; k < 9; ++k) { af += ph[k] * f[k]; bu += ph[k] * u[k]; }
-      const double gr = (g_res != nullptr) ? (double)g_res[pair * N + i] : 0.0;
+      const double gr = (g_res != nullptr) ? gsc * (double)g_res[pair * N + i] : 0.0;
       const double cu = w * w * af, cf = w * w * bu + w * gr, dotp = 2.0 * w * w * af * bu + w * gr * af;
       double gp[9];
 #pragma unroll
@@ -324,7 +329,7 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
         const double n1 = fast_sqrt(l1[0] * l1[0] + l1[1] * l1[1]), nn2 = fast_sqrt(l2[0] * l2[0] + l2[1] * l2[1]);
         const double i1 = fast_rcp(n1 + 1e-6), i2 = fast_rcp(nn2 + 1e-6);
         const double Ss = i1 + i2, ad = fabs(dd);
-        const double g = (ad * Ss <= (double)clamp_at) ? (double)g_epi[pair * N + i] : 0.0;
+        const double g = (ad * Ss <= (double)clamp_at) ? gsc * (double)g_epi[pair * N + i] : 0.0;
         const double sg = (dd > 0.0) ? 1.0 : ((dd < 0.0) ? -1.0 : 0.0);
         const double k1 = (n1 > 0.0) ? ad * i1 * i1 * fast_rcp(n1) : 0.0;
         const double k2 = (nn2 > 0.0) ? ad * i2 * i2 * fast_rcp(nn2) : 0.0;
@@ -393,7 +398,8 @@ extern "C" int dfepe_w8pt_bwd(const float* pts1, const float* pts2, const float*
                               unsigned flags,
                               float image_w, float image_h, float clamp_at, const float* save, const float* F_out,
                               const float* g_F, const float* g_residual, const float* g_epi,
-                              const float* g_weights_extra, float* g_weights, float* g_pts1, float* g_pts2, void* stream) {
+                              const float* g_weights_extra, const float* g_scale, float* g_weights, float* g_pts1, float* g_pts2,
+                              void* stream) {
   const bool raw = (flags & DFEPE_W8PT_RAW_MATCHES) != 0;
   const int logits_mode = (flags & DFEPE_W8PT_LOGITS) ? 1 : 0;
   if (B < 0 || N <= 0 || n_weight_sets < 1) return DFEPE_ERR_INVALID_ARG;
@@ -415,7 +421,7 @@ extern "C" int dfepe_w8pt_bwd(const float* pts1, const float* pts2, const float*
     A.pts1 = pts1; A.pts2 = pts2; A.wts = weights;
     A.Bm = Bm; A.B = B; A.N = N;
     A.hw_sx = raw ? 2.0f / image_w : 0.f; A.hw_sy = raw ? 2.0f / image_h : 0.f; A.clamp_at = clamp_at;
-    A.save = save; A.F_out = F_out; A.g_F = g_F; A.g_res = g_residual; A.g_epi = g_epi; A.g_w_extra = g_weights_extra;
+    A.save = save; A.F_out = F_out; A.g_F = g_F; A.g_res = g_residual; A.g_epi = g_epi; A.g_w_extra = g_weights_extra; A.g_scale = g_scale;
     A.g_w = g_weights; A.g_p1 = g_pts1; A.g_p2 = g_pts2; A.logits_mode = logits_mode;
     return dfepe_w8pt16_bwd_launch(A, raw, static_cast<hipStream_t>(stream));
   }
@@ -427,7 +433,7 @@ extern "C" int dfepe_w8pt_bwd(const float* pts1, const float* pts2, const float*
   const float hw_sx = raw ? 2.0f / image_w : 0.f, hw_sy = raw ? 2.0f / image_h : 0.f;
 #define DFEPE_LAUNCH_BWD(R, P, C)                                                                                           \
   hipLaunchKernelGGL((w8pt_bwd_kernel<R, P, C>), grid, block, 0, st, pts1, pts2, weights, B, Bm, N, hw_sx, hw_sy, clamp_at, save, \
-                     F_out, g_F, g_residual, g_epi, g_weights_extra, logits_mode, g_weights, g_pts1, g_pts2)
+                     F_out, g_F, g_residual, g_epi, g_weights_extra, g_scale, logits_mode, g_weights, g_pts1, g_pts2)
   if (raw) {
     if (pgrad) DFEPE_LAUNCH_BWD(true, true, false); else if (coop) DFEPE_LAUNCH_BWD(true, false, true); else DFEPE_LAUNCH_BWD(true, false, false);
   } else {

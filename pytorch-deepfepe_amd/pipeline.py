@@ -19,7 +19,7 @@ Tensor = torch.Tensor
 def hot_path_forward(matches: Tensor, logits_layers: Tensor, Ks: Tensor, virt1: Tensor, virt2: Tensor,
                      q_gt: Tensor, t_gt: Tensor, R_gt: Tensor, image_size: Sequence[int], clamp_at: float = 0.02,
                      qt: bool = True, clamp_q: float = 0.1, clamp_t: float = 0.5, balance_q: float = 1.0,
-                     balance_t: float = 0.1, hw_T: Optional[Tensor] = None) -> Dict[str, Tensor]:
+                     balance_t: float = 0.1, hw_T: Optional[Tensor] = None, balance_F: float = 1.0) -> Dict[str, Tensor]:
     """matches [B,N,4] pixels, logits_layers [L,B,N]; returns dict with the loss (local batch mean) and
     every intermediate the reference exposes (F per layer, residuals, in-loop epipolar residuals, E per layer,
     per-pair F-loss sums, pose errors and angular metrics)."""
@@ -42,7 +42,7 @@ def hot_path_forward(matches: Tensor, logits_layers: Tensor, Ks: Tensor, virt1: 
     loss_F = loss_layers.mean()
     out = {"F_layers": F_layers, "residual_layers": residuals, "epi_res_layers": epis, "weights_layers": weights,
            "E_layers": E_layers, "loss_sum": loss_sum, "loss_layers": loss_layers, "loss_F": loss_F}
-    loss = loss_F
+    loss = loss_F * balance_F
     if qt:
         q_l2, t_l2, R_deg, t_deg, sel = ops.pose_errors(E_layers, q_gt, t_gt, R_gt)
         loss_qt = torch.clamp(q_l2, 0.0, clamp_q).mean() * balance_q + torch.clamp(t_l2, 0.0, clamp_t).mean() * balance_t
@@ -52,19 +52,35 @@ def hot_path_forward(matches: Tensor, logits_layers: Tensor, Ks: Tensor, virt1: 
     return out
 
 
+_TAIL_WS: Dict[tuple, Tensor] = {}
+
+
+def _tail_workspace(dev, B: int) -> Tensor:
+    """Scratch of dfepe_loss_tail (per-workgroup partial sums + the completion ticket), one per (device, stream, B):
+    zeroed once -- the kernel leaves the ticket at zero."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), ops._stream(), B)
+    ws = _TAIL_WS.get(key)
+    if ws is None:
+        ws = torch.zeros((_lib.lib().dfepe_loss_tail_workspace_bytes(B) + 7) // 8, dtype=torch.float64, device=dev)
+        _TAIL_WS[key] = ws
+    return ws
+
+
 class _HotPathFunction(torch.autograd.Function):
-    """The whole solver-only step as ONE autograd node: 5 x w8pt_fwd (softmax fused) + floss_fwd + pose_fwd + loss_head
-    forward (8 launches), pose_bwd + floss_bwd + 5 x w8pt_bwd backward (7 launches + 1 add).  No intermediate torch
-    ops, no per-op autograd bookkeeping; every buffer is allocated once per call."""
+    """The whole solver-only step as ONE autograd node.  Forward: L x w8pt_fwd (softmax fused) + ONE loss-tail launch that
+    also forms d loss / d F of every layer (dfepe_loss_tail); backward: L x w8pt_bwd, which apply the upstream gradient of
+    the loss as their g_scale.  11 launches for L = 5, no intermediate torch ops, no per-op autograd bookkeeping.
+    ``fused_tail=False`` keeps the round-1 structure (floss_fwd, pose_fwd, loss_head | pose_bwd, floss_bwd: 15 launches)."""
 
     @staticmethod
     def forward(ctx, matches, logits_layers, Ks, virt1, virt2, q_gt, t_gt, R_gt, hw_T, cfg):
-        (H, W, clamp_at, qt, clamp_q, clamp_t, balance_q, balance_t, batched) = cfg
+        (H, W, clamp_at, qt, clamp_q, clamp_t, balance_q, balance_t, batched, balance_F, fused_tail, grad_pairs) = cfg
         ctx.set_materialize_grads(False)  # 13 auxiliary outputs: do not let autograd zero-fill [L,B,N] gradients for them
         lib = _lib.lib()
         L, B, N = logits_layers.shape
         dev = matches.device
         M = virt1.shape[1]
+        fused_tail = fused_tail and M <= 128
         F_layers = torch.empty(L, B, 3, 3, device=dev)
         residuals = torch.empty(L, B, N, device=dev)
         epis = torch.empty(L, B, N, device=dev)
@@ -72,6 +88,7 @@ class _HotPathFunction(torch.autograd.Function):
         saves = torch.empty(L, B, lib.dfepe_save_floats(), device=dev)
         flags = _lib.W8PT_RAW_MATCHES | _lib.W8PT_LOGITS
         st = ops._stream()
+        gF = None
         with torch.cuda.device(dev):
             if batched:  # the L weightings of the same pairs in ONE launch (n_weight_sets = L): no per-layer launch tails
                 rc = lib.dfepe_w8pt_fwd(matches.data_ptr(), None, logits_layers.data_ptr(), B, N, L, flags, W, H, 0.5,
@@ -86,9 +103,6 @@ class _HotPathFunction(torch.autograd.Function):
                     _lib.check(rc, "dfepe_w8pt_fwd")
             loss_sum = torch.empty(L, B, device=dev)
             E_layers = torch.empty(L, B, 3, 3, device=dev)
-            rc = lib.dfepe_floss_fwd(F_layers.data_ptr(), L, B, hw_T.data_ptr(), hw_T.data_ptr(), 0, Ks.data_ptr(), virt1.data_ptr(),
-                                     virt2.data_ptr(), M, clamp_at, loss_sum.data_ptr(), E_layers.data_ptr(), st)
-            _lib.check(rc, "dfepe_floss_fwd")
             q_l2 = t_l2 = R_deg = t_deg = sel = None
             if qt:
                 q_l2 = torch.empty(L, B, device=dev)
@@ -96,16 +110,37 @@ class _HotPathFunction(torch.autograd.Function):
                 R_deg = torch.empty(L, B, device=dev)
                 t_deg = torch.empty(L, B, device=dev)
                 sel = torch.empty(L, B, device=dev, dtype=torch.int32)
-                rc = lib.dfepe_pose_fwd(E_layers.data_ptr(), L, B, q_gt.data_ptr(), t_gt.data_ptr(), R_gt.data_ptr(), q_l2.data_ptr(),
-                                        t_l2.data_ptr(), R_deg.data_ptr(), t_deg.data_ptr(), sel.data_ptr(), st)
-                _lib.check(rc, "dfepe_pose_fwd")
             packed = torch.empty(L + 4, device=dev, dtype=torch.float64)
             scalars = torch.empty(4 + L, device=dev)
-            rc = lib.dfepe_loss_head(loss_sum.data_ptr(), ops._ptr(q_l2), ops._ptr(t_l2), L, B, M, clamp_q, clamp_t, balance_q,
-                                     balance_t, packed.data_ptr(), scalars.data_ptr(), st)
-            _lib.check(rc, "dfepe_loss_head")
-        ctx.save_for_backward(matches, weights, Ks, virt1, virt2, q_gt, t_gt, hw_T, F_layers, E_layers, saves)
+            if fused_tail:
+                gF = torch.empty(L, B, 3, 3, device=dev)
+                ws = _tail_workspace(dev, B)
+                rc = lib.dfepe_loss_tail(F_layers.data_ptr(), L, B, hw_T.data_ptr(), hw_T.data_ptr(), 0, Ks.data_ptr(), virt1.data_ptr(),
+                                         virt2.data_ptr(), M, clamp_at, ops._ptr(q_gt if qt else None), ops._ptr(t_gt if qt else None),
+                                         ops._ptr(R_gt if qt else None), clamp_q, clamp_t, balance_F, balance_q, balance_t,
+                                         float(grad_pairs if grad_pairs else B), loss_sum.data_ptr(), E_layers.data_ptr(), ops._ptr(q_l2),
+                                         ops._ptr(t_l2), ops._ptr(R_deg), ops._ptr(t_deg), ops._ptr(sel), gF.data_ptr(),
+                                         packed.data_ptr(), scalars.data_ptr(), ws.data_ptr(), st)
+                _lib.check(rc, "dfepe_loss_tail")
+            else:
+                rc = lib.dfepe_floss_fwd(F_layers.data_ptr(), L, B, hw_T.data_ptr(), hw_T.data_ptr(), 0, Ks.data_ptr(), virt1.data_ptr(),
+                                         virt2.data_ptr(), M, clamp_at, loss_sum.data_ptr(), E_layers.data_ptr(), st)
+                _lib.check(rc, "dfepe_floss_fwd")
+                if qt:
+                    rc = lib.dfepe_pose_fwd(E_layers.data_ptr(), L, B, q_gt.data_ptr(), t_gt.data_ptr(), R_gt.data_ptr(), q_l2.data_ptr(),
+                                            t_l2.data_ptr(), R_deg.data_ptr(), t_deg.data_ptr(), sel.data_ptr(), st)
+                    _lib.check(rc, "dfepe_pose_fwd")
+                rc = lib.dfepe_loss_head(loss_sum.data_ptr(), ops._ptr(q_l2), ops._ptr(t_l2), L, B, M, clamp_q, clamp_t, balance_q,
+                                         balance_t, packed.data_ptr(), scalars.data_ptr(), st)
+                _lib.check(rc, "dfepe_loss_head")
+                if balance_F != 1.0:
+                    raise _lib.DfepeError("the unfused loss tail mixes loss_F + loss_qt (balance_F = 1); use fused_tail=True")
+        saved = [matches, weights, Ks, virt1, virt2, q_gt, t_gt, hw_T, F_layers, E_layers, saves]
+        if gF is not None:
+            saved.append(gF)
+        ctx.save_for_backward(*saved)
         ctx.cfg = cfg
+        ctx.fused_tail = fused_tail
         extras = (F_layers, residuals, epis, weights, E_layers, loss_sum, packed, scalars)
         pose = (q_l2, t_l2, R_deg, t_deg, sel) if qt else ()
         ctx.mark_non_differentiable(*extras, *pose)
@@ -113,8 +148,8 @@ class _HotPathFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_loss, *unused):
-        matches, weights, Ks, virt1, virt2, q_gt, t_gt, hw_T, F_layers, E_layers, saves = ctx.saved_tensors
-        (H, W, clamp_at, qt, clamp_q, clamp_t, balance_q, balance_t, batched) = ctx.cfg
+        matches, weights, Ks, virt1, virt2, q_gt, t_gt, hw_T, F_layers, E_layers, saves = ctx.saved_tensors[:11]
+        (H, W, clamp_at, qt, clamp_q, clamp_t, balance_q, balance_t, batched, balance_F, _ft, grad_pairs) = ctx.cfg
         lib = _lib.lib()
         L, B, N = weights.shape
         M = virt1.shape[1]
@@ -125,28 +160,34 @@ class _HotPathFunction(torch.autograd.Function):
         st = ops._stream()
         flags = _lib.W8PT_RAW_MATCHES | _lib.W8PT_LOGITS
         g_logits = torch.empty(L, B, N, device=dev)
-        gF = torch.empty(L, B, 3, 3, device=dev)
+        n = float(grad_pairs if grad_pairs else B)
         with torch.cuda.device(dev):
-            gE_ptr = None
-            if qt:
-                gE = torch.empty(L, B, 3, 3, device=dev)
-                rc = lib.dfepe_pose_bwd(E_layers.data_ptr(), L, B, q_gt.data_ptr(), t_gt.data_ptr(), None, None,
-                                        balance_q / float(L * B), clamp_q, balance_t / float(L * B), clamp_t, g_scale.data_ptr(),
-                                        gE.data_ptr(), st)
-                _lib.check(rc, "dfepe_pose_bwd")
-                gE_ptr = gE.data_ptr()
-            rc = lib.dfepe_floss_bwd(F_layers.data_ptr(), L, B, hw_T.data_ptr(), hw_T.data_ptr(), 0, Ks.data_ptr(), virt1.data_ptr(),
-                                     virt2.data_ptr(), M, clamp_at, None, 1.0 / float(L * B * M), g_scale.data_ptr(), gE_ptr,
-                                     gF.data_ptr(), st)
-            _lib.check(rc, "dfepe_floss_bwd")
+            if ctx.fused_tail:
+                gF = ctx.saved_tensors[11]  # d loss / d F with unit upstream; w8pt_bwd applies g_scale
+                gs_ptr = g_scale.data_ptr()
+            else:
+                gF = torch.empty(L, B, 3, 3, device=dev)
+                gs_ptr = None
+                gE_ptr = None
+                if qt:
+                    gE = torch.empty(L, B, 3, 3, device=dev)
+                    rc = lib.dfepe_pose_bwd(E_layers.data_ptr(), L, B, q_gt.data_ptr(), t_gt.data_ptr(), None, None,
+                                            balance_q / (L * n), clamp_q, balance_t / (L * n), clamp_t, g_scale.data_ptr(),
+                                            gE.data_ptr(), st)
+                    _lib.check(rc, "dfepe_pose_bwd")
+                    gE_ptr = gE.data_ptr()
+                rc = lib.dfepe_floss_bwd(F_layers.data_ptr(), L, B, hw_T.data_ptr(), hw_T.data_ptr(), 0, Ks.data_ptr(), virt1.data_ptr(),
+                                         virt2.data_ptr(), M, clamp_at, None, 1.0 / (L * n * M), g_scale.data_ptr(), gE_ptr,
+                                         gF.data_ptr(), st)
+                _lib.check(rc, "dfepe_floss_bwd")
             if batched:
                 rc = lib.dfepe_w8pt_bwd(matches.data_ptr(), None, weights.data_ptr(), B, N, L, flags, W, H, 0.5, saves.data_ptr(),
-                                        F_layers.data_ptr(), gF.data_ptr(), None, None, None, g_logits.data_ptr(), None, None, st)
+                                        F_layers.data_ptr(), gF.data_ptr(), None, None, None, gs_ptr, g_logits.data_ptr(), None, None, st)
                 _lib.check(rc, "dfepe_w8pt_bwd")
             else:
                 for l in range(L):
                     rc = lib.dfepe_w8pt_bwd(matches.data_ptr(), None, weights[l].data_ptr(), B, N, 1, flags, W, H, 0.5,
-                                            saves[l].data_ptr(), F_layers[l].data_ptr(), gF[l].data_ptr(), None, None, None,
+                                            saves[l].data_ptr(), F_layers[l].data_ptr(), gF[l].data_ptr(), None, None, None, gs_ptr,
                                             g_logits[l].data_ptr(), None, None, st)
                     _lib.check(rc, "dfepe_w8pt_bwd")
         return None, g_logits, None, None, None, None, None, None, None, None
@@ -155,17 +196,23 @@ class _HotPathFunction(torch.autograd.Function):
 def hot_path_fused(matches: Tensor, logits_layers: Tensor, Ks: Tensor, virt1: Tensor, virt2: Tensor, q_gt: Tensor,
                    t_gt: Tensor, R_gt: Tensor, image_size: Sequence[int], clamp_at: float = 0.02, qt: bool = True,
                    clamp_q: float = 0.1, clamp_t: float = 0.5, balance_q: float = 1.0, balance_t: float = 0.1,
-                   hw_T: Optional[Tensor] = None, layers_batched: bool = False) -> Dict[str, Tensor]:
-    """Same contract and same numbers as hot_path_forward, 15 kernel launches instead of ~120 (loss = loss_F + loss_qt).
+                   hw_T: Optional[Tensor] = None, layers_batched: bool = False, balance_F: float = 1.0, fused_tail: bool = True,
+                   grad_pairs: Optional[int] = None) -> Dict[str, Tensor]:
+    """Same contract and same numbers as hot_path_forward, 11 kernel launches instead of ~120:
+    loss = balance_F * loss_F + loss_qt.  The reference's pipeline drops the F-loss from the objective when if_qt_loss
+    (Train_model_pipeline.py:580-587, `loss += loss_F * balance_F` commented out): that is balance_F = 0; the solver-only
+    benchmark step keeps both terms (BASELINE metric "F+E+pose+loss") with balance_F = 1.
     ``layers_batched`` fits all L weightings in one launch (legal only because the per-layer logits are given; in the
-    real recurrent model each layer's logits depend on the previous fit): 7 launches."""
+    real recurrent model each layer's logits depend on the previous fit).  ``grad_pairs``: the number of pairs the batch
+    means run over in the gradient (the global batch under data parallelism; default B)."""
     L, B, N = logits_layers.shape
     H, W = float(image_size[0]), float(image_size[1])
     dev = matches.device
     if hw_T is None:
         hw_T = torch.tensor([[2.0 / W, 0.0, -1.0], [0.0, 2.0 / H, -1.0], [0.0, 0.0, 1.0]], device=dev)
     f32 = lambda t: ops._prep(t, "input")
-    cfg = (H, W, float(clamp_at), bool(qt), float(clamp_q), float(clamp_t), float(balance_q), float(balance_t), bool(layers_batched))
+    cfg = (H, W, float(clamp_at), bool(qt), float(clamp_q), float(clamp_t), float(balance_q), float(balance_t), bool(layers_batched),
+           float(balance_F), bool(fused_tail), grad_pairs)
     res = _HotPathFunction.apply(f32(matches), f32(logits_layers), f32(Ks), f32(virt1), f32(virt2), f32(q_gt.reshape(B, 4)),
                                  f32(t_gt.reshape(B, 3)), f32(R_gt.reshape(B, 3, 3)), f32(hw_T), cfg)
     loss, F_layers, residuals, epis, weights, E_layers, loss_sum, packed, scalars = res[:9]

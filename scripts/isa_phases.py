@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(256) k(const W8Args A) {
   const int row = (int)(threadIdx.x >> 4);
   const int pair = (int)blockIdx.x * 16 + row;
   if (pair >= A.B) return;
-  w8pt16_fwd_pair<%d, %s>(A, pair, xch + row * 36);
+  w8pt16_fwd_pair<%d, %s, true>(A, pair, xch + row * 36);
 }
 """,
     "bwd": """#include "dfepe_common.h"

@@ -9,6 +9,7 @@
 #include "rowgroup.h"  // the emulation (this directory comes first on the include path)
 #include "w8pt16_body.h"
 #include "w8pt16_bwd_body.h"
+#include "loss_tail_body.h"
 
 thread_local emu::Row* emu::g_row = nullptr;
 
@@ -73,7 +74,9 @@ int dispatch(const Args& A, int B, int N, bool raw) {
 
 template <int IT, bool RAW>
 struct FwdBody {
-  static void run(const W8Args& A, int pair, double* xch) { w8pt16_fwd_pair<IT, RAW>(A, pair, xch); }
+  static void run(const W8Args& A, int pair, double* xch) {
+    if (A.variant == 0) w8pt16_fwd_pair<IT, RAW, true>(A, pair, xch); else w8pt16_fwd_pair<IT, RAW, false>(A, pair, xch);
+  }
 };
 template <int IT, bool RAW>
 struct BwdBody {
@@ -99,15 +102,41 @@ extern "C" int emu_w8pt16_fwd(const float* pts1, const float* pts2, const float*
 extern "C" int emu_w8pt16_bwd(const float* pts1, const float* pts2, const float* weights, int B, int N, int n_weight_sets,
                               unsigned flags, float image_w, float image_h, float clamp_at, const float* save,
                               const float* F_out, const float* g_F, const float* g_residual, const float* g_epi,
-                              const float* g_weights_extra, float* g_weights, float* g_pts1, float* g_pts2) {
+                              const float* g_weights_extra, const float* g_scale, float* g_weights, float* g_pts1, float* g_pts2) {
   if (N < 1 || N > 128) return -3;
   const bool raw = (flags & DFEPE_W8PT_RAW_MATCHES) != 0;
   W8BwdArgs A;
   A.pts1 = pts1; A.pts2 = pts2; A.wts = weights;
   A.Bm = B; A.B = B * n_weight_sets; A.N = N;
   A.hw_sx = raw ? 2.0f / image_w : 0.f; A.hw_sy = raw ? 2.0f / image_h : 0.f; A.clamp_at = clamp_at;
-  A.save = save; A.F_out = F_out; A.g_F = g_F; A.g_res = g_residual; A.g_epi = g_epi; A.g_w_extra = g_weights_extra;
+  A.save = save; A.F_out = F_out; A.g_F = g_F; A.g_res = g_residual; A.g_epi = g_epi; A.g_w_extra = g_weights_extra; A.g_scale = g_scale;
   A.g_w = g_weights; A.g_p1 = g_pts1; A.g_p2 = g_pts2;
   A.logits_mode = (flags & DFEPE_W8PT_LOGITS) ? 1 : 0;
   return dispatch<BwdBody>(A, A.B, N, raw);
+}
+
+// the fused loss tail, pair by pair (the batch sums of the loss head are left to the caller: part[B][kTailParts])
+extern "C" int emu_loss_tail(const float* F_layers, int L, int B, const float* T1, const float* T2, int t_stride, const float* K,
+                             const float* virt1, const float* virt2, int M, float clamp_at, const float* q_gt, const float* t_gt,
+                             const float* R_gt, float clamp_q, float clamp_t, float coef_F, float coef_q, float coef_t,
+                             float* loss_sum, float* E_layers, float* q_l2, float* t_l2, float* R_deg, float* t_deg, int* sel,
+                             float* g_F, double* part) {
+  if (M < 1 || M > 128 || L < 1 || L > kTailMaxLayers) return -3;
+  TailArgs A;
+  A.F_layers = F_layers; A.L = L; A.B = B; A.M = M; A.t_stride = t_stride; A.T1 = T1; A.T2 = T2; A.K = K;
+  A.virt1 = virt1; A.virt2 = virt2; A.clamp_at = clamp_at; A.q_gt = q_gt; A.t_gt = t_gt; A.R_gt = R_gt;
+  A.clamp_q = clamp_q; A.clamp_t = clamp_t; A.coef_F = coef_F; A.coef_q = coef_q; A.coef_t = coef_t;
+  A.loss_sum = loss_sum; A.E_layers = E_layers; A.q_l2 = q_l2; A.t_l2 = t_l2; A.R_deg = R_deg; A.t_deg = t_deg; A.sel = sel; A.g_F = g_F;
+  for (int pair = 0; pair < B; ++pair) {
+    float lds[kTailLdsFloats];
+    double* pp = part + (size_t)pair * kTailParts;
+    for (int e = 0; e < kTailParts; ++e) pp[e] = 0.0;
+    auto go = [&](auto itc) { run_row([&]() { loss_tail_pair<decltype(itc)::value>(A, pair, lds, pp); }); };
+    if (M <= 16) go(std::integral_constant<int, 1>{});
+    else if (M <= 32) go(std::integral_constant<int, 2>{});
+    else if (M <= 64) go(std::integral_constant<int, 4>{});
+    else if (M <= 112) go(std::integral_constant<int, 7>{});
+    else go(std::integral_constant<int, 8>{});
+  }
+  return 0;
 }

@@ -182,6 +182,47 @@ def test_fused_step_equals_unfused_ops(dfepe):
     np.testing.assert_allclose(a["packed"].cpu().numpy(), ref.cpu().numpy(), rtol=1e-6)
 
 
+@pytest.mark.parametrize("qt,balance_F", [(True, 1.0), (True, 0.0), (False, 1.0), (True, 0.3)])
+def test_fused_loss_tail_equals_the_five_kernel_tail(dfepe, qt, balance_F):
+    """dfepe_loss_tail (one launch: F-loss + E + pose + loss head + d loss / d F, unit upstream, g_scale applied by w8pt_bwd)
+    against the round-1 tail (floss_fwd, pose_fwd, loss_head | pose_bwd, floss_bwd) on the same fits, with a non-unit
+    upstream gradient; balance_F = 0 is the reference's qt-only objective (Train_model_pipeline.py:580-587)."""
+    B, N, depth = 37, 100, 5
+    sc = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(B, N, seed=35, outlier_ratio=0.3, depth_layers=depth), DEV)
+
+    def run(**kw):
+        logits = sc["logits_layers"][:depth].detach().clone().requires_grad_(True)
+        o = dfepe.pipeline.hot_path_fused(sc["matches_xy_ori"], logits, sc["Ks"], sc["pts1_virt_ori"], sc["pts2_virt_ori"], sc["qs_cam"],
+                                          sc["ts_cam"], sc["R_gt"], IMAGE_SIZE, 0.02, qt, **kw)
+        (o["loss"] * 2.5).backward()
+        o["grad_logits"] = logits.grad
+        return o
+
+    a = run(balance_F=balance_F, fused_tail=True)
+    if balance_F == 1.0:
+        b = run(fused_tail=False)
+        assert abs(a["loss"].item() - b["loss"].item()) < 1e-6
+        assert relerr(a["grad_logits"].cpu().numpy(), b["grad_logits"].cpu().numpy()) < 2e-5
+    else:  # the unfused tail only knows loss_F + loss_qt: combine its two pure cases linearly
+        b = run(fused_tail=False)
+        lf, lq = b["loss_F"].item(), b["loss_qt"].item()
+        assert abs(a["loss"].item() - (balance_F * lf + lq)) < 1e-6
+        c = run(balance_F=1.0, fused_tail=True)           # g(loss_F + loss_qt)
+        sc0 = run(balance_F=0.0, fused_tail=True) if balance_F != 0.0 else a  # g(loss_qt)
+        gF_only = c["grad_logits"] - sc0["grad_logits"]
+        expect = balance_F * gF_only + sc0["grad_logits"]
+        assert relerr(a["grad_logits"].cpu().numpy(), expect.cpu().numpy()) < 5e-5
+    for k in ("loss_sum", "E_layers", "F_layers") + (("q_l2", "t_l2", "R_deg", "t_deg") if qt else ()):
+        np.testing.assert_allclose(a[k].cpu().numpy(), b[k].cpu().numpy(), rtol=2e-6, atol=2e-6, err_msg=k)
+    if qt:
+        assert torch.equal(a["sel"], b["sel"])
+    np.testing.assert_allclose(a["packed"].cpu().numpy(), b["packed"].cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(a["loss_layers"].cpu().numpy(), b["loss_layers"].cpu().numpy(), rtol=1e-6)
+    # the completion ticket is back at zero and a second call gives the same bits (deterministic batch sums)
+    a2 = run(balance_F=balance_F, fused_tail=True)
+    assert torch.equal(a2["packed"], a["packed"]) and torch.equal(a2["grad_logits"], a["grad_logits"])
+
+
 def test_layers_batched_launch_is_bit_identical(dfepe):
     """n_weight_sets = L (all layers' weightings of the same pairs in one grid) runs the same per-wave program as L
     separate launches: every output and the logits gradient are bit-identical.  Point gradients are refused there."""

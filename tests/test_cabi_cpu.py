@@ -44,13 +44,18 @@ def test_argument_validation_without_launching(dfepe):
     assert L.dfepe_w8pt_fwd(None, None, None, 4, 100, 1, 0, 0.0, 0.0, 0.5, None, None, None, None, None, None) == -1
     assert L.dfepe_w8pt_fwd(None, None, None, -1, 100, 1, 0, 0.0, 0.0, 0.5, None, None, None, None, None, None) == -1
     assert L.dfepe_w8pt_fwd(None, None, None, 0, 100, 1, 0, 0.0, 0.0, 0.5, None, None, None, None, None, None) == 0  # empty batch
-    assert L.dfepe_w8pt_bwd(None, None, None, 2, 0, 1, 0, 0.0, 0.0, 0.5, None, None, None, None, None, None, None, None, None, None) == -1
+    assert L.dfepe_w8pt_bwd(None, None, None, 2, 0, 1, 0, 0.0, 0.0, 0.5, None, None, None, None, None, None, None, None, None, None, None) == -1
+    assert L.dfepe_w8pt_fwd(None, None, None, 4, 100, 1, 1 << 9, 0.0, 0.0, 0.5, None, None, None, None, None, None) == -1  # unknown flag bit
     assert L.dfepe_floss_fwd(None, 0, 4, None, None, 0, None, None, None, 100, 0.02, None, None, None) == -1
     assert L.dfepe_floss_fwd(None, 5, 0, None, None, 0, None, None, None, 100, 0.02, None, None, None) == 0
     assert L.dfepe_floss_fwd(None, 5, 4, None, None, 3, None, None, None, 100, 0.02, None, None, None) == -1  # bad stride
     assert L.dfepe_pose_fwd(None, 5, 4, None, None, None, None, None, None, None, None, None) == -1
     assert L.dfepe_pose_bwd(None, 5, 0, None, None, None, None, 0.0, 0.0, 0.0, 0.0, None, None, None) == 0
     assert L.dfepe_loss_head(None, None, None, 5, 4, 100, 0.1, 0.5, 1.0, 0.1, None, None, None) == -1
+    tail = lambda L_, B_, M_: L.dfepe_loss_tail(None, L_, B_, None, None, 0, None, None, None, M_, 0.02, None, None, None, 0.1, 0.5, 1.0, 1.0, 0.1, 4.0,
+                                               None, None, None, None, None, None, None, None, None, None, None, None)
+    assert tail(5, 4, 100) == -1 and tail(0, 4, 100) == -1 and tail(5, 4, 200) == -3  # null pointers; no layers; grid too large for the fused kernel
+    assert L.dfepe_loss_tail_workspace_bytes(4096) >= 64 + 256 * 48 * 8
 
 
 def test_no_cpu_fallback(dfepe):

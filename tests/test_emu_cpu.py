@@ -31,7 +31,7 @@ def emu():
     L.emu_w8pt16_fwd.restype = I
     L.emu_w8pt16_fwd.argtypes = [P, P, P, I, I, I, U, F, F, F, P, P, P, P, P]
     L.emu_w8pt16_bwd.restype = I
-    L.emu_w8pt16_bwd.argtypes = [P, P, P, I, I, I, U, F, F, F, P, P, P, P, P, P, P, P, P]
+    L.emu_w8pt16_bwd.argtypes = [P, P, P, I, I, I, U, F, F, F, P, P, P, P, P, P, P, P, P, P]
     return L
 
 
@@ -52,13 +52,13 @@ def emu_fwd(L, pts1, pts2, w, flags, want_epi=True, want_save=True, clamp_at=0.5
     return F, res, epi, save, wout
 
 
-def emu_bwd(L, pts1, pts2, w, flags, save, F, gF, gRes, gEpi, want_pts=False, clamp_at=0.5):
+def emu_bwd(L, pts1, pts2, w, flags, save, F, gF, gRes, gEpi, want_pts=False, clamp_at=0.5, g_scale=None):
     B, N = w.shape
     gW = torch.empty(B, N)
     gP1 = torch.empty_like(pts1) if want_pts else None
     gP2 = torch.empty_like(pts2) if (want_pts and pts2 is not None) else None
     rc = L.emu_w8pt16_bwd(_p(pts1), _p(pts2), _p(w), B, N, 1, flags, float(IMAGE_SIZE[1]), float(IMAGE_SIZE[0]), clamp_at,
-                          _p(save), _p(F), _p(gF), _p(gRes), _p(gEpi), None, _p(gW), _p(gP1), _p(gP2))
+                          _p(save), _p(F), _p(gF), _p(gRes), _p(gEpi), None, _p(g_scale), _p(gW), _p(gP1), _p(gP2))
     assert rc == 0
     return gW, gP1, gP2
 
@@ -169,3 +169,59 @@ def test_point_gradients_body_vs_oracle_autograd(emu, dfepe, oracle, raw):
     else:
         assert relerr(gP1[:, :, :2].numpy(), p1.grad[:, :, :2].numpy()) < 5e-4
         assert relerr(gP2[:, :, :2].numpy(), p2.grad[:, :, :2].numpy()) < 5e-4
+
+
+@pytest.mark.parametrize("L,M,qt,noise", [(5, 100, True, 0.003), (3, 100, False, 0.003), (2, 17, True, 0.02), (4, 128, True, 0.0005)])
+def test_loss_tail_body_vs_oracle(emu, dfepe, oracle, L, M, qt, noise):
+    """The fused loss tail (csrc/loss_tail_body.h) under the row emulation: per-pair F-loss sums, E, pose errors and
+    d loss / d F of every layer against the oracle's f_loss / rt_loss and fp64 autograd."""
+    I, P, F32 = ctypes.c_int, ctypes.c_void_p, ctypes.c_float
+    emu.emu_loss_tail.restype = I
+    emu.emu_loss_tail.argtypes = [P, I, I, P, P, I, P, P, P, I, F32, P, P, P, F32, F32, F32, F32, F32] + [P] * 9
+    B = 6
+    sc = dfepe.synth.make_scene(B, 50, seed=2 + L, n_virtual=M) if "n_virtual" in dfepe.synth.make_scene.__code__.co_varnames else dfepe.synth.make_scene(B, 50, seed=2 + L)
+    v1, v2 = sc["pts1_virt_ori"][:, :M].contiguous(), sc["pts2_virt_ori"][:, :M].contiguous()
+    if v1.shape[1] < M:  # tile the virtual points up to M
+        rep = (M + v1.shape[1] - 1) // v1.shape[1]
+        v1, v2 = v1.repeat(1, rep, 1)[:, :M].contiguous(), v2.repeat(1, rep, 1)[:, :M].contiguous()
+    g = torch.Generator().manual_seed(4)
+    T = oracle.hw_matrix(IMAGE_SIZE, torch.float64)
+    Tinv = torch.linalg.inv(T)
+    Fn = Tinv.T @ sc["F_gt"].double() @ Tinv
+    Fn = Fn / Fn.flatten(1).norm(dim=1)[:, None, None]
+    Fl = torch.stack([Fn + noise * (l + 1) * torch.randn(B, 3, 3, generator=g, dtype=torch.float64) for l in range(L)])
+    Fl = Fl.float().contiguous()  # both sides see the same fp32-representable F
+    clamp, cq, ct, bF, bq, bt = 0.02, 0.1, 0.5, 0.7, 1.0, 0.1
+    coefF, coefq, coeft = bF / (L * B * M), bq / (L * B), bt / (L * B)
+    Ks = sc["Ks"].contiguous()
+    q_gt, t_gt = sc["qs_cam"].reshape(B, 4).contiguous(), sc["ts_cam"].reshape(B, 3).contiguous()
+    R_gt = sc["delta_Rtijs_4_4"][:, :3, :3].transpose(1, 2).contiguous()
+    Tf = T.float().contiguous()
+    loss_sum, E = torch.zeros(L, B), torch.zeros(L, B, 3, 3)
+    q_l2, t_l2, R_deg, t_deg = (torch.zeros(L, B) for _ in range(4))
+    sel = torch.zeros(L, B, dtype=torch.int32)
+    gF = torch.zeros(L, B, 3, 3)
+    part = torch.zeros(B, 48, dtype=torch.float64)
+    rc = emu.emu_loss_tail(_p(Fl), L, B, _p(Tf), _p(Tf), 0, _p(Ks), _p(v1), _p(v2), M, clamp, _p(q_gt) if qt else None, _p(t_gt), _p(R_gt),
+                           cq, ct, coefF, coefq, coeft, _p(loss_sum), _p(E), _p(q_l2), _p(t_l2), _p(R_deg), _p(t_deg), _p(sel), _p(gF), _p(part))
+    assert rc == 0
+    Fo = Fl.double().clone().requires_grad_(True)
+    outs = {"T1": T.expand(B, 3, 3), "T2": T.expand(B, 3, 3), "out_layers": [Fo[l] for l in range(L)], "F_est": Fo[-1],
+            "epi_res_layers": [], "weights_layers": []}
+    losses, _, _, E_layers = oracle.f_loss(outs, v1.double(), v2.double(), Ks.double(), L, clamp)
+    per_pair_sum = losses["loss_per_pair"] * M
+    assert relerr(loss_sum.numpy(), per_pair_sum.detach().numpy()) < 2e-5
+    assert relerr(E.numpy(), torch.stack(E_layers).detach().numpy()) < 2e-6
+    np.testing.assert_allclose(part[:, :L].numpy().T, loss_sum.numpy(), rtol=0, atol=0)
+    lo = bF * losses["loss_F"]
+    if qt:
+        pose = oracle.rt_loss(E_layers, sc["delta_Rtijs_4_4"].double(), sc["qs_cam"].double(), sc["ts_cam"].double())
+        np.testing.assert_allclose(q_l2.numpy(), pose["q_l2"].detach().numpy(), atol=2e-6, rtol=1e-5)
+        np.testing.assert_allclose(t_l2.numpy(), pose["t_l2"].detach().numpy(), atol=2e-6, rtol=1e-5)
+        np.testing.assert_allclose(R_deg.numpy(), pose["R_deg"], atol=2e-3, rtol=1e-4)
+        np.testing.assert_allclose(t_deg.numpy(), pose["t_deg"], atol=2e-2, rtol=1e-4)
+        np.testing.assert_allclose(part[:, 16:16 + L].numpy().T, np.clip(q_l2.numpy(), 0, cq), rtol=0, atol=0)
+        np.testing.assert_allclose(part[:, 32:32 + L].numpy().T, np.clip(t_l2.numpy(), 0, ct), rtol=0, atol=0)
+        lo = lo + oracle.qt_training_loss(pose["q_l2"], pose["t_l2"], cq, ct, bq, bt)
+    lo.backward()
+    assert relerr(gF.numpy(), Fo.grad.numpy()) < 3e-4
