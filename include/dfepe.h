@@ -183,8 +183,8 @@ int dfepe_loss_head(const float *loss_sum, const float *q_l2, const float *t_l2,
  *   grad_pairs: number of pairs the means run over in the gradient coefficients (B, or the global batch under data parallelism)
  *   g_F_layers [L,B,9] or NULL; feed it to dfepe_w8pt_bwd with g_scale = the upstream gradient of the loss
  *   packed [L+4] doubles, scalars [4+L] floats: as dfepe_loss_head, scalars[0] = balance_F * loss_F + loss_qt
- *   workspace: dfepe_loss_tail_workspace_bytes(B) bytes, 8-byte aligned, its first 4 bytes ZERO before the first launch
- *     (the kernel leaves them zero); batch sums are combined in a fixed order (no floating-point atomics): deterministic
+ *   workspace: dfepe_loss_tail_workspace_bytes(B) bytes, 8-byte aligned, contents irrelevant (per-workgroup partial sums;
+ *     a one-workgroup kernel enqueued right behind adds them in a fixed order: no floating-point atomics, deterministic)
  */
 size_t dfepe_loss_tail_workspace_bytes(int B);
 int dfepe_loss_tail(const float *F_layers, int L, int B, const float *T1, const float *T2, int t_stride, const float *K,

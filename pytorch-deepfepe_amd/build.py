@@ -21,6 +21,7 @@ OBJDIR = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libdfepe_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-ffp-contract=on", f"-I{INCLUDE}", f"-I{CSRC}"]
+FLAGS += os.environ.get("DFEPE_EXTRA_FLAGS", "").split()  # experiment builds (A/B timing of a -D switch); empty for the product
 
 
 def _hipcc() -> str:

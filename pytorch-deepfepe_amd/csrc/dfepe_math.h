@@ -175,8 +175,14 @@ __device__ inline void svd3_fast(const float* F, float* U, float* S, float* V) {
   U[2] = sg * c0; U[5] = sg * c1; U[8] = sg * c2;
 }
 
-__device__ __forceinline__ double svd_rsqrt(double x) { return fast_rsqrt(x); }
+// square root / reciprocal flavours of the templated 3x3 SVD: branch-free Newton forms in fp64 (operands are squared
+// column norms and singular values of matrices of moderate magnitude), the hardware ops in fp32
+__device__ __forceinline__ double svd_rsqrt(double x) { return rsqrt_nr<2>(x); }
 __device__ __forceinline__ float svd_rsqrt(float x) { return hw_rsq(x); }
+__device__ __forceinline__ double svd_sqrt(double x) { return sqrt_nr<2>(x); }
+__device__ __forceinline__ float svd_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double svd_rcp(double x) { return rcp_nr<2>(x); }
+__device__ __forceinline__ float svd_rcp(float x) { return 1.0f / x; }
 
 // One-sided (Hestenes) Jacobi SVD of a 3x3 matrix: F = U diag(S) V^T, S descending, S[2] >= 0 given the
 // orientation chosen for u3.  U, V row-major with singular vectors in columns.  Straight-line code on
@@ -224,7 +230,7 @@ __device__ inline void svd3(const T* F, T* U, T* S, T* V) {
   }
   T n[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) n[k] = sqrt(G[k] * G[k] + G[3 + k] * G[3 + k] + G[6 + k] * G[6 + k]);
+  for (int k = 0; k < 3; ++k) n[k] = svd_sqrt(G[k] * G[k] + G[3 + k] * G[3 + k] + G[6 + k] * G[6 + k]);
   // sort columns descending (3-element network)
 #define DFEPE_SWAPCOL(a, b)                                   \
   if (n[a] < n[b]) {                                          \
@@ -241,7 +247,7 @@ __device__ inline void svd3(const T* F, T* U, T* S, T* V) {
   const T tiny = T(1e-30);
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    T inv = T(1) / fmax(n[k], tiny);
+    T inv = svd_rcp(fmax(n[k], tiny));
     U[k] = G[k] * inv;
     U[3 + k] = G[3 + k] * inv;
     U[6 + k] = G[6 + k] * inv;
@@ -250,7 +256,7 @@ __device__ inline void svd3(const T* F, T* U, T* S, T* V) {
   {
     T d = U[0] * U[1] + U[3] * U[4] + U[6] * U[7];
     T a0 = U[1] - d * U[0], a1 = U[4] - d * U[3], a2 = U[7] - d * U[6];
-    T inv = T(1) / fmax(sqrt(a0 * a0 + a1 * a1 + a2 * a2), tiny);
+    T inv = svd_rsqrt(fmax(a0 * a0 + a1 * a1 + a2 * a2, tiny * tiny));
     U[1] = a0 * inv; U[4] = a1 * inv; U[7] = a2 * inv;
   }
   T c0 = U[3] * U[7] - U[6] * U[4];

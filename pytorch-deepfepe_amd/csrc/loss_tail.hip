@@ -1,7 +1,7 @@
 // dfepe_loss_tail -- the fused loss tail of the hot-path step (body: loss_tail_body.h): one 16-lane row per pair, 16 pairs
 // per 256-thread workgroup, ONE launch for F-loss + E-from-F + pose errors + the loss-head sums + d loss / d F of every layer.
-// The batch sums of the loss head are combined deterministically: per-workgroup partial sums in fixed row order, then the
-// last workgroup to finish (atomic ticket) adds the partials in workgroup order -- no floating-point atomics.
+// The batch sums of the loss head are combined deterministically (per-workgroup partial sums in fixed row order, then a
+// one-workgroup kernel that adds the partials in a fixed order) -- no floating-point atomics.
 #include "dfepe_common.h"
 #include "loss_tail_body.h"
 
@@ -9,63 +9,84 @@ namespace {
 
 constexpr int kPairsPerBlock = 16;
 
-struct TailHead {
-  double* partials;    // [gridDim.x][kTailParts]
-  unsigned* ticket;    // zero before the first launch; the kernel leaves it zero
-  double* packed;      // [L+4]
-  float* scalars;      // [4+L]
-  float balance_F, balance_q, balance_t;
-};
-
 template <int IT>
-__global__ void __launch_bounds__(256) loss_tail_kernel(const TailArgs A, const TailHead H) {
+__global__ void __launch_bounds__(256) loss_tail_kernel(const TailArgs A, double* __restrict__ partials) {
   __shared__ float lds[kPairsPerBlock][kTailLdsFloats];
   __shared__ double part[kPairsPerBlock][kTailParts];
-  __shared__ double tot[kTailParts];
-  __shared__ int is_last;
   const int row = (int)(threadIdx.x >> 4);
   const int pair = (int)blockIdx.x * kPairsPerBlock + row;
   for (int e = (int)(threadIdx.x & 15u); e < kTailParts; e += 16) part[row][e] = 0.0;
   rg_sync();
   if (pair < A.B) loss_tail_pair<IT>(A, pair, lds[row], part[row]);
   __syncthreads();
+  // per-workgroup partial sums of the loss head, rows added in fixed order
   if (threadIdx.x < kTailParts) {
     double s = 0.0;
 #pragma unroll
     for (int r = 0; r < kPairsPerBlock; ++r) s += part[r][threadIdx.x];
-    H.partials[(size_t)blockIdx.x * kTailParts + threadIdx.x] = s;
+    partials[(size_t)blockIdx.x * kTailParts + threadIdx.x] = s;
   }
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) is_last = (atomicAdd(H.ticket, 1u) == gridDim.x - 1) ? 1 : 0;
-  __syncthreads();
-  if (!is_last) return;
-  __threadfence();
-  if (threadIdx.x < kTailParts) {
-    double s = 0.0;
-    for (unsigned b = 0; b < gridDim.x; ++b)
-      s += __hip_atomic_load(H.partials + (size_t)b * kTailParts + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    tot[threadIdx.x] = s;
-  }
+}
+
+// The batch sums: one workgroup adds the per-workgroup partials in a fixed order (every thread takes workgroups t, t + 256,
+// ...: all loads in flight together; then DPP wave sums and a 4-way combine).  Deterministic, no floating-point atomics.
+// A launch of its own: the kernel boundary is what makes the partials of all XCDs visible, for less than an in-kernel
+// "last workgroup" protocol costs in agent-scope fences on a multi-XCD part (measured: 24 us against 5 us).
+struct TailHead {
+  const double* partials;  // [nblocks][kTailParts]
+  int nblocks, L, B, M, pose;
+  double* packed;          // [L+4]
+  float* scalars;          // [4+L]
+  float balance_F, balance_q, balance_t;
+};
+
+__global__ void __launch_bounds__(256) loss_tail_head_kernel(const TailHead H) {
+  __shared__ double red[4][kTailParts];
+  const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+  double v[3][kTailMaxLayers];
+#pragma unroll
+  for (int kind = 0; kind < 3; ++kind)
+#pragma unroll
+    for (int l = 0; l < kTailMaxLayers; ++l) {
+      double s = 0.0;
+      if (l < H.L)
+        for (int b = (int)threadIdx.x; b < H.nblocks; b += 256) s += H.partials[(size_t)b * kTailParts + kind * kTailMaxLayers + l];
+      v[kind][l] = s;
+    }
+#pragma unroll
+  for (int kind = 0; kind < 3; ++kind)
+#pragma unroll
+    for (int l = 0; l < kTailMaxLayers; ++l) {
+      if (l < H.L) {
+        const double s = wave_sum(v[kind][l]);
+        if (lane == 0) red[wave][kind * kTailMaxLayers + l] = s;
+      }
+    }
   __syncthreads();
   if (threadIdx.x == 0) {
     // same quantities as dfepe_loss_head
-    const int L = A.L;
+    const int L = H.L;
     double totF = 0.0, tq = 0.0, tt = 0.0;
-    for (int l = 0; l < L; ++l) { H.packed[l] = tot[l]; totF += tot[l]; tq += tot[kTailMaxLayers + l]; tt += tot[2 * kTailMaxLayers + l]; }
+    for (int l = 0; l < L; ++l) {
+      const double f = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+      const int iq = kTailMaxLayers + l, it = 2 * kTailMaxLayers + l;
+      H.packed[l] = f;
+      H.scalars[4 + l] = (float)(f / ((double)H.B * (double)H.M));  // losses.mean() of layer l
+      totF += f;
+      tq += (red[0][iq] + red[1][iq]) + (red[2][iq] + red[3][iq]);
+      tt += (red[0][it] + red[1][it]) + (red[2][it] + red[3][it]);
+    }
     H.packed[L] = tq;
     H.packed[L + 1] = tt;
-    H.packed[L + 2] = (double)A.B;
-    H.packed[L + 3] = (double)A.M;
-    const double n = (double)A.B;
-    const double loss_F = totF / (n * (double)A.M * (double)L);
-    const double loss_qt = (A.q_gt != nullptr) ? (tq * (double)H.balance_q + tt * (double)H.balance_t) / (n * (double)L) : 0.0;
+    H.packed[L + 2] = (double)H.B;
+    H.packed[L + 3] = (double)H.M;
+    const double n = (double)H.B;
+    const double loss_F = totF / (n * (double)H.M * (double)L);
+    const double loss_qt = H.pose ? (tq * (double)H.balance_q + tt * (double)H.balance_t) / (n * (double)L) : 0.0;
     H.scalars[0] = (float)((double)H.balance_F * loss_F + loss_qt);
     H.scalars[1] = (float)loss_F;
     H.scalars[2] = (float)loss_qt;
     H.scalars[3] = 0.0f;
-    for (int l = 0; l < L; ++l) H.scalars[4 + l] = (float)(tot[l] / (n * (double)A.M));  // losses.mean() of layer l
-    *H.ticket = 0u;
   }
 }
 
@@ -73,7 +94,7 @@ __global__ void __launch_bounds__(256) loss_tail_kernel(const TailArgs A, const 
 
 extern "C" size_t dfepe_loss_tail_workspace_bytes(int B) {
   const size_t blocks = (size_t)((B > 0 ? B : 0) + kPairsPerBlock - 1) / kPairsPerBlock;
-  return 64 + blocks * kTailParts * sizeof(double);
+  return blocks * kTailParts * sizeof(double);
 }
 
 extern "C" int dfepe_loss_tail(const float* F_layers, int L, int B, const float* T1, const float* T2, int t_stride,
@@ -99,16 +120,17 @@ extern "C" int dfepe_loss_tail(const float* F_layers, int L, int B, const float*
   A.coef_t = (float)((double)balance_t / ((double)L * grad_pairs));
   A.loss_sum = loss_sum; A.E_layers = E_layers; A.q_l2 = q_l2; A.t_l2 = t_l2; A.R_deg = R_deg; A.t_deg = t_deg; A.sel = sel;
   A.g_F = g_F_layers;
-  TailHead H;
-  H.ticket = static_cast<unsigned*>(workspace);
-  H.partials = reinterpret_cast<double*>(static_cast<unsigned char*>(workspace) + 64);
-  H.packed = packed; H.scalars = scalars; H.balance_F = balance_F; H.balance_q = balance_q; H.balance_t = balance_t;
+  double* partials = static_cast<double*>(workspace);
   const dim3 grid((B + kPairsPerBlock - 1) / kPairsPerBlock), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (M <= 16) hipLaunchKernelGGL((loss_tail_kernel<1>), grid, block, 0, st, A, H);
-  else if (M <= 32) hipLaunchKernelGGL((loss_tail_kernel<2>), grid, block, 0, st, A, H);
-  else if (M <= 64) hipLaunchKernelGGL((loss_tail_kernel<4>), grid, block, 0, st, A, H);
-  else if (M <= 112) hipLaunchKernelGGL((loss_tail_kernel<7>), grid, block, 0, st, A, H);
-  else hipLaunchKernelGGL((loss_tail_kernel<8>), grid, block, 0, st, A, H);
+  if (M <= 16) hipLaunchKernelGGL((loss_tail_kernel<1>), grid, block, 0, st, A, partials);
+  else if (M <= 32) hipLaunchKernelGGL((loss_tail_kernel<2>), grid, block, 0, st, A, partials);
+  else if (M <= 64) hipLaunchKernelGGL((loss_tail_kernel<4>), grid, block, 0, st, A, partials);
+  else if (M <= 112) hipLaunchKernelGGL((loss_tail_kernel<7>), grid, block, 0, st, A, partials);
+  else hipLaunchKernelGGL((loss_tail_kernel<8>), grid, block, 0, st, A, partials);
+  TailHead H;
+  H.partials = partials; H.nblocks = (int)grid.x; H.L = L; H.B = B; H.M = M; H.pose = (q_gt != nullptr) ? 1 : 0;
+  H.packed = packed; H.scalars = scalars; H.balance_F = balance_F; H.balance_q = balance_q; H.balance_t = balance_t;
+  hipLaunchKernelGGL(loss_tail_head_kernel, dim3(1), dim3(256), 0, st, H);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }

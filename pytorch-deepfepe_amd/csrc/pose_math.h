@@ -46,7 +46,7 @@ __device__ __forceinline__ Quat rot_to_quat(const double* R) {
     }
   }
 #undef M_
-  const double sc = 0.5 / sqrt(t);
+  const double sc = 0.5 * rsqrt_nr<2>(t);  // t >= 1 in the branch taken
   o.sg = (v[0] * sc < 0.0) ? -1.0 : 1.0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) o.q[k] = o.sg * sc * v[k];
@@ -59,9 +59,10 @@ __device__ __forceinline__ void rot_to_quat_bwd(const Quat& qq, const double* gq
   double gm[9];  // w.r.t. m = R^T, row-major
 #pragma unroll
   for (int k = 0; k < 9; ++k) gm[k] = 0.0;
-  const double sc = qq.sg * 0.5 / sqrt(qq.tr);
+  const double itr = rcp_nr<2>(qq.tr);
+  const double sc = qq.sg * 0.5 * rsqrt_nr<2>(qq.tr);
   const double gv0 = sc * gq[0], gv1 = sc * gq[1], gv2 = sc * gq[2], gv3 = sc * gq[3];
-  const double gt = -0.5 * (qq.q[0] * gq[0] + qq.q[1] * gq[1] + qq.q[2] * gq[2] + qq.q[3] * gq[3]) / qq.tr;
+  const double gt = -0.5 * (qq.q[0] * gq[0] + qq.q[1] * gq[1] + qq.q[2] * gq[2] + qq.q[3] * gq[3]) * itr;
 #define ADD(i, j, c) gm[3 * (i) + (j)] += (c)
   if (qq.branch == 0) {
     const double T = gv1 + gt;
@@ -121,23 +122,23 @@ __device__ inline void pose_forward(const float* E, const float* q_gt, const flo
   P.sd = (det < 0.0) ? -1.0 : 1.0;
 #pragma unroll
   for (int k = 0; k < 9; ++k) { P.R[0][k] *= P.sd; P.R[1][k] *= P.sd; }
-  const double un = sqrt(U[2] * U[2] + U[5] * U[5] + U[8] * U[8]);
-  P.t[0] = U[2] / un; P.t[1] = U[5] / un; P.t[2] = U[8] / un;
-  const double gn = fmax(sqrt((double)t_gt[0] * t_gt[0] + (double)t_gt[1] * t_gt[1] + (double)t_gt[2] * t_gt[2]), 1e-12);
+  const double iun = rsqrt_nr<2>(U[2] * U[2] + U[5] * U[5] + U[8] * U[8]);
+  P.t[0] = U[2] * iun; P.t[1] = U[5] * iun; P.t[2] = U[8] * iun;
+  const double ign = rcp_nr<2>(fmax(sqrt_nr<2>((double)t_gt[0] * t_gt[0] + (double)t_gt[1] * t_gt[1] + (double)t_gt[2] * t_gt[2]), 1e-12));
 #pragma unroll
-  for (int k = 0; k < 3; ++k) P.tg[k] = (double)t_gt[k] / gn;  // F.normalize(p=2, dim=0) (:151)
+  for (int k = 0; k < 3; ++k) P.tg[k] = (double)t_gt[k] * ign;  // F.normalize(p=2, dim=0) (:151)
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     P.q[c] = rot_to_quat(P.R[c]);
     double e = 0.0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { const double d = P.q[c].q[k] - (double)q_gt[k]; e += d * d; }
-    P.qe[c] = sqrt(e);
+    P.qe[c] = sqrt_nr<2>(e);
     const double sgn = (c == 0) ? 1.0 : -1.0;
     double f = 0.0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) { const double d = sgn * P.t[k] - P.tg[k]; f += d * d; }
-    P.te[c] = sqrt(f);
+    P.te[c] = sqrt_nr<2>(f);
   }
   P.qi = (P.qe[0] < P.qe[1]) ? 0 : 1;  // strict '<' (:160-161)
   P.ti = (P.te[0] < P.te[1]) ? 0 : 1;
@@ -148,15 +149,17 @@ __device__ inline void pose_backward(const Pose& P, const float* q_gt, double gq
   // d|q - q_gt| / dq
   double gq[4], gR[9];
   const Quat& qq = P.q[P.qi];
+  const double iqe = (P.qe[P.qi] > 0.0) ? gql * rcp_nr<2>(P.qe[P.qi]) : 0.0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) gq[k] = (P.qe[P.qi] > 0.0) ? gql * (qq.q[k] - (double)q_gt[k]) / P.qe[P.qi] : 0.0;
+  for (int k = 0; k < 4; ++k) gq[k] = iqe * (qq.q[k] - (double)q_gt[k]);
   rot_to_quat_bwd(qq, gq, gR);
   // d|+-t - t_gt| / du3   (t = u3 / |u3|, |u3| = 1)
   const double sgn = (P.ti == 0) ? 1.0 : -1.0;
+  const double ite = (P.te[P.ti] > 0.0) ? gtl * rcp_nr<2>(P.te[P.ti]) : 0.0;
   double gt[3], gu3[3], tdot = 0.0;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    gt[k] = (P.te[P.ti] > 0.0) ? gtl * (sgn * P.t[k] - P.tg[k]) / P.te[P.ti] : 0.0;
+    gt[k] = ite * (sgn * P.t[k] - P.tg[k]);
     tdot += P.t[k] * gt[k];
   }
 #pragma unroll
@@ -192,11 +195,11 @@ __device__ inline void pose_backward(const Pose& P, const float* q_gt, double gq
       const double Z = A[3 * i + j] - A[3 * j + i];
       const double Y = Bm[3 * i + j] - Bm[3 * j + i];
       if (i < 2 && j < 2) {
-        Mid[3 * i + j] = Z / fmax(P.S[0] + P.S[1], 1e-300);
+        Mid[3 * i + j] = Z * rcp_nr<2>(fmax(P.S[0] + P.S[1], 1e-30));
       } else {
         double den = P.S[j] * P.S[j] - P.S[i] * P.S[i];
-        if (fabs(den) < 1e-300) den = (den < 0.0) ? -1e-300 : 1e-300;
-        Mid[3 * i + j] = (Z * P.S[j] + P.S[i] * Y) / den;
+        if (fabs(den) < 1e-30) den = (den < 0.0) ? -1e-30 : 1e-30;
+        Mid[3 * i + j] = (Z * P.S[j] + P.S[i] * Y) * rcp_nr<2>(den);
       }
     }
   double gEc[9];

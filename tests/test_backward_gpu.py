@@ -238,7 +238,7 @@ def test_layers_batched_launch_is_bit_identical(dfepe):
     m, w = sc["matches_xy_ori"], torch.softmax(sc["logits_layers"][:depth], dim=2).contiguous()
     buf = torch.empty(depth * B * 128, device=DEV)
     rc = L.dfepe_w8pt_bwd(m.data_ptr(), None, w.data_ptr(), B, N, depth, 1, 1241.0, 376.0, 0.5, buf.data_ptr(), buf.data_ptr(),
-                          buf.data_ptr(), None, None, None, buf.data_ptr(), buf.data_ptr(), None, None)
+                          buf.data_ptr(), None, None, None, None, buf.data_ptr(), buf.data_ptr(), None, None)
     assert rc == -3  # DFEPE_ERR_UNSUPPORTED: a point gradient would have to be summed over the sets
 
 
