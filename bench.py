@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the deepFEPE weighted-8-point hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {2,3,4,5}] [--scaling {weak,strong}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one resident batch of synthetic pairs (BASELINE.json config 3,
-the configuration the metric is quoted on):  depth=5 x [softmax -> weighted normalised 8-point fit + in-loop
-epipolar residual]  ->  F-loss on 100 virtual points  ->  E = K^T F K  ->  quaternion/translation pose loss,
-then backward to the per-layer logits.  Inputs already live in HBM when the timed region starts.
-Data parallel over N ranks: every rank owns B_per_gpu independent pairs (weak scaling; the pairs never
-interact), the only exchange is one all-reduce of the small loss vector per step (RCCL).
+Default (no flags) = BASELINE.json config 3, the configuration the metric is quoted on; one "step" = one pass of the hot
+path over one resident batch of synthetic pairs:  depth=5 x [softmax -> weighted normalised 8-point fit + in-loop epipolar
+residual]  ->  F-loss on 100 virtual points  ->  E = K^T F K  ->  quaternion/translation pose loss, then backward to the
+per-layer logits.  Inputs already live in HBM when the timed region starts.  The other BASELINE configs are selectable:
+    2  B=1024, N=100, single weighted-8-point fit (forward) + E-from-F
+    4  B=4096 per GPU (x8 = 32768), 40 % outliers, qt pose-loss objective (the reference's if_qt_loss mixing: the F-loss is
+       evaluated but dropped from the objective, Train_model_pipeline.py:580-587), forward + backward
+    5  B=4096 in total, N=1000, one fit + E-from-F + cheirality-checked pose; strong scaling (the batch is split over ranks)
+Data parallel over N ranks: every rank owns its shard of independent pairs (the pairs never interact), the only exchange
+is one all-reduce of the small loss vector per step (RCCL) where the step has a loss.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel w8pt_fwd vs the
-HBM roofline, measured with HIP events) and `cpu_baseline` (the CPU oracle in its reference-shaped per-sample
-loop on a bounded sample of the same workload).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel against the HBM roofline,
+measured with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle on a bounded sample of the same workload).
 """
 import argparse
 import importlib
@@ -32,20 +35,38 @@ if REPO not in sys.path:
 
 IMAGE_SIZE = [376, 1241, 3]
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+METRIC = "image-pairs/sec (F+E+pose+loss) at B=4096 N=100; median R/t angular err vs ref"
+
+CONFIGS = {
+    2: dict(B=1024, N=100, depth=1, outliers=0.2, scaling="weak", kind="fit",
+            what="BASELINE config 2: B={B}/GPU, N={N}: one weighted-8-point fit (forward, in-loop epipolar residual) + E-from-F"),
+    3: dict(B=4096, N=100, depth=5, outliers=0.2, scaling="weak", kind="train", balance_F=1.0,
+            what="BASELINE config 3: B={B}/GPU, N={N}, depth={L} weighted-8-point fits with fixed per-layer logits + in-loop epipolar "
+                 "residual + F-loss (100 virtual pts) + E-from-F + qt pose loss, forward+backward to the logits"),
+    4: dict(B=4096, N=100, depth=5, outliers=0.4, scaling="weak", kind="train", balance_F=0.0,
+            what="BASELINE config 4: B={B}/GPU (x8 GPUs = 32768), N={N}, 40 % outliers, depth={L}, qt pose-loss objective (F-loss evaluated, "
+                 "dropped from the objective like the reference's if_qt_loss), forward+backward to the logits"),
+    5: dict(B=4096, N=1000, depth=1, outliers=0.2, scaling="strong", kind="pose",
+            what="BASELINE config 5: B={B} pairs in total, N={N}: one weighted-8-point fit + E-from-F + cheirality-checked R,t (depth_thres 50)"),
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=4096, help="pairs per GPU")
-    ap.add_argument("--npoints", type=int, default=100)
-    ap.add_argument("--depth", type=int, default=5)
-    ap.add_argument("--outliers", type=float, default=0.2)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None, help="default: weak for configs 2-4, strong for config 5")
+    ap.add_argument("--batch", type=int, default=None, help="pairs per GPU (weak) or in total (strong); default: the config's")
+    ap.add_argument("--npoints", type=int, default=None)
+    ap.add_argument("--depth", type=int, default=None)
+    ap.add_argument("--outliers", type=float, default=None)
+    ap.add_argument("--blocks", type=int, default=10, help="informational: repeated 20-step blocks after the timed region (median, spread)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-model", action="store_true", help="skip the secondary whole-DeepFNet measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip every informational field (layers_batched, full_model, match_construction ...)")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="pairs in the CPU-baseline sample (~15 s of host work)")
     ap.add_argument("--force-dist", action="store_true",
                     help="single-process smoke test of the multi-GPU code path: a 1-rank RCCL group and the overlapped exchange")
@@ -55,6 +76,22 @@ def parse():
 def log(*a):
     if os.environ.get("DFEPE_BENCH_VERBOSE"):
         print(f"[bench {time.perf_counter():.2f}]", *a, file=sys.stderr, flush=True)
+
+
+def event_time_us(fn, reps=50, rounds=5, warm=5):
+    """median over `rounds` of (HIP events around `reps` back-to-back calls) / reps, on the current stream"""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    durs = []
+    for _ in range(rounds):
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        durs.append(e0.elapsed_time(e1) * 1e3 / reps)
+    return statistics.median(durs)
 
 
 def main():
@@ -84,23 +121,51 @@ def main():
         dist = dist_mod
 
     dfepe = importlib.import_module("pytorch-deepfepe_amd")
-    B, N, L = args.batch, args.npoints, args.depth
+    cfg = dict(CONFIGS[args.config])
+    scaling = args.scaling or cfg["scaling"]
+    B_cfg = args.batch if args.batch is not None else cfg["B"]
+    N = args.npoints if args.npoints is not None else cfg["N"]
+    L = args.depth if args.depth is not None else cfg["depth"]
+    outl = args.outliers if args.outliers is not None else cfg["outliers"]
+    kind = cfg["kind"]
+    if scaling == "strong":  # the batch is fixed; ranks take contiguous shards (dist.shard_range)
+        a, b = dfepe.dist.shard_range(B_cfg, rank, world)
+        B = b - a
+        B_total = B_cfg
+    else:
+        B, B_total = B_cfg, B_cfg * world
+    # every rank generates only its own pairs (seeded per rank): the shards are independent by construction
     scene = dfepe.pipeline.scene_to_device(
-        dfepe.synth.make_scene(B, N, seed=1000 + rank, outlier_ratio=args.outliers, noise_px=0.5, depth_layers=L), dev)
+        dfepe.synth.make_scene(B, N, seed=1000 + rank, outlier_ratio=outl, noise_px=0.5, depth_layers=L), dev)
     H, W = float(IMAGE_SIZE[0]), float(IMAGE_SIZE[1])
     hw_T = torch.tensor([[2.0 / W, 0.0, -1.0], [0.0, 2.0 / H, -1.0], [0.0, 0.0, 1.0]], device=dev)
-    logits = scene["logits_layers"][:L].clone().requires_grad_(True)
-    M_virt = scene["pts1_virt_ori"].shape[1]
+    logits = scene["logits_layers"][:L].clone().requires_grad_(kind == "train")
     state = {}  # tensors produced inside the captured graph are static: replays rewrite them in place
+    m = scene["matches_xy_ori"]
+    w0 = torch.softmax(scene["logits_layers"][0], dim=1).contiguous()
+    TK = (hw_T @ scene["Ks"]).contiguous()  # per-pair constant of E = (T K)^T F (T K), formed once
 
-    def step_body():
-        out = dfepe.pipeline.hot_path_fused(scene["matches_xy_ori"], logits, scene["Ks"], scene["pts1_virt_ori"],
-                                              scene["pts2_virt_ori"], scene["qs_cam"], scene["ts_cam"], scene["R_gt"],
-                                              IMAGE_SIZE, clamp_at=0.02, qt=True, hw_T=hw_T)
-        g, = torch.autograd.grad(out["loss"], logits)
-        state["grad_logits"] = g          # d loss / d logits: what the estimator's backward / an optimizer consumes
-        state["loss_vec"] = out["packed"]  # dist.pack_loss_sums layout (L+4 doubles): the ONLY data exchanged between ranks
-        return out
+    if kind == "train":
+        def step_body():
+            out = dfepe.pipeline.hot_path_fused(m, logits, scene["Ks"], scene["pts1_virt_ori"], scene["pts2_virt_ori"], scene["qs_cam"],
+                                                  scene["ts_cam"], scene["R_gt"], IMAGE_SIZE, clamp_at=0.02, qt=True, hw_T=hw_T,
+                                                  balance_F=cfg["balance_F"], grad_pairs=B_total)
+            g, = torch.autograd.grad(out["loss"], logits)
+            state["grad_logits"] = g           # d loss / d logits: what the estimator's backward / an optimizer consumes
+            state["loss_vec"] = out["packed"]  # dist.pack_loss_sums layout (L+4 doubles): the ONLY data exchanged between ranks
+            return out
+    elif kind == "fit":
+        def step_body():
+            F, res, epi, _, _ = dfepe.ops.w8pt_forward(m, None, w0, True, W, H, 0.5, True, False)
+            state["E"] = dfepe.ops.congruence(F, TK)
+            return {"F_layers": F.unsqueeze(0), "residual": res, "epi": epi}
+    else:  # "pose": fit + E-from-F + cheirality-checked decomposition (the (1,1,0) projection is implied by the decomposition)
+        def step_body():
+            F, res, epi, _, _ = dfepe.ops.w8pt_forward(m, None, w0, True, W, H, 0.5, True, False)
+            E = dfepe.ops.congruence(F, TK)
+            Rt, winner, counts = dfepe.ops.cheirality(E, scene["Ks"], m, 50.0)
+            state["Rt"], state["winner"] = Rt, winner
+            return {"F_layers": F.unsqueeze(0), "Rt": Rt, "winner": winner, "counts": counts}
 
     # eager warm-up (also sizes the caching allocator), then optional graph capture of the whole step
     side = torch.cuda.Stream()
@@ -116,15 +181,15 @@ def main():
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             last = step_body()
-
     log("graph captured" if graph is not None else "eager mode")
 
-    # the only exchange of the data-parallel path: (L+4) doubles over RCCL/xGMI per step
+    # the only exchange of the data-parallel path: (L+4) doubles over RCCL/xGMI per step (steps without a loss exchange nothing)
     # Default: the plain in-stream all-reduce.  DFEPE_BENCH_EXCHANGE=overlap switches to the double-buffered asynchronous
     # exchange (dist.OverlappedLossExchange); on a 1-rank RCCL group (--force-dist) its staging copy and event traffic cost
     # more (+29 us/step) than the collective it hides (+9 us/step), so it stays opt-in until measured on 8 GPUs.
+    has_loss = kind == "train"
     sync_exchange = os.environ.get("DFEPE_BENCH_EXCHANGE", "sync") != "overlap"
-    exchange = dfepe.dist.OverlappedLossExchange(L + 4, dev, depth=2) if (dist is not None and not sync_exchange) else None
+    exchange = dfepe.dist.OverlappedLossExchange(L + 4, dev, depth=2) if (dist is not None and has_loss and not sync_exchange) else None
 
     def run_step():
         if graph is not None:
@@ -133,7 +198,7 @@ def main():
             step_body()
         if exchange is not None:
             exchange.exchange(state["loss_vec"])
-        elif dist is not None:
+        elif dist is not None and has_loss:
             dist.all_reduce(state["loss_vec"])
 
     def barrier():
@@ -157,142 +222,199 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed * 1e3 / args.steps
     log("timed region done", ms_per_step, "ms/step")
-    value = world * B * args.steps / elapsed
+    value = B_total * args.steps / elapsed
 
-    # ---- accuracy bookkeeping (metric second half: median R/t angular error) --------------------------
-    R_deg_med = float(last["R_deg"][-1].median().item())
-    t_deg_med = float(last["t_deg"][-1].median().item())
+    # informational: spread of repeated short blocks (the timed region above is the contract number)
+    block_stats = None
+    if args.blocks > 0:
+        bl = []
+        for _ in range(args.blocks):
+            barrier()
+            tb = time.perf_counter()
+            for _ in range(20):
+                run_step()
+            barrier()
+            bl.append((time.perf_counter() - tb) * 1e3 / 20)
+        block_stats = {"blocks": args.blocks, "steps_per_block": 20, "median_ms_per_step": round(statistics.median(bl), 4),
+                       "min": round(min(bl), 4), "max": round(max(bl), 4)}
 
     result = None
     if rank == 0:
-        # ---- roofline of the dominant kernel (w8pt_fwd), HIP events on the launch stream -----------------
-        w = torch.softmax(scene["logits_layers"][0], dim=1).contiguous()
-        m = scene["matches_xy_ori"]
-        for _ in range(5):
-            dfepe.ops.w8pt_forward(m, None, w, True, W, H, 0.5, True, True)
-        reps = 50
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        durs = []
-        for _ in range(5):
-            e0.record()
-            for _ in range(reps):
-                dfepe.ops.w8pt_forward(m, None, w, True, W, H, 0.5, True, True)
-            e1.record()
-            torch.cuda.synchronize()
-            durs.append(e0.elapsed_time(e1) * 1e-3 / reps)
-        kdur = statistics.median(durs)
+        extras = not args.no_extras
+        # ---- roofline of the dominant kernel (the weighted 8-point fit), HIP events on the launch stream ---------------
+        fit_call = lambda: dfepe.ops.w8pt_forward(m, None, w0, True, W, H, 0.5, True, kind == "train")
+        kdur_us = event_time_us(fit_call)
         alg_bytes = B * (28 * N + 36)  # read 16N matches + 4N weights; write 36 F + 4N residual + 4N epi  
-        achieved = alg_bytes / kdur / 1e9
-        traffic = None
-        issue_bound = None
+        achieved = alg_bytes / (kdur_us * 1e-6) / 1e9
+        row_kernel = N <= dfepe._lib.W8PT16_MAX_N
+        kname = "w8pt16_fwd_kernel<raw> (one 16-lane row per pair)" if row_kernel else "w8pt_fwd_kernel<raw> (wavefront / workgroup per pair)"
+        traffic = issue = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get(f"w8pt_fwd_B{B}_N{N}")
-                valu = tj.get(f"w8pt_fwd_valu_insts_per_wave_B{B}_N{N}")
-                if valu:
-                    # the bound that actually limits this kernel: one wavefront per pair, 4 cycles per wave64 VALU instruction,
-                    # ceil(B / 1024 SIMDs) wavefronts per SIMD; instruction count from the committed PMC pass
-                    wps = -(-B // 1024)
+                traffic = tj.get(f"fit_fwd_B{B}_N{N}")
+                valu = tj.get(f"fit_fwd_valu_insts_per_wave_B{B}_N{N}")
+                if valu and row_kernel:
+                    # what actually limits this kernel: four pairs per wavefront, ceil(B / 4 / 1024 SIMDs) wavefronts per SIMD,
+                    # 4 issue cycles per wave64 VALU instruction; instruction count from the committed PMC pass
+                    wps = -(-B // 4096)
                     cyc = wps * valu * 4.0
-                    clk = tj.get("w8pt_fwd_sustained_clock_ghz")
-                    issue_bound = {"valu_insts_per_wave": valu, "waves_per_simd": wps, "cycles": round(cyc),
-                                   "floor_us_at_2.4GHz": round(cyc / 2.4e3, 2), "frac_at_2.4GHz": round(cyc / 2.4e3 / (kdur * 1e6), 3),
-                                   "sustained_clock_ghz": clk,
-                                   "frac_at_sustained_clock": (round(cyc / (clk * 1e3) / (kdur * 1e6), 3) if clk else None),
-                                   "source": "profiles/traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, SQ_BUSY_CU_CYCLES)"}
+                    clk = tj.get("fit_fwd_sustained_clock_ghz")
+                    issue = {"valu_insts_per_wave": valu, "waves_per_simd": wps, "cycles": round(cyc),
+                             "floor_us_at_2.4GHz": round(cyc / 2.4e3, 2), "frac_of_kernel_time_at_2.4GHz": round(cyc / 2.4e3 / kdur_us, 3),
+                             "sustained_clock_ghz": clk, "source": "profiles/traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, SQ_BUSY_CU_CYCLES)",
+                             "note": "fraction of this kernel's own instruction stream, NOT a roofline"}
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "w8pt_fwd_kernel<raw>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                    "avg_kernel_us": round(kdur * 1e6, 2), "algorithmic_bytes_per_launch": alg_bytes,
-                    "launches_per_step": L, "vector_issue_bound": issue_bound,
-                    "traffic_note": "profiles/traffic.json: PMC 2*FETCH_SIZE+WRITE_SIZE of this probe launch, which (like the training "
-                                    "step) also writes the 512-B save record per pair (2.1 MB) on top of the 28N+36 algorithmic bytes",
-                    "method": f"HIP events around {reps} back-to-back launches, median of 5"}
+                    "avg_kernel_us": round(kdur_us, 2), "algorithmic_bytes_per_launch": alg_bytes,
+                    "launches_per_step": L, "vector_issue": issue,
+                    "traffic_note": "profiles/traffic.json: PMC FETCH_SIZE/WRITE_SIZE of this probe launch, which in the training configs "
+                                    "also writes the 512-B save record per pair on top of the 28N+36 algorithmic bytes",
+                    "method": "HIP events around 50 back-to-back launches on the launch stream, median of 5"}
+        log("roofline probe done", kdur_us)
 
-        log("roofline probe done", kdur)
-        # ---- informational: the same step with all L fits of a layer stack in ONE grid (n_weight_sets = L).  Legal for
-        # this solver-only workload because the per-layer logits are inputs; the recurrent DeepFNet cannot do it, so
-        # it is never `value`.
-        layers_batched = None
-        if world == 1 and graph is not None:
-            def body_b():
-                o = dfepe.pipeline.hot_path_fused(scene["matches_xy_ori"], logits, scene["Ks"], scene["pts1_virt_ori"],
-                                                  scene["pts2_virt_ori"], scene["qs_cam"], scene["ts_cam"], scene["R_gt"],
-                                                  IMAGE_SIZE, clamp_at=0.02, qt=True, hw_T=hw_T, layers_batched=True)
-                return torch.autograd.grad(o["loss"], logits)[0]
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                gb = body_b()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            same = bool(torch.equal(gb, state["grad_logits"]))
-            gr_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr_b):
-                gb = body_b()
-            for _ in range(args.warmup):
-                gr_b.replay()
-            torch.cuda.synchronize()
-            tb = time.perf_counter()
-            for _ in range(args.steps):
-                gr_b.replay()
-            torch.cuda.synchronize()
-            tb = time.perf_counter() - tb
-            layers_batched = {"ms_per_step": round(tb * 1e3 / args.steps, 4), "pairs_per_s": round(B * args.steps / tb, 1),
-                              "grad_bit_identical_to_value_run": same,
-                              "note": "all L layers' fits in one launch; only legal with fixed logits, not `value`"}
-            log("layers-batched variant done", layers_batched)
-        # ---- CPU baseline: the oracle's reference-shaped loop on a bounded sample of the same workload -----
+        acc = {}
+        if kind == "train":
+            acc = {"median_R_deg": round(float(last["R_deg"][-1].median().item()), 5),
+                   "median_t_deg": round(float(last["t_deg"][-1].median().item()), 5)}
+        elif kind == "pose":
+            # geometric truth of the synthetic scene: camera motion = inverse of the scene pose
+            Rt = state["Rt"].reshape(B, 3, 4)
+            Rg = scene["R_gt"]
+            tg = torch.nn.functional.normalize(scene["ts_cam"].reshape(B, 3), dim=1)
+            ok = state["winner"] >= 0
+            cosr = ((Rt[:, :, :3] @ Rg.transpose(1, 2)).diagonal(dim1=1, dim2=2).sum(1) - 1.0) / 2.0
+            Rdeg = torch.rad2deg(torch.acos(cosr.clamp(-1, 1)))
+            te = torch.nn.functional.normalize(Rt[:, :, 3], dim=1)
+            tdeg = torch.rad2deg(torch.acos((te * tg).sum(1).clamp(-1, 1)))
+            acc = {"median_R_deg_vs_scene_truth": round(float(Rdeg[ok].median().item()), 5),
+                   "median_t_deg_vs_scene_truth": round(float(tdeg[ok].median().item()), 5), "pairs_with_a_valid_pose": int(ok.sum().item())}
+
+        # ---- informational (config 3 only): variants and neighbours of the step that are never `value` -----------------
+        layers_batched = recurrent_bwd = full_model = match_row = None
+        if extras and kind == "train" and world == 1:
+            # the backward a recurrent DeepFNet actually runs: the next estimator layer consumes residual and epi_res, so
+            # w8pt_bwd also gets g_residual and g_epi (pass A over the correspondences); the fixed-logits step has g_F only
+            Fo, res, epi, save, wout = dfepe.ops.w8pt_forward(m, None, scene["logits_layers"][0].contiguous(), True, W, H, 0.5, True, True, logits=True)
+            gF, gR, gE = torch.randn_like(Fo), torch.randn_like(res), torch.randn_like(epi)
+            gw = torch.empty_like(wout)
+            t_f = event_time_us(lambda: dfepe.ops.w8pt_backward(m, None, wout, True, W, H, 0.5, save, Fo, gF, None, None, logits=True, out=gw))
+            t_a = event_time_us(lambda: dfepe.ops.w8pt_backward(m, None, wout, True, W, H, 0.5, save, Fo, gF, gR, gE, logits=True, out=gw))
+            recurrent_bwd = {"w8pt_bwd_us_gF_only": round(t_f, 2), "w8pt_bwd_us_gF_gResidual_gEpi": round(t_a, 2),
+                             "note": "eager launches, HIP events; the timed step's logits are inputs, so its backward has g_F only; "
+                                     "a recurrent DeepFNet adds (second - first) per layer"}
+            if graph is not None:
+                # all L fits of a layer stack in ONE grid (n_weight_sets = L).  Legal for this solver-only workload because
+                # the per-layer logits are inputs; the recurrent DeepFNet cannot do it.
+                def body_b():
+                    o = dfepe.pipeline.hot_path_fused(m, logits, scene["Ks"], scene["pts1_virt_ori"], scene["pts2_virt_ori"], scene["qs_cam"],
+                                                      scene["ts_cam"], scene["R_gt"], IMAGE_SIZE, clamp_at=0.02, qt=True, hw_T=hw_T,
+                                                      balance_F=cfg["balance_F"], layers_batched=True)
+                    return torch.autograd.grad(o["loss"], logits)[0]
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    gb = body_b()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                same = bool(torch.equal(gb, state["grad_logits"]))
+                gr_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr_b):
+                    gb = body_b()
+                for _ in range(args.warmup):
+                    gr_b.replay()
+                torch.cuda.synchronize()
+                tb = time.perf_counter()
+                for _ in range(args.steps):
+                    gr_b.replay()
+                torch.cuda.synchronize()
+                tb = time.perf_counter() - tb
+                layers_batched = {"ms_per_step": round(tb * 1e3 / args.steps, 4), "pairs_per_s": round(B * args.steps / tb, 1),
+                                  "grad_bit_identical_to_value_run": same,
+                                  "note": "all L layers' fits in one launch; only legal with fixed logits, not `value`"}
+            log("variants done")
+
+        # ---- CPU baseline: the oracle on a bounded sample of the same workload, on this box's host cores -----------------
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # contract: CPU baseline on rank 0 at N=1 only
-            oracle = importlib.import_module("oracle.deepf_oracle")
-            Bc = min(args.cpu_sample, B)
-            cpu_scene = {k: (v[:Bc] if k != "logits_layers" else v[:, :Bc]).cpu() for k, v in scene.items()}
-            log("cpu baseline start, cpu_count", os.cpu_count(), "torch threads", torch.get_num_threads())
-            warm = {k: (v[:8] if k != "logits_layers" else v[:, :8]) for k, v in cpu_scene.items()}
-            oracle.hot_path_step(warm, IMAGE_SIZE, L, 0.02, qt=True, mode="loop")
-            c0 = time.perf_counter()
-            ref = oracle.hot_path_step(cpu_scene, IMAGE_SIZE, L, 0.02, qt=True, mode="loop")
-            cdt = time.perf_counter() - c0
-            cpu = {"value": round(Bc / cdt, 2), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-                   "sample": f"{Bc} pairs of the same workload (N={N}, depth={L}, fwd+bwd, qt loss), one pass, {cdt:.1f} s; "
-                             "oracle/deepf_oracle.py hot_path_step(mode='loop') = per-sample torch SVD + per-sample pose loop like the reference"}
             import numpy as np
 
-            # F parity on the sample: vs the fp32 reference-shaped run above and vs the same oracle in fp64 (batched)
+            oracle = importlib.import_module("oracle.deepf_oracle")
+
             def _ferr(Fa, Fb):
                 a = Fa.reshape(Fa.shape[0], -1).double(); b = Fb.reshape(Fb.shape[0], -1).double()
                 a = a / a.norm(dim=1, keepdim=True); b = b / b.norm(dim=1, keepdim=True)
                 sgn = torch.sign((a * b).sum(1, keepdim=True))
                 return (a * sgn - b).norm(dim=1)
-            ours_F = last["F_layers"][-1][:Bc].cpu()
-            e32 = _ferr(ours_F, ref["outs"]["out_layers"][-1].detach())
-            ref64 = oracle.hot_path_step({k: v.double() for k, v in cpu_scene.items()}, IMAGE_SIZE, L, 0.02, qt=False, mode="batched", backward=False)
-            e64 = _ferr(ours_F, ref64["outs"]["out_layers"][-1])
-            ours_R = last["R_deg"][-1][:Bc].cpu().numpy()
-            ours_t = last["t_deg"][-1][:Bc].cpu().numpy()
-            acc = {"median_R_deg": round(R_deg_med, 5), "median_t_deg": round(t_deg_med, 5),
-                   "cpu_ref_median_R_deg_sample": round(float(np.median(ref["pose"]["R_deg"][-1])), 5),
-                   "cpu_ref_median_t_deg_sample": round(float(np.median(ref["pose"]["t_deg"][-1])), 5),
-                   "gpu_median_R_deg_sample": round(float(np.median(ours_R)), 5),
-                   "gpu_median_t_deg_sample": round(float(np.median(ours_t)), 5),
-                   "F_fro_err_vs_fp64_oracle_sample": {"max": float(e64.max()), "median": float(e64.median())},
-                   "F_fro_err_vs_fp32_reference_shaped_sample": {"max": float(e32.max()), "median": float(e32.median())}}
-        else:
-            acc = {"median_R_deg": round(R_deg_med, 5), "median_t_deg": round(t_deg_med, 5)}
+
+            threads = torch.get_num_threads()
+            if kind == "train":
+                Bc = min(args.cpu_sample, B)
+                cpu_scene = {k: (v[:Bc] if k != "logits_layers" else v[:, :Bc]).cpu() for k, v in scene.items()}
+                warm = {k: (v[:8] if k != "logits_layers" else v[:, :8]) for k, v in cpu_scene.items()}
+                kw = dict(balance_F=cfg["balance_F"])
+                oracle.hot_path_step(warm, IMAGE_SIZE, L, 0.02, qt=True, mode="loop", **kw)
+                loop_t = []
+                for _ in range(2):  # two passes: the spread between boxes was 40 ... 61 pairs/s in round 1
+                    c0 = time.perf_counter()
+                    ref = oracle.hot_path_step(cpu_scene, IMAGE_SIZE, L, 0.02, qt=True, mode="loop", **kw)
+                    loop_t.append(time.perf_counter() - c0)
+                # the batched restatement (one batched LAPACK call per fit; the pose loop stays per sample like the reference's)
+                Bb = min(4 * Bc, B)
+                cpu_b = {k: (v[:Bb] if k != "logits_layers" else v[:, :Bb]).cpu() for k, v in scene.items()}
+                c0 = time.perf_counter()
+                oracle.hot_path_step(cpu_b, IMAGE_SIZE, L, 0.02, qt=True, mode="batched", **kw)
+                bt = time.perf_counter() - c0
+                cpu = {"value": round(Bc / min(loop_t), 2), "unit": "pairs/s", "cores": threads, "kind": "port",
+                       "sample": f"{Bc} pairs of the same workload (N={N}, depth={L}, fwd+bwd), best of 2 passes ({loop_t[0]:.1f} s, {loop_t[1]:.1f} s); "
+                                 "oracle/deepf_oracle.py hot_path_step(mode='loop') = per-sample torch SVD + per-sample pose loop like the reference",
+                       "batched_restatement": {"value": round(Bb / bt, 2), "unit": "pairs/s", "sample": f"{Bb} pairs, one pass, {bt:.1f} s; "
+                                               "mode='batched': batched LAPACK SVDs, per-sample pose loop"}}
+                ours_F = last["F_layers"][-1][:Bc].cpu()
+                e32 = _ferr(ours_F, ref["outs"]["out_layers"][-1].detach())
+                ref64 = oracle.hot_path_step({k: v.double() for k, v in cpu_scene.items()}, IMAGE_SIZE, L, 0.02, qt=False, mode="batched", backward=False)
+                e64 = _ferr(ours_F, ref64["outs"]["out_layers"][-1])
+                acc.update({"cpu_ref_median_R_deg_sample": round(float(np.median(ref["pose"]["R_deg"][-1])), 5),
+                            "cpu_ref_median_t_deg_sample": round(float(np.median(ref["pose"]["t_deg"][-1])), 5),
+                            "gpu_median_R_deg_sample": round(float(np.median(last["R_deg"][-1][:Bc].cpu().numpy())), 5),
+                            "gpu_median_t_deg_sample": round(float(np.median(last["t_deg"][-1][:Bc].cpu().numpy())), 5),
+                            "F_fro_err_vs_fp64_oracle_sample": {"max": float(e64.max()), "median": float(e64.median())},
+                            "F_fro_err_vs_fp32_reference_shaped_sample": {"max": float(e32.max()), "median": float(e32.median())}})
+            else:
+                Bc = min(args.cpu_sample if kind == "fit" else 48, B)
+                mc, wc = m[:Bc].cpu(), w0[:Bc].cpu()
+                Kc = scene["Ks"][:Bc].cpu()
+
+                def cpu_pass():
+                    p1, p2, T = oracle.normalize_hw(mc, IMAGE_SIZE)
+                    out, _, _ = oracle.fit_forward(p1, p2, wc.unsqueeze(1), mode="loop")
+                    E = Kc.transpose(1, 2) @ T.transpose(1, 2) @ out @ T @ Kc
+                    if kind == "pose":
+                        for b_ in range(Bc):
+                            oracle.cheirality_select(E[b_], Kc[b_].numpy(), mc[b_, :, :2].numpy(), mc[b_, :, 2:].numpy(), 50.0)
+                    return out
+                cpu_pass()
+                c0 = time.perf_counter()
+                outc = cpu_pass()
+                cdt = time.perf_counter() - c0
+                cpu = {"value": round(Bc / cdt, 2), "unit": "pairs/s", "cores": threads, "kind": "port",
+                       "sample": f"{Bc} pairs of the same workload (N={N}), one pass, {cdt:.1f} s; oracle fit_forward(mode='loop')"
+                                 + (" + cheirality_select per pair (DLT stand-in for cv2.triangulatePoints)" if kind == "pose" else "")}
+                e32 = _ferr(last["F_layers"][-1][:Bc].cpu(), outc)
+                acc["F_fro_err_vs_fp32_reference_shaped_sample"] = {"max": float(e32.max()), "median": float(e32.median())}
+            log("cpu baseline done", cpu)
 
         # ---- secondary, informational: the whole DeepFNet step (estimator evaluated as channel-major GEMMs + fused
         #      InstanceNorm/LeakyReLU, solver, F-loss, qt loss, backward to the estimator parameters) --------------------
-        full_model = None
-        if not args.no_full_model and world == 1:
+        if extras and not args.no_full_model and world == 1 and kind == "train" and args.config == 3:
             try:
                 net = dfepe.compat.DeepFNet.DeepFNet(depth=L, image_size=IMAGE_SIZE, if_quality=False).to(dev)
                 dfepe.synth.fill_params_deterministic(net, 1)
                 tgu = dfepe.compat.train_good_utils
                 lp = {"depth": L, "clamp_at": 0.02, "if_tri_depth": False, "if_sample_loss": False, "topK": 8, "matches_good_unique_nums": None}
-                batch = {"matches_xy_ori": scene["matches_xy_ori"], "matches_good_unique_nums": None, "t_scene_scale": None}
+                batch = {"matches_xy_ori": m, "matches_good_unique_nums": None, "t_scene_scale": None}
 
                 def full_step():
                     net.zero_grad(set_to_none=True)
@@ -314,29 +436,21 @@ def main():
                 fdt = (time.perf_counter() - f0) / nfull
                 full_model = {"value": round(B / fdt, 1), "unit": "pairs/s", "ms_per_step": round(fdt * 1e3, 2),
                               "what": "compat.DeepFNet (seeded random weights) forward + F-loss + qt loss + backward to the estimator parameters; "
-                                      "estimator = torch.mm GEMMs (fp32) + fused HIP InstanceNorm/LeakyReLU; not part of `value`"}
+                                      "not part of `value` (the estimator is SURVEY row a18/f-1, outside the solver hot path)"}
                 del net
             except Exception as e:  # never let the secondary measurement break the contract line
                 full_model = {"error": repr(e)[:200]}
 
         # ---- informational: the upstream match-construction row, fp32-MFMA two-way descriptor matching ----
-        match_row = None
-        if world == 1:
+        if extras and world == 1 and args.config == 3:
             try:
                 gm = torch.Generator().manual_seed(0)
                 Bm_, Nm_, Dm_ = 64, 1024, 256
                 da = torch.nn.functional.normalize(torch.randn(Bm_, Nm_, Dm_, generator=gm), dim=2)
                 db = torch.nn.functional.normalize(da[:, torch.randperm(Nm_, generator=gm)] + 0.05 * torch.randn(Bm_, Nm_, Dm_, generator=gm), dim=2)
                 da, db = da.to(dev), db.to(dev)
-                for _ in range(3):
-                    dfepe.ops.nn_match_two_way(da, db, 0.7)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(20):
-                    cntm = dfepe.ops.nn_match_two_way(da, db, 0.7)[3]
-                e1.record()
-                torch.cuda.synchronize()
-                tm_ = e0.elapsed_time(e1) * 1e-3 / 20
+                tm_ = event_time_us(lambda: dfepe.ops.nn_match_two_way(da, db, 0.7), reps=20, rounds=3, warm=3) * 1e-6
+                cntm = dfepe.ops.nn_match_two_way(da, db, 0.7)[3]
                 fl = 2.0 * Bm_ * Nm_ * Nm_ * Dm_
                 match_row = {"workload": f"two-way nearest-neighbour matching of {Bm_} pairs x {Nm_} x {Nm_} descriptors (D={Dm_}, fp32)",
                              "pairs_per_s": round(Bm_ / tm_, 1), "ms": round(tm_ * 1e3, 4),
@@ -346,8 +460,9 @@ def main():
             except Exception as exc:  # informational only
                 match_row = {"error": repr(exc)}
             log("match-construction row done", match_row)
+
         result = {
-            "metric": "image-pairs/sec (F+E+pose+loss) at B=4096 N=100; median R/t angular err vs ref",
+            "metric": METRIC if args.config == 3 else f"image-pairs/sec, BASELINE config {args.config}",
             "value": round(value, 1),
             "unit": "pairs/s",
             "n_gpus": world,
@@ -355,17 +470,20 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
-            "dtype": "f64",
+            # what the path computes in: the solver (moments, tridiagonal eigen-solve, rank-2 step, pose decomposition) is fp64;
+            # tensors cross the boundary as fp32 and the per-point epipolar / F-loss terms are fp32 like the reference's
+            "dtype": "f64 solver arithmetic, f32 I/O and epipolar terms",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE config 3: B={B}/GPU, N={N}, depth={L} weighted-8-point fits with fixed per-layer logits "
-                                   "+ in-loop epipolar residual + F-loss (100 virtual pts) + E-from-F + qt pose loss, forward+backward to the logits",
-                       "B_per_gpu": B, "N": N, "depth": L, "outlier_ratio": args.outliers,
-                       "parallelism": f"dp{world}", "hipgraph": graph is not None},
+            "config": {"workload": cfg["what"].format(B=B_cfg, N=N, L=L), "baseline_config": args.config, "B_per_gpu": B, "B_total": B_total,
+                       "N": N, "depth": L, "outlier_ratio": outl, "parallelism": f"dp{world}", "hipgraph": graph is not None,
+                       "launches_per_step": (2 * L + 2) if kind == "train" else (2 if kind == "fit" else 3)},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "accuracy": acc,
+            "block_stats": block_stats,
+            "recurrent_backward": recurrent_bwd,
             "full_model": full_model,
             "layers_batched": layers_batched,
             "match_construction": match_row,

@@ -223,6 +223,35 @@ def test_cheirality_recovers_generating_pose(dfepe, oracle, N):
     assert Rt_cam.shape == (3, 4) and err[0] < 0.05 and err[1] < 0.5
 
 
+@pytest.mark.parametrize("case,pad_to", [("mixed", 0), ("dense1000", 0), ("dense1000", 2100), ("garbage", 0)])
+def test_cheirality_matches_the_references_own_logic(dfepe, golden, case, pad_to):
+    """dfepe_cheirality against tests/golden/cheirality.npz -- the reference's own _E_to_M_train (utils_F.py:679-763:
+    candidate order, 0 < Z < depth_thres in both cameras, first arg-max, _inv_Rt of the winner) run with a DLT stand-in for
+    cv2.triangulatePoints.  Winner and Rt_cam must agree; a per-candidate count may differ by the odd correspondence whose
+    depth sits on a bound (the 4x4 eigen-solver here is not numpy's SVD; OpenCV's own triangulation is unpinned anyway).
+    pad_to > 2048 embeds the fixture pairs in a large batch: that selects the one-wavefront-per-pair variant at N = 1000."""
+    g = golden("cheirality")
+    E, K, m = (torch.from_numpy(g[f"{case}_{k}"]).float() for k in ("E", "K", "matches"))
+    thr = float(g[f"{case}_depth_thres"])
+    Bf, N = m.shape[0], m.shape[1]
+    if pad_to:
+        sc = dfepe.synth.make_scene(pad_to - Bf, N, seed=9, outlier_ratio=0.2)
+        Ef = sc["E_gt"] / sc["E_gt"].flatten(1).norm(dim=1)[:, None, None]
+        E, K, m = torch.cat((E, Ef.float())), torch.cat((K, sc["Ks"].float())), torch.cat((m, sc["matches_xy_ori"].float()))
+    Rt, win, cnt = dfepe.ops.cheirality(E.to(DEV), K.to(DEV), m.to(DEV), thr)
+    Rt, win, cnt = Rt.cpu().numpy()[:Bf], win.cpu().numpy()[:Bf], cnt.cpu().numpy()[:Bf]
+    gc, gw, gR = g[f"{case}_counts"], g[f"{case}_winner"], g[f"{case}_Rt_cam"]
+    slack = max(1, N // 250)
+    assert np.abs(cnt - gc).max() <= slack, (cnt, gc)
+    for b in range(Bf):
+        top2 = np.sort(gc[b])[-2:]
+        if top2[1] - top2[0] > 2 * slack or gw[b] < 0:  # a decided vote: the winner is not up to a boundary point
+            assert win[b] == gw[b], (b, cnt[b], gc[b])
+        if win[b] == gw[b] and gw[b] >= 0:
+            np.testing.assert_allclose(Rt[b], gR[b], atol=2e-5)
+    assert (win == gw).mean() >= 0.9
+
+
 def test_validation_pose_path(dfepe, oracle):
     """goodCorr_eval_nondecompose / val_rt_batch (the cv2.recoverPose path of the reference, unpinned): recover the
     generating pose from the ground-truth E and from an E estimated by the solver on noisy matches."""

@@ -169,3 +169,22 @@ def test_metrics_against_geometric_truth(oracle):
         assert counts[win] == 64
         assert oracle.rotation_angle_deg(Rt[:, :3].numpy(), cam[:3, :3]) < 1e-4
         assert oracle.vector_angle_deg(Rt[:, 3].numpy(), cam[:3, 3]) < 5e-3  # acos resolution near 0
+
+
+@pytest.mark.parametrize("case", ["mixed", "dense1000", "garbage"])
+def test_cheirality_select_matches_the_references_own_logic(oracle, golden, case):
+    """tests/golden/cheirality.npz is the reference's own _E_to_M_train (utils_F.py:679-763) run with a DLT stand-in for
+    cv2.triangulatePoints: candidate order, 0 < Z < depth_thres in both cameras, first arg-max and _inv_Rt of the winner are
+    the reference's code, so counts per candidate, winner and Rt_cam pin the oracle's selection logic (the per-point
+    triangulation itself stays "stubbed-cv2")."""
+    g = golden("cheirality")
+    E, K, m = (torch.from_numpy(g[f"{case}_{k}"]) for k in ("E", "K", "matches"))
+    thr = float(g[f"{case}_depth_thres"])
+    for b in range(E.shape[0]):
+        Rt, win, counts = oracle.cheirality_select(E[b].double(), K[b].double().numpy(), m[b, :, :2].double().numpy(), m[b, :, 2:].double().numpy(), thr)
+        assert list(counts) == g[f"{case}_counts"][b].tolist()
+        if g[f"{case}_winner"][b] < 0:
+            assert Rt is None
+        else:
+            assert win == int(g[f"{case}_winner"][b])
+            np.testing.assert_allclose(Rt.numpy(), g[f"{case}_Rt_cam"][b], atol=1e-12)
