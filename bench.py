@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-model", action="store_true", help="skip the secondary whole-DeepFNet measurement")
     ap.add_argument("--no-extras", action="store_true", help="skip every informational field (layers_batched, full_model, match_construction ...)")
-    ap.add_argument("--cpu-sample", type=int, default=1024, help="pairs in the CPU-baseline sample (~15 s of host work)")
+    ap.add_argument("--cpu-sample", type=int, default=512, help="pairs in the CPU-baseline sample (~10 s of host work per pass)")
     ap.add_argument("--force-dist", action="store_true",
                     help="single-process smoke test of the multi-GPU code path: a 1-rank RCCL group and the overlapped exchange")
     return ap.parse_args()
@@ -78,16 +78,36 @@ def log(*a):
         print(f"[bench {time.perf_counter():.2f}]", *a, file=sys.stderr, flush=True)
 
 
-def event_time_us(fn, reps=50, rounds=5, warm=5):
-    """median over `rounds` of (HIP events around `reps` back-to-back calls) / reps, on the current stream"""
+def event_time_us(fn, reps=50, rounds=5, warm=5, graph=True):
+    """Average GPU time of one call of `fn`: `reps` back-to-back calls captured in a hipGraph (so that the host launch path --
+    ctypes, tensor allocation -- cannot be the bottleneck of a 10 us kernel), replayed between two HIP events on the launch
+    stream; median over `rounds` replays.  Includes the ~1-2 us dispatch gap between dependent launches."""
     for _ in range(warm):
         fn()
+    torch.cuda.synchronize()
+    g = None
+    if graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     durs = []
     for _ in range(rounds):
         e0.record()
-        for _ in range(reps):
-            fn()
+        if g is not None:
+            g.replay()
+        else:
+            for _ in range(reps):
+                fn()
         e1.record()
         torch.cuda.synchronize()
         durs.append(e0.elapsed_time(e1) * 1e3 / reps)
@@ -273,7 +293,7 @@ def main():
                     "launches_per_step": L, "vector_issue": issue,
                     "traffic_note": "profiles/traffic.json: PMC FETCH_SIZE/WRITE_SIZE of this probe launch, which in the training configs "
                                     "also writes the 512-B save record per pair on top of the 28N+36 algorithmic bytes",
-                    "method": "HIP events around 50 back-to-back launches on the launch stream, median of 5"}
+                    "method": "HIP events around a hipGraph replay of 50 back-to-back launches on the launch stream, median of 5 replays"}
         log("roofline probe done", kdur_us)
 
         acc = {}
@@ -362,7 +382,7 @@ def main():
                     ref = oracle.hot_path_step(cpu_scene, IMAGE_SIZE, L, 0.02, qt=True, mode="loop", **kw)
                     loop_t.append(time.perf_counter() - c0)
                 # the batched restatement (one batched LAPACK call per fit; the pose loop stays per sample like the reference's)
-                Bb = min(4 * Bc, B)
+                Bb = Bc
                 cpu_b = {k: (v[:Bb] if k != "logits_layers" else v[:, :Bb]).cpu() for k, v in scene.items()}
                 c0 = time.perf_counter()
                 oracle.hot_path_step(cpu_b, IMAGE_SIZE, L, 0.02, qt=True, mode="batched", **kw)
@@ -449,7 +469,7 @@ def main():
                 da = torch.nn.functional.normalize(torch.randn(Bm_, Nm_, Dm_, generator=gm), dim=2)
                 db = torch.nn.functional.normalize(da[:, torch.randperm(Nm_, generator=gm)] + 0.05 * torch.randn(Bm_, Nm_, Dm_, generator=gm), dim=2)
                 da, db = da.to(dev), db.to(dev)
-                tm_ = event_time_us(lambda: dfepe.ops.nn_match_two_way(da, db, 0.7), reps=20, rounds=3, warm=3) * 1e-6
+                tm_ = event_time_us(lambda: dfepe.ops.nn_match_two_way(da, db, 0.7), reps=20, rounds=3, warm=3, graph=False) * 1e-6
                 cntm = dfepe.ops.nn_match_two_way(da, db, 0.7)[3]
                 fl = 2.0 * Bm_ * Nm_ * Nm_ * Dm_
                 match_row = {"workload": f"two-way nearest-neighbour matching of {Bm_} pairs x {Nm_} x {Nm_} descriptors (D={Dm_}, fp32)",
