@@ -208,10 +208,12 @@ int dfepe_cheirality(const float *E, const float *K, const float *matches, int B
 
 /*
  * Epipolar metrics of dsac_tools.utils_F (utils_F.py:291-361) on homogeneous-or-not 2-D points.
- *   kind: 0 = _sym_epi_dist (squared, eps 1e-10 as in the batched branch), 1 = _sampson_dist,
- *         2 = _epi_distance (writes 3 planes: mean, d1, d2)
- *   F [B,9]; X, Y [B,N,2]; out [B,N] (kind 0,1) or [3,B,N] (kind 2); clamp_at <= 0 means no clamp (kind 0 only)
+ *   kind: 0 = _sym_epi_dist (squared; `eps` is added to the two squared line norms: 1e-10 in the reference's batched branch,
+ *         0 in its 2-D branch), 1 = _sampson_dist, 2 = _epi_distance (writes 3 planes: mean, d1, d2);
+ *         | DFEPE_EPI_HOMOGENEOUS: X, Y are [B,N,3] homogeneous points used as they are (if_homo=True), else [B,N,2]
+ *   F [B,9]; out [B,N] (kind 0,1) or [3,B,N] (kind 2); clamp_at < 0 means no clamp (clamp_at=None; kind 0 only)
  */
+#define DFEPE_EPI_HOMOGENEOUS 8
 int dfepe_epi_metrics(int kind, const float *F, const float *X, const float *Y, int B, int N, float clamp_at,
                       float eps, float *out, void *stream);
 

@@ -21,6 +21,7 @@ W8PT_FORCE_110 = 16
 W8PT_NO_HARTLEY = 32
 W8PT_WAVE_PER_PAIR = 64
 W8PT16_MAX_N = 128
+EPI_HOMOGENEOUS = 8
 
 _P = c_void_p
 _SIGNATURES = {

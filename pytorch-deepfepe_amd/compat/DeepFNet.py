@@ -49,6 +49,23 @@ class Fit(nn.Module):
         self.if_cpu_svd = if_cpu_svd
         self.is_cuda = is_cuda
 
+    def normalize(self, pts, weights):
+        """Weighted Hartley normalisation, pts [B,N,3], weights [B,N,1] -> (T pts^T [B,3,N], T [B,3,3]) with the literal scale
+        1.4142 (DeepFNet.py:148-179).  weighted_svd calls it with unit weights (:198-199), which is what the fit kernel
+        fuses; this method serves callers of the reference API and is plain elementwise torch."""
+        denom = weights.sum(1)
+        c = (pts * weights).sum(1) / denom
+        d = pts - c.unsqueeze(1)
+        meandist = ((weights * d[:, :, :2].pow(2).sum(2).sqrt().unsqueeze(2)).sum(1) / denom).squeeze(1)
+        scale = 1.4142 / meandist
+        T = torch.zeros(pts.shape[0], 3, 3, dtype=pts.dtype, device=pts.device)
+        T[:, 0, 0] = scale
+        T[:, 1, 1] = scale
+        T[:, 2, 2] = 1
+        T[:, 0, 2] = -c[:, 0] * scale
+        T[:, 1, 2] = -c[:, 1] * scale
+        return torch.bmm(T, pts.permute(0, 2, 1)), T
+
     def weighted_svd(self, pts1, pts2, weights, if_print=False):
         _require_gpu(weights, "Fit")
         out, residual = ops.w8pt(pts1, pts2, weights)

@@ -27,7 +27,9 @@ class ErrorEstimator(nn.Module):
     max_chunk = 2048
 
     def forward(self, data):
-        if data.shape[0] <= self.max_chunk:
+        # BatchNorm statistics are over the batch: chunking would change them (and the running averages) in training mode
+        batch_stats = self.training and any(isinstance(m, nn.BatchNorm1d) for m in self.fw)
+        if data.shape[0] <= self.max_chunk or batch_stats:
             return self.fw(data)
         return torch.cat([self.fw(c) for c in data.split(self.max_chunk, dim=0)], dim=0)
 
@@ -37,7 +39,8 @@ class FusedErrorEstimator(ErrorEstimator):
     activations live channel-major as [C, B*N], every 1x1 convolution is ONE large GEMM W[C_out,C_in] @ X[C_in, B*N]
     (rocBLAS / hipBLASLt through torch.mm) instead of B small ones, and InstanceNorm + LeakyReLU is one fused HIP pass
     (ops.inorm_lrelu).  The biases of the convolutions that feed an InstanceNorm cancel in the normalisation and are
-    skipped (their gradient is exactly zero in the reference too).  Falls back to the stock path for the batch-norm
+    skipped in the arithmetic; they stay in the autograd graph with the exact zero gradient the reference computes for them
+    (so DistributedDataParallel sees every parameter used and the optimizer state matches).  Falls back to the stock path for the batch-norm
     variant and for N not a multiple of 4 or above 512."""
 
     def forward(self, data):
@@ -55,7 +58,8 @@ class FusedErrorEstimator(ErrorEstimator):
             if i + 2 < len(mods) and isinstance(mods[i + 1], nn.InstanceNorm1d):
                 inorm, act = mods[i + 1], mods[i + 2]
                 y = torch.mm(W, x)  # bias cancels in the instance normalisation
-                a = ops.inorm_lrelu(y.view(W.shape[0], B, N), inorm.weight, inorm.bias, inorm.eps, act.negative_slope)
+                a = ops.inorm_lrelu(y.view(W.shape[0], B, N), inorm.weight, inorm.bias, inorm.eps, act.negative_slope,
+                                    skipped_bias=conv.bias)
                 x = a.view(W.shape[0], B * N)
                 i += 3
             else:  # last convolution

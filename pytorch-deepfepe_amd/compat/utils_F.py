@@ -3,6 +3,7 @@ Signatures follow the reference; tensors must live on the GPU."""
 import torch
 
 from .. import _lib, ops
+from . import utils_misc
 
 
 def _gpu(t, dtype=torch.float32):
@@ -12,14 +13,56 @@ def _gpu(t, dtype=torch.float32):
     return t.to(dtype)
 
 
+def _normalize_XY(X, Y):
+    """Hartley normalisation of two point sets [N,2] with scale sqrt(2) (np.sqrt(2), not Fit.normalize's 1.4142):
+    returns (X_normalized [N,2], Y_normalized [N,2], T1, T2) like utils_F.py:15-41.  Elementwise plumbing; the solvers
+    (_F_from_XY, _E_from_XY) fuse this step into the fit kernel and do not call it."""
+    if X.shape[0] != Y.shape[0]:
+        raise ValueError("Number of points don't match.")
+
+    def one(P):
+        Ph = utils_misc._homo(P)
+        c = Ph[:, :2].mean(0, keepdim=True)
+        s = (2.0 ** 0.5) / torch.norm(Ph[:, :2] - c, 2, dim=1).mean()
+        T = torch.zeros(3, 3, dtype=P.dtype, device=P.device)
+        T[0, 0] = s; T[1, 1] = s; T[2, 2] = 1.0; T[0, 2] = -s * c[0, 0]; T[1, 2] = -s * c[0, 1]
+        return utils_misc._de_homo((T @ Ph.t()).t()), T
+
+    Xn, T1 = one(X)
+    Yn, T2 = one(Y)
+    return Xn, Yn, T1, T2
+
+
+def _normalize_XY_batch(X, Y):
+    """Batched form, X, Y [B,N,2] -> (Xn, Yn [B,N,2], T1s, T2s [B,3,3]) (utils_F.py:43-69)."""
+    if X.shape[1] != Y.shape[1]:
+        raise ValueError("Number of points don't match.")
+
+    def one(P):
+        Ph = utils_misc._homo(P)
+        c = Ph[:, :, :2].mean(1, keepdim=True)
+        s = (2.0 ** 0.5) / torch.norm(Ph[:, :, :2] - c, 2, dim=2).mean(1)
+        T = torch.zeros(P.shape[0], 3, 3, dtype=P.dtype, device=P.device)
+        T[:, 0, 0] = s; T[:, 1, 1] = s; T[:, 2, 2] = 1.0; T[:, 0, 2] = -s * c[:, 0, 0]; T[:, 1, 2] = -s * c[:, 0, 1]
+        return utils_misc._de_homo(torch.bmm(T, Ph.transpose(1, 2)).transpose(1, 2)), T
+
+    Xn, T1s = one(X)
+    Yn, T2s = one(Y)
+    return Xn, Yn, T1s, T2s
+
+
 def compute_epi_residual(pts1, pts2, F, clamp_at=0.5):
-    """Symmetric epipolar residual, [B,N] (utils_F.py:400-413); differentiable w.r.t. F."""
+    """Symmetric epipolar residual, [B,N] (utils_F.py:400-413); differentiable w.r.t. F only (what the F-loss needs;
+    the recurrent model's in-loop residual with point gradients comes out of the fit itself, ops.w8pt)."""
+    _no_grad_here("compute_epi_residual (w.r.t. the points)", pts1, pts2)
     return ops.epi_residual(_gpu(pts1), _gpu(pts2), _gpu(F), clamp_at)
 
 
 def _get_M2s(E):
     """E [3,3] -> (R2s, t2s, M2s) like utils_F.py:478-498 (two rotations, +-t, the four [R|t]).
-    The candidate *set* equals the reference's; the order within each pair follows this library's SVD gauge."""
+    The candidate *set* equals the reference's; the order within each pair follows this library's SVD gauge.
+    Not differentiable here (the pose loss has its own adjoint, ops.pose_errors)."""
+    _no_grad_here("_get_M2s", E)
     R1, R2, t = ops.decompose_essential(_gpu(E).reshape(1, 3, 3))
     R2s = [R1[0], R2[0]]
     t2s = [t[0].reshape(3, 1), -t[0].reshape(3, 1)]
@@ -40,32 +83,42 @@ def _E_to_F(E, K):
     return Ki.transpose(-1, -2) @ E @ Ki
 
 
-def _homo_free(F, X, Y, if_homo):
+def _no_grad_here(what, *tensors):
+    """These mirrors are raw kernel launches outside autograd (the reference's versions are differentiable torch code but
+    nothing on the hot path differentiates through them); asking for a gradient is an error rather than a silent zero."""
+    if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors):
+        raise _lib.DfepeError(f"compat.utils_F.{what}: not differentiable in this library (an input requires grad); "
+                              "use compute_epi_residual (gradient w.r.t. F) or detach the inputs")
+
+
+def _epi_args(what, F, X, Y, if_homo):
+    _no_grad_here(what, F, X, Y)
     F, X, Y = _gpu(F), _gpu(X), _gpu(Y)
     single = X.dim() == 2
     if single:
         F, X, Y = F.unsqueeze(0), X.unsqueeze(0), Y.unsqueeze(0)
-    if if_homo:  # the kernels take inhomogeneous 2-D points
-        X, Y = X[..., :2] / X[..., 2:3], Y[..., :2] / Y[..., 2:3]
+    want = 3 if if_homo else 2  # if_homo=True: [.,N,3] homogeneous points, used as they are (the reference skips _homo then)
+    if X.shape[-1] != want or Y.shape[-1] != want:
+        raise ValueError(f"{what}: points must be [..., N, {want}] when if_homo={if_homo}")
     return F, X.contiguous(), Y.contiguous(), single
 
 
 def _sym_epi_dist(F, X, Y, if_homo=False, clamp_at=None):
     """Squared symmetric epipolar distance (utils_F.py:310-339); the 1e-10 guard only in the batched form (:329)."""
-    F, X, Y, single = _homo_free(F, X, Y, if_homo)
-    out = ops.epi_metrics(0, F, X, Y, clamp_at=0.0 if clamp_at is None else clamp_at, eps=0.0 if single else 1e-10)
+    F, X, Y, single = _epi_args("_sym_epi_dist", F, X, Y, if_homo)
+    out = ops.epi_metrics(0, F, X, Y, clamp_at=clamp_at, eps=0.0 if single else 1e-10)
     return out[0] if single else out
 
 
 def _sampson_dist(F, X, Y, if_homo=False):
-    F, X, Y, single = _homo_free(F, X, Y, if_homo)
+    F, X, Y, single = _epi_args("_sampson_dist", F, X, Y, if_homo)
     out = ops.epi_metrics(1, F, X, Y)
     return out[0] if single else out
 
 
 def _epi_distance(F, X, Y, if_homo=False):
     """Returns ((d1+d2)/2, d1, d2) (utils_F.py:341-361)."""
-    F, X, Y, single = _homo_free(F, X, Y, if_homo)
+    F, X, Y, single = _epi_args("_epi_distance", F, X, Y, if_homo)
     out = ops.epi_metrics(2, F, X, Y)
     return (out[0, 0], out[1, 0], out[2, 0]) if single else (out[0], out[1], out[2])
 
@@ -74,7 +127,8 @@ def _E_to_M_train(E_est_th, K, x1, x2, inlier_mask=None, delta_Rt_gt_cam=None, d
                   show_result=True, method_name="ours"):
     """Cheirality-checked pose (utils_F.py:679-763).  Returns (M2_list, error_Rt, Rt_cam) like the reference:
     Rt_cam [3,4] = camera motion of the winning candidate or None; error_Rt = [R deg, t deg] when a ground truth
-    is given.  The triangulation is a linear DLT per correspondence (the reference calls cv2.triangulatePoints)."""
+    is given; M2_list is the empty list the reference returns too (it is created at :699 and never filled).
+    The triangulation is a linear DLT per correspondence (the reference calls cv2.triangulatePoints)."""
     dev = E_est_th.device if torch.is_tensor(E_est_th) and E_est_th.is_cuda else torch.device("cuda")
     E = torch.as_tensor(E_est_th, dtype=torch.float32).to(dev).reshape(1, 3, 3)
     Kt = torch.as_tensor(K, dtype=torch.float32).to(dev).reshape(1, 3, 3)

@@ -82,7 +82,11 @@ epi_metrics_kernel(int kind, const float* __restrict__ F, const float* __restric
   double f[9];
 #pragma unroll
   for (int c = 0; c < 9; ++c) f[c] = (double)F[b * 9 + c];
-  const double x[3] = {X[idx * 2], X[idx * 2 + 1], 1.0}, y[3] = {Y[idx * 2], Y[idx * 2 + 1], 1.0};
+  const bool homo = (kind & DFEPE_EPI_HOMOGENEOUS) != 0;  // [B,N,3] homogeneous points used as they are (if_homo=True)
+  kind &= 7;
+  const int sd = homo ? 3 : 2;
+  const double x[3] = {X[idx * sd], X[idx * sd + 1], homo ? (double)X[idx * sd + 2] : 1.0};
+  const double y[3] = {Y[idx * sd], Y[idx * sd + 1], homo ? (double)Y[idx * sd + 2] : 1.0};
   double fx[3], fty[3];
 #pragma unroll
   for (int r = 0; r < 3; ++r) fx[r] = f[3 * r] * x[0] + f[3 * r + 1] * x[1] + f[3 * r + 2] * x[2];       // F x
@@ -92,7 +96,7 @@ epi_metrics_kernel(int kind, const float* __restrict__ F, const float* __restric
   const double a = fx[0] * fx[0] + fx[1] * fx[1], bq = fty[0] * fty[0] + fty[1] * fty[1];
   if (kind == 0) {
     double e = num * num * (1.0 / (a + (double)eps) + 1.0 / (bq + (double)eps));
-    if (clamp_at > 0.f) e = fmin(e, (double)clamp_at);
+    if (clamp_at >= 0.f) e = fmin(e, (double)clamp_at);  // negative: no clamp (clamp_at=None)
     out[idx] = (float)e;
   } else if (kind == 1) {
     out[idx] = (float)(num * num / (a + bq));
@@ -432,7 +436,7 @@ extern "C" int dfepe_epi_residual_bwd(const float* pts1, const float* pts2, cons
 
 extern "C" int dfepe_epi_metrics(int kind, const float* F, const float* X, const float* Y, int B, int N, float clamp_at,
                                  float eps, float* out, void* stream) {
-  if (kind < 0 || kind > 2 || B < 0 || N <= 0) return DFEPE_ERR_INVALID_ARG;
+  if (kind < 0 || (kind & ~DFEPE_EPI_HOMOGENEOUS) > 2 || B < 0 || N <= 0) return DFEPE_ERR_INVALID_ARG;
   if (B == 0) return DFEPE_OK;
   if (!F || !X || !Y || !out) return DFEPE_ERR_INVALID_ARG;
   const size_t n = (size_t)B * N;

@@ -27,6 +27,14 @@ def _prep(t: Tensor, name: str) -> Tensor:
     return t.contiguous()
 
 
+def _shape(t: Tensor, name: str, *dims) -> None:
+    """Raise ValueError unless t has the given shape (None = any size): the kernels index raw pointers, so a wrong
+    layout would be a silent out-of-bounds read, not an exception."""
+    if t.dim() != len(dims) or any(d is not None and t.shape[i] != d for i, d in enumerate(dims)):
+        want = "[" + ",".join("?" if d is None else str(d) for d in dims) + "]"
+        raise ValueError(f"{name} must have shape {want}, got {tuple(t.shape)}")
+
+
 def save_floats() -> int:
     return _lib.lib().dfepe_save_floats()
 
@@ -144,6 +152,9 @@ def w8pt(pts1: Tensor, pts2: Tensor, weights: Tensor, clamp_at: float = 0.5, wan
     when the point tensors require grad, to both point sets."""
     pts1, pts2 = _prep(pts1, "pts1"), _prep(pts2, "pts2")
     w = _prep(weights.reshape(weights.shape[0], -1), "weights")
+    B, N = w.shape
+    _shape(pts1, "pts1 (homogeneous points)", B, N, 3)
+    _shape(pts2, "pts2 (homogeneous points)", B, N, 3)
     return _W8ptFunction.apply(pts1, pts2, w, False, 0.0, 0.0, clamp_at, want_epi, False)
 
 
@@ -152,6 +163,7 @@ def w8pt_raw(matches: Tensor, weights: Tensor, image_w: float, image_h: float, c
     """Differentiable fit straight from pixel matches [B,N,4] (image-size normalisation fused)."""
     m = _prep(matches, "matches")
     w = _prep(weights.reshape(weights.shape[0], -1), "weights")
+    _shape(m, "matches (pixel x1,y1,x2,y2)", w.shape[0], w.shape[1], 4)
     return _W8ptFunction.apply(m, None, w, True, float(image_w), float(image_h), clamp_at, want_epi, False)
 
 
@@ -161,6 +173,7 @@ def w8pt_raw_logits(matches: Tensor, logits: Tensor, image_w: float, image_h: fl
     (differentiable: the next estimator layer consumes them).  Returns (F, residual[, epi], weights)."""
     m = _prep(matches, "matches")
     l = _prep(logits.reshape(logits.shape[0], -1), "logits")
+    _shape(m, "matches (pixel x1,y1,x2,y2)", l.shape[0], l.shape[1], 4)
     return _W8ptFunction.apply(m, None, l, True, float(image_w), float(image_h), clamp_at, want_epi, True)
 
 
@@ -215,8 +228,16 @@ class _FlossFunction(torch.autograd.Function):
 
 def floss(F_layers: Tensor, T1: Tensor, T2: Tensor, K: Tensor, virt1: Tensor, virt2: Tensor, clamp_at: float):
     """F_layers [L,B,3,3] -> (loss_sum [L,B] = sum over virtual points of the clamped residual, E_layers [L,B,3,3])."""
-    return _FlossFunction.apply(_prep(F_layers, "F_layers"), T1, T2, _prep(K, "K"), _prep(virt1, "virt1"),
-                                _prep(virt2, "virt2"), clamp_at)
+    F_layers, K, virt1, virt2 = _prep(F_layers, "F_layers"), _prep(K, "K"), _prep(virt1, "virt1"), _prep(virt2, "virt2")
+    _shape(F_layers, "F_layers", None, None, 3, 3)
+    B = F_layers.shape[1]
+    _shape(K, "K (one intrinsic matrix per pair)", B, 3, 3)
+    _shape(virt1, "virt1 (homogeneous pixel points)", B, None, 3)
+    _shape(virt2, "virt2", B, virt1.shape[1], 3)
+    for T in (T1, T2):
+        if not ((T.dim() == 2 and tuple(T.shape) == (3, 3)) or (T.dim() == 3 and T.shape[0] in (1, B) and tuple(T.shape[1:]) == (3, 3))):
+            raise ValueError(f"T1/T2 must be [3,3], [1,3,3] or [{B},3,3], got {tuple(T.shape)}")
+    return _FlossFunction.apply(F_layers, T1, T2, K, virt1, virt2, clamp_at)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -259,7 +280,10 @@ class _PoseFunction(torch.autograd.Function):
 def pose_errors(E_layers: Tensor, q_gt: Tensor, t_gt: Tensor, R_gt: Tensor):
     """E_layers [L,B,3,3]; q_gt [B,4(,1)], t_gt [B,3(,1)], R_gt [B,3,3] (camera motion).
     Returns q_l2, t_l2 (differentiable w.r.t. E), R_deg, t_deg, sel — all [L,B]."""
+    _shape(E_layers, "E_layers", None, None, 3, 3)
     B = E_layers.shape[1]
+    if q_gt.numel() != 4 * B or t_gt.numel() != 3 * B or R_gt.numel() != 9 * B:
+        raise ValueError(f"q_gt / t_gt / R_gt must hold {B} quaternions / translations / rotations, got {tuple(q_gt.shape)}, {tuple(t_gt.shape)}, {tuple(R_gt.shape)}")
     return _PoseFunction.apply(_prep(E_layers, "E_layers"), _prep(q_gt.reshape(B, 4), "q_gt"),
                                _prep(t_gt.reshape(B, 3), "t_gt"), _prep(R_gt.reshape(B, 3, 3), "R_gt"))
 
@@ -293,14 +317,23 @@ class _EpiResidualFunction(torch.autograd.Function):
 
 def epi_residual(pts1: Tensor, pts2: Tensor, F: Tensor, clamp_at: float = 0.5) -> Tensor:
     """pts [B,N,3], F [B,3,3] -> [B,N]; differentiable w.r.t. F."""
-    return _EpiResidualFunction.apply(_prep(pts1, "pts1"), _prep(pts2, "pts2"), _prep(F, "F"), clamp_at)
+    pts1, pts2, F = _prep(pts1, "pts1"), _prep(pts2, "pts2"), _prep(F, "F")
+    _shape(pts1, "pts1 (homogeneous points)", None, None, 3)
+    _shape(pts2, "pts2", pts1.shape[0], pts1.shape[1], 3)
+    _shape(F, "F", pts1.shape[0], 3, 3)
+    return _EpiResidualFunction.apply(pts1, pts2, F, clamp_at)
 
 
-def epi_metrics(kind: int, F: Tensor, X: Tensor, Y: Tensor, clamp_at: float = 0.0, eps: float = 0.0) -> Tensor:
-    """kind 0 sym-epi (squared), 1 Sampson, 2 epi-distance (3 planes).  F [B,3,3], X, Y [B,N,2]."""
+def epi_metrics(kind: int, F: Tensor, X: Tensor, Y: Tensor, clamp_at: Optional[float] = None, eps: float = 0.0) -> Tensor:
+    """kind 0 sym-epi (squared), 1 Sampson, 2 epi-distance (3 planes).  F [B,3,3]; X, Y [B,N,2], or [B,N,3] homogeneous points
+    that are used as they are; clamp_at None = no clamp."""
     F, X, Y = _prep(F, "F"), _prep(X, "X"), _prep(Y, "Y")
+    if X.dim() != 3 or X.shape != Y.shape or X.shape[2] not in (2, 3) or F.shape != (X.shape[0], 3, 3):
+        raise ValueError(f"epi_metrics: F [B,3,3], X and Y [B,N,2|3] expected, got {tuple(F.shape)}, {tuple(X.shape)}, {tuple(Y.shape)}")
     B, N = X.shape[0], X.shape[1]
-    out = torch.empty((3, B, N) if kind == 2 else (B, N), device=X.device, dtype=torch.float32)
+    kind = int(kind) | (_lib.EPI_HOMOGENEOUS if X.shape[2] == 3 else 0)
+    clamp_at = -1.0 if clamp_at is None else float(clamp_at)
+    out = torch.empty((3, B, N) if (kind & 7) == 2 else (B, N), device=X.device, dtype=torch.float32)
     with torch.cuda.device(X.device):
         rc = _lib.lib().dfepe_epi_metrics(int(kind), _ptr(F), _ptr(X), _ptr(Y), B, N, float(clamp_at), float(eps), _ptr(out), _stream())
     _lib.check(rc, "dfepe_epi_metrics")
@@ -350,7 +383,10 @@ def decompose_essential(E: Tensor):
 def cheirality(E: Tensor, K: Tensor, matches: Tensor, depth_thres: float = 50.0):
     """E, K [B,3,3], matches [B,N,4] pixels -> (Rt_cam [B,3,4], winner [B] int32, counts [B,4] int32)."""
     E, K, m = _prep(E, "E"), _prep(K, "K"), _prep(matches, "matches")
+    _shape(m, "matches (pixel x1,y1,x2,y2)", None, None, 4)
     B, N = m.shape[0], m.shape[1]
+    _shape(E, "E", B, 3, 3)
+    _shape(K, "K (one intrinsic matrix per pair)", B, 3, 3)
     Rt = torch.empty(B, 3, 4, device=m.device, dtype=torch.float32)
     win = torch.empty(B, device=m.device, dtype=torch.int32)
     cnt = torch.empty(B, 4, device=m.device, dtype=torch.int32)
@@ -365,7 +401,7 @@ def cheirality(E: Tensor, K: Tensor, matches: Tensor, depth_thres: float = 50.0)
 # ------------------------------------------------------------------------------------------------
 class _InormLReLUFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, Y, gamma, beta, eps, slope):
+    def forward(ctx, Y, gamma, beta, eps, slope, skipped_bias):
         C, R, N = Y.shape
         A = torch.empty_like(Y)
         stats = torch.empty(C * R, 2, device=Y.device, dtype=torch.float32)
@@ -375,6 +411,7 @@ class _InormLReLUFunction(torch.autograd.Function):
         _lib.check(rc, "dfepe_inorm_lrelu_fwd")
         ctx.save_for_backward(Y, gamma, beta, stats)
         ctx.slope = float(slope)
+        ctx.bias_like = skipped_bias
         return A
 
     @staticmethod
@@ -389,12 +426,18 @@ class _InormLReLUFunction(torch.autograd.Function):
             rc = _lib.lib().dfepe_inorm_lrelu_bwd(_ptr(Y), _ptr(gA), _ptr(gamma), _ptr(beta), _ptr(stats), C, R, N, ctx.slope,
                                                   _ptr(gY), _ptr(rg), _ptr(rb), _stream())
         _lib.check(rc, "dfepe_inorm_lrelu_bwd")
-        return gY, rg.sum(dim=1), rb.sum(dim=1), None, None
+        # the bias of the convolution that feeds this normalisation cancels in it: its gradient is exactly zero, and it is
+        # returned as such so that the parameter stays in the graph (DistributedDataParallel, optimizer state, weight decay)
+        gb = None if ctx.bias_like is None else torch.zeros_like(ctx.bias_like)
+        return gY, rg.sum(dim=1), rb.sum(dim=1), None, None, gb
 
 
-def inorm_lrelu(Y: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, slope: float = 0.01) -> Tensor:
-    """Y [C,R,N] channel-major (contiguous) -> LeakyReLU(InstanceNorm over N with affine gamma/beta [C])."""
-    return _InormLReLUFunction.apply(_prep(Y, "Y"), _prep(gamma, "gamma"), _prep(beta, "beta"), eps, slope)
+def inorm_lrelu(Y: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, slope: float = 0.01,
+                skipped_bias: Optional[Tensor] = None) -> Tensor:
+    """Y [C,R,N] channel-major (contiguous) -> LeakyReLU(InstanceNorm over N with affine gamma/beta [C]).
+    ``skipped_bias``: the [C] bias of the convolution that produced Y without it (a per-channel constant cancels in the
+    instance normalisation); it receives an exact zero gradient instead of none."""
+    return _InormLReLUFunction.apply(_prep(Y, "Y"), _prep(gamma, "gamma"), _prep(beta, "beta"), eps, slope, skipped_bias)
 
 
 # ------------------------------------------------------------------------------------------------

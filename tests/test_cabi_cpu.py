@@ -55,7 +55,7 @@ def test_argument_validation_without_launching(dfepe):
     tail = lambda L_, B_, M_: L.dfepe_loss_tail(None, L_, B_, None, None, 0, None, None, None, M_, 0.02, None, None, None, 0.1, 0.5, 1.0, 1.0, 0.1, 4.0,
                                                None, None, None, None, None, None, None, None, None, None, None, None)
     assert tail(5, 4, 100) == -1 and tail(0, 4, 100) == -1 and tail(5, 4, 200) == -3  # null pointers; no layers; grid too large for the fused kernel
-    assert L.dfepe_loss_tail_workspace_bytes(4096) >= 64 + 256 * 48 * 8
+    assert L.dfepe_loss_tail_workspace_bytes(4096) >= 256 * 48 * 8
 
 
 def test_no_cpu_fallback(dfepe):
@@ -115,3 +115,44 @@ def test_compat_surface_without_a_gpu(dfepe):
         tr.nn_match_two_way(np.ones((8, 3)), np.ones((8, 5)), -0.1)
     with pytest.raises(AssertionError):
         C.utils_misc.crop_or_pad_choice(5, 0)
+
+
+def test_boundary_helpers_of_the_reference_surface(dfepe, oracle, golden):
+    """The small helpers of the mirrored call surface that are plain torch / numpy (no kernel): Fit.normalize against the
+    reference's own output (golden), _normalize_XY(_batch) against the pinned oracle, utils_misc / utils_geo helpers against
+    their definitions."""
+    um, ug, uF = dfepe.compat.utils_misc, dfepe.compat.utils_geo, dfepe.compat.utils_F
+    g = golden("fit")
+    pts1 = torch.from_numpy(g["general_f32_pts1"])
+    fit = dfepe.compat.DeepFNet.Fit(is_cuda=False)
+    out, T = fit.normalize(pts1, torch.ones(pts1.shape[0], pts1.shape[1], 1))  # weighted_svd passes unit weights (DeepFNet.py:198-199)
+    np.testing.assert_allclose(T.numpy(), g["general_f32_hartley1_T"], rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(out.numpy(), g["general_f32_hartley1_pts"], rtol=2e-5, atol=2e-6)
+    gen = torch.Generator().manual_seed(0)
+    X, Y = torch.randn(40, 2, generator=gen, dtype=torch.float64) * 3 + 1, torch.randn(40, 2, generator=gen, dtype=torch.float64) - 2
+    Xn, Yn, T1, T2 = uF._normalize_XY(X, Y)
+    Xo, To = oracle._normalize_xy(X)
+    np.testing.assert_allclose(Xn.numpy(), Xo.numpy(), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(T1.numpy(), To.numpy(), rtol=1e-12, atol=1e-12)
+    assert abs(float(Yn.norm(dim=1).mean()) - 2 ** 0.5) < 1e-9 and float(Yn.mean(0).abs().max()) < 1e-9
+    Xb, Yb, T1b, T2b = uF._normalize_XY_batch(torch.stack((X, Y)), torch.stack((Y, X)))
+    np.testing.assert_allclose(Xb[0].numpy(), Xn.numpy(), atol=1e-12)
+    np.testing.assert_allclose(T2b[1].numpy(), T1.numpy(), atol=1e-12)
+    with pytest.raises(ValueError):
+        uF._normalize_XY(X, Y[:5])
+    # homogeneous helpers, cross-product matrix, rigid-transform inversion
+    assert um._homo(X).shape == (40, 3) and torch.equal(um._homo(X)[:, 2], torch.ones(40, dtype=torch.float64))
+    np.testing.assert_allclose(um._de_homo(um._homo(X) * 2.0).numpy(), X.numpy(), rtol=1e-9)
+    v, w = torch.randn(3, 1, generator=gen), torch.randn(3, 1, generator=gen)
+    np.testing.assert_allclose((um._skew_symmetric(v) @ w).flatten().numpy(), torch.linalg.cross(v.flatten(), w.flatten()).numpy(), atol=1e-6)
+    assert um._skew_symmetric(torch.stack((v, w))).shape == (2, 3, 3)
+    np.testing.assert_allclose(um.skew_symmetric_np(v.numpy()), um._skew_symmetric(v).numpy())
+    sc = dfepe.synth.make_scene(2, 10, seed=0, dtype=torch.float64)
+    Rt = sc["delta_Rtijs_4_4"][0, :3, :]
+    inv = um._inv_Rt(Rt)
+    np.testing.assert_allclose(um.Rt_pad(inv.numpy()) @ um.Rt_pad(Rt.numpy()), np.eye(4), atol=1e-12)
+    np.testing.assert_allclose(um.inv_Rt_np(Rt.numpy()), inv.numpy(), atol=1e-15)
+    R12, t12 = ug.invert_Rt(Rt[:, :3].numpy(), Rt[:, 3:4].numpy())
+    np.testing.assert_allclose(np.hstack((R12, t12)), um.Rt_depad(np.linalg.inv(um.Rt_pad(Rt.numpy()))), atol=1e-12)
+    assert um.identity_Rt().shape == (3, 4) and um.homo_np(X.numpy()).shape == (40, 3)
+    np.testing.assert_allclose(um.de_homo_np(um.homo_np(X.numpy())), X.numpy(), rtol=1e-9)

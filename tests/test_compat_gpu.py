@@ -80,13 +80,103 @@ def test_deepfnet_full_model_matches_reference_golden(dfepe, golden):
         get_residual_summaries=False)
     np.testing.assert_allclose(losses["loss_F"].item(), g["net_loss_F"], rtol=2e-2)
     losses["loss_F"].backward()
-    # conv biases that feed an InstanceNorm cancel exactly; the fused estimator skips them (grad None = the reference's ~0)
+    # conv biases that feed an InstanceNorm cancel exactly; the fused estimator gives them an exact zero gradient (the reference's ~0)
     gn = {n: (0.0 if p.grad is None else float(p.grad.double().norm())) for n, p in net.named_parameters()}
     ours = np.array([gn[n] for n in sorted(gn)])
     np.testing.assert_allclose(ours, g["net_grad_norms"], rtol=0.1, atol=1e-4 * g["net_grad_norms"].max())
     ga = net.input_weights.fw[0].weight.grad.cpu().numpy().ravel()
     gr = g["net_grad_first_conv"].ravel()
     assert (ga * gr).sum() / (np.linalg.norm(ga) * np.linalg.norm(gr)) > 0.995
+
+
+def test_deepfnet_sign_gauge_departure_is_bounded_and_documented(dfepe, golden):
+    """The reference feeds the SIGNED residual of each fit to the next estimator layer, and the sign is LAPACK's arbitrary
+    one (it has no convention); this library orients f by its largest component.  The recurrent outputs therefore differ
+    from a reference run wherever the two signs differ: this test measures by how much on the
+    golden model (seeded random weights) -- layer 1 is gauge-free and agrees tightly; later layers agree on the sign-invariant
+    quantities only as far as the estimator's sensitivity to that one input channel allows."""
+    g = golden("pipeline")
+    depth = 3
+    net = dfepe.compat.DeepFNet.DeepFNet(depth=depth, image_size=IMAGE_SIZE, if_quality=False, if_cpu_svd=True)
+    dfepe.synth.fill_params_deterministic(net, seed=5)
+    net = net.to(DEV)
+    batch = {"matches_xy_ori": T(g["net_matches_xy_ori"]).to(DEV), "matches_good_unique_nums": None, "t_scene_scale": None}
+    with torch.no_grad():
+        outs = net(batch)
+    a, r, s = unit_align(outs["out_layers"][0].cpu().numpy(), g["net_out_layers"][0])
+    assert np.linalg.norm(a - r, axis=1).max() < 1e-3  # first fit: its weights do not depend on any sign
+    flipped = (s < 0).mean()
+    dep = []
+    for l in range(1, depth):
+        a, r, _ = unit_align(outs["out_layers"][l].cpu().numpy(), g["net_out_layers"][l])
+        dep.append(np.linalg.norm(a - r, axis=1).max())
+    # with every pair's sign equal to the reference's there is no departure beyond fp32 noise; otherwise it is finite and
+    # of the size the estimator's response to a flipped residual channel gives (recorded here, not asserted to be small)
+    assert all(np.isfinite(dep))
+    if flipped == 0.0:
+        assert max(dep) < 1e-3
+    print(f"sign gauge: {100 * flipped:.0f} % of the pairs oriented opposite to the reference's LAPACK run; "
+          f"max unit-Frobenius departure of the later layers' F: {max(dep):.3e}")
+
+
+def test_shape_validation_and_nondifferentiable_mirrors(dfepe):
+    """Wrong layouts raise ValueError before anything is launched (the kernels index raw pointers); mirrors that are raw
+    launches refuse inputs that require grad instead of silently dropping the gradient."""
+    B, N = 3, 20
+    w = torch.rand(B, N, device=DEV)
+    with pytest.raises(ValueError):
+        dfepe.ops.w8pt(torch.rand(B, N, 2, device=DEV), torch.rand(B, N, 2, device=DEV), w)  # [B,N,2] instead of homogeneous [B,N,3]
+    with pytest.raises(ValueError):
+        dfepe.ops.w8pt_raw(torch.rand(B, N, 3, device=DEV), w, 1241, 376)
+    with pytest.raises(ValueError):
+        dfepe.ops.floss(torch.rand(2, B, 3, 3, device=DEV), torch.eye(3, device=DEV), torch.eye(3, device=DEV), torch.rand(3, 3, device=DEV),
+                        torch.rand(B, 10, 3, device=DEV), torch.rand(B, 10, 3, device=DEV), 0.02)  # one shared K instead of [B,3,3]
+    with pytest.raises(ValueError):
+        dfepe.ops.floss(torch.rand(2, B, 3, 3, device=DEV), torch.eye(3, device=DEV), torch.eye(3, device=DEV), torch.rand(B, 3, 3, device=DEV),
+                        torch.rand(B, 10, 3, device=DEV), torch.rand(B, 12, 3, device=DEV), 0.02)
+    with pytest.raises(ValueError):
+        dfepe.ops.pose_errors(torch.rand(2, B, 3, 3, device=DEV), torch.rand(B + 1, 4, device=DEV), torch.rand(B, 3, device=DEV), torch.rand(B, 3, 3, device=DEV))
+    with pytest.raises(ValueError):
+        dfepe.ops.cheirality(torch.rand(B, 3, 3, device=DEV), torch.rand(1, 3, 3, device=DEV), torch.rand(B, N, 4, device=DEV))
+    with pytest.raises(ValueError):
+        dfepe.ops.epi_residual(torch.rand(B, N, 3, device=DEV), torch.rand(B, N, 3, device=DEV), torch.rand(B + 1, 3, 3, device=DEV))
+    uF = dfepe.compat.utils_F
+    F = torch.rand(B, 3, 3, device=DEV, requires_grad=True)
+    X, Y = torch.rand(B, N, 2, device=DEV), torch.rand(B, N, 2, device=DEV)
+    for fn in (uF._sym_epi_dist, uF._sampson_dist, uF._epi_distance):
+        with pytest.raises(dfepe.DfepeError):
+            fn(F, X, Y)
+        fn(F.detach(), X, Y)
+    with pytest.raises(dfepe.DfepeError):
+        uF.compute_epi_residual(torch.rand(B, N, 3, device=DEV, requires_grad=True), torch.rand(B, N, 3, device=DEV), F.detach())
+
+
+def test_epipolar_metrics_on_homogeneous_points(dfepe, oracle):
+    """if_homo=True: homogeneous points are used as they are (third coordinate != 1 included), clamp_at=0.0 clamps to zero,
+    clamp_at=None does not clamp -- like utils_F.py:291-361."""
+    uF = dfepe.compat.utils_F
+    g = torch.Generator().manual_seed(5)
+    B, N = 3, 50
+    F = torch.randn(B, 3, 3, generator=g)
+    w1, w2 = 0.5 + torch.rand(B, N, 1, generator=g), 0.5 + torch.rand(B, N, 1, generator=g)
+    X, Y = torch.randn(B, N, 2, generator=g), torch.randn(B, N, 2, generator=g)
+    Xh, Yh = torch.cat((X, torch.ones(B, N, 1)), 2) * w1, torch.cat((Y, torch.ones(B, N, 1)), 2) * w2
+    Fd, Xd, Yd = F.double(), Xh.double(), Yh.double()
+    num = (Yd @ Fd @ Xd.transpose(1, 2)).diagonal(dim1=1, dim2=2)
+    Fx1, Fx2 = Fd @ Xd.transpose(1, 2), Fd.transpose(1, 2) @ Yd.transpose(1, 2)
+    a, b = Fx1[:, 0] ** 2 + Fx1[:, 1] ** 2, Fx2[:, 0] ** 2 + Fx2[:, 1] ** 2
+    sym = num ** 2 * (1 / (a + 1e-10) + 1 / (b + 1e-10))
+    out = uF._sym_epi_dist(F.to(DEV), Xh.to(DEV), Yh.to(DEV), if_homo=True)
+    np.testing.assert_allclose(out.cpu().numpy(), sym.numpy(), rtol=2e-5)
+    np.testing.assert_allclose(uF._sampson_dist(F.to(DEV), Xh.to(DEV), Yh.to(DEV), if_homo=True).cpu().numpy(), (num ** 2 / (a + b)).numpy(), rtol=2e-5)
+    d = uF._epi_distance(F.to(DEV), Xh.to(DEV), Yh.to(DEV), if_homo=True)
+    np.testing.assert_allclose(d[1].cpu().numpy(), (num.abs() / a.sqrt()).numpy(), rtol=2e-5)
+    assert uF._sym_epi_dist(F.to(DEV), X.to(DEV), Y.to(DEV), clamp_at=0.0).abs().max().item() == 0.0
+    assert uF._sym_epi_dist(F.to(DEV), X.to(DEV), Y.to(DEV), clamp_at=None).max().item() > 1.0
+    np.testing.assert_allclose(uF._sym_epi_dist(F.to(DEV), X.to(DEV), Y.to(DEV)).cpu().numpy(),
+                               oracle.sym_epi_dist(F.double(), X.double(), Y.double()).numpy(), rtol=2e-5)
+    with pytest.raises(ValueError):
+        uF._sym_epi_dist(F.to(DEV), X.to(DEV), Y.to(DEV), if_homo=True)  # 2-D points announced as homogeneous
 
 
 def test_loss_functions_match_reference_golden(dfepe, golden):
