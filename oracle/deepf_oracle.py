@@ -468,6 +468,33 @@ def E_from_XY(X: Tensor, Y: Tensor, K: Tensor, W: Optional[Tensor] = None, if_no
 
 
 # --------------------------------------------------------------------------------------
+# f-4: DSAC hypothesis loop  (dsac_tools/dsac.py:94-197)
+# --------------------------------------------------------------------------------------
+def dsac_scores(X: Tensor, Y: Tensor, K: Tensor, hyps: int, inlier_thresh: float, inlier_beta: float, idx_list):
+    """The reference's loop, one hypothesis at a time (:138-176): E from the 10 sampled correspondences (_E_from_XY, :49),
+    Sampson distances of F = K^-T E K^-1 in pixel space (:68; the reference names an undefined `E_to_F` there), soft inlier
+    count 1 - sigmoid(beta (d - thresh)) (:74), refinement by _E_from_XY with W = diag(sqrt(dists)) (:92), and the
+    per-correspondence average score (:164-165, :197).  `idx_list` = the minimal sets (random.sample draws, :45), passed in
+    so that both sides use the same ones.  **Parity unpinned**: the reference class is not runnable as is (undefined name);
+    this restates its evident algorithm.  Returns (N_scores / (N_counts + 1e-10) [N,1], per-hypothesis scores, refined Es)."""
+    N = X.shape[0]
+    Ki = torch.linalg.inv(K)
+    n_scores, n_counts = torch.zeros(N, 1, dtype=X.dtype), torch.zeros(N, 1, dtype=X.dtype)
+    scores, refined = [], []
+    for h in range(hyps):
+        idx = idx_list[h]
+        E = E_from_XY(X[idx], Y[idx], K)
+        d = sampson_dist(Ki.T @ E @ Ki, X, Y)
+        dists = 1 - torch.sigmoid(inlier_beta * (d - inlier_thresh))
+        score = dists.sum()
+        refined.append(E_from_XY(X, Y, K, W=torch.diag(torch.sqrt(dists))))
+        scores.append(score)
+        n_scores[idx] += score
+        n_counts[idx] += 1.0
+    return n_scores / (n_counts + 1e-10), torch.stack(scores), torch.stack(refined)
+
+
+# --------------------------------------------------------------------------------------
 # helpers for tests / bench (not reference functions)
 # --------------------------------------------------------------------------------------
 def align_sign(A: Tensor, ref: Tensor) -> Tensor:

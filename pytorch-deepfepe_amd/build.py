@@ -2,12 +2,15 @@
 
     python pytorch-deepfepe_amd/build.py [--force]
 
-hipcc cross-compiles gfx950 without a GPU.  Objects are cached under csrc/build/ (git-ignored) and
-only rebuilt when a source or header is newer; the shared library lands next to this file so it
-travels with the repository snapshot to the GPU box.
+hipcc cross-compiles gfx950 without a GPU.  Objects are cached under csrc/build/ (git-ignored), each next to a
+stamp holding the SHA-256 of its source, of every header and of the compiler flags: an object is reused only when
+that content hash matches, so a build() provably compiles what is in the tree (file times play no role; the
+prebuilt objects that travel to the GPU box are rebuilt there if anything differs).  The shared library lands next
+to this file so it travels with the repository snapshot to the GPU box.
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -31,26 +34,38 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
-def _newer(target: str, deps) -> bool:
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _digest(paths, extra: str) -> str:
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stamp_matches(stamp: str, digest: str) -> bool:
+    try:
+        return open(stamp).read().strip() == digest
+    except OSError:
+        return False
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(INCLUDE, "dfepe.h")]
+    hdrs = sorted([os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(INCLUDE, "dfepe.h")])
     jobs = []
     objs = []
+    stamps = {}
     for s in srcs:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJDIR, s[:-4] + ".o")
         objs.append(obj)
-        if force or _newer(obj, [src] + hdrs):
+        digest = _digest([src] + hdrs, " ".join(FLAGS))
+        if force or not os.path.exists(obj) or not _stamp_matches(obj + ".sha256", digest):
             jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
+            stamps[obj] = digest
 
     def run(cmd):
         if verbose:
@@ -64,8 +79,14 @@ def build(force: bool = False, verbose: bool = True) -> str:
         for out in ex.map(run, jobs):
             if verbose and out.strip():
                 print(out)
-    if force or jobs or _newer(LIB, objs):
+    for obj, digest in stamps.items():  # only after the compile succeeded
+        with open(obj + ".sha256", "w") as f:
+            f.write(digest + "\n")
+    link_digest = _digest(objs, "link")
+    if force or jobs or not os.path.exists(LIB) or not _stamp_matches(os.path.join(OBJDIR, "lib.sha256"), link_digest):
         run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB])
+        with open(os.path.join(OBJDIR, "lib.sha256"), "w") as f:
+            f.write(link_digest + "\n")
     return LIB
 
 

@@ -423,3 +423,27 @@ def test_cheirality_batch_size_variants_agree(dfepe):
     Rt2, win2, cnt2 = dfepe.ops.cheirality(E[:200].contiguous(), K[:200].contiguous(), m[:200].contiguous(), 50.0)
     assert torch.equal(win[:200], win2) and torch.equal(cnt[:200], cnt2) and torch.equal(Rt[:200], Rt2)
     assert (win >= 0).float().mean().item() > 0.95
+
+
+def test_dsac_hypothesis_loop(dfepe, oracle):
+    """compat.dsac.DSAC (all hypotheses per launch) against the oracle's per-hypothesis loop on the same minimal sets
+    (Python's `random` seeded identically): per-correspondence average scores, per-hypothesis scores, and the refined E
+    of every hypothesis up to sign."""
+    import random
+
+    sc = dfepe.synth.make_scene(1, 200, seed=8, outlier_ratio=0.3, noise_px=0.5)
+    X, Y, K = sc["matches_xy_ori"][0, :, :2], sc["matches_xy_ori"][0, :, 2:], sc["Ks"][0]
+    hyps, thr, beta = 24, 2.0, 5.0
+    losses = []
+    d = dfepe.compat.dsac.DSAC(hyps, thr, beta, 0.5, K, lambda H, Xa, Ya: losses.append(1) or H.abs().sum())
+    random.seed(5)
+    out = d(X.to(DEV), Y.to(DEV), None)
+    random.seed(5)
+    idx_list = [random.sample(range(200), 10) for _ in range(hyps)]
+    ref, ref_scores, ref_E = oracle.dsac_scores(X.double(), Y.double(), K.double(), hyps, thr, beta, idx_list)
+    assert out.shape == (200, 1) and len(losses) == hyps and d.hyp_losses.shape == (hyps,)
+    np.testing.assert_allclose(d.hyp_scores.cpu().numpy(), ref_scores.numpy(), rtol=2e-3, atol=1e-3)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=2e-3, atol=1e-3)
+    assert d.best_H_idx == int(ref_scores.argmax()) and d.best_corres_idx == idx_list[d.best_H_idx]
+    a, r, _ = unit_align(d.best_H.reshape(1, 3, 3).cpu().numpy(), ref_E[d.best_H_idx].reshape(1, 3, 3).numpy())
+    assert np.linalg.norm(a - r, axis=1).max() < 1e-3
