@@ -207,6 +207,24 @@ int dfepe_cheirality(const float *E, const float *K, const float *matches, int B
                      float *Rt_cam, int *winner, int *counts, void *stream);
 
 /*
+ * Reductions of the validation summary on the device.
+ * Replaces: the numpy post-processing of write_metrics_summary (deepFEPE/train_good_utils.py:758-856) over the per-pair
+ * results of val_rt (:553-646): epipolar-distance inlier ratios at 0.1 / 1.0 px, F1 of "est < th" against "gt < th",
+ * medians and maxima of the pose errors, np.histogram counts of the errors over the thresholds
+ * 0, 0.01, 0.03, 0.05, 0.1, 0.3, 0.5, 1, 2, 5, 10, 90, 180 degrees.
+ *   epi_est, epi_gt [n_epi] epipolar distances of every correspondence under the estimated / ground-truth F (epi_gt may be NULL)
+ *   err_q, err_t [B] rotation / translation errors in degrees
+ *   out: dfepe_metrics_summary_bytes() bytes, 8-byte aligned, overwritten:
+ *     uint64 counts[8]  = #est<0.1, #est<1, (TP, FP, FN) at 0.1, (TP, FP, FN) at 1.0
+ *     uint64 hist[2][12] bin counts for err_q, err_t (bins [th_k, th_k+1), the last closed; values outside [0,180] dropped)
+ *     float  max[2], float mids[2][2] = the two middle order statistics of err_q, err_t (median = their mean)
+ * Raw counts, not ratios: the host derives the ratios after ONE device-to-host copy per validation epoch.
+ */
+size_t dfepe_metrics_summary_bytes(void);
+int dfepe_metrics_summary(const float *epi_est, const float *epi_gt, size_t n_epi, const float *err_q, const float *err_t,
+                          int B, void *out, void *stream);
+
+/*
  * Epipolar metrics of dsac_tools.utils_F (utils_F.py:291-361) on homogeneous-or-not 2-D points.
  *   kind: 0 = _sym_epi_dist (squared; `eps` is added to the two squared line norms: 1e-10 in the reference's batched branch,
  *         0 in its 2-D branch), 1 = _sampson_dist, 2 = _epi_distance (writes 3 planes: mean, d1, d2);

@@ -468,6 +468,32 @@ def E_from_XY(X: Tensor, Y: Tensor, K: Tensor, W: Optional[Tensor] = None, if_no
 
 
 # --------------------------------------------------------------------------------------
+# f-2: validation summary  (train_good_utils.py:758-856 write_metrics_summary)
+# --------------------------------------------------------------------------------------
+METRIC_THS = [0.0, 0.01, 0.03, 0.05, 0.1, 0.3, 0.5, 1.0, 2.0, 5.0, 10.0, 90.0, 180.0]
+
+
+def metrics_summary_np(epi_est: np.ndarray, epi_gt: np.ndarray, err_q: np.ndarray, err_t: np.ndarray) -> Dict[str, object]:
+    """The scalars write_metrics_summary logs for one experiment tag: inlier ratios of the epipolar distances at 0.1 / 1.0
+    (:776-777), F1 of (est < th) against (gt < th) (:788-797; sklearn's binary f1 = 2TP / (2TP + FP + FN)), medians (:799-805)
+    and maxima (:811-816) of the pose errors, cumulative np.histogram ratios over METRIC_THS (:829-853)."""
+    epi_est, epi_gt = np.asarray(epi_est).flatten(), np.asarray(epi_gt).flatten()
+    err_q, err_t = np.asarray(err_q).flatten(), np.asarray(err_t).flatten()
+
+    def f1(y_true, y_pred):
+        tp = np.sum(y_true & y_pred); fp = np.sum(~y_true & y_pred); fn = np.sum(y_true & ~y_pred)
+        return float(2 * tp / (2 * tp + fp + fn)) if (2 * tp + fp + fn) > 0 else 0.0
+
+    n = float(err_q.shape[0])
+    return {"ratio_0.1": float(np.sum(epi_est < 0.1) / epi_est.shape[0]), "ratio_1": float(np.sum(epi_est < 1.0) / epi_est.shape[0]),
+            "F1_0.1": f1(epi_gt < 0.1, epi_est < 0.1), "F1_1": f1(epi_gt < 1.0, epi_est < 1.0),
+            "median_err_q": float(np.median(err_q)), "median_err_t": float(np.median(err_t)),
+            "max_err_q": float(np.amax(err_q)), "max_err_t": float(np.amax(err_t)),
+            "ratio_q": np.cumsum(np.histogram(err_q, METRIC_THS)[0].astype(float) / n).tolist(),
+            "ratio_t": np.cumsum(np.histogram(err_t, METRIC_THS)[0].astype(float) / n).tolist()}
+
+
+# --------------------------------------------------------------------------------------
 # f-4: DSAC hypothesis loop  (dsac_tools/dsac.py:94-197)
 # --------------------------------------------------------------------------------------
 def dsac_scores(X: Tensor, Y: Tensor, K: Tensor, hyps: int, inlier_thresh: float, inlier_beta: float, idx_list):

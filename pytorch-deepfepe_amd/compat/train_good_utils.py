@@ -135,6 +135,67 @@ def val_rt_batch(Ks, matches_xy, E_ests, delta_Rtijs_4_4, project_E=True, depth_
     return {"err_R_deg": err_R, "err_t_deg": err_t, "Rt_cam": Rt, "winner": win, "counts": cnt}
 
 
+def validation_summary(Ks, matches_xy, E_ests, F_ests, F_gts, delta_Rtijs_4_4, project_E=True, depth_thres=50.0):
+    """One validation batch end to end on the device: val_rt_batch (pose errors of every pair), the epipolar distances of
+    every correspondence under the estimated and the ground-truth F (epi_distance_np: d1 + d2, utils_F.py:363-385, as val_rt
+    calls it, train_good_utils.py:609-614), and the reductions write_metrics_summary applies to them (:758-856).
+    Returns (summary dict of python floats for the 'ours' tag, per-pair dict of device tensors)."""
+    from . import utils_F
+
+    pairs = val_rt_batch(Ks, matches_xy, E_ests, delta_Rtijs_4_4, project_E=project_E, depth_thres=depth_thres)
+    X, Y = matches_xy[:, :, :2].contiguous(), matches_xy[:, :, 2:].contiguous()
+    d_est = 2.0 * utils_F._epi_distance(F_ests, X, Y)[0]  # (d1 + d2), the first return value of epi_distance_np
+    d_gt = 2.0 * utils_F._epi_distance(F_gts, X, Y)[0]
+    pairs.update({"epi_dists": d_est, "epi_dists_gt": d_gt})
+    return ops.metrics_summary(d_est, d_gt, pairs["err_R_deg"], pairs["err_t_deg"]), pairs
+
+
+def write_metrics_summary(writer, dict_of_lists, task, n_iter):
+    """Same call and same scalar tags as the reference's write_metrics_summary (train_good_utils.py:758-856).  The values of
+    dict_of_lists[metric][exp] may be lists of numpy arrays (the reference's layout) or of device tensors; the counting,
+    F1, median, maximum and histogram reductions run on the device (ops.metrics_summary), one small copy per experiment tag.
+    Histograms (writer.add_histogram) receive the host copy of the error vectors like the reference's."""
+    metric_list = list(dict_of_lists.keys())
+    exp_list = list(dict_of_lists[metric_list[0]].keys())
+    assert "epi_dists" in metric_list
+    dev = torch.device("cuda")
+
+    def flat(v):
+        parts = [torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x, dtype=torch.float32).reshape(-1) for x in (v if isinstance(v, (list, tuple)) else [v])]
+        return torch.cat([p.to(dev) for p in parts])
+
+    gt_epi = flat(dict_of_lists["epi_dists"]["gt"])
+    for tag in exp_list:
+        epi = flat(dict_of_lists["epi_dists"][tag])
+        err_q, err_t = flat(dict_of_lists["err_q"][tag]), flat(dict_of_lists["err_t"][tag])
+        sm = ops.metrics_summary(epi, gt_epi, err_q, err_t)
+        writer.add_scalar(task + "-Error-epi_dists/%s-0.1" % tag, sm["ratio_0.1"], n_iter)
+        writer.add_scalar(task + "-Error-epi_dists/%s-1" % tag, sm["ratio_1"], n_iter)
+        writer.add_scalar(task + "-Error-F1/%s-0.1" % tag, sm["F1_0.1"], n_iter)
+        writer.add_scalar(task + "-Error-F1/%s-1" % tag, sm["F1_1"], n_iter)
+        for metric in metric_list:
+            if metric == "epi_dists":
+                continue
+            if metric == "err_q":
+                med = sm["median_err_q"]
+            elif metric == "err_t":
+                med = sm["median_err_t"]
+            else:  # any further per-pair metric: the same device median
+                other = flat(dict_of_lists[metric][tag])
+                med = ops.metrics_summary(epi[:0], None, other, other)["median_err_q"]
+            writer.add_scalar(task + "-Error-Median/%s-%s" % (metric, tag), med, n_iter)
+        writer.add_scalar(task + "-Error-MAX/err_q_MAX_%s" % tag, sm["max_err_q"], n_iter)
+        writer.add_scalar(task + "-Error-MAX/err_t_MAX_%s" % tag, sm["max_err_t"], n_iter)
+        if hasattr(writer, "add_histogram"):
+            q_np, t_np = err_q.cpu().numpy(), err_t.cpu().numpy()
+            writer.add_histogram(task + "-Error-hist/err_q_%s" % tag, q_np, n_iter)
+            writer.add_histogram(task + "-Error-hist/err_t_%s" % tag, t_np, n_iter)
+            writer.add_histogram(task + "-Error-hist/err_t-Clip10.degree_%s" % tag, np.clip(t_np, 0.0, 10.0), n_iter)
+        for k, th in enumerate(ops.METRIC_THS[1:]):
+            writer.add_scalar(task + "-Error-ratio/ratio_q{}_{}".format(th, tag), sm["ratio_q"][k], n_iter)
+            writer.add_scalar(task + "-Error-ratio/ratio_t{}_{}".format(th, tag), sm["ratio_t"][k], n_iter)
+
+
 def matches_from_SP_outputs(xs_SP, deses_SP, reses_SP, nn_thresh, out_num_points=1000):
     """The per-pair loop of get_matches_from_SP (train_good_utils.py:679-724) for the whole batch on the GPU.
     xs_SP, reses_SP: two tensors [B,N,2] (keypoints, sub-pixel offsets); deses_SP: two tensors [B,N,D] (unit norm).

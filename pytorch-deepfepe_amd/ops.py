@@ -397,6 +397,50 @@ def cheirality(E: Tensor, K: Tensor, matches: Tensor, depth_thres: float = 50.0)
 
 
 # ------------------------------------------------------------------------------------------------
+# validation summary reductions ("next" row f-2)
+# ------------------------------------------------------------------------------------------------
+METRIC_THS = (0.0, 0.01, 0.03, 0.05, 0.1, 0.3, 0.5, 1.0, 2.0, 5.0, 10.0, 90.0, 180.0)
+
+
+def metrics_summary(epi_est: Tensor, epi_gt: Optional[Tensor], err_q: Tensor, err_t: Tensor) -> dict:
+    """Device-side reductions of write_metrics_summary (train_good_utils.py:758-856) for one experiment tag: epi_est / epi_gt
+    = epipolar distances of every correspondence (any shape, same numel), err_q / err_t [B] pose errors in degrees.
+    Two launches and ONE device-to-host copy of 280 bytes.  Returns python floats: ratio_0.1, ratio_1, F1_0.1, F1_1 (None
+    without epi_gt), median / max of err_q and err_t, and ratio_q / ratio_t = cumulative fractions below METRIC_THS[1:]."""
+    import numpy as np
+
+    e = _prep(epi_est.reshape(-1), "epi_est")
+    g = None if epi_gt is None else _prep(epi_gt.reshape(-1), "epi_gt")
+    q, t = _prep(err_q.reshape(-1), "err_q"), _prep(err_t.reshape(-1), "err_t")
+    if g is not None and g.numel() != e.numel():
+        raise ValueError("epi_gt must have as many entries as epi_est")
+    if q.numel() != t.numel():
+        raise ValueError("err_q and err_t must have the same length")
+    L = _lib.lib()
+    nbytes = int(L.dfepe_metrics_summary_bytes())
+    out = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=e.device)
+    with torch.cuda.device(e.device):
+        rc = L.dfepe_metrics_summary(_ptr(e) if e.numel() else None, _ptr(g), e.numel(), _ptr(q), _ptr(t), q.numel(), _ptr(out), _stream())
+    _lib.check(rc, "dfepe_metrics_summary")
+    raw = out.cpu().numpy().tobytes()[:nbytes]
+    counts = np.frombuffer(raw, dtype=np.uint64, count=8).astype(np.float64)
+    hist = np.frombuffer(raw, dtype=np.uint64, count=24, offset=64).astype(np.float64).reshape(2, 12)
+    mx = np.frombuffer(raw, dtype=np.float32, count=2, offset=64 + 192)
+    mids = np.frombuffer(raw, dtype=np.float32, count=4, offset=64 + 192 + 8).reshape(2, 2)
+    n, B = max(e.numel(), 1), max(q.numel(), 1)
+
+    def f1(tp, fp, fn):
+        return float(2 * tp / (2 * tp + fp + fn)) if (2 * tp + fp + fn) > 0 else 0.0
+
+    res = {"ratio_0.1": float(counts[0] / n), "ratio_1": float(counts[1] / n),
+           "F1_0.1": f1(*counts[2:5]) if g is not None else None, "F1_1": f1(*counts[5:8]) if g is not None else None,
+           "median_err_q": float(0.5 * (float(mids[0, 0]) + float(mids[0, 1]))), "median_err_t": float(0.5 * (float(mids[1, 0]) + float(mids[1, 1]))),
+           "max_err_q": float(mx[0]), "max_err_t": float(mx[1]),
+           "ratio_q": (np.cumsum(hist[0]) / B).tolist(), "ratio_t": (np.cumsum(hist[1]) / B).tolist()}
+    return res
+
+
+# ------------------------------------------------------------------------------------------------
 # InstanceNorm1d(affine) + LeakyReLU on channel-major activations (weight-estimator fusion, "next" row f-1)
 # ------------------------------------------------------------------------------------------------
 class _InormLReLUFunction(torch.autograd.Function):

@@ -447,3 +447,49 @@ def test_dsac_hypothesis_loop(dfepe, oracle):
     assert d.best_H_idx == int(ref_scores.argmax()) and d.best_corres_idx == idx_list[d.best_H_idx]
     a, r, _ = unit_align(d.best_H.reshape(1, 3, 3).cpu().numpy(), ref_E[d.best_H_idx].reshape(1, 3, 3).numpy())
     assert np.linalg.norm(a - r, axis=1).max() < 1e-3
+
+
+class _Recorder:
+    def __init__(self):
+        self.scalars, self.hists = {}, {}
+
+    def add_scalar(self, tag, value, n_iter):
+        self.scalars[tag] = float(value)
+
+    def add_histogram(self, tag, values, n_iter):
+        self.hists[tag] = np.asarray(values)
+
+
+def test_write_metrics_summary_matches_reference_golden(dfepe, golden):
+    """compat.train_good_utils.write_metrics_summary (counts, F1, medians, maxima, histogram ratios reduced on the device)
+    against every scalar the reference's own write_metrics_summary logged for the same inputs (tests/golden/metrics.npz)."""
+    g = golden("metrics")
+    want = dict(zip([str(t) for t in g["tags"]], g["values"]))
+    d = {}
+    for k in g.files:
+        if k.startswith("in_"):
+            metric, tag = k[3:].rsplit("_", 1)
+            # half as numpy arrays (the reference's layout), half as device tensors
+            d.setdefault(metric, {})[tag] = [a if i % 2 else torch.from_numpy(a).to(DEV) for i, a in enumerate(g[k])]
+    rec = _Recorder()
+    dfepe.compat.train_good_utils.write_metrics_summary(rec, d, "val", 7)
+    assert sorted(rec.scalars) == sorted(want)
+    for tag, v in want.items():
+        assert abs(rec.scalars[tag] - v) < 2e-6 * max(1.0, abs(v)), (tag, rec.scalars[tag], v)
+    assert len(rec.hists) == 9
+
+
+def test_validation_summary_end_to_end(dfepe, oracle):
+    """val_rt_batch + epipolar distances + the summary reductions in one call, against the oracle's numpy summary of the
+    same per-pair tensors."""
+    B, N = 64, 200
+    sc = dfepe.synth.make_scene(B, N, seed=3, outlier_ratio=0.2, noise_px=0.5)
+    E = sc["E_gt"] + 2e-3 * torch.randn(B, 3, 3, generator=torch.Generator().manual_seed(1)) * sc["E_gt"].abs().max()
+    F_est = sc["F_gt"] + 2e-3 * torch.randn(B, 3, 3, generator=torch.Generator().manual_seed(2)) * sc["F_gt"].abs().amax(dim=(1, 2), keepdim=True)
+    sm, pairs = dfepe.compat.train_good_utils.validation_summary(sc["Ks"].to(DEV), sc["matches_xy_ori"].to(DEV), E.to(DEV), F_est.to(DEV),
+                                                                 sc["F_gt"].to(DEV), sc["delta_Rtijs_4_4"].to(DEV))
+    ref = oracle.metrics_summary_np(pairs["epi_dists"].cpu().numpy(), pairs["epi_dists_gt"].cpu().numpy(), pairs["err_R_deg"].cpu().numpy(),
+                                    pairs["err_t_deg"].cpu().numpy())
+    for k, v in ref.items():
+        np.testing.assert_allclose(np.asarray(sm[k]), np.asarray(v), rtol=2e-6, atol=1e-7, err_msg=k)
+    assert sm["ratio_1"] > 0.5 and sm["median_err_q"] < 5.0

@@ -188,3 +188,33 @@ def test_cheirality_select_matches_the_references_own_logic(oracle, golden, case
         else:
             assert win == int(g[f"{case}_winner"][b])
             np.testing.assert_allclose(Rt.numpy(), g[f"{case}_Rt_cam"][b], atol=1e-12)
+
+
+def _metric_inputs(g):
+    d = {}
+    for k in g.files:
+        if k.startswith("in_"):
+            _, rest = k.split("_", 1)
+            metric, tag = rest.rsplit("_", 1)
+            d.setdefault(metric, {})[tag] = [a for a in g[k]]
+    return d
+
+
+def test_metrics_summary_matches_the_references_write_metrics_summary(oracle, golden):
+    """tests/golden/metrics.npz = every scalar the reference's own write_metrics_summary (train_good_utils.py:758-856) logs on
+    seeded inputs (recording writer): pins the oracle's numpy restatement of the validation summary."""
+    g = golden("metrics")
+    want = dict(zip([str(t) for t in g["tags"]], g["values"]))
+    d = _metric_inputs(g)
+    gt = np.stack(d["epi_dists"]["gt"]).flatten()
+    for tag in d["epi_dists"]:
+        sm = oracle.metrics_summary_np(np.stack(d["epi_dists"][tag]), gt, np.stack(d["err_q"][tag]), np.stack(d["err_t"][tag]))
+        assert abs(sm["ratio_0.1"] - want[f"val-Error-epi_dists/{tag}-0.1"]) < 1e-12
+        assert abs(sm["ratio_1"] - want[f"val-Error-epi_dists/{tag}-1"]) < 1e-12
+        assert abs(sm["F1_0.1"] - want[f"val-Error-F1/{tag}-0.1"]) < 1e-12 and abs(sm["F1_1"] - want[f"val-Error-F1/{tag}-1"]) < 1e-12
+        assert abs(sm["median_err_q"] - want[f"val-Error-Median/err_q-{tag}"]) < 1e-12
+        assert abs(sm["median_err_t"] - want[f"val-Error-Median/err_t-{tag}"]) < 1e-12
+        assert abs(sm["max_err_q"] - want[f"val-Error-MAX/err_q_MAX_{tag}"]) < 1e-12
+        for k, th in enumerate(oracle.METRIC_THS[1:]):
+            assert abs(sm["ratio_q"][k] - want[f"val-Error-ratio/ratio_q{th}_{tag}"]) < 1e-12
+            assert abs(sm["ratio_t"][k] - want[f"val-Error-ratio/ratio_t{th}_{tag}"]) < 1e-12
