@@ -229,6 +229,8 @@ geo_misc_kernel(int kind, const float* __restrict__ in0, const float* __restrict
 //   three-term recurrence (for a real-rooted polynomial it climbs monotonically to the smallest root from below, cubic
 //   rate, and does not care whether the outliers' lam4 / lam3 is 1e-7 or 0.9: <= 6 steps on DLT matrices);
 //   eigenvector of T by a twisted factorisation (pivot where |gamma_r| is smallest);  back-transformation.
+// Reciprocals and square roots are the branch-free Newton forms (operands are entries of the scaled normal matrix, far inside
+// the fp32 exponent range the seeds need): the range-checked variants cost a divergent branch each, 20 per DLT.
 // ~6x fewer instructions than the 6-7 cyclic Jacobi sweeps this replaces, same accuracy: scripts/proto_eig4.py checks
 // the algorithm against numpy.linalg.eigh on 16 000 DLT matrices with 25 % outliers (eigenvalue error 7e-16 lam_max,
 // eigenvector error x gap 7e-16, no cheirality decision changed).
@@ -237,11 +239,11 @@ __device__ __forceinline__ double guard_piv(double z, double tiny) { return (fab
 __device__ inline void smallest_eigvec4(const double* S /*4x4 row-major, symmetric*/, double* x) {
   // ---- Householder 1 on (S10, S20, S30)
   const double a0 = S[4], a1 = S[8], a2 = S[12];
-  const double alpha = (a0 < 0.0) ? fast_sqrt(a0 * a0 + a1 * a1 + a2 * a2) : -fast_sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+  const double alpha = (a0 < 0.0) ? sqrt_nr<2>(a0 * a0 + a1 * a1 + a2 * a2) : -sqrt_nr<2>(a0 * a0 + a1 * a1 + a2 * a2);
   const double v0 = a0 - alpha, v1 = a1, v2 = a2;
   const double vv = v0 * v0 + v1 * v1 + v2 * v2;
   const bool ok1 = vv > 0.0;
-  const double beta = ok1 ? 2.0 * fast_rcp(vv) : 0.0;
+  const double beta = ok1 ? 2.0 * rcp_nr<2>(vv) : 0.0;
   const double p0 = beta * (S[5] * v0 + S[6] * v1 + S[7] * v2);
   const double p1 = beta * (S[6] * v0 + S[10] * v1 + S[11] * v2);
   const double p2 = beta * (S[7] * v0 + S[11] * v1 + S[15] * v2);
@@ -251,11 +253,11 @@ __device__ inline void smallest_eigvec4(const double* S /*4x4 row-major, symmetr
   const double B01 = S[6] - v0 * q1 - q0 * v1, B02 = S[7] - v0 * q2 - q0 * v2;
   const double B11 = S[10] - 2.0 * v1 * q1, B12 = S[11] - v1 * q2 - q1 * v2, B22 = S[15] - 2.0 * v2 * q2;
   // ---- Householder 2 on (B10, B20)
-  const double alpha2 = (B01 < 0.0) ? fast_sqrt(B01 * B01 + B02 * B02) : -fast_sqrt(B01 * B01 + B02 * B02);
+  const double alpha2 = (B01 < 0.0) ? sqrt_nr<2>(B01 * B01 + B02 * B02) : -sqrt_nr<2>(B01 * B01 + B02 * B02);
   const double w0 = B01 - alpha2, w1 = B02;
   const double ww = w0 * w0 + w1 * w1;
   const bool ok2 = ww > 0.0;
-  const double beta2 = ok2 ? 2.0 * fast_rcp(ww) : 0.0;
+  const double beta2 = ok2 ? 2.0 * rcp_nr<2>(ww) : 0.0;
   const double r0 = beta2 * (B11 * w0 + B12 * w1), r1 = beta2 * (B12 * w0 + B22 * w1);
   const double k2 = 0.5 * beta2 * (r0 * w0 + r1 * w1);
   const double s0 = r0 - k2 * w0, s1 = r1 - k2 * w1;
@@ -273,10 +275,10 @@ __device__ inline void smallest_eigvec4(const double* S /*4x4 row-major, symmetr
     const double P3 = c2 * P2 - f1 * c0, D3 = c2 * D2 - P2 + f1, E3 = c2 * E2 - 2.0 * D2;
     const double P4 = c3 * P3 - f2 * P2, D4 = c3 * D3 - P3 - f2 * D2, E4 = c3 * E3 - 2.0 * D3 - f2 * E2;
     const bool good = (P4 > 0.0) && !done;  // p <= 0: on the root (or past it by round-off)
-    const double ip = good ? fast_rcp(P4) : 0.0;
+    const double ip = good ? rcp_nr<2>(P4) : 0.0;
     const double G = D4 * ip, H = G * G - E4 * ip;
-    const double den = G - fast_sqrt(fmax(3.0 * (4.0 * H - G * G), 0.0));  // G < 0 left of the smallest root
-    const double step = (good && den < 0.0) ? -4.0 * fast_rcp(den) : 0.0;
+    const double den = G - sqrt_nr<2>(fmax(3.0 * (4.0 * H - G * G), 0.0));  // G < 0 left of the smallest root
+    const double step = (good && den < 0.0) ? -4.0 * rcp_nr<2>(den) : 0.0;
     const double nl = lam + step;
     done = done || !good || !(step > 1e-16 * scale) || (nl == lam);
     if (!done) lam = nl;
@@ -286,13 +288,13 @@ __device__ inline void smallest_eigvec4(const double* S /*4x4 row-major, symmetr
   const double tiny = 1e-300 + 1e-30 * scale;
   const double c0 = d0 - lam, c1 = d1 - lam, c2 = d2 - lam, c3 = d3 - lam;
   const double dp0 = c0;
-  const double i0 = fast_rcp(guard_piv(dp0, tiny)), dp1 = c1 - f0 * i0;
-  const double i1 = fast_rcp(guard_piv(dp1, tiny)), dp2 = c2 - f1 * i1;
-  const double i2 = fast_rcp(guard_piv(dp2, tiny)), dp3 = c3 - f2 * i2;
+  const double i0 = rcp_nr<2>(guard_piv(dp0, tiny)), dp1 = c1 - f0 * i0;
+  const double i1 = rcp_nr<2>(guard_piv(dp1, tiny)), dp2 = c2 - f1 * i1;
+  const double i2 = rcp_nr<2>(guard_piv(dp2, tiny)), dp3 = c3 - f2 * i2;
   const double dm3 = c3;
-  const double j3 = fast_rcp(guard_piv(dm3, tiny)), dm2 = c2 - f2 * j3;
-  const double j2 = fast_rcp(guard_piv(dm2, tiny)), dm1 = c1 - f1 * j2;
-  const double j1 = fast_rcp(guard_piv(dm1, tiny)), dm0 = c0 - f0 * j1;
+  const double j3 = rcp_nr<2>(guard_piv(dm3, tiny)), dm2 = c2 - f2 * j3;
+  const double j2 = rcp_nr<2>(guard_piv(dm2, tiny)), dm1 = c1 - f1 * j2;
+  const double j1 = rcp_nr<2>(guard_piv(dm1, tiny)), dm0 = c0 - f0 * j1;
   const double g0 = fabs(dm0), g1 = fabs(dp1 + dm1 - c1), g2 = fabs(dp2 + dm2 - c2), g3 = fabs(dp3);
   int r = 0;
   double gm = g0;
@@ -361,19 +363,32 @@ cheirality_kernel(const float* __restrict__ E, const float* __restrict__ K, cons
         A[8 + c] = x2 * P2[8 + c] - P2[c];
         A[12 + c] = y2 * P2[8 + c] - P2[4 + c];
       }
+      // normal matrix A^T A (symmetric: 10 distinct entries), scaled to unit trace (the null vector does not care; the
+      // eigen-solver's Newton seeds want O(1) operands whatever the pixel scale)
       double S[16];
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) S[4 * r + c] = A[r] * A[c] + A[4 + r] * A[4 + c] + A[8 + r] * A[8 + c] + A[12 + r] * A[12 + c];
+        for (int c = r; c < 4; ++c) S[4 * r + c] = A[r] * A[c] + A[4 + r] * A[4 + c] + A[8 + r] * A[8 + c] + A[12 + r] * A[12 + c];
+      const double itr = rcp_nr<1>(fmax(S[0] + S[5] + S[10] + S[15], 1e-30));
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = r; c < 4; ++c) { S[4 * r + c] *= itr; S[4 * c + r] = S[4 * r + c]; }
       double X[4];
       smallest_eigvec4(S, X);
-      const double iw = 1.0 / X[3];
-      const double X0 = X[0] * iw, X1 = X[1] * iw, z1 = X[2] * iw;
-      const double z2 = Rc[6] * X0 + Rc[7] * X1 + Rc[8] * z1 + t[2];
+      // depths z1 = X2 / X3 and z2 = (R_3 . X_012 + t_3 X3) / X3 tested without the division: 0 < z < thr  <=>  z' w > 0 and
+      // |z'| < thr |w| for z = z' / w
+      const double wq = X[3];
+      const double z1n = X[2];
+      const double z2n = Rc[6] * X[0] + Rc[7] * X[1] + Rc[8] * X[2] + t[2] * wq;
       const double thr = (double)depth_thres;
-      const bool pos = live && (z1 > 0.0) && (z1 < thr) && (z2 > 0.0) && (z2 < thr);
-      const bool neg = live && (z1 < 0.0) && (z1 > -thr) && (z2 < 0.0) && (z2 > -thr);
+      const double aw = thr * fabs(wq);
+      const bool inr = live && (fabs(z1n) < aw) && (fabs(z2n) < aw) && (wq != 0.0);
+      const bool s1p = (z1n > 0.0) == (wq > 0.0), s2p = (z2n > 0.0) == (wq > 0.0);
+      const bool nz = (z1n != 0.0) && (z2n != 0.0);
+      const bool pos = inr && nz && s1p && s2p;    // both depths in (0, thr)
+      const bool neg = inr && nz && !s1p && !s2p;  // both in (-thr, 0): the (R, -t) candidate sees them in (0, thr)
       cnt[2 * rr] += __popcll(__ballot(pos));
       cnt[2 * rr + 1] += __popcll(__ballot(neg));
     }
@@ -399,7 +414,9 @@ cheirality_kernel(const float* __restrict__ E, const float* __restrict__ K, cons
     }
     if (winner != nullptr) winner[pair] = (cnt[win] > 0) ? win : -1;
     // camera motion = inverse of [R|t]: [R^T | -R^T t]   (utils_misc._inv_Rt, utils_misc.py:115-121)
-    const double* Rc = R[win >> 1];
+    double Rc[9];  // selected by value: a runtime index into R would put the whole array into scratch memory
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rc[k] = (win >> 1) ? R[1][k] : R[0][k];
     const double sg = (win & 1) ? -1.0 : 1.0;
     float* dst = Rt_cam + pair * 12;
 #pragma unroll
