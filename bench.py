@@ -266,8 +266,9 @@ def main():
         kdur_us = event_time_us(fit_call)
         alg_bytes = B * (28 * N + 36)  # read 16N matches + 4N weights; write 36 F + 4N residual + 4N epi  
         achieved = alg_bytes / (kdur_us * 1e-6) / 1e9
-        row_kernel = N <= dfepe._lib.W8PT16_MAX_N
-        kname = "w8pt16_fwd_kernel<raw> (one 16-lane row per pair)" if row_kernel else "w8pt_fwd_kernel<raw> (wavefront / workgroup per pair)"
+        row_kernel = True
+        kname = ("w8pt16_fwd_kernel<raw> (one 16-lane row per pair, correspondences in registers)" if N <= dfepe._lib.W8PT16_MAX_N
+                 else "w8pt16_fwd_kernel<0, raw> (one 16-lane row per pair, correspondences re-read per phase)")
         traffic = issue = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):

@@ -1,4 +1,4 @@
-// w8pt16 -- the row-per-pair kernels of the weighted 8-point fit (N <= 128): launchers.
+// w8pt16 -- the row-per-pair kernels of the weighted 8-point fit: launchers.
 //
 // Grid: one 256-thread workgroup = 16 pairs (4 wavefronts x 4 rows).  B = 4096 pairs -> 256 workgroups = one per CU,
 // one wavefront per SIMD; larger batches stack more wavefronts per SIMD.  No block-level barrier; each pair owns 36
@@ -32,7 +32,8 @@ template <bool RAW, bool PLAIN>
 void launch_fwd(const W8Args& A, hipStream_t st) {
   const dim3 grid((A.B + kPairsPerBlock - 1) / kPairsPerBlock), block(256);
   const int N = A.N;
-  if (N <= 16) hipLaunchKernelGGL((w8pt16_fwd_kernel<1, RAW, PLAIN>), grid, block, 0, st, A);
+  if (N > 128) hipLaunchKernelGGL((w8pt16_fwd_kernel<0, RAW, PLAIN>), grid, block, 0, st, A);  // any N: correspondences re-read per phase
+  else if (N <= 16) hipLaunchKernelGGL((w8pt16_fwd_kernel<1, RAW, PLAIN>), grid, block, 0, st, A);
   else if (N <= 32) hipLaunchKernelGGL((w8pt16_fwd_kernel<2, RAW, PLAIN>), grid, block, 0, st, A);
   else if (N <= 64) hipLaunchKernelGGL((w8pt16_fwd_kernel<4, RAW, PLAIN>), grid, block, 0, st, A);
   else if (N <= 112) hipLaunchKernelGGL((w8pt16_fwd_kernel<7, RAW, PLAIN>), grid, block, 0, st, A);
@@ -43,7 +44,8 @@ template <bool RAW, bool PGRAD>
 void launch_bwd(const W8BwdArgs& A, hipStream_t st) {
   const dim3 grid((A.B + kPairsPerBlock - 1) / kPairsPerBlock), block(256);
   const int N = A.N;
-  if (N <= 16) hipLaunchKernelGGL((w8pt16_bwd_kernel<1, RAW, PGRAD>), grid, block, 0, st, A);
+  if (N > 128) hipLaunchKernelGGL((w8pt16_bwd_kernel<0, RAW, PGRAD>), grid, block, 0, st, A);
+  else if (N <= 16) hipLaunchKernelGGL((w8pt16_bwd_kernel<1, RAW, PGRAD>), grid, block, 0, st, A);
   else if (N <= 32) hipLaunchKernelGGL((w8pt16_bwd_kernel<2, RAW, PGRAD>), grid, block, 0, st, A);
   else if (N <= 64) hipLaunchKernelGGL((w8pt16_bwd_kernel<4, RAW, PGRAD>), grid, block, 0, st, A);
   else if (N <= 112) hipLaunchKernelGGL((w8pt16_bwd_kernel<7, RAW, PGRAD>), grid, block, 0, st, A);
@@ -52,7 +54,7 @@ void launch_bwd(const W8BwdArgs& A, hipStream_t st) {
 
 }  // namespace
 
-// Called by dfepe_w8pt_fwd / dfepe_w8pt_bwd (w8pt_fwd.hip / w8pt_bwd.hip) after argument validation, for N <= DFEPE_W8PT16_MAX_N.
+// Called by dfepe_w8pt_fwd / dfepe_w8pt_bwd (w8pt_fwd.hip / w8pt_bwd.hip) after argument validation.
 int dfepe_w8pt16_fwd_launch(const W8Args& A, bool raw, hipStream_t st) {
   const bool plain = A.variant == 0;
   if (raw) { if (plain) launch_fwd<true, true>(A, st); else launch_fwd<true, false>(A, st); }

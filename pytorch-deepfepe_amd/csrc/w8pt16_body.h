@@ -1,6 +1,6 @@
-// w8pt16 -- weighted normalised 8-point fit with ONE 16-LANE ROW PER IMAGE PAIR (four pairs per wavefront), N <= 128.
+// w8pt16 -- weighted normalised 8-point fit with ONE 16-LANE ROW PER IMAGE PAIR (four pairs per wavefront), any N.
 //
-// Same arithmetic contract as w8pt_fwd.hip (which keeps serving large N):
+// Arithmetic contract:
 //   NormalizeAndExpand_HW   deepFEPE/models/DeepFNet.py:93-120   (fused when RAW)
 //   Fit.normalize           deepFEPE/models/DeepFNet.py:148-179  (Hartley, unit weights, literal 1.4142)
 //   Fit.weighted_svd        deepFEPE/models/DeepFNet.py:181-257
@@ -78,6 +78,45 @@ __device__ __forceinline__ void static_for(Fn&& fn) {
     fn(std::integral_constant<int, I>{});
     static_for<I + 1, E>(fn);
   }
+}
+
+// Loop over a lane's correspondences: fully unrolled when their number IT is a template constant (N <= 128: they live in
+// registers), a run-time loop otherwise (IT = 0: any N, the phases re-read the correspondences from global memory / L2).
+template <int IT, class Fn>
+__device__ __forceinline__ void for_points(int nit, Fn&& fn) {
+  if constexpr (IT > 0) {
+    static_for<0, IT>([&](auto c) { fn((int)decltype(c)::value); });
+  } else {
+    for (int it = 0; it < nit; ++it) fn(it);
+  }
+}
+
+// One correspondence from global memory, image-size normalised (RAW) and sanitised: index clamped into the pair (no branch
+// per correspondence), coordinates zeroed when not finite or past N.  keep = it enters X; valid = it exists.
+template <bool RAW>
+__device__ __forceinline__ void load_point(const float* __restrict__ pts1, const float* __restrict__ pts2, size_t mp, int N, int i,
+                                           float hw_sx, float hw_sy, Pt& p, bool& valid, bool& keep) {
+  valid = i < N;
+  const int ic = valid ? i : N - 1;
+  p.z1 = p.z2 = 1.0f;
+  if (RAW) {
+    const float4 m = reinterpret_cast<const float4*>(pts1)[mp * N + ic];
+    p.x1 = fmaf(m.x, hw_sx, -1.0f);
+    p.y1 = fmaf(m.y, hw_sy, -1.0f);
+    p.x2 = fmaf(m.z, hw_sx, -1.0f);
+    p.y2 = fmaf(m.w, hw_sy, -1.0f);
+  } else {
+    const float* a = pts1 + (mp * N + ic) * 3;
+    const float* b = pts2 + (mp * N + ic) * 3;
+    p.x1 = a[0]; p.y1 = a[1]; p.z1 = a[2];
+    p.x2 = b[0]; p.y2 = b[1]; p.z2 = b[2];
+  }
+  // one comparison: the sum of magnitudes is below the bound only if every coordinate is finite and of sane size
+  float mag = (fabsf(p.x1) + fabsf(p.y1)) + (fabsf(p.x2) + fabsf(p.y2));
+  if (!RAW) mag += fabsf(p.z1) + fabsf(p.z2);
+  keep = valid && (mag < 1e18f);  // false for NaN
+  p.x1 = keep ? p.x1 : 0.0f; p.y1 = keep ? p.y1 : 0.0f; p.x2 = keep ? p.x2 : 0.0f; p.y2 = keep ? p.y2 : 0.0f;
+  if (!RAW) { p.z1 = keep ? p.z1 : 1.0f; p.z2 = keep ? p.z2 : 1.0f; }
 }
 
 // One halving step of the in-row reduce-scatter: CNT live values per lane -> (CNT+1)/2.
@@ -246,7 +285,8 @@ __device__ __forceinline__ void eig9_select(double* Ar, const int l, const int k
 }
 
 // ---- forward, one pair ---------------------------------------------------------------------------------------
-// IT = ceil(N / 16) correspondences per lane, kept in registers.  xch: 36 doubles of LDS owned by this pair.
+// IT = ceil(N / 16) correspondences per lane, kept in registers (N <= 128); IT = 0: any N, correspondences re-read per phase.
+// xch: 36 doubles of LDS owned by this pair.
 // PLAIN: none of the textbook-solver variant flags is set (the hot instantiation carries no test for them).
 template <int IT, bool RAW, bool PLAIN>
 __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair, double* xch) {
@@ -260,85 +300,91 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   // Loads are unconditional (index clamped into the pair, value masked afterwards): no branch per correspondence, all of a
   // lane's loads are in flight together.  A correspondence with a non-finite coordinate or weight is dropped here, once
   // (zero row of X, like the reference's NaN scrub, models/model_utils.py:5-15), so that no later phase needs a guard.
-  Pt pt[IT];
-  float wv[IT];
-  bool kept[IT];
+  // IT > 0: the lane's correspondences and weights stay in registers for the whole kernel (one HBM read).  IT = 0 (N > 128):
+  // every phase re-reads them (16 B per correspondence, L2 hits after the first pass) and re-derives the weight.
+  constexpr int ITR = (IT > 0) ? IT : 1;
+  const int nit = (IT > 0) ? IT : (N + 15) >> 4;
+  Pt pt[ITR];
+  float wv[ITR];
+  bool kept[ITR];
   const float* wsrc = A.wts + (size_t)pair * N;
-#pragma unroll
-  for (int it = 0; it < IT; ++it) {
-    const int i = it * 16 + l;
-    const bool valid = i < N;
-    const int ic = valid ? i : N - 1;
-    Pt p;
-    p.z1 = p.z2 = 1.0f;
-    if (RAW) {
-      const float4 m = reinterpret_cast<const float4*>(A.pts1)[mp * N + ic];
-      p.x1 = fmaf(m.x, A.hw_sx, -1.0f);
-      p.y1 = fmaf(m.y, A.hw_sy, -1.0f);
-      p.x2 = fmaf(m.z, A.hw_sx, -1.0f);
-      p.y2 = fmaf(m.w, A.hw_sy, -1.0f);
-    } else {
-      const float* a = A.pts1 + (mp * N + ic) * 3;
-      const float* b = A.pts2 + (mp * N + ic) * 3;
-      p.x1 = a[0]; p.y1 = a[1]; p.z1 = a[2];
-      p.x2 = b[0]; p.y2 = b[1]; p.z2 = b[2];
-    }
-    float w = wsrc[ic];
-    // one comparison: the sum of magnitudes is below the bound only if every coordinate is finite and of sane size
-    float mag = (fabsf(p.x1) + fabsf(p.y1)) + (fabsf(p.x2) + fabsf(p.y2));
-    if (!RAW) mag += fabsf(p.z1) + fabsf(p.z2);
-    const bool keep = valid && (mag < 1e18f);  // false for NaN
-    p.x1 = keep ? p.x1 : 0.0f; p.y1 = keep ? p.y1 : 0.0f; p.x2 = keep ? p.x2 : 0.0f; p.y2 = keep ? p.y2 : 0.0f;
-    if (!RAW) { p.z1 = keep ? p.z1 : 1.0f; p.z2 = keep ? p.z2 : 1.0f; }
-    if (A.logits_mode) w = valid ? w : -INFINITY;
-    else w = (keep && fabsf(w) < 3e38f) ? w : 0.0f;
-    pt[it] = p;
-    wv[it] = w;
-    kept[it] = keep;
+  float lmax = 0.0f, linv = 1.0f;  // softmax of the logits: w = exp(logit - lmax) * linv
+  if constexpr (IT > 0) {
+    for_points<IT>(nit, [&](int it) {
+      const int i = it * 16 + l;
+      bool valid, keep;
+      load_point<RAW>(A.pts1, A.pts2, mp, N, i, A.hw_sx, A.hw_sy, pt[it], valid, keep);
+      float w = wsrc[valid ? i : N - 1];
+      if (A.logits_mode) w = valid ? w : -INFINITY;
+      else w = (keep && fabsf(w) < 3e38f) ? w : 0.0f;
+      wv[it] = w;
+      kept[it] = keep;
+    });
   }
   if (A.logits_mode) {
     // fused F.softmax(logits, dim=N) (DeepFNet.py:443,512)
     float mx = -INFINITY;
-#pragma unroll
-    for (int it = 0; it < IT; ++it) mx = fmaxf(mx, wv[it]);
-    mx = rg_max(mx);
-    float sm = 0.0f;
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      const float e = expf(wv[it] - mx);  // padding lanes hold -inf: exactly 0
-      wv[it] = e;
-      sm += e;
-    }
-    const float inv = 1.0f / rg_sum(sm);
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      wv[it] *= inv;
+    for_points<IT>(nit, [&](int it) {
       const int i = it * 16 + l;
-      if (A.weights_out != nullptr && i < N) A.weights_out[(size_t)pair * N + i] = wv[it];
-      wv[it] = kept[it] ? wv[it] : 0.0f;  // a dropped correspondence keeps its softmax weight in weights_out, not in X
-    }
+      const float lg = (IT > 0) ? wv[(IT > 0) ? it : 0] : ((i < N) ? wsrc[i] : -INFINITY);
+      mx = fmaxf(mx, lg);
+    });
+    lmax = rg_max(mx);
+    float sm = 0.0f;
+    for_points<IT>(nit, [&](int it) {
+      const int i = it * 16 + l;
+      const float lg = (IT > 0) ? wv[(IT > 0) ? it : 0] : ((i < N) ? wsrc[i] : -INFINITY);
+      const float e = expf(lg - lmax);  // padding lanes hold -inf: exactly 0
+      if (IT > 0) wv[(IT > 0) ? it : 0] = e;
+      sm += e;
+    });
+    linv = 1.0f / rg_sum(sm);
+    for_points<IT>(nit, [&](int it) {
+      const int i = it * 16 + l;
+      const float wgt = ((IT > 0) ? wv[(IT > 0) ? it : 0] : ((i < N) ? expf(wsrc[i] - lmax) : 0.0f)) * linv;
+      if (A.weights_out != nullptr && i < N) A.weights_out[(size_t)pair * N + i] = wgt;
+      // a dropped correspondence keeps its softmax weight in weights_out, not in X
+      if (IT > 0) wv[(IT > 0) ? it : 0] = kept[(IT > 0) ? it : 0] ? wgt : 0.0f;
+    });
   }
+  // the correspondence `it` of this lane as every later phase sees it: coordinates, weight in X, existence
+  auto point = [&](int it, Pt& p, float& w, bool& valid) {
+    if constexpr (IT > 0) {
+      p = pt[it];
+      w = wv[it];
+      valid = it * 16 + l < N;
+    } else {
+      const int i = it * 16 + l;
+      bool keep;
+      load_point<RAW>(A.pts1, A.pts2, mp, N, i, A.hw_sx, A.hw_sy, p, valid, keep);
+      const float raw = wsrc[valid ? i : N - 1];
+      if (A.logits_mode) w = keep ? expf(raw - lmax) * linv : 0.0f;
+      else w = (keep && fabsf(raw) < 3e38f) ? raw : 0.0f;
+    }
+  };
   const bool hartley = (variant & DFEPE_W8PT_NO_HARTLEY) == 0;
   const double invN = 1.0 / (double)N;
   double c1x = 0.0, c1y = 0.0, c2x = 0.0, c2y = 0.0, s1 = 1.0, s2 = 1.0;
   if (hartley) {
     double sx1 = 0, sy1 = 0, sx2 = 0, sy2 = 0;
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {  // lanes past N hold zeros
-      sx1 += (double)pt[it].x1; sy1 += (double)pt[it].y1; sx2 += (double)pt[it].x2; sy2 += (double)pt[it].y2;
-    }
+    for_points<IT>(nit, [&](int it) {  // padding / dropped correspondences hold zeros
+      Pt p; float w; bool valid;
+      point(it, p, w, valid);
+      sx1 += (double)p.x1; sy1 += (double)p.y1; sx2 += (double)p.x2; sy2 += (double)p.y2;
+    });
     c1x = rg_sum(sx1) * invN; c1y = rg_sum(sy1) * invN; c2x = rg_sum(sx2) * invN; c2y = rg_sum(sy2) * invN;
   DFEPE_MARK("P1");
     // ---- phase 1: Hartley scale (mean distance to the centroid) -------------------------------------------------
     double d1 = 0, d2 = 0;
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      const double vm = (it * 16 + l < N) ? 1.0 : 0.0;  // arithmetic mask: no branch around the square roots
-      const double ax = (double)pt[it].x1 - c1x, ay = (double)pt[it].y1 - c1y;
-      const double bx = (double)pt[it].x2 - c2x, by = (double)pt[it].y2 - c2y;
+    for_points<IT>(nit, [&](int it) {
+      Pt p; float w; bool valid;
+      point(it, p, w, valid);
+      const double vm = valid ? 1.0 : 0.0;  // arithmetic mask: no branch around the square roots
+      const double ax = (double)p.x1 - c1x, ay = (double)p.y1 - c1y;
+      const double bx = (double)p.x2 - c2x, by = (double)p.y2 - c2y;
       d1 = fma(vm, sqrt_nr<1>(ax * ax + ay * ay), d1);
       d2 = fma(vm, sqrt_nr<1>(bx * bx + by * by), d2);
-    }
+    });
     // Fit.normalize uses the literal 1.4142, not sqrt(2) (DeepFNet.py:168); utils_F._normalize_XY uses np.sqrt(2)
     const double hscale = (variant & DFEPE_W8PT_SQRT2) ? 1.4142135623730951 : 1.4142;
     s1 = hscale * rcp_nr<2>(rg_sum(d1) * invN);
@@ -350,10 +396,10 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   double acc[36];
 #pragma unroll
   for (int e = 0; e < 36; ++e) acc[e] = 0.0;
-#pragma unroll
-  for (int it = 0; it < IT; ++it) {
-    const Pt p = pt[it];
-    const double w = (double)wv[it];
+  for_points<IT>(nit, [&](int it) {
+    Pt p; float wf; bool valid;
+    point(it, p, wf, valid);
+    const double w = (double)wf;
     const double z1 = p.z1, z2 = p.z2;
     const double a0 = s1 * ((double)p.x1 - c1x * z1), a1 = s1 * ((double)p.y1 - c1y * z1), a2 = z1;
     const double b0 = s2 * ((double)p.x2 - c2x * z2), b1 = s2 * ((double)p.y2 - c2y * z2);
@@ -366,7 +412,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     for (int u = 0; u < 6; ++u)
 #pragma unroll
       for (int v = 0; v < 6; ++v) acc[6 * u + v] = fma(bb[u], aa[v], acc[6 * u + v]);
-  }
+  });
 
   DFEPE_MARK("P3");
   // ---- phase 3: reduce-scatter inside the row (36 -> 18 -> 9 -> 5 -> 3 values per lane), M through LDS --------------
@@ -527,14 +573,14 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   // ---- phase 6: per-correspondence outputs ----------------------------------------------------------------------
   float* rdst = A.residual + (size_t)pair * N;
   float* edst = (A.epi_res != nullptr) ? A.epi_res + (size_t)pair * N : nullptr;
-#pragma unroll
-  for (int it = 0; it < IT; ++it) {
+  for_points<IT>(nit, [&](int it) {
     const int i = it * 16 + l;
-    const Pt p = pt[it];
+    Pt p; float wf; bool valid;
+    point(it, p, wf, valid);
     // residual_i = w_i p^_i . f  (DeepFNet.py:203-214,251); straight-line, only the stores are guarded
     double ra[3], rb[2], inv;
     row_factors(p, s1, c1x, c1y, s2, c2x, c2y, ra, rb, inv);
-    const float r = (float)(row_bilinear(ra, rb, f) * inv * (double)wv[it]);
+    const float r = (float)(row_bilinear(ra, rb, f) * inv * (double)wf);
     // l1 = F^T x2 (row form x2 F), l2 = F x1, dd = x2^T F x1 = x1 . l1     (utils_F.py:402-411), fp32 like the reference
     const float l1x = fmaf(p.x2, of[0], fmaf(p.y2, of[3], p.z2 * of[6]));
     const float l1y = fmaf(p.x2, of[1], fmaf(p.y2, of[4], p.z2 * of[7]));
@@ -545,9 +591,9 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     const float n1 = hw_sqrt(fmaf(l1x, l1x, l1y * l1y)) + 1e-6f;  // v_sqrt_f32 / v_rcp_f32: 1 ulp, far inside the tolerance
     const float m2 = hw_sqrt(fmaf(l2x, l2x, l2y * l2y)) + 1e-6f;
     const float d = fminf(fabsf(dd) * (hw_rcp(n1) + hw_rcp(m2)), A.clamp_at);
-    if (i < N) {
+    if (valid) {
       rdst[i] = r;
       if (edst != nullptr) edst[i] = d;
     }
-  }
+  });
 }

@@ -1,4 +1,4 @@
-// w8pt16 backward -- analytic adjoint of w8pt16_fwd_pair, one 16-lane row per image pair (N <= 128).
+// w8pt16 backward -- analytic adjoint of w8pt16_fwd_pair, one 16-lane row per image pair (any N; IT = 0 re-reads per pass).
 //
 // Replaces torch.autograd's replay of the per-sample torch.svd calls of Fit.weighted_svd
 // (deepFEPE/models/DeepFNet.py:232-256) with closed forms:
@@ -115,40 +115,35 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
   const double inv_tr = sv[S16_INVTR];
   const bool good = sv[S16_TAG] == S16_TAG_VALUE;  // a record of the other forward kernel would be misread: poison instead
 
-  // same unconditional loads and the same drop rule as the forward (w8pt16_fwd_pair, phase 0)
-  Pt pt[IT];
-  float wv[IT];   // the weight (softmax output in logits mode); 0 on padding lanes
-  bool kept[IT];  // false: the forward dropped this correspondence from X
+  // same unconditional loads and the same drop rule as the forward (w8pt16_fwd_pair, phase 0); IT = 0: any N, re-read per pass
+  constexpr int ITR = (IT > 0) ? IT : 1;
+  const int nit = (IT > 0) ? IT : (N + 15) >> 4;
+  Pt pt[ITR];
+  float wv[ITR];   // the weight (softmax output in logits mode); 0 on padding lanes
+  bool kept[ITR];  // false: the forward dropped this correspondence from X
   const float* wsrc = A.wts + (size_t)pair * N;
-#pragma unroll
-  for (int it = 0; it < IT; ++it) {
+  auto fetch = [&](int it, Pt& p, float& w, bool& valid, bool& keep) {
     const int i = it * 16 + l;
-    const bool valid = i < N;
-    const int ic = valid ? i : N - 1;
-    Pt p;
-    p.z1 = p.z2 = 1.0f;
-    if (RAW) {
-      const float4 m = reinterpret_cast<const float4*>(A.pts1)[mp * N + ic];
-      p.x1 = fmaf(m.x, A.hw_sx, -1.0f);
-      p.y1 = fmaf(m.y, A.hw_sy, -1.0f);
-      p.x2 = fmaf(m.z, A.hw_sx, -1.0f);
-      p.y2 = fmaf(m.w, A.hw_sy, -1.0f);
-    } else {
-      const float* a = A.pts1 + (mp * N + ic) * 3;
-      const float* b = A.pts2 + (mp * N + ic) * 3;
-      p.x1 = a[0]; p.y1 = a[1]; p.z1 = a[2];
-      p.x2 = b[0]; p.y2 = b[1]; p.z2 = b[2];
-    }
-    const float w = wsrc[ic];
-    float mag = (fabsf(p.x1) + fabsf(p.y1)) + (fabsf(p.x2) + fabsf(p.y2));
-    if (!RAW) mag += fabsf(p.z1) + fabsf(p.z2);
-    const bool keep = valid && (mag < 1e18f) && (fabsf(w) < 3e38f);
-    p.x1 = keep ? p.x1 : 0.0f; p.y1 = keep ? p.y1 : 0.0f; p.x2 = keep ? p.x2 : 0.0f; p.y2 = keep ? p.y2 : 0.0f;
-    if (!RAW) { p.z1 = keep ? p.z1 : 1.0f; p.z2 = keep ? p.z2 : 1.0f; }
-    pt[it] = p;
-    wv[it] = (valid && fabsf(w) < 3e38f) ? w : 0.0f;
-    kept[it] = keep;
+    load_point<RAW>(A.pts1, A.pts2, mp, N, i, A.hw_sx, A.hw_sy, p, valid, keep);
+    const float raw = wsrc[valid ? i : N - 1];
+    const bool wfin = fabsf(raw) < 3e38f;
+    keep = keep && wfin;
+    w = (valid && wfin) ? raw : 0.0f;
+  };
+  if constexpr (IT > 0) {
+    for_points<IT>(nit, [&](int it) {
+      bool valid;
+      fetch(it, pt[it], wv[it], valid, kept[it]);
+    });
   }
+  auto point = [&](int it, Pt& p, float& w, bool& valid, bool& keep) {
+    if constexpr (IT > 0) {
+      p = pt[it]; w = wv[it]; keep = kept[it];
+      valid = it * 16 + l < N;
+    } else {
+      fetch(it, p, w, valid, keep);
+    }
+  };
 
   DFEPE_MARK("B1_passA");
   // ---- pass A: X^T g_r  and  sum_i g_epi_i d(d_i)/d(out) ---------------------------------------------------------
@@ -164,16 +159,16 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
     float gxf[9], gof[9];
 #pragma unroll
     for (int c = 0; c < 9; ++c) { gxf[c] = 0.0f; gof[c] = 0.0f; }
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
+    for_points<IT>(nit, [&](int it) {
       const int i = it * 16 + l;
-      if (i >= N) continue;
-      const Pt p = pt[it];
+      Pt p; float wf; bool valid, keep;
+      point(it, p, wf, valid, keep);
+      if (!valid) return;
       if (A.g_res != nullptr) {
-        const double w = (double)wv[it];
+        const double w = (double)wf;
         double ra[3], rb[2], inv;
         row_factors(p, s1, c1x, c1y, s2, c2x, c2y, ra, rb, inv);
-        const double gw = kept[it] ? (double)A.g_res[(size_t)pair * N + i] * w * inv : 0.0;
+        const double gw = keep ? (double)A.g_res[(size_t)pair * N + i] * w * inv : 0.0;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const double ga = gw * ra[c];
@@ -207,7 +202,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
             gof[3 * r + c] += (float)(g * t);
           }
       }
-    }
+    });
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
       if (A.g_res != nullptr) gx[c] = (double)rg_sum(gxf[c]);
@@ -328,35 +323,36 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
   DFEPE_MARK("B6_passB");
   // ---- pass B: g_w ---------------------------------------------------------------------------------------------
   float* dst = A.g_w + (size_t)pair * N;
-  float gwv[IT];
+  float gwv[ITR];
   float wg = 0.0f;
-#pragma unroll
-  for (int it = 0; it < IT; ++it) {
+  for_points<IT>(nit, [&](int it) {
     const int i = it * 16 + l;
-    float gwi = 0.0f;
-    if (i < N) {
-      const double w = (double)wv[it];
-      double ra[3], rb[2], inv;
-      row_factors(pt[it], s1, c1x, c1y, s2, c2x, c2y, ra, rb, inv);
-      const bool ok = kept[it];
-      const double a = row_bilinear(ra, rb, f) * inv, b = row_bilinear(ra, rb, u) * inv;  // p^ . f, p^ . u
-      const double gr = (A.g_res != nullptr) ? gsc * (double)A.g_res[(size_t)pair * N + i] : 0.0;
-      gwi = ok ? (float)(2.0 * w * a * b + gr * a) : 0.0f;
-      if (A.g_w_extra != nullptr) gwi += A.g_w_extra[(size_t)pair * N + i];
+    Pt p; float wf; bool valid, keep;
+    point(it, p, wf, valid, keep);
+    double ra[3], rb[2], inv;
+    row_factors(p, s1, c1x, c1y, s2, c2x, c2y, ra, rb, inv);
+    const double w = (double)wf;
+    const double a = row_bilinear(ra, rb, f) * inv, b = row_bilinear(ra, rb, u) * inv;  // p^ . f, p^ . u
+    const double gr = (A.g_res != nullptr && valid) ? gsc * (double)A.g_res[(size_t)pair * N + i] : 0.0;
+    float gwi = keep ? (float)(2.0 * w * a * b + gr * a) : 0.0f;
+    if (A.g_w_extra != nullptr && valid) gwi += A.g_w_extra[(size_t)pair * N + i];
+    gwi = valid ? gwi : 0.0f;
+    wg = fmaf(gwi, wf, wg);
+    if constexpr (IT > 0) gwv[it] = gwi;
+    else if (valid) dst[i] = gwi;  // provisional when the softmax adjoint follows: the same lane re-reads it below
+  });
+  // softmax adjoint g_logit_i = w_i (g_w_i - sum_j w_j g_w_j)
+  const float sdot = A.logits_mode ? rg_sum(wg) : 0.0f;
+  if constexpr (IT > 0) {
+    for_points<IT>(nit, [&](int it) {
+      const int i = it * 16 + l;
+      if (i < N) dst[i] = A.logits_mode ? wv[it] * (gwv[it] - sdot) : gwv[it];
+    });
+  } else if (A.logits_mode) {
+    for (int it = 0; it < nit; ++it) {
+      const int i = it * 16 + l;
+      if (i < N) dst[i] = wsrc[i] * (dst[i] - sdot);
     }
-    gwv[it] = gwi;
-    wg = fmaf(gwi, wv[it], wg);
-  }
-  if (A.logits_mode) {
-    // softmax adjoint g_logit_i = w_i (g_w_i - sum_j w_j g_w_j)
-    const float s = rg_sum(wg);
-#pragma unroll
-    for (int it = 0; it < IT; ++it) gwv[it] = wv[it] * (gwv[it] - s);
-  }
-#pragma unroll
-  for (int it = 0; it < IT; ++it) {
-    const int i = it * 16 + l;
-    if (i < N) dst[i] = gwv[it];
   }
 
   if constexpr (PGRAD) {
@@ -378,19 +374,19 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
     float sums[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) sums[k] = 0.0f;
-    float q1x[IT], q1y[IT], q2x[IT], q2y[IT];
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
+    float q1x[ITR], q1y[ITR], q2x[ITR], q2y[ITR];
+    for_points<IT>(nit, [&](int it) {
       const int i = it * 16 + l;
-      q1x[it] = q1y[it] = q2x[it] = q2y[it] = 0.0f;
-      if (i >= N) continue;
-      const Pt p = pt[it];
-      const double w = (double)wv[it];
+      Pt p; float wf; bool valid, keep;
+      point(it, p, wf, valid, keep);
+      if constexpr (IT > 0) q1x[it] = q1y[it] = q2x[it] = q2y[it] = 0.0f;
+      if (!valid) return;
+      const double w = (double)wf;
       const double z1 = p.z1, z2 = p.z2;
       const double a[3] = {s1 * ((double)p.x1 - c1x * z1), s1 * ((double)p.y1 - c1y * z1), z1};
       const double b0 = s2 * ((double)p.x2 - c2x * z2), b1 = s2 * ((double)p.y2 - c2y * z2);
       const double n2 = (a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) * (b0 * b0 + b1 * b1 + 1.0);
-      const bool ok = kept[it] && (n2 > 1e-24);
+      const bool ok = keep && (n2 > 1e-24);
       const double inv = ok ? rsqrt_nr<1>(n2) : 0.0;
       double ph[9];
 #pragma unroll
@@ -428,8 +424,18 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
         }
       }
       // provisional values; the Hartley terms are added below once their sums over the pair are known
-      q1x[it] = (float)(s1 * ga0 + e1[0]); q1y[it] = (float)(s1 * ga1 + e1[1]);
-      q2x[it] = (float)(s2 * gb0 + e2[0]); q2y[it] = (float)(s2 * gb1 + e2[1]);
+      const float p1x = (float)(s1 * ga0 + e1[0]), p1y = (float)(s1 * ga1 + e1[1]);
+      const float p2x = (float)(s2 * gb0 + e2[0]), p2y = (float)(s2 * gb1 + e2[1]);
+      if constexpr (IT > 0) {
+        q1x[it] = p1x; q1y[it] = p1y; q2x[it] = p2x; q2y[it] = p2y;
+      } else if (RAW) {  // parked in the output: the same lane finishes them in the second pass
+        float4 q; q.x = p1x; q.y = p1y; q.z = p2x; q.w = p2y;
+        reinterpret_cast<float4*>(A.g_p1)[(size_t)pair * N + i] = q;
+      } else {
+        float* d1 = A.g_p1 + ((size_t)pair * N + i) * 3;
+        float* d2 = A.g_p2 + ((size_t)pair * N + i) * 3;
+        d1[0] = p1x; d1[1] = p1y; d2[0] = p2x; d2[1] = p2y;
+      }
       if (!RAW) {
         A.g_p1[((size_t)pair * N + i) * 3 + 2] = (float)(ga2 - s1 * (c1x * ga0 + c1y * ga1) + e1[2]);
         A.g_p2[((size_t)pair * N + i) * 3 + 2] = (float)(-s2 * (c2x * gb0 + c2y * gb1) + e2[2]);
@@ -445,7 +451,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
       sums[5] += (float)(-s2 * z2 * gb1);
       sums[6] += (float)(dx1 * ir1); sums[7] += (float)(dy1 * ir1);
       sums[8] += (float)(dx2 * ir2); sums[9] += (float)(dy2 * ir2);
-    }
+    });
     double tot[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) tot[k] = (double)rg_sum(sums[k]);
@@ -455,26 +461,36 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
     const double Gd1 = -Gs1 * s1 * s1 / kH, Gd2 = -Gs2 * s2 * s2 / kH;   // s = k / dbar
     const double Gc1x = (tot[1] - s1 * gT1[2] - Gd1 * invN * tot[6]) * invN, Gc1y = (tot[2] - s1 * gT1[5] - Gd1 * invN * tot[7]) * invN;
     const double Gc2x = (tot[4] - s2 * gT2[2] - Gd2 * invN * tot[8]) * invN, Gc2y = (tot[5] - s2 * gT2[5] - Gd2 * invN * tot[9]) * invN;
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
+    for_points<IT>(nit, [&](int it) {
       const int i = it * 16 + l;
-      if (i >= N) continue;
-      const Pt p = pt[it];
+      Pt p; float wf; bool valid, keep;
+      point(it, p, wf, valid, keep);
+      if (!valid) return;
       const double dx1 = (double)p.x1 - c1x, dy1 = (double)p.y1 - c1y, dx2 = (double)p.x2 - c2x, dy2 = (double)p.y2 - c2y;
       const double r1 = dx1 * dx1 + dy1 * dy1, r2 = dx2 * dx2 + dy2 * dy2;
       const double ir1 = (r1 > 0.0) ? rsqrt_nr<1>(r1) : 0.0, ir2 = (r2 > 0.0) ? rsqrt_nr<1>(r2) : 0.0;
       const float a1x = (float)(Gd1 * invN * dx1 * ir1 + Gc1x), a1y = (float)(Gd1 * invN * dy1 * ir1 + Gc1y);
       const float a2x = (float)(Gd2 * invN * dx2 * ir2 + Gc2x), a2y = (float)(Gd2 * invN * dy2 * ir2 + Gc2y);
+      float p1x, p1y, p2x, p2y;  // the provisional values of the first pass
+      if constexpr (IT > 0) {
+        p1x = q1x[it]; p1y = q1y[it]; p2x = q2x[it]; p2y = q2y[it];
+      } else if (RAW) {
+        const float4 q = reinterpret_cast<const float4*>(A.g_p1)[(size_t)pair * N + i];
+        p1x = q.x; p1y = q.y; p2x = q.z; p2y = q.w;
+      } else {
+        p1x = A.g_p1[((size_t)pair * N + i) * 3]; p1y = A.g_p1[((size_t)pair * N + i) * 3 + 1];
+        p2x = A.g_p2[((size_t)pair * N + i) * 3]; p2y = A.g_p2[((size_t)pair * N + i) * 3 + 1];
+      }
       if (RAW) {
         float4 q;  // chain through x^ = 2x/W - 1
-        q.x = (q1x[it] + a1x) * A.hw_sx; q.y = (q1y[it] + a1y) * A.hw_sy; q.z = (q2x[it] + a2x) * A.hw_sx; q.w = (q2y[it] + a2y) * A.hw_sy;
+        q.x = (p1x + a1x) * A.hw_sx; q.y = (p1y + a1y) * A.hw_sy; q.z = (p2x + a2x) * A.hw_sx; q.w = (p2y + a2y) * A.hw_sy;
         reinterpret_cast<float4*>(A.g_p1)[(size_t)pair * N + i] = q;
       } else {
         float* d1 = A.g_p1 + ((size_t)pair * N + i) * 3;
         float* d2 = A.g_p2 + ((size_t)pair * N + i) * 3;
-        d1[0] = q1x[it] + a1x; d1[1] = q1y[it] + a1y; d2[0] = q2x[it] + a2x; d2[1] = q2y[it] + a2y;
+        d1[0] = p1x + a1x; d1[1] = p1y + a1y; d2[0] = p2x + a2x; d2[1] = p2y + a2y;
       }
-    }
+    });
   }
 }
 

@@ -762,7 +762,7 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
   if (raw && (reinterpret_cast<uintptr_t>(pts1) & 15u)) return DFEPE_ERR_INVALID_ARG;  // float4 loads
 
   if (flags & ~DFEPE_W8PT_ALL_FLAGS) return DFEPE_ERR_INVALID_ARG;  // unknown flag bits are rejected, not ignored
-  if (N <= DFEPE_W8PT16_MAX_N && !(flags & DFEPE_W8PT_WAVE_PER_PAIR)) {
+  if (!(flags & DFEPE_W8PT_WAVE_PER_PAIR)) {
     // small N: one 16-lane row per pair, correspondences in registers, fp64 tridiagonal eigen-solver (w8pt16.hip)
     W8Args A;
     A.pts1 = pts1; A.pts2 = pts2; A.wts = weights;

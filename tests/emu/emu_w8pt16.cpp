@@ -61,7 +61,8 @@ int dispatch(const Args& A, int B, int N, bool raw) {
       run_row([&]() { Body<decltype(itc)::value, decltype(rawc)::value>::run(A, pair, xch); });
     };
     auto with_it = [&](auto rawc) {
-      if (N <= 16) go(std::integral_constant<int, 1>{}, rawc);
+      if (N > 128) go(std::integral_constant<int, 0>{}, rawc);
+      else if (N <= 16) go(std::integral_constant<int, 1>{}, rawc);
       else if (N <= 32) go(std::integral_constant<int, 2>{}, rawc);
       else if (N <= 64) go(std::integral_constant<int, 4>{}, rawc);
       else if (N <= 112) go(std::integral_constant<int, 7>{}, rawc);
@@ -87,7 +88,7 @@ struct BwdBody {
 extern "C" int emu_w8pt16_fwd(const float* pts1, const float* pts2, const float* weights, int B, int N, int n_weight_sets,
                               unsigned flags, float image_w, float image_h, float clamp_at, float* F_out, float* residual,
                               float* epi_res, float* save, float* weights_out) {
-  if (N < 1 || N > 128) return -3;
+  if (N < 1) return -3;
   const bool raw = (flags & DFEPE_W8PT_RAW_MATCHES) != 0;
   W8Args A;
   A.pts1 = pts1; A.pts2 = pts2; A.wts = weights;
@@ -103,7 +104,7 @@ extern "C" int emu_w8pt16_bwd(const float* pts1, const float* pts2, const float*
                               unsigned flags, float image_w, float image_h, float clamp_at, const float* save,
                               const float* F_out, const float* g_F, const float* g_residual, const float* g_epi,
                               const float* g_weights_extra, const float* g_scale, float* g_weights, float* g_pts1, float* g_pts2) {
-  if (N < 1 || N > 128) return -3;
+  if (N < 1) return -3;
   const bool raw = (flags & DFEPE_W8PT_RAW_MATCHES) != 0;
   W8BwdArgs A;
   A.pts1 = pts1; A.pts2 = pts2; A.wts = weights;
