@@ -57,7 +57,8 @@ extern "C" {
                                         kernels (fp32 Jacobi + fp64 polish, correspondences staged in LDS, N <= ~8000) instead of
                                         the row-per-pair kernels (one 16-lane DPP row per pair, four pairs per wavefront, fp64
                                         tridiagonal eigen-solver, any N); pass the same bit to dfepe_w8pt_bwd, whose `save`
-                                        record format follows the forward kernel.  Kept for A/B measurements.            */
+                                        record format follows the forward kernel.  Without the bit the library picks: rows for
+                                        N <= DFEPE_W8PT16_MAX_N and for any N once the launch has >= 2048 pairs, else these. */
 #define DFEPE_W8PT_ALL_FLAGS 127u   /* any other bit in `flags` is DFEPE_ERR_INVALID_ARG                              */
 #define DFEPE_W8PT16_MAX_N 128      /* largest N whose correspondences the row-per-pair kernels keep in registers for the whole
                                        kernel (one HBM read); larger N re-reads them per phase (L2 hits)                 */

@@ -48,6 +48,15 @@
 #define S16_TAG 127    // record format tag
 #define S16_TAG_VALUE 16.0f
 
+// Which kernel family serves a launch -- the forward and the backward must agree, their `save` records differ.  Rows
+// (this file) whenever the correspondences fit the registers (N <= 128), and for larger N when the batch fills the GPU
+// (measured at N = 1000: 78 us against 129 us at 4096 pairs, but 68 us against 39 us at 512 pairs, where the round-1
+// cooperative workgroup per pair spreads one pair over four wavefronts).
+inline bool dfepe_w8pt_use_rows(int N, long long pairs, unsigned flags) {
+  if (flags & DFEPE_W8PT_WAVE_PER_PAIR) return false;
+  return N <= DFEPE_W8PT16_MAX_N || pairs >= 2048;
+}
+
 __host__ __device__ constexpr int s16_hv_off(int k) { return 8 * k - (k * (k - 1)) / 2; }
 
 struct W8Args {
@@ -80,36 +89,76 @@ __device__ __forceinline__ void static_for(Fn&& fn) {
   }
 }
 
-// Loop over a lane's correspondences: fully unrolled when their number IT is a template constant (N <= 128: they live in
-// registers), a run-time loop otherwise (IT = 0: any N, the phases re-read the correspondences from global memory / L2).
-template <int IT, class Fn>
-__device__ __forceinline__ void for_points(int nit, Fn&& fn) {
+// One correspondence as a phase sees it: coordinates (zeros when dropped or padding), weight, existence, membership in X.
+struct PRec {
+  Pt p;
+  float w;   // weight in X (0 when dropped or padding)
+  float ws;  // softmax weight before the drop mask (logits mode, looped kernel)
+  bool valid, keep;
+};
+
+// What one correspondence costs in global loads: RAW: (x1,y1,x2,y2) as one float4 + one weight-like float; otherwise two
+// homogeneous points + the weight.  v[7] is spare (the backward parks a provisional gradient there).
+struct RawRec {
+  float v[8];
+};
+
+// Loop over a lane's correspondences.  IT > 0 (N <= 128, they live in registers): fully unrolled.  IT = 0 (any N): chunks of
+// eight, double-buffered on the RAW loads -- load(it) only issues global loads (index clamped: it may lie past the end),
+// decode(it, raw) does all dependent arithmetic.  The next chunk's loads are issued before the current chunk is decoded and
+// consumed, so their latency (a wavefront alone on its SIMD has nothing else to hide it behind) overlaps a chunk of work.
+constexpr int kPointChunk = 8;
+template <int IT, class Load, class Decode, class Fn>
+__device__ __forceinline__ void for_points(int nit, Load&& load, Decode&& decode, Fn&& fn) {
   if constexpr (IT > 0) {
-    static_for<0, IT>([&](auto c) { fn((int)decltype(c)::value); });
+    static_for<0, IT>([&](auto c) {
+      constexpr int it = decltype(c)::value;
+      const PRec r = decode(it, load(it));
+      fn(it, r);
+    });
   } else {
-    for (int it = 0; it < nit; ++it) fn(it);
+    RawRec cur[kPointChunk], nxt[kPointChunk];
+#pragma unroll
+    for (int j = 0; j < kPointChunk; ++j) cur[j] = load(j);
+    for (int base = 0; base < nit; base += kPointChunk) {
+#pragma unroll
+      for (int j = 0; j < kPointChunk; ++j) nxt[j] = load(base + kPointChunk + j);
+#pragma unroll
+      for (int j = 0; j < kPointChunk; ++j) fn(base + j, decode(base + j, cur[j]));
+#pragma unroll
+      for (int j = 0; j < kPointChunk; ++j) cur[j] = nxt[j];
+    }
   }
 }
 
-// One correspondence from global memory, image-size normalised (RAW) and sanitised: index clamped into the pair (no branch
-// per correspondence), coordinates zeroed when not finite or past N.  keep = it enters X; valid = it exists.
+// The coordinates of correspondence i (clamped into the pair: no branch per correspondence) as loaded ...
 template <bool RAW>
-__device__ __forceinline__ void load_point(const float* __restrict__ pts1, const float* __restrict__ pts2, size_t mp, int N, int i,
-                                           float hw_sx, float hw_sy, Pt& p, bool& valid, bool& keep) {
-  valid = i < N;
-  const int ic = valid ? i : N - 1;
-  p.z1 = p.z2 = 1.0f;
+__device__ __forceinline__ void load_point_raw(const float* __restrict__ pts1, const float* __restrict__ pts2, size_t mp, int N, int i,
+                                               RawRec& r) {
+  const int ic = (i < N) ? i : N - 1;
   if (RAW) {
     const float4 m = reinterpret_cast<const float4*>(pts1)[mp * N + ic];
-    p.x1 = fmaf(m.x, hw_sx, -1.0f);
-    p.y1 = fmaf(m.y, hw_sy, -1.0f);
-    p.x2 = fmaf(m.z, hw_sx, -1.0f);
-    p.y2 = fmaf(m.w, hw_sy, -1.0f);
+    r.v[0] = m.x; r.v[1] = m.y; r.v[2] = m.z; r.v[3] = m.w;
   } else {
     const float* a = pts1 + (mp * N + ic) * 3;
     const float* b = pts2 + (mp * N + ic) * 3;
-    p.x1 = a[0]; p.y1 = a[1]; p.z1 = a[2];
-    p.x2 = b[0]; p.y2 = b[1]; p.z2 = b[2];
+    r.v[0] = a[0]; r.v[1] = a[1]; r.v[2] = a[2]; r.v[3] = b[0]; r.v[4] = b[1]; r.v[5] = b[2];
+  }
+}
+// ... and decoded: image-size normalised (RAW) and sanitised, coordinates zeroed when not finite or past N.
+// keep = it enters X; valid = it exists.
+template <bool RAW>
+__device__ __forceinline__ void decode_point(const RawRec& r, int N, int i, float hw_sx, float hw_sy, Pt& p, bool& valid, bool& keep) {
+  valid = i < N;
+  p.z1 = p.z2 = 1.0f;
+  if (RAW) {
+    p.x1 = fmaf(r.v[0], hw_sx, -1.0f);
+    p.y1 = fmaf(r.v[1], hw_sy, -1.0f);
+    p.x2 = fmaf(r.v[2], hw_sx, -1.0f);
+    p.y2 = fmaf(r.v[3], hw_sy, -1.0f);
+  } else {
+    p.x1 = r.v[0]; p.y1 = r.v[1]; p.z1 = r.v[2];
+    p.x2 = r.v[3]; p.y2 = r.v[4]; p.z2 = r.v[5];
   }
   // one comparison: the sum of magnitudes is below the bound only if every coordinate is finite and of sane size
   float mag = (fabsf(p.x1) + fabsf(p.y1)) + (fabsf(p.x2) + fabsf(p.y2));
@@ -117,6 +166,13 @@ __device__ __forceinline__ void load_point(const float* __restrict__ pts1, const
   keep = valid && (mag < 1e18f);  // false for NaN
   p.x1 = keep ? p.x1 : 0.0f; p.y1 = keep ? p.y1 : 0.0f; p.x2 = keep ? p.x2 : 0.0f; p.y2 = keep ? p.y2 : 0.0f;
   if (!RAW) { p.z1 = keep ? p.z1 : 1.0f; p.z2 = keep ? p.z2 : 1.0f; }
+}
+template <bool RAW>
+__device__ __forceinline__ void load_point(const float* __restrict__ pts1, const float* __restrict__ pts2, size_t mp, int N, int i,
+                                           float hw_sx, float hw_sy, Pt& p, bool& valid, bool& keep) {
+  RawRec r;
+  load_point_raw<RAW>(pts1, pts2, mp, N, i, r);
+  decode_point<RAW>(r, N, i, hw_sx, hw_sy, p, valid, keep);
 }
 
 // One halving step of the in-row reduce-scatter: CNT live values per lane -> (CNT+1)/2.
@@ -303,6 +359,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   // IT > 0: the lane's correspondences and weights stay in registers for the whole kernel (one HBM read).  IT = 0 (N > 128):
   // every phase re-reads them (16 B per correspondence, L2 hits after the first pass) and re-derives the weight.
   constexpr int ITR = (IT > 0) ? IT : 1;
+  constexpr int kWi = RAW ? 4 : 6;  // slot of the weight-like value in a RawRec
   const int nit = (IT > 0) ? IT : (N + 15) >> 4;
   Pt pt[ITR];
   float wv[ITR];
@@ -310,7 +367,8 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   const float* wsrc = A.wts + (size_t)pair * N;
   float lmax = 0.0f, linv = 1.0f;  // softmax of the logits: w = exp(logit - lmax) * linv
   if constexpr (IT > 0) {
-    for_points<IT>(nit, [&](int it) {
+    static_for<0, IT>([&](auto c) {
+      constexpr int it = decltype(c)::value;
       const int i = it * 16 + l;
       bool valid, keep;
       load_point<RAW>(A.pts1, A.pts2, mp, N, i, A.hw_sx, A.hw_sy, pt[it], valid, keep);
@@ -323,63 +381,100 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   }
   if (A.logits_mode) {
     // fused F.softmax(logits, dim=N) (DeepFNet.py:443,512)
+    // the raw logit of correspondence `it` of this lane, -inf past the end
+    auto logit_load = [&](int it) {
+      RawRec r;
+      if constexpr (IT == 0) {
+        const int i = it * 16 + l;
+        r.v[kWi] = wsrc[(i < N) ? i : N - 1];
+      }
+      return r;
+    };
+    auto logit = [&](int it, const RawRec& raw) {
+      PRec r;
+      if constexpr (IT > 0) r.w = wv[it];
+      else r.w = (it * 16 + l < N) ? raw.v[kWi] : -INFINITY;
+      return r;
+    };
     float mx = -INFINITY;
-    for_points<IT>(nit, [&](int it) {
-      const int i = it * 16 + l;
-      const float lg = (IT > 0) ? wv[(IT > 0) ? it : 0] : ((i < N) ? wsrc[i] : -INFINITY);
-      mx = fmaxf(mx, lg);
-    });
+    for_points<IT>(nit, logit_load, logit, [&](int it, const PRec& r) { mx = fmaxf(mx, r.w); });
     lmax = rg_max(mx);
-    float sm = 0.0f;
-    for_points<IT>(nit, [&](int it) {
-      const int i = it * 16 + l;
-      const float lg = (IT > 0) ? wv[(IT > 0) ? it : 0] : ((i < N) ? wsrc[i] : -INFINITY);
-      const float e = expf(lg - lmax);  // padding lanes hold -inf: exactly 0
-      if (IT > 0) wv[(IT > 0) ? it : 0] = e;
-      sm += e;
-    });
-    linv = 1.0f / rg_sum(sm);
-    for_points<IT>(nit, [&](int it) {
-      const int i = it * 16 + l;
-      const float wgt = ((IT > 0) ? wv[(IT > 0) ? it : 0] : ((i < N) ? expf(wsrc[i] - lmax) : 0.0f)) * linv;
-      if (A.weights_out != nullptr && i < N) A.weights_out[(size_t)pair * N + i] = wgt;
-      // a dropped correspondence keeps its softmax weight in weights_out, not in X
-      if (IT > 0) wv[(IT > 0) ? it : 0] = kept[(IT > 0) ? it : 0] ? wgt : 0.0f;
-    });
+    if constexpr (IT > 0) {
+      float sm = 0.0f;
+      static_for<0, IT>([&](auto c) {
+        constexpr int it = decltype(c)::value;
+        const float e = expf(wv[it] - lmax);  // padding lanes hold -inf: exactly 0
+        wv[it] = e;
+        sm += e;
+      });
+      linv = 1.0f / rg_sum(sm);
+      static_for<0, IT>([&](auto c) {
+        constexpr int it = decltype(c)::value;
+        const int i = it * 16 + l;
+        const float wgt = wv[it] * linv;
+        if (A.weights_out != nullptr && i < N) A.weights_out[(size_t)pair * N + i] = wgt;
+        wv[it] = kept[it] ? wgt : 0.0f;  // a dropped correspondence keeps its softmax weight in weights_out, not in X
+      });
+    }
+    // IT = 0: the sum of exponentials rides on the centroid pass below, the weights are written by the moments pass
   }
   // the correspondence `it` of this lane as every later phase sees it: coordinates, weight in X, existence
-  auto point = [&](int it, Pt& p, float& w, bool& valid) {
+  // Looped kernel (IT = 0), logits mode: pass 1 needs exp(logit - max) of every existing correspondence (stage 0), the moments
+  // pass the normalised weight (stage 1, which also writes weights_out), the output pass reads weights_out back when the
+  // caller provided it (stage 2; written by this very lane) instead of a third exponential.
+  int wstage = 0;
+  auto point_load = [&](int it) {
+    RawRec r;
+    if constexpr (IT == 0) {
+      const int i = it * 16 + l;
+      load_point_raw<RAW>(A.pts1, A.pts2, mp, N, i, r);
+      const float* wp = (A.logits_mode && wstage == 2 && A.weights_out != nullptr) ? A.weights_out + (size_t)pair * N : wsrc;
+      r.v[kWi] = wp[(i < N) ? i : N - 1];
+    }
+    return r;
+  };
+  auto point = [&](int it, const RawRec& raw) {
+    PRec r;
     if constexpr (IT > 0) {
-      p = pt[it];
-      w = wv[it];
-      valid = it * 16 + l < N;
+      r.p = pt[it];
+      r.w = wv[it];
+      r.ws = wv[it];
+      r.valid = it * 16 + l < N;
+      r.keep = kept[it];
     } else {
       const int i = it * 16 + l;
-      bool keep;
-      load_point<RAW>(A.pts1, A.pts2, mp, N, i, A.hw_sx, A.hw_sy, p, valid, keep);
-      const float raw = wsrc[valid ? i : N - 1];
-      if (A.logits_mode) w = keep ? expf(raw - lmax) * linv : 0.0f;
-      else w = (keep && fabsf(raw) < 3e38f) ? raw : 0.0f;
+      decode_point<RAW>(raw, N, i, A.hw_sx, A.hw_sy, r.p, r.valid, r.keep);
+      const float wr = raw.v[kWi];
+      if (A.logits_mode) {
+        r.ws = (wstage == 2 && A.weights_out != nullptr) ? wr : expf(wr - lmax) * linv;  // linv = 1 until the sum is known
+        r.ws = r.valid ? r.ws : 0.0f;
+        r.w = r.keep ? r.ws : 0.0f;
+      } else {
+        r.w = (r.keep && fabsf(wr) < 3e38f) ? wr : 0.0f;
+        r.ws = r.w;
+      }
     }
+    return r;
   };
   const bool hartley = (variant & DFEPE_W8PT_NO_HARTLEY) == 0;
   const double invN = 1.0 / (double)N;
   double c1x = 0.0, c1y = 0.0, c2x = 0.0, c2y = 0.0, s1 = 1.0, s2 = 1.0;
   if (hartley) {
     double sx1 = 0, sy1 = 0, sx2 = 0, sy2 = 0;
-    for_points<IT>(nit, [&](int it) {  // padding / dropped correspondences hold zeros
-      Pt p; float w; bool valid;
-      point(it, p, w, valid);
+    float sme = 0.0f;
+    for_points<IT>(nit, point_load, point, [&](int it, const PRec& r) {  // padding / dropped correspondences hold zeros
+      const Pt& p = r.p;
       sx1 += (double)p.x1; sy1 += (double)p.y1; sx2 += (double)p.x2; sy2 += (double)p.y2;
+      sme += r.ws;
     });
+    if (IT == 0 && A.logits_mode) linv = 1.0f / rg_sum(sme);
     c1x = rg_sum(sx1) * invN; c1y = rg_sum(sy1) * invN; c2x = rg_sum(sx2) * invN; c2y = rg_sum(sy2) * invN;
   DFEPE_MARK("P1");
     // ---- phase 1: Hartley scale (mean distance to the centroid) -------------------------------------------------
     double d1 = 0, d2 = 0;
-    for_points<IT>(nit, [&](int it) {
-      Pt p; float w; bool valid;
-      point(it, p, w, valid);
-      const double vm = valid ? 1.0 : 0.0;  // arithmetic mask: no branch around the square roots
+    for_points<IT>(nit, point_load, point, [&](int it, const PRec& r) {
+      const Pt& p = r.p;
+      const double vm = r.valid ? 1.0 : 0.0;  // arithmetic mask: no branch around the square roots
       const double ax = (double)p.x1 - c1x, ay = (double)p.y1 - c1y;
       const double bx = (double)p.x2 - c2x, by = (double)p.y2 - c2y;
       d1 = fma(vm, sqrt_nr<1>(ax * ax + ay * ay), d1);
@@ -391,15 +486,20 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     s2 = hscale * rcp_nr<2>(rg_sum(d2) * invN);
   }
 
+  if (IT == 0 && A.logits_mode && !hartley) {
+    float sme = 0.0f;
+    for_points<IT>(nit, point_load, point, [&](int it, const PRec& r) { sme += r.ws; });
+    linv = 1.0f / rg_sum(sme);
+  }
+  wstage = 1;
   DFEPE_MARK("P2");
   // ---- phase 2: X^T X = sum_i k_i^2 (b b^T) (x) (a a^T): 36 distinct fp64 sums per lane ---------------------------
   double acc[36];
 #pragma unroll
   for (int e = 0; e < 36; ++e) acc[e] = 0.0;
-  for_points<IT>(nit, [&](int it) {
-    Pt p; float wf; bool valid;
-    point(it, p, wf, valid);
-    const double w = (double)wf;
+  for_points<IT>(nit, point_load, point, [&](int it, const PRec& r) {
+    const Pt& p = r.p;
+    const double w = (double)r.w;
     const double z1 = p.z1, z2 = p.z2;
     const double a0 = s1 * ((double)p.x1 - c1x * z1), a1 = s1 * ((double)p.y1 - c1y * z1), a2 = z1;
     const double b0 = s2 * ((double)p.x2 - c2x * z2), b1 = s2 * ((double)p.y2 - c2y * z2);
@@ -412,7 +512,11 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     for (int u = 0; u < 6; ++u)
 #pragma unroll
       for (int v = 0; v < 6; ++v) acc[6 * u + v] = fma(bb[u], aa[v], acc[6 * u + v]);
+    if constexpr (IT == 0) {
+      if (A.logits_mode && A.weights_out != nullptr && r.valid) A.weights_out[(size_t)pair * N + it * 16 + l] = r.ws;
+    }
   });
+  wstage = 2;
 
   DFEPE_MARK("P3");
   // ---- phase 3: reduce-scatter inside the row (36 -> 18 -> 9 -> 5 -> 3 values per lane), M through LDS --------------
@@ -573,10 +677,11 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   // ---- phase 6: per-correspondence outputs ----------------------------------------------------------------------
   float* rdst = A.residual + (size_t)pair * N;
   float* edst = (A.epi_res != nullptr) ? A.epi_res + (size_t)pair * N : nullptr;
-  for_points<IT>(nit, [&](int it) {
+  for_points<IT>(nit, point_load, point, [&](int it, const PRec& rec) {
     const int i = it * 16 + l;
-    Pt p; float wf; bool valid;
-    point(it, p, wf, valid);
+    const Pt& p = rec.p;
+    const float wf = rec.w;
+    const bool valid = rec.valid;
     // residual_i = w_i p^_i . f  (DeepFNet.py:203-214,251); straight-line, only the stores are guarded
     double ra[3], rb[2], inv;
     row_factors(p, s1, c1x, c1y, s2, c2x, c2y, ra, rb, inv);

@@ -122,26 +122,44 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
   float wv[ITR];   // the weight (softmax output in logits mode); 0 on padding lanes
   bool kept[ITR];  // false: the forward dropped this correspondence from X
   const float* wsrc = A.wts + (size_t)pair * N;
-  auto fetch = [&](int it, Pt& p, float& w, bool& valid, bool& keep) {
+  constexpr int kWi = RAW ? 4 : 6;  // slot of the weight in a RawRec
+  auto point_load = [&](int it) {
+    RawRec r;
     const int i = it * 16 + l;
-    load_point<RAW>(A.pts1, A.pts2, mp, N, i, A.hw_sx, A.hw_sy, p, valid, keep);
-    const float raw = wsrc[valid ? i : N - 1];
-    const bool wfin = fabsf(raw) < 3e38f;
-    keep = keep && wfin;
-    w = (valid && wfin) ? raw : 0.0f;
+    load_point_raw<RAW>(A.pts1, A.pts2, mp, N, i, r);
+    r.v[kWi] = wsrc[(i < N) ? i : N - 1];
+    return r;
+  };
+  auto point_decode = [&](int it, const RawRec& raw) {
+    PRec r;
+    const int i = it * 16 + l;
+    decode_point<RAW>(raw, N, i, A.hw_sx, A.hw_sy, r.p, r.valid, r.keep);
+    const float wr = raw.v[kWi];
+    const bool wfin = fabsf(wr) < 3e38f;
+    r.keep = r.keep && wfin;
+    r.w = (r.valid && wfin) ? wr : 0.0f;
+    r.ws = r.w;
+    return r;
   };
   if constexpr (IT > 0) {
-    for_points<IT>(nit, [&](int it) {
-      bool valid;
-      fetch(it, pt[it], wv[it], valid, kept[it]);
+    static_for<0, IT>([&](auto c) {
+      constexpr int it = decltype(c)::value;
+      const PRec r = point_decode(it, point_load(it));
+      pt[it] = r.p; wv[it] = r.w; kept[it] = r.keep;
     });
   }
-  auto point = [&](int it, Pt& p, float& w, bool& valid, bool& keep) {
+  auto cached_load = [&](int it) {
+    if constexpr (IT > 0) return RawRec{};
+    else return point_load(it);
+  };
+  auto point = [&](int it, const RawRec& raw) {
     if constexpr (IT > 0) {
-      p = pt[it]; w = wv[it]; keep = kept[it];
-      valid = it * 16 + l < N;
+      PRec r;
+      r.p = pt[it]; r.w = wv[it]; r.ws = wv[it]; r.keep = kept[it];
+      r.valid = it * 16 + l < N;
+      return r;
     } else {
-      fetch(it, p, w, valid, keep);
+      return point_decode(it, raw);
     }
   };
 
@@ -159,11 +177,12 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
     float gxf[9], gof[9];
 #pragma unroll
     for (int c = 0; c < 9; ++c) { gxf[c] = 0.0f; gof[c] = 0.0f; }
-    for_points<IT>(nit, [&](int it) {
+    for_points<IT>(nit, cached_load, point, [&](int it, const PRec& rec) {
       const int i = it * 16 + l;
-      Pt p; float wf; bool valid, keep;
-      point(it, p, wf, valid, keep);
-      if (!valid) return;
+      const Pt& p = rec.p;
+      const float wf = rec.w;
+      const bool keep = rec.keep;
+      if (!rec.valid) return;
       if (A.g_res != nullptr) {
         const double w = (double)wf;
         double ra[3], rb[2], inv;
@@ -325,10 +344,11 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
   float* dst = A.g_w + (size_t)pair * N;
   float gwv[ITR];
   float wg = 0.0f;
-  for_points<IT>(nit, [&](int it) {
+  for_points<IT>(nit, cached_load, point, [&](int it, const PRec& rec) {
     const int i = it * 16 + l;
-    Pt p; float wf; bool valid, keep;
-    point(it, p, wf, valid, keep);
+    const Pt& p = rec.p;
+    const float wf = rec.w;
+    const bool valid = rec.valid, keep = rec.keep;
     double ra[3], rb[2], inv;
     row_factors(p, s1, c1x, c1y, s2, c2x, c2y, ra, rb, inv);
     const double w = (double)wf;
@@ -344,15 +364,30 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
   // softmax adjoint g_logit_i = w_i (g_w_i - sum_j w_j g_w_j)
   const float sdot = A.logits_mode ? rg_sum(wg) : 0.0f;
   if constexpr (IT > 0) {
-    for_points<IT>(nit, [&](int it) {
+    static_for<0, IT>([&](auto c) {
+      constexpr int it = decltype(c)::value;
       const int i = it * 16 + l;
       if (i < N) dst[i] = A.logits_mode ? wv[it] * (gwv[it] - sdot) : gwv[it];
     });
   } else if (A.logits_mode) {
-    for (int it = 0; it < nit; ++it) {
+    // (weight, provisional gradient) of correspondence `it`
+    auto parked_load = [&](int it) {
+      RawRec r;
       const int i = it * 16 + l;
-      if (i < N) dst[i] = wsrc[i] * (dst[i] - sdot);
-    }
+      r.v[0] = wsrc[(i < N) ? i : N - 1];
+      r.v[1] = dst[(i < N) ? i : N - 1];
+      return r;
+    };
+    auto parked = [&](int it, const RawRec& raw) {
+      PRec r;
+      r.valid = it * 16 + l < N;
+      r.w = raw.v[0];
+      r.p.x1 = raw.v[1];
+      return r;
+    };
+    for_points<0>(nit, parked_load, parked, [&](int it, const PRec& r) {
+      if (r.valid) dst[it * 16 + l] = r.w * (r.p.x1 - sdot);
+    });
   }
 
   if constexpr (PGRAD) {
@@ -375,12 +410,13 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
 #pragma unroll
     for (int k = 0; k < 10; ++k) sums[k] = 0.0f;
     float q1x[ITR], q1y[ITR], q2x[ITR], q2y[ITR];
-    for_points<IT>(nit, [&](int it) {
+    for_points<IT>(nit, cached_load, point, [&](int it, const PRec& rec) {
       const int i = it * 16 + l;
-      Pt p; float wf; bool valid, keep;
-      point(it, p, wf, valid, keep);
+      const Pt& p = rec.p;
+      const float wf = rec.w;
+      const bool keep = rec.keep;
       if constexpr (IT > 0) q1x[it] = q1y[it] = q2x[it] = q2y[it] = 0.0f;
-      if (!valid) return;
+      if (!rec.valid) return;
       const double w = (double)wf;
       const double z1 = p.z1, z2 = p.z2;
       const double a[3] = {s1 * ((double)p.x1 - c1x * z1), s1 * ((double)p.y1 - c1y * z1), z1};
@@ -461,11 +497,10 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
     const double Gd1 = -Gs1 * s1 * s1 / kH, Gd2 = -Gs2 * s2 * s2 / kH;   // s = k / dbar
     const double Gc1x = (tot[1] - s1 * gT1[2] - Gd1 * invN * tot[6]) * invN, Gc1y = (tot[2] - s1 * gT1[5] - Gd1 * invN * tot[7]) * invN;
     const double Gc2x = (tot[4] - s2 * gT2[2] - Gd2 * invN * tot[8]) * invN, Gc2y = (tot[5] - s2 * gT2[5] - Gd2 * invN * tot[9]) * invN;
-    for_points<IT>(nit, [&](int it) {
+    for_points<IT>(nit, cached_load, point, [&](int it, const PRec& rec) {
       const int i = it * 16 + l;
-      Pt p; float wf; bool valid, keep;
-      point(it, p, wf, valid, keep);
-      if (!valid) return;
+      const Pt& p = rec.p;
+      if (!rec.valid) return;
       const double dx1 = (double)p.x1 - c1x, dy1 = (double)p.y1 - c1y, dx2 = (double)p.x2 - c2x, dy2 = (double)p.y2 - c2y;
       const double r1 = dx1 * dx1 + dy1 * dy1, r2 = dx2 * dx2 + dy2 * dy2;
       const double ir1 = (r1 > 0.0) ? rsqrt_nr<1>(r1) : 0.0, ir2 = (r2 > 0.0) ? rsqrt_nr<1>(r2) : 0.0;

@@ -416,7 +416,7 @@ extern "C" int dfepe_w8pt_bwd(const float* pts1, const float* pts2, const float*
   if (raw && !(image_w > 0.f && image_h > 0.f)) return DFEPE_ERR_INVALID_ARG;
   if (raw && (reinterpret_cast<uintptr_t>(pts1) & 15u)) return DFEPE_ERR_INVALID_ARG;
   if (flags & ~DFEPE_W8PT_ALL_FLAGS) return DFEPE_ERR_INVALID_ARG;
-  if (!(flags & DFEPE_W8PT_WAVE_PER_PAIR)) {  // same rule as dfepe_w8pt_fwd: the record formats differ
+  if (dfepe_w8pt_use_rows(N, (long long)B, flags)) {  // same rule as dfepe_w8pt_fwd (B already counts the weight sets): the record formats differ
     W8BwdArgs A;
     A.pts1 = pts1; A.pts2 = pts2; A.wts = weights;
     A.Bm = Bm; A.B = B; A.N = N;

@@ -762,8 +762,8 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
   if (raw && (reinterpret_cast<uintptr_t>(pts1) & 15u)) return DFEPE_ERR_INVALID_ARG;  // float4 loads
 
   if (flags & ~DFEPE_W8PT_ALL_FLAGS) return DFEPE_ERR_INVALID_ARG;  // unknown flag bits are rejected, not ignored
-  if (!(flags & DFEPE_W8PT_WAVE_PER_PAIR)) {
-    // small N: one 16-lane row per pair, correspondences in registers, fp64 tridiagonal eigen-solver (w8pt16.hip)
+  if (dfepe_w8pt_use_rows(N, (long long)B * n_weight_sets, flags)) {
+    // one 16-lane row per pair, fp64 tridiagonal eigen-solver (w8pt16.hip)
     W8Args A;
     A.pts1 = pts1; A.pts2 = pts2; A.wts = weights;
     A.Bm = B; A.B = B * n_weight_sets; A.N = N;
