@@ -182,8 +182,7 @@ def main():
     else:  # "pose": fit + E-from-F + cheirality-checked decomposition (the (1,1,0) projection is implied by the decomposition)
         def step_body():
             F, res, epi, _, _ = dfepe.ops.w8pt_forward(m, None, w0, True, W, H, 0.5, True, False)
-            E = dfepe.ops.congruence(F, TK)
-            Rt, winner, counts = dfepe.ops.cheirality(E, scene["Ks"], m, 50.0)
+            Rt, winner, counts = dfepe.ops.cheirality(F, scene["Ks"], m, 50.0, pre=TK)  # E = (T K)^T F (T K) formed inside
             state["Rt"], state["winner"] = Rt, winner
             return {"F_layers": F.unsqueeze(0), "Rt": Rt, "winner": winner, "counts": counts}
 
@@ -499,7 +498,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg["what"].format(B=B_cfg, N=N, L=L), "baseline_config": args.config, "B_per_gpu": B, "B_total": B_total,
                        "N": N, "depth": L, "outlier_ratio": outl, "parallelism": f"dp{world}", "hipgraph": graph is not None,
-                       "launches_per_step": (2 * L + 2) if kind == "train" else (2 if kind == "fit" else 3)},
+                       "launches_per_step": (2 * L + 2) if kind == "train" else 2},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "accuracy": acc,

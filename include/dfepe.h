@@ -203,10 +203,12 @@ int dfepe_loss_tail(const float *F_layers, int L, int B, const float *T1, const 
  * the order (R1,t),(R1,-t),(R2,t),(R2,-t), linear triangulation of every correspondence (the reference calls
  * cv2.triangulatePoints), count of points with 0 < Z < depth_thres in both cameras, first arg-max wins.
  *   E [B,9]; K [B,9]; matches [B,N,4] pixels
+ *   pre [B,9] or NULL: when given, the matrix decomposed is pre^T E pre -- pass E = F (the fit's output) and pre = T K to fuse
+ *     E-from-F (E = K^T T^T F T K, train_good_utils.py:356-358) into this launch
  *   Rt_cam [B,12]  inverse (camera motion) of the winner, zeros when no candidate has a valid point
  *   winner [B] int32 (-1 when none); counts [B,4] int32
  */
-int dfepe_cheirality(const float *E, const float *K, const float *matches, int B, int N, float depth_thres,
+int dfepe_cheirality(const float *E, const float *pre, const float *K, const float *matches, int B, int N, float depth_thres,
                      float *Rt_cam, int *winner, int *counts, void *stream);
 
 /*

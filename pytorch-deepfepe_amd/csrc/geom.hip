@@ -316,9 +316,10 @@ __device__ inline void smallest_eigvec4(const double* S /*4x4 row-major, symmetr
   x[0] = y0; x[1] = y1; x[2] = y2; x[3] = y3;  // not normalised: the caller only uses ratios
 }
 
-__global__ void __launch_bounds__(256)
-cheirality_kernel(const float* __restrict__ E, const float* __restrict__ K, const float* __restrict__ matches, int B, int N,
-                  float depth_thres, float* __restrict__ Rt_cam, int* __restrict__ winner, int* __restrict__ counts) {
+__global__ void __launch_bounds__(256, 4)  // <= 128 VGPRs: four wavefronts per SIMD, i.e. 4096 one-wavefront pairs resident at once
+cheirality_kernel(const float* __restrict__ E, const float* __restrict__ pre, const float* __restrict__ K,
+                  const float* __restrict__ matches, int B, int N, float depth_thres, float* __restrict__ Rt_cam,
+                  int* __restrict__ winner, int* __restrict__ counts) {
   // one workgroup per pair; with 256 threads the four wavefronts take every fourth group of 64 correspondences and meet in LDS
   __shared__ int wcnt[4][4];
   const int lane = threadIdx.x & 63;
@@ -327,12 +328,32 @@ cheirality_kernel(const float* __restrict__ E, const float* __restrict__ K, cons
   double Ed[9], Kd[9], R[2][9], t[3];
 #pragma unroll
   for (int k = 0; k < 9; ++k) { Ed[k] = (double)E[pair * 9 + k]; Kd[k] = to_sgpr((double)K[pair * 9 + k]); }
+  if (pre != nullptr) {  // E-from-F fused: the matrix decomposed is pre^T E pre (E = F, pre = T K; train_good_utils.py:356-358)
+    double Ad[9], tmp[9], Ef[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Ad[k] = (double)pre[pair * 9 + k];
+    mat3_mul_tn(Ad, Ed, tmp);
+    mat3_mul(tmp, Ad, Ef);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Ed[k] = (double)(float)Ef[k];  // through fp32 like the stand-alone congruence kernel's output
+  }
   decompose_E(Ed, R[0], R[1], t);
   // per-pair (wave-uniform) quantities live in scalar registers; the per-correspondence DLT owns the VGPRs
 #pragma unroll
   for (int k = 0; k < 9; ++k) { R[0][k] = to_sgpr(R[0][k]); R[1][k] = to_sgpr(R[1][k]); }
 #pragma unroll
   for (int k = 0; k < 3; ++k) t[k] = to_sgpr(t[k]);
+  // the two candidate projection matrices K [R | t], formed once per pair and parked in scalar registers
+  double P2s[2][12];
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        P2s[rr][4 * r + c] = to_sgpr(Kd[3 * r] * R[rr][c] + Kd[3 * r + 1] * R[rr][3 + c] + Kd[3 * r + 2] * R[rr][6 + c]);
+      P2s[rr][4 * r + 3] = to_sgpr(Kd[3 * r] * t[0] + Kd[3 * r + 1] * t[1] + Kd[3 * r + 2] * t[2]);
+    }
   int cnt[4] = {0, 0, 0, 0};
   const int nw = blockDim.x >> 6;  // 4 wavefronts per pair for small batches (latency), 1 for large ones (throughput)
   for (int base = wave * WAVE; base < N; base += nw * WAVE) {
@@ -345,13 +366,7 @@ cheirality_kernel(const float* __restrict__ E, const float* __restrict__ K, cons
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
       const double* Rc = R[rr];
-      double P2[12];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) P2[4 * r + c] = Kd[3 * r] * Rc[c] + Kd[3 * r + 1] * Rc[3 + c] + Kd[3 * r + 2] * Rc[6 + c];
-        P2[4 * r + 3] = Kd[3 * r] * t[0] + Kd[3 * r + 1] * t[1] + Kd[3 * r + 2] * t[2];
-      }
+      const double* P2 = P2s[rr];
       // DLT rows: x*P[2]-P[0], y*P[2]-P[1] for both views (P1 = K [I|0])
       double A[16];
       const double x1 = m.x, y1 = m.y, x2 = m.z, y2 = m.w;
@@ -470,13 +485,13 @@ extern "C" int dfepe_geo_misc(int kind, const float* in0, const float* in1, int 
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
-extern "C" int dfepe_cheirality(const float* E, const float* K, const float* matches, int B, int N, float depth_thres,
-                                float* Rt_cam, int* winner, int* counts, void* stream) {
+extern "C" int dfepe_cheirality(const float* E, const float* pre, const float* K, const float* matches, int B, int N,
+                                float depth_thres, float* Rt_cam, int* winner, int* counts, void* stream) {
   if (B < 0 || N <= 0) return DFEPE_ERR_INVALID_ARG;
   if (B == 0) return DFEPE_OK;
   if (!E || !K || !matches || !Rt_cam) return DFEPE_ERR_INVALID_ARG;
   if (reinterpret_cast<uintptr_t>(matches) & 15u) return DFEPE_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(cheirality_kernel, dim3(B), dim3(B >= 2048 ? 64 : 256), 0, static_cast<hipStream_t>(stream), E, K, matches, B, N,
-                     depth_thres, Rt_cam, winner, counts);
+  hipLaunchKernelGGL(cheirality_kernel, dim3(B), dim3(B >= 2048 ? 64 : 256), 0, static_cast<hipStream_t>(stream), E, pre, K, matches,
+                     B, N, depth_thres, Rt_cam, winner, counts);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }

@@ -349,6 +349,20 @@ def test_cheirality_matches_the_references_own_logic(dfepe, golden, case, pad_to
     assert decided >= Bf // 2
 
 
+def test_cheirality_with_fused_E_from_F(dfepe):
+    """pre = T K: the launch decomposes (T K)^T F (T K) -- same result as the stand-alone congruence followed by cheirality."""
+    B, N = 9, 300
+    sc = dfepe.synth.make_scene(B, N, seed=4, outlier_ratio=0.2)
+    d = {k: v.to(DEV) for k, v in sc.items()}
+    w = torch.softmax(d["logits_layers"][0], 1).contiguous()
+    F = dfepe.ops.w8pt_forward(d["matches_xy_ori"], None, w, True, 1241.0, 376.0, 0.5, False, False)[0]
+    T = torch.tensor([[2.0 / 1241, 0.0, -1.0], [0.0, 2.0 / 376, -1.0], [0.0, 0.0, 1.0]], device=DEV)
+    TK = (T @ d["Ks"]).contiguous()
+    a = dfepe.ops.cheirality(dfepe.ops.congruence(F, TK), d["Ks"], d["matches_xy_ori"], 50.0)
+    b = dfepe.ops.cheirality(F, d["Ks"], d["matches_xy_ori"], 50.0, pre=TK)
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[0], b[0])
+
+
 def test_validation_pose_path(dfepe, oracle):
     """goodCorr_eval_nondecompose / val_rt_batch (the cv2.recoverPose path of the reference, unpinned): recover the
     generating pose from the ground-truth E and from an E estimated by the solver on noisy matches."""
