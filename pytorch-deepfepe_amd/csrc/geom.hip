@@ -316,7 +316,7 @@ __device__ inline void smallest_eigvec4(const double* S /*4x4 row-major, symmetr
   x[0] = y0; x[1] = y1; x[2] = y2; x[3] = y3;  // not normalised: the caller only uses ratios
 }
 
-__global__ void __launch_bounds__(256, 4)  // <= 128 VGPRs: four wavefronts per SIMD, i.e. 4096 one-wavefront pairs resident at once
+__global__ void __launch_bounds__(256)
 cheirality_kernel(const float* __restrict__ E, const float* __restrict__ pre, const float* __restrict__ K,
                   const float* __restrict__ matches, int B, int N, float depth_thres, float* __restrict__ Rt_cam,
                   int* __restrict__ winner, int* __restrict__ counts) {
@@ -343,7 +343,8 @@ cheirality_kernel(const float* __restrict__ E, const float* __restrict__ pre, co
   for (int k = 0; k < 9; ++k) { R[0][k] = to_sgpr(R[0][k]); R[1][k] = to_sgpr(R[1][k]); }
 #pragma unroll
   for (int k = 0; k < 3; ++k) t[k] = to_sgpr(t[k]);
-  // the two candidate projection matrices K [R | t], formed once per pair and parked in scalar registers
+  // the two candidate projection matrices K [R | t], formed once per pair (measured: parking them in scalar registers and
+  // capping the kernel at 128 VGPRs for four wavefronts per SIMD is slower -- SGPR spills and constant-bus moves in the loop)
   double P2s[2][12];
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr)
@@ -351,8 +352,8 @@ cheirality_kernel(const float* __restrict__ E, const float* __restrict__ pre, co
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
       for (int c = 0; c < 3; ++c)
-        P2s[rr][4 * r + c] = to_sgpr(Kd[3 * r] * R[rr][c] + Kd[3 * r + 1] * R[rr][3 + c] + Kd[3 * r + 2] * R[rr][6 + c]);
-      P2s[rr][4 * r + 3] = to_sgpr(Kd[3 * r] * t[0] + Kd[3 * r + 1] * t[1] + Kd[3 * r + 2] * t[2]);
+        P2s[rr][4 * r + c] = Kd[3 * r] * R[rr][c] + Kd[3 * r + 1] * R[rr][3 + c] + Kd[3 * r + 2] * R[rr][6 + c];
+      P2s[rr][4 * r + 3] = Kd[3 * r] * t[0] + Kd[3 * r + 1] * t[1] + Kd[3 * r + 2] * t[2];
     }
   int cnt[4] = {0, 0, 0, 0};
   const int nw = blockDim.x >> 6;  // 4 wavefronts per pair for small batches (latency), 1 for large ones (throughput)

@@ -273,10 +273,24 @@ __device__ __forceinline__ void eig9_select(double* Ar, const int l, const int k
   double te2[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) te2[k] = te[k] * te[k];
-  double lo = -1e-3, hi = 1.0 + 1e-3;  // unit trace, positive semi-definite: the spectrum lies in [0, 1]
+  // unit trace, positive semi-definite: the spectrum lies in [0, 1].  Round 0 probes the powers 17^-16 ... 17^-1 (the wanted
+  // eigenvalue is usually orders of magnitude below the trace: one round finds its magnitude instead of three or four rounds
+  // each keeping the lowest seventeenth); the following rounds split the bracket linearly until it is 2e-16 wide (absolute:
+  // that is the accuracy of M itself), 9-12 rounds instead of a fixed 13.  Counts are monotone in the probe, so
+  // m = number of probes still below the wanted eigenvalue locates the sub-interval.
+  const float kLog2_17 = 4.087462841250339f;
+  auto pow17 = [&](int e) { return (double)exp2f((float)e * kLog2_17); };  // probe positions need no accuracy
+  double lo = -1e-3, hi = 1.0 + 1e-3;
+  {
+    const int c = sturm_count(td, te2, pow17(l - 16));
+    const int m = rg_sum((c <= kth) ? 1 : 0);
+    lo = (m > 0) ? pow17(m - 17) : lo;
+    hi = (m < 16) ? pow17(m - 16) : hi;
+  }
   const double frac = (double)(l + 1) * (1.0 / 17.0);
-  for (int round = 0; round < 13; ++round) {
+  for (int round = 0; round < 14; ++round) {
     const double wdt = hi - lo;
+    if (!(wdt > 2e-16)) break;  // uniform over the row
     const int c = sturm_count(td, te2, fma(wdt, frac, lo));
     const int m = rg_sum((c <= kth) ? 1 : 0);  // probes still below the wanted eigenvalue (counts are monotone in l)
     const double step = wdt * (1.0 / 17.0);
