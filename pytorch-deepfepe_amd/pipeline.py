@@ -69,7 +69,7 @@ def _tail_workspace(dev, B: int) -> Tensor:
 class _HotPathFunction(torch.autograd.Function):
     """The whole solver-only step as ONE autograd node.  Forward: L x w8pt_fwd (softmax fused) + ONE loss-tail launch that
     also forms d loss / d F of every layer (dfepe_loss_tail); backward: L x w8pt_bwd, which apply the upstream gradient of
-    the loss as their g_scale.  11 launches for L = 5, no intermediate torch ops, no per-op autograd bookkeeping.
+    the loss as their g_scale.  12 launches for L = 5 (5 fits, tail, head, 5 adjoints), no intermediate torch ops, no per-op autograd bookkeeping.
     ``fused_tail=False`` keeps the round-1 structure (floss_fwd, pose_fwd, loss_head | pose_bwd, floss_bwd: 15 launches)."""
 
     @staticmethod
@@ -198,7 +198,7 @@ def hot_path_fused(matches: Tensor, logits_layers: Tensor, Ks: Tensor, virt1: Te
                    clamp_q: float = 0.1, clamp_t: float = 0.5, balance_q: float = 1.0, balance_t: float = 0.1,
                    hw_T: Optional[Tensor] = None, layers_batched: bool = False, balance_F: float = 1.0, fused_tail: bool = True,
                    grad_pairs: Optional[int] = None) -> Dict[str, Tensor]:
-    """Same contract and same numbers as hot_path_forward, 11 kernel launches instead of ~120:
+    """Same contract and same numbers as hot_path_forward, 12 kernel launches instead of ~120:
     loss = balance_F * loss_F + loss_qt.  The reference's pipeline drops the F-loss from the objective when if_qt_loss
     (Train_model_pipeline.py:580-587, `loss += loss_F * balance_F` commented out): that is balance_F = 0; the solver-only
     benchmark step keeps both terms (BASELINE metric "F+E+pose+loss") with balance_F = 1.

@@ -46,7 +46,7 @@ groups = collections.OrderedDict()
 for r in trace:
     d = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
     groups.setdefault((short(r["Kernel_Name"]), int(r["Grid_Size_X"])), []).append(d)
-md = [f"# {tag} — rocprofv3 summaries (MI355X, B={B}/GPU, N={N}, depth {L}, fused step = 11 launches in one hipGraph)", "",
+md = [f"# {tag} — rocprofv3 summaries (MI355X, B={B}/GPU, N={N}, depth {L}, fused step = 12 launches in one hipGraph)", "",
       "Produced by `scripts/profile_round.sh` (GPU box) + `scripts/profile_summary.py` (here).", "",
       "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 200 --warmup 20`", "",
       f"The verbatim per-name `--stats` table is `{tag}_bench_kernel_stats.csv`.  bench.py runs, besides the timed region, the roofline probe "
@@ -79,7 +79,7 @@ md += ["", f"bench line of the same (profiled) run: `value` = {line['value']:.0f
        f"roofline.avg_kernel_us = {line['roofline']['avg_kernel_us']} (HIP events around a hipGraph of 50 back-to-back stand-alone fits, "
        f"i.e. kernel + the dispatch gap between dependent launches).  The rocprof average of the forward fit at the hot-path grid is "
        f"{fwd_avg_us:.2f} us.  Sum of the step's kernel averages: {step_sum:.1f} us of the {1e3*line['ms_per_step']:.1f} us step; the rest is "
-       "dispatch gaps between the 11 dependent launches.", ""]
+       "dispatch gaps between the 12 dependent launches.", ""]
 
 fetch, write = counters("pmc_fetch"), counters("pmc_write")
 alg = {  # algorithmic bytes per launch in the fused step (SURVEY.md 8d + what the step additionally writes)
