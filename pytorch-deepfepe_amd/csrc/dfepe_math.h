@@ -190,9 +190,17 @@ __device__ __forceinline__ float svd_rcp(float x) { return 1.0f / x; }
 template <typename T>
 __device__ inline void svd3(const T* F, T* U, T* S, T* V) {
   T G[9];
+  // Exact power-of-two prescale to max|F| in [0.5, 1): the vectors do not depend on the scale, S is scaled back exactly, and
+  // the Newton reciprocals / square roots (fp32 seeds) see O(1) operands whatever the scale of the input (an essential
+  // matrix times 1e-6 used to leave their range: scripts/stress_pose.py).
+  T big = T(0);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) big = fmax(big, fabs(F[i]));
+  int ex = 0;
+  if (big > T(0) && big < T(1e300)) (void)frexp(big, &ex);
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
-    G[i] = F[i];
+    G[i] = ldexp(F[i], -ex);
     V[i] = (i % 4 == 0) ? T(1) : T(0);
   }
   const T tol = (sizeof(T) == 4) ? T(1e-7) : T(1e-15);
@@ -264,7 +272,7 @@ __device__ inline void svd3(const T* F, T* U, T* S, T* V) {
   T c2 = U[0] * U[4] - U[3] * U[1];
   T sg = (c0 * G[2] + c1 * G[5] + c2 * G[8] < T(0)) ? T(-1) : T(1);
   U[2] = sg * c0; U[5] = sg * c1; U[8] = sg * c2;
-  S[0] = n[0]; S[1] = n[1]; S[2] = n[2];
+  S[0] = ldexp(n[0], ex); S[1] = ldexp(n[1], ex); S[2] = ldexp(n[2], ex);
 }
 
 // ---- smallest singular triplet of a 3x3 matrix in closed form (fp64) -----------------------------------------------
