@@ -228,22 +228,22 @@ geo_misc_kernel(int kind, const float* __restrict__ in0, const float* __restrict
 //   two Householder reflections -> tridiagonal T;  Laguerre's iteration from lam = 0 on det(T - lam I) through the
 //   three-term recurrence (for a real-rooted polynomial it climbs monotonically to the smallest root from below, cubic
 //   rate, and does not care whether the outliers' lam4 / lam3 is 1e-7 or 0.9: <= 6 steps on DLT matrices);
-//   eigenvector of T by a twisted factorisation (pivot where |gamma_r| is smallest);  back-transformation.
-// Reciprocals and square roots are the branch-free Newton forms (operands are entries of the scaled normal matrix, far inside
-// the fp32 exponent range the seeds need): the range-checked variants cost a divergent branch each, 20 per DLT.
-// ~6x fewer instructions than the 6-7 cyclic Jacobi sweeps this replaces, same accuracy: scripts/proto_eig4.py checks
-// the algorithm against numpy.linalg.eigh on 16 000 DLT matrices with 25 % outliers (eigenvalue error 7e-16 lam_max,
-// eigenvector error x gap 7e-16, no cheirality decision changed).
-__device__ __forceinline__ double guard_piv(double z, double tiny) { return (fabs(z) < tiny) ? ((z < 0.0) ? -tiny : tiny) : z; }
-
+//   eigenvector of T as the best-conditioned column of adj(T - lam I), whose entries are products of the leading and
+//   trailing principal minors the recurrence already yields (the same vector a twisted factorisation gives, pivot chosen
+//   where |gamma_r| is smallest = where the diagonal cofactor is largest, without its six divisions);  back-transformation.
+// Reciprocals and square roots are the branch-free Newton forms with ONE step on the fp32 seed (1e-14 relative): inside the
+// iteration only the convergence speed depends on them, in the reflectors 1e-14 is the orthogonality they are built to.
+// scripts/proto_eig4.py checks the algorithm against numpy.linalg.eigh on 16 000 DLT matrices with 25 % outliers (eigenvalue
+// error 7e-16 lam_max, eigenvector error x gap 7e-16, no cheirality decision changed).
 __device__ inline void smallest_eigvec4(const double* S /*4x4 row-major, symmetric*/, double* x) {
   // ---- Householder 1 on (S10, S20, S30)
   const double a0 = S[4], a1 = S[8], a2 = S[12];
-  const double alpha = (a0 < 0.0) ? sqrt_nr<2>(a0 * a0 + a1 * a1 + a2 * a2) : -sqrt_nr<2>(a0 * a0 + a1 * a1 + a2 * a2);
+  const double sg1 = a0 * a0 + a1 * a1 + a2 * a2;
+  const double alpha = (a0 < 0.0) ? sqrt_nr<1>(sg1) : -sqrt_nr<1>(sg1);
   const double v0 = a0 - alpha, v1 = a1, v2 = a2;
   const double vv = v0 * v0 + v1 * v1 + v2 * v2;
   const bool ok1 = vv > 0.0;
-  const double beta = ok1 ? 2.0 * rcp_nr<2>(vv) : 0.0;
+  const double beta = ok1 ? 2.0 * rcp_nr<1>(vv) : 0.0;
   const double p0 = beta * (S[5] * v0 + S[6] * v1 + S[7] * v2);
   const double p1 = beta * (S[6] * v0 + S[10] * v1 + S[11] * v2);
   const double p2 = beta * (S[7] * v0 + S[11] * v1 + S[15] * v2);
@@ -253,11 +253,12 @@ __device__ inline void smallest_eigvec4(const double* S /*4x4 row-major, symmetr
   const double B01 = S[6] - v0 * q1 - q0 * v1, B02 = S[7] - v0 * q2 - q0 * v2;
   const double B11 = S[10] - 2.0 * v1 * q1, B12 = S[11] - v1 * q2 - q1 * v2, B22 = S[15] - 2.0 * v2 * q2;
   // ---- Householder 2 on (B10, B20)
-  const double alpha2 = (B01 < 0.0) ? sqrt_nr<2>(B01 * B01 + B02 * B02) : -sqrt_nr<2>(B01 * B01 + B02 * B02);
+  const double sg2 = B01 * B01 + B02 * B02;
+  const double alpha2 = (B01 < 0.0) ? sqrt_nr<1>(sg2) : -sqrt_nr<1>(sg2);
   const double w0 = B01 - alpha2, w1 = B02;
   const double ww = w0 * w0 + w1 * w1;
   const bool ok2 = ww > 0.0;
-  const double beta2 = ok2 ? 2.0 * rcp_nr<2>(ww) : 0.0;
+  const double beta2 = ok2 ? 2.0 * rcp_nr<1>(ww) : 0.0;
   const double r0 = beta2 * (B11 * w0 + B12 * w1), r1 = beta2 * (B12 * w0 + B22 * w1);
   const double k2 = 0.5 * beta2 * (r0 * w0 + r1 * w1);
   const double s0 = r0 - k2 * w0, s1 = r1 - k2 * w1;
@@ -275,39 +276,31 @@ __device__ inline void smallest_eigvec4(const double* S /*4x4 row-major, symmetr
     const double P3 = c2 * P2 - f1 * c0, D3 = c2 * D2 - P2 + f1, E3 = c2 * E2 - 2.0 * D2;
     const double P4 = c3 * P3 - f2 * P2, D4 = c3 * D3 - P3 - f2 * D2, E4 = c3 * E3 - 2.0 * D3 - f2 * E2;
     const bool good = (P4 > 0.0) && !done;  // p <= 0: on the root (or past it by round-off)
-    const double ip = good ? rcp_nr<2>(P4) : 0.0;
+    const double ip = good ? rcp_nr<1>(P4) : 0.0;
     const double G = D4 * ip, H = G * G - E4 * ip;
-    const double den = G - sqrt_nr<2>(fmax(3.0 * (4.0 * H - G * G), 0.0));  // G < 0 left of the smallest root
-    const double step = (good && den < 0.0) ? -4.0 * rcp_nr<2>(den) : 0.0;
+    const double den = G - sqrt_nr<1>(fmax(3.0 * (4.0 * H - G * G), 0.0));  // G < 0 left of the smallest root
+    const double step = (good && den < 0.0) ? -4.0 * rcp_nr<1>(den) : 0.0;
     const double nl = lam + step;
     done = done || !good || !(step > 1e-16 * scale) || (nl == lam);
     if (!done) lam = nl;
     if (__ballot(!done) == 0ull) break;  // wave-uniform exit
   }
-  // ---- twisted factorisation of T - lam: forward pivots dp, backward pivots dm, gamma_r = dp_r + dm_r - (d_r - lam)
-  const double tiny = 1e-300 + 1e-30 * scale;
+  // ---- null vector of T - lam: column r of the adjugate, adj[i][j] = (-1)^(i+j) P_i e_i..e_(j-1) Q_(j+1) for i <= j, with
+  // P_i the leading principal minor of order i and Q_j the trailing one starting at row j; r = the largest diagonal cofactor
   const double c0 = d0 - lam, c1 = d1 - lam, c2 = d2 - lam, c3 = d3 - lam;
-  const double dp0 = c0;
-  const double i0 = rcp_nr<2>(guard_piv(dp0, tiny)), dp1 = c1 - f0 * i0;
-  const double i1 = rcp_nr<2>(guard_piv(dp1, tiny)), dp2 = c2 - f1 * i1;
-  const double i2 = rcp_nr<2>(guard_piv(dp2, tiny)), dp3 = c3 - f2 * i2;
-  const double dm3 = c3;
-  const double j3 = rcp_nr<2>(guard_piv(dm3, tiny)), dm2 = c2 - f2 * j3;
-  const double j2 = rcp_nr<2>(guard_piv(dm2, tiny)), dm1 = c1 - f1 * j2;
-  const double j1 = rcp_nr<2>(guard_piv(dm1, tiny)), dm0 = c0 - f0 * j1;
-  const double g0 = fabs(dm0), g1 = fabs(dp1 + dm1 - c1), g2 = fabs(dp2 + dm2 - c2), g3 = fabs(dp3);
+  const double P1 = c0, P2 = c1 * c0 - f0, P3 = c2 * P2 - f1 * P1;
+  const double Q3 = c3, Q2 = c2 * c3 - f2, Q1 = c1 * Q2 - f1 * Q3;
+  const double g0 = fabs(Q1), g1 = fabs(P1 * Q2), g2 = fabs(P2 * Q3), g3 = fabs(P3);
   int r = 0;
   double gm = g0;
-  if (g1 < gm) { gm = g1; r = 1; }
-  if (g2 < gm) { gm = g2; r = 2; }
-  if (g3 < gm) { gm = g3; r = 3; }
-  // y_k / y_{k+1} = u_k above the twist, y_k / y_{k-1} = l_k below it
-  const double u0 = -e0 * i0, u1 = -e1 * i1, u2 = -e2 * i2;
-  const double l1 = -e0 * j1, l2 = -e1 * j2, l3 = -e2 * j3;
-  double y0 = (r == 0) ? 1.0 : ((r == 1) ? u0 : ((r == 2) ? u0 * u1 : u0 * u1 * u2));
-  double y1 = (r == 0) ? l1 : ((r == 1) ? 1.0 : ((r == 2) ? u1 : u1 * u2));
-  double y2 = (r == 0) ? l1 * l2 : ((r == 1) ? l2 : ((r == 2) ? 1.0 : u2));
-  double y3 = (r == 0) ? l1 * l2 * l3 : ((r == 1) ? l2 * l3 : ((r == 2) ? l3 : 1.0));
+  if (g1 > gm) { gm = g1; r = 1; }
+  if (g2 > gm) { gm = g2; r = 2; }
+  if (g3 > gm) { gm = g3; r = 3; }
+  const double e01 = e0 * e1, e12 = e1 * e2, e012 = e01 * e2;
+  double y0 = (r == 0) ? Q1 : ((r == 1) ? -e0 * Q2 : ((r == 2) ? e01 * Q3 : -e012));
+  double y1 = (r == 0) ? -e0 * Q2 : ((r == 1) ? P1 * Q2 : ((r == 2) ? -P1 * e1 * Q3 : P1 * e12));
+  double y2 = (r == 0) ? e01 * Q3 : ((r == 1) ? -P1 * e1 * Q3 : ((r == 2) ? P2 * Q3 : -P2 * e2));
+  double y3 = (r == 0) ? -e012 : ((r == 1) ? P1 * e12 : ((r == 2) ? -P2 * e2 : P3));
   // ---- back-transformation x = H1 H2 y
   const double t2 = beta2 * (w0 * y2 + w1 * y3);
   y2 -= t2 * w0; y3 -= t2 * w1;

@@ -39,21 +39,30 @@ struct TailHead {
   double* packed;          // [L+4]
   float* scalars;          // [4+L]
   float balance_F, balance_q, balance_t;
+  double inv_BM, inv_BML, inv_BL;  // 1 / (B M), 1 / (B M L), 1 / (B L)
 };
 
 __global__ void __launch_bounds__(256) loss_tail_head_kernel(const TailHead H) {
   __shared__ double red[4][kTailParts];
   const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+  // every thread adds whole rows of partials (workgroups t, t + 256, ...): 24 independent 16-byte loads in flight per row;
+  // entries of layers >= L are zeros the tail kernel wrote
   double v[3][kTailMaxLayers];
 #pragma unroll
   for (int kind = 0; kind < 3; ++kind)
 #pragma unroll
-    for (int l = 0; l < kTailMaxLayers; ++l) {
-      double s = 0.0;
-      if (l < H.L)
-        for (int b = (int)threadIdx.x; b < H.nblocks; b += 256) s += H.partials[(size_t)b * kTailParts + kind * kTailMaxLayers + l];
-      v[kind][l] = s;
+    for (int l = 0; l < kTailMaxLayers; ++l) v[kind][l] = 0.0;
+  for (int b = (int)threadIdx.x; b < H.nblocks; b += 256) {
+    const double2* row = reinterpret_cast<const double2*>(H.partials + (size_t)b * kTailParts);
+    double2 t[kTailParts / 2];
+#pragma unroll
+    for (int k = 0; k < kTailParts / 2; ++k) t[k] = row[k];
+#pragma unroll
+    for (int k = 0; k < kTailParts / 2; ++k) {
+      v[(2 * k) / kTailMaxLayers][(2 * k) % kTailMaxLayers] += t[k].x;
+      v[(2 * k + 1) / kTailMaxLayers][(2 * k + 1) % kTailMaxLayers] += t[k].y;
     }
+  }
 #pragma unroll
   for (int kind = 0; kind < 3; ++kind)
 #pragma unroll
@@ -64,16 +73,20 @@ __global__ void __launch_bounds__(256) loss_tail_head_kernel(const TailHead H) {
       }
     }
   __syncthreads();
+  // same quantities as dfepe_loss_head; lane l < L finishes layer l, lane 0 the totals (reciprocals come from the host: a
+  // dependent chain of fp64 divisions in one lane was a fifth of this kernel)
+  const int L = H.L;
+  if (threadIdx.x < (unsigned)L) {
+    const int l = (int)threadIdx.x;
+    const double f = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    H.packed[l] = f;
+    H.scalars[4 + l] = (float)(f * H.inv_BM);  // losses.mean() of layer l
+  }
   if (threadIdx.x == 0) {
-    // same quantities as dfepe_loss_head
-    const int L = H.L;
     double totF = 0.0, tq = 0.0, tt = 0.0;
     for (int l = 0; l < L; ++l) {
-      const double f = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
       const int iq = kTailMaxLayers + l, it = 2 * kTailMaxLayers + l;
-      H.packed[l] = f;
-      H.scalars[4 + l] = (float)(f / ((double)H.B * (double)H.M));  // losses.mean() of layer l
-      totF += f;
+      totF += (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
       tq += (red[0][iq] + red[1][iq]) + (red[2][iq] + red[3][iq]);
       tt += (red[0][it] + red[1][it]) + (red[2][it] + red[3][it]);
     }
@@ -81,9 +94,8 @@ __global__ void __launch_bounds__(256) loss_tail_head_kernel(const TailHead H) {
     H.packed[L + 1] = tt;
     H.packed[L + 2] = (double)H.B;
     H.packed[L + 3] = (double)H.M;
-    const double n = (double)H.B;
-    const double loss_F = totF / (n * (double)H.M * (double)L);
-    const double loss_qt = H.pose ? (tq * (double)H.balance_q + tt * (double)H.balance_t) / (n * (double)L) : 0.0;
+    const double loss_F = totF * H.inv_BML;
+    const double loss_qt = H.pose ? (tq * (double)H.balance_q + tt * (double)H.balance_t) * H.inv_BL : 0.0;
     H.scalars[0] = (float)((double)H.balance_F * loss_F + loss_qt);
     H.scalars[1] = (float)loss_F;
     H.scalars[2] = (float)loss_qt;
@@ -132,6 +144,7 @@ extern "C" int dfepe_loss_tail(const float* F_layers, int L, int B, const float*
   TailHead H;
   H.partials = partials; H.nblocks = (int)grid.x; H.L = L; H.B = B; H.M = M; H.pose = (q_gt != nullptr) ? 1 : 0;
   H.packed = packed; H.scalars = scalars; H.balance_F = balance_F; H.balance_q = balance_q; H.balance_t = balance_t;
+  H.inv_BM = 1.0 / ((double)B * (double)M); H.inv_BML = H.inv_BM / (double)L; H.inv_BL = 1.0 / ((double)B * (double)L);
   hipLaunchKernelGGL(loss_tail_head_kernel, dim3(1), dim3(256), 0, st, H);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }

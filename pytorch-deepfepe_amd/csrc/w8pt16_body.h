@@ -208,11 +208,15 @@ __device__ __forceinline__ int sturm_count(const double* td, const double* te2, 
 // Factors of one row of the design matrix: p = b (x) a with a = T1 x1, b = T2 x2 (b[2] = 1), p^ = inv * p,
 // inv = 1 / max(|p|, 1e-12) = 1 / max(|a| |b|, 1e-12)  (DeepFNet.py:203-212).  Branch-free; bilinear forms p^ . g = inv * b^T G a replace the explicit 9-vector wherever only dot products
 // of the row are needed.
-__device__ __forceinline__ bool row_factors(const Pt& p, double s1, double c1x, double c1y, double s2, double c2x, double c2y,
-                                            double* a, double* b, double& inv) {
+__device__ __forceinline__ void row_ab(const Pt& p, double s1, double c1x, double c1y, double s2, double c2x, double c2y,
+                                       double* a, double* b) {
   const double z1 = p.z1, z2 = p.z2;
   a[0] = s1 * ((double)p.x1 - c1x * z1); a[1] = s1 * ((double)p.y1 - c1y * z1); a[2] = z1;
   b[0] = s2 * ((double)p.x2 - c2x * z2); b[1] = s2 * ((double)p.y2 - c2y * z2);
+}
+__device__ __forceinline__ bool row_factors(const Pt& p, double s1, double c1x, double c1y, double s2, double c2x, double c2y,
+                                            double* a, double* b, double& inv) {
+  row_ab(p, s1, c1x, c1y, s2, c2x, c2y, a, b);
   const double n2 = (a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) * (b[0] * b[0] + b[1] * b[1] + 1.0);
   inv = fmin(rsqrt_nr<1>(n2), 1e12);  // n2 is finite: the callers drop non-finite correspondences when they load them
   return true;
@@ -509,6 +513,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   DFEPE_MARK("P2");
   // ---- phase 2: X^T X = sum_i k_i^2 (b b^T) (x) (a a^T): 36 distinct fp64 sums per lane ---------------------------
   double acc[36];
+  double invs[IT > 0 ? IT : 1];
 #pragma unroll
   for (int e = 0; e < 36; ++e) acc[e] = 0.0;
   for_points<IT>(nit, point_load, point, [&](int it, const PRec& r) {
@@ -518,8 +523,12 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     const double a0 = s1 * ((double)p.x1 - c1x * z1), a1 = s1 * ((double)p.y1 - c1y * z1), a2 = z1;
     const double b0 = s2 * ((double)p.x2 - c2x * z2), b1 = s2 * ((double)p.y2 - c2y * z2);
     const double n2 = (a0 * a0 + a1 * a1 + a2 * a2) * (b0 * b0 + b1 * b1 + 1.0);  // |p|^2, finite (phase 0 dropped the rest)
-    // (w / max(|p|, 1e-12))^2; a dropped or padding correspondence has w = 0 and contributes exact zeros
-    const double k2 = (variant & DFEPE_W8PT_NO_ROWNORM) ? (w * w) : (w * w) * rcp_nr<2>(fmax(n2, 1e-24));
+    // (w / max(|p|, 1e-12))^2; a dropped or padding correspondence has w = 0 and contributes exact zeros.  1 / |p| is kept
+    // for the residual of phase 6 when the correspondences live in registers.
+    const double inv = fmin(rsqrt_nr<2>(n2), 1e12);
+    if constexpr (IT > 0) invs[it] = inv;
+    const double wi = (variant & DFEPE_W8PT_NO_ROWNORM) ? w : w * inv;
+    const double k2 = wi * wi;
     const double aa[6] = {a0 * a0, a0 * a1, a0 * a2, a1 * a1, a1 * a2, a2 * a2};
     const double bb[6] = {k2 * b0 * b0, k2 * b0 * b1, k2 * b0, k2 * b1 * b1, k2 * b1, k2};
 #pragma unroll
@@ -698,7 +707,12 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     const bool valid = rec.valid;
     // residual_i = w_i p^_i . f  (DeepFNet.py:203-214,251); straight-line, only the stores are guarded
     double ra[3], rb[2], inv;
-    row_factors(p, s1, c1x, c1y, s2, c2x, c2y, ra, rb, inv);
+    if constexpr (IT > 0) {
+      row_ab(p, s1, c1x, c1y, s2, c2x, c2y, ra, rb);
+      inv = invs[it];
+    } else {
+      row_factors(p, s1, c1x, c1y, s2, c2x, c2y, ra, rb, inv);
+    }
     const float r = (float)(row_bilinear(ra, rb, f) * inv * (double)wf);
     // l1 = F^T x2 (row form x2 F), l2 = F x1, dd = x2^T F x1 = x1 . l1     (utils_F.py:402-411), fp32 like the reference
     const float l1x = fmaf(p.x2, of[0], fmaf(p.y2, of[3], p.z2 * of[6]));

@@ -1,6 +1,7 @@
 """Prototype (numpy, vectorised over many matrices) of the cheap smallest-eigenvector routine for the 4x4 DLT normal
 matrix: Householder tridiagonalisation -> Laguerre iteration from below on the tridiagonal characteristic recurrence
-(monotone for real-rooted polynomials) -> twisted-factorisation eigenvector -> back-transformation.
+(monotone for real-rooted polynomials) -> null vector as an adjugate column (division-free twisted factorisation)
+-> back-transformation.
 Checked against numpy.linalg.eigh on DLT matrices of synthetic scenes (inliers and outliers)."""
 import importlib, sys, os
 import numpy as np
@@ -68,29 +69,19 @@ def smallest_eigvec4(S, iters=12):
         if done.all():
             break
     nit = it + 1
-    # --- twisted factorisation eigenvector of T - lam
+    # --- null vector of T - lam: the column of adj(T - lam I) with the largest diagonal cofactor.  adj[i][j] =
+    # (-1)^(i+j) P_i e_i..e_(j-1) Q_(j+1) (i <= j), P_i / Q_j the leading / trailing principal minors -- the vector a twisted
+    # factorisation gives (its pivot gamma_r = det / (P_r Q_(r+1)) is smallest where that cofactor is largest), division-free.
     a = d - lam[:, None]
-    tiny = 1e-300 + 1e-30 * scale
-    def guard(z):
-        return np.where(np.abs(z) < tiny, np.where(z < 0, -tiny, tiny), z)
-    dp = np.zeros((n, 4)); dm = np.zeros((n, 4))
-    dp[:, 0] = a[:, 0]
-    for k in range(1, 4):
-        dp[:, k] = a[:, k] - e2s[:, k - 1] / guard(dp[:, k - 1])
-    dm[:, 3] = a[:, 3]
-    for k in range(2, -1, -1):
-        dm[:, k] = a[:, k] - e2s[:, k] / guard(dm[:, k + 1])
-    gam = dp + dm - a
-    r = np.abs(gam).argmin(1)
-    yv = np.zeros((n, 4))
-    idx = np.arange(n)
-    yv[idx, r] = 1.0
-    for k in range(2, -1, -1):       # upwards from r: y_k = -e_k y_{k+1} / dp_k   for k < r
-        m = k < r
-        yv[:, k] = np.where(m, -e[:, k] * yv[:, k + 1] / guard(dp[:, k]), yv[:, k])
-    for k in range(1, 4):            # downwards from r: y_k = -e_{k-1} y_{k-1} / dm_k  for k > r
-        m = k > r
-        yv[:, k] = np.where(m, -e[:, k - 1] * yv[:, k - 1] / guard(dm[:, k]), yv[:, k])
+    P1 = a[:, 0]; P2 = a[:, 1] * a[:, 0] - e2s[:, 0]; P3 = a[:, 2] * P2 - e2s[:, 1] * P1
+    Q3 = a[:, 3]; Q2 = a[:, 2] * a[:, 3] - e2s[:, 2]; Q1 = a[:, 1] * Q2 - e2s[:, 1] * Q3
+    e0, e1, e2_ = e[:, 0], e[:, 1], e[:, 2]
+    cols = np.stack([np.stack([Q1, -e0 * Q2, e0 * e1 * Q3, -e0 * e1 * e2_], 1),
+                     np.stack([-e0 * Q2, P1 * Q2, -P1 * e1 * Q3, P1 * e1 * e2_], 1),
+                     np.stack([e0 * e1 * Q3, -P1 * e1 * Q3, P2 * Q3, -P2 * e2_], 1),
+                     np.stack([-e0 * e1 * e2_, P1 * e1 * e2_, -P2 * e2_, P3], 1)], 1)  # [n, r, component]
+    r = np.abs(np.stack([Q1, P1 * Q2, P2 * Q3, P3], 1)).argmax(1)
+    yv = cols[np.arange(n), r].copy()
     # --- back-transform x = H1 H2 y  (H2 acts on components 2,3; H1 on 1..3)
     t2 = beta2 * (v2[:, 0] * yv[:, 2] + v2[:, 1] * yv[:, 3])
     yv[:, 2] -= t2 * v2[:, 0]; yv[:, 3] -= t2 * v2[:, 1]
