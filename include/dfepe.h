@@ -89,7 +89,7 @@ int dfepe_selftest_rowgroup(const double *x, const double *y, double *out, void 
  *   F_out      [B,9]    T2^T F' T1                          (reference `out`)
  *   residual   [B,N]    X f/|f|                             (reference `residual`)
  *   epi_res    [B,N]    or NULL
- *   save       [B,DFEPE_SAVE_FLOATS] or NULL (needed for backward)
+ *   save       [B,DFEPE_SAVE_FLOATS] or NULL (needed for backward); 16-byte aligned
  *   weights_out[B,N]    softmax(logits) when DFEPE_W8PT_LOGITS (may be NULL), ignored otherwise
  * Sign gauge: the reference inherits LAPACK's arbitrary sign of f; here f is oriented so that its
  * largest-magnitude component is positive (F_out and residual flip together, everything downstream is

@@ -10,7 +10,8 @@ import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdfepe_hip.so")
+# DFEPE_LIB_PATH: another build of the same library (scripts/ab_step.sh times two builds alternately on one box)
+LIB_PATH = os.environ.get("DFEPE_LIB_PATH") or os.path.join(_HERE, "libdfepe_hip.so")
 
 OK = 0
 W8PT_RAW_MATCHES = 1

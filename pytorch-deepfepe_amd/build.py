@@ -23,7 +23,9 @@ INCLUDE = os.path.abspath(os.path.join(HERE, "..", "include"))
 OBJDIR = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libdfepe_hip.so")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-ffp-contract=on", f"-I{INCLUDE}", f"-I{CSRC}"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-ffp-contract=on",
+         "-mllvm", "-amdgpu-kernarg-preload-count=16",  # leading scalar kernel arguments arrive in SGPRs (w8pt16.hip)
+         f"-I{INCLUDE}", f"-I{CSRC}"]
 FLAGS += os.environ.get("DFEPE_EXTRA_FLAGS", "").split()  # experiment builds (A/B timing of a -D switch); empty for the product
 
 

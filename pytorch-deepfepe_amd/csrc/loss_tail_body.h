@@ -88,22 +88,62 @@ __device__ __forceinline__ void loss_tail_pair(const TailArgs& A, const int pair
     mat3_mul(t2, k, Am);  // A = T2 K, C = T1 K:  E = A^T F C
     mat3_mul(t1, k, Cm);
   }
-  // the pair's virtual points, transformed once (unconditional loads, index clamped, masked afterwards)
+  // ---- every global load of the kernel, issued together (one memory round trip): the pair's virtual points (index clamped,
+  // masked afterwards), the ground truth of the pose part (null-safe addresses), F of every layer
   float x1[IT][3], x2[IT][3], vm[IT];
+  float r1[IT][3], r2[IT][3];
   const float* v1 = A.virt1 + (size_t)pair * M * 3;
   const float* v2 = A.virt2 + (size_t)pair * M * 3;
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
     const int i = it * 16 + l;
     const int ic = (i < M) ? i : M - 1;
-    tail_eval_point(v1 + 3 * ic, t1, x1[it]);
-    tail_eval_point(v2 + 3 * ic, t2, x2[it]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r1[it][k] = v1[3 * ic + k]; r2[it][k] = v2[3 * ic + k]; }
     vm[it] = (i < M) ? 1.0f : 0.0f;
   }
-  for (int e = l; e < L * 9; e += 16) {
-    const int ly = e / 9, c = e - 9 * ly;
-    ldsF[e] = A.F_layers[((size_t)ly * B + pair) * 9 + c];
-    ldsG[e] = 0.0f;
+  const bool has_pose = A.q_gt != nullptr, has_R = has_pose && A.R_gt != nullptr;
+  float qg[4], tg[3], Rg[9];
+  {
+    const float* safe = A.K + (size_t)pair * 9;
+    const float* qp = has_pose ? A.q_gt + (size_t)pair * 4 : safe;
+    const float* tp = has_pose ? A.t_gt + (size_t)pair * 3 : safe;
+    const float* rp = has_R ? A.R_gt + (size_t)pair * 9 : safe;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) qg[k] = qp[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tg[k] = tp[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rg[k] = rp[k];
+  }
+  constexpr int kPer = (kTailMaxLayers * 9 + 15) / 16;
+  float fl[kPer];
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int e = k * 16 + l, ec = (e < L * 9) ? e : 0;
+    const int ly = ec / 9, c = ec - 9 * ly;
+    fl[k] = A.F_layers[((size_t)ly * B + pair) * 9 + c];
+  }
+  // ---- the virtual points, transformed once.  They are needed only after the pose block below, which stores its results:
+  // left to itself the compiler sinks the transforms (and the consumers of the loads above) past those stores, and the
+  // in-order memory counter then makes them wait for the stores to complete -- hence the pins.
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    tail_eval_point(r1[it], t1, x1[it]);
+    tail_eval_point(r2[it], t2, x2[it]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { rg_pin(x1[it][k]); rg_pin(x2[it][k]); }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) rg_pin(qg[k]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) rg_pin(tg[k]);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) rg_pin(Rg[k]);
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int e = k * 16 + l;
+    if (e < L * 9) { ldsF[e] = fl[k]; ldsG[e] = 0.0f; }
   }
   rg_sync();
 
@@ -120,12 +160,12 @@ __device__ __forceinline__ void loss_tail_pair(const TailArgs& A, const int pair
     for (int c = 0; c < 9; ++c) { Ef[c] = (float)e[c]; A.E_layers[lb * 9 + c] = Ef[c]; }
     if (A.q_gt != nullptr) {
       Pose P;
-      pose_forward(Ef, A.q_gt + (size_t)pair * 4, A.t_gt + (size_t)pair * 3, P);  // on the fp32 E, like dfepe_pose_fwd on E_layers
+      pose_forward(Ef, qg, tg, P);  // on the fp32 E, like dfepe_pose_fwd on E_layers
       const double qe = P.qe[P.qi], te = P.te[P.ti];
       A.q_l2[lb] = (float)qe;
       A.t_l2[lb] = (float)te;
       if (A.sel != nullptr) A.sel[lb] = P.qi | (P.ti << 1);
-      if (A.R_deg != nullptr && A.R_gt != nullptr) A.R_deg[lb] = (float)pose_R_deg(P, A.R_gt + (size_t)pair * 9);
+      if (A.R_deg != nullptr && A.R_gt != nullptr) A.R_deg[lb] = (float)pose_R_deg(P, Rg);
       if (A.t_deg != nullptr) A.t_deg[lb] = (float)pose_t_deg(P);
       part[kTailMaxLayers + l] = (double)fminf(fmaxf((float)qe, 0.0f), A.clamp_q);
       part[2 * kTailMaxLayers + l] = (double)fminf(fmaxf((float)te, 0.0f), A.clamp_t);
@@ -134,7 +174,7 @@ __device__ __forceinline__ void loss_tail_pair(const TailArgs& A, const int pair
         const double gql = ((float)qe <= A.clamp_q) ? (double)A.coef_q : 0.0;
         const double gtl = ((float)te <= A.clamp_t) ? (double)A.coef_t : 0.0;
         double gE[9], add[9];
-        pose_backward(P, A.q_gt + (size_t)pair * 4, gql, gtl, gE);
+        pose_backward(P, qg, gql, gtl, gE);
         // through dfepe_pose_bwd's fp32 g_E, then E = A^T F C:  g_F += A g_E C^T
 #pragma unroll
         for (int c = 0; c < 9; ++c) gE[c] = (double)(float)gE[c];

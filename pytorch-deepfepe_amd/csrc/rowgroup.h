@@ -101,6 +101,12 @@ __device__ __forceinline__ double rg_xchg(double v) {
   return rg_dpp_f64<ctrl>(v);
 }
 
+// Forces `x` to be materialised in a vector register at this point of the program: a scheduling fence for one value.  Used to
+// make the consumers of early global loads run BEFORE a block that issues stores -- the memory counter is in-order, so a
+// consumer scheduled after the stores would wait for the stores to complete, not just for its load.
+__device__ __forceinline__ void rg_pin(float& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void rg_pin(double& x) { asm volatile("" : "+v"(x)); }
+
 // Orders a row's LDS writes before its later LDS reads.  The lanes of a row belong to one wavefront, whose LDS operations
 // execute in issue order: only the compiler has to be stopped from moving memory operations across.
 __device__ __forceinline__ void rg_sync() {

@@ -11,12 +11,30 @@ namespace {
 
 constexpr int kPairsPerBlock = 16;
 
+// Kernel arguments: what a wavefront needs before it can issue its global loads comes first, as plain scalars / pointers --
+// with -amdgpu-kernarg-preload-count=16 (build.py) the command processor hands those 16 dwords over in SGPRs at wave launch,
+// so the loads do not wait for a scalar-cache miss on the kernarg segment first; the rest follows as a struct and is fetched
+// in the shadow of the global loads.
+struct W8FwdRest {
+  float* epi_res;
+  float* save;
+  float* weights_out;
+  int logits_mode;
+  unsigned variant;
+};
+
 template <int IT, bool RAW, bool PLAIN>
-__global__ void __launch_bounds__(256) w8pt16_fwd_kernel(const W8Args A) {
+__global__ void __launch_bounds__(256)
+w8pt16_fwd_kernel(const float* pts1, const float* pts2, const float* wts, int B, int Bm, int N, float hw_sx, float hw_sy,
+                  float clamp_at, float* F_out, float* residual, const W8FwdRest R) {
   __shared__ double xch[kPairsPerBlock * 36];
   const int row = (int)(threadIdx.x >> 4);
   const int pair = (int)blockIdx.x * kPairsPerBlock + row;
-  if (pair >= A.B) return;  // a whole row leaves; rows never wait for each other
+  if (pair >= B) return;  // a whole row leaves; rows never wait for each other
+  W8Args A;
+  A.pts1 = pts1; A.pts2 = pts2; A.wts = wts; A.B = B; A.Bm = Bm; A.N = N; A.hw_sx = hw_sx; A.hw_sy = hw_sy;
+  A.clamp_at = clamp_at; A.F_out = F_out; A.residual = residual; A.epi_res = R.epi_res; A.save = R.save;
+  A.weights_out = R.weights_out; A.logits_mode = R.logits_mode; A.variant = R.variant;
   w8pt16_fwd_pair<IT, RAW, PLAIN>(A, pair, xch + row * 36);
 }
 
@@ -32,12 +50,18 @@ template <bool RAW, bool PLAIN>
 void launch_fwd(const W8Args& A, hipStream_t st) {
   const dim3 grid((A.B + kPairsPerBlock - 1) / kPairsPerBlock), block(256);
   const int N = A.N;
-  if (N > 128) hipLaunchKernelGGL((w8pt16_fwd_kernel<0, RAW, PLAIN>), grid, block, 0, st, A);  // any N: correspondences re-read per phase
-  else if (N <= 16) hipLaunchKernelGGL((w8pt16_fwd_kernel<1, RAW, PLAIN>), grid, block, 0, st, A);
-  else if (N <= 32) hipLaunchKernelGGL((w8pt16_fwd_kernel<2, RAW, PLAIN>), grid, block, 0, st, A);
-  else if (N <= 64) hipLaunchKernelGGL((w8pt16_fwd_kernel<4, RAW, PLAIN>), grid, block, 0, st, A);
-  else if (N <= 112) hipLaunchKernelGGL((w8pt16_fwd_kernel<7, RAW, PLAIN>), grid, block, 0, st, A);
-  else hipLaunchKernelGGL((w8pt16_fwd_kernel<8, RAW, PLAIN>), grid, block, 0, st, A);
+  W8FwdRest R;
+  R.epi_res = A.epi_res; R.save = A.save; R.weights_out = A.weights_out; R.logits_mode = A.logits_mode; R.variant = A.variant;
+#define DFEPE_FWD(IT_)                                                                                                     \
+  hipLaunchKernelGGL((w8pt16_fwd_kernel<IT_, RAW, PLAIN>), grid, block, 0, st, A.pts1, A.pts2, A.wts, A.B, A.Bm, A.N, A.hw_sx, \
+                     A.hw_sy, A.clamp_at, A.F_out, A.residual, R)
+  if (N > 128) DFEPE_FWD(0);  // any N: correspondences re-read per phase
+  else if (N <= 16) DFEPE_FWD(1);
+  else if (N <= 32) DFEPE_FWD(2);
+  else if (N <= 64) DFEPE_FWD(4);
+  else if (N <= 112) DFEPE_FWD(7);
+  else DFEPE_FWD(8);
+#undef DFEPE_FWD
 }
 
 template <bool RAW, bool PGRAD>

@@ -381,6 +381,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   const int nit = (IT > 0) ? IT : (N + 15) >> 4;
   Pt pt[ITR];
   float wv[ITR];
+  float wsm[ITR];  // softmax weights as weights_out wants them (logits mode, IT > 0)
   bool kept[ITR];
   const float* wsrc = A.wts + (size_t)pair * N;
   float lmax = 0.0f, linv = 1.0f;  // softmax of the logits: w = exp(logit - lmax) * linv
@@ -428,9 +429,10 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
       linv = 1.0f / rg_sum(sm);
       static_for<0, IT>([&](auto c) {
         constexpr int it = decltype(c)::value;
-        const int i = it * 16 + l;
         const float wgt = wv[it] * linv;
-        if (A.weights_out != nullptr && i < N) A.weights_out[(size_t)pair * N + i] = wgt;
+        // weights_out is stored with the other per-correspondence outputs in phase 6: a store here is still in flight at the
+        // join with the plain-weights path, where the compiler has to wait for it (~1 us of store latency, nothing to hide it)
+        wsm[it] = wgt;
         wv[it] = kept[it] ? wgt : 0.0f;  // a dropped correspondence keeps its softmax weight in weights_out, not in X
       });
     }
@@ -653,36 +655,30 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
 
   DFEPE_MARK("P5s_save");
   if (A.save != nullptr) {
-    float* sv = A.save + (size_t)pair * DFEPE_SAVE_FLOATS;
-    // per-lane pieces: lane c < 9 writes f[c], z[c], td[c], te[c]; every lane writes its reflector components
-    float fm = (float)f[0], zm = (float)(sgn * z[0]);
-    double tdm = td[0], tem = te[0];
+    float* sv = static_cast<float*>(__builtin_assume_aligned(A.save, 16)) + (size_t)pair * DFEPE_SAVE_FLOATS;
+    // Everything but the reflector components is uniform over the row, so ONE lane per piece stores it with plain
+    // (wide) stores; picking "lane c writes element c" instead costs a select chain per element (~90 v_cndmask).
+    if (l == 0) {
 #pragma unroll
-    for (int c = 1; c < 9; ++c) {
-      fm = (l == c) ? (float)f[c] : fm;
-      zm = (l == c) ? (float)(sgn * z[c]) : zm;
-      tdm = (l == c) ? td[c] : tdm;
-      if (c < 8) tem = (l == c) ? te[c] : tem;
+      for (int c = 0; c < 9; ++c) sv[S16_F + c] = (float)f[c];
+    } else if (l == 1) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) sv[S16_Z + c] = (float)(sgn * z[c]);
+    } else if (l == 2) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) reinterpret_cast<double*>(sv + S16_TD)[c] = td[c];
+    } else if (l == 3) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) reinterpret_cast<double*>(sv + S16_TE)[c] = te[c];
+    } else if (l == 4) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { sv[S16_U3 + c] = (float)u3[c]; sv[S16_V3 + c] = (float)v3[c]; }
+#pragma unroll
+      for (int c = 0; c < 7; ++c) sv[S16_HB + c] = (float)hb[c];
     }
-    if (l < 9) {
-      sv[S16_F + l] = fm;
-      sv[S16_Z + l] = zm;
-      reinterpret_cast<double*>(sv + S16_TD)[l] = tdm;
-    }
-    if (l < 8) reinterpret_cast<double*>(sv + S16_TE)[l] = tem;
 #pragma unroll
     for (int k = 0; k < 7; ++k)  // lanes that hold no component of reflector k write a scratch slot: no branch per reflector
       sv[(l > k && l < 9) ? S16_HV + s16_hv_off(k) + (l - k - 1) : S16_SCRATCH] = (float)hv[k];
-    {
-      float uvm = (float)u3[0], hbm = (float)hb[0];
-#pragma unroll
-      for (int c = 1; c < 7; ++c) {
-        if (c < 6) uvm = (l == c) ? (float)((c < 3) ? u3[c] : v3[c - 3]) : uvm;
-        hbm = (l == c) ? (float)hb[c] : hbm;
-      }
-      if (l < 6) sv[S16_U3 + l] = uvm;  // u3 (3), v3 (3)
-      if (l < 7) sv[S16_HB + l] = hbm;
-    }
     if (l == 9) {
       sv[S16_T1 + 0] = (float)s1; sv[S16_T1 + 1] = (float)c1x; sv[S16_T1 + 2] = (float)c1y;
       sv[S16_T2 + 0] = (float)s2; sv[S16_T2 + 1] = (float)c2x; sv[S16_T2 + 2] = (float)c2y;
@@ -727,6 +723,9 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     if (valid) {
       rdst[i] = r;
       if (edst != nullptr) edst[i] = d;
+      if constexpr (IT > 0) {
+        if (A.logits_mode && A.weights_out != nullptr) A.weights_out[(size_t)pair * N + i] = wsm[it];
+      }
     }
   });
 }

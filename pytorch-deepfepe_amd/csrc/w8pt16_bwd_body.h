@@ -108,9 +108,21 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
 #pragma unroll
   for (int k = 0; k < 7; ++k) {
     hb[k] = sv[S16_HB + k];
-    hv[k] = (l > k && l < 9) ? (double)sv[S16_HV + s16_hv_off(k) + (l - k - 1)] : 0.0;
+    // unconditional load from a clamped slot, then a select: a load under `?:` compiles to branch + load + wait, seven
+    // dependent memory round trips in a row
+    const bool own = l > k && l < 9;
+    const float hvk = sv[own ? S16_HV + s16_hv_off(k) + (l - k - 1) : S16_SCRATCH];
+    hv[k] = own ? (double)hvk : 0.0;
   }
   const double lam = reinterpret_cast<const double*>(sv + S16_LAM)[0];
+  // d loss / d F_out and its scale: loaded here (null-safe addresses) with everything else, not where they are first used
+  float gF_in[9];
+  {
+    const float* gp = (A.g_F != nullptr) ? A.g_F + (size_t)pair * 9 : sv + S16_F;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) gF_in[c] = gp[c];
+  }
+  const float gs_in = ((A.g_scale != nullptr) ? A.g_scale : sv + S16_TAG)[l & 0];  // a vector load: the scalar cache would miss
   const int twist = (int)sv[S16_TWIST];
   const double inv_tr = sv[S16_INVTR];
   const bool good = sv[S16_TAG] == S16_TAG_VALUE;  // a record of the other forward kernel would be misread: poison instead
@@ -141,13 +153,29 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
     r.ws = r.w;
     return r;
   };
+  // Upstream per-correspondence gradients: null-safe pointers (an absent tensor reads the weights instead and is masked), so
+  // that every load is unconditional and can be issued with the correspondences -- one memory round trip, not one per use.
+  const bool has_res = A.g_res != nullptr, has_epi = A.g_epi != nullptr, has_wx = A.g_w_extra != nullptr;
+  const float* gres_p = has_res ? A.g_res + (size_t)pair * N : wsrc;
+  const float* gepi_p = has_epi ? A.g_epi + (size_t)pair * N : wsrc;
+  const float* gwx_p = has_wx ? A.g_w_extra + (size_t)pair * N : wsrc;
+  float gres_r[ITR], gepi_r[ITR], gwx_r[ITR];  // IT > 0: in registers from the start
   if constexpr (IT > 0) {
     static_for<0, IT>([&](auto c) {
       constexpr int it = decltype(c)::value;
-      const PRec r = point_decode(it, point_load(it));
+      const int i = it * 16 + l;
+      const int ic = (i < N) ? i : N - 1;
+      const RawRec raw = point_load(it);
+      const float a = gres_p[ic], b = gepi_p[ic], cxt = gwx_p[ic];
+      const PRec r = point_decode(it, raw);
       pt[it] = r.p; wv[it] = r.w; kept[it] = r.keep;
+      gres_r[it] = has_res ? a : 0.0f; gepi_r[it] = has_epi ? b : 0.0f; gwx_r[it] = has_wx ? cxt : 0.0f;
     });
   }
+  // upstream gradients of correspondence (it, i): registers (IT > 0) or unconditional loads (IT = 0); 0 when absent
+  auto up_res = [&](int it, int i) { if constexpr (IT > 0) return gres_r[it]; else return has_res ? gres_p[(i < N) ? i : N - 1] : 0.0f; };
+  auto up_epi = [&](int it, int i) { if constexpr (IT > 0) return gepi_r[it]; else return has_epi ? gepi_p[(i < N) ? i : N - 1] : 0.0f; };
+  auto up_wx = [&](int it, int i) { if constexpr (IT > 0) return gwx_r[it]; else return has_wx ? gwx_p[(i < N) ? i : N - 1] : 0.0f; };
   auto cached_load = [&](int it) {
     if constexpr (IT > 0) return RawRec{};
     else return point_load(it);
@@ -187,7 +215,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
         const double w = (double)wf;
         double ra[3], rb[2], inv;
         row_factors(p, s1, c1x, c1y, s2, c2x, c2y, ra, rb, inv);
-        const double gw = keep ? (double)A.g_res[(size_t)pair * N + i] * w * inv : 0.0;
+        const double gw = keep ? (double)up_res(it, i) * w * inv : 0.0;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const double ga = gw * ra[c];
@@ -207,7 +235,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
         const double S = i1 + i2, ad = fabs(dd);
         const double d = ad * S;
         // clamp(max=) passes the gradient up to and including the bound
-        const double g = (d <= (double)A.clamp_at) ? (double)A.g_epi[(size_t)pair * N + i] : 0.0;
+        const double g = (d <= (double)A.clamp_at) ? (double)up_epi(it, i) : 0.0;
         const double sg = (dd > 0.0) ? 1.0 : ((dd < 0.0) ? -1.0 : 0.0);
         const double k1 = (n1 > 0.0) ? ad * i1 * i1 * rcp_nr<1>(n1) : 0.0;
         const double k2 = (n2 > 0.0) ? ad * i2 * i2 * rcp_nr<1>(n2) : 0.0;
@@ -230,9 +258,9 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
   }
   if (A.g_F != nullptr) {
 #pragma unroll
-    for (int c = 0; c < 9; ++c) go[c] += (double)A.g_F[(size_t)pair * 9 + c];
+    for (int c = 0; c < 9; ++c) go[c] += (double)gF_in[c];
   }
-  const double gsc = (A.g_scale != nullptr) ? (double)A.g_scale[0] : 1.0;  // everything downstream is linear in the three gradients
+  const double gsc = (A.g_scale != nullptr) ? (double)gs_in : 1.0;  // everything downstream is linear in the three gradients
   if (A.g_scale != nullptr) {
 #pragma unroll
     for (int c = 0; c < 9; ++c) { go[c] *= gsc; gx[c] *= gsc; }
@@ -353,9 +381,9 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
     row_factors(p, s1, c1x, c1y, s2, c2x, c2y, ra, rb, inv);
     const double w = (double)wf;
     const double a = row_bilinear(ra, rb, f) * inv, b = row_bilinear(ra, rb, u) * inv;  // p^ . f, p^ . u
-    const double gr = (A.g_res != nullptr && valid) ? gsc * (double)A.g_res[(size_t)pair * N + i] : 0.0;
+    const double gr = valid ? gsc * (double)up_res(it, i) : 0.0;
     float gwi = keep ? (float)(2.0 * w * a * b + gr * a) : 0.0f;
-    if (A.g_w_extra != nullptr && valid) gwi += A.g_w_extra[(size_t)pair * N + i];
+    gwi += valid ? up_wx(it, i) : 0.0f;
     gwi = valid ? gwi : 0.0f;
     wg = fmaf(gwi, wf, wg);
     if constexpr (IT > 0) gwv[it] = gwi;
@@ -430,7 +458,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
       double af = 0.0, bu = 0.0;
 #pragma unroll
       for (int k = 0; k < 9; ++k) { af += ph[k] * f[k]; bu += ph[k] * u[k]; }
-      const double gr = (A.g_res != nullptr) ? gsc * (double)A.g_res[(size_t)pair * N + i] : 0.0;
+      const double gr = gsc * (double)up_res(it, i);
       const double cu = w * w * af, cf = w * w * bu + w * gr, dotp = 2.0 * w * w * af * bu + w * gr * af;
       double gp[9];
 #pragma unroll
@@ -449,7 +477,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
         const double n1 = sqrt_nr<1>(l1[0] * l1[0] + l1[1] * l1[1]), nn2 = sqrt_nr<1>(l2[0] * l2[0] + l2[1] * l2[1]);
         const double i1 = rcp_nr<1>(n1 + 1e-6), i2 = rcp_nr<1>(nn2 + 1e-6);
         const double Ss = i1 + i2, ad = fabs(dd);
-        const double g = (ad * Ss <= (double)A.clamp_at) ? gsc * (double)A.g_epi[(size_t)pair * N + i] : 0.0;
+        const double g = (ad * Ss <= (double)A.clamp_at) ? gsc * (double)up_epi(it, i) : 0.0;
         const double sg = (dd > 0.0) ? 1.0 : ((dd < 0.0) ? -1.0 : 0.0);
         const double k1 = (n1 > 0.0) ? ad * i1 * i1 * rcp_nr<1>(n1) : 0.0;
         const double k2 = (nn2 > 0.0) ? ad * i2 * i2 * rcp_nr<1>(nn2) : 0.0;

@@ -760,6 +760,7 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
   if (!pts1 || (!raw && !pts2) || !weights || !F_out || !residual) return DFEPE_ERR_INVALID_ARG;
   if (raw && !(image_w > 0.f && image_h > 0.f)) return DFEPE_ERR_INVALID_ARG;
   if (raw && (reinterpret_cast<uintptr_t>(pts1) & 15u)) return DFEPE_ERR_INVALID_ARG;  // float4 loads
+  if (reinterpret_cast<uintptr_t>(save) & 15u) return DFEPE_ERR_INVALID_ARG;          // wide stores of the record
 
   if (flags & ~DFEPE_W8PT_ALL_FLAGS) return DFEPE_ERR_INVALID_ARG;  // unknown flag bits are rejected, not ignored
   if (dfepe_w8pt_use_rows(N, (long long)B * n_weight_sets, flags)) {

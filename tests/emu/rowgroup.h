@@ -115,3 +115,7 @@ inline double rg_xchg(double v) {
 
 // all lanes' earlier shared-memory writes are visible after this
 inline void rg_sync() { emu::yield(); }
+
+// scheduling hint on the device, nothing to do here
+inline void rg_pin(float&) {}
+inline void rg_pin(double&) {}
