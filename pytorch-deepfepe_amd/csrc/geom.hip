@@ -350,11 +350,15 @@ cheirality_kernel(const float* __restrict__ E, const float* __restrict__ pre, co
     }
   int cnt[4] = {0, 0, 0, 0};
   const int nw = blockDim.x >> 6;  // 4 wavefronts per pair for small batches (latency), 1 for large ones (throughput)
+  // the next group's correspondence is loaded (index clamped, no branch) before the current one is triangulated: ~1 600
+  // instructions of DLT work cover its latency
+  const float4* mrow = reinterpret_cast<const float4*>(matches) + pair * N;
+  float4 mnext = mrow[min(wave * WAVE + lane, N - 1)];
   for (int base = wave * WAVE; base < N; base += nw * WAVE) {
     const int i = base + lane;
     const bool live = i < N;
-    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live) m = reinterpret_cast<const float4*>(matches)[pair * N + i];
+    const float4 m = mnext;
+    mnext = mrow[min(i + nw * WAVE, N - 1)];
     // One DLT per rotation: flipping t negates the 4th column of the view-2 rows, hence the 4th component of the null
     // vector, hence both depths exactly -- candidates (R,t) and (R,-t) are counted from the same triangulation.
 #pragma unroll

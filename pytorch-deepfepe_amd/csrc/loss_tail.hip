@@ -9,10 +9,16 @@ namespace {
 
 constexpr int kPairsPerBlock = 16;
 
+// Leading scalar / pointer arguments: preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count, see w8pt16.hip); the
+// kernel reads them instead of the copies inside A.
 template <int IT>
-__global__ void __launch_bounds__(256) loss_tail_kernel(const TailArgs A, double* __restrict__ partials) {
+__global__ void __launch_bounds__(256)
+loss_tail_kernel(const float* F_layers, int L, int B, int M, int t_stride, const float* T1, const float* T2, const float* K,
+                 const float* virt1, const TailArgs A0, double* __restrict__ partials) {
   __shared__ float lds[kPairsPerBlock][kTailLdsFloats];
   __shared__ double part[kPairsPerBlock][kTailParts];
+  TailArgs A = A0;
+  A.F_layers = F_layers; A.L = L; A.B = B; A.M = M; A.t_stride = t_stride; A.T1 = T1; A.T2 = T2; A.K = K; A.virt1 = virt1;
   const int row = (int)(threadIdx.x >> 4);
   const int pair = (int)blockIdx.x * kPairsPerBlock + row;
   for (int e = (int)(threadIdx.x & 15u); e < kTailParts; e += 16) part[row][e] = 0.0;
@@ -136,11 +142,11 @@ extern "C" int dfepe_loss_tail(const float* F_layers, int L, int B, const float*
   double* partials = static_cast<double*>(workspace);
   const dim3 grid((B + kPairsPerBlock - 1) / kPairsPerBlock), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (M <= 16) hipLaunchKernelGGL((loss_tail_kernel<1>), grid, block, 0, st, A, partials);
-  else if (M <= 32) hipLaunchKernelGGL((loss_tail_kernel<2>), grid, block, 0, st, A, partials);
-  else if (M <= 64) hipLaunchKernelGGL((loss_tail_kernel<4>), grid, block, 0, st, A, partials);
-  else if (M <= 112) hipLaunchKernelGGL((loss_tail_kernel<7>), grid, block, 0, st, A, partials);
-  else hipLaunchKernelGGL((loss_tail_kernel<8>), grid, block, 0, st, A, partials);
+  if (M <= 16) hipLaunchKernelGGL((loss_tail_kernel<1>), grid, block, 0, st, A.F_layers, A.L, A.B, A.M, A.t_stride, A.T1, A.T2, A.K, A.virt1, A, partials);
+  else if (M <= 32) hipLaunchKernelGGL((loss_tail_kernel<2>), grid, block, 0, st, A.F_layers, A.L, A.B, A.M, A.t_stride, A.T1, A.T2, A.K, A.virt1, A, partials);
+  else if (M <= 64) hipLaunchKernelGGL((loss_tail_kernel<4>), grid, block, 0, st, A.F_layers, A.L, A.B, A.M, A.t_stride, A.T1, A.T2, A.K, A.virt1, A, partials);
+  else if (M <= 112) hipLaunchKernelGGL((loss_tail_kernel<7>), grid, block, 0, st, A.F_layers, A.L, A.B, A.M, A.t_stride, A.T1, A.T2, A.K, A.virt1, A, partials);
+  else hipLaunchKernelGGL((loss_tail_kernel<8>), grid, block, 0, st, A.F_layers, A.L, A.B, A.M, A.t_stride, A.T1, A.T2, A.K, A.virt1, A, partials);
   TailHead H;
   H.partials = partials; H.nblocks = (int)grid.x; H.L = L; H.B = B; H.M = M; H.pose = (q_gt != nullptr) ? 1 : 0;
   H.packed = packed; H.scalars = scalars; H.balance_F = balance_F; H.balance_q = balance_q; H.balance_t = balance_t;

@@ -11,7 +11,7 @@ namespace {
 
 constexpr int kPairsPerBlock = 16;
 
-// Kernel arguments: what a wavefront needs before it can issue its global loads comes first, as plain scalars / pointers --
+// Kernel arguments (forward and backward alike): what a wavefront needs before it can issue its global loads comes first, as plain scalars / pointers --
 // with -amdgpu-kernarg-preload-count=16 (build.py) the command processor hands those 16 dwords over in SGPRs at wave launch,
 // so the loads do not wait for a scalar-cache miss on the kernarg segment first; the rest follows as a struct and is fetched
 // in the shadow of the global loads.
@@ -38,11 +38,31 @@ w8pt16_fwd_kernel(const float* pts1, const float* pts2, const float* wts, int B,
   w8pt16_fwd_pair<IT, RAW, PLAIN>(A, pair, xch + row * 36);
 }
 
+struct W8BwdRest {
+  const float* F_out;
+  const float* g_F;
+  const float* g_res;
+  const float* g_epi;
+  const float* g_w_extra;
+  const float* g_scale;
+  float* g_w;
+  float* g_p1;
+  float* g_p2;
+  int logits_mode;
+};
+
 template <int IT, bool RAW, bool PGRAD>
-__global__ void __launch_bounds__(256) w8pt16_bwd_kernel(const W8BwdArgs A) {
+__global__ void __launch_bounds__(256)
+w8pt16_bwd_kernel(const float* pts1, const float* pts2, const float* wts, int B, int Bm, int N, float hw_sx, float hw_sy,
+                  float clamp_at, const float* save, const W8BwdRest R) {
   const int row = (int)(threadIdx.x >> 4);
   const int pair = (int)blockIdx.x * kPairsPerBlock + row;
-  if (pair >= A.B) return;
+  if (pair >= B) return;
+  W8BwdArgs A;
+  A.pts1 = pts1; A.pts2 = pts2; A.wts = wts; A.B = B; A.Bm = Bm; A.N = N; A.hw_sx = hw_sx; A.hw_sy = hw_sy;
+  A.clamp_at = clamp_at; A.save = save; A.F_out = R.F_out; A.g_F = R.g_F; A.g_res = R.g_res; A.g_epi = R.g_epi;
+  A.g_w_extra = R.g_w_extra; A.g_scale = R.g_scale; A.g_w = R.g_w; A.g_p1 = R.g_p1; A.g_p2 = R.g_p2;
+  A.logits_mode = R.logits_mode;
   w8pt16_bwd_pair_impl<IT, RAW, PGRAD>(A, pair, nullptr);
 }
 
@@ -68,12 +88,19 @@ template <bool RAW, bool PGRAD>
 void launch_bwd(const W8BwdArgs& A, hipStream_t st) {
   const dim3 grid((A.B + kPairsPerBlock - 1) / kPairsPerBlock), block(256);
   const int N = A.N;
-  if (N > 128) hipLaunchKernelGGL((w8pt16_bwd_kernel<0, RAW, PGRAD>), grid, block, 0, st, A);
-  else if (N <= 16) hipLaunchKernelGGL((w8pt16_bwd_kernel<1, RAW, PGRAD>), grid, block, 0, st, A);
-  else if (N <= 32) hipLaunchKernelGGL((w8pt16_bwd_kernel<2, RAW, PGRAD>), grid, block, 0, st, A);
-  else if (N <= 64) hipLaunchKernelGGL((w8pt16_bwd_kernel<4, RAW, PGRAD>), grid, block, 0, st, A);
-  else if (N <= 112) hipLaunchKernelGGL((w8pt16_bwd_kernel<7, RAW, PGRAD>), grid, block, 0, st, A);
-  else hipLaunchKernelGGL((w8pt16_bwd_kernel<8, RAW, PGRAD>), grid, block, 0, st, A);
+  W8BwdRest R;
+  R.F_out = A.F_out; R.g_F = A.g_F; R.g_res = A.g_res; R.g_epi = A.g_epi; R.g_w_extra = A.g_w_extra; R.g_scale = A.g_scale;
+  R.g_w = A.g_w; R.g_p1 = A.g_p1; R.g_p2 = A.g_p2; R.logits_mode = A.logits_mode;
+#define DFEPE_BWD(IT_)                                                                                                     \
+  hipLaunchKernelGGL((w8pt16_bwd_kernel<IT_, RAW, PGRAD>), grid, block, 0, st, A.pts1, A.pts2, A.wts, A.B, A.Bm, A.N, A.hw_sx, \
+                     A.hw_sy, A.clamp_at, A.save, R)
+  if (N > 128) DFEPE_BWD(0);
+  else if (N <= 16) DFEPE_BWD(1);
+  else if (N <= 32) DFEPE_BWD(2);
+  else if (N <= 64) DFEPE_BWD(4);
+  else if (N <= 112) DFEPE_BWD(7);
+  else DFEPE_BWD(8);
+#undef DFEPE_BWD
 }
 
 }  // namespace
