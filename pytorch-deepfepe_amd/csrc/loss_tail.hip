@@ -9,22 +9,37 @@ namespace {
 
 constexpr int kPairsPerBlock = 16;
 
+// Workgroup = 16 pairs: wavefronts 0..3 run the F-loss rows (16 lanes per pair), the wavefronts after them the 3x3 work, one
+// lane per (pair, layer) -- 16 L items, layer-major so that a wavefront's lanes run the same layer.  The two parts are
+// independent until the final g_F = coef_F * (F-loss part) + (pose part), so they run CONCURRENTLY on the same SIMDs: B = 4096
+// is one F-loss wavefront per SIMD, and a lone wavefront leaves a quarter of the issue slots and every memory wait unused.
+// (In one row per pair, one part after the other, the kernel took 17 us.)
 // Leading scalar / pointer arguments: preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count, see w8pt16.hip); the
 // kernel reads them instead of the copies inside A.
 template <int IT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 loss_tail_kernel(const float* F_layers, int L, int B, int M, int t_stride, const float* T1, const float* T2, const float* K,
                  const float* virt1, const TailArgs A0, double* __restrict__ partials) {
   __shared__ float lds[kPairsPerBlock][kTailLdsFloats];
   __shared__ double part[kPairsPerBlock][kTailParts];
   TailArgs A = A0;
   A.F_layers = F_layers; A.L = L; A.B = B; A.M = M; A.t_stride = t_stride; A.T1 = T1; A.T2 = T2; A.K = K; A.virt1 = virt1;
-  const int row = (int)(threadIdx.x >> 4);
-  const int pair = (int)blockIdx.x * kPairsPerBlock + row;
-  for (int e = (int)(threadIdx.x & 15u); e < kTailParts; e += 16) part[row][e] = 0.0;
-  rg_sync();
-  if (pair < A.B) loss_tail_pair<IT>(A, pair, lds[row], part[row]);
+  const int pair0 = (int)blockIdx.x * kPairsPerBlock;
+  for (int e = (int)threadIdx.x; e < kPairsPerBlock * kTailParts; e += (int)blockDim.x) (&part[0][0])[e] = 0.0;
   __syncthreads();
+  const bool floss_wave = threadIdx.x < 256u;  // uniform per wavefront
+  const int row = (int)(threadIdx.x >> 4) & 15;
+  if (floss_wave) {
+    if (pair0 + row < B) tail_floss_row<IT>(A, pair0 + row, lds[row], part[row], lds[row] + kTailMaxLayers * 9);
+  } else {
+    const int item = (int)threadIdx.x - 256;  // layer-major: item = layer * 16 + pair-in-workgroup
+    const int layer = item >> 4, prow = item & 15;
+    if (layer < L && pair0 + prow < B)
+      tail_pose_item(A, pair0 + prow, layer, lds[prow] + 2 * kTailMaxLayers * 9 + layer * 9, &part[prow][kTailMaxLayers + layer],
+                     &part[prow][2 * kTailMaxLayers + layer]);
+  }
+  __syncthreads();
+  if (floss_wave && pair0 + row < B) tail_floss_finish(A, pair0 + row, lds[row] + kTailMaxLayers * 9, lds[row] + 2 * kTailMaxLayers * 9);
   // per-workgroup partial sums of the loss head, rows added in fixed order
   if (threadIdx.x < kTailParts) {
     double s = 0.0;
@@ -140,7 +155,8 @@ extern "C" int dfepe_loss_tail(const float* F_layers, int L, int B, const float*
   A.loss_sum = loss_sum; A.E_layers = E_layers; A.q_l2 = q_l2; A.t_l2 = t_l2; A.R_deg = R_deg; A.t_deg = t_deg; A.sel = sel;
   A.g_F = g_F_layers;
   double* partials = static_cast<double*>(workspace);
-  const dim3 grid((B + kPairsPerBlock - 1) / kPairsPerBlock), block(256);
+  // 4 F-loss wavefronts + one lane per (pair, layer): 16 L lanes, rounded up to wavefronts
+  const dim3 grid((B + kPairsPerBlock - 1) / kPairsPerBlock), block(256 + 64 * ((kPairsPerBlock * L + 63) / 64));
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (M <= 16) hipLaunchKernelGGL((loss_tail_kernel<1>), grid, block, 0, st, A.F_layers, A.L, A.B, A.M, A.t_stride, A.T1, A.T2, A.K, A.virt1, A, partials);
   else if (M <= 32) hipLaunchKernelGGL((loss_tail_kernel<2>), grid, block, 0, st, A.F_layers, A.L, A.B, A.M, A.t_stride, A.T1, A.T2, A.K, A.virt1, A, partials);

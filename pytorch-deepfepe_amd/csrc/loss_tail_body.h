@@ -7,8 +7,9 @@
 // of each term is formed right where its forward value is: the epipolar terms of a virtual point are computed once and feed
 // both the loss sum and the gradient sum; the pose adjoint follows the pose errors in the same lane.  This replaces five
 // launches (floss_fwd, pose_fwd, loss_head, pose_bwd, floss_bwd: ~47 us of mostly launch latency and dependent global loads
-// at B = 4096) by one.  Lanes stride over the M <= 128 virtual points (transformed once, kept in registers for all layers);
-// lane l < L owns layer l for the 3x3 work (E, pose forward + adjoint).  Written against rowgroup.h only (tests/emu/).
+// at B = 4096) by one.  Two parts: the F-loss rows (lanes stride over the M <= 128 virtual points, transformed once and kept in
+// registers for all layers) and the 3x3 work of each (pair, layer) in one lane (E, pose forward + adjoint).  Written against
+// rowgroup.h only (tests/emu/).
 #pragma once
 #include <rowgroup.h>  // angle brackets on purpose: tests/emu/ substitutes its host emulation through the include path
 
@@ -17,7 +18,7 @@
 #include "pose_math.h"
 
 constexpr int kTailMaxLayers = 16;
-constexpr int kTailLdsFloats = 2 * kTailMaxLayers * 9;  // per pair: F of every layer, then the pose part of d loss / d F
+constexpr int kTailLdsFloats = 3 * kTailMaxLayers * 9;  // per pair: F of every layer, the F-loss and the pose parts of d loss / d F
 constexpr int kTailParts = 3 * kTailMaxLayers;          // per pair: loss_sum[l], clamp(q_l2[l]), clamp(t_l2[l])
 
 struct TailArgs {
@@ -71,25 +72,89 @@ __device__ __forceinline__ void tail_eval_point(const float* v, const double* T,
   for (int r = 0; r < 3; ++r) x[r] = (float)(T[3 * r] * a + T[3 * r + 1] * b + T[3 * r + 2] * c);
 }
 
-// lds: kTailLdsFloats floats, part: kTailParts doubles (zero-initialised by the caller), both private to this pair's row
+// ---- the 3x3 part of ONE (pair, layer): E = K^T T2^T F T1 K, its pose errors and their adjoint ----------------------------
+// Plain single-lane code (no row primitives).  gpose: 9 floats, the pose part of d loss / d F of this (pair, layer);
+// part_q / part_t: where clamp(q_l2), clamp(t_l2) of this item go for the loss-head sums.
+__device__ __forceinline__ void tail_pose_item(const TailArgs& A, const int pair, const int layer, float* gpose, double* part_q,
+                                               double* part_t) {
+  const int B = A.B;
+  // every global load first (null-safe addresses): one memory round trip
+  double t1[9], t2[9], k[9], o[9];
+  float qg[4], tg[3], Rg[9];
+  const bool has_pose = A.q_gt != nullptr, has_R = has_pose && A.R_gt != nullptr;
+  {
+    const float* safe = A.K + (size_t)pair * 9;
+    const float* qp = has_pose ? A.q_gt + (size_t)pair * 4 : safe;
+    const float* tp = has_pose ? A.t_gt + (size_t)pair * 3 : safe;
+    const float* rp = has_R ? A.R_gt + (size_t)pair * 9 : safe;
+    const float* fp = A.F_layers + ((size_t)layer * B + pair) * 9;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      t1[c] = A.T1[(size_t)pair * A.t_stride + c]; t2[c] = A.T2[(size_t)pair * A.t_stride + c];
+      k[c] = safe[c]; o[c] = fp[c]; Rg[c] = rp[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qg[c] = qp[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) tg[c] = tp[c];
+  }
+  // consumers of the loads above must not sink below the stores of E (the memory counter is in-order: they would wait for the
+  // stores to complete)
+#pragma unroll
+  for (int c = 0; c < 9; ++c) rg_pin(Rg[c]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) rg_pin(qg[c]);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) rg_pin(tg[c]);
+  double Am[9], Cm[9], tmp[9], e[9];
+  mat3_mul(t2, k, Am);  // A = T2 K, C = T1 K:  E = A^T F C
+  mat3_mul(t1, k, Cm);
+  const size_t lb = (size_t)layer * B + pair;
+  mat3_mul_tn(Am, o, tmp);
+  mat3_mul(tmp, Cm, e);
+  float Ef[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) { Ef[c] = (float)e[c]; A.E_layers[lb * 9 + c] = Ef[c]; gpose[c] = 0.0f; }
+  if (!has_pose) return;
+  Pose P;
+  pose_forward(Ef, qg, tg, P);  // on the fp32 E, like dfepe_pose_fwd on E_layers
+  const double qe = P.qe[P.qi], te = P.te[P.ti];
+  A.q_l2[lb] = (float)qe;
+  A.t_l2[lb] = (float)te;
+  if (A.sel != nullptr) A.sel[lb] = P.qi | (P.ti << 1);
+  if (A.R_deg != nullptr && A.R_gt != nullptr) A.R_deg[lb] = (float)pose_R_deg(P, Rg);
+  if (A.t_deg != nullptr) A.t_deg[lb] = (float)pose_t_deg(P);
+  *part_q = (double)fminf(fmaxf((float)qe, 0.0f), A.clamp_q);
+  *part_t = (double)fminf(fmaxf((float)te, 0.0f), A.clamp_t);
+  if (A.g_F != nullptr) {
+    // torch.clamp passes the gradient on [min, max] inclusive
+    const double gql = ((float)qe <= A.clamp_q) ? (double)A.coef_q : 0.0;
+    const double gtl = ((float)te <= A.clamp_t) ? (double)A.coef_t : 0.0;
+    double gE[9], add[9];
+    pose_backward(P, qg, gql, gtl, gE);
+    // through dfepe_pose_bwd's fp32 g_E, then E = A^T F C:  g_F += A g_E C^T
+#pragma unroll
+    for (int c = 0; c < 9; ++c) gE[c] = (double)(float)gE[c];
+    mat3_mul(Am, gE, tmp);
+    mat3_mul_nt(tmp, Cm, add);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) gpose[c] = (float)add[c];
+  }
+}
+
+// ---- the F-loss of every layer of one pair over its virtual points, with its gradient: one 16-lane row ---------------------
+// Phase 1 (tail_floss_row): everything that does not need the pose part; leaves the per-layer gradient sums of lane c < 9 in
+// gsum[ly] and writes loss_sum / part[ly].  Phase 2 (tail_floss_finish), after the pose items of this pair are done:
+// g_F = coef_F * gsum + gpose (lane c < 9 reads back what it wrote).
+// ldsF, gsum: kTailMaxLayers * 9 floats each, private to the row.
 template <int IT>
-__device__ __forceinline__ void loss_tail_pair(const TailArgs& A, const int pair, float* lds, double* part) {
+__device__ __forceinline__ void tail_floss_row(const TailArgs& A, const int pair, float* ldsF, double* part, float* gsum) {
   const int l = rg_lane();
   const int L = A.L, B = A.B, M = A.M;
-  float* ldsF = lds;                       // [L][9] F of every layer
-  float* ldsG = lds + kTailMaxLayers * 9;  // [L][9] pose part of d loss / d F
-  double t1[9], t2[9], Am[9], Cm[9];
+  // every global load first: transforms, the pair's virtual points (index clamped, masked afterwards), F of every layer
+  double t1[9], t2[9];
 #pragma unroll
   for (int c = 0; c < 9; ++c) { t1[c] = A.T1[(size_t)pair * A.t_stride + c]; t2[c] = A.T2[(size_t)pair * A.t_stride + c]; }
-  {
-    double k[9];
-#pragma unroll
-    for (int c = 0; c < 9; ++c) k[c] = A.K[(size_t)pair * 9 + c];
-    mat3_mul(t2, k, Am);  // A = T2 K, C = T1 K:  E = A^T F C
-    mat3_mul(t1, k, Cm);
-  }
-  // ---- every global load of the kernel, issued together (one memory round trip): the pair's virtual points (index clamped,
-  // masked afterwards), the ground truth of the pose part (null-safe addresses), F of every layer
   float x1[IT][3], x2[IT][3], vm[IT];
   float r1[IT][3], r2[IT][3];
   const float* v1 = A.virt1 + (size_t)pair * M * 3;
@@ -102,20 +167,6 @@ __device__ __forceinline__ void loss_tail_pair(const TailArgs& A, const int pair
     for (int k = 0; k < 3; ++k) { r1[it][k] = v1[3 * ic + k]; r2[it][k] = v2[3 * ic + k]; }
     vm[it] = (i < M) ? 1.0f : 0.0f;
   }
-  const bool has_pose = A.q_gt != nullptr, has_R = has_pose && A.R_gt != nullptr;
-  float qg[4], tg[3], Rg[9];
-  {
-    const float* safe = A.K + (size_t)pair * 9;
-    const float* qp = has_pose ? A.q_gt + (size_t)pair * 4 : safe;
-    const float* tp = has_pose ? A.t_gt + (size_t)pair * 3 : safe;
-    const float* rp = has_R ? A.R_gt + (size_t)pair * 9 : safe;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) qg[k] = qp[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) tg[k] = tp[k];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Rg[k] = rp[k];
-  }
   constexpr int kPer = (kTailMaxLayers * 9 + 15) / 16;
   float fl[kPer];
 #pragma unroll
@@ -124,70 +175,17 @@ __device__ __forceinline__ void loss_tail_pair(const TailArgs& A, const int pair
     const int ly = ec / 9, c = ec - 9 * ly;
     fl[k] = A.F_layers[((size_t)ly * B + pair) * 9 + c];
   }
-  // ---- the virtual points, transformed once.  They are needed only after the pose block below, which stores its results:
-  // left to itself the compiler sinks the transforms (and the consumers of the loads above) past those stores, and the
-  // in-order memory counter then makes them wait for the stores to complete -- hence the pins.
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
     tail_eval_point(r1[it], t1, x1[it]);
     tail_eval_point(r2[it], t2, x2[it]);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { rg_pin(x1[it][k]); rg_pin(x2[it][k]); }
   }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) rg_pin(qg[k]);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) rg_pin(tg[k]);
-#pragma unroll
-  for (int k = 0; k < 9; ++k) rg_pin(Rg[k]);
 #pragma unroll
   for (int k = 0; k < kPer; ++k) {
     const int e = k * 16 + l;
-    if (e < L * 9) { ldsF[e] = fl[k]; ldsG[e] = 0.0f; }
+    if (e < L * 9) ldsF[e] = fl[k];
   }
   rg_sync();
-
-  // ---- lane l < L: E of layer l, its pose errors and their adjoint ---------------------------------------------
-  if (l < L) {
-    const size_t lb = (size_t)l * B + pair;
-    double o[9], tmp[9], e[9];
-#pragma unroll
-    for (int c = 0; c < 9; ++c) o[c] = (double)ldsF[l * 9 + c];
-    mat3_mul_tn(Am, o, tmp);
-    mat3_mul(tmp, Cm, e);
-    float Ef[9];
-#pragma unroll
-    for (int c = 0; c < 9; ++c) { Ef[c] = (float)e[c]; A.E_layers[lb * 9 + c] = Ef[c]; }
-    if (A.q_gt != nullptr) {
-      Pose P;
-      pose_forward(Ef, qg, tg, P);  // on the fp32 E, like dfepe_pose_fwd on E_layers
-      const double qe = P.qe[P.qi], te = P.te[P.ti];
-      A.q_l2[lb] = (float)qe;
-      A.t_l2[lb] = (float)te;
-      if (A.sel != nullptr) A.sel[lb] = P.qi | (P.ti << 1);
-      if (A.R_deg != nullptr && A.R_gt != nullptr) A.R_deg[lb] = (float)pose_R_deg(P, Rg);
-      if (A.t_deg != nullptr) A.t_deg[lb] = (float)pose_t_deg(P);
-      part[kTailMaxLayers + l] = (double)fminf(fmaxf((float)qe, 0.0f), A.clamp_q);
-      part[2 * kTailMaxLayers + l] = (double)fminf(fmaxf((float)te, 0.0f), A.clamp_t);
-      if (A.g_F != nullptr) {
-        // torch.clamp passes the gradient on [min, max] inclusive
-        const double gql = ((float)qe <= A.clamp_q) ? (double)A.coef_q : 0.0;
-        const double gtl = ((float)te <= A.clamp_t) ? (double)A.coef_t : 0.0;
-        double gE[9], add[9];
-        pose_backward(P, qg, gql, gtl, gE);
-        // through dfepe_pose_bwd's fp32 g_E, then E = A^T F C:  g_F += A g_E C^T
-#pragma unroll
-        for (int c = 0; c < 9; ++c) gE[c] = (double)(float)gE[c];
-        mat3_mul(Am, gE, tmp);
-        mat3_mul_nt(tmp, Cm, add);
-#pragma unroll
-        for (int c = 0; c < 9; ++c) ldsG[l * 9 + c] = (float)add[c];
-      }
-    }
-  }
-  rg_sync();
-
-  // ---- F-loss of every layer over the virtual points, with its gradient ---------------------------------------------
   const bool grad = A.g_F != nullptr;
   for (int ly = 0; ly < L; ++ly) {
     float o[9];
@@ -233,7 +231,27 @@ __device__ __forceinline__ void loss_tail_pair(const TailArgs& A, const int pair
         const float tot = rg_sum(gof[c]);
         mine = (l == c) ? tot : mine;
       }
-      if (l < 9) A.g_F[((size_t)ly * B + pair) * 9 + l] = fmaf(A.coef_F, mine, ldsG[ly * 9 + l]);
+      if (l < 9) gsum[ly * 9 + l] = mine;
     }
   }
+}
+__device__ __forceinline__ void tail_floss_finish(const TailArgs& A, const int pair, const float* gsum, const float* gpose /*[L][9]*/) {
+  const int l = rg_lane();
+  if (A.g_F == nullptr || l >= 9) return;
+  for (int ly = 0; ly < A.L; ++ly) A.g_F[((size_t)ly * A.B + pair) * 9 + l] = fmaf(A.coef_F, gsum[ly * 9 + l], gpose[ly * 9 + l]);
+}
+
+// One pair in ONE row, both parts in sequence (lane l < L takes layer l's 3x3 work): what tests/emu/ runs; the kernel
+// (loss_tail.hip) runs the two parts in different wavefronts of a workgroup so that they overlap.
+// lds: kTailLdsFloats floats, part: kTailParts doubles (zero-initialised by the caller), both private to this pair's row
+template <int IT>
+__device__ __forceinline__ void loss_tail_pair(const TailArgs& A, const int pair, float* lds, double* part) {
+  const int l = rg_lane();
+  float* ldsF = lds;                        // [L][9] F of every layer
+  float* gsum = lds + kTailMaxLayers * 9;       // [L][9] F-loss part of d loss / d F (before coef_F)
+  float* gpose = lds + 2 * kTailMaxLayers * 9;  // [L][9] pose part of d loss / d F
+  if (l < A.L) tail_pose_item(A, pair, l, gpose + l * 9, part + kTailMaxLayers + l, part + 2 * kTailMaxLayers + l);
+  rg_sync();
+  tail_floss_row<IT>(A, pair, ldsF, part, gsum);
+  tail_floss_finish(A, pair, gsum, gpose);
 }
