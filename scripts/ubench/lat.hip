@@ -11,6 +11,8 @@ __global__ void __launch_bounds__(64) k(double* out, double seed, long long* cyc
   double a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
   float f0 = (float)a0, f1 = f0 + 1, f2 = f0 + 2, f3 = f0 + 3;
   const double m = 0.999999, c = 1e-9;
+  double b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+  float g0 = 0, g1 = 0, g2 = 0, g3 = 0;
   long long t0 = __builtin_amdgcn_s_memrealtime();
   long long c0 = __builtin_readcyclecounter();
   for (int it = 0; it < 64; ++it) {
@@ -42,11 +44,35 @@ __global__ void __launch_bounds__(64) k(double* out, double seed, long long* cyc
       if (MODE == 13) {  // cvt chain: f64->f32->f64
         for (int q = 0; q < 2; ++q) { float t = (float)a0; a0 = (double)t; }
       }
+      // ---- issue cost of single instructions, four independent destinations each (no dependence between them)
+      if (MODE == 14) asm volatile("v_mov_b64_dpp %0, %4 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+                                   "v_mov_b64_dpp %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %3, %7 row_newbcast:3 row_mask:0xf bank_mask:0xf"
+                                   : "=v"(b0), "=v"(b1), "=v"(b2), "=v"(b3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+      if (MODE == 15) asm volatile("v_mov_b32_dpp %0, %4 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+                                   "v_mov_b32_dpp %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %7 row_newbcast:3 row_mask:0xf bank_mask:0xf"
+                                   : "=v"(g0), "=v"(g1), "=v"(g2), "=v"(g3) : "v"(f0), "v"(f1), "v"(f2), "v"(f3));
+      if (MODE == 16) asm volatile("v_cvt_f64_f32 %0, %4\n v_cvt_f64_f32 %1, %5\n v_cvt_f64_f32 %2, %6\n v_cvt_f64_f32 %3, %7"
+                                   : "=v"(b0), "=v"(b1), "=v"(b2), "=v"(b3) : "v"(f0), "v"(f1), "v"(f2), "v"(f3));
+      if (MODE == 17) asm volatile("v_cvt_f32_f64 %0, %4\n v_cvt_f32_f64 %1, %5\n v_cvt_f32_f64 %2, %6\n v_cvt_f32_f64 %3, %7"
+                                   : "=v"(g0), "=v"(g1), "=v"(g2), "=v"(g3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+      if (MODE == 18) asm volatile("v_cndmask_b32 %0, %4, %5, vcc\n v_cndmask_b32 %1, %5, %6, vcc\n v_cndmask_b32 %2, %6, %7, vcc\n v_cndmask_b32 %3, %7, %4, vcc"
+                                   : "=v"(g0), "=v"(g1), "=v"(g2), "=v"(g3) : "v"(f0), "v"(f1), "v"(f2), "v"(f3) : "vcc");
+      if (MODE == 19) asm volatile("v_mul_f64 %0, %4, %5\n v_mul_f64 %1, %5, %6\n v_add_f64 %2, %6, %7\n v_add_f64 %3, %7, %4"
+                                   : "=v"(b0), "=v"(b1), "=v"(b2), "=v"(b3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+      if (MODE == 20) asm volatile("v_accvgpr_write_b32 a0, %4\n v_accvgpr_write_b32 a1, %5\n v_accvgpr_read_b32 %0, a2\n v_accvgpr_read_b32 %1, a3\n"
+                                   : "=v"(g0), "=v"(g1), "=v"(g2), "=v"(g3) : "v"(f0), "v"(f1), "v"(f2), "v"(f3) : "a0", "a1", "a2", "a3");
+      if (MODE == 21) asm volatile("v_mov_b64 %0, %4\n v_mov_b64 %1, %5\n v_mov_b64 %2, %6\n v_mov_b64 %3, %7"
+                                   : "=v"(b0), "=v"(b1), "=v"(b2), "=v"(b3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+      if (MODE == 22) asm volatile("v_fmac_f64_dpp %0, %4, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %1, %5, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+                                   "v_fmac_f64_dpp %2, %6, %7 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %3, %7, %4 row_newbcast:3 row_mask:0xf bank_mask:0xf"
+                                   : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+      if (MODE == 23) asm volatile("v_exp_f32 %0, %4\n v_exp_f32 %1, %5\n v_rsq_f32 %2, %6\n v_sqrt_f32 %3, %7"
+                                   : "=v"(g0), "=v"(g1), "=v"(g2), "=v"(g3) : "v"(f0), "v"(f1), "v"(f2), "v"(f3));
     }
   }
   long long c1 = __builtin_readcyclecounter();
   long long t1 = __builtin_amdgcn_s_memrealtime();
-  out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + f0 + f1 + f2 + f3;
+  out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + f0 + f1 + f2 + f3 + b0 + b1 + b2 + b3 + g0 + g1 + g2 + g3;
   if (threadIdx.x == 0 && blockIdx.x == 0) { cyc[0] = c1 - c0; cyc[1] = t1 - t0; }
 }
 
@@ -71,7 +97,7 @@ void run(const char* name, int ops_per_rep4, int blocks) {
 }
 
 int main() {
-  for (int blocks : {1, 1024, 2048, 4096}) {
+  for (int blocks : {1, 1024, 4096}) {
     run<0>("fp64 fma dependent", 4, blocks);
     run<1>("fp64 fma 4 independent chains", 4, blocks);
     run<2>("fp32 fma dependent", 4, blocks);
@@ -86,6 +112,16 @@ int main() {
     run<9>("v_rsq_f64 independent", 4, blocks);
     run<10>("v_fmac_f64_dpp (acc chain)", 4, blocks);
     run<11>("s_nop 1 + v_fmac_f64_dpp (src = acc)", 4, blocks);
+    run<14>("v_mov_b64_dpp x4 independent", 4, blocks);
+    run<15>("v_mov_b32_dpp x4 independent", 4, blocks);
+    run<16>("v_cvt_f64_f32 x4 independent", 4, blocks);
+    run<17>("v_cvt_f32_f64 x4 independent", 4, blocks);
+    run<18>("v_cndmask_b32 x4 independent", 4, blocks);
+    run<19>("v_mul_f64 x2 + v_add_f64 x2 independent", 4, blocks);
+    run<20>("v_accvgpr_write x2 + read x2", 4, blocks);
+    run<21>("v_mov_b64 x4 independent", 4, blocks);
+    run<22>("v_fmac_f64_dpp x4 independent accumulators", 4, blocks);
+    run<23>("v_exp_f32 x2, v_rsq_f32, v_sqrt_f32", 4, blocks);
   }
   return 0;
 }
