@@ -281,9 +281,15 @@ def main():
                     wps = -(-B // 4096)
                     cyc = wps * valu * 4.0
                     clk = tj.get("fit_fwd_sustained_clock_ghz")
+                    # ~5.1 cycles of SIMD time per VALU instruction of this mix (scripts/ubench/lat.hip: fp64 FMA, DPP moves,
+                    # conversions, selects; the same with one or four wavefronts per SIMD) at the sustained clock of the PMC pass
+                    real_us = wps * valu * 5.1 / ((clk or 2.0) * 1e3)
                     issue = {"valu_insts_per_wave": valu, "waves_per_simd": wps, "cycles": round(cyc),
                              "floor_us_at_2.4GHz": round(cyc / 2.4e3, 2), "frac_of_kernel_time_at_2.4GHz": round(cyc / 2.4e3 / kdur_us, 3),
-                             "sustained_clock_ghz": clk, "source": "profiles/traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, SQ_BUSY_CU_CYCLES)",
+                             "sustained_clock_ghz": clk, "issue_bound_us_at_measured_rate": round(real_us, 2),
+                             "frac_of_kernel_time_at_measured_rate": round(real_us / kdur_us, 3),
+                             "source": "profiles/traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, SQ_BUSY_CU_CYCLES); 5.1 cycles per instruction "
+                                       "from scripts/ubench/lat.hip",
                              "note": "fraction of this kernel's own instruction stream, NOT a roofline"}
             except Exception:
                 traffic = None
