@@ -138,8 +138,12 @@ def test_hot_path_step_matches_oracle(dfepe, oracle, depth, qt):
     assert relerr(ours["grad_logits"].cpu().numpy(), ref["grad_logits"].numpy()) < 5e-4
 
 
-def test_hot_path_step_matches_reference_golden(dfepe, golden):
-    """Same step against the reference's own fp32 run (tests/golden/pipeline.npz)."""
+def test_hot_path_step_matches_reference_golden(dfepe, oracle, golden):
+    """Same step against the reference's own fp32 run (tests/golden/pipeline.npz).
+
+    The reference's fp32 autograd through B x depth torch.svd nodes is the noisy side of the gradient comparison: the test
+    measures, on the same inputs, reference-fp32 vs fp64-oracle (4e-5 of the largest entry) and ours vs fp64-oracle (1e-6),
+    prints both, and bounds ours-vs-reference by 5e-4."""
     g = golden("pipeline")
     pre = "solver_"
     sc = {k: torch.from_numpy(g[pre + k]) for k in ("matches_xy_ori", "Ks", "delta_Rtijs_4_4", "qs_cam", "ts_cam", "pts1_virt_ori", "pts2_virt_ori", "logits_layers")}
@@ -160,7 +164,22 @@ def test_hot_path_step_matches_reference_golden(dfepe, golden):
         ref = g[pre + key]
         ours_g = logits.grad.cpu().numpy()
         cos = (ours_g * ref).sum() / (np.linalg.norm(ours_g) * np.linalg.norm(ref))
-        assert cos > 0.999 and relerr(ours_g, ref) < 5e-2
+        assert cos > 0.99999 and relerr(ours_g, ref) < 5e-4  # measured 4e-5: all of it the reference's own fp32 noise (below)
+        # the fp64 truth of the same loss on the same inputs
+        s64 = {k: v.double() for k, v in sc.items()}
+        lg = s64["logits_layers"].clone().requires_grad_(True)
+        o64 = oracle.deepf_forward(s64["matches_xy_ori"], IMAGE_SIZE, 5, logits_layers=lg)
+        l64, _, _, E64 = oracle.f_loss(o64, s64["pts1_virt_ori"], s64["pts2_virt_ori"], s64["Ks"], 5, 0.02)
+        if qt_only:
+            pose = oracle.rt_loss(E64, s64["delta_Rtijs_4_4"], s64["qs_cam"], s64["ts_cam"])
+            loss64 = oracle.qt_training_loss(pose["q_l2"], pose["t_l2"], 0.1, 0.5, 1.0, 0.1)
+        else:
+            loss64 = l64["loss_F"]
+        truth, = torch.autograd.grad(loss64, lg)
+        truth = truth.numpy()
+        e_ours, e_ref = relerr(ours_g, truth), relerr(ref, truth)
+        print(f"{key}: |ours - fp64 truth| = {e_ours:.2e}, |reference fp32 - fp64 truth| = {e_ref:.2e} (relative to the largest entry)")
+        assert e_ours < 2e-5 and e_ref < 5e-4
 
 
 def test_fused_step_equals_unfused_ops(dfepe):

@@ -66,27 +66,53 @@ def test_deepfnet_full_model_matches_reference_golden(dfepe, golden):
     outs = net(batch)
     assert set(outs.keys()) == {"logits", "logits_layers", "F_est", "epi_res_layers", "T1", "T2", "out_layers", "pts1", "pts2",
                                 "weights", "residual_layers", "weights_layers"}
+    # What sets the tolerances below: the estimator is ~0.8 GFLOP of fp32 GEMMs + InstanceNorms per pair, and two fp32
+    # implementations of the SAME network differ by their summation order.  Measured here: this package's fused estimator
+    # (channel-major GEMMs) against its own stock-PyTorch estimator (conv1d, MIOpen) with identical parameters -- the distance
+    # to the reference's run is required to stay within a small multiple of that fp32 reordering noise.
+    net_b = dfepe.compat.DeepFNet.DeepFNet(depth=depth, image_size=IMAGE_SIZE, if_quality=False, if_cpu_svd=True, fused_estimator=False)
+    net_b.load_state_dict(net.state_dict())
+    net_b = net_b.to(DEV)
+    layer_b = {"i": 0}
+    fit_b = net_b._fit
+
+    def fit_b_gauge(matches, logits, data_batch, want_epi):
+        o = fit_b(matches, logits, data_batch, want_epi)
+        ref = torch.from_numpy(g["net_out_layers"][layer_b["i"]]).to(DEV)
+        sg = torch.sign((o[0].detach() * ref).flatten(1).sum(1))
+        layer_b["i"] += 1
+        return (o[0] * sg[:, None, None], o[1] * sg[:, None]) + tuple(o[2:])
+
+    net_b._fit = fit_b_gauge
+    with torch.no_grad():
+        outs_b = net_b(batch)
+    noise = max(float((outs["logits_layers"][l].detach() - outs_b["logits_layers"][l]).abs().max()) for l in range(depth))
+    dist = max(float(np.abs(outs["logits_layers"][l].detach().cpu().numpy() - g["net_logits_layers"][l]).max()) for l in range(depth))
+    print(f"logits: |fused - stock estimator| (same parameters, both fp32) = {noise:.2e}; |ours - reference| = {dist:.2e}")
+    assert dist < max(20 * noise, 2e-3)
     for l in range(depth):
         a, r, _ = unit_align(outs["out_layers"][l].detach().cpu().numpy(), g["net_out_layers"][l])
-        assert np.linalg.norm(a - r, axis=1).max() < 1e-3, l
-        np.testing.assert_allclose(outs["logits_layers"][l].detach().cpu().numpy(), g["net_logits_layers"][l], atol=2e-2, rtol=2e-2)
-        np.testing.assert_allclose(outs["weights_layers"][l].detach().cpu().numpy(), g["net_weights_layers"][l], atol=2e-4, rtol=3e-2)
-        np.testing.assert_allclose(outs["residual_layers"][l].detach().cpu().numpy(), g["net_residual_layers"][l], atol=2e-5, rtol=2e-2)
+        # tolerances = ~10-20 x the distances measured on an MI355X (scripts/measure_golden_tolerances.py: F 1e-5, logits 8e-5,
+        # weights 2e-6, residual 8e-8, epipolar residual 3e-5, loss 9e-7 relative, gradient norms 8e-6, cosine 0.99999994)
+        assert np.linalg.norm(a - r, axis=1).max() < 2e-4, l
+        np.testing.assert_allclose(outs["logits_layers"][l].detach().cpu().numpy(), g["net_logits_layers"][l], atol=1e-3, rtol=1e-3)
+        np.testing.assert_allclose(outs["weights_layers"][l].detach().cpu().numpy(), g["net_weights_layers"][l], atol=3e-5, rtol=2e-3)
+        np.testing.assert_allclose(outs["residual_layers"][l].detach().cpu().numpy(), g["net_residual_layers"][l], atol=2e-6, rtol=2e-3)
     for l in range(depth - 1):
-        np.testing.assert_allclose(outs["epi_res_layers"][l].detach().cpu().numpy(), g["net_epi_res_layers"][l], atol=2e-3, rtol=2e-2)
+        np.testing.assert_allclose(outs["epi_res_layers"][l].detach().cpu().numpy(), g["net_epi_res_layers"][l], atol=5e-4, rtol=2e-3)
     loss_params = {"depth": depth, "clamp_at": 0.02, "if_tri_depth": False, "if_sample_loss": False, "topK": 8, "matches_good_unique_nums": None}
     losses, E_ests, F_ests, _, _, _, E_layers = dfepe.compat.train_good_utils.get_all_loss_DeepF(
         outs, T(g["net_pts1_virt_ori"]).to(DEV), T(g["net_pts2_virt_ori"]).to(DEV), T(g["net_Ks"]).to(DEV), loss_params,
         get_residual_summaries=False)
-    np.testing.assert_allclose(losses["loss_F"].item(), g["net_loss_F"], rtol=2e-2)
+    np.testing.assert_allclose(losses["loss_F"].item(), g["net_loss_F"], rtol=1e-4)
     losses["loss_F"].backward()
     # conv biases that feed an InstanceNorm cancel exactly; the fused estimator gives them an exact zero gradient (the reference's ~0)
     gn = {n: (0.0 if p.grad is None else float(p.grad.double().norm())) for n, p in net.named_parameters()}
     ours = np.array([gn[n] for n in sorted(gn)])
-    np.testing.assert_allclose(ours, g["net_grad_norms"], rtol=0.1, atol=1e-4 * g["net_grad_norms"].max())
+    np.testing.assert_allclose(ours, g["net_grad_norms"], rtol=5e-3, atol=1e-4 * g["net_grad_norms"].max())
     ga = net.input_weights.fw[0].weight.grad.cpu().numpy().ravel()
     gr = g["net_grad_first_conv"].ravel()
-    assert (ga * gr).sum() / (np.linalg.norm(ga) * np.linalg.norm(gr)) > 0.995
+    assert (ga * gr).sum() / (np.linalg.norm(ga) * np.linalg.norm(gr)) > 0.99999
 
 
 def test_deepfnet_sign_gauge_departure_is_bounded_and_documented(dfepe, golden):

@@ -122,9 +122,10 @@ def test_pipeline_gradients(oracle, golden, name, depth):
     for ours, ref in ((gF, g[pre + "grad_logits_lossF"]), (gQT, g[pre + "grad_logits_lossQT"])):
         ours = ours.numpy()
         denom = np.abs(ref).max() + 1e-30
-        assert np.max(np.abs(ours - ref)) / denom < 5e-2, np.max(np.abs(ours - ref)) / denom
+        # measured 9e-6 (F-loss) / 4e-5 (qt loss) of the largest entry: the reference's fp32 autograd against the fp64 truth
+        assert np.max(np.abs(ours - ref)) / denom < 1e-3, np.max(np.abs(ours - ref)) / denom
         cos = (ours * ref).sum() / (np.linalg.norm(ours) * np.linalg.norm(ref) + 1e-30)
-        assert cos > 0.999
+        assert cos > 0.99999
 
 
 def test_geometry_small(oracle, golden):
