@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-model", action="store_true", help="skip the secondary whole-DeepFNet measurement")
+    ap.add_argument("--no-defer-head", action="store_true", help="launch the loss head as a kernel of its own instead of finishing it inside the first backward launch")
     ap.add_argument("--no-extras", action="store_true", help="skip every informational field (layers_batched, full_model, match_construction ...)")
     ap.add_argument("--cpu-sample", type=int, default=512, help="pairs in the CPU-baseline sample (~10 s of host work per pass)")
     ap.add_argument("--force-dist", action="store_true",
@@ -169,7 +170,7 @@ def main():
         def step_body():
             out = dfepe.pipeline.hot_path_fused(m, logits, scene["Ks"], scene["pts1_virt_ori"], scene["pts2_virt_ori"], scene["qs_cam"],
                                                   scene["ts_cam"], scene["R_gt"], IMAGE_SIZE, clamp_at=0.02, qt=True, hw_T=hw_T,
-                                                  balance_F=cfg["balance_F"], grad_pairs=B_total)
+                                                  balance_F=cfg["balance_F"], grad_pairs=B_total, defer_loss_head=not args.no_defer_head)
             g, = torch.autograd.grad(out["loss"], logits)
             state["grad_logits"] = g           # d loss / d logits: what the estimator's backward / an optimizer consumes
             state["loss_vec"] = out["packed"]  # dist.pack_loss_sums layout (L+4 doubles): the ONLY data exchanged between ranks
@@ -504,7 +505,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg["what"].format(B=B_cfg, N=N, L=L), "baseline_config": args.config, "B_per_gpu": B, "B_total": B_total,
                        "N": N, "depth": L, "outlier_ratio": outl, "parallelism": f"dp{world}", "hipgraph": graph is not None,
-                       "launches_per_step": (2 * L + 2) if kind == "train" else 2},
+                       "launches_per_step": ((2 * L + 2) if args.no_defer_head else (2 * L + 1)) if kind == "train" else 2,
+                       "loss_head": ("a launch of its own" if args.no_defer_head else
+                                     "batch sums of the loss finished in spare wavefronts of the first backward launch (defer_loss_head)")},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "accuracy": acc,

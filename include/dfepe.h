@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFEPE_VERSION 120 /* 0.2.0 */
+#define DFEPE_VERSION 121 /* 0.2.0 */
 
 #define DFEPE_OK 0
 #define DFEPE_ERR_INVALID_ARG (-1) /* null pointer, non-positive size, bad flag combination   */
@@ -114,12 +114,17 @@ int dfepe_w8pt_fwd(const float *pts1, const float *pts2, const float *weights, i
  *   g_pts1, g_pts2 [B,N,3] or NULL: gradient w.r.t. the point coordinates (through the rows, the Hartley transforms and,
  *     when g_epi is given, the residual's direct dependence); with DFEPE_W8PT_RAW_MATCHES g_pts1 is [B,N,4] (gradient
  *     w.r.t. the pixel matches, 16-byte aligned) and g_pts2 is ignored.  NULL skips that part of the kernel.
+ *   pending_loss_head: NULL, or the `workspace` of a dfepe_loss_tail(..., defer_head = 1) call enqueued earlier on the same
+ *     stream: this launch then also finishes that call's loss head (packed / scalars), in spare wavefronts of its first
+ *     workgroup where the kernel family allows it, as a kernel of its own behind it otherwise.  Pass it to exactly ONE
+ *     backward launch of the step.
  */
 int dfepe_w8pt_bwd(const float *pts1, const float *pts2, const float *weights, int B, int N, int n_weight_sets,
                    unsigned flags, float image_w, float image_h, float clamp_at,
                    const float *save, const float *F_out,
                    const float *g_F, const float *g_residual, const float *g_epi, const float *g_weights_extra,
-                   const float *g_scale, float *g_weights, float *g_pts1, float *g_pts2, void *stream);
+                   const float *g_scale, float *g_weights, float *g_pts1, float *g_pts2, const void *pending_loss_head,
+                   void *stream);
 
 /*
  * F-loss and E-from-F over all layers.
@@ -186,8 +191,13 @@ int dfepe_loss_head(const float *loss_sum, const float *q_l2, const float *t_l2,
  *   grad_pairs: number of pairs the means run over in the gradient coefficients (B, or the global batch under data parallelism)
  *   g_F_layers [L,B,9] or NULL; feed it to dfepe_w8pt_bwd with g_scale = the upstream gradient of the loss
  *   packed [L+4] doubles, scalars [4+L] floats: as dfepe_loss_head, scalars[0] = balance_F * loss_F + loss_qt
- *   workspace: dfepe_loss_tail_workspace_bytes(B) bytes, 8-byte aligned, contents irrelevant (per-workgroup partial sums;
+ *   workspace: dfepe_loss_tail_workspace_bytes(B) bytes, 16-byte aligned, contents irrelevant (per-workgroup partial sums;
  *     a one-workgroup kernel enqueued right behind adds them in a fixed order: no floating-point atomics, deterministic)
+ *   defer_head: 0 = packed / scalars are complete when this call's work is (two launches).  1 = only the per-pair outputs
+ *     and g_F_layers are; the batch sums are left pending in `workspace` and finished by the dfepe_w8pt_bwd launch that is
+ *     handed `workspace` as its pending_loss_head (same stream, before packed / scalars are read).  For a training step
+ *     whose backward follows at once (a captured graph): the backward does not need the scalars, and the head's launch
+ *     (~7 us) leaves the step's critical path.
  */
 size_t dfepe_loss_tail_workspace_bytes(int B);
 int dfepe_loss_tail(const float *F_layers, int L, int B, const float *T1, const float *T2, int t_stride, const float *K,
@@ -195,7 +205,7 @@ int dfepe_loss_tail(const float *F_layers, int L, int B, const float *T1, const 
                     const float *q_gt, const float *t_gt, const float *R_gt, float clamp_q, float clamp_t,
                     float balance_F, float balance_q, float balance_t, double grad_pairs,
                     float *loss_sum, float *E_layers, float *q_l2, float *t_l2, float *R_deg, float *t_deg, int *sel,
-                    float *g_F_layers, double *packed, float *scalars, void *workspace, void *stream);
+                    float *g_F_layers, double *packed, float *scalars, void *workspace, int defer_head, void *stream);
 
 /*
  * Cheirality-checked pose from E.

@@ -4,10 +4,13 @@
 // one-workgroup kernel that adds the partials in a fixed order) -- no floating-point atomics.
 #include "dfepe_common.h"
 #include "loss_tail_body.h"
+#include "loss_head_body.h"
 
 namespace {
 
 constexpr int kPairsPerBlock = 16;
+constexpr size_t kTailDescBytes = 256;  // start of the workspace: a TailHead for a deferred head
+static_assert(sizeof(TailHead) <= kTailDescBytes, "descriptor slot too small");
 
 // Workgroup = 16 pairs: wavefronts 0..3 run the F-loss rows (16 lanes per pair), the wavefronts after them the 3x3 work, one
 // lane per (pair, layer) -- 16 L items, layer-major so that a wavefront's lanes run the same layer.  The two parts are
@@ -19,12 +22,14 @@ constexpr int kPairsPerBlock = 16;
 template <int IT>
 __global__ void __launch_bounds__(512)
 loss_tail_kernel(const float* F_layers, int L, int B, int M, int t_stride, const float* T1, const float* T2, const float* K,
-                 const float* virt1, const TailArgs A0, double* __restrict__ partials) {
+                 const float* virt1, const TailArgs A0, double* __restrict__ partials, const TailHead Hd, const int write_desc) {
   __shared__ float lds[kPairsPerBlock][kTailLdsFloats];
   __shared__ double part[kPairsPerBlock][kTailParts];
   TailArgs A = A0;
   A.F_layers = F_layers; A.L = L; A.B = B; A.M = M; A.t_stride = t_stride; A.T1 = T1; A.T2 = T2; A.K = K; A.virt1 = virt1;
   const int pair0 = (int)blockIdx.x * kPairsPerBlock;
+  // deferred head: its descriptor travels at the start of the workspace, in front of the partials
+  if (write_desc && blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<TailHead*>(reinterpret_cast<char*>(partials) - kTailDescBytes) = Hd;
   for (int e = (int)threadIdx.x; e < kPairsPerBlock * kTailParts; e += (int)blockDim.x) (&part[0][0])[e] = 0.0;
   __syncthreads();
   const bool floss_wave = threadIdx.x < 256u;  // uniform per wavefront
@@ -49,86 +54,37 @@ loss_tail_kernel(const float* F_layers, int L, int B, int M, int t_stride, const
   }
 }
 
-// The batch sums: one workgroup adds the per-workgroup partials in a fixed order (every thread takes workgroups t, t + 256,
-// ...: all loads in flight together; then DPP wave sums and a 4-way combine).  Deterministic, no floating-point atomics.
-// (A one-wavefront version with four partials per lane was measured slower: 14.7 us against 8.9 us.)
-// A launch of its own: the kernel boundary is what makes the partials of all XCDs visible, for less than an in-kernel
-// "last workgroup" protocol costs in agent-scope fences on a multi-XCD part (measured: 24 us against 5 us).
-struct TailHead {
-  const double* partials;  // [nblocks][kTailParts]
-  int nblocks, L, B, M, pose;
-  double* packed;          // [L+4]
-  float* scalars;          // [4+L]
-  float balance_F, balance_q, balance_t;
-  double inv_BM, inv_BML, inv_BL;  // 1 / (B M), 1 / (B M L), 1 / (B L)
-};
-
+// The batch sums (loss_head_body.h).  A launch of its own: the kernel boundary is what makes the partials of all XCDs visible,
+// for less than an in-kernel "last workgroup" protocol costs in agent-scope fences on a multi-XCD part (measured: 24 us against
+// 5 us; a one-wavefront version: 14.7 us).  With defer_head the launch is left to the first backward fit of the step, which
+// runs the same code in four spare wavefronts of its workgroup 0 (dfepe_w8pt_bwd, pending_loss_head).
 __global__ void __launch_bounds__(256) loss_tail_head_kernel(const TailHead H) {
-  __shared__ double red[4][kTailParts];
-  const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
-  // every thread adds whole rows of partials (workgroups t, t + 256, ...): 24 independent 16-byte loads in flight per row;
-  // entries of layers >= L are zeros the tail kernel wrote
-  double v[3][kTailMaxLayers];
-#pragma unroll
-  for (int kind = 0; kind < 3; ++kind)
-#pragma unroll
-    for (int l = 0; l < kTailMaxLayers; ++l) v[kind][l] = 0.0;
-  for (int b = (int)threadIdx.x; b < H.nblocks; b += 256) {
-    const double2* row = reinterpret_cast<const double2*>(H.partials + (size_t)b * kTailParts);
-    double2 t[kTailParts / 2];
-#pragma unroll
-    for (int k = 0; k < kTailParts / 2; ++k) t[k] = row[k];
-#pragma unroll
-    for (int k = 0; k < kTailParts / 2; ++k) {
-      v[(2 * k) / kTailMaxLayers][(2 * k) % kTailMaxLayers] += t[k].x;
-      v[(2 * k + 1) / kTailMaxLayers][(2 * k + 1) % kTailMaxLayers] += t[k].y;
-    }
-  }
-#pragma unroll
-  for (int kind = 0; kind < 3; ++kind)
-#pragma unroll
-    for (int l = 0; l < kTailMaxLayers; ++l) {
-      if (l < H.L) {
-        const double s = wave_sum(v[kind][l]);
-        if (lane == 0) red[wave][kind * kTailMaxLayers + l] = s;
-      }
-    }
+  __shared__ TailHeadLds lds;
+  if (threadIdx.x == 0) lds.arrived = 0u;
   __syncthreads();
-  // same quantities as dfepe_loss_head; lane l < L finishes layer l, lane 0 the totals (reciprocals come from the host: a
-  // dependent chain of fp64 divisions in one lane was a fifth of this kernel)
-  const int L = H.L;
-  if (threadIdx.x < (unsigned)L) {
-    const int l = (int)threadIdx.x;
-    const double f = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
-    H.packed[l] = f;
-    H.scalars[4 + l] = (float)(f * H.inv_BM);  // losses.mean() of layer l
-  }
-  if (threadIdx.x == 0) {
-    double totF = 0.0, tq = 0.0, tt = 0.0;
-    for (int l = 0; l < L; ++l) {
-      const int iq = kTailMaxLayers + l, it = 2 * kTailMaxLayers + l;
-      totF += (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
-      tq += (red[0][iq] + red[1][iq]) + (red[2][iq] + red[3][iq]);
-      tt += (red[0][it] + red[1][it]) + (red[2][it] + red[3][it]);
-    }
-    H.packed[L] = tq;
-    H.packed[L + 1] = tt;
-    H.packed[L + 2] = (double)H.B;
-    H.packed[L + 3] = (double)H.M;
-    const double loss_F = totF * H.inv_BML;
-    const double loss_qt = H.pose ? (tq * (double)H.balance_q + tt * (double)H.balance_t) * H.inv_BL : 0.0;
-    H.scalars[0] = (float)((double)H.balance_F * loss_F + loss_qt);
-    H.scalars[1] = (float)loss_F;
-    H.scalars[2] = (float)loss_qt;
-    H.scalars[3] = 0.0f;
-  }
+  loss_head_run(H, (int)threadIdx.x, &lds);
+}
+// the same from a descriptor in device memory (the fallback of a deferred head when the backward fit is served by the
+// wavefront-per-pair kernels)
+__global__ void __launch_bounds__(256) loss_tail_head_desc_kernel(const TailHead* Hp) {
+  __shared__ TailHeadLds lds;
+  if (threadIdx.x == 0) lds.arrived = 0u;
+  __syncthreads();
+  const TailHead H = *Hp;
+  loss_head_run(H, (int)threadIdx.x, &lds);
 }
 
 }  // namespace
 
 extern "C" size_t dfepe_loss_tail_workspace_bytes(int B) {
   const size_t blocks = (size_t)((B > 0 ? B : 0) + kPairsPerBlock - 1) / kPairsPerBlock;
-  return blocks * kTailParts * sizeof(double);
+  return kTailDescBytes + blocks * kTailParts * sizeof(double);  // the descriptor of a deferred head, then the partials
+}
+
+// launches the pending loss head described in `workspace` (dfepe_loss_tail with defer_head) as a kernel of its own
+int dfepe_loss_head_from_workspace(const void* workspace_desc, hipStream_t st) {
+  hipLaunchKernelGGL(loss_tail_head_desc_kernel, dim3(1), dim3(256), 0, st, static_cast<const TailHead*>(workspace_desc));
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
 extern "C" int dfepe_loss_tail(const float* F_layers, int L, int B, const float* T1, const float* T2, int t_stride,
@@ -136,7 +92,8 @@ extern "C" int dfepe_loss_tail(const float* F_layers, int L, int B, const float*
                                const float* q_gt, const float* t_gt, const float* R_gt, float clamp_q, float clamp_t,
                                float balance_F, float balance_q, float balance_t, double grad_pairs, float* loss_sum,
                                float* E_layers, float* q_l2, float* t_l2, float* R_deg, float* t_deg, int* sel,
-                               float* g_F_layers, double* packed, float* scalars, void* workspace, void* stream) {
+                               float* g_F_layers, double* packed, float* scalars, void* workspace, int defer_head,
+                               void* stream) {
   if (L <= 0 || L > kTailMaxLayers || B <= 0 || M <= 0) return DFEPE_ERR_INVALID_ARG;
   if (M > 128) return DFEPE_ERR_UNSUPPORTED;  // the unfused kernels (dfepe_floss_*, dfepe_pose_*, dfepe_loss_head) serve larger grids
   if (t_stride != 0 && t_stride != 9) return DFEPE_ERR_INVALID_ARG;
@@ -144,7 +101,7 @@ extern "C" int dfepe_loss_tail(const float* F_layers, int L, int B, const float*
     return DFEPE_ERR_INVALID_ARG;
   if (q_gt && (!t_gt || !q_l2 || !t_l2)) return DFEPE_ERR_INVALID_ARG;
   if (R_deg && !R_gt) return DFEPE_ERR_INVALID_ARG;
-  if ((reinterpret_cast<uintptr_t>(workspace) & 7u) || !(grad_pairs > 0.0)) return DFEPE_ERR_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 15u) || !(grad_pairs > 0.0)) return DFEPE_ERR_INVALID_ARG;
   TailArgs A;
   A.F_layers = F_layers; A.L = L; A.B = B; A.M = M; A.t_stride = t_stride; A.T1 = T1; A.T2 = T2; A.K = K;
   A.virt1 = virt1; A.virt2 = virt2; A.clamp_at = clamp_at; A.q_gt = q_gt; A.t_gt = t_gt; A.R_gt = R_gt;
@@ -154,19 +111,21 @@ extern "C" int dfepe_loss_tail(const float* F_layers, int L, int B, const float*
   A.coef_t = (float)((double)balance_t / ((double)L * grad_pairs));
   A.loss_sum = loss_sum; A.E_layers = E_layers; A.q_l2 = q_l2; A.t_l2 = t_l2; A.R_deg = R_deg; A.t_deg = t_deg; A.sel = sel;
   A.g_F = g_F_layers;
-  double* partials = static_cast<double*>(workspace);
+  double* partials = reinterpret_cast<double*>(static_cast<char*>(workspace) + kTailDescBytes);
   // 4 F-loss wavefronts + one lane per (pair, layer): 16 L lanes, rounded up to wavefronts
   const dim3 grid((B + kPairsPerBlock - 1) / kPairsPerBlock), block(256 + 64 * ((kPairsPerBlock * L + 63) / 64));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (M <= 16) hipLaunchKernelGGL((loss_tail_kernel<1>), grid, block, 0, st, A.F_layers, A.L, A.B, A.M, A.t_stride, A.T1, A.T2, A.K, A.virt1, A, partials);
-  else if (M <= 32) hipLaunchKernelGGL((loss_tail_kernel<2>), grid, block, 0, st, A.F_layers, A.L, A.B, A.M, A.t_stride, A.T1, A.T2, A.K, A.virt1, A, partials);
-  else if (M <= 64) hipLaunchKernelGGL((loss_tail_kernel<4>), grid, block, 0, st, A.F_layers, A.L, A.B, A.M, A.t_stride, A.T1, A.T2, A.K, A.virt1, A, partials);
-  else if (M <= 112) hipLaunchKernelGGL((loss_tail_kernel<7>), grid, block, 0, st, A.F_layers, A.L, A.B, A.M, A.t_stride, A.T1, A.T2, A.K, A.virt1, A, partials);
-  else hipLaunchKernelGGL((loss_tail_kernel<8>), grid, block, 0, st, A.F_layers, A.L, A.B, A.M, A.t_stride, A.T1, A.T2, A.K, A.virt1, A, partials);
   TailHead H;
   H.partials = partials; H.nblocks = (int)grid.x; H.L = L; H.B = B; H.M = M; H.pose = (q_gt != nullptr) ? 1 : 0;
   H.packed = packed; H.scalars = scalars; H.balance_F = balance_F; H.balance_q = balance_q; H.balance_t = balance_t;
   H.inv_BM = 1.0 / ((double)B * (double)M); H.inv_BML = H.inv_BM / (double)L; H.inv_BL = 1.0 / ((double)B * (double)L);
+  const int wd = defer_head ? 1 : 0;
+  if (M <= 16) hipLaunchKernelGGL((loss_tail_kernel<1>), grid, block, 0, st, A.F_layers, A.L, A.B, A.M, A.t_stride, A.T1, A.T2, A.K, A.virt1, A, partials, H, wd);
+  else if (M <= 32) hipLaunchKernelGGL((loss_tail_kernel<2>), grid, block, 0, st, A.F_layers, A.L, A.B, A.M, A.t_stride, A.T1, A.T2, A.K, A.virt1, A, partials, H, wd);
+  else if (M <= 64) hipLaunchKernelGGL((loss_tail_kernel<4>), grid, block, 0, st, A.F_layers, A.L, A.B, A.M, A.t_stride, A.T1, A.T2, A.K, A.virt1, A, partials, H, wd);
+  else if (M <= 112) hipLaunchKernelGGL((loss_tail_kernel<7>), grid, block, 0, st, A.F_layers, A.L, A.B, A.M, A.t_stride, A.T1, A.T2, A.K, A.virt1, A, partials, H, wd);
+  else hipLaunchKernelGGL((loss_tail_kernel<8>), grid, block, 0, st, A.F_layers, A.L, A.B, A.M, A.t_stride, A.T1, A.T2, A.K, A.virt1, A, partials, H, wd);
+  if (defer_head) return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;  // the first backward fit runs the head
   hipLaunchKernelGGL(loss_tail_head_kernel, dim3(1), dim3(256), 0, st, H);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }

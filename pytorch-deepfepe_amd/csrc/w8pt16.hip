@@ -6,6 +6,7 @@
 #include "dfepe_common.h"
 #include "w8pt16_body.h"
 #include "w8pt16_bwd_body.h"
+#include "loss_head_body.h"
 
 namespace {
 
@@ -62,8 +63,39 @@ w8pt16_bwd_kernel(const float* pts1, const float* pts2, const float* wts, int B,
   A.pts1 = pts1; A.pts2 = pts2; A.wts = wts; A.B = B; A.Bm = Bm; A.N = N; A.hw_sx = hw_sx; A.hw_sy = hw_sy;
   A.clamp_at = clamp_at; A.save = save; A.F_out = R.F_out; A.g_F = R.g_F; A.g_res = R.g_res; A.g_epi = R.g_epi;
   A.g_w_extra = R.g_w_extra; A.g_scale = R.g_scale; A.g_w = R.g_w; A.g_p1 = R.g_p1; A.g_p2 = R.g_p2;
-  A.logits_mode = R.logits_mode;
+  A.logits_mode = R.logits_mode; A.pending_head = nullptr;
   w8pt16_bwd_pair_impl<IT, RAW, PGRAD>(A, pair, nullptr);
+}
+
+// The same backward fit with four more wavefronts per workgroup; in workgroup 0 they run the loss head that dfepe_loss_tail
+// deferred (loss_head_body.h), elsewhere they leave at once.  The head is off the step's critical path this way: nothing in
+// the backward needs its scalars, and the 512-thread workgroup (two wavefronts per SIMD: <= 256 registers) costs this ONE
+// launch of the step a few AGPR moves.
+template <int IT, bool RAW>
+__global__ void __launch_bounds__(512)
+w8pt16_bwd_head_kernel(const float* pts1, const float* pts2, const float* wts, int B, int Bm, int N, float hw_sx, float hw_sy,
+                       float clamp_at, const float* save, const W8BwdRest R, const TailHead* __restrict__ head) {
+  __shared__ TailHeadLds lds;
+  if (blockIdx.x == 0) {  // uniform over the workgroup: all eight wavefronts are still alive here
+    if (threadIdx.x == 0) lds.arrived = 0u;
+    __syncthreads();
+  }
+  if (threadIdx.x >= 256u) {
+    if (blockIdx.x == 0) {
+      const TailHead H = *head;
+      loss_head_run(H, (int)threadIdx.x - 256, &lds);
+    }
+    return;
+  }
+  const int row = (int)(threadIdx.x >> 4);
+  const int pair = (int)blockIdx.x * kPairsPerBlock + row;
+  if (pair >= B) return;
+  W8BwdArgs A;
+  A.pts1 = pts1; A.pts2 = pts2; A.wts = wts; A.B = B; A.Bm = Bm; A.N = N; A.hw_sx = hw_sx; A.hw_sy = hw_sy;
+  A.clamp_at = clamp_at; A.save = save; A.F_out = R.F_out; A.g_F = R.g_F; A.g_res = R.g_res; A.g_epi = R.g_epi;
+  A.g_w_extra = R.g_w_extra; A.g_scale = R.g_scale; A.g_w = R.g_w; A.g_p1 = R.g_p1; A.g_p2 = R.g_p2;
+  A.logits_mode = R.logits_mode; A.pending_head = nullptr;
+  w8pt16_bwd_pair_impl<IT, RAW, false>(A, pair, nullptr);
 }
 
 template <bool RAW, bool PLAIN>
@@ -103,6 +135,27 @@ void launch_bwd(const W8BwdArgs& A, hipStream_t st) {
 #undef DFEPE_BWD
 }
 
+// with the deferred loss head riding along (no point gradients in this variant: the caller falls back to a head launch)
+template <bool RAW>
+void launch_bwd_head(const W8BwdArgs& A, hipStream_t st) {
+  const dim3 grid((A.B + kPairsPerBlock - 1) / kPairsPerBlock), block(512);
+  const int N = A.N;
+  W8BwdRest R;
+  R.F_out = A.F_out; R.g_F = A.g_F; R.g_res = A.g_res; R.g_epi = A.g_epi; R.g_w_extra = A.g_w_extra; R.g_scale = A.g_scale;
+  R.g_w = A.g_w; R.g_p1 = A.g_p1; R.g_p2 = A.g_p2; R.logits_mode = A.logits_mode;
+  const TailHead* head = static_cast<const TailHead*>(A.pending_head);
+#define DFEPE_BWDH(IT_)                                                                                                   \
+  hipLaunchKernelGGL((w8pt16_bwd_head_kernel<IT_, RAW>), grid, block, 0, st, A.pts1, A.pts2, A.wts, A.B, A.Bm, A.N, A.hw_sx, \
+                     A.hw_sy, A.clamp_at, A.save, R, head)
+  if (N > 128) DFEPE_BWDH(0);
+  else if (N <= 16) DFEPE_BWDH(1);
+  else if (N <= 32) DFEPE_BWDH(2);
+  else if (N <= 64) DFEPE_BWDH(4);
+  else if (N <= 112) DFEPE_BWDH(7);
+  else DFEPE_BWDH(8);
+#undef DFEPE_BWDH
+}
+
 }  // namespace
 
 // Called by dfepe_w8pt_fwd / dfepe_w8pt_bwd (w8pt_fwd.hip / w8pt_bwd.hip) after argument validation.
@@ -113,9 +166,16 @@ int dfepe_w8pt16_fwd_launch(const W8Args& A, bool raw, hipStream_t st) {
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
+int dfepe_loss_head_from_workspace(const void* workspace_desc, hipStream_t st);  // loss_tail.hip
+
 int dfepe_w8pt16_bwd_launch(const W8BwdArgs& A, bool raw, hipStream_t st) {
   const bool pgrad = A.g_p1 != nullptr;
+  if (A.pending_head != nullptr && !pgrad) {
+    if (raw) launch_bwd_head<true>(A, st); else launch_bwd_head<false>(A, st);
+    return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+  }
   if (raw) { if (pgrad) launch_bwd<true, true>(A, st); else launch_bwd<true, false>(A, st); }
   else { if (pgrad) launch_bwd<false, true>(A, st); else launch_bwd<false, false>(A, st); }
-  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+  if (hipGetLastError() != hipSuccess) return DFEPE_ERR_HIP;
+  return (A.pending_head != nullptr) ? dfepe_loss_head_from_workspace(A.pending_head, st) : DFEPE_OK;
 }

@@ -33,6 +33,7 @@ struct W8BwdArgs {
   float* g_p1;
   float* g_p2;
   int logits_mode;
+  const void* pending_head;  // host side only: a deferred loss head to run beside this launch (dfepe_w8pt_bwd), or nullptr
 };
 
 __device__ __forceinline__ double guard_den16(double d) {

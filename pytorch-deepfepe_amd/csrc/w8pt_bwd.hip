@@ -394,12 +394,14 @@ w8pt_bwd_kernel(const float* __restrict__ pts1, const float* __restrict__ pts2, 
 
 }  // namespace
 
+int dfepe_loss_head_from_workspace(const void* workspace_desc, hipStream_t st);  // loss_tail.hip
+
 extern "C" int dfepe_w8pt_bwd(const float* pts1, const float* pts2, const float* weights, int B, int N, int n_weight_sets,
                               unsigned flags,
                               float image_w, float image_h, float clamp_at, const float* save, const float* F_out,
                               const float* g_F, const float* g_residual, const float* g_epi,
                               const float* g_weights_extra, const float* g_scale, float* g_weights, float* g_pts1, float* g_pts2,
-                              void* stream) {
+                              const void* pending_loss_head, void* stream) {
   const bool raw = (flags & DFEPE_W8PT_RAW_MATCHES) != 0;
   const int logits_mode = (flags & DFEPE_W8PT_LOGITS) ? 1 : 0;
   if (B < 0 || N <= 0 || n_weight_sets < 1) return DFEPE_ERR_INVALID_ARG;
@@ -407,6 +409,7 @@ extern "C" int dfepe_w8pt_bwd(const float* pts1, const float* pts2, const float*
   if (B == 0) return DFEPE_OK;
   if (!pts1 || (!raw && !pts2) || !weights || !save || !g_weights) return DFEPE_ERR_INVALID_ARG;
   if (g_epi && !F_out) return DFEPE_ERR_INVALID_ARG;
+  if (reinterpret_cast<uintptr_t>(pending_loss_head) & 15u) return DFEPE_ERR_INVALID_ARG;
   const bool pgrad = g_pts1 != nullptr;
   if (pgrad && n_weight_sets != 1) return DFEPE_ERR_UNSUPPORTED;  // point gradients of shared correspondences would need a sum over the sets
   const int Bm = B;
@@ -422,7 +425,7 @@ extern "C" int dfepe_w8pt_bwd(const float* pts1, const float* pts2, const float*
     A.Bm = Bm; A.B = B; A.N = N;
     A.hw_sx = raw ? 2.0f / image_w : 0.f; A.hw_sy = raw ? 2.0f / image_h : 0.f; A.clamp_at = clamp_at;
     A.save = save; A.F_out = F_out; A.g_F = g_F; A.g_res = g_residual; A.g_epi = g_epi; A.g_w_extra = g_weights_extra; A.g_scale = g_scale;
-    A.g_w = g_weights; A.g_p1 = g_pts1; A.g_p2 = g_pts2; A.logits_mode = logits_mode;
+    A.g_w = g_weights; A.g_p1 = g_pts1; A.g_p2 = g_pts2; A.logits_mode = logits_mode; A.pending_head = pending_loss_head;
     return dfepe_w8pt16_bwd_launch(A, raw, static_cast<hipStream_t>(stream));
   }
   const int waves = 4;
@@ -440,5 +443,6 @@ extern "C" int dfepe_w8pt_bwd(const float* pts1, const float* pts2, const float*
     if (pgrad) DFEPE_LAUNCH_BWD(false, true, false); else if (coop) DFEPE_LAUNCH_BWD(false, false, true); else DFEPE_LAUNCH_BWD(false, false, false);
   }
 #undef DFEPE_LAUNCH_BWD
-  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+  if (hipGetLastError() != hipSuccess) return DFEPE_ERR_HIP;
+  return (pending_loss_head != nullptr) ? dfepe_loss_head_from_workspace(pending_loss_head, st) : DFEPE_OK;  // a launch of its own here
 }

@@ -70,7 +70,8 @@ def w8pt_forward(pts1: Tensor, pts2: Optional[Tensor], weights: Tensor, raw: boo
 
 
 def w8pt_backward(pts1, pts2, weights, raw, image_w, image_h, clamp_at, save, F, gF, gRes, gEpi, logits=False, gW_extra=None,
-                  out: Optional[Tensor] = None, want_pts: bool = False, wave_per_pair: bool = False, g_scale: Optional[Tensor] = None):
+                  out: Optional[Tensor] = None, want_pts: bool = False, wave_per_pair: bool = False, g_scale: Optional[Tensor] = None,
+                  pending_loss_head: Optional[Tensor] = None):
     """Raw launch of the adjoint; returns d/d(weights) (or d/d(logits) when ``logits``; then ``weights`` must be the
     forward's weights_out) and, when ``want_pts``, the gradients w.r.t. the points ([B,N,3] x 2, or [B,N,4] for raw matches)."""
     L = _lib.lib()
@@ -83,7 +84,7 @@ def w8pt_backward(pts1, pts2, weights, raw, image_w, image_h, clamp_at, save, F,
     with torch.cuda.device(weights.device):
         rc = L.dfepe_w8pt_bwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, 1, _flags(raw, logits, wave_per_pair), float(image_w), float(image_h),
                               float(clamp_at), _ptr(save), _ptr(F), _ptr(gF), _ptr(gRes), _ptr(gEpi), _ptr(gW_extra), _ptr(g_scale), _ptr(gW),
-                              _ptr(gP1), _ptr(gP2), _stream())
+                              _ptr(gP1), _ptr(gP2), _ptr(pending_loss_head), _stream())
     _lib.check(rc, "dfepe_w8pt_bwd")
     return (gW, gP1, gP2) if want_pts else gW
 

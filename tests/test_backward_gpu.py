@@ -201,6 +201,33 @@ def test_fused_step_equals_unfused_ops(dfepe):
     np.testing.assert_allclose(a["packed"].cpu().numpy(), ref.cpu().numpy(), rtol=1e-6)
 
 
+@pytest.mark.parametrize("B,N,batched", [(37, 100, False), (300, 100, True), (5, 200, False)])
+def test_deferred_loss_head_gives_the_same_step(dfepe, B, N, batched):
+    """defer_loss_head: the batch sums of the loss tail are finished by the first backward launch (four spare wavefronts of
+    its first workgroup for the row kernels; a launch behind it for the wavefront-per-pair kernels, N = 200 at B = 5) instead
+    of a launch of their own.  After backward every output and the gradients are those of the undeferred step, bit for bit."""
+    depth = 5
+    sc = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(B, N, seed=41, outlier_ratio=0.3, depth_layers=depth), DEV)
+
+    def run(defer):
+        logits = sc["logits_layers"][:depth].detach().clone().requires_grad_(True)
+        o = dfepe.pipeline.hot_path_fused(sc["matches_xy_ori"], logits, sc["Ks"], sc["pts1_virt_ori"], sc["pts2_virt_ori"], sc["qs_cam"],
+                                          sc["ts_cam"], sc["R_gt"], IMAGE_SIZE, 0.02, True, layers_batched=batched, defer_loss_head=defer)
+        (o["loss"] * 1.5).backward()
+        torch.cuda.synchronize()
+        o["grad_logits"] = logits.grad
+        return o
+
+    a, b = run(False), run(True)
+    for k in ("loss", "loss_F", "loss_qt", "loss_layers", "packed", "loss_sum", "q_l2", "t_l2", "grad_logits", "F_layers", "E_layers"):
+        assert torch.equal(a[k], b[k]), k
+    # without a backward (no gradient requested) the head is not deferred: the scalars are there after the forward
+    with torch.no_grad():
+        c = dfepe.pipeline.hot_path_fused(sc["matches_xy_ori"], sc["logits_layers"][:depth], sc["Ks"], sc["pts1_virt_ori"], sc["pts2_virt_ori"],
+                                          sc["qs_cam"], sc["ts_cam"], sc["R_gt"], IMAGE_SIZE, 0.02, True, defer_loss_head=True)
+    assert torch.equal(c["loss"], a["loss"]) and torch.equal(c["packed"], a["packed"])
+
+
 @pytest.mark.parametrize("qt,balance_F", [(True, 1.0), (True, 0.0), (False, 1.0), (True, 0.3)])
 def test_fused_loss_tail_equals_the_five_kernel_tail(dfepe, qt, balance_F):
     """dfepe_loss_tail (one launch: F-loss + E + pose + loss head + d loss / d F, unit upstream, g_scale applied by w8pt_bwd)
@@ -257,7 +284,7 @@ def test_layers_batched_launch_is_bit_identical(dfepe):
     m, w = sc["matches_xy_ori"], torch.softmax(sc["logits_layers"][:depth], dim=2).contiguous()
     buf = torch.empty(depth * B * 128, device=DEV)
     rc = L.dfepe_w8pt_bwd(m.data_ptr(), None, w.data_ptr(), B, N, depth, 1, 1241.0, 376.0, 0.5, buf.data_ptr(), buf.data_ptr(),
-                          buf.data_ptr(), None, None, None, None, buf.data_ptr(), buf.data_ptr(), None, None)
+                          buf.data_ptr(), None, None, None, None, buf.data_ptr(), buf.data_ptr(), None, None, None)
     assert rc == -3  # DFEPE_ERR_UNSUPPORTED: a point gradient would have to be summed over the sets
 
 
