@@ -9,7 +9,8 @@ O = os.path.join(REPO, "gpurun_out", f"prof_{tag}")
 P = os.path.join(REPO, "profiles")
 B, N, L, M = 4096, 100, 5, 100
 FIT_FWD, FIT_BWD, TAIL, HEAD = "w8pt16_fwd_kernel<7, true, true>", "w8pt16_bwd_kernel<7, true, false>", "loss_tail_kernel<7>", "loss_tail_head_kernel"
-HOT = (FIT_FWD, FIT_BWD, TAIL, HEAD)
+BWD_HEAD = "w8pt16_bwd_head_kernel<7, true>"  # the first backward fit of the step, with the deferred loss head in spare wavefronts
+HOT = (FIT_FWD, FIT_BWD, BWD_HEAD, TAIL, HEAD)
 
 
 def short(name):
@@ -46,7 +47,7 @@ groups = collections.OrderedDict()
 for r in trace:
     d = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
     groups.setdefault((short(r["Kernel_Name"]), int(r["Grid_Size_X"])), []).append(d)
-md = [f"# {tag} — rocprofv3 summaries (MI355X, B={B}/GPU, N={N}, depth {L}, fused step = 12 launches in one hipGraph)", "",
+md = [f"# {tag} — rocprofv3 summaries (MI355X, B={B}/GPU, N={N}, depth {L}, fused step = 11 launches in one hipGraph)", "",
       "Produced by `scripts/profile_round.sh` (GPU box) + `scripts/profile_summary.py` (here).", "",
       "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 200 --warmup 20`", "",
       f"The verbatim per-name `--stats` table is `{tag}_bench_kernel_stats.csv`.  bench.py runs, besides the timed region, the roofline probe "
@@ -65,21 +66,25 @@ for (k, g), ds in groups.items():
             what = "per-layer launch (one 16-lane row per pair: 4096 pairs = 1024 wavefronts)" + (" (in-step + roofline probe)" if k == FIT_FWD else "")
             if k == FIT_FWD:
                 fwd_avg_us = mean(ds) / 1e3
-            step_sum += L * mean(ds) / 1e3
+            step_sum += (L if k == FIT_FWD else L - 1) * mean(ds) / 1e3  # the first backward launch is BWD_HEAD
         elif g == B * 16 * L:
             what = "layers-batched variant (informational)"
         else:
             what = "other batch size (full-model / sample checks)"
+    elif k == BWD_HEAD:
+        what = "first backward fit of the step + the deferred loss head in four spare wavefronts of workgroup 0 (512-thread workgroups)"
+        step_sum += mean(ds) / 1e3
+    elif k == HEAD:
+        what = "loss head as a launch of its own: only the informational layers-batched variant (the timed step defers it)"
     else:
         what = "once per step"
-        if g in (B * 16, 256):
-            step_sum += mean(ds) / 1e3
+        step_sum += mean(ds) / 1e3
     md.append(f"| `{k}` | {g} | {what} | {len(ds)} | {mean(ds)/1e3:.2f} | {ds_sorted[len(ds)//2]/1e3:.2f} | {min(ds)/1e3:.2f} | {max(ds)/1e3:.2f} |")
 md += ["", f"bench line of the same (profiled) run: `value` = {line['value']:.0f} pairs/s, ms_per_step = {line['ms_per_step']}, "
        f"roofline.avg_kernel_us = {line['roofline']['avg_kernel_us']} (HIP events around a hipGraph of 50 back-to-back stand-alone fits, "
        f"i.e. kernel + the dispatch gap between dependent launches).  The rocprof average of the forward fit at the hot-path grid is "
        f"{fwd_avg_us:.2f} us.  Sum of the step's kernel averages: {step_sum:.1f} us of the {1e3*line['ms_per_step']:.1f} us step; the rest is "
-       "dispatch gaps between the 12 dependent launches.", ""]
+       "dispatch gaps between the 11 dependent launches.", ""]
 
 fetch, write = counters("pmc_fetch"), counters("pmc_write")
 alg = {  # algorithmic bytes per launch in the fused step (SURVEY.md 8d + what the step additionally writes)
