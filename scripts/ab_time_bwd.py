@@ -10,7 +10,7 @@ for path in sys.argv[1:3]:
     L.dfepe_w8pt_fwd.restype = I
     L.dfepe_w8pt_fwd.argtypes = [P, P, P, I, I, I, U, F, F, F, P, P, P, P, P, P]
     L.dfepe_w8pt_bwd.restype = I
-    L.dfepe_w8pt_bwd.argtypes = [P, P, P, I, I, I, U, F, F, F, P, P, P, P, P, P, P, P, P, P]
+    L.dfepe_w8pt_bwd.argtypes = [P, P, P, I, I, I, U, F, F, F, P, P, P, P, P, P, P, P, P, P, P, P]
     libs.append(L)
 B, N = 4096, 100
 sc = d.synth.make_scene(B, N, seed=1, outlier_ratio=0.2)
@@ -23,7 +23,7 @@ assert libs[0].dfepe_w8pt_fwd(m.data_ptr(), None, lg.data_ptr(), B, N, 1, 3, 124
                                sv.data_ptr(), wo.data_ptr(), st) == 0
 def launch(L):
     rc = L.dfepe_w8pt_bwd(m.data_ptr(), None, wo.data_ptr(), B, N, 1, 3, 1241.0, 376.0, 0.5, sv.data_ptr(), Fo.data_ptr(), gF.data_ptr(), None, None,
-                          None, gl.data_ptr(), None, None, st)
+                          None, None, gl.data_ptr(), None, None, None, st)  # g_weights_extra, g_scale, g_weights, g_pts1, g_pts2, pending head
     assert rc == 0
 def t(L, n=50):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
