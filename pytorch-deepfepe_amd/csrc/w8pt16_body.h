@@ -17,10 +17,13 @@
 //     iteration that depends on the data's conditioning:
 //       Householder tridiagonalisation (lane i holds row i of M; broadcasts are row_newbcast DPP moves),
 //       the (skip+1)-th smallest eigenvalue by 16-way multisection on the division-free Sturm sequence (every lane of the
-//       row probes its own shift: 13 rounds shrink the bracket by 17^13 ~ 1e16),
+//       row probes its own shift: a log-spaced round finds the magnitude, ~9 linear rounds of 17x each finish it),
 //       its eigenvector by twisted factorisation, back-transformed through the seven reflectors;
 //     everything is fp64 (full-rate on gfx950), so there is no fp32 sweep to polish and no cluster repair;
-//   * the backward (w8pt16_bwd_pair) applies (M - lam I)^+ through the same tridiagonal form saved here.
+//   * the backward (w8pt16_bwd_pair) applies (M - lam I)^+ through the same tridiagonal form saved here;
+//   * every global load is issued at the top, unconditionally (clamped indices), and every store at the bottom: a load under
+//     a condition costs a dependent memory round trip, and a consumer scheduled after a store waits for the STORE (in-order
+//     memory counter).  The kernel is bound by instruction issue (~5 cycles per vector instruction), not by latency.
 // The bodies are written against rowgroup.h only, so tests/emu/ runs them on the host against the oracle.
 #pragma once
 #include <type_traits>
