@@ -186,7 +186,9 @@ __device__ __forceinline__ void tail_floss_row(const TailArgs& A, const int pair
     if (e < L * 9) ldsF[e] = fl[k];
   }
   rg_sync();
-  const bool grad = A.g_F != nullptr;
+  // with balance_F = 0 (the reference's objective when if_qt_loss, Train_model_pipeline.py:580-587) the F-loss is evaluated but
+  // carries no gradient: its adjoint (more than half of this function) is skipped
+  const bool grad = A.g_F != nullptr && A.coef_F != 0.0f;
   for (int ly = 0; ly < L; ++ly) {
     float o[9];
 #pragma unroll
@@ -238,7 +240,9 @@ __device__ __forceinline__ void tail_floss_row(const TailArgs& A, const int pair
 __device__ __forceinline__ void tail_floss_finish(const TailArgs& A, const int pair, const float* gsum, const float* gpose /*[L][9]*/) {
   const int l = rg_lane();
   if (A.g_F == nullptr || l >= 9) return;
-  for (int ly = 0; ly < A.L; ++ly) A.g_F[((size_t)ly * A.B + pair) * 9 + l] = fmaf(A.coef_F, gsum[ly * 9 + l], gpose[ly * 9 + l]);
+  const bool floss_grad = A.coef_F != 0.0f;  // else gsum was not written
+  for (int ly = 0; ly < A.L; ++ly)
+    A.g_F[((size_t)ly * A.B + pair) * 9 + l] = floss_grad ? fmaf(A.coef_F, gsum[ly * 9 + l], gpose[ly * 9 + l]) : gpose[ly * 9 + l];
 }
 
 // One pair in ONE row, both parts in sequence (lane l < L takes layer l's 3x3 work): what tests/emu/ runs; the kernel
