@@ -281,6 +281,10 @@ __device__ inline void svd3(const T* F, T* U, T* S, T* V) {
 // cubic: Newton from 0 converges monotonically from below (all roots real, p > 0, p' < 0, p'' > 0 left of the smallest
 // one), and the null vector of a rank-2 symmetric 3x3 is the largest cross product of two of its rows.  s3 = u3^T F v3 is
 // stationary w.r.t. first-order errors of the vectors.  ~250 straight-line instructions instead of a Jacobi SVD.
+// ROBUST: also right when the matrix has rank 1 (every cross product is round-off): then any vector orthogonal to its dominant
+// row is a null vector.  The fit never needs it (its matrix comes from a generic eigenvector); the pose path takes whatever E
+// it is given.
+template <bool ROBUST = false>
 __device__ __forceinline__ void sym3_null_vector(double c00, double c01, double c02, double c11, double c12, double c22, double* n) {
   // rows r0 = (c00,c01,c02), r1 = (c01,c11,c12), r2 = (c02,c12,c22)
   const double a0 = c01 * c12 - c02 * c11, a1 = c02 * c01 - c00 * c12, a2 = c00 * c11 - c01 * c01;  // r0 x r1
@@ -293,9 +297,24 @@ __device__ __forceinline__ void sym3_null_vector(double c00, double c01, double 
   const double inv = (nx > 0.0) ? rsqrt_nr<2>(nx) : 0.0;
   n[0] = x0 * inv; n[1] = x1 * inv; n[2] = x2 * inv;
   if (!(nx > 0.0)) { n[0] = 0.0; n[1] = 0.0; n[2] = 1.0; }  // the zero matrix: any unit vector
+  if constexpr (ROBUST) {
+    const double r0 = c00 * c00 + c01 * c01 + c02 * c02, r1 = c01 * c01 + c11 * c11 + c12 * c12, r2 = c02 * c02 + c12 * c12 + c22 * c22;
+    const double rmax = fmax(r0, fmax(r1, r2));
+    if (nx <= 1e-24 * rmax * rmax && rmax > 0.0) {  // |row x row| below 1e-12 |row|^2: rank 1 to working precision
+      const bool k0 = r0 >= r1 && r0 >= r2, k1 = !k0 && r1 >= r2;
+      const double d0 = k0 ? c00 : (k1 ? c01 : c02), d1 = k0 ? c01 : (k1 ? c11 : c12), d2 = k0 ? c02 : (k1 ? c12 : c22);
+      // e_k x d for the axis d is least aligned with
+      const double ax = fabs(d0), ay = fabs(d1), az = fabs(d2);
+      const bool kx = ax <= ay && ax <= az, ky = !kx && ay <= az;
+      const double y0 = kx ? 0.0 : (ky ? d2 : -d1), y1 = kx ? -d2 : (ky ? 0.0 : d0), y2 = kx ? d1 : (ky ? -d0 : 0.0);
+      const double iy = rsqrt_nr<2>(fmax(y0 * y0 + y1 * y1 + y2 * y2, 1e-300));
+      n[0] = y0 * iy; n[1] = y1 * iy; n[2] = y2 * iy;
+    }
+  }
 }
 
 // F row-major, assumed O(1) in magnitude (the solver passes a unit-Frobenius F).  Returns s3 >= 0, unit u3, v3.
+template <bool ROBUST = false>
 __device__ __forceinline__ void smallest_singular_triplet3(const double* F, double* u3, double* v3, double& s3) {
   // B = F^T F
   const double b00 = F[0] * F[0] + F[3] * F[3] + F[6] * F[6], b01 = F[0] * F[1] + F[3] * F[4] + F[6] * F[7];
@@ -312,12 +331,12 @@ __device__ __forceinline__ void smallest_singular_triplet3(const double* F, doub
     if (!(dx > 1e-17 * c2)) break;                                // also leaves on NaN; p <= 0: at (or rounded past) the root
     x += dx;
   }
-  sym3_null_vector(b00 - x, b01, b02, b11 - x, b12, b22 - x, v3);
+  sym3_null_vector<ROBUST>(b00 - x, b01, b02, b11 - x, b12, b22 - x, v3);
   // D = F F^T
   const double d00 = F[0] * F[0] + F[1] * F[1] + F[2] * F[2], d01 = F[0] * F[3] + F[1] * F[4] + F[2] * F[5];
   const double d02 = F[0] * F[6] + F[1] * F[7] + F[2] * F[8], d11 = F[3] * F[3] + F[4] * F[4] + F[5] * F[5];
   const double d12 = F[3] * F[6] + F[4] * F[7] + F[5] * F[8], d22 = F[6] * F[6] + F[7] * F[7] + F[8] * F[8];
-  sym3_null_vector(d00 - x, d01, d02, d11 - x, d12, d22 - x, u3);
+  sym3_null_vector<ROBUST>(d00 - x, d01, d02, d11 - x, d12, d22 - x, u3);
   double s = 0.0;
 #pragma unroll
   for (int r = 0; r < 3; ++r)
@@ -325,6 +344,88 @@ __device__ __forceinline__ void smallest_singular_triplet3(const double* F, doub
     for (int c = 0; c < 3; ++c) s += u3[r] * F[3 * r + c] * v3[c];
   if (s < 0.0) { s = -s; u3[0] = -u3[0]; u3[1] = -u3[1]; u3[2] = -u3[2]; }
   s3 = s;
+}
+
+// Unit vectors a1, a2 completing n (unit) to a right-handed orthonormal basis (a1, a2, n): a1 = e_k x n normalised with k the
+// axis n is least aligned with (|e_k x n|^2 >= 2/3), a2 = n x a1.  Branch-free.
+__device__ __forceinline__ void orthonormal_complement3(const double* n, double* a1, double* a2) {
+  const double ax = fabs(n[0]), ay = fabs(n[1]), az = fabs(n[2]);
+  const bool kx = ax <= ay && ax <= az, ky = !kx && ay <= az;
+  // e_x x n = (0, -n2, n1);  e_y x n = (n2, 0, -n0);  e_z x n = (-n1, n0, 0)
+  const double c0 = kx ? 0.0 : (ky ? n[2] : -n[1]);
+  const double c1 = kx ? -n[2] : (ky ? 0.0 : n[0]);
+  const double c2 = kx ? n[1] : (ky ? -n[0] : 0.0);
+  const double inv = rsqrt_nr<2>(c0 * c0 + c1 * c1 + c2 * c2);
+  a1[0] = c0 * inv; a1[1] = c1 * inv; a1[2] = c2 * inv;
+  a2[0] = n[1] * a1[2] - n[2] * a1[1]; a2[1] = n[2] * a1[0] - n[0] * a1[2]; a2[2] = n[0] * a1[1] - n[1] * a1[0];
+}
+
+// Closed-form SVD of a 3x3 matrix with the contract of svd3<double> (F = U diag(S) V^T, S descending and >= 0, singular vectors
+// in the columns of the row-major U, V; u3 oriented along F v3), without a Jacobi iteration: the smallest singular triplet as
+// above, then the 2x2 problem in the orthogonal complements of u3 / v3, whose one Jacobi rotation is exact.  ~450 straight-line
+// instructions against ~170 per sweep of the one-sided Jacobi (4-6 sweeps).  Repeated s1 = s2 (essential matrices) is fine:
+// any orthonormal pair of the plane is a valid answer, and U, V are produced consistently (u_i = F v_i / s_i).
+__device__ inline void svd3_closed(const double* Fin, double* U, double* S, double* V) {
+  // exact power-of-two prescale (see svd3): the closed forms assume O(1) entries
+  double big = 0.0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) big = fmax(big, fabs(Fin[i]));
+  int ex = 0;
+  if (big > 0.0 && big < 1e300) (void)frexp(big, &ex);
+  double F[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) F[i] = ldexp(Fin[i], -ex);
+  double u3[3], v3[3], s3;
+  smallest_singular_triplet3<true>(F, u3, v3, s3);
+  double a1[3], a2[3], b1[3], b2[3];
+  orthonormal_complement3(v3, a1, a2);
+  orthonormal_complement3(u3, b1, b2);
+  // G = F [a1 a2] (3x2), B = [b1 b2]^T G (2x2)
+  double g1[3], g2[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    g1[r] = F[3 * r] * a1[0] + F[3 * r + 1] * a1[1] + F[3 * r + 2] * a1[2];
+    g2[r] = F[3 * r] * a2[0] + F[3 * r + 1] * a2[1] + F[3 * r + 2] * a2[2];
+  }
+  const double B00 = b1[0] * g1[0] + b1[1] * g1[1] + b1[2] * g1[2], B01 = b1[0] * g2[0] + b1[1] * g2[1] + b1[2] * g2[2];
+  const double B10 = b2[0] * g1[0] + b2[1] * g1[1] + b2[2] * g1[2], B11 = b2[0] * g2[0] + b2[1] * g2[1] + b2[2] * g2[2];
+  // one rotation of the columns of B diagonalises B^T B = [[al, ga], [ga, be]]: (c, s) as in svd3
+  const double al = B00 * B00 + B10 * B10, be = B01 * B01 + B11 * B11, ga = B00 * B01 + B10 * B11;
+  const double d = be - al, b = 2.0 * ga;
+  const double h2 = d * d + b * b;
+  const bool rot = h2 > 0.0;
+  const double rh = rot ? rsqrt_nr<2>(h2) : 0.0;
+  const double x = 0.5 + 0.5 * fabs(d) * rh;  // cos^2; 1/2 .. 1
+  const double y = rsqrt_nr<2>(x);
+  const double c = rot ? x * y : 1.0;
+  const double sn = rot ? copysign(0.5, d) * b * rh * y : 0.0;
+  // rotated columns: first = c col0 - s col1, second = s col0 + c col1
+  double p0x = c * B00 - sn * B01, p0y = c * B10 - sn * B11;
+  double p1x = sn * B00 + c * B01, p1y = sn * B10 + c * B11;
+  double q0x = c, q0y = -sn, q1x = sn, q1y = c;  // the corresponding right vectors in the (a1, a2) basis
+  double n0 = p0x * p0x + p0y * p0y, n1 = p1x * p1x + p1y * p1y;
+  if (n0 < n1) {  // descending
+    double t;
+    t = p0x; p0x = p1x; p1x = t; t = p0y; p0y = p1y; p1y = t; t = n0; n0 = n1; n1 = t;
+    t = q0x; q0x = q1x; q1x = t; t = q0y; q0y = q1y; q1y = t;
+  }
+  const double s1 = sqrt_nr<2>(n0), s2 = sqrt_nr<2>(n1);
+  // left vectors in the (b1, b2) basis: the first from its column, the second perpendicular to it, oriented along its column
+  // (well defined even when s2 = 0)
+  const double i1 = (n0 > 0.0) ? rsqrt_nr<2>(n0) : 0.0;
+  const double l0x = (n0 > 0.0) ? p0x * i1 : 1.0, l0y = (n0 > 0.0) ? p0y * i1 : 0.0;
+  const double sg = (-l0y * p1x + l0x * p1y < 0.0) ? -1.0 : 1.0;
+  const double l1x = -sg * l0y, l1y = sg * l0x;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    U[3 * r + 0] = b1[r] * l0x + b2[r] * l0y;
+    U[3 * r + 1] = b1[r] * l1x + b2[r] * l1y;
+    U[3 * r + 2] = u3[r];
+    V[3 * r + 0] = a1[r] * q0x + a2[r] * q0y;
+    V[3 * r + 1] = a1[r] * q1x + a2[r] * q1y;
+    V[3 * r + 2] = v3[r];
+  }
+  S[0] = ldexp(s1, ex); S[1] = ldexp(s2, ex); S[2] = ldexp(s3, ex);
 }
 
 // y = C^+ x for a symmetric 3x3 C (6 distinct entries) with unit null vector n: (C + n n^T)^-1 (x - n (n.x)) by the

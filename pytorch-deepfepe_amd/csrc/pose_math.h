@@ -6,7 +6,7 @@
 //   _l2_error     dsac_tools/utils_geo.py:165-167
 //   selection by strict '<'                       train_good_utils.py:160-168 (R and t picked independently)
 //   rot12_to_angle_error / vector_angle           dsac_tools/utils_geo.py:150-155, 175-179
-// Everything is 3x3 work in fp64 registers of ONE lane (3x3 one-sided Jacobi SVD).  The adjoint of the SVD uses the
+// Everything is 3x3 work in fp64 registers of ONE lane (closed-form 3x3 SVD, dfepe_math.h svd3_closed).  The adjoint of the SVD uses the
 // combined (1,2)-block form Z12/(s1+s2): for R = U W V^T the generic 1/(s1^2-s2^2) terms cancel analytically, so true
 // essential matrices (s1 == s2) stay finite.  cv2.Rodrigues is replaced by atan2(|axis|, trace-1) (same angle; OpenCV
 // arithmetic is unpinned).  Pure per-lane C++ (needs dfepe_math.h).
@@ -105,7 +105,7 @@ __device__ inline void pose_forward(const float* E, const float* q_gt, const flo
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int c = 0; c < 3; ++c) Ec[3 * r + c] = (double)E[3 * c + r];
-  svd3<double>(Ec, P.U, P.S, P.V);
+  svd3_closed(Ec, P.U, P.S, P.V);
   const double* U = P.U;
   const double* V = P.V;
   // U W = [u2, -u1, u3],  U W^T = [-u2, u1, u3]   (columns);   R = (U W) V^T
