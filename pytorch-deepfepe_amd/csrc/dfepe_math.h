@@ -97,7 +97,8 @@ __device__ __forceinline__ void mat3_mul_nt(const T* A, const T* B, T* C) {  // 
 }
 
 // fp32 one-sided Jacobi SVD of a 3x3 matrix on the hardware transcendentals (v_rsq_f32 / v_rcp_f32, ~1 ulp):
-// same contract as svd3<float> below, ~50 instructions per rotation with two dependent transcendentals
+// F = U diag(S) V^T, S descending, singular vectors in the columns of the row-major U, V; ~50 instructions per rotation with two
+// dependent transcendentals
 // (r = rsq(d^2+b^2); x = (1+|d| r)/2; y = rsq(x); c = x y; s = sgn(d) b r y / 2) and a division-free skip test.
 // Used for the rank-2 step of the solver, where the dropped triplet is re-measured in fp64 afterwards.
 __device__ inline void svd3_fast(const float* F, float* U, float* S, float* V) {
@@ -173,106 +174,6 @@ __device__ inline void svd3_fast(const float* F, float* U, float* S, float* V) {
   const float c2 = U[0] * U[4] - U[3] * U[1];
   const float sg = (c0 * G[2] + c1 * G[5] + c2 * G[8] < 0.0f) ? -1.0f : 1.0f;
   U[2] = sg * c0; U[5] = sg * c1; U[8] = sg * c2;
-}
-
-// square root / reciprocal flavours of the templated 3x3 SVD: branch-free Newton forms in fp64 (operands are squared
-// column norms and singular values of matrices of moderate magnitude), the hardware ops in fp32
-__device__ __forceinline__ double svd_rsqrt(double x) { return rsqrt_nr<2>(x); }
-__device__ __forceinline__ float svd_rsqrt(float x) { return hw_rsq(x); }
-__device__ __forceinline__ double svd_sqrt(double x) { return sqrt_nr<2>(x); }
-__device__ __forceinline__ float svd_sqrt(float x) { return sqrtf(x); }
-__device__ __forceinline__ double svd_rcp(double x) { return rcp_nr<2>(x); }
-__device__ __forceinline__ float svd_rcp(float x) { return 1.0f / x; }
-
-// One-sided (Hestenes) Jacobi SVD of a 3x3 matrix: F = U diag(S) V^T, S descending, S[2] >= 0 given the
-// orientation chosen for u3.  U, V row-major with singular vectors in columns.  Straight-line code on
-// values in registers; `T` is float (forward rank-2 step, backward bookkeeping) or double (pose kernels).
-template <typename T>
-__device__ inline void svd3(const T* F, T* U, T* S, T* V) {
-  T G[9];
-  // Exact power-of-two prescale to max|F| in [0.5, 1): the vectors do not depend on the scale, S is scaled back exactly, and
-  // the Newton reciprocals / square roots (fp32 seeds) see O(1) operands whatever the scale of the input (an essential
-  // matrix times 1e-6 used to leave their range: scripts/stress_pose.py).
-  T big = T(0);
-#pragma unroll
-  for (int i = 0; i < 9; ++i) big = fmax(big, fabs(F[i]));
-  int ex = 0;
-  if (big > T(0) && big < T(1e300)) (void)frexp(big, &ex);
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    G[i] = ldexp(F[i], -ex);
-    V[i] = (i % 4 == 0) ? T(1) : T(0);
-  }
-  const T tol = (sizeof(T) == 4) ? T(1e-7) : T(1e-15);
-  for (int sweep = 0; sweep < 12; ++sweep) {
-    T worst = T(0);
-#pragma unroll
-    for (int pq = 0; pq < 3; ++pq) {
-      const int p = (pq == 2) ? 1 : 0;
-      const int q = (pq == 0) ? 1 : 2;
-      T al = G[p] * G[p] + G[3 + p] * G[3 + p] + G[6 + p] * G[6 + p];
-      T be = G[q] * G[q] + G[3 + q] * G[3 + q] + G[6 + q] * G[6 + q];
-      T ga = G[p] * G[q] + G[3 + p] * G[3 + q] + G[6 + p] * G[6 + q];
-      const bool rot = ga * ga > tol * tol * al * be;  // division-free skip test
-      worst = rot ? T(1) : worst;
-      if (rot) {
-        // r = 1/h, h = sqrt(d^2+b^2); x = (1 + |d|/h)/2 = cos^2; c = sqrt(x), s = sgn(d) b / (2 h c)
-        const T d = be - al, b = T(2) * ga;
-        const T rh = svd_rsqrt(d * d + b * b);
-        const T x = T(0.5) + T(0.5) * fabs(d) * rh;
-        const T y = svd_rsqrt(x);
-        const T c = x * y;
-        const T s = copysign(T(0.5), d) * b * rh * y;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          T gp = G[3 * r + p], gq = G[3 * r + q];
-          G[3 * r + p] = c * gp - s * gq;
-          G[3 * r + q] = s * gp + c * gq;
-          T vp = V[3 * r + p], vq = V[3 * r + q];
-          V[3 * r + p] = c * vp - s * vq;
-          V[3 * r + q] = s * vp + c * vq;
-        }
-      }
-    }
-    if (worst == T(0)) break;
-  }
-  T n[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) n[k] = svd_sqrt(G[k] * G[k] + G[3 + k] * G[3 + k] + G[6 + k] * G[6 + k]);
-  // sort columns descending (3-element network)
-#define DFEPE_SWAPCOL(a, b)                                   \
-  if (n[a] < n[b]) {                                          \
-    T tn = n[a]; n[a] = n[b]; n[b] = tn;                      \
-    _Pragma("unroll") for (int r = 0; r < 3; ++r) {           \
-      T tg = G[3 * r + a]; G[3 * r + a] = G[3 * r + b]; G[3 * r + b] = tg; \
-      T tv = V[3 * r + a]; V[3 * r + a] = V[3 * r + b]; V[3 * r + b] = tv; \
-    }                                                         \
-  }
-  DFEPE_SWAPCOL(0, 1)
-  DFEPE_SWAPCOL(1, 2)
-  DFEPE_SWAPCOL(0, 1)
-#undef DFEPE_SWAPCOL
-  const T tiny = T(1e-30);
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    T inv = svd_rcp(fmax(n[k], tiny));
-    U[k] = G[k] * inv;
-    U[3 + k] = G[3 + k] * inv;
-    U[6 + k] = G[6 + k] * inv;
-  }
-  // u2 re-orthogonalised against u1 (matters only when s2 is tiny), u3 = u1 x u2 oriented along g3
-  {
-    T d = U[0] * U[1] + U[3] * U[4] + U[6] * U[7];
-    T a0 = U[1] - d * U[0], a1 = U[4] - d * U[3], a2 = U[7] - d * U[6];
-    T inv = svd_rsqrt(fmax(a0 * a0 + a1 * a1 + a2 * a2, tiny * tiny));
-    U[1] = a0 * inv; U[4] = a1 * inv; U[7] = a2 * inv;
-  }
-  T c0 = U[3] * U[7] - U[6] * U[4];
-  T c1 = U[6] * U[1] - U[0] * U[7];
-  T c2 = U[0] * U[4] - U[3] * U[1];
-  T sg = (c0 * G[2] + c1 * G[5] + c2 * G[8] < T(0)) ? T(-1) : T(1);
-  U[2] = sg * c0; U[5] = sg * c1; U[8] = sg * c2;
-  S[0] = ldexp(n[0], ex); S[1] = ldexp(n[1], ex); S[2] = ldexp(n[2], ex);
 }
 
 // ---- smallest singular triplet of a 3x3 matrix in closed form (fp64) -----------------------------------------------
@@ -360,13 +261,15 @@ __device__ __forceinline__ void orthonormal_complement3(const double* n, double*
   a2[0] = n[1] * a1[2] - n[2] * a1[1]; a2[1] = n[2] * a1[0] - n[0] * a1[2]; a2[2] = n[0] * a1[1] - n[1] * a1[0];
 }
 
-// Closed-form SVD of a 3x3 matrix with the contract of svd3<double> (F = U diag(S) V^T, S descending and >= 0, singular vectors
-// in the columns of the row-major U, V; u3 oriented along F v3), without a Jacobi iteration: the smallest singular triplet as
+// Closed-form SVD of a 3x3 matrix in fp64: F = U diag(S) V^T, S descending and >= 0, singular vectors in the columns of the
+// row-major U, V, u3 oriented along F v3 -- without a Jacobi iteration: the smallest singular triplet as
 // above, then the 2x2 problem in the orthogonal complements of u3 / v3, whose one Jacobi rotation is exact.  ~450 straight-line
-// instructions against ~170 per sweep of the one-sided Jacobi (4-6 sweeps).  Repeated s1 = s2 (essential matrices) is fine:
+// instructions against ~170 per sweep of the one-sided Jacobi it replaced (4-6 sweeps).  Repeated s1 = s2 (essential matrices) is fine:
 // any orthonormal pair of the plane is a valid answer, and U, V are produced consistently (u_i = F v_i / s_i).
 __device__ inline void svd3_closed(const double* Fin, double* U, double* S, double* V) {
-  // exact power-of-two prescale (see svd3): the closed forms assume O(1) entries
+  // exact power-of-two prescale to max|F| in [0.5, 1): the vectors do not depend on the scale, S is scaled back exactly, and the
+  // closed forms / Newton seeds see O(1) entries whatever the scale of the input (an essential matrix times 1e-6 used to leave
+  // their range: scripts/stress_pose.py)
   double big = 0.0;
 #pragma unroll
   for (int i = 0; i < 9; ++i) big = fmax(big, fabs(Fin[i]));
@@ -389,7 +292,8 @@ __device__ inline void svd3_closed(const double* Fin, double* U, double* S, doub
   }
   const double B00 = b1[0] * g1[0] + b1[1] * g1[1] + b1[2] * g1[2], B01 = b1[0] * g2[0] + b1[1] * g2[1] + b1[2] * g2[2];
   const double B10 = b2[0] * g1[0] + b2[1] * g1[1] + b2[2] * g1[2], B11 = b2[0] * g2[0] + b2[1] * g2[1] + b2[2] * g2[2];
-  // one rotation of the columns of B diagonalises B^T B = [[al, ga], [ga, be]]: (c, s) as in svd3
+  // one rotation of the columns of B diagonalises B^T B = [[al, ga], [ga, be]]: r = 1/h, h = sqrt(d^2 + b^2);
+  // x = (1 + |d|/h)/2 = cos^2; c = sqrt(x), s = sgn(d) b / (2 h c)
   const double al = B00 * B00 + B10 * B10, be = B01 * B01 + B11 * B11, ga = B00 * B01 + B10 * B11;
   const double d = be - al, b = 2.0 * ga;
   const double h2 = d * d + b * b;

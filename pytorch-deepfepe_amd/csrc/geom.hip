@@ -143,7 +143,7 @@ __device__ inline void quat_of(const double* R, double* q) {
 // det < 0), t = u3 / |u3|
 __device__ inline void decompose_E(const double* E, double* R1, double* R2, double* t) {
   double U[9], S[3], V[9];
-  svd3<double>(E, U, S, V);
+  svd3_closed(E, U, S, V);
   double UW[9], UWt[9];
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
@@ -194,7 +194,7 @@ geo_misc_kernel(int kind, const float* __restrict__ in0, const float* __restrict
     double E[9], U[9], S[3], V[9], Ed[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) E[k] = (double)in0[i * 9 + k];
-    svd3<double>(E, U, S, V);
+    svd3_closed(E, U, S, V);
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
