@@ -227,3 +227,50 @@ def test_loss_tail_body_vs_oracle(emu, dfepe, oracle, L, M, qt, noise):
         lo = lo + oracle.qt_training_loss(pose["q_l2"], pose["t_l2"], cq, ct, bq, bt)
     lo.backward()
     assert relerr(gF.numpy(), Fo.grad.numpy()) < 3e-4
+
+
+def test_loss_tail_body_degenerate_matrices_stay_finite(emu, dfepe, oracle):
+    """Rank-1, zero, and badly scaled F (whatever a diverged estimator may produce) through the fused loss tail: the
+    closed-form 3x3 SVD (svd3_closed, with its rank-1 branch of the null vector) and the pose adjoint return finite numbers, and
+    where the oracle's pose is well defined (the scaled essential matrices) they still agree with it."""
+    I, P, F32 = ctypes.c_int, ctypes.c_void_p, ctypes.c_float
+    emu.emu_loss_tail.restype = I
+    emu.emu_loss_tail.argtypes = [P, I, I, P, P, I, P, P, P, I, F32, P, P, P, F32, F32, F32, F32, F32] + [P] * 9
+    B, L, M = 6, 2, 32
+    sc = dfepe.synth.make_scene(B, 50, seed=11)
+    v1, v2 = sc["pts1_virt_ori"][:, :M].contiguous(), sc["pts2_virt_ori"][:, :M].contiguous()
+    T = oracle.hw_matrix(IMAGE_SIZE, torch.float64)
+    Tinv = torch.linalg.inv(T)
+    Fn = Tinv.T @ sc["F_gt"].double() @ Tinv
+    Fn = Fn / Fn.flatten(1).norm(dim=1)[:, None, None]
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.randn(3, generator=g, dtype=torch.float64), torch.randn(3, generator=g, dtype=torch.float64)
+    Fl = torch.stack([Fn.clone(), Fn.clone()])
+    Fl[:, 0] = torch.outer(a, b)          # rank 1
+    Fl[:, 1] = 0.0                        # zero
+    Fl[:, 2] = Fn[2] * 1e-6               # tiny
+    Fl[:, 3] = Fn[3] * 1e6                # huge
+    Fl[:, 4] = torch.outer(a, a) * 1e-3   # rank 1, symmetric
+    Fl = Fl.float().contiguous()
+    Ks = sc["Ks"].contiguous()
+    q_gt, t_gt = sc["qs_cam"].reshape(B, 4).contiguous(), sc["ts_cam"].reshape(B, 3).contiguous()
+    R_gt = sc["delta_Rtijs_4_4"][:, :3, :3].transpose(1, 2).contiguous()
+    Tf = T.float().contiguous()
+    loss_sum, E = torch.zeros(L, B), torch.zeros(L, B, 3, 3)
+    q_l2, t_l2, R_deg, t_deg = (torch.zeros(L, B) for _ in range(4))
+    sel = torch.zeros(L, B, dtype=torch.int32)
+    gF = torch.zeros(L, B, 3, 3)
+    part = torch.zeros(B, 48, dtype=torch.float64)
+    rc = emu.emu_loss_tail(_p(Fl), L, B, _p(Tf), _p(Tf), 0, _p(Ks), _p(v1), _p(v2), M, 0.02, _p(q_gt), _p(t_gt), _p(R_gt),
+                           0.1, 0.5, 1.0 / (L * B * M), 1.0 / (L * B), 0.1 / (L * B), _p(loss_sum), _p(E), _p(q_l2), _p(t_l2), _p(R_deg),
+                           _p(t_deg), _p(sel), _p(gF), _p(part))
+    assert rc == 0
+    for t in (loss_sum, E, q_l2, t_l2, R_deg, t_deg, gF, part):
+        assert torch.isfinite(t).all()
+    # the pose of a (tiny / huge) essential matrix does not depend on its scale
+    E_layers = [Tf.double().T @ Fl[l].double() @ Tf.double() for l in range(L)]
+    E_layers = [Ks.double().transpose(1, 2) @ e @ Ks.double() for e in E_layers]
+    pose = oracle.rt_loss(E_layers, sc["delta_Rtijs_4_4"].double(), sc["qs_cam"].double(), sc["ts_cam"].double())
+    for bidx in (2, 3, 5):
+        np.testing.assert_allclose(q_l2[:, bidx].numpy(), pose["q_l2"][:, bidx].numpy(), atol=5e-6)
+        np.testing.assert_allclose(t_l2[:, bidx].numpy(), pose["t_l2"][:, bidx].numpy(), atol=5e-6)
