@@ -71,7 +71,49 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=512, help="pairs in the CPU-baseline sample (~10 s of host work per pass)")
     ap.add_argument("--force-dist", action="store_true",
                     help="single-process smoke test of the multi-GPU code path: a 1-rank RCCL group and the overlapped exchange")
+    ap.add_argument("--launcher", choices=("auto", "torchrun", "none"), default="auto",
+                    help="auto: a plain `python bench.py --gpus N` (no RANK in the environment) with N > 1 re-executes itself under "
+                         "torch.distributed.run with N ranks; torchrun: do that even for N = 1 (exercises the launch path on a 1-GPU box); "
+                         "none: never re-execute")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_command(argv, gpus, port):
+    """The command a plain `python bench.py --gpus N` turns itself into: the driver's own N > 1 invocation."""
+    argv = list(argv)
+    while "--launcher" in argv:  # the ranks must not launch again
+        i = argv.index("--launcher")
+        del argv[i:i + 2]
+    argv = [a for a in argv if not a.startswith("--launcher=")]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), *argv, "--launcher", "none"]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, RCCL).  The
+    reference's counterpart is one process driving every GPU through nn.DataParallel (deepFEPE/train_good.py:311-312).
+    Rank 0's JSON line passes through this process's stdout; the launcher's exit code is returned."""
+    import subprocess
+
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this node exposes {have} GPU(s)")
+    cmd = launch_command(sys.argv[1:], args.gpus, _free_port())
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    log("self-launch:", " ".join(cmd))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def log(*a):
@@ -117,6 +159,9 @@ def event_time_us(fn, reps=50, rounds=5, warm=5, graph=True):
 
 def main():
     args = parse()
+    launched = "RANK" in os.environ or "LOCAL_RANK" in os.environ
+    if not launched and args.launcher != "none" and (args.gpus > 1 or args.launcher == "torchrun"):
+        raise SystemExit(self_launch(args))
     # stdout carries exactly ONE line, the result JSON.  RCCL prints a version banner to the C-level stdout (flushed at exit,
     # i.e. after the JSON), so descriptor 1 is pointed at stderr for the whole run and the line is written to the saved one.
     sys.stdout.flush()
@@ -126,14 +171,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (plain `python bench.py --gpus N` does it itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU implementation)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or args.force_dist:
+    if world > 1 or args.force_dist or launched:
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -236,10 +280,16 @@ def main():
         run_step()
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [round(elapsed * 1e3 / args.steps, 4)]
+    rccl_world = None
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank_ms = [round(float(e.item()) * 1e3 / args.steps, 4) for e in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        rccl_world = dist.get_world_size()
     ms_per_step = elapsed * 1e3 / args.steps
     log("timed region done", ms_per_step, "ms/step")
     value = B_total * args.steps / elapsed
@@ -496,6 +546,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step_per_rank": per_rank_ms,
+            "rccl_world_size": rccl_world,
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,

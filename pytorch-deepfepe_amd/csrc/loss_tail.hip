@@ -30,6 +30,11 @@ loss_tail_kernel(const float* F_layers, int L, int B, int M, int t_stride, const
   const int pair0 = (int)blockIdx.x * kPairsPerBlock;
   // deferred head: its descriptor travels at the start of the workspace, in front of the partials
   if (write_desc && blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<TailHead*>(reinterpret_cast<char*>(partials) - kTailDescBytes) = Hd;
+  // ... and until the first backward launch has run that head, the batch scalars read as NaN, not as uninitialised memory
+  if (write_desc && blockIdx.x == 0 && (int)threadIdx.x < L + 4) {
+    Hd.packed[threadIdx.x] = __longlong_as_double(0x7FF8000000000000LL);
+    Hd.scalars[threadIdx.x] = __uint_as_float(0x7FC00000u);
+  }
   for (int e = (int)threadIdx.x; e < kPairsPerBlock * kTailParts; e += (int)blockDim.x) (&part[0][0])[e] = 0.0;
   __syncthreads();
   const bool floss_wave = threadIdx.x < 256u;  // uniform per wavefront

@@ -13,7 +13,8 @@
 namespace {
 
 constexpr int kNumThs = 13;
-__constant__ float kThs[kNumThs] = {0.0f, 0.01f, 0.03f, 0.05f, 0.1f, 0.3f, 0.5f, 1.0f, 2.0f, 5.0f, 10.0f, 90.0f, 180.0f};
+// np.histogram compares in float64 against float64 edges: a float32 error exactly at a float-rounded edge must land where numpy puts it
+__constant__ double kThs[kNumThs] = {0.0, 0.01, 0.03, 0.05, 0.1, 0.3, 0.5, 1.0, 2.0, 5.0, 10.0, 90.0, 180.0};
 
 __device__ __forceinline__ unsigned wave_count(bool p) { return (unsigned)__popcll(__ballot(p)); }
 
@@ -53,27 +54,35 @@ __global__ void __launch_bounds__(256) err_stats_kernel(const float* __restrict_
   const float x = live ? v[i] : 0.0f;
   // np.histogram: bins [ths[k], ths[k+1]), the last one closed on the right; values outside [0, 180] are dropped
   int bin = -1;
-  if (live && x >= kThs[0] && x <= kThs[kNumThs - 1]) {
+  const double xd = (double)x;
+  if (live && xd >= kThs[0] && xd <= kThs[kNumThs - 1]) {
     bin = kNumThs - 2;
 #pragma unroll
     for (int k = kNumThs - 2; k >= 0; --k)
-      if (x < kThs[k + 1]) bin = k;
+      if (xd < kThs[k + 1]) bin = k;
   }
   for (int k = 0; k < kNumThs - 1; ++k) {
     const unsigned cnt = wave_count(bin == k);
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&hist[which * (kNumThs - 1) + k], (unsigned long long)cnt);
   }
-  if (live && x >= 0.0f) atomicMax(&maxbits[which], __float_as_uint(x));  // non-negative floats order like their bit patterns
+  // non-negative floats order like their bit patterns, and the canonical NaN pattern sits above +inf: one NaN error makes the
+  // maximum NaN, as np.amax does (a diverged run must stay visible, train_good_utils.py:811-816)
+  if (live && (x >= 0.0f || x != x)) atomicMax(&maxbits[which], (x != x) ? 0x7FC00000u : __float_as_uint(x));
   if (live) {
-    int less = 0, equal = 0;
+    int less = 0, equal = 0, nans = 0;
     for (int j = 0; j < B; ++j) {
       const float y = v[j];
       less += (y < x) ? 1 : 0;
       equal += (y == x) ? 1 : 0;
+      nans += (y != y) ? 1 : 0;
     }
     const int k0 = (B - 1) / 2, k1 = B / 2;  // the middle order statistics (the same one for odd B)
-    if (less <= k0 && k0 < less + equal) mids[2 * which] = x;  // every lane that qualifies writes the same value
-    if (less <= k1 && k1 < less + equal) mids[2 * which + 1] = x;
+    if (nans) {  // np.median of a vector with a NaN is NaN; every lane sees the same count, so nobody writes anything else
+      mids[2 * which] = mids[2 * which + 1] = __uint_as_float(0x7FC00000u);
+    } else {
+      if (less <= k0 && k0 < less + equal) mids[2 * which] = x;  // every lane that qualifies writes the same value
+      if (less <= k1 && k1 < less + equal) mids[2 * which + 1] = x;
+    }
   }
 }
 

@@ -52,18 +52,11 @@ def hot_path_forward(matches: Tensor, logits_layers: Tensor, Ks: Tensor, virt1: 
     return out
 
 
-_TAIL_WS: Dict[tuple, Tensor] = {}
-
-
 def _tail_workspace(dev, B: int) -> Tensor:
-    """Scratch of dfepe_loss_tail (per-workgroup partial sums + the completion ticket), one per (device, stream, B):
-    contents irrelevant."""
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), ops._stream(), B)
-    ws = _TAIL_WS.get(key)
-    if ws is None:
-        ws = torch.zeros((_lib.lib().dfepe_loss_tail_workspace_bytes(B) + 7) // 8, dtype=torch.float64, device=dev)
-        _TAIL_WS[key] = ws
-    return ws
+    """Scratch of dfepe_loss_tail (per-workgroup partial sums, and the descriptor of a deferred head): ~100 KB from the caching
+    allocator per call, so that it belongs to the stream / graph-capture pool the call runs in (a cached buffer shared between
+    an eager call and a captured graph, or two graphs replayed on different streams, would race on the partial sums)."""
+    return torch.empty((_lib.lib().dfepe_loss_tail_workspace_bytes(B) + 7) // 8, dtype=torch.float64, device=dev)
 
 
 class _HotPathFunction(torch.autograd.Function):
@@ -80,7 +73,12 @@ class _HotPathFunction(torch.autograd.Function):
         L, B, N = logits_layers.shape
         dev = matches.device
         M = virt1.shape[1]
-        fused_tail = fused_tail and M <= 128
+        forced = []  # why the one-launch tail cannot serve this call (dfepe_loss_tail: M <= 128 virtual points, L <= 16 layers)
+        if M > 128:
+            forced.append(f"M = {M} > 128 virtual points")
+        if L > _lib.TAIL_MAX_LAYERS:
+            forced.append(f"depth {L} > {_lib.TAIL_MAX_LAYERS}")
+        fused_tail = fused_tail and not forced
         F_layers = torch.empty(L, B, 3, 3, device=dev)
         residuals = torch.empty(L, B, N, device=dev)
         epis = torch.empty(L, B, N, device=dev)
@@ -117,8 +115,7 @@ class _HotPathFunction(torch.autograd.Function):
                 # deferred loss head: packed / scalars are finished by the first backward launch (off the critical path); the
                 # workspace then carries the head's descriptor from here to there, so it belongs to this call alone
                 defer = bool(defer_head and ctx.needs_input_grad[1])
-                ws = (torch.empty((lib.dfepe_loss_tail_workspace_bytes(B) + 7) // 8, dtype=torch.float64, device=dev) if defer
-                      else _tail_workspace(dev, B))
+                ws = _tail_workspace(dev, B)
                 ctx.pending_ws = ws if defer else None
                 rc = lib.dfepe_loss_tail(F_layers.data_ptr(), L, B, hw_T.data_ptr(), hw_T.data_ptr(), 0, Ks.data_ptr(), virt1.data_ptr(),
                                          virt2.data_ptr(), M, clamp_at, ops._ptr(q_gt if qt else None), ops._ptr(t_gt if qt else None),
@@ -138,8 +135,8 @@ class _HotPathFunction(torch.autograd.Function):
                 rc = lib.dfepe_loss_head(loss_sum.data_ptr(), ops._ptr(q_l2), ops._ptr(t_l2), L, B, M, clamp_q, clamp_t, balance_q,
                                          balance_t, packed.data_ptr(), scalars.data_ptr(), st)
                 _lib.check(rc, "dfepe_loss_head")
-                if balance_F != 1.0:
-                    raise _lib.DfepeError("the unfused loss tail mixes loss_F + loss_qt (balance_F = 1); use fused_tail=True")
+                if balance_F != 1.0:  # dfepe_loss_head mixes loss_F + loss_qt; any other balance is one more tiny op here
+                    scalars[0:1].copy_(scalars[1:2] * balance_F + (scalars[2:3] if qt else 0.0))
         saved = [matches, weights, Ks, virt1, virt2, q_gt, t_gt, hw_T, F_layers, E_layers, saves]
         if gF is not None:
             saved.append(gF)
@@ -182,7 +179,7 @@ class _HotPathFunction(torch.autograd.Function):
                     _lib.check(rc, "dfepe_pose_bwd")
                     gE_ptr = gE.data_ptr()
                 rc = lib.dfepe_floss_bwd(F_layers.data_ptr(), L, B, hw_T.data_ptr(), hw_T.data_ptr(), 0, Ks.data_ptr(), virt1.data_ptr(),
-                                         virt2.data_ptr(), M, clamp_at, None, 1.0 / (L * n * M), g_scale.data_ptr(), gE_ptr,
+                                         virt2.data_ptr(), M, clamp_at, None, balance_F / (L * n * M), g_scale.data_ptr(), gE_ptr,
                                          gF.data_ptr(), st)
                 _lib.check(rc, "dfepe_floss_bwd")
             pend = getattr(ctx, "pending_ws", None)

@@ -379,3 +379,25 @@ def test_point_gradients_vs_oracle_autograd(dfepe, oracle, use_epi):
         lo = lo + (oracle.compute_epi_residual(q1, q2, o_out, 0.5) * GE.double()).sum()
     lo.backward()
     assert relerr(m.grad.cpu().numpy(), mo.grad.numpy()) < 2e-3
+
+
+@pytest.mark.parametrize("balance_F", [0.0, 0.3])
+def test_unfused_tail_honours_balance_F(dfepe, balance_F):
+    """fused_tail=False (and the forced fall-backs: M > 128 virtual points, depth > 16) mixes balance_F * loss_F + loss_qt like the
+    one-launch tail; balance_F = 0 is the reference's real qt objective (Train_model_pipeline.py:580-587)."""
+    B, N, depth = 21, 100, 3
+    sc = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(B, N, seed=36, outlier_ratio=0.3, depth_layers=depth), DEV)
+    a = dfepe.pipeline.hot_path_step(sc, IMAGE_SIZE, depth, 0.02, qt=True, balance_F=balance_F, fused_tail=True)
+    b = dfepe.pipeline.hot_path_step(sc, IMAGE_SIZE, depth, 0.02, qt=True, balance_F=balance_F, fused_tail=False)
+    assert abs(a["loss"].item() - b["loss"].item()) < 1e-6
+    assert relerr(a["grad_logits"].cpu().numpy(), b["grad_logits"].cpu().numpy()) < 5e-5
+
+
+def test_depth_beyond_the_fused_tail_falls_back_instead_of_raising(dfepe):
+    """dfepe_loss_tail serves <= 16 layers per launch; a deeper stack takes the five-kernel tail (same numbers as two fused halves)."""
+    B, N, depth = 6, 100, 18
+    sc = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(B, N, seed=37, outlier_ratio=0.2, depth_layers=depth), DEV)
+    o = dfepe.pipeline.hot_path_step(sc, IMAGE_SIZE, depth, 0.02, qt=True)
+    ref = dfepe.pipeline.hot_path_step(sc, IMAGE_SIZE, depth, 0.02, qt=True, fused=False)
+    assert abs(o["loss"].item() - ref["loss"].item()) < 1e-6
+    assert relerr(o["grad_logits"].cpu().numpy(), ref["grad_logits"].cpu().numpy()) < 5e-5

@@ -540,3 +540,20 @@ def test_validation_summary_end_to_end(dfepe, oracle):
     for k, v in ref.items():
         np.testing.assert_allclose(np.asarray(sm[k]), np.asarray(v), rtol=2e-6, atol=1e-7, err_msg=k)
     assert 0.0 <= sm["ratio_0.1"] <= sm["ratio_1"] <= 1.0 and np.isfinite(sm["median_err_q"]) and sm["ratio_q"][-1] <= 1.0
+
+
+def test_metrics_summary_propagates_nan_and_bins_like_numpy(dfepe):
+    """A diverged pair must stay visible: np.median / np.amax of a vector holding a NaN are NaN (train_good_utils.py:799-816);
+    np.histogram compares float64 values with float64 edges, so a float32 error just below a float-rounded edge stays below it."""
+    q = torch.tensor([0.5, 2.0, float("nan"), 1.0, 7.0], device=DEV)
+    t = torch.tensor([0.5, 2.0, 3.0, 1.0, 7.0], device=DEV)
+    epi = torch.rand(5, 10, device=DEV)
+    s = dfepe.ops.metrics_summary(epi, None, q, t)
+    assert np.isnan(s["median_err_q"]) and np.isnan(s["max_err_q"])
+    assert s["median_err_t"] == 2.0 and s["max_err_t"] == 7.0
+    # float32(0.01) = 0.0099999998 < 0.01 (double); float32(0.3) = 0.30000001 > 0.3; float32(0.1) = 0.100000001 > 0.1
+    edge = torch.tensor([0.01, 0.3, 0.1, 0.03], dtype=torch.float32, device=DEV)
+    s = dfepe.ops.metrics_summary(epi, None, edge, edge)
+    e64 = edge.cpu().numpy().astype(np.float64)
+    hist, _ = np.histogram(e64, bins=np.array(dfepe.ops.METRIC_THS))
+    np.testing.assert_allclose(s["ratio_q"], np.cumsum(hist) / 4.0)

@@ -144,3 +144,20 @@ def test_overlapped_loss_exchange_without_process_group():
     assert ex.drain() is None
     ex.exchange(torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64))
     np.testing.assert_allclose(ex.drain().numpy(), [1.0, 2.0, 3.0])
+
+
+def test_bench_self_launch_command_is_the_drivers_invocation():
+    """`python bench.py --gpus N` (no RANK in the environment) re-executes under torch.distributed.run with N ranks on 127.0.0.1
+    -- the command the driver uses for N > 1 -- and the ranks are told not to launch again."""
+    sys.path.insert(0, REPO)
+    bench = importlib.import_module("bench")
+    cmd = bench.launch_command(["--gpus", "8", "--steps", "3", "--launcher", "torchrun", "--warmup", "1"], 8, 29999)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert "--nproc-per-node=8" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    tail = cmd[cmd.index(os.path.join(REPO, "bench.py")) + 1:]
+    assert tail == ["--gpus", "8", "--steps", "3", "--warmup", "1", "--launcher", "none"]
+    # on this GPU-less container the launch refuses with a message instead of spawning ranks that cannot run
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "GPU" in r.stderr

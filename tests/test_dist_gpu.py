@@ -1,0 +1,179 @@
+"""What the data-parallel path rests on, checked on ONE GPU (the driver runs 8-GPU nodes itself):
+
+* ``grad_pairs``: a rank that owns a shard of the batch must produce exactly the rows of the global-batch gradient;
+* the step bench.py times (captured hipGraph, deferred loss head, grad_pairs) is bit-identical to the eager, undeferred step
+  the full-size parity test compares with the oracle;
+* a real RCCL group (one rank) behind a graph replay through dist.reduce_losses / OverlappedLossExchange;
+* ``python bench.py --gpus N`` launches its own ranks (the form the driver uses for N = 1, deepFEPE/train_good.py:311-312 is
+  the reference's single-process counterpart).
+GPU box only."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+IMAGE_SIZE = [376, 1241, 3]
+DEV = "cuda:0"
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fused(dfepe, sc, L, **kw):
+    logits = sc["logits_layers"][:L].detach().clone().requires_grad_(True)
+    o = dfepe.pipeline.hot_path_fused(sc["matches_xy_ori"], logits, sc["Ks"], sc["pts1_virt_ori"], sc["pts2_virt_ori"], sc["qs_cam"],
+                                      sc["ts_cam"], sc["R_gt"], IMAGE_SIZE, 0.02, True, **kw)
+    o["loss"].backward()
+    torch.cuda.synchronize()
+    o["grad_logits"] = logits.grad
+    return o
+
+
+@pytest.mark.parametrize("B,cut,balance_F", [(4096, 2048, 1.0), (301, 100, 0.0)])
+def test_grad_pairs_shards_reproduce_the_global_batch_gradient(dfepe, B, cut, balance_F):
+    """Two ranks' shards (here: two calls on one GPU) run with grad_pairs = global batch give the rows of the full-batch
+    d loss / d logits: the batch means of train_good_utils.py:340-364 / Train_model_pipeline.py:580-586 divide by the GLOBAL
+    number of pairs.  Per-pair arithmetic does not depend on the batch, so the rows agree bit for bit; the loss scalars combine
+    through dist.reduce_losses from the packed sums."""
+    L = 5
+    full = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(B, 100, seed=91, outlier_ratio=0.3, depth_layers=L), DEV)
+    whole = _fused(dfepe, full, L, balance_F=balance_F)
+    parts, packed = [], []
+    for a, b in ((0, cut), (cut, B)):
+        shard = {k: (v[:, a:b] if k == "logits_layers" else v[a:b]).contiguous() for k, v in full.items()}
+        o = _fused(dfepe, shard, L, balance_F=balance_F, grad_pairs=B)
+        parts.append(o["grad_logits"])
+        packed.append(o["packed"].clone())
+    g = torch.cat(parts, dim=1)
+    assert torch.equal(g, whole["grad_logits"])
+    # and without grad_pairs the shard gradient is the LOCAL mean's: larger by B / shard size
+    shard = {k: (v[:, :cut] if k == "logits_layers" else v[:cut]).contiguous() for k, v in full.items()}
+    loc = _fused(dfepe, shard, L, balance_F=balance_F)
+    ratio = (loc["grad_logits"].double().norm() / parts[0].double().norm()).item()
+    assert abs(ratio - B / cut) < 1e-4 * B / cut
+    # the loss scalars of the global batch from the two packed vectors (what the all-reduce sums)
+    red = dfepe.dist.reduce_losses(packed[0] + packed[1], L, 1.0, 0.1)
+    np.testing.assert_allclose(red["loss_F"].item(), whole["loss_F"].item(), rtol=2e-6)
+    np.testing.assert_allclose(red["loss_qt"].item(), whole["loss_qt"].item(), rtol=2e-6)
+    assert int(red["n_pairs"].item()) == B
+
+
+@pytest.mark.parametrize("balance_F,outl", [(1.0, 0.2), (0.0, 0.4)])
+def test_captured_deferred_step_is_the_eager_step_bit_for_bit_at_bench_size(dfepe, balance_F, outl):
+    """bench.py's timed step -- hot_path_fused(grad_pairs=B_total, defer_loss_head=True) captured in a hipGraph and replayed --
+    against the eager, undeferred default that tests/test_fullsize_gpu.py compares with the fp64 oracle, at B=4096, N=100,
+    depth 5 (configs 3 and 4): every output and d loss / d logits identical, also after repeated replays."""
+    B, N, L = 4096, 100, 5
+    sc = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(B, N, seed=2024, outlier_ratio=outl, noise_px=0.5, depth_layers=L), DEV)
+    eager = _fused(dfepe, sc, L, balance_F=balance_F)
+    H, W = float(IMAGE_SIZE[0]), float(IMAGE_SIZE[1])
+    hw_T = torch.tensor([[2.0 / W, 0.0, -1.0], [0.0, 2.0 / H, -1.0], [0.0, 0.0, 1.0]], device=DEV)
+    logits = sc["logits_layers"][:L].clone().requires_grad_(True)
+    state = {}
+
+    def step_body():  # bench.py: step_body of kind == "train"
+        out = dfepe.pipeline.hot_path_fused(sc["matches_xy_ori"], logits, sc["Ks"], sc["pts1_virt_ori"], sc["pts2_virt_ori"], sc["qs_cam"],
+                                            sc["ts_cam"], sc["R_gt"], IMAGE_SIZE, clamp_at=0.02, qt=True, hw_T=hw_T, balance_F=balance_F,
+                                            grad_pairs=B, defer_loss_head=True)
+        state["g"], = torch.autograd.grad(out["loss"], logits)
+        return out
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step_body()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = step_body()
+    for rep in range(3):
+        for t in (out["loss"], out["packed"], state["g"], out["F_layers"]):  # poison: a replay must rewrite everything
+            t.detach().fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        for k in ("loss", "loss_F", "loss_qt", "loss_layers", "packed", "loss_sum", "q_l2", "t_l2", "R_deg", "t_deg", "F_layers", "E_layers"):
+            assert torch.equal(out[k], eager[k]), (k, rep)
+        assert torch.equal(state["g"], eager["grad_logits"]), rep
+
+
+def test_one_rank_rccl_group_behind_a_graph_replay(dfepe):
+    """A real RCCL communicator (world size 1: one GPU under this lease) on the path bench.py --gpus N runs per step: graph replay
+    of the fused step -> all-reduce of the packed (L+4)-double vector -> dist.reduce_losses, in-stream and through the
+    double-buffered OverlappedLossExchange; the reduced means are the step's own batch means."""
+    import torch.distributed as dist
+
+    L, B = 5, 512
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        assert dist.get_backend() == "nccl"
+        sc = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(B, 100, seed=5, outlier_ratio=0.4, depth_layers=L), DEV)
+        eager = _fused(dfepe, sc, L)
+        logits = sc["logits_layers"][:L].clone().requires_grad_(True)
+        state = {}
+
+        def step_body():
+            out = dfepe.pipeline.hot_path_fused(sc["matches_xy_ori"], logits, sc["Ks"], sc["pts1_virt_ori"], sc["pts2_virt_ori"], sc["qs_cam"],
+                                                sc["ts_cam"], sc["R_gt"], IMAGE_SIZE, 0.02, True, grad_pairs=B * dist.get_world_size(),
+                                                defer_loss_head=True)
+            state["g"], = torch.autograd.grad(out["loss"], logits)
+            return out
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step_body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = step_body()
+        ex = dfepe.dist.OverlappedLossExchange(L + 4, torch.device(DEV), depth=2)
+        for _ in range(4):
+            graph.replay()
+            ex.exchange(out["packed"])
+        last = ex.drain().clone()
+        graph.replay()
+        red = dfepe.dist.reduce_losses(out["packed"].clone(), L, 1.0, 0.1)  # in-stream all-reduce
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert torch.equal(last, out["packed"])
+        np.testing.assert_allclose(red["loss_F"].item(), eager["loss_F"].item(), rtol=2e-6)
+        np.testing.assert_allclose(red["loss_qt"].item(), eager["loss_qt"].item(), rtol=2e-6)
+        np.testing.assert_allclose(red["loss_layers"].cpu().numpy(), eager["loss_layers"].double().cpu().numpy(), rtol=2e-6)
+        assert torch.equal(state["g"], eager["grad_logits"])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("flags", [["--gpus", "1", "--launcher", "torchrun"], ["--gpus", "1", "--force-dist"]])
+def test_bench_launches_its_own_ranks(flags):
+    """`python bench.py --gpus N` without a launcher re-executes under torch.distributed.run (here N = 1 forced through the same
+    path) and prints ONE JSON line from rank 0 that names the RCCL world it ran in."""
+    env = dict(os.environ)
+    env.pop("RANK", None), env.pop("LOCAL_RANK", None), env.pop("WORLD_SIZE", None)
+    env["MASTER_PORT"] = str(_free_port())
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *flags, "--steps", "20", "--warmup", "3", "--batch", "512", "--no-extras",
+                        "--no-cpu-baseline", "--blocks", "0"], cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=580)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["rccl_world_size"] == 1 and len(j["ms_per_step_per_rank"]) == 1
+    assert j["value"] > 0 and j["config"]["B_total"] == 512
