@@ -365,6 +365,85 @@ def cheirality_select(E: Tensor, K: np.ndarray, x1: np.ndarray, x2: np.ndarray, 
 
 
 # --------------------------------------------------------------------------------------
+# a15: evaluation-time pose  (utils_F.py:909-954 goodCorr_eval_nondecompose, train_good_utils.py:553-646 val_rt)
+#      own-source logic pinned by tests/golden/valrt.npz; cv2.recoverPose itself: parity unpinned
+# --------------------------------------------------------------------------------------
+def recover_pose(E: np.ndarray, p1: np.ndarray, p2: np.ndarray, focal: float, pp, dist: float = 50.0):
+    """Restatement of the published algorithm of cv2.recoverPose(E, p1, p2, focal=, pp=) (OpenCV 3.4; call site
+    utils_F.py:936): decomposeEssentialMat (U, V^T made proper rotations, W = [[0,1,0],[-1,0,0],[0,0,1]], t = U[:,2]), the
+    candidates [R1|t], [R2|t], [R1|-t], [R2|-t], linear triangulation of the (x - pp) / focal points against [I|0], a point
+    counts when its depth is in (0, dist) in both cameras, the first candidate with the largest count wins.  Returns
+    (count, R, t, counts) in the scene convention x2 ~ R x1 + t."""
+    E = np.asarray(E, dtype=np.float64)
+    q1 = (np.asarray(p1, dtype=np.float64) - np.asarray(pp, dtype=np.float64)) / focal
+    q2 = (np.asarray(p2, dtype=np.float64) - np.asarray(pp, dtype=np.float64)) / focal
+    U, _, Vt = np.linalg.svd(E)
+    U = -U if np.linalg.det(U) < 0 else U
+    Vt = -Vt if np.linalg.det(Vt) < 0 else Vt
+    Wm = np.array([[0.0, 1.0, 0.0], [-1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    R1, R2, t = U @ Wm @ Vt, U @ Wm.T @ Vt, U[:, 2:3]
+    P0 = np.hstack((np.eye(3), np.zeros((3, 1))))
+    cands = ((R1, t), (R2, t), (R1, -t), (R2, -t))
+    counts = []
+    for R, tt in cands:
+        P = np.hstack((R, tt))
+        Q = triangulate_dlt(P0, P, q1, q2)
+        ok = (Q[2] * Q[3]) > 0
+        Q = Q / Q[3]
+        ok &= Q[2] < dist
+        z2 = (P @ Q)[2]
+        ok &= (z2 > 0) & (z2 < dist)
+        counts.append(int(ok.sum()))
+    k = int(np.argmax(counts))
+    return counts[k], cands[k][0], cands[k][1], counts
+
+
+def good_corr_eval_nondecompose(p1s, p2s, E_hat, delta_Rtij_inv, K, scores=None):
+    """utils_F.goodCorr_eval_nondecompose (:909-954): optional top-10 % score mask (threshold = the (num_top)-th largest score,
+    kept with `>=`, :912-919); fewer than 5 correspondences: (180, 90) degrees and the identity pose (:949-952); otherwise
+    recoverPose, utils_geo.invert_Rt (utils_geo.py:192-196) and the angles of the camera motion against the ground truth
+    (:942-944).  Returns (hstack(R, t) of the scene motion, (err_q_deg, err_t_deg))."""
+    p1s, p2s = np.asarray(p1s), np.asarray(p2s)
+    if scores is not None:
+        scores = np.asarray(scores)
+        num_top = max(1, len(scores) // 10)
+        th = np.sort(scores)[::-1][num_top]
+        mask = scores >= th
+        p1s, p2s = p1s[mask], p2s[mask]
+    if p1s.shape[0] < 5:
+        return np.hstack((np.eye(3, dtype=np.float32), np.zeros((3, 1), np.float32))), (180.0, 90.0)
+    K = np.asarray(K)
+    _, R, t, _ = recover_pose(E_hat, p1s, p2s, focal=float(K[0, 0]), pp=(float(K[0, 2]), float(K[1, 2])))
+    R_cam, t_cam = R.T, -R.T @ t  # invert_Rt
+    gt = np.asarray(delta_Rtij_inv, dtype=np.float64)
+    err_q = rotation_angle_deg(R_cam, gt[:3, :3])
+    err_t = vector_angle_deg(t_cam.reshape(3), gt[:3, 3].reshape(3))
+    return np.hstack((R, t)), (err_q, err_t)
+
+
+def epi_distance_np(F: np.ndarray, X: np.ndarray, Y: np.ndarray):
+    """utils_F.epi_distance_np (:363-385), if_homo=False, 2-D form: |y^T F x| (1/|Fx|_xy + 1/|F^T y|_xy); returns (d1 + d2, d1, d2)."""
+    F = np.asarray(F, dtype=np.float64)  # the yard-stick evaluates in float64 whatever the inputs are
+    Xh = np.hstack((np.asarray(X, dtype=np.float64), np.ones((len(X), 1))))
+    Yh = np.hstack((np.asarray(Y, dtype=np.float64), np.ones((len(Y), 1))))
+    num = np.abs(np.einsum("ni,ij,nj->n", Yh, F, Xh))
+    Fx1, Fx2 = F @ Xh.T, F.T @ Yh.T
+    r1, r2 = 1.0 / np.sqrt(Fx1[0] ** 2 + Fx1[1] ** 2), 1.0 / np.sqrt(Fx2[0] ** 2 + Fx2[1] ** 2)
+    return num * (r1 + r2), num * r1, num * r2
+
+
+def val_rt(K, x1, x2, E_est, E_gt, F_est, F_gt, delta_Rtij_4_4):
+    """train_good_utils.val_rt (:553-646) without its OpenCV-baseline leg: pose errors of the estimated and of the ground-truth E
+    against inv(delta)[:3] (:581,586-601), epi_distance_np of both F over the pair's correspondences (:602-607).
+    Returns dict(err_est, epi_est, err_gt, epi_gt, M_est)."""
+    dinv = np.linalg.inv(np.asarray(delta_Rtij_4_4))[:3]
+    M_est, err_est = good_corr_eval_nondecompose(x1, x2, np.asarray(E_est).astype(np.float64), dinv, K, None)
+    _, err_gt = good_corr_eval_nondecompose(x1, x2, np.asarray(E_gt).astype(np.float64), dinv, K, None)
+    return {"err_est": np.array(err_est), "epi_est": epi_distance_np(F_est, x1, x2)[0], "err_gt": np.array(err_gt),
+            "epi_gt": epi_distance_np(F_gt, x1, x2)[0], "M_est": M_est}
+
+
+# --------------------------------------------------------------------------------------
 # a14: E projection  (utils_F.py:455-462, Train_model_pipeline.py:954-964)
 # --------------------------------------------------------------------------------------
 def F_to_E(F: Tensor, K: Tensor) -> Tensor:

@@ -112,6 +112,26 @@ def get_Rt_loss(E_ests_layers, Ks_cpu, x1_cpu, x2_cpu, delta_Rtijs_4_4_cpu, qs_c
     }
 
 
+def val_rt(idx, K_np, x1_single_np, x2_single_np, E_est_np, E_gt_np, F_est_np, F_gt_np, delta_Rtijs_4_4_cpu_np, five_point,
+           if_opencv=True):
+    """Same call and same 9-tuple as the reference's per-pair validation worker (train_good_utils.py:553-646):
+    (error_Rt_estW, epi_dist_mean_estW, error_Rt_opencv, epi_dist_mean_opencv, error_Rt_gt, epi_dist_mean_gt, idx, M_estW, M_opencv).
+    The estimated-E and ground-truth-E legs go through utils_F.goodCorr_eval_nondecompose (the cheirality kernel in place of
+    cv2.recoverPose) and utils_F.epi_distance_np.  The OpenCV five-point / eight-point RANSAC baseline (``if_opencv``,
+    utils_opencv.recover_camera_opencv) is outside this build (OpenCV baselines): its three slots are None.
+    One pair per call like the reference; val_rt_batch / validation_summary below are the batched forms."""
+    from . import utils_F
+
+    delta_Rtij_inv = np.linalg.inv(np.asarray(delta_Rtijs_4_4_cpu_np))[:3]
+    M_estW, error_Rt_estW = utils_F.goodCorr_eval_nondecompose(x1_single_np, x2_single_np, np.asarray(E_est_np).astype(np.float64),
+                                                                delta_Rtij_inv, K_np, None)
+    M_gt, error_Rt_gt = utils_F.goodCorr_eval_nondecompose(x1_single_np, x2_single_np, np.asarray(E_gt_np).astype(np.float64),
+                                                            delta_Rtij_inv, K_np, None)
+    epi_dist_mean_estW, _, _ = utils_F.epi_distance_np(F_est_np, x1_single_np, x2_single_np, if_homo=False)
+    epi_dist_mean_gt, _, _ = utils_F.epi_distance_np(F_gt_np, x1_single_np, x2_single_np, if_homo=False)
+    return (error_Rt_estW, epi_dist_mean_estW, None, None, error_Rt_gt, epi_dist_mean_gt, idx, M_estW, None)
+
+
 def val_rt_batch(Ks, matches_xy, E_ests, delta_Rtijs_4_4, project_E=True, depth_thres=50.0):
     """Batched GPU counterpart of the validation fan-out (Train_model_pipeline.py:954-964,1048-1061 -> val_rt :553-646 ->
     utils_F.goodCorr_eval_nondecompose -> cv2.recoverPose): optional projection of E onto singular values (1,1,0),

@@ -557,3 +557,58 @@ def test_metrics_summary_propagates_nan_and_bins_like_numpy(dfepe):
     e64 = edge.cpu().numpy().astype(np.float64)
     hist, _ = np.histogram(e64, bins=np.array(dfepe.ops.METRIC_THS))
     np.testing.assert_allclose(s["ratio_q"], np.cumsum(hist) / 4.0)
+
+
+def _decisive(counts):
+    c = np.sort(np.asarray(counts))[::-1]
+    return c[0] > 0 and c[0] > c[1]
+
+
+def test_val_rt_matches_the_references_own_code(dfepe, golden):
+    """compat.train_good_utils.val_rt / val_rt_batch / validation_summary and compat.utils_F.goodCorr_eval_nondecompose against
+    tests/golden/valrt.npz = the reference's own val_rt (train_good_utils.py:553-646) and goodCorr_eval_nondecompose
+    (utils_F.py:909-954) run with a stand-in for cv2.recoverPose: score mask, < 5 points fall-back, invert_Rt, angles,
+    epi_distance_np.  Pairs whose in-front counts tie at the top are decided by the SVD sign gauge and are skipped for the pose."""
+    g = golden("valrt")
+    tgu, uF = dfepe.compat.train_good_utils, dfepe.compat.utils_F
+    B = g["valrt_K"].shape[0]
+    dec = [b for b in range(B) if _decisive(g["valrt_counts_est"][b])]
+    assert len(dec) >= 8
+    for b in range(B):
+        m = g["valrt_matches"][b]
+        r = tgu.val_rt(b, g["valrt_K"][b], m[:, :2], m[:, 2:], g["valrt_E_est"][b], g["valrt_E_gt"][b], g["valrt_F_est"][b], g["valrt_F_gt"][b],
+                       g["valrt_delta"][b], five_point=False, if_opencv=False)
+        assert r[6] == b and r[2] is None and r[3] is None and r[8] is None
+        # float32 evaluation of |y^T F x| with pixel coordinates (the reference's is float32 too): relative to the distance scale
+        np.testing.assert_allclose(r[1], g["valrt_epi_est"][b], rtol=2e-3, atol=2e-3 * np.abs(g["valrt_epi_est"][b]).max())
+        np.testing.assert_allclose(r[5], g["valrt_epi_gt"][b], rtol=2e-3, atol=2e-3 * max(np.abs(g["valrt_epi_gt"][b]).max(), 1.0))
+        if b in dec:
+            np.testing.assert_allclose(r[0], g["valrt_err_est"][b], atol=0.05, rtol=1e-3)
+            np.testing.assert_allclose(r[7], g["valrt_M_est"][b], atol=2e-4)
+        if _decisive(g["valrt_counts_gt"][b]):
+            np.testing.assert_allclose(r[4], g["valrt_err_gt"][b], atol=0.05, rtol=1e-3)
+    # the batched forms on the same pairs
+    t = lambda k: torch.from_numpy(g[k]).to(DEV)
+    pairs = tgu.val_rt_batch(t("valrt_K"), t("valrt_matches"), t("valrt_E_est"), t("valrt_delta"))
+    np.testing.assert_allclose(pairs["err_R_deg"].cpu().numpy()[dec], g["valrt_err_est"][dec, 0], atol=0.05, rtol=1e-3)
+    np.testing.assert_allclose(pairs["err_t_deg"].cpu().numpy()[dec], g["valrt_err_est"][dec, 1], atol=0.05, rtol=1e-3)
+    sm, per = tgu.validation_summary(t("valrt_K"), t("valrt_matches"), t("valrt_E_est"), t("valrt_F_est"), t("valrt_F_gt"), t("valrt_delta"))
+    np.testing.assert_allclose(per["epi_dists"].cpu().numpy(), g["valrt_epi_est"], rtol=2e-3, atol=2e-3 * np.abs(g["valrt_epi_est"]).max())
+    ref_ratio = float((g["valrt_epi_est"] < 1.0).mean())
+    assert abs(sm["ratio_1"] - ref_ratio) <= 2.0 / g["valrt_epi_est"].size
+    # goodCorr_eval_nondecompose with scores: only the top decile (ties kept by `>=`) decides the pose
+    for b in range(g["scores_K"].shape[0]):
+        if not _decisive(g["scores_counts"][b]):
+            continue
+        m = g["scores_matches"][b]
+        dinv = np.linalg.inv(g["scores_delta"][b])[:3]
+        M, err = uF.goodCorr_eval_nondecompose(m[:, :2], m[:, 2:], g["scores_E"][b].astype(np.float64), dinv, g["scores_K"][b], g["scores_scores"][b])
+        np.testing.assert_allclose(err, g["scores_err"][b], atol=0.05, rtol=1e-3)
+        np.testing.assert_allclose(M, g["scores_M"][b], atol=2e-4)
+    bb = int(g["few_pair"])
+    m = g["scores_matches"][bb]
+    dinv = np.linalg.inv(g["scores_delta"][bb])[:3]
+    for j, n in enumerate(g["few_n"]):
+        M, err = uF.goodCorr_eval_nondecompose(m[40:40 + n, :2], m[40:40 + n, 2:], g["scores_E"][bb].astype(np.float64), dinv, g["scores_K"][bb], None)
+        np.testing.assert_allclose(err, g["few_err"][j], atol=0.05, rtol=1e-3)
+        np.testing.assert_allclose(M, g["few_M"][j], atol=2e-4)

@@ -64,7 +64,9 @@ def test_grad_pairs_shards_reproduce_the_global_batch_gradient(dfepe, B, cut, ba
     ratio = (loc["grad_logits"].double().norm() / parts[0].double().norm()).item()
     assert abs(ratio - B / cut) < 1e-4 * B / cut
     # the loss scalars of the global batch from the two packed vectors (what the all-reduce sums)
-    red = dfepe.dist.reduce_losses(packed[0] + packed[1], L, 1.0, 0.1)
+    both = packed[0] + packed[1]
+    both[L + 3] = packed[0][L + 3]  # M travels with the vector but is not summed (dist.reduce_losses keeps it out of the all-reduce)
+    red = dfepe.dist.reduce_losses(both, L, 1.0, 0.1)
     np.testing.assert_allclose(red["loss_F"].item(), whole["loss_F"].item(), rtol=2e-6)
     np.testing.assert_allclose(red["loss_qt"].item(), whole["loss_qt"].item(), rtol=2e-6)
     assert int(red["n_pairs"].item()) == B

@@ -219,3 +219,51 @@ def test_metrics_summary_matches_the_references_write_metrics_summary(oracle, go
         for k, th in enumerate(oracle.METRIC_THS[1:]):
             assert abs(sm["ratio_q"][k] - want[f"val-Error-ratio/ratio_q{th}_{tag}"]) < 1e-12
             assert abs(sm["ratio_t"][k] - want[f"val-Error-ratio/ratio_t{th}_{tag}"]) < 1e-12
+
+
+def _decisive(counts):
+    """The in-front counts name one winner: the largest is positive and unique (a tie is decided by the SVD sign gauge)."""
+    c = np.sort(np.asarray(counts))[::-1]
+    return c[0] > 0 and c[0] > c[1]
+
+
+def test_val_rt_and_goodcorr_eval_match_the_references_own_code(oracle, golden):
+    """tests/golden/valrt.npz = the reference's own val_rt (train_good_utils.py:553-646) and goodCorr_eval_nondecompose
+    (utils_F.py:909-954) run with a stand-in for cv2.recoverPose ("stubbed-cv2"): the score mask, the < 5 points fall-back,
+    invert_Rt + angles, the epi_distance_np statistics.  The oracle restates all of it, including recoverPose's published
+    algorithm."""
+    g = golden("valrt")
+    for b in range(g["valrt_K"].shape[0]):
+        m = g["valrt_matches"][b]
+        r = oracle.val_rt(g["valrt_K"][b], m[:, :2], m[:, 2:], g["valrt_E_est"][b], g["valrt_E_gt"][b], g["valrt_F_est"][b], g["valrt_F_gt"][b],
+                          g["valrt_delta"][b])
+        # the reference evaluates epi_distance_np in float32 (its inputs are float32 arrays): |y^T F x| carries eps32 * sum of
+        # the magnitudes of its terms, with pixel coordinates ~1e3 that is the whole difference to this float64 evaluation
+        for Fk, key in (("valrt_F_est", "epi_est"), ("valrt_F_gt", "epi_gt")):
+            Fm = g[Fk][b].astype(np.float64)
+            Xh, Yh = np.hstack((m[:, :2], np.ones((len(m), 1)))), np.hstack((m[:, 2:], np.ones((len(m), 1))))
+            Fx1, Fx2 = Fm @ Xh.T, Fm.T @ Yh.T
+            rs = 1.0 / np.sqrt(Fx1[0] ** 2 + Fx1[1] ** 2) + 1.0 / np.sqrt(Fx2[0] ** 2 + Fx2[1] ** 2)
+            bound = 8 * np.finfo(np.float32).eps * np.einsum("ni,ij,nj->n", np.abs(Yh), np.abs(Fm), np.abs(Xh)) * rs
+            assert (np.abs(r[key] - g["valrt_" + key][b]) <= bound + 1e-5 * np.abs(r[key])).all(), key
+        # angles: the reference's vector_angle squares the float32 ground-truth translation in float32 (utils_geo.py:169-179), so
+        # its cosine carries eps32 and an angle near zero sqrt(2 eps32) = 0.02 degrees; away from zero the effect is < 1e-3 degrees
+        if _decisive(g["valrt_counts_est"][b]):
+            np.testing.assert_allclose(r["err_est"], g["valrt_err_est"][b], atol=0.03)
+            np.testing.assert_allclose(r["M_est"], g["valrt_M_est"][b], atol=1e-9)
+        if _decisive(g["valrt_counts_gt"][b]):
+            np.testing.assert_allclose(r["err_gt"], g["valrt_err_gt"][b], atol=0.03)
+    for b in range(g["scores_K"].shape[0]):
+        m = g["scores_matches"][b]
+        dinv = np.linalg.inv(g["scores_delta"][b])[:3]
+        M, err = oracle.good_corr_eval_nondecompose(m[:, :2], m[:, 2:], g["scores_E"][b].astype(np.float64), dinv, g["scores_K"][b], g["scores_scores"][b])
+        if _decisive(g["scores_counts"][b]):
+            np.testing.assert_allclose(err, g["scores_err"][b], atol=0.03)
+            np.testing.assert_allclose(M, g["scores_M"][b], atol=1e-9)
+    bb = int(g["few_pair"])
+    m = g["scores_matches"][bb]
+    dinv = np.linalg.inv(g["scores_delta"][bb])[:3]
+    for j, n in enumerate(g["few_n"]):
+        M, err = oracle.good_corr_eval_nondecompose(m[40:40 + n, :2], m[40:40 + n, 2:], g["scores_E"][bb].astype(np.float64), dinv, g["scores_K"][bb], None)
+        np.testing.assert_allclose(err, g["few_err"][j], atol=0.03)
+        np.testing.assert_allclose(M, g["few_M"][j], atol=1e-9)
