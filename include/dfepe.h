@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFEPE_VERSION 121 /* 0.2.0 */
+#define DFEPE_VERSION 130 /* 0.3.0 */
 
 #define DFEPE_OK 0
 #define DFEPE_ERR_INVALID_ARG (-1) /* null pointer, non-positive size, bad flag combination   */
@@ -125,6 +125,17 @@ int dfepe_w8pt_bwd(const float *pts1, const float *pts2, const float *weights, i
                    const float *g_F, const float *g_residual, const float *g_epi, const float *g_weights_extra,
                    const float *g_scale, float *g_weights, float *g_pts1, float *g_pts2, const void *pending_loss_head,
                    void *stream);
+
+/*
+ * Closing steps of the 8-point solvers for an EXPLICIT design matrix (dense-W form of the textbook solvers).
+ * Replaces: the part of utils_F._E_from_XY / _F_from_XY after `XX = torch.mm(W, XX)` (deepFEPE/dsac_tools/utils_F.py:129-155,
+ *           245-275) when W [N,N] is not diagonal: V[:, -1] of torch.svd(XX), the 3x3 step (S3 -> 0, or (1,1,0) with
+ *           DFEPE_W8PT_FORCE_110), T2^T F T1.  A diagonal W is a per-correspondence weight: dfepe_w8pt_fwd serves it from the points.
+ *   rows [B,N,9] design rows as the SVD sees them (already multiplied by W); T1, T2 [B,9] or both NULL (no de-normalisation);
+ *   F_out [B,9].  flags: 0 or DFEPE_W8PT_FORCE_110.  Sign gauge as dfepe_w8pt_fwd.  Forward only.
+ */
+int dfepe_w8pt_rows_fwd(const float *rows, int B, int N, unsigned flags, const float *T1, const float *T2, float *F_out,
+                        void *stream);
 
 /*
  * F-loss and E-from-F over all layers.

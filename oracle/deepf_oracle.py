@@ -77,13 +77,14 @@ def hartley(pts: Tensor) -> Tuple[Tensor, Tensor]:
 # --------------------------------------------------------------------------------------
 # a4/a5: the weighted normalised 8-point fit  (models/DeepFNet.py:181-257, 278-295)
 # --------------------------------------------------------------------------------------
-def fit_rows(pts1: Tensor, pts2: Tensor, weights: Tensor):
-    """Rows of the design matrix: p (unit rows, :203-212) and X = p*w (:214; w not sqrt'ed)."""
+def fit_rows(pts1: Tensor, pts2: Tensor, weights: Tensor, normalize_svd: bool = True):
+    """Rows of the design matrix: p (unit rows unless Fit(normalize_SVD=False), :203-212) and X = p*w (:214; w not sqrt'ed)."""
     w = weights.reshape(weights.shape[0], -1, 1)  # [B,N,1]  (:192)
     a, T1 = hartley(pts1)
     b, T2 = hartley(pts2)
     p = torch.cat((b[:, :, 0:1] * a, b[:, :, 1:2] * a, a), 2)  # [x2*x1,x2*y1,x2, y2*x1,y2*y1,y2, x1,y1,1]
-    p = p / p.norm(dim=2, keepdim=True).clamp_min(1e-12)  # F.normalize(dim=2) (:212)
+    if normalize_svd:
+        p = p / p.norm(dim=2, keepdim=True).clamp_min(1e-12)  # F.normalize(dim=2) (:211-212)
     return p, p * w, T1, T2
 
 
@@ -107,13 +108,13 @@ def _rank2(Fm: Tensor, mode: str) -> Tensor:
     return U @ torch.diag_embed(S) @ Vh
 
 
-def fit_forward(pts1: Tensor, pts2: Tensor, weights: Tensor, mode: str = "batched"):
+def fit_forward(pts1: Tensor, pts2: Tensor, weights: Tensor, mode: str = "batched", normalize_svd: bool = True):
     """Fit.forward: pts [B,N,3], weights [B,1,N] -> (out [B,3,3], residual [B,N], aux).
 
     out = T2^T F' T1 (:256), residual = X f/|f| (:251).  The sign of f is whatever the SVD
     returns (the reference has no convention); callers compare up to a per-pair sign.
     """
-    p, X, T1, T2 = fit_rows(pts1, pts2, weights)
+    p, X, T1, T2 = fit_rows(pts1, pts2, weights, normalize_svd)
     f = _smallest_right_singular_vector(X, mode)  # [B,9]
     fhat = f / f.norm(dim=1, keepdim=True)
     Fp = _rank2(f.reshape(-1, 3, 3), mode)

@@ -33,6 +33,7 @@ _SIGNATURES = {
     "dfepe_selftest_rowgroup": (c_int, [_P, _P, _P, _P]),
     "dfepe_w8pt_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_uint, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     "dfepe_w8pt_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_uint, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dfepe_w8pt_rows_fwd": (c_int, [_P, c_int, c_int, c_uint, _P, _P, _P, _P]),
     "dfepe_floss_fwd": (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, c_float, _P, _P, _P]),
     "dfepe_floss_bwd": (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, c_float, _P, c_float, _P, _P, _P, _P]),
     "dfepe_pose_fwd": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

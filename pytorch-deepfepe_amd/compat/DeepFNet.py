@@ -44,8 +44,7 @@ class Fit(nn.Module):
 
     def __init__(self, is_cuda=True, is_test=False, if_cpu_svd=False, normalize_SVD=True):
         super().__init__()
-        if not normalize_SVD:
-            raise NotImplementedError("normalize_SVD=False (un-normalised rows) is not built; every reference config uses True")
+        self.normalize_SVD = normalize_SVD  # False: rows of X are w_i p_i instead of w_i p_i / |p_i| (DeepFNet.py:211-212)
         self.if_cpu_svd = if_cpu_svd
         self.is_cuda = is_cuda
 
@@ -68,7 +67,7 @@ class Fit(nn.Module):
 
     def weighted_svd(self, pts1, pts2, weights, if_print=False):
         _require_gpu(weights, "Fit")
-        out, residual = ops.w8pt(pts1, pts2, weights)
+        out, residual = ops.w8pt(pts1, pts2, weights, normalize_rows=self.normalize_SVD)
         return out, residual
 
     def forward(self, pts1, pts2, weights, if_print=False, matches_good_unique_num=None):

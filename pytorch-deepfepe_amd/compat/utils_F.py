@@ -218,23 +218,35 @@ def epi_distance_np(F, X, Y, if_homo=False):
 
 
 def _diag_weights(W, N):
-    """The reference left-multiplies the design matrix by a dense W [N,N] (utils_F.py:129-130); its callers pass
-    torch.diag(w) (train_good_utils.get_E_ests).  Only diagonal W is built: it is a per-correspondence weight."""
-    if W is None:
-        return None
+    """The reference left-multiplies the design matrix by W [N,N] (utils_F.py:129-130); its callers pass torch.diag(w)
+    (train_good_utils.get_E_ests): a per-correspondence weight, which the fit kernel takes from the points.  Returns the weight
+    vector for a vector or a diagonal matrix, None for a dense matrix (served by _dense_w_solve)."""
     W = _gpu(W)
     if W.dim() == 1:
         return W
     off = W - torch.diag(torch.diagonal(W))
-    if float(off.abs().max()) != 0.0:
-        raise NotImplementedError("dense (non-diagonal) W is not built; pass torch.diag(w) or the weight vector")
-    return torch.diagonal(W)
+    return torch.diagonal(W) if float(off.abs().max()) == 0.0 else None
+
+
+def _dense_w_solve(X, Y, W, essential, normalize):
+    """Dense W [N,N] (utils_F.py:129-130,245-246): rows of W @ XX are mixtures of correspondences, so the design matrix is formed
+    explicitly (elementwise plumbing + one [N,N]x[N,9] product) and handed to the explicit-rows closing kernel
+    (dfepe_w8pt_rows_fwd: null vector, 3x3 step, T2^T F T1)."""
+    T1 = T2 = None
+    if normalize:
+        X, Y, T1, T2 = _normalize_XY(X, Y)
+    x1, y1, x2, y2 = X[:, 0], X[:, 1], Y[:, 0], Y[:, 1]
+    XX = torch.stack((x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, torch.ones_like(x1)), dim=1)  # [N,9] (:122-127)
+    rows = torch.mm(_gpu(W), XX).unsqueeze(0).contiguous()
+    return ops.eight_point_rows(rows, None if T1 is None else T1.unsqueeze(0), None if T2 is None else T2.unsqueeze(0), essential)[0]
 
 
 def _F_from_XY(X, Y, W=None, normalize=True, show_debug=False):
     """Normalised 8-point fundamental matrix from X, Y [N,2] (utils_F.py:223-275); sign follows this library's gauge."""
     X, Y = _gpu(X), _gpu(Y)
-    w = _diag_weights(W, X.shape[0])
+    w = None if W is None else _diag_weights(W, X.shape[0])
+    if W is not None and w is None:
+        return _dense_w_solve(X, Y, W, False, normalize)
     return ops.eight_point(X.unsqueeze(0), Y.unsqueeze(0), None if w is None else w.unsqueeze(0), essential=False, normalize=normalize)[0]
 
 
@@ -262,5 +274,7 @@ def _E_from_XY(X, Y, K, W=None, if_normzliedK=False, normalize=True, show_debug=
         ones = torch.ones(X.shape[0], 1, device=X.device)
         Xh, Yh = torch.cat((X, ones), 1) @ Ki.t(), torch.cat((Y, ones), 1) @ Ki.t()
         X, Y = Xh[:, :2] / (Xh[:, 2:3] + 1e-10), Yh[:, :2] / (Yh[:, 2:3] + 1e-10)  # _de_homo (utils_misc.py:69-78)
-    w = _diag_weights(W, X.shape[0])
+    w = None if W is None else _diag_weights(W, X.shape[0])
+    if W is not None and w is None:
+        return _dense_w_solve(X, Y, W, True, normalize)
     return ops.eight_point(X.unsqueeze(0), Y.unsqueeze(0), None if w is None else w.unsqueeze(0), essential=True, normalize=normalize)[0]

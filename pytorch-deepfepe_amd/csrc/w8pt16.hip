@@ -50,9 +50,10 @@ struct W8BwdRest {
   float* g_p1;
   float* g_p2;
   int logits_mode;
+  unsigned variant;
 };
 
-template <int IT, bool RAW, bool PGRAD>
+template <int IT, bool RAW, bool PGRAD, bool PLAIN>
 __global__ void __launch_bounds__(256)
 w8pt16_bwd_kernel(const float* pts1, const float* pts2, const float* wts, int B, int Bm, int N, float hw_sx, float hw_sy,
                   float clamp_at, const float* save, const W8BwdRest R) {
@@ -63,8 +64,8 @@ w8pt16_bwd_kernel(const float* pts1, const float* pts2, const float* wts, int B,
   A.pts1 = pts1; A.pts2 = pts2; A.wts = wts; A.B = B; A.Bm = Bm; A.N = N; A.hw_sx = hw_sx; A.hw_sy = hw_sy;
   A.clamp_at = clamp_at; A.save = save; A.F_out = R.F_out; A.g_F = R.g_F; A.g_res = R.g_res; A.g_epi = R.g_epi;
   A.g_w_extra = R.g_w_extra; A.g_scale = R.g_scale; A.g_w = R.g_w; A.g_p1 = R.g_p1; A.g_p2 = R.g_p2;
-  A.logits_mode = R.logits_mode; A.pending_head = nullptr;
-  w8pt16_bwd_pair_impl<IT, RAW, PGRAD>(A, pair, nullptr);
+  A.logits_mode = R.logits_mode; A.variant = R.variant; A.pending_head = nullptr;
+  w8pt16_bwd_pair_impl<IT, RAW, PGRAD, PLAIN>(A, pair, nullptr);
 }
 
 // The same backward fit with four more wavefronts per workgroup; in workgroup 0 they run the loss head that dfepe_loss_tail
@@ -94,7 +95,7 @@ w8pt16_bwd_head_kernel(const float* pts1, const float* pts2, const float* wts, i
   A.pts1 = pts1; A.pts2 = pts2; A.wts = wts; A.B = B; A.Bm = Bm; A.N = N; A.hw_sx = hw_sx; A.hw_sy = hw_sy;
   A.clamp_at = clamp_at; A.save = save; A.F_out = R.F_out; A.g_F = R.g_F; A.g_res = R.g_res; A.g_epi = R.g_epi;
   A.g_w_extra = R.g_w_extra; A.g_scale = R.g_scale; A.g_w = R.g_w; A.g_p1 = R.g_p1; A.g_p2 = R.g_p2;
-  A.logits_mode = R.logits_mode; A.pending_head = nullptr;
+  A.logits_mode = R.logits_mode; A.variant = 0u; A.pending_head = nullptr;
   w8pt16_bwd_pair_impl<IT, RAW, false>(A, pair, nullptr);
 }
 
@@ -116,15 +117,15 @@ void launch_fwd(const W8Args& A, hipStream_t st) {
 #undef DFEPE_FWD
 }
 
-template <bool RAW, bool PGRAD>
+template <bool RAW, bool PGRAD, bool PLAIN>
 void launch_bwd(const W8BwdArgs& A, hipStream_t st) {
   const dim3 grid((A.B + kPairsPerBlock - 1) / kPairsPerBlock), block(256);
   const int N = A.N;
   W8BwdRest R;
   R.F_out = A.F_out; R.g_F = A.g_F; R.g_res = A.g_res; R.g_epi = A.g_epi; R.g_w_extra = A.g_w_extra; R.g_scale = A.g_scale;
-  R.g_w = A.g_w; R.g_p1 = A.g_p1; R.g_p2 = A.g_p2; R.logits_mode = A.logits_mode;
+  R.g_w = A.g_w; R.g_p1 = A.g_p1; R.g_p2 = A.g_p2; R.logits_mode = A.logits_mode; R.variant = A.variant;
 #define DFEPE_BWD(IT_)                                                                                                     \
-  hipLaunchKernelGGL((w8pt16_bwd_kernel<IT_, RAW, PGRAD>), grid, block, 0, st, A.pts1, A.pts2, A.wts, A.B, A.Bm, A.N, A.hw_sx, \
+  hipLaunchKernelGGL((w8pt16_bwd_kernel<IT_, RAW, PGRAD, PLAIN>), grid, block, 0, st, A.pts1, A.pts2, A.wts, A.B, A.Bm, A.N, A.hw_sx, \
                      A.hw_sy, A.clamp_at, A.save, R)
   if (N > 128) DFEPE_BWD(0);
   else if (N <= 16) DFEPE_BWD(1);
@@ -142,7 +143,7 @@ void launch_bwd_head(const W8BwdArgs& A, hipStream_t st) {
   const int N = A.N;
   W8BwdRest R;
   R.F_out = A.F_out; R.g_F = A.g_F; R.g_res = A.g_res; R.g_epi = A.g_epi; R.g_w_extra = A.g_w_extra; R.g_scale = A.g_scale;
-  R.g_w = A.g_w; R.g_p1 = A.g_p1; R.g_p2 = A.g_p2; R.logits_mode = A.logits_mode;
+  R.g_w = A.g_w; R.g_p1 = A.g_p1; R.g_p2 = A.g_p2; R.logits_mode = A.logits_mode; R.variant = 0u;
   const TailHead* head = static_cast<const TailHead*>(A.pending_head);
 #define DFEPE_BWDH(IT_)                                                                                                   \
   hipLaunchKernelGGL((w8pt16_bwd_head_kernel<IT_, RAW>), grid, block, 0, st, A.pts1, A.pts2, A.wts, A.B, A.Bm, A.N, A.hw_sx, \
@@ -170,12 +171,18 @@ int dfepe_loss_head_from_workspace(const void* workspace_desc, hipStream_t st); 
 
 int dfepe_w8pt16_bwd_launch(const W8BwdArgs& A, bool raw, hipStream_t st) {
   const bool pgrad = A.g_p1 != nullptr;
+  if (A.variant != 0u) {  // un-normalised rows: weight gradients only, no riding loss head
+    if (pgrad) return DFEPE_ERR_UNSUPPORTED;
+    if (raw) launch_bwd<true, false, false>(A, st); else launch_bwd<false, false, false>(A, st);
+    if (hipGetLastError() != hipSuccess) return DFEPE_ERR_HIP;
+    return (A.pending_head != nullptr) ? dfepe_loss_head_from_workspace(A.pending_head, st) : DFEPE_OK;
+  }
   if (A.pending_head != nullptr && !pgrad) {
     if (raw) launch_bwd_head<true>(A, st); else launch_bwd_head<false>(A, st);
     return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
   }
-  if (raw) { if (pgrad) launch_bwd<true, true>(A, st); else launch_bwd<true, false>(A, st); }
-  else { if (pgrad) launch_bwd<false, true>(A, st); else launch_bwd<false, false>(A, st); }
+  if (raw) { if (pgrad) launch_bwd<true, true, true>(A, st); else launch_bwd<true, false, true>(A, st); }
+  else { if (pgrad) launch_bwd<false, true, true>(A, st); else launch_bwd<false, false, true>(A, st); }
   if (hipGetLastError() != hipSuccess) return DFEPE_ERR_HIP;
   return (A.pending_head != nullptr) ? dfepe_loss_head_from_workspace(A.pending_head, st) : DFEPE_OK;
 }

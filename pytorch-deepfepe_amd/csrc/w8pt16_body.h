@@ -712,6 +712,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     } else {
       row_factors(p, s1, c1x, c1y, s2, c2x, c2y, ra, rb, inv);
     }
+    if (!PLAIN) inv = (variant & DFEPE_W8PT_NO_ROWNORM) ? 1.0 : inv;  // X_i = w_i p_i
     const float r = (float)(row_bilinear(ra, rb, f) * inv * (double)wf);
     // l1 = F^T x2 (row form x2 F), l2 = F x1, dd = x2^T F x1 = x1 . l1     (utils_F.py:402-411), fp32 like the reference
     const float l1x = fmaf(p.x2, of[0], fmaf(p.y2, of[3], p.z2 * of[6]));

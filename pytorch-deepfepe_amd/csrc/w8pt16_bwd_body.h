@@ -33,6 +33,7 @@ struct W8BwdArgs {
   float* g_p1;
   float* g_p2;
   int logits_mode;
+  unsigned variant;  // DFEPE_W8PT_NO_ROWNORM (Fit(normalize_SVD=False), DeepFNet.py:211): rows enter X un-normalised; 0 otherwise
   const void* pending_head;  // host side only: a deferred loss head to run beside this launch (dfepe_w8pt_bwd), or nullptr
 };
 
@@ -90,8 +91,12 @@ __device__ __forceinline__ void tri_pinv_apply(const double* td, const double* t
   for (int k = 0; k < 9; ++k) y[k] = fma(-zy, z[k], y[k]);
 }
 
-template <int IT, bool RAW, bool PGRAD>
+// PLAIN: no variant flag is set (the hot instantiations carry no test for them); otherwise A.variant may hold NO_ROWNORM
+// (p^ = p: the row factor `inv` is 1 and constant), without point gradients.
+template <int IT, bool RAW, bool PGRAD, bool PLAIN = true>
 __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const int pair, double* /*xch*/) {
+  static_assert(PLAIN || !PGRAD, "the un-normalised-rows variant has no point gradients");
+  const bool norow = PLAIN ? false : (A.variant & DFEPE_W8PT_NO_ROWNORM) != 0;
   const int l = rg_lane();
   const int N = A.N;
   const size_t mp = (size_t)(pair % A.Bm);
@@ -216,6 +221,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
         const double w = (double)wf;
         double ra[3], rb[2], inv;
         row_factors(p, s1, c1x, c1y, s2, c2x, c2y, ra, rb, inv);
+        if (!PLAIN) inv = norow ? 1.0 : inv;
         const double gw = keep ? (double)up_res(it, i) * w * inv : 0.0;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -380,6 +386,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
     const bool valid = rec.valid, keep = rec.keep;
     double ra[3], rb[2], inv;
     row_factors(p, s1, c1x, c1y, s2, c2x, c2y, ra, rb, inv);
+    if (!PLAIN) inv = norow ? 1.0 : inv;
     const double w = (double)wf;
     const double a = row_bilinear(ra, rb, f) * inv, b = row_bilinear(ra, rb, u) * inv;  // p^ . f, p^ . u
     const double gr = valid ? gsc * (double)up_res(it, i) : 0.0;

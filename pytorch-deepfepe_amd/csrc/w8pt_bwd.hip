@@ -405,7 +405,9 @@ extern "C" int dfepe_w8pt_bwd(const float* pts1, const float* pts2, const float*
   const bool raw = (flags & DFEPE_W8PT_RAW_MATCHES) != 0;
   const int logits_mode = (flags & DFEPE_W8PT_LOGITS) ? 1 : 0;
   if (B < 0 || N <= 0 || n_weight_sets < 1) return DFEPE_ERR_INVALID_ARG;
-  if (flags & (DFEPE_W8PT_SQRT2 | DFEPE_W8PT_NO_ROWNORM | DFEPE_W8PT_FORCE_110 | DFEPE_W8PT_NO_HARTLEY)) return DFEPE_ERR_UNSUPPORTED;
+  if (flags & (DFEPE_W8PT_SQRT2 | DFEPE_W8PT_FORCE_110 | DFEPE_W8PT_NO_HARTLEY)) return DFEPE_ERR_UNSUPPORTED;
+  const unsigned variant = flags & DFEPE_W8PT_NO_ROWNORM;  // the one variant with an adjoint (row kernels, weight gradients)
+  if (variant && (g_pts1 != nullptr || !dfepe_w8pt_use_rows(N, (long long)B * n_weight_sets, flags))) return DFEPE_ERR_UNSUPPORTED;
   if (B == 0) return DFEPE_OK;
   if (!pts1 || (!raw && !pts2) || !weights || !save || !g_weights) return DFEPE_ERR_INVALID_ARG;
   if (g_epi && !F_out) return DFEPE_ERR_INVALID_ARG;
@@ -425,7 +427,7 @@ extern "C" int dfepe_w8pt_bwd(const float* pts1, const float* pts2, const float*
     A.Bm = Bm; A.B = B; A.N = N;
     A.hw_sx = raw ? 2.0f / image_w : 0.f; A.hw_sy = raw ? 2.0f / image_h : 0.f; A.clamp_at = clamp_at;
     A.save = save; A.F_out = F_out; A.g_F = g_F; A.g_res = g_residual; A.g_epi = g_epi; A.g_w_extra = g_weights_extra; A.g_scale = g_scale;
-    A.g_w = g_weights; A.g_p1 = g_pts1; A.g_p2 = g_pts2; A.logits_mode = logits_mode; A.pending_head = pending_loss_head;
+    A.g_w = g_weights; A.g_p1 = g_pts1; A.g_p2 = g_pts2; A.logits_mode = logits_mode; A.variant = variant; A.pending_head = pending_loss_head;
     return dfepe_w8pt16_bwd_launch(A, raw, static_cast<hipStream_t>(stream));
   }
   const int waves = 4;

@@ -755,7 +755,9 @@ extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float*
   const int logits_mode = (flags & DFEPE_W8PT_LOGITS) ? 1 : 0;
   const unsigned variant = flags & (DFEPE_W8PT_SQRT2 | DFEPE_W8PT_NO_ROWNORM | DFEPE_W8PT_FORCE_110 | DFEPE_W8PT_NO_HARTLEY);
   if (B < 0 || N <= 0 || n_weight_sets < 1) return DFEPE_ERR_INVALID_ARG;
-  if (variant && save) return DFEPE_ERR_UNSUPPORTED;  // the textbook variants are forward-only
+  // the textbook variants are forward-only; un-normalised rows alone (Fit(normalize_SVD=False)) have a backward in the row kernels
+  if (variant && save && !(variant == DFEPE_W8PT_NO_ROWNORM && dfepe_w8pt_use_rows(N, (long long)B * n_weight_sets, flags)))
+    return DFEPE_ERR_UNSUPPORTED;
   if (B == 0) return DFEPE_OK;
   if (!pts1 || (!raw && !pts2) || !weights || !F_out || !residual) return DFEPE_ERR_INVALID_ARG;
   if (raw && !(image_w > 0.f && image_h > 0.f)) return DFEPE_ERR_INVALID_ARG;

@@ -42,14 +42,14 @@ def save_floats() -> int:
 # ------------------------------------------------------------------------------------------------
 # weighted 8-point fit
 # ------------------------------------------------------------------------------------------------
-def _flags(raw: bool, logits: bool, wave_per_pair: bool = False) -> int:
+def _flags(raw: bool, logits: bool, wave_per_pair: bool = False, extra: int = 0) -> int:
     return ((_lib.W8PT_RAW_MATCHES if raw else 0) | (_lib.W8PT_LOGITS if logits else 0) |
-            (_lib.W8PT_WAVE_PER_PAIR if wave_per_pair else 0))
+            (_lib.W8PT_WAVE_PER_PAIR if wave_per_pair else 0) | int(extra))
 
 
 def w8pt_forward(pts1: Tensor, pts2: Optional[Tensor], weights: Tensor, raw: bool, image_w: float, image_h: float,
                  clamp_at: float, want_epi: bool, want_save: bool, logits: bool = False, F_out: Optional[Tensor] = None,
-                 wave_per_pair: bool = False):
+                 wave_per_pair: bool = False, extra_flags: int = 0):
     """Raw (non-differentiable) launch.  weights (or logits when ``logits``) [B,N].
     Returns F [B,3,3], residual [B,N], epi [B,N]|None, save|None, weights_out [B,N]|None.  ``F_out`` lets the caller
     provide the destination (e.g. one [B,3,3] slice of a per-layer stack).  ``wave_per_pair`` forces the one-wavefront-per-pair
@@ -63,7 +63,7 @@ def w8pt_forward(pts1: Tensor, pts2: Optional[Tensor], weights: Tensor, raw: boo
     save = torch.empty(B, L.dfepe_save_floats(), device=dev, dtype=torch.float32) if want_save else None
     w_out = torch.empty(B, N, device=dev, dtype=torch.float32) if logits else None
     with torch.cuda.device(dev):
-        rc = L.dfepe_w8pt_fwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, 1, _flags(raw, logits, wave_per_pair), float(image_w),
+        rc = L.dfepe_w8pt_fwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, 1, _flags(raw, logits, wave_per_pair, extra_flags), float(image_w),
                               float(image_h), float(clamp_at), _ptr(F), _ptr(residual), _ptr(epi), _ptr(save), _ptr(w_out), _stream())
     _lib.check(rc, "dfepe_w8pt_fwd")
     return F, residual, epi, save, w_out
@@ -71,7 +71,7 @@ def w8pt_forward(pts1: Tensor, pts2: Optional[Tensor], weights: Tensor, raw: boo
 
 def w8pt_backward(pts1, pts2, weights, raw, image_w, image_h, clamp_at, save, F, gF, gRes, gEpi, logits=False, gW_extra=None,
                   out: Optional[Tensor] = None, want_pts: bool = False, wave_per_pair: bool = False, g_scale: Optional[Tensor] = None,
-                  pending_loss_head: Optional[Tensor] = None):
+                  pending_loss_head: Optional[Tensor] = None, extra_flags: int = 0):
     """Raw launch of the adjoint; returns d/d(weights) (or d/d(logits) when ``logits``; then ``weights`` must be the
     forward's weights_out) and, when ``want_pts``, the gradients w.r.t. the points ([B,N,3] x 2, or [B,N,4] for raw matches)."""
     L = _lib.lib()
@@ -82,7 +82,7 @@ def w8pt_backward(pts1, pts2, weights, raw, image_w, image_h, clamp_at, save, F,
         gP1 = torch.empty_like(pts1)
         gP2 = None if raw else torch.empty_like(pts2)
     with torch.cuda.device(weights.device):
-        rc = L.dfepe_w8pt_bwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, 1, _flags(raw, logits, wave_per_pair), float(image_w), float(image_h),
+        rc = L.dfepe_w8pt_bwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, 1, _flags(raw, logits, wave_per_pair, extra_flags), float(image_w), float(image_h),
                               float(clamp_at), _ptr(save), _ptr(F), _ptr(gF), _ptr(gRes), _ptr(gEpi), _ptr(gW_extra), _ptr(g_scale), _ptr(gW),
                               _ptr(gP1), _ptr(gP2), _ptr(pending_loss_head), _stream())
     _lib.check(rc, "dfepe_w8pt_bwd")
@@ -111,16 +111,36 @@ def eight_point(X: Tensor, Y: Tensor, w: Optional[Tensor], essential: bool, norm
     return F
 
 
+def eight_point_rows(rows: Tensor, T1: Optional[Tensor], T2: Optional[Tensor], essential: bool) -> Tensor:
+    """Closing steps of the textbook solvers on an explicit design matrix rows [B,N,9] (the dense-W form,
+    utils_F.py:129-155,245-275): smallest right singular vector, S3 -> 0 or (1,1,0), T2^T F T1 (T1, T2 [B,3,3] or None)."""
+    rows = _prep(rows, "rows")
+    _shape(rows, "rows (design matrix)", None, None, 9)
+    B, N = rows.shape[0], rows.shape[1]
+    if (T1 is None) != (T2 is None):
+        raise ValueError("T1 and T2 come together")
+    if T1 is not None:
+        T1, T2 = _prep(T1, "T1"), _prep(T2, "T2")
+        _shape(T1, "T1", B, 3, 3)
+        _shape(T2, "T2", B, 3, 3)
+    F = torch.empty(B, 3, 3, device=rows.device)
+    with torch.cuda.device(rows.device):
+        rc = _lib.lib().dfepe_w8pt_rows_fwd(_ptr(rows), B, N, _lib.W8PT_FORCE_110 if essential else 0, _ptr(T1), _ptr(T2), _ptr(F), _stream())
+    _lib.check(rc, "dfepe_w8pt_rows_fwd")
+    return F
+
+
 def _cf(t: Optional[Tensor]) -> Optional[Tensor]:
     return None if t is None else t.contiguous().float()
 
 
 class _W8ptFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pts1, pts2, weights, raw, image_w, image_h, clamp_at, want_epi, logits):
+    def forward(ctx, pts1, pts2, weights, raw, image_w, image_h, clamp_at, want_epi, logits, extra_flags=0):
         ctx.set_materialize_grads(False)  # unused outputs (e.g. the last layer's epi) must not cost a zero-fill
         F, residual, epi, save, w_out = w8pt_forward(pts1, pts2, weights, raw, image_w, image_h, clamp_at, want_epi,
-                                                     want_save=True, logits=logits)
+                                                     want_save=True, logits=logits, extra_flags=extra_flags)
+        ctx.extra_flags = extra_flags
         ctx.save_for_backward(pts1, pts2 if pts2 is not None else pts1.new_empty(0), w_out if logits else weights, save, F)
         ctx.cfg = (raw, image_w, image_h, clamp_at, want_epi, logits)
         outs = [F, residual]
@@ -138,25 +158,29 @@ class _W8ptFunction(torch.autograd.Function):
         gEpi = rest.pop(0) if want_epi else None
         gWout = rest.pop(0) if logits else None
         if gF is None and gRes is None and gEpi is None and gWout is None:
-            return (None,) * 9
+            return (None,) * 10
         want_pts = ctx.needs_input_grad[0] or (not raw and ctx.needs_input_grad[1])
         res = w8pt_backward(pts1, pts2 if pts2.numel() else None, weights, raw, image_w, image_h, clamp_at, save, F,
-                            _cf(gF), _cf(gRes), _cf(gEpi), logits=logits, gW_extra=_cf(gWout), want_pts=want_pts)
+                            _cf(gF), _cf(gRes), _cf(gEpi), logits=logits, gW_extra=_cf(gWout), want_pts=want_pts,
+                            extra_flags=ctx.extra_flags)
         if want_pts:
             gW, gP1, gP2 = res
-            return gP1, gP2, gW, None, None, None, None, None, None
-        return None, None, res, None, None, None, None, None, None
+            return gP1, gP2, gW, None, None, None, None, None, None, None
+        return None, None, res, None, None, None, None, None, None, None
 
 
-def w8pt(pts1: Tensor, pts2: Tensor, weights: Tensor, clamp_at: float = 0.5, want_epi: bool = False):
+def w8pt(pts1: Tensor, pts2: Tensor, weights: Tensor, clamp_at: float = 0.5, want_epi: bool = False, normalize_rows: bool = True):
     """Differentiable fit on homogeneous points [B,N,3]; weights [B,N] or [B,1,N].  Gradients flow to the weights and,
-    when the point tensors require grad, to both point sets."""
+    when the point tensors require grad, to both point sets.  ``normalize_rows=False`` = Fit(normalize_SVD=False)
+    (DeepFNet.py:211): the design rows enter X un-normalised; gradients then flow to the weights only."""
     pts1, pts2 = _prep(pts1, "pts1"), _prep(pts2, "pts2")
     w = _prep(weights.reshape(weights.shape[0], -1), "weights")
     B, N = w.shape
     _shape(pts1, "pts1 (homogeneous points)", B, N, 3)
     _shape(pts2, "pts2 (homogeneous points)", B, N, 3)
-    return _W8ptFunction.apply(pts1, pts2, w, False, 0.0, 0.0, clamp_at, want_epi, False)
+    if not normalize_rows and torch.is_grad_enabled() and (pts1.requires_grad or pts2.requires_grad):
+        raise _lib.DfepeError("w8pt(normalize_rows=False): gradients w.r.t. the points are not built for un-normalised rows")
+    return _W8ptFunction.apply(pts1, pts2, w, False, 0.0, 0.0, clamp_at, want_epi, False, 0 if normalize_rows else _lib.W8PT_NO_ROWNORM)
 
 
 def w8pt_raw(matches: Tensor, weights: Tensor, image_w: float, image_h: float, clamp_at: float = 0.5,

@@ -277,8 +277,6 @@ def test_dsac_tools_functions_match_reference_golden(dfepe, oracle, golden):
                       (uF._E_from_XY(x1[0], x2[0], K, W=torch.diag(T(g["W_diag"]).to(DEV))), "E_from_XY_W")):
         a, r, _ = unit_align(ours.cpu().numpy()[None], g[key][None])
         assert np.abs(a - r).max() < 5e-4, (key, np.abs(a - r).max())
-    with pytest.raises(NotImplementedError):
-        uF._F_from_XY(x1[0], x2[0], W=torch.ones(64, 64, device=DEV))
     # normalize=False (no Hartley step) against the fp64 oracle on K^-1-normalised points, where it is well conditioned
     x1n = (torch.cat((x1[0], torch.ones(x1.shape[1], 1, device=DEV)), 1) @ torch.linalg.inv(K).t())[:, :2].contiguous()
     x2n = (torch.cat((x2[0], torch.ones(x2.shape[1], 1, device=DEV)), 1) @ torch.linalg.inv(K).t())[:, :2].contiguous()
@@ -612,3 +610,41 @@ def test_val_rt_matches_the_references_own_code(dfepe, golden):
         M, err = uF.goodCorr_eval_nondecompose(m[40:40 + n, :2], m[40:40 + n, 2:], g["scores_E"][bb].astype(np.float64), dinv, g["scores_K"][bb], None)
         np.testing.assert_allclose(err, g["few_err"][j], atol=0.05, rtol=1e-3)
         np.testing.assert_allclose(M, g["few_M"][j], atol=2e-4)
+
+
+def test_dense_W_and_unnormalised_rows_match_the_reference(dfepe, oracle, golden):
+    """The last corners of the mirrored surface against the reference's own outputs (tests/golden/surface.npz):
+    _E_from_XY / _F_from_XY with a dense W [N,N] (utils_F.py:129-130,245-246; the explicit-rows kernel) and
+    Fit(normalize_SVD=False) (DeepFNet.py:211-214) forward + d/d(weights)."""
+    g = golden("surface")
+    uF = dfepe.compat.utils_F
+    for b in range(g["densew_W"].shape[0]):
+        m = T(g["densew_matches"][b]).float().to(DEV)
+        K, W = T(g["densew_K"][b]).float().to(DEV), T(g["densew_W"][b]).float().to(DEV)
+        for ours, key in ((uF._E_from_XY(m[:, :2], m[:, 2:], K, W=W), "densew_E"), (uF._F_from_XY(m[:, :2], m[:, 2:], W=W), "densew_F")):
+            a, r, _ = unit_align(ours.cpu().numpy()[None], g[key][b][None])
+            assert np.abs(a - r).max() < 5e-4, (key, b, np.abs(a - r).max())  # fp32 inputs and _normalize_XY vs the fp64 reference run
+    # Fit(normalize_SVD=False): module forward and autograd to the weights
+    H, W_ = IMAGE_SIZE[0], IMAGE_SIZE[1]
+    m = T(g["nosvdnorm_matches"]).float().to(DEV)
+    norm = dfepe.compat.DeepFNet.NormalizeAndExpand_HW(IMAGE_SIZE)
+    p1, p2, _, _ = norm(m)
+    pts1, pts2 = p1.permute(0, 2, 1).contiguous(), p2.permute(0, 2, 1).contiguous()
+    w = T(g["nosvdnorm_weights"]).float().to(DEV).requires_grad_(True)
+    fit = dfepe.compat.DeepFNet.Fit(normalize_SVD=False)
+    out, res = fit(pts1, pts2, w)
+    GF, GR = T(g["nosvdnorm_GF"]).float().to(DEV), T(g["nosvdnorm_GR"]).float().to(DEV)
+    s = torch.sign((out.detach() * GF).flatten(1).sum(1))
+    ((s[:, None, None] * out * GF).sum() + (s[:, None] * res * GR).sum()).backward()
+    a, r, sg = unit_align(out.detach().cpu().numpy(), g["nosvdnorm_out_f64"])
+    assert np.abs(a - r).max() < 2e-5
+    # residual = X f / |f| with un-normalised rows: sign per pair from the F alignment, scale is absolute
+    r64 = g["nosvdnorm_residual_f64"]
+    sgn = np.sign((out.detach().cpu().numpy().reshape(-1, 9) * g["nosvdnorm_out_f64"].reshape(-1, 9)).sum(1))[:, None]
+    assert np.abs(res.detach().cpu().numpy() * sgn - r64).max() < 2e-5 * np.abs(r64).max() + 1e-7
+    gw, gw64 = w.grad.cpu().numpy(), g["nosvdnorm_grad_w_f64"]
+    assert np.abs(gw - gw64).max() < 2e-3 * np.abs(gw64).max()
+    # and the rows really are un-normalised: the default module gives a different F
+    out_n, _ = dfepe.compat.DeepFNet.Fit()(pts1, pts2, w.detach())
+    a2, r2, _ = unit_align(out_n.cpu().numpy(), g["nosvdnorm_out_f64"])
+    assert np.abs(a2 - r2).max() > 1e-4

@@ -267,3 +267,29 @@ def test_val_rt_and_goodcorr_eval_match_the_references_own_code(oracle, golden):
         M, err = oracle.good_corr_eval_nondecompose(m[40:40 + n, :2], m[40:40 + n, 2:], g["scores_E"][bb].astype(np.float64), dinv, g["scores_K"][bb], None)
         np.testing.assert_allclose(err, g["few_err"][j], atol=0.03)
         np.testing.assert_allclose(M, g["few_M"][j], atol=1e-9)
+
+
+def test_surface_corners_dense_W_and_unnormalised_rows(oracle, golden):
+    """oracle.E_from_XY / F_from_XY with a dense W and oracle.fit_forward(normalize_svd=False) against the reference's own
+    outputs (tests/golden/surface.npz, make_golden_surface.py)."""
+    g = golden("surface")
+    for b in range(g["densew_W"].shape[0]):
+        m, K, W = torch.from_numpy(g["densew_matches"][b]), torch.from_numpy(g["densew_K"][b]), torch.from_numpy(g["densew_W"][b])
+        for ours, key in ((oracle.E_from_XY(m[:, :2], m[:, 2:], K, W=W), "densew_E"), (oracle.F_from_XY(m[:, :2], m[:, 2:], W=W), "densew_F"),
+                          (oracle.F_from_XY(m[:, :2], m[:, 2:], W=W, normalize=False), "densew_F_nonorm")):
+            ref = torch.from_numpy(g[key][b])
+            a = oracle.unit_frobenius(oracle.align_sign(ours, ref))
+            assert (a - oracle.unit_frobenius(ref)).abs().max() < (1e-9 if key != "densew_F_nonorm" else 1e-6), key
+    m = torch.from_numpy(g["nosvdnorm_matches"])
+    p1, p2, _ = oracle.normalize_hw(m, IMAGE_SIZE)
+    w = torch.from_numpy(g["nosvdnorm_weights"]).clone().requires_grad_(True)
+    out, res, _ = oracle.fit_forward(p1, p2, w, normalize_svd=False)
+    GF, GR = torch.from_numpy(g["nosvdnorm_GF"]), torch.from_numpy(g["nosvdnorm_GR"])
+    s = torch.sign((out.detach() * GF).flatten(1).sum(1))
+    ((s[:, None, None] * out * GF).sum() + (s[:, None] * res * GR).sum()).backward()
+    ref = torch.from_numpy(g["nosvdnorm_out_f64"])
+    sg = torch.sign((out.detach() * ref).flatten(1).sum(1))
+    assert (out.detach() * sg[:, None, None] - ref).abs().max() < 1e-9 * ref.abs().max()
+    assert (res.detach() * sg[:, None] - torch.from_numpy(g["nosvdnorm_residual_f64"])).abs().max() < 1e-9
+    gref = torch.from_numpy(g["nosvdnorm_grad_w_f64"])
+    assert (w.grad - gref).abs().max() < 1e-6 * gref.abs().max()
