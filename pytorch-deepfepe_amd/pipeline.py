@@ -73,12 +73,9 @@ class _HotPathFunction(torch.autograd.Function):
         L, B, N = logits_layers.shape
         dev = matches.device
         M = virt1.shape[1]
-        forced = []  # why the one-launch tail cannot serve this call (dfepe_loss_tail: M <= 128 virtual points, L <= 16 layers)
-        if M > 128:
-            forced.append(f"M = {M} > 128 virtual points")
-        if L > _lib.TAIL_MAX_LAYERS:
-            forced.append(f"depth {L} > {_lib.TAIL_MAX_LAYERS}")
-        fused_tail = fused_tail and not forced
+        if L > _lib.TAIL_MAX_LAYERS:  # before any launch: every loss kernel (fused tail, dfepe_floss_*, dfepe_loss_head) stacks <= 16 layers
+            raise _lib.DfepeError(f"depth {L} > {_lib.TAIL_MAX_LAYERS} layers per loss launch (the reference's configs use depth 5)")
+        fused_tail = fused_tail and M <= 128  # more virtual points than a row holds: the five-kernel tail serves any M
         F_layers = torch.empty(L, B, 3, 3, device=dev)
         residuals = torch.empty(L, B, N, device=dev)
         epis = torch.empty(L, B, N, device=dev)

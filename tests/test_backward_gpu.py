@@ -393,11 +393,19 @@ def test_unfused_tail_honours_balance_F(dfepe, balance_F):
     assert relerr(a["grad_logits"].cpu().numpy(), b["grad_logits"].cpu().numpy()) < 5e-5
 
 
-def test_depth_beyond_the_fused_tail_falls_back_instead_of_raising(dfepe):
-    """dfepe_loss_tail serves <= 16 layers per launch; a deeper stack takes the five-kernel tail (same numbers as two fused halves)."""
-    B, N, depth = 6, 100, 18
-    sc = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(B, N, seed=37, outlier_ratio=0.2, depth_layers=depth), DEV)
-    o = dfepe.pipeline.hot_path_step(sc, IMAGE_SIZE, depth, 0.02, qt=True)
-    ref = dfepe.pipeline.hot_path_step(sc, IMAGE_SIZE, depth, 0.02, qt=True, fused=False)
-    assert abs(o["loss"].item() - ref["loss"].item()) < 1e-6
-    assert relerr(o["grad_logits"].cpu().numpy(), ref["grad_logits"].cpu().numpy()) < 5e-5
+def test_limits_of_the_loss_launches_are_checked_before_anything_runs(dfepe):
+    """More than 16 layers: refused up front with the limit in the message (every loss kernel stacks <= 16 layers per launch).
+    More than 128 virtual points: the five-kernel tail takes over silently, with any balance_F."""
+    B, N = 6, 100
+    sc = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(B, N, seed=37, outlier_ratio=0.2, depth_layers=18), DEV)
+    with pytest.raises(dfepe.DfepeError, match="depth 18 > 16"):
+        dfepe.pipeline.hot_path_step(sc, IMAGE_SIZE, 18, 0.02, qt=True)
+    sc = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(B, N, seed=38, outlier_ratio=0.2, depth_layers=3), DEV)
+    big = dict(sc)
+    big["pts1_virt_ori"] = torch.cat((sc["pts1_virt_ori"], sc["pts1_virt_ori"][:, :60]), 1).contiguous()  # M = 160
+    big["pts2_virt_ori"] = torch.cat((sc["pts2_virt_ori"], sc["pts2_virt_ori"][:, :60]), 1).contiguous()
+    o = dfepe.pipeline.hot_path_step(big, IMAGE_SIZE, 3, 0.02, qt=True, balance_F=0.3)
+    ref = dfepe.pipeline.hot_path_step(big, IMAGE_SIZE, 3, 0.02, qt=True, fused=False)
+    want = 0.3 * ref["loss_F"].item() + ref["loss_qt"].item()
+    assert abs(o["loss"].item() - want) < 1e-6
+    assert torch.isfinite(o["grad_logits"]).all()
