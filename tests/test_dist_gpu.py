@@ -128,10 +128,12 @@ def test_one_rank_rccl_group_behind_a_graph_replay(dfepe):
         eager = _fused(dfepe, sc, L)
         logits = sc["logits_layers"][:L].clone().requires_grad_(True)
         state = {}
+        H, W = float(IMAGE_SIZE[0]), float(IMAGE_SIZE[1])
+        hw_T = torch.tensor([[2.0 / W, 0.0, -1.0], [0.0, 2.0 / H, -1.0], [0.0, 0.0, 1.0]], device=DEV)  # a host copy: not capturable
 
         def step_body():
             out = dfepe.pipeline.hot_path_fused(sc["matches_xy_ori"], logits, sc["Ks"], sc["pts1_virt_ori"], sc["pts2_virt_ori"], sc["qs_cam"],
-                                                sc["ts_cam"], sc["R_gt"], IMAGE_SIZE, 0.02, True, grad_pairs=B * dist.get_world_size(),
+                                                sc["ts_cam"], sc["R_gt"], IMAGE_SIZE, 0.02, True, hw_T=hw_T, grad_pairs=B * dist.get_world_size(),
                                                 defer_loss_head=True)
             state["g"], = torch.autograd.grad(out["loss"], logits)
             return out
