@@ -9,12 +9,12 @@ so ``import dfepe.compat`` style imports work too.
 """
 import sys as _sys
 
-from . import _lib, ops, synth, pipeline, compat, dist  # noqa: F401
+from . import _lib, ops, synth, pipeline, estimator, compat, dist  # noqa: F401
 from ._lib import DfepeError, LIB_PATH, EXPORTED_SYMBOLS  # noqa: F401
 
 __version__ = "0.1.0"
 
 _sys.modules.setdefault("dfepe", _sys.modules[__name__])
-for _name in ("_lib", "ops", "synth", "pipeline", "dist", "compat", "compat.DeepFNet", "compat.ErrorEstimators", "compat.utils_F",
+for _name in ("_lib", "ops", "synth", "pipeline", "estimator", "dist", "compat", "compat.DeepFNet", "compat.ErrorEstimators", "compat.utils_F",
               "compat.utils_geo", "compat.train_good_utils"):
     _sys.modules.setdefault("dfepe." + _name, _sys.modules[__name__ + "." + _name])

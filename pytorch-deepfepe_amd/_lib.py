@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_uint, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DFEPE_LIB_PATH: another build of the same library (scripts/ab_step.sh times two builds alternately on one box)
@@ -51,6 +51,14 @@ _SIGNATURES = {
     "dfepe_geo_misc": (c_int, [c_int, _P, _P, c_int, _P, _P]),
     "dfepe_inorm_lrelu_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P]),
     "dfepe_inorm_lrelu_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
+    "dfepe_est_points": (c_int, []),
+    "dfepe_est_split": (c_int, [_P, c_long, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "dfepe_est_layer_fwd": (c_int, [_P, c_size_t, _P, c_size_t, c_int, c_int, c_int, _P, _P, c_float, c_float, _P, c_size_t, _P, _P]),
+    "dfepe_est_gemm_nt": (c_int, [_P, c_size_t, _P, c_size_t, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    "dfepe_est_gemm_tn": (c_int, [_P, c_size_t, c_int, _P, c_size_t, c_int, c_int, c_int, _P, _P]),
+    "dfepe_est_in_bwd": (c_int, [_P, _P, _P, _P, c_size_t, _P, _P, _P, c_float, c_int, c_int, _P, c_size_t, _P, _P, _P]),
+    "dfepe_est_head_fwd": (c_int, [_P, c_size_t, c_int, c_int, _P, _P, _P, _P]),
+    "dfepe_est_head_dw": (c_int, [_P, c_size_t, c_int, c_int, c_int, _P, _P, _P]),
     "dfepe_nn_match_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dfepe_nn_match_two_way": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P]),
     "dfepe_gather_matches": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),

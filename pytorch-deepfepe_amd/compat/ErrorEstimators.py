@@ -35,7 +35,12 @@ class ErrorEstimator(nn.Module):
 
 
 class FusedErrorEstimator(ErrorEstimator):
-    """Same parameters / state_dict as ErrorEstimator, MI355X-shaped evaluation ("next" row f-1 of SURVEY.md §8):
+    """Same parameters / state_dict as ErrorEstimator, MI355X-shaped evaluation ("next" row f-1 of SURVEY.md §8).
+
+    Default (``split_bf16 = True``, N = 100 points per pair): the whole stack runs on the bf16 matrix cores with fp32-accurate
+    split operands -- csrc/est_gemm.hip through ``estimator.estimator_forward``: per layer ONE kernel (GEMM + InstanceNorm +
+    LeakyReLU in its epilogue) forward, three backward (normalisation adjoint, weight-gradient GEMM, data-gradient GEMM).
+    ``split_bf16 = False`` (or any other N) keeps the native-fp32 evaluation described next:
     activations live channel-major as [C, B*N], every 1x1 convolution is ONE large GEMM W[C_out,C_in] @ X[C_in, B*N]
     (rocBLAS / hipBLASLt through torch.mm) instead of B small ones, and InstanceNorm + LeakyReLU is one fused HIP pass
     (ops.inorm_lrelu).  The biases of the convolutions that feed an InstanceNorm cancel in the normalisation and are
@@ -43,12 +48,23 @@ class FusedErrorEstimator(ErrorEstimator):
     (so DistributedDataParallel sees every parameter used and the optimizer state matches).  Falls back to the stock path for the batch-norm
     variant and for N not a multiple of 4 or above 512."""
 
+    split_bf16 = True
+
     def forward(self, data):
-        from .. import ops
+        from .. import estimator, ops
 
         B, C0, N = data.shape
         mods = list(self.fw)
-        if any(isinstance(m, nn.BatchNorm1d) for m in mods) or (N % 4) or N > 512 or not data.is_cuda:
+        has_bn = any(isinstance(m, nn.BatchNorm1d) for m in mods)
+        if self.split_bf16 and not has_bn and estimator.supported(data):
+            hidden, i = [], 0
+            while i + 2 < len(mods) and isinstance(mods[i + 1], nn.InstanceNorm1d):
+                hidden.append((mods[i].weight, mods[i].bias, mods[i + 1].weight, mods[i + 1].bias))
+                i += 3
+            head, inorm, act = mods[i], mods[1], mods[2]
+            if i == len(mods) - 1 and act.negative_slope > 0 and all(m.affine for m in mods if isinstance(m, nn.InstanceNorm1d)):
+                return estimator.estimator_forward(data, hidden, (head.weight, head.bias), eps=inorm.eps, slope=act.negative_slope)
+        if has_bn or (N % 4) or N > 512 or not data.is_cuda:
             return super().forward(data)
         x = data.permute(1, 0, 2).reshape(C0, B * N)  # channel-major
         i = 0

@@ -1,0 +1,599 @@
+// est_gemm -- the per-correspondence weight estimator on the matrix cores.
+//
+// Replaces: the Conv1d(k=1) -> InstanceNorm1d(affine) -> LeakyReLU stack of ErrorEstimator
+// (deepFEPE/models/ErrorEstimators.py:47-64), called depth times per step (deepFEPE/models/DeepFNet.py:441,510), forward and
+// backward.  Every 1x1 convolution is a GEMM  Y[C_out, cols] = W[C_out, C_in] X[C_in, cols]  over cols = pairs x N points.
+//
+// Precision: the reference trains this stack in fp32.  bf16 MFMA is 16x the fp32 MFMA rate, so every fp32 operand is
+// carried as a sum of bf16 PLANES  a = a0 + a1 + a2  (a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1): 24 mantissa
+// bits, the split is exact) and a product is the sum of the plane products of order i + j <= 2 (six bf16 MFMAs, fp32
+// accumulate): error ~2^-24 per product, the fp32 class (scripts/proto_split_bf16.py: logits 2.7e-7 from the fp64 truth
+// against 2.9e-6 for stock fp32 and 6.6e-5 for two planes).  The backward products use two planes (i + j <= 1, three MFMAs,
+// ~2^-16): gradients need far less than the activations the next fit is sensitive to.
+//
+// Layout: activations POINT-major  P[plane][col][C]  (C contiguous = the K of the next layer's GEMM and of the data-gradient
+// GEMM), weights W[plane][C_out][C_in].  Kernels:
+//   est_gemm_nt   C[m][n] = sum_terms A_i[m][:] . B_j[n][:]   (both operands K-contiguous), 128 x 208 block tile = 128 channels
+//                 x two whole pairs (N = 100: 2 x 100 columns + 8 of the next block, recomputed there), K step 32, operands staged
+//                 by LDS-DMA (global_load_lds_dwordx4) as [plane][k/8][row][8] so that an MFMA fragment is one conflict-free
+//                 ds_read_b128, single LDS stage, two workgroups per CU overlap each other's load and MFMA phases.
+//                 Epilogues: EPI_F32 (plain fp32 store, the data-gradient GEMM) and EPI_IN (forward: InstanceNorm statistics of
+//                 each (channel, pair) straight from the accumulators -- a pair's 100 columns sit in the 16 lanes of a DPP row
+//                 across 7 column tiles --, affine, LeakyReLU, split into three planes, 8-byte stores; the convolution bias
+//                 cancels in the normalisation).
+//   est_gemm_tn   dW[co][ci] = sum_cols dY[col][co] X[col][ci]: both operands are K-major here, fragments come from
+//                 ds_read_b64_tr_b16 (the LDS transpose read) of an XOR-swizzled [k][128 channels] image, split-K over columns.
+//   est_in_bwd    InstanceNorm + LeakyReLU adjoint in the point-major layout (x^ and the activation sign recovered from the
+//                 stored planes), writes dY as two planes.
+//   est_head_*    the last Conv1d(256 -> 1) and its adjoint pieces (a GEMV: VALU, HBM-bound).
+#include "dfepe_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef unsigned short bf16_t;  // storage type of a plane element
+
+#define DFEPE_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define DFEPE_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+constexpr int kPts = 100;          // points per pair the fused epilogues are built for (N of BASELINE configs 2-4)
+constexpr int BM = 128;            // channels per block tile
+constexpr int NT = 13;             // 16-column tiles per block: 2 pairs = 200 columns + 8
+constexpr int BN = NT * 16;        // 208
+constexpr int BSTEP = 2 * kPts;    // columns a block owns
+constexpr int BK = 32;             // K step = one MFMA 16x16x32
+
+__device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes of a DPP row, in every lane
+  v += dpp_f32<0xB1>(v);
+  v += dpp_f32<0x4E>(v);
+  v += dpp_f32<0x141>(v);
+  v += dpp_f32<0x140>(v);
+  return v;
+}
+
+// fp32 -> three bf16 planes (round-to-nearest-even each, remainders exact in fp32), two values at a time
+__device__ __forceinline__ void split3(float x, float y, unsigned& p0, unsigned& p1, unsigned& p2) {
+  f32x2 v = {x, y};
+  const bf16x2 h = __builtin_convertvector(v, bf16x2);
+  v -= __builtin_convertvector(h, f32x2);
+  const bf16x2 m = __builtin_convertvector(v, bf16x2);
+  v -= __builtin_convertvector(m, f32x2);
+  const bf16x2 l = __builtin_convertvector(v, bf16x2);
+  p0 = __builtin_bit_cast(unsigned, h); p1 = __builtin_bit_cast(unsigned, m); p2 = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ void split2(float x, float y, unsigned& p0, unsigned& p1) {
+  f32x2 v = {x, y};
+  const bf16x2 h = __builtin_convertvector(v, bf16x2);
+  v -= __builtin_convertvector(h, f32x2);
+  const bf16x2 m = __builtin_convertvector(v, bf16x2);
+  p0 = __builtin_bit_cast(unsigned, h); p1 = __builtin_bit_cast(unsigned, m);
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+enum { EPI_F32 = 0, EPI_IN = 1 };
+
+struct EpiArgs {
+  // EPI_F32: out[col][m] fp32, ld = ldc
+  float* out;
+  int ldc;
+  // EPI_IN
+  const float* gamma;
+  const float* beta;
+  float eps, slope;
+  bf16_t* planes;        // [3][ncols][M]
+  size_t plane_stride;   // elements between planes
+  float* rstd;           // [npairs][M]
+};
+
+// C[m][n] = sum over plane pairs (i, j), i + j <= ORDER, of A_i[m][:] . B_j[n][:]
+//   A: [NPA][M][K] (a_plane elements between planes), B: [NPB][ncols][K]; K % 32 == 0, M % 4 == 0.
+// Block (bx, by): columns [200 bx, 200 bx + 208), channels [128 by, 128 by + 128); 4 wavefronts, wavefront w owns channels
+// 32 w .. 32 w + 31 (two 16-row MFMA tiles) x all 13 column tiles: 26 accumulator tiles = 104 registers.
+template <int NPA, int NPB, int ORDER, int EPI>
+__global__ void __launch_bounds__(256, 2)
+est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* __restrict__ B, size_t b_plane, int M, int ncols, int K,
+                   const EpiArgs E) {
+  constexpr int kABytes = NPA * 4 * BM * 16, kBBytes = NPB * 4 * BN * 16;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kABytes + kBBytes];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  // XCD-aware order: consecutive workgroup ids go round-robin to the 8 XCDs; the channel blocks of one column block share its
+  // activation tile, so they are given consecutive slots of ONE XCD (its L2 then serves the re-reads)
+  const int mblocks = (int)gridDim.y, cblocks = (int)gridDim.x;
+  int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+  {
+    const int id = by * cblocks + bx;  // linear dispatch order (x fastest)
+    const int total = mblocks * cblocks;
+    if ((cblocks & 7) == 0) {
+      const int xcd = id & 7, s = id >> 3;
+      by = s % mblocks;
+      bx = (s / mblocks) * 8 + xcd;
+    }
+    (void)total;
+  }
+  const int m0 = by * BM, n0 = bx * BSTEP;
+
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging tasks of this wavefront: 64 consecutive 16-byte chunks of one (operand, plane, k-group) each ----------------
+  constexpr int kATasks = NPA * 4 * (BM / 64), kBTasks = NPB * 4 * ((BN + 63) / 64), kTasks = kATasks + kBTasks;
+  constexpr int kPerWave = (kTasks + 3) / 4;
+  const int nk = K / BK;
+  for (int ks = 0; ks < nk; ++ks) {
+    const int k0 = ks * BK;
+#pragma unroll
+    for (int i = 0; i < kPerWave; ++i) {
+      const int t = wave + 4 * i;  // wave-uniform
+      if (t < kATasks) {
+        const int p = t / (4 * (BM / 64)), kg = (t / (BM / 64)) & 3, rb = t % (BM / 64);
+        int row = m0 + rb * 64 + lane;
+        row = (row < M) ? row : M - 1;
+        const bf16_t* src = A + (size_t)p * a_plane + (size_t)row * K + k0 + kg * 8;
+        unsigned char* dst = lds + ((p * 4 + kg) * BM + rb * 64) * 16;
+        __builtin_amdgcn_global_load_lds(DFEPE_GLOBAL_PTR(src), DFEPE_LDS_PTR(dst), 16, 0, 0);
+      } else if (t < kTasks) {
+        constexpr int RB = (BN + 63) / 64;
+        const int u = t - kATasks;
+        const int p = u / (4 * RB), kg = (u / RB) & 3, rb = u % RB;
+        const int r = rb * 64 + lane;
+        int row = n0 + r;
+        row = (row < ncols) ? row : ncols - 1;
+        const bf16_t* src = B + (size_t)p * b_plane + (size_t)row * K + k0 + kg * 8;
+        unsigned char* dst = lds + kABytes + ((p * 4 + kg) * BN + rb * 64) * 16;
+        if (r < BN) __builtin_amdgcn_global_load_lds(DFEPE_GLOBAL_PTR(src), DFEPE_LDS_PTR(dst), 16, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- MFMA phase -------------------------------------------------------------------------------------------------------
+    bf16x8 a[2][NPA];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int p = 0; p < NPA; ++p)
+        a[mt][p] = *reinterpret_cast<const bf16x8*>(lds + ((p * 4 + g) * BM + wave * 32 + mt * 16 + c) * 16);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      bf16x8 b[NPB];
+#pragma unroll
+      for (int p = 0; p < NPB; ++p) b[p] = *reinterpret_cast<const bf16x8*>(lds + kABytes + ((p * 4 + g) * BN + nt * 16 + c) * 16);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        // smallest terms first
+#pragma unroll
+        for (int ord = ORDER; ord >= 0; --ord)
+#pragma unroll
+          for (int i = 0; i <= ord; ++i) {
+            const int j = ord - i;
+            if (i < NPA && j < NPB) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][i], b[j], acc[mt][nt], 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds, per tile (mt, nt), channels ch0 + r (r = 0..3) of column n0 + 16 nt + c -----------------------
+  if constexpr (EPI == EPI_F32) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int ch0 = m0 + wave * 32 + mt * 16 + 4 * g;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int cl = nt * 16 + c, col = n0 + cl;
+        if (cl < BSTEP && col < ncols && ch0 < M)
+          *reinterpret_cast<f32x4*>(E.out + (size_t)col * E.ldc + ch0) = acc[mt][nt];
+      }
+    }
+  } else {
+    // pair 0 = columns 0..99 (tiles 0..5 and lanes 0..3 of tile 6), pair 1 = 100..199 (lanes 4..15 of tile 6, tiles 7..11,
+    // lanes 0..7 of tile 12); lanes 8..15 of tile 12 belong to the next block
+    const float inv_n = 1.0f / (float)kPts;
+    const bool t6p0 = c < 4, t12ok = c < 8;
+    const int pair0 = 2 * bx;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int ch0 = m0 + wave * 32 + mt * 16 + 4 * g;
+      const bool chok = ch0 < M;
+      const int chc = chok ? ch0 : 0;
+      const f32x4 gam = *reinterpret_cast<const f32x4*>(E.gamma + chc), bet = *reinterpret_cast<const f32x4*>(E.beta + chc);
+      f32x4 mean0, mean1, rs0, rs1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) s0 += acc[mt][nt][r];
+        s0 += t6p0 ? acc[mt][6][r] : 0.f;
+        s1 += t6p0 ? 0.f : acc[mt][6][r];
+#pragma unroll
+        for (int nt = 7; nt < 12; ++nt) s1 += acc[mt][nt][r];
+        s1 += t12ok ? acc[mt][12][r] : 0.f;
+        const float mu0 = row16_sum(s0) * inv_n, mu1 = row16_sum(s1) * inv_n;
+        float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) { const float d = acc[mt][nt][r] - mu0; q0 = fmaf(d, d, q0); }
+        { const float d = acc[mt][6][r] - (t6p0 ? mu0 : mu1); const float dd = d * d; q0 += t6p0 ? dd : 0.f; q1 += t6p0 ? 0.f : dd; }
+#pragma unroll
+        for (int nt = 7; nt < 12; ++nt) { const float d = acc[mt][nt][r] - mu1; q1 = fmaf(d, d, q1); }
+        { const float d = acc[mt][12][r] - mu1; q1 += t12ok ? d * d : 0.f; }
+        mean0[r] = mu0; mean1[r] = mu1;
+        rs0[r] = 1.0f / sqrtf(row16_sum(q0) * inv_n + E.eps);  // biased variance, like F.instance_norm
+        rs1[r] = 1.0f / sqrtf(row16_sum(q1) * inv_n + E.eps);
+      }
+      if (chok && c == 0) {
+        if ((size_t)(pair0) * kPts < (size_t)ncols) *reinterpret_cast<f32x4*>(E.rstd + (size_t)pair0 * M + ch0) = rs0;
+        if ((size_t)(pair0 + 1) * kPts < (size_t)ncols) *reinterpret_cast<f32x4*>(E.rstd + (size_t)(pair0 + 1) * M + ch0) = rs1;
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const bool first = (nt < 6) || (nt == 6 && t6p0);
+        const int cl = nt * 16 + c, col = n0 + cl;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float mu = first ? mean0[r] : mean1[r], rs = first ? rs0[r] : rs1[r];
+          const float z = fmaf((acc[mt][nt][r] - mu) * rs, gam[r], bet[r]);
+          v[r] = (z > 0.f) ? z : z * E.slope;
+        }
+        unsigned p0a, p1a, p2a, p0b, p1b, p2b;
+        split3(v[0], v[1], p0a, p1a, p2a);
+        split3(v[2], v[3], p0b, p1b, p2b);
+        if (cl < BSTEP && col < ncols && chok) {
+          bf16_t* dst = E.planes + (size_t)col * M + ch0;
+          *reinterpret_cast<uint2*>(dst) = make_uint2(p0a, p0b);
+          *reinterpret_cast<uint2*>(dst + E.plane_stride) = make_uint2(p1a, p1b);
+          *reinterpret_cast<uint2*>(dst + 2 * E.plane_stride) = make_uint2(p2a, p2b);
+        }
+      }
+    }
+  }
+}
+
+// ---- dW[co][ci] = sum_cols dY[col][co] X[col][ci], two planes each (three products) ------------------------------------------
+// Block: 128 x 128 output tile (2 x 2 wavefronts of 64 x 64 = 4 x 4 MFMA tiles), one slice of the columns (split-K); the partial
+// product goes to part[slice][co][ci] (summed by the caller: deterministic, no floating-point atomics).
+// LDS image per (operand, plane): [32 k][16 chunks of 8 channels], filled by LDS-DMA; chunk position q of row k holds channel
+// chunk q ^ 2 (k & 7)  (the swizzle lives on the SOURCE address, the image itself is lane-linear), so that the eight rows a
+// ds_read_b64_tr_b16 half-wave touches fall on eight different bank groups.
+__global__ void __launch_bounds__(256, 2)
+est_gemm_tn_kernel(const bf16_t* __restrict__ dY, size_t dy_plane, int Cout, const bf16_t* __restrict__ X, size_t x_plane, int Cin,
+                   int ncols, int cols_per_slice, float* __restrict__ part) {
+  constexpr int kOpBytes = 2 * BK * 256;  // two planes of [32][256 B]
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kOpBytes];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = (int)blockIdx.x * 128, n0 = (int)blockIdx.y * 128, slice = (int)blockIdx.z;
+  const int kbeg = slice * cols_per_slice;
+  int kend = kbeg + cols_per_slice;
+  kend = (kend < ncols) ? kend : ncols;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int kr = lane >> 4, pos = lane & 15;  // DMA role: row within a group of four, chunk position
+  const int c = lane & 15, g = lane >> 4;
+  const int tr_row = (c >> 2), tr_piece = c & 3;  // ds_read_tr role inside the 16-lane group
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    // 2 operands x 2 planes x 8 row groups = 32 DMA instructions per stage, 8 per wavefront
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int t = wave * 8 + i;  // wave-uniform: operand = t >> 4, plane = (t >> 3) & 1, row group = t & 7
+      const int op = t >> 4, p = (t >> 3) & 1, rg = t & 7;
+      const int k = rg * 4 + kr;
+      int col = k0 + k;
+      const bool live = col < kend;  // past the slice: zeros
+      col = live ? col : kend - 1;
+      const int chunk = pos ^ (2 * (k & 7));
+      const int C = op ? Cin : Cout, base = op ? n0 : m0;
+      int ch = base + chunk * 8;
+      ch = (ch + 8 <= C) ? ch : 0;  // channels past the operand: any valid address, masked at the store
+      const bf16_t* src = (op ? X + (size_t)p * x_plane : dY + (size_t)p * dy_plane) + (size_t)col * C + ch;
+      unsigned char* dst = lds + op * kOpBytes + p * (BK * 256) + rg * 4 * 256;
+      __builtin_amdgcn_global_load_lds(DFEPE_GLOBAL_PTR(src), DFEPE_LDS_PTR(dst), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (k0 + BK > kend) {  // ragged last step of the slice: rows past the end hold a copy of the last column -- zero them
+      for (int e = tid; e < 2 * kOpBytes / 16; e += 256) {
+        const int k = (e >> 4) & (BK - 1);
+        if (k0 + k >= kend) reinterpret_cast<uint4*>(lds)[e] = make_uint4(0, 0, 0, 0);
+      }
+      __syncthreads();
+    }
+    bf16x8 a[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int t = wr * 4 + mt;  // 16-channel tile of this operand: chunks 2t, 2t+1
+        s16x4 lo, hi;
+        {
+          const int k = 4 * g + tr_row;
+          const int q = (2 * t) ^ (2 * (k & 7));
+          lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + p * (BK * 256) + k * 256 + q * 16 + tr_piece * 8));
+        }
+        {
+          const int k = 16 + 4 * g + tr_row;
+          const int q = (2 * t) ^ (2 * (k & 7));
+          hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + p * (BK * 256) + k * 256 + q * 16 + tr_piece * 8));
+        }
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        a[mt][p] = __builtin_bit_cast(bf16x8, both);
+      }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      bf16x8 b[2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int t = wc * 4 + nt;
+        s16x4 lo, hi;
+        {
+          const int k = 4 * g + tr_row;
+          const int q = (2 * t) ^ (2 * (k & 7));
+          lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + kOpBytes + p * (BK * 256) + k * 256 + q * 16 + tr_piece * 8));
+        }
+        {
+          const int k = 16 + 4 * g + tr_row;
+          const int q = (2 * t) ^ (2 * (k & 7));
+          hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + kOpBytes + p * (BK * 256) + k * 256 + q * 16 + tr_piece * 8));
+        }
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        b[p] = __builtin_bit_cast(bf16x8, both);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][1], b[0], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][0], b[1], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][0], b[0], acc[mt][nt], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  float* dst = part + (size_t)slice * Cout * Cin;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int ci = n0 + wc * 64 + nt * 16 + c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = m0 + wr * 64 + mt * 16 + 4 * g + r;
+        if (co < Cout && ci < Cin) dst[(size_t)co * Cin + ci] = acc[mt][nt][r];
+      }
+    }
+}
+
+// ---- InstanceNorm + LeakyReLU adjoint, point-major ----------------------------------------------------------------------------
+// One workgroup = one pair (100 columns) x 64 channels: 32 channel pairs x 8 row groups of 13 columns.  Inputs: the upstream
+// gradient dA [cols][C] fp32 -- or, for the layer under the head, its rank-one form dlogit[col] * w_head[c] --, the layer's
+// output planes (a = lrelu(z), z = gamma x^ + beta: z and x^ are recovered from them), rstd, gamma, beta.  Outputs: dY as two
+// planes, and the pair's contributions to d gamma / d beta ([pair][C] each, summed by the caller).
+__global__ void __launch_bounds__(256)
+est_in_bwd_kernel(const float* __restrict__ dA, const float* __restrict__ dlogit, const float* __restrict__ w_head,
+                  const bf16_t* __restrict__ planes, size_t plane_stride, const float* __restrict__ rstd,
+                  const float* __restrict__ gamma, const float* __restrict__ beta, float slope, int C, int ncols,
+                  bf16_t* __restrict__ dYp, size_t dy_plane, float* __restrict__ dgamma_part, float* __restrict__ dbeta_part) {
+  __shared__ float red[2][8][64];
+  const int pair = (int)blockIdx.x, cb = (int)blockIdx.y * 64;
+  const int cp = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int ch = cb + 2 * cp;
+  const bool chok = ch < C;
+  const int chc = chok ? ch : 0;
+  const float g0 = gamma[chc], g1 = gamma[chc + 1], b0 = beta[chc], b1 = beta[chc + 1];
+  const float ig0 = (fabsf(g0) > 1e-30f) ? 1.0f / g0 : 0.0f, ig1 = (fabsf(g1) > 1e-30f) ? 1.0f / g1 : 0.0f;
+  const float islope = 1.0f / slope;
+  const float r0 = rstd[(size_t)pair * C + chc], r1 = rstd[(size_t)pair * C + chc + 1];
+  constexpr int RPG = 13;  // 8 x 13 >= 100
+  float dz0[RPG], dz1[RPG], xh0[RPG], xh1[RPG];
+  float s10 = 0.f, s11 = 0.f, s20 = 0.f, s21 = 0.f;
+#pragma unroll
+  for (int i = 0; i < RPG; ++i) {
+    const int rl = rg * RPG + i;
+    const bool live = rl < kPts;
+    const size_t col = (size_t)pair * kPts + (live ? rl : 0);
+    const unsigned u0 = *reinterpret_cast<const unsigned*>(planes + col * C + chc);
+    const unsigned u1 = *reinterpret_cast<const unsigned*>(planes + plane_stride + col * C + chc);
+    const unsigned u2 = *reinterpret_cast<const unsigned*>(planes + 2 * plane_stride + col * C + chc);
+    const float a0 = (bf16_lo(u0) + bf16_lo(u1)) + bf16_lo(u2), a1 = (bf16_hi(u0) + bf16_hi(u1)) + bf16_hi(u2);
+    float d0, d1;
+    if (dA != nullptr) {
+      const f32x2 d = *reinterpret_cast<const f32x2*>(dA + col * C + chc);
+      d0 = d[0]; d1 = d[1];
+    } else {
+      const float dl = dlogit[col];
+      d0 = dl * w_head[chc]; d1 = dl * w_head[chc + 1];
+    }
+    const float z0 = (a0 > 0.f) ? a0 : a0 * islope, z1 = (a1 > 0.f) ? a1 : a1 * islope;
+    const float e0 = live ? ((a0 > 0.f) ? d0 : d0 * slope) : 0.f, e1 = live ? ((a1 > 0.f) ? d1 : d1 * slope) : 0.f;
+    const float x0 = (z0 - b0) * ig0, x1 = (z1 - b1) * ig1;
+    dz0[i] = e0; dz1[i] = e1; xh0[i] = x0; xh1[i] = x1;
+    s10 += e0; s11 += e1; s20 = fmaf(e0, x0, s20); s21 = fmaf(e1, x1, s21);
+  }
+  red[0][rg][2 * cp] = s10; red[0][rg][2 * cp + 1] = s11;
+  red[1][rg][2 * cp] = s20; red[1][rg][2 * cp + 1] = s21;
+  __syncthreads();
+  float S10 = 0.f, S11 = 0.f, S20 = 0.f, S21 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    S10 += red[0][q][2 * cp]; S11 += red[0][q][2 * cp + 1];
+    S20 += red[1][q][2 * cp]; S21 += red[1][q][2 * cp + 1];
+  }
+  if (rg == 0 && chok) {
+    dbeta_part[(size_t)pair * C + ch] = S10; dbeta_part[(size_t)pair * C + ch + 1] = S11;
+    dgamma_part[(size_t)pair * C + ch] = S20; dgamma_part[(size_t)pair * C + ch + 1] = S21;
+  }
+  const float inv_n = 1.0f / (float)kPts;
+  const float k0 = r0 * g0, k1 = r1 * g1;
+  const float m10 = S10 * inv_n, m11 = S11 * inv_n, m20 = S20 * inv_n, m21 = S21 * inv_n;
+#pragma unroll
+  for (int i = 0; i < RPG; ++i) {
+    const int rl = rg * RPG + i;
+    if (rl < kPts && chok) {
+      const size_t col = (size_t)pair * kPts + rl;
+      const float y0 = k0 * (dz0[i] - m10 - xh0[i] * m20), y1 = k1 * (dz1[i] - m11 - xh1[i] * m21);
+      unsigned p0, p1;
+      split2(y0, y1, p0, p1);
+      *reinterpret_cast<unsigned*>(dYp + col * C + ch) = p0;
+      *reinterpret_cast<unsigned*>(dYp + dy_plane + col * C + ch) = p1;
+    }
+  }
+  (void)ncols;
+}
+
+// ---- head: logits[col] = sum_c w[c] a[col][c] + b (Conv1d(256 -> 1)); one 16-lane row per column ----------------------------
+__global__ void __launch_bounds__(256)
+est_head_fwd_kernel(const bf16_t* __restrict__ planes, size_t plane_stride, int C, int ncols, const float* __restrict__ w,
+                    const float* __restrict__ bias, float* __restrict__ logits) {
+  const int col = (int)blockIdx.x * 16 + (int)(threadIdx.x >> 4), l = threadIdx.x & 15;
+  const int cc = (col < ncols) ? col : ncols - 1;
+  float s = 0.f;
+  for (int ch = 2 * l; ch < C; ch += 32) {
+    const unsigned u0 = *reinterpret_cast<const unsigned*>(planes + (size_t)cc * C + ch);
+    const unsigned u1 = *reinterpret_cast<const unsigned*>(planes + plane_stride + (size_t)cc * C + ch);
+    const unsigned u2 = *reinterpret_cast<const unsigned*>(planes + 2 * plane_stride + (size_t)cc * C + ch);
+    s = fmaf((bf16_lo(u0) + bf16_lo(u1)) + bf16_lo(u2), w[ch], s);
+    s = fmaf((bf16_hi(u0) + bf16_hi(u1)) + bf16_hi(u2), w[ch + 1], s);
+  }
+  s = row16_sum(s);
+  if (l == 0 && col < ncols) logits[col] = s + (bias ? bias[0] : 0.f);
+}
+// d w_head partials: part[block][c] = sum over the block's columns of dlogit[col] a[col][c]
+__global__ void __launch_bounds__(256)
+est_head_dw_kernel(const bf16_t* __restrict__ planes, size_t plane_stride, int C, int ncols, int cols_per_block,
+                   const float* __restrict__ dlogit, float* __restrict__ part) {
+  const int c0 = (int)blockIdx.x * cols_per_block;
+  int c1 = c0 + cols_per_block;
+  c1 = (c1 < ncols) ? c1 : ncols;
+  for (int ch = 2 * (int)threadIdx.x; ch < C; ch += 512) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int col = c0; col < c1; ++col) {
+      const unsigned u0 = *reinterpret_cast<const unsigned*>(planes + (size_t)col * C + ch);
+      const unsigned u1 = *reinterpret_cast<const unsigned*>(planes + plane_stride + (size_t)col * C + ch);
+      const unsigned u2 = *reinterpret_cast<const unsigned*>(planes + 2 * plane_stride + (size_t)col * C + ch);
+      const float d = dlogit[col];
+      s0 = fmaf((bf16_lo(u0) + bf16_lo(u1)) + bf16_lo(u2), d, s0);
+      s1 = fmaf((bf16_hi(u0) + bf16_hi(u1)) + bf16_hi(u2), d, s1);
+    }
+    part[(size_t)blockIdx.x * C + ch] = s0;
+    part[(size_t)blockIdx.x * C + ch + 1] = s1;
+  }
+}
+
+// fp32 [rows][C] (ld = src_ld, first C_src columns used, the rest zero) -> NP planes [rows][C]
+template <int NP>
+__global__ void __launch_bounds__(256)
+est_split_kernel(const float* __restrict__ src, long rows, int C_src, int src_ld, int C, bf16_t* __restrict__ planes, size_t plane_stride) {
+  const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (e >= rows * C) return;
+  const long r = e / C;
+  const int ch = (int)(e - r * C);
+  const float x = (ch < C_src) ? src[r * src_ld + ch] : 0.f, y = (ch + 1 < C_src) ? src[r * src_ld + ch + 1] : 0.f;
+  unsigned p0, p1, p2;
+  split3(x, y, p0, p1, p2);
+  *reinterpret_cast<unsigned*>(planes + e) = p0;
+  if (NP > 1) *reinterpret_cast<unsigned*>(planes + plane_stride + e) = p1;
+  if (NP > 2) *reinterpret_cast<unsigned*>(planes + 2 * plane_stride + e) = p2;
+}
+
+}  // namespace
+
+extern "C" int dfepe_est_points(void) { return kPts; }
+
+extern "C" int dfepe_est_split(const float* src, long rows, int C_src, int src_ld, int C, int n_planes, void* planes, size_t plane_stride,
+                               void* stream) {
+  if (!src || !planes || rows < 0 || C <= 0 || (C & 1) || C_src <= 0 || C_src > C || n_planes < 1 || n_planes > 3) return DFEPE_ERR_INVALID_ARG;
+  if (rows == 0) return DFEPE_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned blocks = (unsigned)((rows * C / 2 + 255) / 256);
+  bf16_t* P = static_cast<bf16_t*>(planes);
+  if (n_planes == 3) hipLaunchKernelGGL((est_split_kernel<3>), dim3(blocks), dim3(256), 0, st, src, rows, C_src, src_ld, C, P, plane_stride);
+  else if (n_planes == 2) hipLaunchKernelGGL((est_split_kernel<2>), dim3(blocks), dim3(256), 0, st, src, rows, C_src, src_ld, C, P, plane_stride);
+  else hipLaunchKernelGGL((est_split_kernel<1>), dim3(blocks), dim3(256), 0, st, src, rows, C_src, src_ld, C, P, plane_stride);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+// forward layer: planes_out[3][ncols][M] = split(lrelu(IN(W X))), rstd[npairs][M]
+extern "C" int dfepe_est_layer_fwd(const void* W, size_t w_plane, const void* X, size_t x_plane, int M, int ncols, int K,
+                                   const float* gamma, const float* beta, float eps, float slope, void* planes_out,
+                                   size_t out_plane, float* rstd, void* stream) {
+  if (!W || !X || !gamma || !beta || !planes_out || !rstd || M <= 0 || (M & 3) || ncols <= 0 || (ncols % kPts) || K <= 0 || (K % BK))
+    return DFEPE_ERR_INVALID_ARG;
+  if (!(slope > 0.f)) return DFEPE_ERR_UNSUPPORTED;  // the backward inverts the activation
+  EpiArgs E{};
+  E.gamma = gamma; E.beta = beta; E.eps = eps; E.slope = slope; E.planes = static_cast<bf16_t*>(planes_out); E.plane_stride = out_plane;
+  E.rstd = rstd;
+  const dim3 grid((ncols + BSTEP - 1) / BSTEP, (M + BM - 1) / BM), block(256);
+  hipLaunchKernelGGL((est_gemm_nt_kernel<3, 3, 2, EPI_IN>), grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(W),
+                     w_plane, static_cast<const bf16_t*>(X), x_plane, M, ncols, K, E);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+// plain product: out[col][m] (fp32, ld = ldc) = sum_terms A_i[m][:] . B_j[col][:]; n_planes = 2 (three products) or 3 (six)
+extern "C" int dfepe_est_gemm_nt(const void* A, size_t a_plane, const void* B, size_t b_plane, int M, int ncols, int K, int n_planes,
+                                 float* out, int ldc, void* stream) {
+  if (!A || !B || !out || M <= 0 || (M & 3) || ncols <= 0 || K <= 0 || (K % BK) || ldc < M) return DFEPE_ERR_INVALID_ARG;
+  if (n_planes != 2 && n_planes != 3) return DFEPE_ERR_INVALID_ARG;
+  EpiArgs E{};
+  E.out = out; E.ldc = ldc;
+  const dim3 grid((ncols + BSTEP - 1) / BSTEP, (M + BM - 1) / BM), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n_planes == 3)
+    hipLaunchKernelGGL((est_gemm_nt_kernel<3, 3, 2, EPI_F32>), grid, block, 0, st, static_cast<const bf16_t*>(A), a_plane,
+                       static_cast<const bf16_t*>(B), b_plane, M, ncols, K, E);
+  else
+    hipLaunchKernelGGL((est_gemm_nt_kernel<2, 2, 1, EPI_F32>), grid, block, 0, st, static_cast<const bf16_t*>(A), a_plane,
+                       static_cast<const bf16_t*>(B), b_plane, M, ncols, K, E);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+// weight gradient partials: part[slices][Cout][Cin]
+extern "C" int dfepe_est_gemm_tn(const void* dY, size_t dy_plane, int Cout, const void* X, size_t x_plane, int Cin, int ncols,
+                                 int slices, float* part, void* stream) {
+  if (!dY || !X || !part || Cout <= 0 || Cin <= 0 || (Cout & 7) || (Cin & 7) || ncols <= 0 || slices <= 0) return DFEPE_ERR_INVALID_ARG;
+  int cps = (ncols + slices - 1) / slices;
+  cps = ((cps + BK - 1) / BK) * BK;
+  const dim3 grid((Cout + 127) / 128, (Cin + 127) / 128, slices), block(256);
+  hipLaunchKernelGGL(est_gemm_tn_kernel, grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(dY), dy_plane, Cout,
+                     static_cast<const bf16_t*>(X), x_plane, Cin, ncols, cps, part);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+extern "C" int dfepe_est_in_bwd(const float* dA, const float* dlogit, const float* w_head, const void* planes, size_t plane_stride,
+                                const float* rstd, const float* gamma, const float* beta, float slope, int C, int ncols, void* dY,
+                                size_t dy_plane, float* dgamma_part, float* dbeta_part, void* stream) {
+  if ((!dA && !(dlogit && w_head)) || !planes || !rstd || !gamma || !beta || !dY || !dgamma_part || !dbeta_part) return DFEPE_ERR_INVALID_ARG;
+  if (C <= 0 || (C & 1) || ncols <= 0 || (ncols % kPts) || !(slope > 0.f)) return DFEPE_ERR_INVALID_ARG;
+  const dim3 grid(ncols / kPts, (C + 63) / 64), block(256);
+  hipLaunchKernelGGL(est_in_bwd_kernel, grid, block, 0, static_cast<hipStream_t>(stream), dA, dlogit, w_head,
+                     static_cast<const bf16_t*>(planes), plane_stride, rstd, gamma, beta, slope, C, ncols, static_cast<bf16_t*>(dY), dy_plane,
+                     dgamma_part, dbeta_part);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+extern "C" int dfepe_est_head_fwd(const void* planes, size_t plane_stride, int C, int ncols, const float* w, const float* bias,
+                                  float* logits, void* stream) {
+  if (!planes || !w || !logits || C <= 0 || (C & 1) || ncols <= 0) return DFEPE_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(est_head_fwd_kernel, dim3((ncols + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const bf16_t*>(planes), plane_stride, C, ncols, w, bias, logits);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+extern "C" int dfepe_est_head_dw(const void* planes, size_t plane_stride, int C, int ncols, int blocks, const float* dlogit, float* part,
+                                 void* stream) {
+  if (!planes || !dlogit || !part || C <= 0 || (C & 1) || ncols <= 0 || blocks <= 0) return DFEPE_ERR_INVALID_ARG;
+  const int cpb = (ncols + blocks - 1) / blocks;
+  hipLaunchKernelGGL(est_head_dw_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(planes),
+                     plane_stride, C, ncols, cpb, dlogit, part);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}

@@ -1,0 +1,159 @@
+"""The per-correspondence weight estimator on the matrix cores: host side.
+
+``estimator_forward(x, layers, head)`` evaluates the Conv1d(k=1) -> InstanceNorm1d(affine) -> LeakyReLU stack of
+ErrorEstimator (deepFEPE/models/ErrorEstimators.py:47-64) with the kernels of csrc/est_gemm.hip: every fp32 operand travels as
+three bf16 planes (a = a0 + a1 + a2, exact), a forward product is six bf16 MFMAs with fp32 accumulation (fp32-class accuracy),
+a backward product three; InstanceNorm + LeakyReLU + the split into planes are the forward GEMM's epilogue.  One autograd node
+for the whole stack; parameters and inputs are the module's own fp32 tensors.  PyTorch is plumbing here (allocation, the
+tiny weight transposes, the sums over split-K / per-pair partials)."""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from .ops import _ptr, _stream
+
+Tensor = torch.Tensor
+BF16 = torch.bfloat16
+
+
+def supported(x: Tensor) -> bool:
+    """The fused kernels are built for N = dfepe_est_points() (100) points per pair."""
+    return x.is_cuda and x.dim() == 3 and x.shape[2] == _lib.lib().dfepe_est_points() and x.shape[0] > 0
+
+
+def _pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+def _split(src: Tensor, rows: int, c_src: int, c: int, n_planes: int) -> Tensor:
+    """fp32 [rows, c_src] (contiguous) -> bf16 planes [n_planes, rows, c], channels past c_src zero."""
+    out = torch.empty(n_planes, rows, c, device=src.device, dtype=BF16)
+    rc = _lib.lib().dfepe_est_split(_ptr(src), rows, c_src, c_src, c, n_planes, _ptr(out), rows * c, _stream())
+    _lib.check(rc, "dfepe_est_split")
+    return out
+
+
+def _slices_for(cout: int, cin: int) -> int:
+    tiles = ((cout + 127) // 128) * ((cin + 127) // 128)
+    return max(1, min(512, 768 // tiles))
+
+
+class _EstimatorFunction(torch.autograd.Function):
+    """args: x [B, C0, N], then per hidden layer (conv weight [Co,Ci,1], conv bias [Co], gamma [Co], beta [Co]), then the head's
+    (weight [1,C,1], bias [1] or None); cfg = (n_hidden, eps, slope)."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, *params):
+        n_hidden, eps, slope = cfg
+        lib = _lib.lib()
+        B, C0, N = x.shape
+        cols = B * N
+        dev = x.device
+        st = _stream()
+        with torch.cuda.device(dev):
+            xin = x.detach().float().permute(0, 2, 1).reshape(cols, C0).contiguous()
+            acts = [_split(xin, cols, C0, _pad32(C0), 3)]  # planes of every layer's input, point-major [3, cols, C]
+            rstds = []
+            for l in range(n_hidden):
+                W, _b, gamma, beta = params[4 * l:4 * l + 4]
+                Co, Ci = W.shape[0], W.shape[1]
+                K = acts[-1].shape[2]
+                Wp = _split(W.detach().float().reshape(Co, Ci).contiguous(), Co, Ci, K, 3)
+                out = torch.empty(3, cols, Co, device=dev, dtype=BF16)
+                rstd = torch.empty(B, Co, device=dev, dtype=torch.float32)
+                rc = lib.dfepe_est_layer_fwd(_ptr(Wp), Co * K, _ptr(acts[-1]), cols * K, Co, cols, K, _ptr(gamma.detach().float().contiguous()),
+                                             _ptr(beta.detach().float().contiguous()), float(eps), float(slope), _ptr(out), cols * Co, _ptr(rstd), st)
+                _lib.check(rc, "dfepe_est_layer_fwd")
+                acts.append(out)
+                rstds.append(rstd)
+            Wh, bh = params[4 * n_hidden], params[4 * n_hidden + 1]
+            C = acts[-1].shape[2]
+            wh = Wh.detach().float().reshape(-1).contiguous()
+            logits = torch.empty(cols, device=dev, dtype=torch.float32)
+            rc = lib.dfepe_est_head_fwd(_ptr(acts[-1]), cols * C, C, cols, _ptr(wh), _ptr(None if bh is None else bh.detach().float().contiguous()),
+                                        _ptr(logits), st)
+            _lib.check(rc, "dfepe_est_head_fwd")
+        ctx.cfg = cfg
+        ctx.shape = (B, C0, N)
+        ctx.acts, ctx.rstds = acts, rstds  # device buffers of this node (planes are not autograd tensors)
+        ctx.save_for_backward(*[p for p in params if p is not None])
+        ctx.has_head_bias = bh is not None
+        return logits.view(B, 1, N)
+
+    @staticmethod
+    def backward(ctx, g_logits):
+        n_hidden, eps, slope = ctx.cfg
+        lib = _lib.lib()
+        B, C0, N = ctx.shape
+        cols = B * N
+        saved = list(ctx.saved_tensors)
+        params = saved if ctx.has_head_bias else saved + [None]
+        acts, rstds = ctx.acts, ctx.rstds
+        dev = g_logits.device
+        st = _stream()
+        grads: List[Optional[Tensor]] = [None] * len(params)
+        with torch.cuda.device(dev):
+            dl = g_logits.detach().float().reshape(cols).contiguous()
+            Wh = params[4 * n_hidden]
+            C = acts[-1].shape[2]
+            wh = Wh.detach().float().reshape(-1).contiguous()
+            nblk = 512
+            part = torch.empty(nblk, C, device=dev, dtype=torch.float32)
+            rc = lib.dfepe_est_head_dw(_ptr(acts[-1]), cols * C, C, cols, nblk, _ptr(dl), _ptr(part), st)
+            _lib.check(rc, "dfepe_est_head_dw")
+            grads[4 * n_hidden] = part.sum(0).reshape(Wh.shape).to(Wh.dtype)
+            if ctx.has_head_bias:
+                grads[4 * n_hidden + 1] = dl.sum().reshape(1).to(params[4 * n_hidden + 1].dtype)
+            dA = None  # fp32 [cols, C_l]: gradient w.r.t. the output of hidden layer l (None: the rank-one head form)
+            for l in range(n_hidden - 1, -1, -1):
+                W, bconv, gamma, beta = params[4 * l:4 * l + 4]
+                Co, Ci = W.shape[0], W.shape[1]
+                a_out, a_in = acts[l + 1], acts[l]
+                K = a_in.shape[2]
+                dY = torch.empty(2, cols, Co, device=dev, dtype=BF16)
+                dg = torch.empty(B, Co, device=dev, dtype=torch.float32)
+                db = torch.empty(B, Co, device=dev, dtype=torch.float32)
+                rc = lib.dfepe_est_in_bwd(_ptr(dA), _ptr(dl if dA is None else None), _ptr(wh if dA is None else None), _ptr(a_out), cols * Co,
+                                          _ptr(rstds[l]), _ptr(gamma.detach().float().contiguous()), _ptr(beta.detach().float().contiguous()),
+                                          float(slope), Co, cols, _ptr(dY), cols * Co, _ptr(dg), _ptr(db), st)
+                _lib.check(rc, "dfepe_est_in_bwd")
+                grads[4 * l + 2] = dg.sum(0).to(gamma.dtype)
+                grads[4 * l + 3] = db.sum(0).to(beta.dtype)
+                grads[4 * l + 1] = torch.zeros_like(bconv)  # the bias cancels in the instance normalisation: exact zero, like the reference's autograd
+                # dW = dY^T X (split-K over the columns, partials summed here: deterministic)
+                slices = _slices_for(Co, K)
+                partw = torch.empty(slices, Co, K, device=dev, dtype=torch.float32)
+                rc = lib.dfepe_est_gemm_tn(_ptr(dY), cols * Co, Co, _ptr(a_in), cols * K, K, cols, slices, _ptr(partw), st)
+                _lib.check(rc, "dfepe_est_gemm_tn")
+                grads[4 * l] = partw.sum(0)[:, :Ci].reshape(W.shape).to(W.dtype)
+                need_dx = l > 0 or ctx.needs_input_grad[1]
+                if need_dx:
+                    Mp = (K + 3) // 4 * 4
+                    WT = torch.zeros(Mp, Co, device=dev, dtype=torch.float32)
+                    WT[:Ci] = W.detach().float().reshape(Co, Ci).t()
+                    WTp = _split(WT, Mp, Co, Co, 2)
+                    dA = torch.empty(cols, Mp, device=dev, dtype=torch.float32)
+                    rc = lib.dfepe_est_gemm_nt(_ptr(WTp), Mp * Co, _ptr(dY), cols * Co, Mp, cols, Co, 2, _ptr(dA), Mp, st)
+                    _lib.check(rc, "dfepe_est_gemm_nt")
+                del dY
+            gx = None
+            if ctx.needs_input_grad[1]:
+                gx = dA[:, :C0].reshape(B, N, C0).permute(0, 2, 1).contiguous()
+        ctx.acts = ctx.rstds = None
+        return (None, gx, *grads)
+
+
+def estimator_forward(x: Tensor, hidden: Sequence[Tuple[Tensor, Tensor, Tensor, Tensor]], head: Tuple[Tensor, Optional[Tensor]],
+                      eps: float = 1e-5, slope: float = 0.01) -> Tensor:
+    """x [B, C0, N=100] fp32 on the GPU -> logits [B, 1, N].  hidden: per layer (conv weight, conv bias, InstanceNorm weight,
+    InstanceNorm bias); head: (conv weight [1,C,1], bias or None)."""
+    if not supported(x):
+        raise _lib.DfepeError(f"estimator_forward: needs a GPU tensor [B, C, {_lib.lib().dfepe_est_points()}], got {tuple(x.shape)} on {x.device}")
+    flat: List[Optional[Tensor]] = []
+    for layer in hidden:
+        flat.extend(layer)
+    flat.extend(head)
+    return _EstimatorFunction.apply((len(hidden), float(eps), float(slope)), x, *flat)

@@ -1,0 +1,188 @@
+"""Row f-1 on the matrix cores (csrc/est_gemm.hip): each kernel against a float64 restatement of
+deepFEPE/models/ErrorEstimators.py:47-64 (Conv1d(k=1) = matrix product, F.instance_norm, F.leaky_relu), then the whole
+estimator against the stock PyTorch module run in float64.  Tolerances: forward products carry three bf16 planes per operand
+(six MFMAs, ~2^-24 per product: the fp32 class), backward products two (three MFMAs, ~2^-16).  GPU box only."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def relerr(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-300))
+
+
+def planes_to_f64(P):
+    return P.double().sum(0)
+
+
+def _split(dfepe, src, c, n_planes=3):
+    return dfepe.estimator._split(src.contiguous(), src.shape[0], src.shape[1], c, n_planes)
+
+
+def test_split_planes_are_exact(dfepe):
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(1000, 7, generator=g) * torch.logspace(-6, 3, 7)).to(DEV)
+    P = _split(dfepe, x, 32)
+    assert P.shape == (3, 1000, 32) and P.dtype == torch.bfloat16
+    rec = planes_to_f64(P)
+    assert torch.equal(rec[:, :7].float(), x)  # three bf16 planes hold all 24 mantissa bits
+    assert rec[:, 7:].abs().max().item() == 0.0
+    P2 = _split(dfepe, x, 32, 2)
+    assert relerr(planes_to_f64(P2)[:, :7], x) < 2.0 ** -16
+
+
+@pytest.mark.parametrize("M,K,pairs,n_planes", [(128, 32, 4, 3), (64, 64, 3, 3), (256, 1024, 5, 3), (32, 128, 8, 2), (512, 256, 16, 2)])
+def test_gemm_nt_matches_float64(dfepe, M, K, pairs, n_planes):
+    """out[col][m] = sum_k A[m][k] B[col][k] on planes; odd pair counts exercise the half-empty last block, M < 128 the masked rows."""
+    lib = dfepe._lib.lib()
+    cols = pairs * 100
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    Bm = torch.randn(cols, K, generator=g).to(DEV)
+    Ap, Bp = _split(dfepe, A, K, n_planes), _split(dfepe, Bm, K, n_planes)
+    out = torch.full((cols, M), float("nan"), device=DEV)
+    rc = lib.dfepe_est_gemm_nt(Ap.data_ptr(), M * K, Bp.data_ptr(), cols * K, M, cols, K, n_planes, out.data_ptr(), M, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = planes_to_f64(Bp) @ planes_to_f64(Ap).t()
+    scale = (planes_to_f64(Bp).abs() @ planes_to_f64(Ap).abs().t()).max()
+    err = float((out.double() - ref).abs().max() / scale)
+    assert err < (2e-7 if n_planes == 3 else 3e-5), err
+
+
+@pytest.mark.parametrize("Cout,K,pairs", [(64, 32, 3), (128, 64, 2), (1024, 128, 4), (256, 512, 5)])
+def test_layer_forward_matches_float64(dfepe, Cout, K, pairs):
+    """One layer: planes_out = split(leaky_relu(instance_norm(W X))), rstd per (pair, channel)."""
+    lib = dfepe._lib.lib()
+    cols = pairs * 100
+    g = torch.Generator().manual_seed(Cout)
+    W = (torch.randn(Cout, K, generator=g) / K ** 0.5).to(DEV)
+    X = torch.randn(cols, K, generator=g).to(DEV)
+    gamma = (1 + 0.2 * torch.randn(Cout, generator=g)).to(DEV)
+    beta = (0.3 * torch.randn(Cout, generator=g)).to(DEV)
+    Wp, Xp = _split(dfepe, W, K), _split(dfepe, X, K)
+    out = torch.zeros(3, cols, Cout, device=DEV, dtype=torch.bfloat16)
+    rstd = torch.zeros(pairs, Cout, device=DEV)
+    rc = lib.dfepe_est_layer_fwd(Wp.data_ptr(), Cout * K, Xp.data_ptr(), cols * K, Cout, cols, K, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.01,
+                                 out.data_ptr(), cols * Cout, rstd.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    Y = (X.double() @ W.double().t()).view(pairs, 100, Cout).permute(0, 2, 1)  # [pairs, C, N]
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.instance_norm(Y, weight=gamma.double(), bias=beta.double(), eps=1e-5), 0.01)
+    got = planes_to_f64(out).view(pairs, 100, Cout).permute(0, 2, 1)
+    assert relerr(got, ref) < 2e-6
+    ref_rstd = 1.0 / torch.sqrt(Y.var(2, unbiased=False) + 1e-5)
+    assert relerr(rstd, ref_rstd) < 2e-6
+
+
+@pytest.mark.parametrize("C,pairs,head", [(64, 3, False), (256, 2, True), (1024, 2, False)])
+def test_instance_norm_adjoint_matches_autograd(dfepe, C, pairs, head):
+    lib = dfepe._lib.lib()
+    cols = pairs * 100
+    g = torch.Generator().manual_seed(C + pairs)
+    Y = (torch.randn(pairs, C, 100, generator=g, dtype=torch.float64) * 2 + 0.5).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g, dtype=torch.float64)).requires_grad_(True)
+    beta = (0.3 * torch.randn(C, generator=g, dtype=torch.float64)).requires_grad_(True)
+    a = torch.nn.functional.leaky_relu(torch.nn.functional.instance_norm(Y, weight=gamma, bias=beta, eps=1e-5), 0.01)
+    if head:
+        dl = torch.randn(cols, generator=g, dtype=torch.float64)
+        wh = torch.randn(C, generator=g, dtype=torch.float64)
+        G = (dl.view(pairs, 1, 100) * wh.view(1, C, 1))
+    else:
+        G = torch.randn(pairs, C, 100, generator=g, dtype=torch.float64)
+    (a * G).sum().backward()
+    a_pm = a.detach().permute(0, 2, 1).reshape(cols, C).float().to(DEV)
+    P = _split(dfepe, a_pm, C)
+    rstd = (1.0 / torch.sqrt(Y.detach().var(2, unbiased=False) + 1e-5)).float().to(DEV).contiguous()
+    dA = G.permute(0, 2, 1).reshape(cols, C).float().to(DEV).contiguous()
+    dY = torch.zeros(2, cols, C, device=DEV, dtype=torch.bfloat16)
+    dg, db = torch.zeros(pairs, C, device=DEV), torch.zeros(pairs, C, device=DEV)
+    gm, bt = gamma.detach().float().to(DEV), beta.detach().float().to(DEV)
+    if head:
+        dl_d, wh_d = dl.float().to(DEV), wh.float().to(DEV)
+        rc = lib.dfepe_est_in_bwd(None, dl_d.data_ptr(), wh_d.data_ptr(), P.data_ptr(), cols * C, rstd.data_ptr(), gm.data_ptr(), bt.data_ptr(), 0.01,
+                                  C, cols, dY.data_ptr(), cols * C, dg.data_ptr(), db.data_ptr(), None)
+    else:
+        rc = lib.dfepe_est_in_bwd(dA.data_ptr(), None, None, P.data_ptr(), cols * C, rstd.data_ptr(), gm.data_ptr(), bt.data_ptr(), 0.01,
+                                  C, cols, dY.data_ptr(), cols * C, dg.data_ptr(), db.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref_dY = Y.grad.permute(0, 2, 1).reshape(cols, C)
+    assert relerr(planes_to_f64(dY).cpu(), ref_dY) < 5e-5
+    assert relerr(dg.sum(0).cpu(), gamma.grad) < 5e-5
+    assert relerr(db.sum(0).cpu(), beta.grad) < 5e-5
+
+
+@pytest.mark.parametrize("Cout,Cin,pairs,slices", [(64, 32, 3, 4), (128, 64, 7, 3), (1024, 128, 5, 8), (256, 512, 4, 1)])
+def test_gemm_tn_weight_gradient(dfepe, Cout, Cin, pairs, slices):
+    """dW[co][ci] = sum_cols dY[col][co] X[col][ci] through the transposing LDS reads, split-K partials."""
+    lib = dfepe._lib.lib()
+    cols = pairs * 100
+    g = torch.Generator().manual_seed(Cout + Cin)
+    dYf = torch.randn(cols, Cout, generator=g).to(DEV)
+    Xf = torch.randn(cols, Cin, generator=g).to(DEV)
+    dYp, Xp = _split(dfepe, dYf, Cout, 2), _split(dfepe, Xf, Cin, 3)
+    part = torch.full((slices, Cout, Cin), float("nan"), device=DEV)
+    rc = lib.dfepe_est_gemm_tn(dYp.data_ptr(), cols * Cout, Cout, Xp.data_ptr(), cols * Cin, Cin, cols, slices, part.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    A, Bm = planes_to_f64(dYp), planes_to_f64(Xp[:2])
+    ref = A.t() @ Bm
+    scale = (A.abs().t() @ Bm.abs()).max()
+    err = float((part.double().sum(0) - ref).abs().max() / scale)
+    assert err < 3e-5, err
+
+
+def test_head_forward_and_weight_gradient(dfepe):
+    lib = dfepe._lib.lib()
+    C, cols = 256, 700
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(cols, C, generator=g).to(DEV)
+    w, b = torch.randn(C, generator=g).to(DEV), torch.randn(1, generator=g).to(DEV)
+    P = _split(dfepe, a, C)
+    logits = torch.zeros(cols, device=DEV)
+    assert lib.dfepe_est_head_fwd(P.data_ptr(), cols * C, C, cols, w.data_ptr(), b.data_ptr(), logits.data_ptr(), None) == 0
+    assert relerr(logits, a.double() @ w.double() + b.double()) < 1e-6
+    dl = torch.randn(cols, generator=g).to(DEV)
+    part = torch.zeros(8, C, device=DEV)
+    assert lib.dfepe_est_head_dw(P.data_ptr(), cols * C, C, cols, 8, dl.data_ptr(), part.data_ptr(), None) == 0
+    assert relerr(part.sum(0), dl.double() @ a.double()) < 1e-5
+
+
+@pytest.mark.parametrize("cin,B", [(4, 6), (7, 5)])
+def test_whole_estimator_matches_the_stock_module_in_float64(dfepe, cin, B):
+    """estimator.estimator_forward through compat.FusedErrorEstimator against the stock stack evaluated in float64: logits to the
+    fp32 class, every gradient (input, convolution weights, InstanceNorm affine, head) to the two-plane class."""
+    EE = dfepe.compat.ErrorEstimators
+    stock = EE.ErrorEstimator(cin)
+    dfepe.synth.fill_params_deterministic(stock, seed=5)
+    fused = EE.FusedErrorEstimator(cin).to(DEV)
+    fused.load_state_dict(stock.state_dict())
+    stock = stock.double()
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(B, cin, 100, generator=g)
+    G = torch.randn(B, 1, 100, generator=g)
+    xa = x.double().requires_grad_(True)
+    xb = x.to(DEV).requires_grad_(True)
+    ya = stock(xa)
+    yb = fused(xb)
+    assert yb.shape == (B, 1, 100)
+    assert float((yb.detach().cpu().double() - ya.detach()).abs().max()) < 5e-6  # stock fp32 is 3e-6 from this truth
+    (ya * G.double()).sum().backward()
+    (yb * G.to(DEV)).sum().backward()
+    assert relerr(xb.grad.cpu(), xa.grad) < 2e-4
+    pa, pb = dict(stock.named_parameters()), dict(fused.named_parameters())
+    for name in pa:
+        assert pb[name].grad is not None, name
+        if pb[name].grad.abs().max().item() == 0.0:  # biases that cancel in an InstanceNorm: exact zero here, ~1e-16 noise there
+            assert name.endswith(".bias") and pa[name].grad.abs().max().item() < 1e-9
+            continue
+        assert relerr(pb[name].grad.cpu(), pa[name].grad) < 2e-4, name
+    # the native-fp32 evaluation stays available behind the switch and agrees
+    fused.split_bf16 = False
+    yc = fused(x.to(DEV))
+    assert float((yc.detach() - yb.detach()).abs().max()) < 1e-4
