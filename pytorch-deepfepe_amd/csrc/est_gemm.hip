@@ -11,12 +11,15 @@
 // against 2.9e-6 for stock fp32 and 6.6e-5 for two planes).  The backward products use two planes (i + j <= 1, three MFMAs,
 // ~2^-16): gradients need far less than the activations the next fit is sensitive to.
 //
-// Layout: activations POINT-major  P[plane][col][C]  (C contiguous = the K of the next layer's GEMM and of the data-gradient
-// GEMM), weights W[plane][C_out][C_in].  Kernels:
+// Layout: activations POINT-major and K-BLOCKED:  P[plane][C/32][col][32]  (the 32 channels of a K step are contiguous per
+// column, and the columns of a K step are contiguous: the 208 x 32 operand tile of a block is ONE contiguous 13 KB run, so
+// every LDS-DMA instruction moves a full contiguous KiB -- row-major [col][C] made each instruction touch 64 different lines
+// and the address unit, not the matrix cores, set the pace), weights W[plane][C_in/32][C_out][32] alike.  Kernels:
 //   est_gemm_nt   C[m][n] = sum_terms A_i[m][:] . B_j[n][:]   (both operands K-contiguous), 128 x 208 block tile = 128 channels
 //                 x two whole pairs (N = 100: 2 x 100 columns + 8 of the next block, recomputed there), K step 32, operands staged
-//                 by LDS-DMA (global_load_lds_dwordx4) as [plane][k/8][row][8] so that an MFMA fragment is one conflict-free
-//                 ds_read_b128, single LDS stage, two workgroups per CU overlap each other's load and MFMA phases.
+//                 by LDS-DMA (global_load_lds_dwordx4) as [plane][row][4 chunks of 8 k] with the chunk order XOR-permuted per group
+//                 of four rows (on the SOURCE address: the LDS image of a DMA is lane-linear), so that an MFMA fragment is one
+//                 conflict-free ds_read_b128; single LDS stage, two workgroups per CU overlap each other's load and MFMA phases.
 //                 Epilogues: EPI_F32 (plain fp32 store, the data-gradient GEMM) and EPI_IN (forward: InstanceNorm statistics of
 //                 each (channel, pair) straight from the accumulators -- a pair's 100 columns sit in the 16 lanes of a DPP row
 //                 across 7 column tiles --, affine, LeakyReLU, split into three planes, 8-byte stores; the convolution bias
@@ -75,6 +78,12 @@ __device__ __forceinline__ void split2(float x, float y, unsigned& p0, unsigned&
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
+// element (row, ch) of a K-blocked plane with `rows` rows
+__device__ __forceinline__ size_t kb_index(size_t row, int ch, size_t rows) { return ((size_t)(ch >> 5) * rows + row) * 32 + (ch & 31); }
+// chunk permutation of the staged [row][4 chunks] image: rows 4r..4r+3 of a 16-row tile hold chunk kg at position kg ^ f(r),
+// f = (0, 2, 3, 1): each of the four 16-lane service groups of a ds_read_b128 then covers all 16 slots of the bank row
+__device__ __forceinline__ int chunk_swz(int rowgroup) { return (0x78 >> (2 * (rowgroup & 3))) & 3; }
+
 enum { EPI_F32 = 0, EPI_IN = 1 };
 
 struct EpiArgs {
@@ -124,32 +133,35 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- staging tasks of this wavefront: 64 consecutive 16-byte chunks of one (operand, plane, k-group) each ----------------
-  constexpr int kATasks = NPA * 4 * (BM / 64), kBTasks = NPB * 4 * ((BN + 63) / 64), kTasks = kATasks + kBTasks;
+  // ---- staging tasks of this wavefront: one contiguous KiB (16 rows x 64 B of one plane's K block) per LDS-DMA instruction ----
+  constexpr int kATasks = NPA * (BM / 16), kBTasks = NPB * NT, kTasks = kATasks + kBTasks;
   constexpr int kPerWave = (kTasks + 3) / 4;
+  const int drow = lane >> 2, dchunk = (lane & 3) ^ chunk_swz(lane >> 4);  // DMA role: row within the instruction, source chunk
+  const int fsw = chunk_swz(c >> 2);                                       // fragment role: this lane's rows sit in row group c >> 2
+  // Row i of the wavefront's A tile mt holds channel 8 (i >> 2) + 4 mt + (i & 3) of its 32 (not 16 mt + i): an accumulator lane
+  // (row group g) then owns the EIGHT consecutive channels 8 g .. 8 g + 7 across its two tiles, so the epilogue stores 16 bytes per
+  // lane and plane, 64 contiguous bytes per column, one contiguous KiB per store instruction
+  const int fswA[2] = {chunk_swz(2 * (c >> 2)), chunk_swz(2 * (c >> 2) + 1)};
   const int nk = K / BK;
   for (int ks = 0; ks < nk; ++ks) {
-    const int k0 = ks * BK;
 #pragma unroll
     for (int i = 0; i < kPerWave; ++i) {
       const int t = wave + 4 * i;  // wave-uniform
       if (t < kATasks) {
-        const int p = t / (4 * (BM / 64)), kg = (t / (BM / 64)) & 3, rb = t % (BM / 64);
-        int row = m0 + rb * 64 + lane;
+        const int p = t / (BM / 16), rb = t % (BM / 16);
+        int row = m0 + rb * 16 + drow;
         row = (row < M) ? row : M - 1;
-        const bf16_t* src = A + (size_t)p * a_plane + (size_t)row * K + k0 + kg * 8;
-        unsigned char* dst = lds + ((p * 4 + kg) * BM + rb * 64) * 16;
+        const bf16_t* src = A + (size_t)p * a_plane + ((size_t)ks * M + row) * 32 + dchunk * 8;
+        unsigned char* dst = lds + (p * BM + rb * 16) * 64;
         __builtin_amdgcn_global_load_lds(DFEPE_GLOBAL_PTR(src), DFEPE_LDS_PTR(dst), 16, 0, 0);
       } else if (t < kTasks) {
-        constexpr int RB = (BN + 63) / 64;
         const int u = t - kATasks;
-        const int p = u / (4 * RB), kg = (u / RB) & 3, rb = u % RB;
-        const int r = rb * 64 + lane;
-        int row = n0 + r;
+        const int p = u / NT, rb = u % NT;
+        int row = n0 + rb * 16 + drow;
         row = (row < ncols) ? row : ncols - 1;
-        const bf16_t* src = B + (size_t)p * b_plane + (size_t)row * K + k0 + kg * 8;
-        unsigned char* dst = lds + kABytes + ((p * 4 + kg) * BN + rb * 64) * 16;
-        if (r < BN) __builtin_amdgcn_global_load_lds(DFEPE_GLOBAL_PTR(src), DFEPE_LDS_PTR(dst), 16, 0, 0);
+        const bf16_t* src = B + (size_t)p * b_plane + ((size_t)ks * ncols + row) * 32 + dchunk * 8;
+        unsigned char* dst = lds + kABytes + (p * BN + rb * 16) * 64;
+        __builtin_amdgcn_global_load_lds(DFEPE_GLOBAL_PTR(src), DFEPE_LDS_PTR(dst), 16, 0, 0);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -160,37 +172,48 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int p = 0; p < NPA; ++p)
-        a[mt][p] = *reinterpret_cast<const bf16x8*>(lds + ((p * 4 + g) * BM + wave * 32 + mt * 16 + c) * 16);
+        a[mt][p] = *reinterpret_cast<const bf16x8*>(lds + ((p * BM + wave * 32 + 8 * (c >> 2) + 4 * mt + (c & 3)) * 4 + (g ^ fswA[mt])) * 16);
+    // the column tile's B fragments are fetched one tile ahead of the MFMAs that consume them (two register sets): the LDS
+    // latency of tile nt + 1 hides behind the twelve MFMAs of tile nt instead of stalling every tile
+    bf16x8 b[2][NPB];
+#pragma unroll
+    for (int p = 0; p < NPB; ++p) b[0][p] = *reinterpret_cast<const bf16x8*>(lds + kABytes + ((p * BN + c) * 4 + (g ^ fsw)) * 16);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      bf16x8 b[NPB];
+      if (nt + 1 < NT) {
 #pragma unroll
-      for (int p = 0; p < NPB; ++p) b[p] = *reinterpret_cast<const bf16x8*>(lds + kABytes + ((p * 4 + g) * BN + nt * 16 + c) * 16);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        // smallest terms first
-#pragma unroll
-        for (int ord = ORDER; ord >= 0; --ord)
-#pragma unroll
-          for (int i = 0; i <= ord; ++i) {
-            const int j = ord - i;
-            if (i < NPA && j < NPB) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][i], b[j], acc[mt][nt], 0, 0, 0);
-          }
+        for (int p = 0; p < NPB; ++p)
+          b[(nt + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(lds + kABytes + ((p * BN + (nt + 1) * 16 + c) * 4 + (g ^ fsw)) * 16);
       }
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this tile's MFMAs (the scheduler would sink it to its first use)
+      // smallest terms first; the two row tiles alternate, so that no MFMA waits for the one issued just before it
+#pragma unroll
+      for (int ord = ORDER; ord >= 0; --ord)
+#pragma unroll
+        for (int i = 0; i <= ord; ++i) {
+          const int j = ord - i;
+          if (i < NPA && j < NPB) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][i], b[nt & 1][j], acc[mt][nt], 0, 0, 0);
+          }
+        }
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds, per tile (mt, nt), channels ch0 + r (r = 0..3) of column n0 + 16 nt + c -----------------------
+  // ---- epilogue: lane holds, per column n0 + 16 nt + c, channels ch8 + 4 mt + r (mt = 0, 1; r = 0..3): eight in a row --------
+  const int ch8 = m0 + wave * 32 + 8 * g;
+  const bool chok = ch8 < M;  // M % 8 == 0
   if constexpr (EPI == EPI_F32) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int ch0 = m0 + wave * 32 + mt * 16 + 4 * g;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int cl = nt * 16 + c, col = n0 + cl;
-        if (cl < BSTEP && col < ncols && ch0 < M)
-          *reinterpret_cast<f32x4*>(E.out + (size_t)col * E.ldc + ch0) = acc[mt][nt];
+    for (int nt = 0; nt < NT; ++nt) {
+      const int cl = nt * 16 + c, col = n0 + cl;
+      if (cl < BSTEP && col < ncols && chok) {
+        float* dst = E.out + (size_t)col * E.ldc + ch8;
+        *reinterpret_cast<f32x4*>(dst) = acc[0][nt];
+        *reinterpret_cast<f32x4*>(dst + 4) = acc[1][nt];
       }
     }
   } else {
@@ -199,13 +222,12 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
     const float inv_n = 1.0f / (float)kPts;
     const bool t6p0 = c < 4, t12ok = c < 8;
     const int pair0 = 2 * bx;
+    const int chc = chok ? ch8 : 0;
+    f32x4 gam[2], bet[2], mean0[2], mean1[2], rs0[2], rs1[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      const int ch0 = m0 + wave * 32 + mt * 16 + 4 * g;
-      const bool chok = ch0 < M;
-      const int chc = chok ? ch0 : 0;
-      const f32x4 gam = *reinterpret_cast<const f32x4*>(E.gamma + chc), bet = *reinterpret_cast<const f32x4*>(E.beta + chc);
-      f32x4 mean0, mean1, rs0, rs1;
+      gam[mt] = *reinterpret_cast<const f32x4*>(E.gamma + chc + 4 * mt);
+      bet[mt] = *reinterpret_cast<const f32x4*>(E.beta + chc + 4 * mt);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float s0 = 0.f, s1 = 0.f;
@@ -224,34 +246,38 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
 #pragma unroll
         for (int nt = 7; nt < 12; ++nt) { const float d = acc[mt][nt][r] - mu1; q1 = fmaf(d, d, q1); }
         { const float d = acc[mt][12][r] - mu1; q1 += t12ok ? d * d : 0.f; }
-        mean0[r] = mu0; mean1[r] = mu1;
-        rs0[r] = 1.0f / sqrtf(row16_sum(q0) * inv_n + E.eps);  // biased variance, like F.instance_norm
-        rs1[r] = 1.0f / sqrtf(row16_sum(q1) * inv_n + E.eps);
+        mean0[mt][r] = mu0; mean1[mt][r] = mu1;
+        rs0[mt][r] = 1.0f / sqrtf(row16_sum(q0) * inv_n + E.eps);  // biased variance, like F.instance_norm
+        rs1[mt][r] = 1.0f / sqrtf(row16_sum(q1) * inv_n + E.eps);
       }
       if (chok && c == 0) {
-        if ((size_t)(pair0) * kPts < (size_t)ncols) *reinterpret_cast<f32x4*>(E.rstd + (size_t)pair0 * M + ch0) = rs0;
-        if ((size_t)(pair0 + 1) * kPts < (size_t)ncols) *reinterpret_cast<f32x4*>(E.rstd + (size_t)(pair0 + 1) * M + ch0) = rs1;
+        if ((size_t)(pair0) * kPts < (size_t)ncols) *reinterpret_cast<f32x4*>(E.rstd + (size_t)pair0 * M + ch8 + 4 * mt) = rs0[mt];
+        if ((size_t)(pair0 + 1) * kPts < (size_t)ncols) *reinterpret_cast<f32x4*>(E.rstd + (size_t)(pair0 + 1) * M + ch8 + 4 * mt) = rs1[mt];
       }
+      // z = (v - mean) * (rstd gamma) + beta  (the difference first: no cancellation against a large mean)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const bool first = (nt < 6) || (nt == 6 && t6p0);
-        const int cl = nt * 16 + c, col = n0 + cl;
+      for (int r = 0; r < 4; ++r) { rs0[mt][r] *= gam[mt][r]; rs1[mt][r] *= gam[mt][r]; }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const bool first = (nt < 6) || (nt == 6 && t6p0);
+      const int cl = nt * 16 + c, col = n0 + cl;
+      unsigned pl[3][4];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float mu = first ? mean0[r] : mean1[r], rs = first ? rs0[r] : rs1[r];
-          const float z = fmaf((acc[mt][nt][r] - mu) * rs, gam[r], bet[r]);
+          const float z = fmaf(acc[mt][nt][r] - (first ? mean0[mt][r] : mean1[mt][r]), first ? rs0[mt][r] : rs1[mt][r], bet[mt][r]);
           v[r] = (z > 0.f) ? z : z * E.slope;
         }
-        unsigned p0a, p1a, p2a, p0b, p1b, p2b;
-        split3(v[0], v[1], p0a, p1a, p2a);
-        split3(v[2], v[3], p0b, p1b, p2b);
-        if (cl < BSTEP && col < ncols && chok) {
-          bf16_t* dst = E.planes + (size_t)col * M + ch0;
-          *reinterpret_cast<uint2*>(dst) = make_uint2(p0a, p0b);
-          *reinterpret_cast<uint2*>(dst + E.plane_stride) = make_uint2(p1a, p1b);
-          *reinterpret_cast<uint2*>(dst + 2 * E.plane_stride) = make_uint2(p2a, p2b);
-        }
+        split3(v[0], v[1], pl[0][2 * mt], pl[1][2 * mt], pl[2][2 * mt]);
+        split3(v[2], v[3], pl[0][2 * mt + 1], pl[1][2 * mt + 1], pl[2][2 * mt + 1]);
+      }
+      if (cl < BSTEP && col < ncols && chok) {
+        bf16_t* dst = E.planes + kb_index((size_t)col, ch8, (size_t)ncols);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(dst + p * E.plane_stride) = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
       }
     }
   }
@@ -260,9 +286,10 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
 // ---- dW[co][ci] = sum_cols dY[col][co] X[col][ci], two planes each (three products) ------------------------------------------
 // Block: 128 x 128 output tile (2 x 2 wavefronts of 64 x 64 = 4 x 4 MFMA tiles), one slice of the columns (split-K); the partial
 // product goes to part[slice][co][ci] (summed by the caller: deterministic, no floating-point atomics).
-// LDS image per (operand, plane): [32 k][16 chunks of 8 channels], filled by LDS-DMA; chunk position q of row k holds channel
-// chunk q ^ 2 (k & 7)  (the swizzle lives on the SOURCE address, the image itself is lane-linear), so that the eight rows a
-// ds_read_b64_tr_b16 half-wave touches fall on eight different bank groups.
+// LDS image per (operand, plane): [4 channel blocks][32 k][4 chunks of 8 channels] = the K-blocked global layout as it is (each
+// LDS-DMA instruction copies one contiguous KiB: 16 columns of one channel block); chunk position q of column k holds channel
+// chunk q ^ 2 ((k >> 2) & 1)  (the swizzle lives on the SOURCE address, the image itself is lane-linear), so that the eight
+// columns a ds_read_b64_tr_b16 half-wave touches fall on all 64 banks.
 __global__ void __launch_bounds__(256, 2)
 est_gemm_tn_kernel(const bf16_t* __restrict__ dY, size_t dy_plane, int Cout, const bf16_t* __restrict__ X, size_t x_plane, int Cin,
                    int ncols, int cols_per_slice, float* __restrict__ part) {
@@ -279,84 +306,67 @@ est_gemm_tn_kernel(const bf16_t* __restrict__ dY, size_t dy_plane, int Cout, con
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int kr = lane >> 4, pos = lane & 15;  // DMA role: row within a group of four, chunk position
+  const int dcol = lane >> 2, dq = (lane & 3) ^ (2 * ((lane >> 4) & 1));  // DMA role: column within the instruction, source chunk
   const int c = lane & 15, g = lane >> 4;
   const int tr_row = (c >> 2), tr_piece = c & 3;  // ds_read_tr role inside the 16-lane group
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    // 2 operands x 2 planes x 8 row groups = 32 DMA instructions per stage, 8 per wavefront
+    // 2 operands x 2 planes x 4 channel blocks x 2 column halves = 32 DMA instructions per stage, 8 per wavefront
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int t = wave * 8 + i;  // wave-uniform: operand = t >> 4, plane = (t >> 3) & 1, row group = t & 7
-      const int op = t >> 4, p = (t >> 3) & 1, rg = t & 7;
-      const int k = rg * 4 + kr;
-      int col = k0 + k;
-      const bool live = col < kend;  // past the slice: zeros
-      col = live ? col : kend - 1;
-      const int chunk = pos ^ (2 * (k & 7));
+      const int t = wave * 8 + i;  // wave-uniform: operand = t >> 4, plane = (t >> 3) & 1, channel block = (t >> 1) & 3, half = t & 1
+      const int op = t >> 4, p = (t >> 3) & 1, cb = (t >> 1) & 3, half = t & 1;
+      int col = k0 + half * 16 + dcol;
+      col = (col < kend) ? col : kend - 1;  // past the slice: a copy of the last column, zeroed below
       const int C = op ? Cin : Cout, base = op ? n0 : m0;
-      int ch = base + chunk * 8;
-      ch = (ch + 8 <= C) ? ch : 0;  // channels past the operand: any valid address, masked at the store
-      const bf16_t* src = (op ? X + (size_t)p * x_plane : dY + (size_t)p * dy_plane) + (size_t)col * C + ch;
-      unsigned char* dst = lds + op * kOpBytes + p * (BK * 256) + rg * 4 * 256;
+      int ch = base + cb * 32;
+      ch = (ch < C) ? ch : 0;  // channel blocks past the operand: any valid address, masked at the store
+      const bf16_t* src = (op ? X + (size_t)p * x_plane : dY + (size_t)p * dy_plane) + kb_index((size_t)col, ch, (size_t)ncols) + dq * 8;
+      unsigned char* dst = lds + op * kOpBytes + p * (BK * 256) + cb * (BK * 64) + half * 16 * 64;
       __builtin_amdgcn_global_load_lds(DFEPE_GLOBAL_PTR(src), DFEPE_LDS_PTR(dst), 16, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (k0 + BK > kend) {  // ragged last step of the slice: rows past the end hold a copy of the last column -- zero them
       for (int e = tid; e < 2 * kOpBytes / 16; e += 256) {
-        const int k = (e >> 4) & (BK - 1);
+        const int k = (e >> 2) & (BK - 1);  // image [operand][plane][channel block][32 columns][4 chunks]
         if (k0 + k >= kend) reinterpret_cast<uint4*>(lds)[e] = make_uint4(0, 0, 0, 0);
       }
       __syncthreads();
     }
+    // one 16-channel fragment (8 k-values per lane: rows 4g..4g+3 and 16+4g..16+4g+3 of the stage) through the transposing read
+    auto frag = [&](int op, int p, int t) {
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+      // 16-channel tile t: channel block t >> 1, chunks 2 (t & 1), 2 (t & 1) + 1 of the column's 64 bytes
+      const unsigned char* base = lds + op * kOpBytes + p * (BK * 256) + (t >> 1) * (BK * 64) + tr_piece * 8;
+      const int ka = 4 * g + tr_row, kb = 16 + 4 * g + tr_row;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(base + ka * 64 + (((2 * (t & 1)) ^ (2 * ((ka >> 2) & 1))) * 16)));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(base + kb * 64 + (((2 * (t & 1)) ^ (2 * ((kb >> 2) & 1))) * 16)));
+      return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
     bf16x8 a[4][2];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int t = wr * 4 + mt;  // 16-channel tile of this operand: chunks 2t, 2t+1
-        s16x4 lo, hi;
-        {
-          const int k = 4 * g + tr_row;
-          const int q = (2 * t) ^ (2 * (k & 7));
-          lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + p * (BK * 256) + k * 256 + q * 16 + tr_piece * 8));
-        }
-        {
-          const int k = 16 + 4 * g + tr_row;
-          const int q = (2 * t) ^ (2 * (k & 7));
-          hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + p * (BK * 256) + k * 256 + q * 16 + tr_piece * 8));
-        }
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
-        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        a[mt][p] = __builtin_bit_cast(bf16x8, both);
-      }
+      for (int p = 0; p < 2; ++p) a[mt][p] = frag(0, p, wr * 4 + mt);
+    bf16x8 b[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) b[0][p] = frag(1, p, wc * 4);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      bf16x8 b[2];
+      if (nt + 1 < 4) {
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int t = wc * 4 + nt;
-        s16x4 lo, hi;
-        {
-          const int k = 4 * g + tr_row;
-          const int q = (2 * t) ^ (2 * (k & 7));
-          lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + kOpBytes + p * (BK * 256) + k * 256 + q * 16 + tr_piece * 8));
-        }
-        {
-          const int k = 16 + 4 * g + tr_row;
-          const int q = (2 * t) ^ (2 * (k & 7));
-          hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + kOpBytes + p * (BK * 256) + k * 256 + q * 16 + tr_piece * 8));
-        }
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
-        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        b[p] = __builtin_bit_cast(bf16x8, both);
+        for (int p = 0; p < 2; ++p) b[(nt + 1) & 1][p] = frag(1, p, wc * 4 + nt + 1);
       }
+      __builtin_amdgcn_sched_barrier(0);  // the next tile's fragments stay ahead of this tile's MFMAs
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][1], b[0], acc[mt][nt], 0, 0, 0);
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][0], b[1], acc[mt][nt], 0, 0, 0);
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][0], b[0], acc[mt][nt], 0, 0, 0);
-      }
+      for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][1], b[nt & 1][0], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][0], b[nt & 1][1], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][0], b[nt & 1][0], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }
@@ -402,9 +412,10 @@ est_in_bwd_kernel(const float* __restrict__ dA, const float* __restrict__ dlogit
     const int rl = rg * RPG + i;
     const bool live = rl < kPts;
     const size_t col = (size_t)pair * kPts + (live ? rl : 0);
-    const unsigned u0 = *reinterpret_cast<const unsigned*>(planes + col * C + chc);
-    const unsigned u1 = *reinterpret_cast<const unsigned*>(planes + plane_stride + col * C + chc);
-    const unsigned u2 = *reinterpret_cast<const unsigned*>(planes + 2 * plane_stride + col * C + chc);
+    const size_t at = kb_index(col, chc, (size_t)ncols);
+    const unsigned u0 = *reinterpret_cast<const unsigned*>(planes + at);
+    const unsigned u1 = *reinterpret_cast<const unsigned*>(planes + plane_stride + at);
+    const unsigned u2 = *reinterpret_cast<const unsigned*>(planes + 2 * plane_stride + at);
     const float a0 = (bf16_lo(u0) + bf16_lo(u1)) + bf16_lo(u2), a1 = (bf16_hi(u0) + bf16_hi(u1)) + bf16_hi(u2);
     float d0, d1;
     if (dA != nullptr) {
@@ -444,11 +455,11 @@ est_in_bwd_kernel(const float* __restrict__ dA, const float* __restrict__ dlogit
       const float y0 = k0 * (dz0[i] - m10 - xh0[i] * m20), y1 = k1 * (dz1[i] - m11 - xh1[i] * m21);
       unsigned p0, p1;
       split2(y0, y1, p0, p1);
-      *reinterpret_cast<unsigned*>(dYp + col * C + ch) = p0;
-      *reinterpret_cast<unsigned*>(dYp + dy_plane + col * C + ch) = p1;
+      const size_t at = kb_index(col, ch, (size_t)ncols);
+      *reinterpret_cast<unsigned*>(dYp + at) = p0;
+      *reinterpret_cast<unsigned*>(dYp + dy_plane + at) = p1;
     }
   }
-  (void)ncols;
 }
 
 // ---- head: logits[col] = sum_c w[c] a[col][c] + b (Conv1d(256 -> 1)); one 16-lane row per column ----------------------------
@@ -459,38 +470,53 @@ est_head_fwd_kernel(const bf16_t* __restrict__ planes, size_t plane_stride, int 
   const int cc = (col < ncols) ? col : ncols - 1;
   float s = 0.f;
   for (int ch = 2 * l; ch < C; ch += 32) {
-    const unsigned u0 = *reinterpret_cast<const unsigned*>(planes + (size_t)cc * C + ch);
-    const unsigned u1 = *reinterpret_cast<const unsigned*>(planes + plane_stride + (size_t)cc * C + ch);
-    const unsigned u2 = *reinterpret_cast<const unsigned*>(planes + 2 * plane_stride + (size_t)cc * C + ch);
+    const size_t at = kb_index((size_t)cc, ch, (size_t)ncols);
+    const unsigned u0 = *reinterpret_cast<const unsigned*>(planes + at);
+    const unsigned u1 = *reinterpret_cast<const unsigned*>(planes + plane_stride + at);
+    const unsigned u2 = *reinterpret_cast<const unsigned*>(planes + 2 * plane_stride + at);
     s = fmaf((bf16_lo(u0) + bf16_lo(u1)) + bf16_lo(u2), w[ch], s);
     s = fmaf((bf16_hi(u0) + bf16_hi(u1)) + bf16_hi(u2), w[ch + 1], s);
   }
   s = row16_sum(s);
   if (l == 0 && col < ncols) logits[col] = s + (bias ? bias[0] : 0.f);
 }
-// d w_head partials: part[block][c] = sum over the block's columns of dlogit[col] a[col][c]
+// d w_head partials: part[block][c] = sum over the block's columns of dlogit[col] a[col][c].  Thread = (channel pair, one of
+// eight column groups): the 16 channel pairs of a K block read one contiguous 64-byte row per column.
 __global__ void __launch_bounds__(256)
 est_head_dw_kernel(const bf16_t* __restrict__ planes, size_t plane_stride, int C, int ncols, int cols_per_block,
                    const float* __restrict__ dlogit, float* __restrict__ part) {
+  __shared__ float red[8][64];
   const int c0 = (int)blockIdx.x * cols_per_block;
   int c1 = c0 + cols_per_block;
   c1 = (c1 < ncols) ? c1 : ncols;
-  for (int ch = 2 * (int)threadIdx.x; ch < C; ch += 512) {
+  const int cp = threadIdx.x & 31, cg = threadIdx.x >> 5;
+  for (int cb = 0; cb < C; cb += 64) {
+    const int ch = cb + 2 * cp;
     float s0 = 0.f, s1 = 0.f;
-    for (int col = c0; col < c1; ++col) {
-      const unsigned u0 = *reinterpret_cast<const unsigned*>(planes + (size_t)col * C + ch);
-      const unsigned u1 = *reinterpret_cast<const unsigned*>(planes + plane_stride + (size_t)col * C + ch);
-      const unsigned u2 = *reinterpret_cast<const unsigned*>(planes + 2 * plane_stride + (size_t)col * C + ch);
-      const float d = dlogit[col];
-      s0 = fmaf((bf16_lo(u0) + bf16_lo(u1)) + bf16_lo(u2), d, s0);
-      s1 = fmaf((bf16_hi(u0) + bf16_hi(u1)) + bf16_hi(u2), d, s1);
+    if (ch < C) {
+      for (int col = c0 + cg; col < c1; col += 8) {
+        const size_t at = kb_index((size_t)col, ch, (size_t)ncols);
+        const unsigned u0 = *reinterpret_cast<const unsigned*>(planes + at);
+        const unsigned u1 = *reinterpret_cast<const unsigned*>(planes + plane_stride + at);
+        const unsigned u2 = *reinterpret_cast<const unsigned*>(planes + 2 * plane_stride + at);
+        const float d = dlogit[col];
+        s0 = fmaf((bf16_lo(u0) + bf16_lo(u1)) + bf16_lo(u2), d, s0);
+        s1 = fmaf((bf16_hi(u0) + bf16_hi(u1)) + bf16_hi(u2), d, s1);
+      }
     }
-    part[(size_t)blockIdx.x * C + ch] = s0;
-    part[(size_t)blockIdx.x * C + ch + 1] = s1;
+    red[cg][2 * cp] = s0; red[cg][2 * cp + 1] = s1;
+    __syncthreads();
+    if (threadIdx.x < 64 && cb + (int)threadIdx.x < C) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += red[q][threadIdx.x];
+      part[(size_t)blockIdx.x * C + cb + threadIdx.x] = t;
+    }
+    __syncthreads();
   }
 }
 
-// fp32 [rows][C] (ld = src_ld, first C_src columns used, the rest zero) -> NP planes [rows][C]
+// fp32 [rows][C] (ld = src_ld, first C_src columns used, the rest zero) -> NP K-blocked planes [C/32][rows][32]
 template <int NP>
 __global__ void __launch_bounds__(256)
 est_split_kernel(const float* __restrict__ src, long rows, int C_src, int src_ld, int C, bf16_t* __restrict__ planes, size_t plane_stride) {
@@ -501,9 +527,10 @@ est_split_kernel(const float* __restrict__ src, long rows, int C_src, int src_ld
   const float x = (ch < C_src) ? src[r * src_ld + ch] : 0.f, y = (ch + 1 < C_src) ? src[r * src_ld + ch + 1] : 0.f;
   unsigned p0, p1, p2;
   split3(x, y, p0, p1, p2);
-  *reinterpret_cast<unsigned*>(planes + e) = p0;
-  if (NP > 1) *reinterpret_cast<unsigned*>(planes + plane_stride + e) = p1;
-  if (NP > 2) *reinterpret_cast<unsigned*>(planes + 2 * plane_stride + e) = p2;
+  const size_t at = kb_index((size_t)r, ch, (size_t)rows);
+  *reinterpret_cast<unsigned*>(planes + at) = p0;
+  if (NP > 1) *reinterpret_cast<unsigned*>(planes + plane_stride + at) = p1;
+  if (NP > 2) *reinterpret_cast<unsigned*>(planes + 2 * plane_stride + at) = p2;
 }
 
 }  // namespace
@@ -512,7 +539,7 @@ extern "C" int dfepe_est_points(void) { return kPts; }
 
 extern "C" int dfepe_est_split(const float* src, long rows, int C_src, int src_ld, int C, int n_planes, void* planes, size_t plane_stride,
                                void* stream) {
-  if (!src || !planes || rows < 0 || C <= 0 || (C & 1) || C_src <= 0 || C_src > C || n_planes < 1 || n_planes > 3) return DFEPE_ERR_INVALID_ARG;
+  if (!src || !planes || rows < 0 || C <= 0 || (C & 31) || C_src <= 0 || C_src > C || n_planes < 1 || n_planes > 3) return DFEPE_ERR_INVALID_ARG;
   if (rows == 0) return DFEPE_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const unsigned blocks = (unsigned)((rows * C / 2 + 255) / 256);
@@ -527,7 +554,7 @@ extern "C" int dfepe_est_split(const float* src, long rows, int C_src, int src_l
 extern "C" int dfepe_est_layer_fwd(const void* W, size_t w_plane, const void* X, size_t x_plane, int M, int ncols, int K,
                                    const float* gamma, const float* beta, float eps, float slope, void* planes_out,
                                    size_t out_plane, float* rstd, void* stream) {
-  if (!W || !X || !gamma || !beta || !planes_out || !rstd || M <= 0 || (M & 3) || ncols <= 0 || (ncols % kPts) || K <= 0 || (K % BK))
+  if (!W || !X || !gamma || !beta || !planes_out || !rstd || M <= 0 || (M & 31) || ncols <= 0 || (ncols % kPts) || K <= 0 || (K % BK))
     return DFEPE_ERR_INVALID_ARG;
   if (!(slope > 0.f)) return DFEPE_ERR_UNSUPPORTED;  // the backward inverts the activation
   EpiArgs E{};
@@ -542,7 +569,7 @@ extern "C" int dfepe_est_layer_fwd(const void* W, size_t w_plane, const void* X,
 // plain product: out[col][m] (fp32, ld = ldc) = sum_terms A_i[m][:] . B_j[col][:]; n_planes = 2 (three products) or 3 (six)
 extern "C" int dfepe_est_gemm_nt(const void* A, size_t a_plane, const void* B, size_t b_plane, int M, int ncols, int K, int n_planes,
                                  float* out, int ldc, void* stream) {
-  if (!A || !B || !out || M <= 0 || (M & 3) || ncols <= 0 || K <= 0 || (K % BK) || ldc < M) return DFEPE_ERR_INVALID_ARG;
+  if (!A || !B || !out || M <= 0 || (M & 7) || ncols <= 0 || K <= 0 || (K % BK) || ldc < M || (ldc & 3)) return DFEPE_ERR_INVALID_ARG;
   if (n_planes != 2 && n_planes != 3) return DFEPE_ERR_INVALID_ARG;
   EpiArgs E{};
   E.out = out; E.ldc = ldc;
@@ -560,7 +587,7 @@ extern "C" int dfepe_est_gemm_nt(const void* A, size_t a_plane, const void* B, s
 // weight gradient partials: part[slices][Cout][Cin]
 extern "C" int dfepe_est_gemm_tn(const void* dY, size_t dy_plane, int Cout, const void* X, size_t x_plane, int Cin, int ncols,
                                  int slices, float* part, void* stream) {
-  if (!dY || !X || !part || Cout <= 0 || Cin <= 0 || (Cout & 7) || (Cin & 7) || ncols <= 0 || slices <= 0) return DFEPE_ERR_INVALID_ARG;
+  if (!dY || !X || !part || Cout <= 0 || Cin <= 0 || (Cout & 31) || (Cin & 31) || ncols <= 0 || slices <= 0) return DFEPE_ERR_INVALID_ARG;
   int cps = (ncols + slices - 1) / slices;
   cps = ((cps + BK - 1) / BK) * BK;
   const dim3 grid((Cout + 127) / 128, (Cin + 127) / 128, slices), block(256);
@@ -573,7 +600,7 @@ extern "C" int dfepe_est_in_bwd(const float* dA, const float* dlogit, const floa
                                 const float* rstd, const float* gamma, const float* beta, float slope, int C, int ncols, void* dY,
                                 size_t dy_plane, float* dgamma_part, float* dbeta_part, void* stream) {
   if ((!dA && !(dlogit && w_head)) || !planes || !rstd || !gamma || !beta || !dY || !dgamma_part || !dbeta_part) return DFEPE_ERR_INVALID_ARG;
-  if (C <= 0 || (C & 1) || ncols <= 0 || (ncols % kPts) || !(slope > 0.f)) return DFEPE_ERR_INVALID_ARG;
+  if (C <= 0 || (C & 31) || ncols <= 0 || (ncols % kPts) || !(slope > 0.f)) return DFEPE_ERR_INVALID_ARG;
   const dim3 grid(ncols / kPts, (C + 63) / 64), block(256);
   hipLaunchKernelGGL(est_in_bwd_kernel, grid, block, 0, static_cast<hipStream_t>(stream), dA, dlogit, w_head,
                      static_cast<const bf16_t*>(planes), plane_stride, rstd, gamma, beta, slope, C, ncols, static_cast<bf16_t*>(dY), dy_plane,
@@ -583,7 +610,7 @@ extern "C" int dfepe_est_in_bwd(const float* dA, const float* dlogit, const floa
 
 extern "C" int dfepe_est_head_fwd(const void* planes, size_t plane_stride, int C, int ncols, const float* w, const float* bias,
                                   float* logits, void* stream) {
-  if (!planes || !w || !logits || C <= 0 || (C & 1) || ncols <= 0) return DFEPE_ERR_INVALID_ARG;
+  if (!planes || !w || !logits || C <= 0 || (C & 31) || ncols <= 0) return DFEPE_ERR_INVALID_ARG;
   hipLaunchKernelGGL(est_head_fwd_kernel, dim3((ncols + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const bf16_t*>(planes), plane_stride, C, ncols, w, bias, logits);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
@@ -591,7 +618,7 @@ extern "C" int dfepe_est_head_fwd(const void* planes, size_t plane_stride, int C
 
 extern "C" int dfepe_est_head_dw(const void* planes, size_t plane_stride, int C, int ncols, int blocks, const float* dlogit, float* part,
                                  void* stream) {
-  if (!planes || !dlogit || !part || C <= 0 || (C & 1) || ncols <= 0 || blocks <= 0) return DFEPE_ERR_INVALID_ARG;
+  if (!planes || !dlogit || !part || C <= 0 || (C & 31) || ncols <= 0 || blocks <= 0) return DFEPE_ERR_INVALID_ARG;
   const int cpb = (ncols + blocks - 1) / blocks;
   hipLaunchKernelGGL(est_head_dw_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(planes),
                      plane_stride, C, ncols, cpb, dlogit, part);

@@ -131,7 +131,7 @@ class _EstimatorFunction(torch.autograd.Function):
                 grads[4 * l] = partw.sum(0)[:, :Ci].reshape(W.shape).to(W.dtype)
                 need_dx = l > 0 or ctx.needs_input_grad[1]
                 if need_dx:
-                    Mp = (K + 3) // 4 * 4
+                    Mp = (K + 7) // 8 * 8
                     WT = torch.zeros(Mp, Co, device=dev, dtype=torch.float32)
                     WT[:Ci] = W.detach().float().reshape(Co, Ci).t()
                     WTp = _split(WT, Mp, Co, Co, 2)
