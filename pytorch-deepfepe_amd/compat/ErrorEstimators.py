@@ -62,7 +62,7 @@ class FusedErrorEstimator(ErrorEstimator):
                 hidden.append((mods[i].weight, mods[i].bias, mods[i + 1].weight, mods[i + 1].bias))
                 i += 3
             head, inorm, act = mods[i], mods[1], mods[2]
-            if i == len(mods) - 1 and act.negative_slope > 0 and all(m.affine for m in mods if isinstance(m, nn.InstanceNorm1d)):
+            if i == len(mods) - 1 and head.weight.shape[0] == 1 and act.negative_slope > 0 and all(m.affine for m in mods if isinstance(m, nn.InstanceNorm1d)):
                 return estimator.estimator_forward(data, hidden, (head.weight, head.bias), eps=inorm.eps, slope=act.negative_slope)
         if has_bn or (N % 4) or N > 512 or not data.is_cuda:
             return super().forward(data)

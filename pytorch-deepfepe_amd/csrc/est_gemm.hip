@@ -84,7 +84,7 @@ __device__ __forceinline__ size_t kb_index(size_t row, int ch, size_t rows) { re
 // f = (0, 2, 3, 1): each of the four 16-lane service groups of a ds_read_b128 then covers all 16 slots of the bank row
 __device__ __forceinline__ int chunk_swz(int rowgroup) { return (0x78 >> (2 * (rowgroup & 3))) & 3; }
 
-enum { EPI_F32 = 0, EPI_IN = 1 };
+enum { EPI_F32 = 0, EPI_IN = 1, EPI_INB = 2 };
 
 struct EpiArgs {
   // EPI_F32: out[col][m] fp32, ld = ldc
@@ -97,33 +97,41 @@ struct EpiArgs {
   bf16_t* planes;        // [3][ncols][M]
   size_t plane_stride;   // elements between planes
   float* rstd;           // [npairs][M]
+  // EPI_INB (data-gradient GEMM + InstanceNorm/LeakyReLU adjoint of the layer below): planes/plane_stride = dY out [2][...]
+  const bf16_t* aplanes;  // [3][M/32][ncols][32]: that layer's forward output
+  size_t a_stride;
+  const float* rstd_in;   // [npairs][M]
+  float* dgamma_part;     // [npairs][M]
+  float* dbeta_part;
 };
 
 // C[m][n] = sum over plane pairs (i, j), i + j <= ORDER, of A_i[m][:] . B_j[n][:]
 //   A: [NPA][M][K] (a_plane elements between planes), B: [NPB][ncols][K]; K % 32 == 0, M % 4 == 0.
 // Block (bx, by): columns [200 bx, 200 bx + 208), channels [128 by, 128 by + 128); 4 wavefronts, wavefront w owns channels
 // 32 w .. 32 w + 31 (two 16-row MFMA tiles) x all 13 column tiles: 26 accumulator tiles = 104 registers.
+// One LDS stage, two workgroups per CU: while one multiplies, the other waits for its LDS-DMA.  Measured alternatives at
+// B = 4096 (1024 -> 512 layer, 2.16 ms as built): two LDS stages with one workgroup per CU (DMA of step k + 1 under the MFMAs of
+// step k) 2.68 ms -- a lone wavefront per SIMD issues its 16 DMA instructions, 45 fragment reads and 156 MFMAs in order;
+// weights straight from global memory into a second register set + two LDS stages of the activations only, still two workgroups
+// per CU: 1.47 vs 1.43 ms with two planes (206 registers), spills with three.  The step is bound by instruction issue around the
+// MFMAs (DMA setup, fragment reads, barriers), not by an exposed load latency.
 template <int NPA, int NPB, int ORDER, int EPI>
 __global__ void __launch_bounds__(256, 2)
 est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* __restrict__ B, size_t b_plane, int M, int ncols, int K,
                    const EpiArgs E) {
-  constexpr int kABytes = NPA * 4 * BM * 16, kBBytes = NPB * 4 * BN * 16;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[kABytes + kBBytes];
+  constexpr int kABytes = NPA * BM * 64, kBBytes = NPB * BN * 64;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_all[kABytes + kBBytes];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
   // XCD-aware order: consecutive workgroup ids go round-robin to the 8 XCDs; the channel blocks of one column block share its
   // activation tile, so they are given consecutive slots of ONE XCD (its L2 then serves the re-reads)
   const int mblocks = (int)gridDim.y, cblocks = (int)gridDim.x;
   int bx = (int)blockIdx.x, by = (int)blockIdx.y;
-  {
+  if ((cblocks & 7) == 0) {
     const int id = by * cblocks + bx;  // linear dispatch order (x fastest)
-    const int total = mblocks * cblocks;
-    if ((cblocks & 7) == 0) {
-      const int xcd = id & 7, s = id >> 3;
-      by = s % mblocks;
-      bx = (s / mblocks) * 8 + xcd;
-    }
-    (void)total;
+    const int xcd = id & 7, s = id >> 3;
+    by = s % mblocks;
+    bx = (s / mblocks) * 8 + xcd;
   }
   const int m0 = by * BM, n0 = bx * BSTEP;
 
@@ -143,7 +151,7 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
   // lane and plane, 64 contiguous bytes per column, one contiguous KiB per store instruction
   const int fswA[2] = {chunk_swz(2 * (c >> 2)), chunk_swz(2 * (c >> 2) + 1)};
   const int nk = K / BK;
-  for (int ks = 0; ks < nk; ++ks) {
+  auto stage_issue = [&](int ks, unsigned char* lds) {
 #pragma unroll
     for (int i = 0; i < kPerWave; ++i) {
       const int t = wave + 4 * i;  // wave-uniform
@@ -164,15 +172,15 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
         __builtin_amdgcn_global_load_lds(DFEPE_GLOBAL_PTR(src), DFEPE_LDS_PTR(dst), 16, 0, 0);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // ---- MFMA phase -------------------------------------------------------------------------------------------------------
-    bf16x8 a[2][NPA];
+  };
+  auto a_from_lds = [&](const unsigned char* lds, bf16x8 (&a)[2][NPA]) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int p = 0; p < NPA; ++p)
         a[mt][p] = *reinterpret_cast<const bf16x8*>(lds + ((p * BM + wave * 32 + 8 * (c >> 2) + 4 * mt + (c & 3)) * 4 + (g ^ fswA[mt])) * 16);
+  };
+  auto mfma_phase = [&](const unsigned char* lds, const bf16x8 (&a)[2][NPA]) {
     // the column tile's B fragments are fetched one tile ahead of the MFMAs that consume them (two register sets): the LDS
     // latency of tile nt + 1 hides behind the twelve MFMAs of tile nt instead of stalling every tile
     bf16x8 b[2][NPB];
@@ -200,6 +208,15 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
         }
       __builtin_amdgcn_sched_barrier(0);
     }
+  };
+
+  for (int ks = 0; ks < nk; ++ks) {
+    stage_issue(ks, lds_all);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    bf16x8 a[2][NPA];
+    a_from_lds(lds_all, a);
+    mfma_phase(lds_all, a);
     __syncthreads();
   }
 
@@ -214,6 +231,117 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
         float* dst = E.out + (size_t)col * E.ldc + ch8;
         *reinterpret_cast<f32x4*>(dst) = acc[0][nt];
         *reinterpret_cast<f32x4*>(dst + 4) = acc[1][nt];
+      }
+    }
+  } else if constexpr (EPI == EPI_INB) {
+    // The accumulators hold dA = d loss / d (output of the layer below) for this tile; that layer's InstanceNorm + LeakyReLU adjoint
+    // runs here instead of in a kernel of its own (est_in_bwd_kernel: same arithmetic), so dA never travels through HBM:
+    //   a = lrelu(z), z = gamma x^ + beta (recovered from the stored planes), e = dA lrelu'(z),
+    //   dY = rstd gamma (e - mean(e) - x^ mean(e x^)) over the pair's 100 columns; d gamma = sum e x^, d beta = sum e.
+    // Two passes over the planes (x^ is not kept: 104 more registers would not fit): sums, then dY.
+    const float inv_n = 1.0f / (float)kPts;
+    const bool t6p0 = c < 4, t12ok = c < 8;
+    const int pair0 = 2 * bx;
+    const int chc = chok ? ch8 : 0;
+    const bool p0ok = (size_t)pair0 * kPts < (size_t)ncols, p1ok = (size_t)(pair0 + 1) * kPts < (size_t)ncols;
+    f32x4 gam[2], bet[2], ig[2], k0[2], k1[2];
+    const float islope = 1.0f / E.slope;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      gam[mt] = *reinterpret_cast<const f32x4*>(E.gamma + chc + 4 * mt);
+      bet[mt] = *reinterpret_cast<const f32x4*>(E.beta + chc + 4 * mt);
+      k0[mt] = *reinterpret_cast<const f32x4*>(E.rstd_in + (size_t)(p0ok ? pair0 : 0) * M + chc + 4 * mt);
+      k1[mt] = *reinterpret_cast<const f32x4*>(E.rstd_in + (size_t)(p1ok ? pair0 + 1 : 0) * M + chc + 4 * mt);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ig[mt][r] = (fabsf(gam[mt][r]) > 1e-30f) ? 1.0f / gam[mt][r] : 0.0f;
+        k0[mt][r] *= gam[mt][r]; k1[mt][r] *= gam[mt][r];
+      }
+    }
+    auto load_a = [&](int nt, float (&av)[2][4]) {  // the eight activations of this lane's column nt, all three planes
+      const int cl = nt * 16 + c;
+      int col = n0 + cl;
+      col = (col < ncols) ? col : ncols - 1;
+      const bf16_t* src = E.aplanes + kb_index((size_t)col, chc, (size_t)ncols);
+      const uint4 u0 = *reinterpret_cast<const uint4*>(src), u1 = *reinterpret_cast<const uint4*>(src + E.a_stride),
+                  u2 = *reinterpret_cast<const uint4*>(src + 2 * E.a_stride);
+      const unsigned w0[4] = {u0.x, u0.y, u0.z, u0.w}, w1[4] = {u1.x, u1.y, u1.z, u1.w}, w2[4] = {u2.x, u2.y, u2.z, u2.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        av[q >> 1][2 * (q & 1)] = (bf16_lo(w0[q]) + bf16_lo(w1[q])) + bf16_lo(w2[q]);
+        av[q >> 1][2 * (q & 1) + 1] = (bf16_hi(w0[q]) + bf16_hi(w1[q])) + bf16_hi(w2[q]);
+      }
+    };
+    f32x4 s1a[2], s1b[2], s2a[2], s2b[2];  // sums of e and e x^ over pair 0 (a) and pair 1 (b)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) { s1a[mt] = f32x4{0, 0, 0, 0}; s1b[mt] = s1a[mt]; s2a[mt] = s1a[mt]; s2b[mt] = s1a[mt]; }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const bool first = (nt < 6) || (nt == 6 && t6p0);
+      const bool inpair = (nt < 12) || t12ok;  // columns 200..207 belong to the next block
+      float av[2][4];
+      load_a(nt, av);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = av[mt][r];
+          const bool pos = a > 0.f;
+          const float z = pos ? a : a * islope;
+          float e = pos ? acc[mt][nt][r] : acc[mt][nt][r] * E.slope;
+          e = inpair ? e : 0.f;
+          const float xh = (z - bet[mt][r]) * ig[mt][r];
+          acc[mt][nt][r] = e;
+          const float ex = e * xh;
+          s1a[mt][r] += first ? e : 0.f; s1b[mt][r] += first ? 0.f : e;
+          s2a[mt][r] += first ? ex : 0.f; s2b[mt][r] += first ? 0.f : ex;
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s1a[mt][r] = row16_sum(s1a[mt][r]); s1b[mt][r] = row16_sum(s1b[mt][r]);
+        s2a[mt][r] = row16_sum(s2a[mt][r]); s2b[mt][r] = row16_sum(s2b[mt][r]);
+      }
+      if (chok && c == 0) {
+        if (p0ok) {
+          *reinterpret_cast<f32x4*>(E.dbeta_part + (size_t)pair0 * M + ch8 + 4 * mt) = s1a[mt];
+          *reinterpret_cast<f32x4*>(E.dgamma_part + (size_t)pair0 * M + ch8 + 4 * mt) = s2a[mt];
+        }
+        if (p1ok) {
+          *reinterpret_cast<f32x4*>(E.dbeta_part + (size_t)(pair0 + 1) * M + ch8 + 4 * mt) = s1b[mt];
+          *reinterpret_cast<f32x4*>(E.dgamma_part + (size_t)(pair0 + 1) * M + ch8 + 4 * mt) = s2b[mt];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s1a[mt][r] *= inv_n; s1b[mt][r] *= inv_n; s2a[mt][r] *= inv_n; s2b[mt][r] *= inv_n; }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const bool first = (nt < 6) || (nt == 6 && t6p0);
+      const int cl = nt * 16 + c, col = n0 + cl;
+      float av[2][4];
+      load_a(nt, av);
+      unsigned pl[2][4];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        float y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = av[mt][r];
+          const float z = (a > 0.f) ? a : a * islope;
+          const float xh = (z - bet[mt][r]) * ig[mt][r];
+          const float m1 = first ? s1a[mt][r] : s1b[mt][r], m2 = first ? s2a[mt][r] : s2b[mt][r];
+          y[r] = (first ? k0[mt][r] : k1[mt][r]) * (acc[mt][nt][r] - m1 - xh * m2);
+        }
+        split2(y[0], y[1], pl[0][2 * mt], pl[1][2 * mt]);
+        split2(y[2], y[3], pl[0][2 * mt + 1], pl[1][2 * mt + 1]);
+      }
+      if (cl < BSTEP && col < ncols && chok) {
+        bf16_t* dst = E.planes + kb_index((size_t)col, ch8, (size_t)ncols);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) *reinterpret_cast<uint4*>(dst + p * E.plane_stride) = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
       }
     }
   } else {
@@ -581,6 +709,23 @@ extern "C" int dfepe_est_gemm_nt(const void* A, size_t a_plane, const void* B, s
   else
     hipLaunchKernelGGL((est_gemm_nt_kernel<2, 2, 1, EPI_F32>), grid, block, 0, st, static_cast<const bf16_t*>(A), a_plane,
                        static_cast<const bf16_t*>(B), b_plane, M, ncols, K, E);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+// data gradient of layer l fused with the InstanceNorm + LeakyReLU adjoint of layer l - 1:
+//   dA = W_l^T dY_l (two planes each) stays in the accumulators; dY_{l-1} = adjoint(dA; a_{l-1}, rstd_{l-1}, gamma, beta) as two planes,
+//   per-pair contributions to d gamma / d beta of layer l - 1.  M = channels of layer l - 1 (% 32 == 0), K = channels of layer l.
+extern "C" int dfepe_est_layer_bwd_data(const void* WT, size_t wt_plane, const void* dY, size_t dy_plane, int M, int ncols, int K,
+                                        const void* a_prev, size_t a_plane, const float* rstd_prev, const float* gamma, const float* beta,
+                                        float slope, void* dY_prev, size_t dyp_plane, float* dgamma_part, float* dbeta_part, void* stream) {
+  if (!WT || !dY || !a_prev || !rstd_prev || !gamma || !beta || !dY_prev || !dgamma_part || !dbeta_part) return DFEPE_ERR_INVALID_ARG;
+  if (M <= 0 || (M & 31) || ncols <= 0 || (ncols % kPts) || K <= 0 || (K % BK) || !(slope > 0.f)) return DFEPE_ERR_INVALID_ARG;
+  EpiArgs E{};
+  E.gamma = gamma; E.beta = beta; E.slope = slope; E.planes = static_cast<bf16_t*>(dY_prev); E.plane_stride = dyp_plane;
+  E.aplanes = static_cast<const bf16_t*>(a_prev); E.a_stride = a_plane; E.rstd_in = rstd_prev; E.dgamma_part = dgamma_part; E.dbeta_part = dbeta_part;
+  const dim3 grid((ncols + BSTEP - 1) / BSTEP, (M + BM - 1) / BM), block(256);
+  hipLaunchKernelGGL((est_gemm_nt_kernel<2, 2, 1, EPI_INB>), grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(WT),
+                     wt_plane, static_cast<const bf16_t*>(dY), dy_plane, M, ncols, K, E);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
