@@ -300,6 +300,42 @@ int dfepe_inorm_lrelu_bwd(const float *Y, const float *gA, const float *gamma, c
                           int C, int R, int N, float slope, float *gY, float *row_ggamma, float *row_gbeta, void *stream);
 
 /*
+ * The weight estimator on the matrix cores, N = dfepe_est_points() = 100 points per pair.
+ * Replaces: ErrorEstimator.forward, the Conv1d(k=1) -> InstanceNorm1d(affine) -> LeakyReLU stack and its autograd backward
+ *           (deepFEPE/models/ErrorEstimators.py:47-64, called at deepFEPE/models/DeepFNet.py:441,510).
+ * Every fp32 operand travels as bf16 PLANES (a = a0 + a1 + a2, exact), a forward product = six bf16 MFMAs (fp32-class accuracy),
+ * a backward product = three.  Plane buffers are bf16, POINT-major and K-blocked: element (row, ch) of a plane with `rows` rows
+ * lives at ((ch / 32) * rows + row) * 32 + ch % 32; `*_plane` arguments are the element strides between planes; ncols = pairs * 100.
+ *   dfepe_est_split      fp32 [rows][C_src] (ld = src_ld) -> n_planes planes with C (% 32 == 0) channels, the tail zero
+ *   dfepe_est_layer_fwd  planes_out[3][...M] = split(leaky_relu(instance_norm(W X) * gamma + beta)); rstd [pairs][M];
+ *                        W planes [3] of [M][K], X planes [3] of [ncols][K]; the convolution bias cancels in the normalisation
+ *   dfepe_est_gemm_nt    out[col][m] (fp32, ld = ldc) = sum_k A[m][k] B[col][k] on n_planes (2 or 3) planes: the data gradient
+ *                        dA = W^T dY
+ *   dfepe_est_gemm_tn    part[slices][Cout][Cin] = split-K partial sums of dW = dY^T X (two planes each; the caller adds the slices)
+ *   dfepe_est_in_bwd     dY planes [2] = adjoint of InstanceNorm + LeakyReLU given dA [ncols][C] fp32 (or its rank-one head form
+ *                        dlogit[col] * w_head[c]), the layer's output planes [3], rstd, gamma, beta; per-pair d gamma / d beta
+ *   dfepe_est_head_fwd   logits[col] = sum_c w[c] a[col][c] + bias[0]   (the last Conv1d(C -> 1))
+ *   dfepe_est_head_dw    part[blocks][C] = partial sums of d w = sum_col dlogit[col] a[col][c]
+ */
+int dfepe_est_points(void);
+int dfepe_est_split(const float *src, long rows, int C_src, int src_ld, int C, int n_planes, void *planes, size_t plane_stride,
+                    void *stream);
+int dfepe_est_layer_fwd(const void *W, size_t w_plane, const void *X, size_t x_plane, int M, int ncols, int K,
+                        const float *gamma, const float *beta, float eps, float slope, void *planes_out, size_t out_plane,
+                        float *rstd, void *stream);
+int dfepe_est_gemm_nt(const void *A, size_t a_plane, const void *B, size_t b_plane, int M, int ncols, int K, int n_planes,
+                      float *out, int ldc, void *stream);
+int dfepe_est_gemm_tn(const void *dY, size_t dy_plane, int Cout, const void *X, size_t x_plane, int Cin, int ncols, int slices,
+                      float *part, void *stream);
+int dfepe_est_in_bwd(const float *dA, const float *dlogit, const float *w_head, const void *planes, size_t plane_stride,
+                     const float *rstd, const float *gamma, const float *beta, float slope, int C, int ncols, void *dY,
+                     size_t dy_plane, float *dgamma_part, float *dbeta_part, void *stream);
+int dfepe_est_head_fwd(const void *planes, size_t plane_stride, int C, int ncols, const float *w, const float *bias, float *logits,
+                       void *stream);
+int dfepe_est_head_dw(const void *planes, size_t plane_stride, int C, int ncols, int blocks, const float *dlogit, float *part,
+                      void *stream);
+
+/*
  * Match construction: what produces the [B,N,4] correspondences of dfepe_w8pt_fwd.
  * Replaces the per-pair host loop of get_matches_from_SP (deepFEPE/train_good_utils.py:683-716):
  *   SP_tracker.nn_match_two_way(desc1.T, desc2.T, nn_thresh)  (:687-691; PointTracker of the un-vendored `superpoint`

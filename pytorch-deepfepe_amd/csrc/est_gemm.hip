@@ -27,7 +27,9 @@
 //   est_gemm_tn   dW[co][ci] = sum_cols dY[col][co] X[col][ci]: both operands are K-major here, fragments come from
 //                 ds_read_b64_tr_b16 (the LDS transpose read) of an XOR-swizzled [k][128 channels] image, split-K over columns.
 //   est_in_bwd    InstanceNorm + LeakyReLU adjoint in the point-major layout (x^ and the activation sign recovered from the
-//                 stored planes), writes dY as two planes.
+//                 stored planes), writes dY as two planes.  (Run as the data-gradient GEMM's epilogue instead -- dA kept in the
+//                 accumulators -- it needs x^ or a second pass over the planes on top of 104 accumulator registers: it spilled
+//                 and measured 12.05 against 11.95 ms per call for the two kernels; this kernel streams at 5 TB/s.)
 //   est_head_*    the last Conv1d(256 -> 1) and its adjoint pieces (a GEMV: VALU, HBM-bound).
 #include "dfepe_common.h"
 
@@ -84,7 +86,7 @@ __device__ __forceinline__ size_t kb_index(size_t row, int ch, size_t rows) { re
 // f = (0, 2, 3, 1): each of the four 16-lane service groups of a ds_read_b128 then covers all 16 slots of the bank row
 __device__ __forceinline__ int chunk_swz(int rowgroup) { return (0x78 >> (2 * (rowgroup & 3))) & 3; }
 
-enum { EPI_F32 = 0, EPI_IN = 1, EPI_INB = 2 };
+enum { EPI_F32 = 0, EPI_IN = 1 };
 
 struct EpiArgs {
   // EPI_F32: out[col][m] fp32, ld = ldc
@@ -97,12 +99,6 @@ struct EpiArgs {
   bf16_t* planes;        // [3][ncols][M]
   size_t plane_stride;   // elements between planes
   float* rstd;           // [npairs][M]
-  // EPI_INB (data-gradient GEMM + InstanceNorm/LeakyReLU adjoint of the layer below): planes/plane_stride = dY out [2][...]
-  const bf16_t* aplanes;  // [3][M/32][ncols][32]: that layer's forward output
-  size_t a_stride;
-  const float* rstd_in;   // [npairs][M]
-  float* dgamma_part;     // [npairs][M]
-  float* dbeta_part;
 };
 
 // C[m][n] = sum over plane pairs (i, j), i + j <= ORDER, of A_i[m][:] . B_j[n][:]
@@ -231,117 +227,6 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
         float* dst = E.out + (size_t)col * E.ldc + ch8;
         *reinterpret_cast<f32x4*>(dst) = acc[0][nt];
         *reinterpret_cast<f32x4*>(dst + 4) = acc[1][nt];
-      }
-    }
-  } else if constexpr (EPI == EPI_INB) {
-    // The accumulators hold dA = d loss / d (output of the layer below) for this tile; that layer's InstanceNorm + LeakyReLU adjoint
-    // runs here instead of in a kernel of its own (est_in_bwd_kernel: same arithmetic), so dA never travels through HBM:
-    //   a = lrelu(z), z = gamma x^ + beta (recovered from the stored planes), e = dA lrelu'(z),
-    //   dY = rstd gamma (e - mean(e) - x^ mean(e x^)) over the pair's 100 columns; d gamma = sum e x^, d beta = sum e.
-    // Two passes over the planes (x^ is not kept: 104 more registers would not fit): sums, then dY.
-    const float inv_n = 1.0f / (float)kPts;
-    const bool t6p0 = c < 4, t12ok = c < 8;
-    const int pair0 = 2 * bx;
-    const int chc = chok ? ch8 : 0;
-    const bool p0ok = (size_t)pair0 * kPts < (size_t)ncols, p1ok = (size_t)(pair0 + 1) * kPts < (size_t)ncols;
-    f32x4 gam[2], bet[2], ig[2], k0[2], k1[2];
-    const float islope = 1.0f / E.slope;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      gam[mt] = *reinterpret_cast<const f32x4*>(E.gamma + chc + 4 * mt);
-      bet[mt] = *reinterpret_cast<const f32x4*>(E.beta + chc + 4 * mt);
-      k0[mt] = *reinterpret_cast<const f32x4*>(E.rstd_in + (size_t)(p0ok ? pair0 : 0) * M + chc + 4 * mt);
-      k1[mt] = *reinterpret_cast<const f32x4*>(E.rstd_in + (size_t)(p1ok ? pair0 + 1 : 0) * M + chc + 4 * mt);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        ig[mt][r] = (fabsf(gam[mt][r]) > 1e-30f) ? 1.0f / gam[mt][r] : 0.0f;
-        k0[mt][r] *= gam[mt][r]; k1[mt][r] *= gam[mt][r];
-      }
-    }
-    auto load_a = [&](int nt, float (&av)[2][4]) {  // the eight activations of this lane's column nt, all three planes
-      const int cl = nt * 16 + c;
-      int col = n0 + cl;
-      col = (col < ncols) ? col : ncols - 1;
-      const bf16_t* src = E.aplanes + kb_index((size_t)col, chc, (size_t)ncols);
-      const uint4 u0 = *reinterpret_cast<const uint4*>(src), u1 = *reinterpret_cast<const uint4*>(src + E.a_stride),
-                  u2 = *reinterpret_cast<const uint4*>(src + 2 * E.a_stride);
-      const unsigned w0[4] = {u0.x, u0.y, u0.z, u0.w}, w1[4] = {u1.x, u1.y, u1.z, u1.w}, w2[4] = {u2.x, u2.y, u2.z, u2.w};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        av[q >> 1][2 * (q & 1)] = (bf16_lo(w0[q]) + bf16_lo(w1[q])) + bf16_lo(w2[q]);
-        av[q >> 1][2 * (q & 1) + 1] = (bf16_hi(w0[q]) + bf16_hi(w1[q])) + bf16_hi(w2[q]);
-      }
-    };
-    f32x4 s1a[2], s1b[2], s2a[2], s2b[2];  // sums of e and e x^ over pair 0 (a) and pair 1 (b)
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) { s1a[mt] = f32x4{0, 0, 0, 0}; s1b[mt] = s1a[mt]; s2a[mt] = s1a[mt]; s2b[mt] = s1a[mt]; }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const bool first = (nt < 6) || (nt == 6 && t6p0);
-      const bool inpair = (nt < 12) || t12ok;  // columns 200..207 belong to the next block
-      float av[2][4];
-      load_a(nt, av);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float a = av[mt][r];
-          const bool pos = a > 0.f;
-          const float z = pos ? a : a * islope;
-          float e = pos ? acc[mt][nt][r] : acc[mt][nt][r] * E.slope;
-          e = inpair ? e : 0.f;
-          const float xh = (z - bet[mt][r]) * ig[mt][r];
-          acc[mt][nt][r] = e;
-          const float ex = e * xh;
-          s1a[mt][r] += first ? e : 0.f; s1b[mt][r] += first ? 0.f : e;
-          s2a[mt][r] += first ? ex : 0.f; s2b[mt][r] += first ? 0.f : ex;
-        }
-    }
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s1a[mt][r] = row16_sum(s1a[mt][r]); s1b[mt][r] = row16_sum(s1b[mt][r]);
-        s2a[mt][r] = row16_sum(s2a[mt][r]); s2b[mt][r] = row16_sum(s2b[mt][r]);
-      }
-      if (chok && c == 0) {
-        if (p0ok) {
-          *reinterpret_cast<f32x4*>(E.dbeta_part + (size_t)pair0 * M + ch8 + 4 * mt) = s1a[mt];
-          *reinterpret_cast<f32x4*>(E.dgamma_part + (size_t)pair0 * M + ch8 + 4 * mt) = s2a[mt];
-        }
-        if (p1ok) {
-          *reinterpret_cast<f32x4*>(E.dbeta_part + (size_t)(pair0 + 1) * M + ch8 + 4 * mt) = s1b[mt];
-          *reinterpret_cast<f32x4*>(E.dgamma_part + (size_t)(pair0 + 1) * M + ch8 + 4 * mt) = s2b[mt];
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { s1a[mt][r] *= inv_n; s1b[mt][r] *= inv_n; s2a[mt][r] *= inv_n; s2b[mt][r] *= inv_n; }
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const bool first = (nt < 6) || (nt == 6 && t6p0);
-      const int cl = nt * 16 + c, col = n0 + cl;
-      float av[2][4];
-      load_a(nt, av);
-      unsigned pl[2][4];
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        float y[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float a = av[mt][r];
-          const float z = (a > 0.f) ? a : a * islope;
-          const float xh = (z - bet[mt][r]) * ig[mt][r];
-          const float m1 = first ? s1a[mt][r] : s1b[mt][r], m2 = first ? s2a[mt][r] : s2b[mt][r];
-          y[r] = (first ? k0[mt][r] : k1[mt][r]) * (acc[mt][nt][r] - m1 - xh * m2);
-        }
-        split2(y[0], y[1], pl[0][2 * mt], pl[1][2 * mt]);
-        split2(y[2], y[3], pl[0][2 * mt + 1], pl[1][2 * mt + 1]);
-      }
-      if (cl < BSTEP && col < ncols && chok) {
-        bf16_t* dst = E.planes + kb_index((size_t)col, ch8, (size_t)ncols);
-#pragma unroll
-        for (int p = 0; p < 2; ++p) *reinterpret_cast<uint4*>(dst + p * E.plane_stride) = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
       }
     }
   } else {
@@ -709,23 +594,6 @@ extern "C" int dfepe_est_gemm_nt(const void* A, size_t a_plane, const void* B, s
   else
     hipLaunchKernelGGL((est_gemm_nt_kernel<2, 2, 1, EPI_F32>), grid, block, 0, st, static_cast<const bf16_t*>(A), a_plane,
                        static_cast<const bf16_t*>(B), b_plane, M, ncols, K, E);
-  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
-}
-
-// data gradient of layer l fused with the InstanceNorm + LeakyReLU adjoint of layer l - 1:
-//   dA = W_l^T dY_l (two planes each) stays in the accumulators; dY_{l-1} = adjoint(dA; a_{l-1}, rstd_{l-1}, gamma, beta) as two planes,
-//   per-pair contributions to d gamma / d beta of layer l - 1.  M = channels of layer l - 1 (% 32 == 0), K = channels of layer l.
-extern "C" int dfepe_est_layer_bwd_data(const void* WT, size_t wt_plane, const void* dY, size_t dy_plane, int M, int ncols, int K,
-                                        const void* a_prev, size_t a_plane, const float* rstd_prev, const float* gamma, const float* beta,
-                                        float slope, void* dY_prev, size_t dyp_plane, float* dgamma_part, float* dbeta_part, void* stream) {
-  if (!WT || !dY || !a_prev || !rstd_prev || !gamma || !beta || !dY_prev || !dgamma_part || !dbeta_part) return DFEPE_ERR_INVALID_ARG;
-  if (M <= 0 || (M & 31) || ncols <= 0 || (ncols % kPts) || K <= 0 || (K % BK) || !(slope > 0.f)) return DFEPE_ERR_INVALID_ARG;
-  EpiArgs E{};
-  E.gamma = gamma; E.beta = beta; E.slope = slope; E.planes = static_cast<bf16_t*>(dY_prev); E.plane_stride = dyp_plane;
-  E.aplanes = static_cast<const bf16_t*>(a_prev); E.a_stride = a_plane; E.rstd_in = rstd_prev; E.dgamma_part = dgamma_part; E.dbeta_part = dbeta_part;
-  const dim3 grid((ncols + BSTEP - 1) / BSTEP, (M + BM - 1) / BM), block(256);
-  hipLaunchKernelGGL((est_gemm_nt_kernel<2, 2, 1, EPI_INB>), grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(WT),
-                     wt_plane, static_cast<const bf16_t*>(dY), dy_plane, M, ncols, K, E);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 

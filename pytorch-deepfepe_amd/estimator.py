@@ -107,22 +107,19 @@ class _EstimatorFunction(torch.autograd.Function):
             grads[4 * n_hidden] = part.sum(0).reshape(Wh.shape).to(Wh.dtype)
             if ctx.has_head_bias:
                 grads[4 * n_hidden + 1] = dl.sum().reshape(1).to(params[4 * n_hidden + 1].dtype)
-            # hidden layer n: its adjoint starts from the head's rank-one gradient dlogit[col] * w_head[c]
-            l = n_hidden - 1
-            W, bconv, gamma, beta = params[4 * l:4 * l + 4]
-            Co = W.shape[0]
-            dY = torch.empty(2, cols, Co, device=dev, dtype=BF16)
-            dg = torch.empty(B, Co, device=dev, dtype=torch.float32)
-            db = torch.empty(B, Co, device=dev, dtype=torch.float32)
-            rc = lib.dfepe_est_in_bwd(None, _ptr(dl), _ptr(wh), _ptr(acts[l + 1]), cols * Co, _ptr(rstds[l]), _ptr(gamma.detach().float().contiguous()),
-                                      _ptr(beta.detach().float().contiguous()), float(slope), Co, cols, _ptr(dY), cols * Co, _ptr(dg), _ptr(db), st)
-            _lib.check(rc, "dfepe_est_in_bwd")
-            dA0 = None
+            dA = None  # fp32 [cols, C_l]: gradient w.r.t. the output of hidden layer l (None: the rank-one head form)
             for l in range(n_hidden - 1, -1, -1):
                 W, bconv, gamma, beta = params[4 * l:4 * l + 4]
                 Co, Ci = W.shape[0], W.shape[1]
-                a_in = acts[l]
+                a_out, a_in = acts[l + 1], acts[l]
                 K = a_in.shape[2]
+                dY = torch.empty(2, cols, Co, device=dev, dtype=BF16)
+                dg = torch.empty(B, Co, device=dev, dtype=torch.float32)
+                db = torch.empty(B, Co, device=dev, dtype=torch.float32)
+                rc = lib.dfepe_est_in_bwd(_ptr(dA), _ptr(dl if dA is None else None), _ptr(wh if dA is None else None), _ptr(a_out), cols * Co,
+                                          _ptr(rstds[l]), _ptr(gamma.detach().float().contiguous()), _ptr(beta.detach().float().contiguous()),
+                                          float(slope), Co, cols, _ptr(dY), cols * Co, _ptr(dg), _ptr(db), st)
+                _lib.check(rc, "dfepe_est_in_bwd")
                 grads[4 * l + 2] = dg.sum(0).to(gamma.dtype)
                 grads[4 * l + 3] = db.sum(0).to(beta.dtype)
                 grads[4 * l + 1] = torch.zeros_like(bconv)  # the bias cancels in the instance normalisation: exact zero, like the reference's autograd
@@ -132,30 +129,19 @@ class _EstimatorFunction(torch.autograd.Function):
                 rc = lib.dfepe_est_gemm_tn(_ptr(dY), cols * Co, Co, _ptr(a_in), cols * K, K, cols, slices, _ptr(partw), st)
                 _lib.check(rc, "dfepe_est_gemm_tn")
                 grads[4 * l] = partw.sum(0)[:, :Ci].reshape(W.shape).to(W.dtype)
-                if l > 0:
-                    # dA_{l-1} = W^T dY, and the adjoint of layer l-1's InstanceNorm + LeakyReLU in the same kernel's epilogue
-                    Wp_, bp_, gprev, bprev = params[4 * (l - 1):4 * l]
-                    WTp = _split(W.detach().float().reshape(Co, Ci).t().contiguous(), Ci, Co, Co, 2)
-                    dYp = torch.empty(2, cols, Ci, device=dev, dtype=BF16)
-                    dg = torch.empty(B, Ci, device=dev, dtype=torch.float32)
-                    db = torch.empty(B, Ci, device=dev, dtype=torch.float32)
-                    rc = lib.dfepe_est_layer_bwd_data(_ptr(WTp), Ci * Co, _ptr(dY), cols * Co, Ci, cols, Co, _ptr(a_in), cols * Ci, _ptr(rstds[l - 1]),
-                                                      _ptr(gprev.detach().float().contiguous()), _ptr(bprev.detach().float().contiguous()), float(slope),
-                                                      _ptr(dYp), cols * Ci, _ptr(dg), _ptr(db), st)
-                    _lib.check(rc, "dfepe_est_layer_bwd_data")
-                    dY = dYp
-                elif ctx.needs_input_grad[1]:
+                need_dx = l > 0 or ctx.needs_input_grad[1]
+                if need_dx:
                     Mp = (K + 7) // 8 * 8
                     WT = torch.zeros(Mp, Co, device=dev, dtype=torch.float32)
                     WT[:Ci] = W.detach().float().reshape(Co, Ci).t()
                     WTp = _split(WT, Mp, Co, Co, 2)
-                    dA0 = torch.empty(cols, Mp, device=dev, dtype=torch.float32)
-                    rc = lib.dfepe_est_gemm_nt(_ptr(WTp), Mp * Co, _ptr(dY), cols * Co, Mp, cols, Co, 2, _ptr(dA0), Mp, st)
+                    dA = torch.empty(cols, Mp, device=dev, dtype=torch.float32)
+                    rc = lib.dfepe_est_gemm_nt(_ptr(WTp), Mp * Co, _ptr(dY), cols * Co, Mp, cols, Co, 2, _ptr(dA), Mp, st)
                     _lib.check(rc, "dfepe_est_gemm_nt")
-            del dY
+                del dY
             gx = None
             if ctx.needs_input_grad[1]:
-                gx = dA0[:, :C0].reshape(B, N, C0).permute(0, 2, 1).contiguous()
+                gx = dA[:, :C0].reshape(B, N, C0).permute(0, 2, 1).contiguous()
         ctx.acts = ctx.rstds = None
         return (None, gx, *grads)
 

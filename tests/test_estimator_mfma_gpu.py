@@ -139,36 +139,6 @@ def test_gemm_tn_weight_gradient(dfepe, Cout, Cin, pairs, slices):
     assert err < 3e-5, err
 
 
-@pytest.mark.parametrize("M,K,pairs", [(64, 128, 3), (1024, 512, 2), (128, 1024, 5)])
-def test_fused_data_gradient_equals_gemm_plus_adjoint(dfepe, M, K, pairs):
-    """dfepe_est_layer_bwd_data (W^T dY with the layer-below InstanceNorm/LeakyReLU adjoint in the epilogue) against the two
-    kernels it replaces run one after the other (plain product to fp32, then est_in_bwd): same planes, same per-pair partials."""
-    lib = dfepe._lib.lib()
-    cols = pairs * 100
-    g = torch.Generator().manual_seed(M + K)
-    WT = (torch.randn(M, K, generator=g) / K ** 0.5).to(DEV)
-    dYf = torch.randn(cols, K, generator=g).to(DEV)
-    a = torch.nn.functional.leaky_relu(torch.randn(cols, M, generator=g), 0.01).to(DEV)
-    gamma = (1 + 0.2 * torch.randn(M, generator=g)).to(DEV)
-    beta = (0.3 * torch.randn(M, generator=g)).to(DEV)
-    rstd = (0.5 + torch.rand(pairs, M, generator=g)).to(DEV)
-    WTp, dYp, ap = _split(dfepe, WT, K, 2), _split(dfepe, dYf, K, 2), _split(dfepe, a, M, 3)
-    # reference: two kernels
-    dA = torch.empty(cols, M, device=DEV)
-    assert lib.dfepe_est_gemm_nt(WTp.data_ptr(), M * K, dYp.data_ptr(), cols * K, M, cols, K, 2, dA.data_ptr(), M, None) == 0
-    ref = torch.zeros(2, cols, M, device=DEV, dtype=torch.bfloat16)
-    rg, rb = torch.zeros(pairs, M, device=DEV), torch.zeros(pairs, M, device=DEV)
-    assert lib.dfepe_est_in_bwd(dA.data_ptr(), None, None, ap.data_ptr(), cols * M, rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 0.01, M, cols,
-                                ref.data_ptr(), cols * M, rg.data_ptr(), rb.data_ptr(), None) == 0
-    out = torch.zeros(2, cols, M, device=DEV, dtype=torch.bfloat16)
-    og, ob = torch.zeros(pairs, M, device=DEV), torch.zeros(pairs, M, device=DEV)
-    assert lib.dfepe_est_layer_bwd_data(WTp.data_ptr(), M * K, dYp.data_ptr(), cols * K, M, cols, K, ap.data_ptr(), cols * M, rstd.data_ptr(),
-                                        gamma.data_ptr(), beta.data_ptr(), 0.01, out.data_ptr(), cols * M, og.data_ptr(), ob.data_ptr(), None) == 0
-    torch.cuda.synchronize()
-    assert relerr(planes_to_f64(out), planes_to_f64(ref)) < 2e-5  # different summation order of the per-pair sums
-    assert relerr(og, rg) < 2e-5 and relerr(ob, rb) < 2e-5
-
-
 def test_head_forward_and_weight_gradient(dfepe):
     lib = dfepe._lib.lib()
     C, cols = 256, 700
