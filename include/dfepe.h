@@ -53,15 +53,13 @@ extern "C" {
 #define DFEPE_W8PT_NO_HARTLEY 32u /* no Hartley normalisation, T1 = T2 = I (`normalize=False` of _E_from_XY /
                                      _F_from_XY, utils_F.py:116-119,233-236)                                 */
 
-#define DFEPE_W8PT_WAVE_PER_PAIR 64u /* scheduling only, same function: use the round-1 one-wavefront- (or workgroup-) per-pair
-                                        kernels (fp32 Jacobi + fp64 polish, correspondences staged in LDS, N <= ~8000) instead of
-                                        the row-per-pair kernels (one 16-lane DPP row per pair, four pairs per wavefront, fp64
-                                        tridiagonal eigen-solver, any N); pass the same bit to dfepe_w8pt_bwd, whose `save`
-                                        record format follows the forward kernel.  Without the bit the library picks: rows for
-                                        N <= DFEPE_W8PT16_MAX_N and for any N once the launch has >= 2048 pairs, else these. */
+#define DFEPE_W8PT_ROW_PER_PAIR 64u /* scheduling only, same function, same `save` record: never spread a pair over the 16 rows of
+                                       a cooperative workgroup (what the library does for 128 < N <= 2048 below 3072 pairs);
+                                       one 16-lane row per pair, correspondences re-read per phase.  A/B timing; pass the same
+                                       bit to dfepe_w8pt_bwd or not, the record format does not depend on it.             */
 #define DFEPE_W8PT_ALL_FLAGS 127u   /* any other bit in `flags` is DFEPE_ERR_INVALID_ARG                              */
-#define DFEPE_W8PT16_MAX_N 128      /* largest N whose correspondences the row-per-pair kernels keep in registers for the whole
-                                       kernel (one HBM read); larger N re-reads them per phase (L2 hits)                 */
+#define DFEPE_W8PT16_MAX_N 128      /* largest N whose correspondences ONE row keeps in registers for the whole kernel; above it
+                                       a cooperative workgroup per pair does (N <= 2048), or they are re-read per phase       */
 
 int dfepe_version(void);
 const char *dfepe_strerror(int code);

@@ -20,7 +20,7 @@ W8PT_SQRT2 = 4
 W8PT_NO_ROWNORM = 8
 W8PT_FORCE_110 = 16
 W8PT_NO_HARTLEY = 32
-W8PT_WAVE_PER_PAIR = 64
+W8PT_ROW_PER_PAIR = 64
 W8PT16_MAX_N = 128
 TAIL_MAX_LAYERS = 16  # dfepe_loss_tail: layers per launch (kTailMaxLayers, csrc/loss_tail_body.h)
 EPI_HOMOGENEOUS = 8

@@ -361,8 +361,8 @@ __global__ void __launch_bounds__(256)
 cheirality_kernel(const float* __restrict__ E, const float* __restrict__ pre, const float* __restrict__ K,
                   const float* __restrict__ matches, int B, int N, float depth_thres, float* __restrict__ Rt_cam,
                   int* __restrict__ winner, int* __restrict__ counts) {
-  // one workgroup per pair; with 256 threads the four wavefronts take every fourth group of 64 correspondences and meet in LDS
-  __shared__ int wcnt[4][4];
+  // one workgroup per pair; with W wavefronts each takes every W-th group of 64 correspondences and they meet in LDS
+  __shared__ int wcnt[8][4];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
   const size_t pair = blockIdx.x;
@@ -476,7 +476,11 @@ cheirality_kernel(const float* __restrict__ E, const float* __restrict__ pre, co
   if (wave != 0) return;
   if (nw > 1) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) cnt[c] = (wcnt[0][c] + wcnt[1][c]) + (wcnt[2][c] + wcnt[3][c]);
+    for (int c = 0; c < 4; ++c) {
+      int tsum = 0;
+      for (int w = 0; w < nw; ++w) tsum += wcnt[w][c];
+      cnt[c] = tsum;
+    }
   }
   int win = 0;
 #pragma unroll
@@ -551,7 +555,10 @@ extern "C" int dfepe_cheirality(const float* E, const float* pre, const float* K
   if (B == 0) return DFEPE_OK;
   if (!E || !K || !matches || !Rt_cam) return DFEPE_ERR_INVALID_ARG;
   if (reinterpret_cast<uintptr_t>(matches) & 15u) return DFEPE_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(cheirality_kernel, dim3(B), dim3(B >= 2048 ? 64 : 256), 0, static_cast<hipStream_t>(stream), E, pre, K, matches,
+  // wavefronts per pair: throughput wants one (B >= 2048: every SIMD already holds >= 2 pairs), latency wants four (eight would
+  // not help: at 170 registers a CU holds eight wavefronts either way, i.e. two 4-wavefront pairs or one 8-wavefront pair)
+  const int threads = (B >= 2048) ? 64 : 256;
+  hipLaunchKernelGGL(cheirality_kernel, dim3(B), dim3(threads), 0, static_cast<hipStream_t>(stream), E, pre, K, matches,
                      B, N, depth_thres, Rt_cam, winner, counts);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }

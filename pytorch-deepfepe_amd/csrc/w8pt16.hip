@@ -11,6 +11,13 @@
 namespace {
 
 constexpr int kPairsPerBlock = 16;
+constexpr int kCoopMaxN = 2048;  // cooperative workgroup per pair: N / 256 correspondences per lane in registers (IT <= 8)
+// ... while the batch is small: the solver phase needs ~256 registers, so two workgroups (two pairs) fit a CU and a launch
+// takes ceil(pairs / 512) rounds of ~13 us (N = 1000); from 4096 pairs on one row per pair (IT = 0, 78 us) is faster
+constexpr int kCoopMaxPairs = 3072;
+// the forward and the backward agree on this by construction (same N, same pair count, same flag), and the `save` record is the
+// same either way
+static bool use_coop(int N, int pairs, bool row_per_pair) { return N > 128 && N <= kCoopMaxN && pairs <= kCoopMaxPairs && !row_per_pair; }
 
 // Kernel arguments (forward and backward alike): what a wavefront needs before it can issue its global loads comes first, as plain scalars / pointers --
 // with -amdgpu-kernarg-preload-count=16 (build.py) the command processor hands those 16 dwords over in SGPRs at wave launch,
@@ -35,8 +42,22 @@ w8pt16_fwd_kernel(const float* pts1, const float* pts2, const float* wts, int B,
   W8Args A;
   A.pts1 = pts1; A.pts2 = pts2; A.wts = wts; A.B = B; A.Bm = Bm; A.N = N; A.hw_sx = hw_sx; A.hw_sy = hw_sy;
   A.clamp_at = clamp_at; A.F_out = F_out; A.residual = residual; A.epi_res = R.epi_res; A.save = R.save;
-  A.weights_out = R.weights_out; A.logits_mode = R.logits_mode; A.variant = R.variant;
+  A.weights_out = R.weights_out; A.logits_mode = R.logits_mode; A.variant = R.variant; A.row_per_pair = false;
   w8pt16_fwd_pair<IT, RAW, PLAIN>(A, pair, xch + row * 36);
+}
+
+// Cooperative variant: one 256-thread workgroup (16 rows) per pair, for N > 128 (w8pt16_body.h: W8Coop).
+template <int IT, bool RAW, bool PLAIN>
+__global__ void __launch_bounds__(256, (IT <= 4 ? 2 : 1))  // two workgroups per CU (<= 256 registers) while the correspondences allow it
+w8pt16_coop_fwd_kernel(const float* pts1, const float* pts2, const float* wts, int B, int Bm, int N, float hw_sx, float hw_sy,
+                       float clamp_at, float* F_out, float* residual, const W8FwdRest R) {
+  __shared__ W8Coop co;
+  const int pair = (int)blockIdx.x;
+  W8Args A;
+  A.pts1 = pts1; A.pts2 = pts2; A.wts = wts; A.B = B; A.Bm = Bm; A.N = N; A.hw_sx = hw_sx; A.hw_sy = hw_sy;
+  A.clamp_at = clamp_at; A.F_out = F_out; A.residual = residual; A.epi_res = R.epi_res; A.save = R.save;
+  A.weights_out = R.weights_out; A.logits_mode = R.logits_mode; A.variant = R.variant; A.row_per_pair = false;
+  w8pt16_fwd_pair<IT, RAW, PLAIN, 16>(A, pair, nullptr, &co, (int)(threadIdx.x >> 4));
 }
 
 struct W8BwdRest {
@@ -64,8 +85,22 @@ w8pt16_bwd_kernel(const float* pts1, const float* pts2, const float* wts, int B,
   A.pts1 = pts1; A.pts2 = pts2; A.wts = wts; A.B = B; A.Bm = Bm; A.N = N; A.hw_sx = hw_sx; A.hw_sy = hw_sy;
   A.clamp_at = clamp_at; A.save = save; A.F_out = R.F_out; A.g_F = R.g_F; A.g_res = R.g_res; A.g_epi = R.g_epi;
   A.g_w_extra = R.g_w_extra; A.g_scale = R.g_scale; A.g_w = R.g_w; A.g_p1 = R.g_p1; A.g_p2 = R.g_p2;
-  A.logits_mode = R.logits_mode; A.variant = R.variant; A.pending_head = nullptr;
+  A.logits_mode = R.logits_mode; A.variant = R.variant; A.pending_head = nullptr; A.row_per_pair = false;
   w8pt16_bwd_pair_impl<IT, RAW, PGRAD, PLAIN>(A, pair, nullptr);
+}
+
+template <int IT, bool RAW>
+__global__ void __launch_bounds__(256, (IT <= 4 ? 2 : 1))
+w8pt16_coop_bwd_kernel(const float* pts1, const float* pts2, const float* wts, int B, int Bm, int N, float hw_sx, float hw_sy,
+                       float clamp_at, const float* save, const W8BwdRest R) {
+  __shared__ W8BwdCoop co;
+  const int pair = (int)blockIdx.x;
+  W8BwdArgs A;
+  A.pts1 = pts1; A.pts2 = pts2; A.wts = wts; A.B = B; A.Bm = Bm; A.N = N; A.hw_sx = hw_sx; A.hw_sy = hw_sy;
+  A.clamp_at = clamp_at; A.save = save; A.F_out = R.F_out; A.g_F = R.g_F; A.g_res = R.g_res; A.g_epi = R.g_epi;
+  A.g_w_extra = R.g_w_extra; A.g_scale = R.g_scale; A.g_w = R.g_w; A.g_p1 = R.g_p1; A.g_p2 = R.g_p2;
+  A.logits_mode = R.logits_mode; A.variant = 0u; A.pending_head = nullptr; A.row_per_pair = false;
+  w8pt16_bwd_pair_impl<IT, RAW, false, true, 16>(A, pair, nullptr, &co, (int)(threadIdx.x >> 4));
 }
 
 // The same backward fit with four more wavefronts per workgroup; in workgroup 0 they run the loss head that dfepe_loss_tail
@@ -95,7 +130,7 @@ w8pt16_bwd_head_kernel(const float* pts1, const float* pts2, const float* wts, i
   A.pts1 = pts1; A.pts2 = pts2; A.wts = wts; A.B = B; A.Bm = Bm; A.N = N; A.hw_sx = hw_sx; A.hw_sy = hw_sy;
   A.clamp_at = clamp_at; A.save = save; A.F_out = R.F_out; A.g_F = R.g_F; A.g_res = R.g_res; A.g_epi = R.g_epi;
   A.g_w_extra = R.g_w_extra; A.g_scale = R.g_scale; A.g_w = R.g_w; A.g_p1 = R.g_p1; A.g_p2 = R.g_p2;
-  A.logits_mode = R.logits_mode; A.variant = 0u; A.pending_head = nullptr;
+  A.logits_mode = R.logits_mode; A.variant = 0u; A.pending_head = nullptr; A.row_per_pair = false;
   w8pt16_bwd_pair_impl<IT, RAW, false>(A, pair, nullptr);
 }
 
@@ -108,7 +143,16 @@ void launch_fwd(const W8Args& A, hipStream_t st) {
 #define DFEPE_FWD(IT_)                                                                                                     \
   hipLaunchKernelGGL((w8pt16_fwd_kernel<IT_, RAW, PLAIN>), grid, block, 0, st, A.pts1, A.pts2, A.wts, A.B, A.Bm, A.N, A.hw_sx, \
                      A.hw_sy, A.clamp_at, A.F_out, A.residual, R)
-  if (N > 128) DFEPE_FWD(0);  // any N: correspondences re-read per phase
+  if (use_coop(N, A.B, A.row_per_pair)) {  // one workgroup per pair: 16 rows x IT correspondences per lane
+    const dim3 cgrid(A.B);
+#define DFEPE_CFWD(IT_)                                                                                                    \
+  hipLaunchKernelGGL((w8pt16_coop_fwd_kernel<IT_, RAW, PLAIN>), cgrid, block, 0, st, A.pts1, A.pts2, A.wts, A.B, A.Bm, A.N, A.hw_sx, \
+                     A.hw_sy, A.clamp_at, A.F_out, A.residual, R)
+    if (N <= 512) DFEPE_CFWD(2);
+    else if (N <= 1024) DFEPE_CFWD(4);
+    else DFEPE_CFWD(8);
+#undef DFEPE_CFWD
+  } else if (N > 128) DFEPE_FWD(0);  // any N: correspondences re-read per phase
   else if (N <= 16) DFEPE_FWD(1);
   else if (N <= 32) DFEPE_FWD(2);
   else if (N <= 64) DFEPE_FWD(4);
@@ -127,6 +171,19 @@ void launch_bwd(const W8BwdArgs& A, hipStream_t st) {
 #define DFEPE_BWD(IT_)                                                                                                     \
   hipLaunchKernelGGL((w8pt16_bwd_kernel<IT_, RAW, PGRAD, PLAIN>), grid, block, 0, st, A.pts1, A.pts2, A.wts, A.B, A.Bm, A.N, A.hw_sx, \
                      A.hw_sy, A.clamp_at, A.save, R)
+  if constexpr (!PGRAD && PLAIN) {
+    if (use_coop(N, A.B, A.row_per_pair)) {
+      const dim3 cgrid(A.B);
+#define DFEPE_CBWD(IT_)                                                                                                    \
+  hipLaunchKernelGGL((w8pt16_coop_bwd_kernel<IT_, RAW>), cgrid, block, 0, st, A.pts1, A.pts2, A.wts, A.B, A.Bm, A.N, A.hw_sx, A.hw_sy, \
+                     A.clamp_at, A.save, R)
+      if (N <= 512) DFEPE_CBWD(2);
+      else if (N <= 1024) DFEPE_CBWD(4);
+      else DFEPE_CBWD(8);
+#undef DFEPE_CBWD
+      return;
+    }
+  }
   if (N > 128) DFEPE_BWD(0);
   else if (N <= 16) DFEPE_BWD(1);
   else if (N <= 32) DFEPE_BWD(2);
@@ -177,7 +234,7 @@ int dfepe_w8pt16_bwd_launch(const W8BwdArgs& A, bool raw, hipStream_t st) {
     if (hipGetLastError() != hipSuccess) return DFEPE_ERR_HIP;
     return (A.pending_head != nullptr) ? dfepe_loss_head_from_workspace(A.pending_head, st) : DFEPE_OK;
   }
-  if (A.pending_head != nullptr && !pgrad) {
+  if (A.pending_head != nullptr && !pgrad && !use_coop(A.N, A.B, A.row_per_pair)) {
     if (raw) launch_bwd_head<true>(A, st); else launch_bwd_head<false>(A, st);
     return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
   }

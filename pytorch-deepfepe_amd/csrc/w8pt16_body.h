@@ -48,17 +48,8 @@
 #define S16_S3 110     //                                              s3 >= 0
 #define S16_INVTR 125  // 1 / trace(M)
 #define S16_SCRATCH 126 // written with garbage (branch-free stores of the lanes that have nothing to contribute)
-#define S16_TAG 127    // record format tag
+#define S16_TAG 127    // record tag: the backward poisons its output when handed anything but a record of this layout
 #define S16_TAG_VALUE 16.0f
-
-// Which kernel family serves a launch -- the forward and the backward must agree, their `save` records differ.  Rows
-// (this file) whenever the correspondences fit the registers (N <= 128), and for larger N when the batch fills the GPU
-// (measured at N = 1000: 78 us against 129 us at 4096 pairs, but 68 us against 39 us at 512 pairs, where the round-1
-// cooperative workgroup per pair spreads one pair over four wavefronts).
-inline bool dfepe_w8pt_use_rows(int N, long long pairs, unsigned flags) {
-  if (flags & DFEPE_W8PT_WAVE_PER_PAIR) return false;
-  return N <= DFEPE_W8PT16_MAX_N || pairs >= 2048;
-}
 
 __host__ __device__ constexpr int s16_hv_off(int k) { return 8 * k - (k * (k - 1)) / 2; }
 
@@ -75,11 +66,12 @@ struct W8Args {
   float* weights_out;
   int logits_mode;
   unsigned variant;
+  bool row_per_pair;  // host side only: never the cooperative workgroup (DFEPE_W8PT_ROW_PER_PAIR)
 };
 
 // phase markers for scripts/isa_phases.py (hipcc -DDFEPE_ISA_MARKS -S): comments in the assembly, nothing otherwise
 #ifdef DFEPE_ISA_MARKS
-#define DFEPE_MARK(name) asm volatile("; MARK " name)
+#define DFEPE_MARK(name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; MARK " name); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define DFEPE_MARK(name)
 #endif
@@ -361,14 +353,53 @@ __device__ __forceinline__ void eig9_select(double* Ar, const int l, const int k
   });
 }
 
+// ---- cooperative variant: ROWS = 16 rows (one 256-thread workgroup) share ONE pair ------------------------------------
+// For N > 128 a single row would walk N / 16 correspondences per lane four times; here lane L = 16 row + l of the workgroup owns
+// correspondences L, L + 256, ... (IT = ceil(N / 256) of them, in registers), the per-correspondence phases run on all 16 rows,
+// pair-wide sums go through this LDS block (one barrier each), row 0 alone runs the eigen / rank-2 phases and publishes f and
+// F_out for the output phase of all rows.  Same arithmetic, same `save` record as the row-per-pair kernel.
+struct W8Coop {
+  double red[12][16];   // one slot per pair-wide reduction: [slot][row]
+  double part[16][36];  // per-row moment sums (after the in-row reduce-scatter)
+  double xch[36];       // their sum over the rows
+  double f[9];          // the oriented unit eigenvector
+  float of[9];          // F_out
+};
+#ifndef DFEPE_BLOCK_SYNC
+#define DFEPE_BLOCK_SYNC() __syncthreads()
+#endif
+
 // ---- forward, one pair ---------------------------------------------------------------------------------------
 // IT = ceil(N / 16) correspondences per lane, kept in registers (N <= 128); IT = 0: any N, correspondences re-read per phase.
 // xch: 36 doubles of LDS owned by this pair.
 // PLAIN: none of the textbook-solver variant flags is set (the hot instantiation carries no test for them).
-template <int IT, bool RAW, bool PLAIN>
-__device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair, double* xch) {
+template <int IT, bool RAW, bool PLAIN, int ROWS = 1>
+__device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair, double* xch, W8Coop* co = nullptr, const int rowid = 0) {
+  static_assert(ROWS == 1 || (ROWS == 16 && IT > 0), "one row per pair, or the 16 rows of a workgroup with the correspondences in registers");
+  constexpr int S = 16 * ROWS;  // lanes per pair
   const int l = rg_lane();
+  const int L = rowid * 16 + l;  // lane within the pair
   const int N = A.N;
+  // pair-wide reductions: inside the row by DPP; across the 16 rows of a cooperative workgroup through LDS (row r's value in
+  // slot[r], re-read as lane r's operand of a second row reduction).  Every call site has its own slot: one barrier per reduction.
+  auto psum = [&](double v, int slot) {
+    v = rg_sum(v);
+    if constexpr (ROWS > 1) {
+      if (l == 0) co->red[slot][rowid] = v;
+      DFEPE_BLOCK_SYNC();
+      v = rg_sum(co->red[slot][l]);
+    }
+    return v;
+  };
+  auto pmaxf = [&](float v, int slot) {
+    v = rg_max(v);
+    if constexpr (ROWS > 1) {
+      if (l == 0) co->red[slot][rowid] = (double)v;
+      DFEPE_BLOCK_SYNC();
+      v = rg_max((float)co->red[slot][l]);
+    }
+    return v;
+  };
   const unsigned variant = PLAIN ? 0u : A.variant;
   const size_t mp = (size_t)(pair % A.Bm);  // several weight sets may share one set of correspondences
 
@@ -381,7 +412,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   // every phase re-reads them (16 B per correspondence, L2 hits after the first pass) and re-derives the weight.
   constexpr int ITR = (IT > 0) ? IT : 1;
   constexpr int kWi = RAW ? 4 : 6;  // slot of the weight-like value in a RawRec
-  const int nit = (IT > 0) ? IT : (N + 15) >> 4;
+  const int nit = (IT > 0) ? IT : (N + S - 1) / S;
   Pt pt[ITR];
   float wv[ITR];
   float wsm[ITR];  // softmax weights as weights_out wants them (logits mode, IT > 0)
@@ -391,7 +422,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   if constexpr (IT > 0) {
     static_for<0, IT>([&](auto c) {
       constexpr int it = decltype(c)::value;
-      const int i = it * 16 + l;
+      const int i = it * S + L;
       bool valid, keep;
       load_point<RAW>(A.pts1, A.pts2, mp, N, i, A.hw_sx, A.hw_sy, pt[it], valid, keep);
       float w = wsrc[valid ? i : N - 1];
@@ -407,7 +438,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     auto logit_load = [&](int it) {
       RawRec r;
       if constexpr (IT == 0) {
-        const int i = it * 16 + l;
+        const int i = it * S + L;
         r.v[kWi] = wsrc[(i < N) ? i : N - 1];
       }
       return r;
@@ -415,12 +446,12 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     auto logit = [&](int it, const RawRec& raw) {
       PRec r;
       if constexpr (IT > 0) r.w = wv[it];
-      else r.w = (it * 16 + l < N) ? raw.v[kWi] : -INFINITY;
+      else r.w = (it * S + L < N) ? raw.v[kWi] : -INFINITY;
       return r;
     };
     float mx = -INFINITY;
     for_points<IT>(nit, logit_load, logit, [&](int it, const PRec& r) { mx = fmaxf(mx, r.w); });
-    lmax = rg_max(mx);
+    lmax = pmaxf(mx, 0);
     if constexpr (IT > 0) {
       float sm = 0.0f;
       static_for<0, IT>([&](auto c) {
@@ -429,7 +460,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
         wv[it] = e;
         sm += e;
       });
-      linv = 1.0f / rg_sum(sm);
+      linv = 1.0f / (float)psum((double)sm, 1);
       static_for<0, IT>([&](auto c) {
         constexpr int it = decltype(c)::value;
         const float wgt = wv[it] * linv;
@@ -449,7 +480,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   auto point_load = [&](int it) {
     RawRec r;
     if constexpr (IT == 0) {
-      const int i = it * 16 + l;
+      const int i = it * S + L;
       load_point_raw<RAW>(A.pts1, A.pts2, mp, N, i, r);
       const float* wp = (A.logits_mode && wstage == 2 && A.weights_out != nullptr) ? A.weights_out + (size_t)pair * N : wsrc;
       r.v[kWi] = wp[(i < N) ? i : N - 1];
@@ -462,10 +493,10 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
       r.p = pt[it];
       r.w = wv[it];
       r.ws = wv[it];
-      r.valid = it * 16 + l < N;
+      r.valid = it * S + L < N;
       r.keep = kept[it];
     } else {
-      const int i = it * 16 + l;
+      const int i = it * S + L;
       decode_point<RAW>(raw, N, i, A.hw_sx, A.hw_sy, r.p, r.valid, r.keep);
       const float wr = raw.v[kWi];
       if (A.logits_mode) {
@@ -491,7 +522,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
       sme += r.ws;
     });
     if (IT == 0 && A.logits_mode) linv = 1.0f / rg_sum(sme);
-    c1x = rg_sum(sx1) * invN; c1y = rg_sum(sy1) * invN; c2x = rg_sum(sx2) * invN; c2y = rg_sum(sy2) * invN;
+    c1x = psum(sx1, 2) * invN; c1y = psum(sy1, 3) * invN; c2x = psum(sx2, 4) * invN; c2y = psum(sy2, 5) * invN;
   DFEPE_MARK("P1");
     // ---- phase 1: Hartley scale (mean distance to the centroid) -------------------------------------------------
     double d1 = 0, d2 = 0;
@@ -505,8 +536,8 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     });
     // Fit.normalize uses the literal 1.4142, not sqrt(2) (DeepFNet.py:168); utils_F._normalize_XY uses np.sqrt(2)
     const double hscale = (variant & DFEPE_W8PT_SQRT2) ? 1.4142135623730951 : 1.4142;
-    s1 = hscale * rcp_nr<2>(rg_sum(d1) * invN);
-    s2 = hscale * rcp_nr<2>(rg_sum(d2) * invN);
+    s1 = hscale * rcp_nr<2>(psum(d1, 6) * invN);
+    s2 = hscale * rcp_nr<2>(psum(d2, 7) * invN);
   }
 
   if (IT == 0 && A.logits_mode && !hartley) {
@@ -541,7 +572,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
 #pragma unroll
       for (int v = 0; v < 6; ++v) acc[6 * u + v] = fma(bb[u], aa[v], acc[6 * u + v]);
     if constexpr (IT == 0) {
-      if (A.logits_mode && A.weights_out != nullptr && r.valid) A.weights_out[(size_t)pair * N + it * 16 + l] = r.ws;
+      if (A.logits_mode && A.weights_out != nullptr && r.valid) A.weights_out[(size_t)pair * N + it * S + L] = r.ws;
     }
   });
   wstage = 2;
@@ -560,11 +591,29 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
       if (l & m) { idx += h; cnt -= h; } else { cnt = (cnt < h) ? cnt : h; }
       width = h;
     }
+    if constexpr (ROWS > 1) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-      if (k < cnt) xch[idx + k] = acc[k];
+      for (int k = 0; k < 3; ++k)
+        if (k < cnt) co->part[rowid][idx + k] = acc[k];
+      DFEPE_BLOCK_SYNC();
+      if (L < 36) {  // sum the 16 rows' partial moments in a fixed order
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += co->part[r][L];
+        co->xch[L] = t;
+      }
+      DFEPE_BLOCK_SYNC();
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (k < cnt) xch[idx + k] = acc[k];
+    }
   }
-  rg_sync();
+  if constexpr (ROWS > 1) xch = co->xch;
+  else rg_sync();
+  double f[9];
+  float of[9];
+  if (ROWS == 1 || rowid == 0) {  // the solver phases: one row per pair
   // sum (u, v) is M[3r+c][3r'+c'] for (r, r') = symmetric pair u, (c, c') = symmetric pair v.  Lane i < 9 fetches row i.
   double Ar[9];
   double tr;
@@ -591,7 +640,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   // (DeepFNet.py:232-233): for N >= 9 the smallest eigenvalue of X^T X; for N < 9 the reduced SVD has only N columns,
   // so the reference takes the smallest of the N non-null directions: 9 - N eigenvalues are passed over.
   const int kth = (N >= 9) ? 0 : 9 - N;
-  double f[9], z[9], td[9], te[8], hv[7], hb[7], lam;
+  double z[9], td[9], te[8], hv[7], hb[7], lam;
   int twist;
   eig9_select(Ar, l, kth, f, z, twist, lam, td, te, hv, hb);
 
@@ -645,7 +694,6 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     out[3 + c] = s2 * Mx[3 + c];
     out[6 + c] = Mx[6 + c] - s2 * (c2x * Mx[c] + c2y * Mx[3 + c]);
   }
-  float of[9];
 #pragma unroll
   for (int c = 0; c < 9; ++c) of[c] = (float)out[c];
   {
@@ -694,13 +742,22 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     }
     if (l == 11) reinterpret_cast<double*>(sv + S16_LAM)[0] = lam;
   }
+  if constexpr (ROWS > 1) {
+    if (l < 9) { co->f[l] = f[l]; co->of[l] = of[l]; }
+  }
+  }  // solver row
+  if constexpr (ROWS > 1) {
+    DFEPE_BLOCK_SYNC();
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { f[c] = co->f[c]; of[c] = co->of[c]; }
+  }
 
   DFEPE_MARK("P6");
   // ---- phase 6: per-correspondence outputs ----------------------------------------------------------------------
   float* rdst = A.residual + (size_t)pair * N;
   float* edst = (A.epi_res != nullptr) ? A.epi_res + (size_t)pair * N : nullptr;
   for_points<IT>(nit, point_load, point, [&](int it, const PRec& rec) {
-    const int i = it * 16 + l;
+    const int i = it * S + L;
     const Pt& p = rec.p;
     const float wf = rec.w;
     const bool valid = rec.valid;

@@ -35,6 +35,7 @@ struct W8BwdArgs {
   int logits_mode;
   unsigned variant;  // DFEPE_W8PT_NO_ROWNORM (Fit(normalize_SVD=False), DeepFNet.py:211): rows enter X un-normalised; 0 otherwise
   const void* pending_head;  // host side only: a deferred loss head to run beside this launch (dfepe_w8pt_bwd), or nullptr
+  bool row_per_pair;         // host side only: never the cooperative workgroup (DFEPE_W8PT_ROW_PER_PAIR)
 };
 
 __device__ __forceinline__ double guard_den16(double d) {
@@ -93,11 +94,21 @@ __device__ __forceinline__ void tri_pinv_apply(const double* td, const double* t
 
 // PLAIN: no variant flag is set (the hot instantiations carry no test for them); otherwise A.variant may hold NO_ROWNORM
 // (p^ = p: the row factor `inv` is 1 and constant), without point gradients.
-template <int IT, bool RAW, bool PGRAD, bool PLAIN = true>
-__device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const int pair, double* /*xch*/) {
+// LDS block of the cooperative variant (ROWS = 16: one workgroup per pair, see W8Coop in w8pt16_body.h)
+struct W8BwdCoop {
+  float red[20][16];  // pass-A sums and the softmax-adjoint dot product: [value][row]
+  double u[9];        // the eigenvector adjoint, published by row 0
+};
+
+template <int IT, bool RAW, bool PGRAD, bool PLAIN = true, int ROWS = 1>
+__device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const int pair, double* /*xch*/, W8BwdCoop* co = nullptr,
+                                                     const int rowid = 0) {
   static_assert(PLAIN || !PGRAD, "the un-normalised-rows variant has no point gradients");
+  static_assert(ROWS == 1 || (ROWS == 16 && IT > 0 && !PGRAD), "cooperative variant: correspondences in registers, weight gradients only");
+  constexpr int S = 16 * ROWS;
   const bool norow = PLAIN ? false : (A.variant & DFEPE_W8PT_NO_ROWNORM) != 0;
   const int l = rg_lane();
+  const int L = rowid * 16 + l;  // lane within the pair
   const int N = A.N;
   const size_t mp = (size_t)(pair % A.Bm);
   const float* sv = A.save + (size_t)pair * DFEPE_SAVE_FLOATS;
@@ -135,7 +146,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
 
   // same unconditional loads and the same drop rule as the forward (w8pt16_fwd_pair, phase 0); IT = 0: any N, re-read per pass
   constexpr int ITR = (IT > 0) ? IT : 1;
-  const int nit = (IT > 0) ? IT : (N + 15) >> 4;
+  const int nit = (IT > 0) ? IT : (N + S - 1) / S;
   Pt pt[ITR];
   float wv[ITR];   // the weight (softmax output in logits mode); 0 on padding lanes
   bool kept[ITR];  // false: the forward dropped this correspondence from X
@@ -143,14 +154,14 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
   constexpr int kWi = RAW ? 4 : 6;  // slot of the weight in a RawRec
   auto point_load = [&](int it) {
     RawRec r;
-    const int i = it * 16 + l;
+    const int i = it * S + L;
     load_point_raw<RAW>(A.pts1, A.pts2, mp, N, i, r);
     r.v[kWi] = wsrc[(i < N) ? i : N - 1];
     return r;
   };
   auto point_decode = [&](int it, const RawRec& raw) {
     PRec r;
-    const int i = it * 16 + l;
+    const int i = it * S + L;
     decode_point<RAW>(raw, N, i, A.hw_sx, A.hw_sy, r.p, r.valid, r.keep);
     const float wr = raw.v[kWi];
     const bool wfin = fabsf(wr) < 3e38f;
@@ -169,7 +180,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
   if constexpr (IT > 0) {
     static_for<0, IT>([&](auto c) {
       constexpr int it = decltype(c)::value;
-      const int i = it * 16 + l;
+      const int i = it * S + L;
       const int ic = (i < N) ? i : N - 1;
       const RawRec raw = point_load(it);
       const float a = gres_p[ic], b = gepi_p[ic], cxt = gwx_p[ic];
@@ -190,7 +201,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
     if constexpr (IT > 0) {
       PRec r;
       r.p = pt[it]; r.w = wv[it]; r.ws = wv[it]; r.keep = kept[it];
-      r.valid = it * 16 + l < N;
+      r.valid = it * S + L < N;
       return r;
     } else {
       return point_decode(it, raw);
@@ -212,7 +223,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
 #pragma unroll
     for (int c = 0; c < 9; ++c) { gxf[c] = 0.0f; gof[c] = 0.0f; }
     for_points<IT>(nit, cached_load, point, [&](int it, const PRec& rec) {
-      const int i = it * 16 + l;
+      const int i = it * S + L;
       const Pt& p = rec.p;
       const float wf = rec.w;
       const bool keep = rec.keep;
@@ -259,8 +270,22 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
     });
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
-      if (A.g_res != nullptr) gx[c] = (double)rg_sum(gxf[c]);
-      if (A.g_epi != nullptr) go[c] = (double)rg_sum(gof[c]);
+      if (A.g_res != nullptr) gxf[c] = rg_sum(gxf[c]);
+      if (A.g_epi != nullptr) gof[c] = rg_sum(gof[c]);
+    }
+    if constexpr (ROWS > 1) {  // the 16 rows' sums through LDS: one barrier for all 18 values
+      if (l == 0) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) { co->red[c][rowid] = gxf[c]; co->red[9 + c][rowid] = gof[c]; }
+      }
+      DFEPE_BLOCK_SYNC();
+#pragma unroll
+      for (int c = 0; c < 9; ++c) { gxf[c] = rg_sum(co->red[c][l]); gof[c] = rg_sum(co->red[9 + c][l]); }
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      if (A.g_res != nullptr) gx[c] = (double)gxf[c];
+      if (A.g_epi != nullptr) go[c] = (double)gof[c];
     }
   }
   if (A.g_F != nullptr) {
@@ -274,7 +299,13 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
   }
 
   DFEPE_MARK("B2_uniform");
-  // ---- uniform part ------------------------------------------------------------------------------------------
+  double u[9];
+  double u3[3], v3[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { u3[c] = sv[S16_U3 + c]; v3[c] = sv[S16_V3 + c]; }
+  const double s3 = sv[S16_S3];
+  if (ROWS == 1 || rowid == 0) {
+  // ---- uniform part (one row per pair) ------------------------------------------------------------------------
   // g_F' = T2 g_out T1^T with T = [[s,0,-s cx],[0,s,-s cy],[0,0,1]] written out
   double tmp[9], G[9];
 #pragma unroll
@@ -296,10 +327,6 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
   // so with p = A_u G v3, q = A_v G^T u3, a33 = u3^T G v3:
   //   g_F = G - (a33 u3 + s3^2 p + s3 F q) v3^T - u3 (s3 F^T p + s3^2 q)^T
   // (the same five-term expression the full-SVD form sum_k coef_k (...) u_k / v_k collapses to).
-  double u3[3], v3[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) { u3[c] = sv[S16_U3 + c]; v3[c] = sv[S16_V3 + c]; }
-  const double s3 = sv[S16_S3];
   double gf[9];
   {
     const double* Fm = f;
@@ -336,7 +363,6 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
   }
   DFEPE_MARK("B4_eigadj");
   // eigenvector adjoint: u = -(1/trace) H (T - lam I)^+ H^T g_f.  H^T = H_6 ... H_0 (each H_k symmetric).
-  double u[9];
   {
     double gt[9], y[9];
 #pragma unroll
@@ -373,6 +399,15 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
 #pragma unroll
     for (int c = 0; c < 9; ++c) u[c] = sc * y[c];
   }
+  if constexpr (ROWS > 1) {
+    if (l < 9) co->u[l] = u[l];
+  }
+  }  // solver row
+  if constexpr (ROWS > 1) {
+    DFEPE_BLOCK_SYNC();
+#pragma unroll
+    for (int c = 0; c < 9; ++c) u[c] = co->u[c];
+  }
 
   DFEPE_MARK("B6_passB");
   // ---- pass B: g_w ---------------------------------------------------------------------------------------------
@@ -380,7 +415,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
   float gwv[ITR];
   float wg = 0.0f;
   for_points<IT>(nit, cached_load, point, [&](int it, const PRec& rec) {
-    const int i = it * 16 + l;
+    const int i = it * S + L;
     const Pt& p = rec.p;
     const float wf = rec.w;
     const bool valid = rec.valid, keep = rec.keep;
@@ -398,31 +433,36 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
     else if (valid) dst[i] = gwi;  // provisional when the softmax adjoint follows: the same lane re-reads it below
   });
   // softmax adjoint g_logit_i = w_i (g_w_i - sum_j w_j g_w_j)
-  const float sdot = A.logits_mode ? rg_sum(wg) : 0.0f;
+  float sdot = A.logits_mode ? rg_sum(wg) : 0.0f;
+  if constexpr (ROWS > 1) {
+    if (l == 0) co->red[18][rowid] = sdot;
+    DFEPE_BLOCK_SYNC();
+    sdot = rg_sum(co->red[18][l]);
+  }
   if constexpr (IT > 0) {
     static_for<0, IT>([&](auto c) {
       constexpr int it = decltype(c)::value;
-      const int i = it * 16 + l;
+      const int i = it * S + L;
       if (i < N) dst[i] = A.logits_mode ? wv[it] * (gwv[it] - sdot) : gwv[it];
     });
   } else if (A.logits_mode) {
     // (weight, provisional gradient) of correspondence `it`
     auto parked_load = [&](int it) {
       RawRec r;
-      const int i = it * 16 + l;
+      const int i = it * S + L;
       r.v[0] = wsrc[(i < N) ? i : N - 1];
       r.v[1] = dst[(i < N) ? i : N - 1];
       return r;
     };
     auto parked = [&](int it, const RawRec& raw) {
       PRec r;
-      r.valid = it * 16 + l < N;
+      r.valid = it * S + L < N;
       r.w = raw.v[0];
       r.p.x1 = raw.v[1];
       return r;
     };
     for_points<0>(nit, parked_load, parked, [&](int it, const PRec& r) {
-      if (r.valid) dst[it * 16 + l] = r.w * (r.p.x1 - sdot);
+      if (r.valid) dst[it * S + L] = r.w * (r.p.x1 - sdot);
     });
   }
 
@@ -447,7 +487,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
     for (int k = 0; k < 10; ++k) sums[k] = 0.0f;
     float q1x[ITR], q1y[ITR], q2x[ITR], q2y[ITR];
     for_points<IT>(nit, cached_load, point, [&](int it, const PRec& rec) {
-      const int i = it * 16 + l;
+      const int i = it * S + L;
       const Pt& p = rec.p;
       const float wf = rec.w;
       const bool keep = rec.keep;
@@ -534,7 +574,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
     const double Gc1x = (tot[1] - s1 * gT1[2] - Gd1 * invN * tot[6]) * invN, Gc1y = (tot[2] - s1 * gT1[5] - Gd1 * invN * tot[7]) * invN;
     const double Gc2x = (tot[4] - s2 * gT2[2] - Gd2 * invN * tot[8]) * invN, Gc2y = (tot[5] - s2 * gT2[5] - Gd2 * invN * tot[9]) * invN;
     for_points<IT>(nit, cached_load, point, [&](int it, const PRec& rec) {
-      const int i = it * 16 + l;
+      const int i = it * S + L;
       const Pt& p = rec.p;
       if (!rec.valid) return;
       const double dx1 = (double)p.x1 - c1x, dy1 = (double)p.y1 - c1y, dx2 = (double)p.x2 - c2x, dy2 = (double)p.y2 - c2y;

@@ -42,18 +42,18 @@ def save_floats() -> int:
 # ------------------------------------------------------------------------------------------------
 # weighted 8-point fit
 # ------------------------------------------------------------------------------------------------
-def _flags(raw: bool, logits: bool, wave_per_pair: bool = False, extra: int = 0) -> int:
+def _flags(raw: bool, logits: bool, row_per_pair: bool = False, extra: int = 0) -> int:
     return ((_lib.W8PT_RAW_MATCHES if raw else 0) | (_lib.W8PT_LOGITS if logits else 0) |
-            (_lib.W8PT_WAVE_PER_PAIR if wave_per_pair else 0) | int(extra))
+            (_lib.W8PT_ROW_PER_PAIR if row_per_pair else 0) | int(extra))
 
 
 def w8pt_forward(pts1: Tensor, pts2: Optional[Tensor], weights: Tensor, raw: bool, image_w: float, image_h: float,
                  clamp_at: float, want_epi: bool, want_save: bool, logits: bool = False, F_out: Optional[Tensor] = None,
-                 wave_per_pair: bool = False, extra_flags: int = 0):
+                 row_per_pair: bool = False, extra_flags: int = 0):
     """Raw (non-differentiable) launch.  weights (or logits when ``logits``) [B,N].
     Returns F [B,3,3], residual [B,N], epi [B,N]|None, save|None, weights_out [B,N]|None.  ``F_out`` lets the caller
-    provide the destination (e.g. one [B,3,3] slice of a per-layer stack).  ``wave_per_pair`` forces the one-wavefront-per-pair
-    kernel where the row-per-pair kernel (N <= 128) would run; the matching backward call must pass the same value."""
+    provide the destination (e.g. one [B,3,3] slice of a per-layer stack).  ``row_per_pair`` forces one 16-lane row per pair
+    where a cooperative workgroup per pair (N > 128 at small batch) would run: same function, same ``save`` record."""
     L = _lib.lib()
     B, N = weights.shape
     dev = weights.device
@@ -63,14 +63,14 @@ def w8pt_forward(pts1: Tensor, pts2: Optional[Tensor], weights: Tensor, raw: boo
     save = torch.empty(B, L.dfepe_save_floats(), device=dev, dtype=torch.float32) if want_save else None
     w_out = torch.empty(B, N, device=dev, dtype=torch.float32) if logits else None
     with torch.cuda.device(dev):
-        rc = L.dfepe_w8pt_fwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, 1, _flags(raw, logits, wave_per_pair, extra_flags), float(image_w),
+        rc = L.dfepe_w8pt_fwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, 1, _flags(raw, logits, row_per_pair, extra_flags), float(image_w),
                               float(image_h), float(clamp_at), _ptr(F), _ptr(residual), _ptr(epi), _ptr(save), _ptr(w_out), _stream())
     _lib.check(rc, "dfepe_w8pt_fwd")
     return F, residual, epi, save, w_out
 
 
 def w8pt_backward(pts1, pts2, weights, raw, image_w, image_h, clamp_at, save, F, gF, gRes, gEpi, logits=False, gW_extra=None,
-                  out: Optional[Tensor] = None, want_pts: bool = False, wave_per_pair: bool = False, g_scale: Optional[Tensor] = None,
+                  out: Optional[Tensor] = None, want_pts: bool = False, row_per_pair: bool = False, g_scale: Optional[Tensor] = None,
                   pending_loss_head: Optional[Tensor] = None, extra_flags: int = 0):
     """Raw launch of the adjoint; returns d/d(weights) (or d/d(logits) when ``logits``; then ``weights`` must be the
     forward's weights_out) and, when ``want_pts``, the gradients w.r.t. the points ([B,N,3] x 2, or [B,N,4] for raw matches)."""
@@ -82,7 +82,7 @@ def w8pt_backward(pts1, pts2, weights, raw, image_w, image_h, clamp_at, save, F,
         gP1 = torch.empty_like(pts1)
         gP2 = None if raw else torch.empty_like(pts2)
     with torch.cuda.device(weights.device):
-        rc = L.dfepe_w8pt_bwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, 1, _flags(raw, logits, wave_per_pair, extra_flags), float(image_w), float(image_h),
+        rc = L.dfepe_w8pt_bwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, 1, _flags(raw, logits, row_per_pair, extra_flags), float(image_w), float(image_h),
                               float(clamp_at), _ptr(save), _ptr(F), _ptr(gF), _ptr(gRes), _ptr(gEpi), _ptr(gW_extra), _ptr(g_scale), _ptr(gW),
                               _ptr(gP1), _ptr(gP2), _ptr(pending_loss_head), _stream())
     _lib.check(rc, "dfepe_w8pt_bwd")

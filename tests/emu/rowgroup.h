@@ -13,6 +13,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 #include <ucontext.h>
 
 #include <type_traits>
@@ -21,6 +22,9 @@
 #define __host__
 #define __global__
 #define __forceinline__ inline
+// the cooperative (16 rows per pair) variant of the bodies is device-only: the emulation runs one row per pair, where the
+// block-level barrier is never reached
+#define DFEPE_BLOCK_SYNC() abort()
 
 struct float4 {
   float x, y, z, w;

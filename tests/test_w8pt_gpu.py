@@ -178,19 +178,34 @@ def test_near_degenerate_weightings_pick_the_reference_eigenvector(dfepe, oracle
     assert np.median(err) < 2e-6 and (err[well] < 1e-5).mean() > 0.97
 
 
-def test_two_wavefronts_per_pair_variant(dfepe, oracle):
-    """N = 800 with more than 1024 pairs selects the cooperative workgroup of TWO wavefronts per pair (the 4-wavefront
-    variant is covered by the small-batch large-N cases): same parity bar as everywhere else."""
-    B, N = 1100, 800
+@pytest.mark.parametrize("B,N", [(40, 800), (9, 130), (5, 2048), (3, 2500)])
+def test_cooperative_workgroup_per_pair(dfepe, oracle, B, N):
+    """128 < N <= 2048 at small batch: the 16 rows of a workgroup share one pair (IT = 2 / 4 / 8 correspondences per lane; N = 2500
+    is past the limit and takes the looped row kernel).  Same parity bar as everywhere else, and bit-for-bit ... no: the moment sums
+    are added in a different order, so agreement with the one-row-per-pair kernel (DFEPE_W8PT_ROW_PER_PAIR) is to rounding; the
+    backward takes either kernel's `save` record (one format)."""
     sc = dfepe.synth.make_scene(B, N, seed=4, outlier_ratio=0.2, noise_px=0.5)
-    m = sc["matches_xy_ori"]
-    w = torch.softmax(sc["logits_layers"][0], dim=1)
-    F, res, epi = dfepe.ops.w8pt_raw(m.to(DEV), w.to(DEV), IMAGE_SIZE[1], IMAGE_SIZE[0], clamp_at=0.5, want_epi=True)
-    p1, p2, _ = oracle.normalize_hw(m.double(), IMAGE_SIZE)
-    o_out, o_res, _ = oracle.fit_forward(p1, p2, w.double().unsqueeze(1))
+    m = sc["matches_xy_ori"].to(DEV)
+    w = torch.softmax(sc["logits_layers"][0], dim=1).to(DEV)
+    F, res, epi = dfepe.ops.w8pt_raw(m, w, IMAGE_SIZE[1], IMAGE_SIZE[0], clamp_at=0.5, want_epi=True)
+    p1, p2, _ = oracle.normalize_hw(m.cpu().double(), IMAGE_SIZE)
+    o_out, o_res, _ = oracle.fit_forward(p1, p2, w.cpu().double().unsqueeze(1))
     a, r, s_ = unit_align(F.cpu().numpy(), o_out.numpy())
     assert np.linalg.norm(a - r, axis=1).max() < 5e-6
     np.testing.assert_allclose(res.cpu().numpy() * s_[:, None], o_res.numpy(), atol=1e-6, rtol=1e-4)
-    # and it is the same function as the one-wavefront-per-pair kernel (DFEPE_W8PT_WAVE_PER_PAIR forces that variant)
-    F1 = dfepe.ops.w8pt_forward(m.to(DEV), None, w.to(DEV), True, float(IMAGE_SIZE[1]), float(IMAGE_SIZE[0]), 0.5, True, False, wave_per_pair=True)[0]
-    assert (F1 - F).abs().max().item() < 2e-6 * F.abs().max().item()
+    W_, H_ = float(IMAGE_SIZE[1]), float(IMAGE_SIZE[0])
+    F1, res1, epi1, save1, _ = dfepe.ops.w8pt_forward(m, None, w, True, W_, H_, 0.5, True, True, row_per_pair=True)
+    F2, res2, epi2, save2, _ = dfepe.ops.w8pt_forward(m, None, w, True, W_, H_, 0.5, True, True)
+    assert (F1 - F2).abs().max().item() < 2e-6 * F2.abs().max().item()
+    assert (epi1 - epi2).abs().max().item() < 1e-5
+    # one record format: the adjoint of either kernel accepts the other's record
+    g = torch.Generator().manual_seed(B + N)
+    gF = torch.randn(B, 3, 3, generator=g).to(DEV)
+    gR = torch.randn(B, N, generator=g).to(DEV)
+    ga = dfepe.ops.w8pt_backward(m, None, w, True, W_, H_, 0.5, save1, F1, gF, gR, None)
+    gb = dfepe.ops.w8pt_backward(m, None, w, True, W_, H_, 0.5, save2, F2, gF, gR, None, row_per_pair=True)
+    gc = dfepe.ops.w8pt_backward(m, None, w, True, W_, H_, 0.5, save2, F2, gF, gR, None)
+    assert torch.isfinite(ga).all()
+    # the least-squares solution is well conditioned here (N >= 130 noisy correspondences): gradients agree to the record's fp32 entries
+    scale = gc.abs().max().item()
+    assert (ga - gc).abs().max().item() < 2e-3 * scale and (gb - gc).abs().max().item() < 2e-3 * scale
