@@ -74,6 +74,12 @@ __device__ __forceinline__ int rg_sum(int v) {
   v += rg_dpp_i32<0x140>(v);
   return v;
 }
+// number of lanes of the row for which p holds: one ballot + a popcount of the row's 16 bits (rows of the wavefront that have
+// left a loop are masked off and contribute zeros to their own bits only)
+__device__ __forceinline__ int rg_count(bool p) {
+  const unsigned long long b = __ballot(p);
+  return __popc((unsigned)(b >> (threadIdx.x & 48u)) & 0xffffu);
+}
 __device__ __forceinline__ float rg_max(float v) {
   v = fmaxf(v, rg_dpp_f32<0xB1>(v));
   v = fmaxf(v, rg_dpp_f32<0x4E>(v));

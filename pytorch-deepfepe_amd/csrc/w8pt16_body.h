@@ -187,6 +187,20 @@ __device__ __forceinline__ void rg_halve(double* a, bool upper) {
 // Number of eigenvalues below x of the symmetric tridiagonal (td, te), te2 = te^2: sign changes of the three-term
 // recurrence p_k = (d_k - x) p_{k-1} - e_{k-1}^2 p_{k-2}.  Division-free; with a unit-trace matrix |p_k| stays within
 // [1e-150, 1].  An exact zero counts as positive: its neighbours have opposite signs, so the count is the same.
+// "x lies at or below the smallest eigenvalue" = the count is zero = no term of the sequence is negative: one compare per term
+// and mask arithmetic on the scalar unit instead of counting sign changes (the case of every N >= 9: kth = 0)
+__device__ __forceinline__ bool sturm_none_below(const double* td, const double* te2, double x) {
+  double pm2 = 1.0, pm1 = td[0] - x;
+  bool neg = pm1 < 0.0;
+#pragma unroll
+  for (int k = 1; k < 9; ++k) {
+    const double p = fma(td[k] - x, pm1, -(te2[k - 1] * pm2));
+    neg = neg || (p < 0.0);
+    pm2 = pm1;
+    pm1 = p;
+  }
+  return !neg;
+}
 __device__ __forceinline__ int sturm_count(const double* td, const double* te2, double x) {
   double pm2 = 1.0, pm1 = td[0] - x;
   int cnt = (pm1 < 0.0) ? 1 : 0;
@@ -280,9 +294,10 @@ __device__ __forceinline__ void eig9_select(double* Ar, const int l, const int k
   const float kLog2_17 = 4.087462841250339f;
   auto pow17 = [&](int e) { return (double)exp2f((float)e * kLog2_17); };  // probe positions need no accuracy
   double lo = -1e-3, hi = 1.0 + 1e-3;
+  // probe still below the wanted eigenvalue?  kth = 0 (uniform over the launch: N >= 9) takes the cheaper test
+  auto below = [&](double x) { return (kth == 0) ? sturm_none_below(td, te2, x) : (sturm_count(td, te2, x) <= kth); };
   {
-    const int c = sturm_count(td, te2, pow17(l - 16));
-    const int m = rg_sum((c <= kth) ? 1 : 0);
+    const int m = rg_count(below(pow17(l - 16)));
     lo = (m > 0) ? pow17(m - 17) : lo;
     hi = (m < 16) ? pow17(m - 16) : hi;
   }
@@ -290,8 +305,7 @@ __device__ __forceinline__ void eig9_select(double* Ar, const int l, const int k
   for (int round = 0; round < 14; ++round) {
     const double wdt = hi - lo;
     if (!(wdt > 2e-16)) break;  // uniform over the row
-    const int c = sturm_count(td, te2, fma(wdt, frac, lo));
-    const int m = rg_sum((c <= kth) ? 1 : 0);  // probes still below the wanted eigenvalue (counts are monotone in l)
+    const int m = rg_count(below(fma(wdt, frac, lo)));  // probes still below the wanted eigenvalue (monotone in l)
     const double step = wdt * (1.0 / 17.0);
     lo = fma(step, (double)m, lo);
     hi = lo + step;
@@ -306,14 +320,14 @@ __device__ __forceinline__ void eig9_select(double* Ar, const int l, const int k
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     dp[k] = pivot_guard(dp[k]);
-    rp[k] = rcp_nr<2>(dp[k]);
+    rp[k] = rcp_nr<1>(dp[k]);  // one Newton step from the fp32 seed: ~2e-14, far inside what the eigenvector needs
     dp[k + 1] = (td[k + 1] - lam) - te2[k] * rp[k];
   }
   dm[8] = td[8] - lam;
 #pragma unroll
   for (int k = 7; k >= 0; --k) {
     dm[k + 1] = pivot_guard(dm[k + 1]);
-    rm[k + 1] = rcp_nr<2>(dm[k + 1]);
+    rm[k + 1] = rcp_nr<1>(dm[k + 1]);
     dm[k] = (td[k] - lam) - te2[k] * rm[k + 1];
   }
   twist = 0;
@@ -561,7 +575,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     const double n2 = (a0 * a0 + a1 * a1 + a2 * a2) * (b0 * b0 + b1 * b1 + 1.0);  // |p|^2, finite (phase 0 dropped the rest)
     // (w / max(|p|, 1e-12))^2; a dropped or padding correspondence has w = 0 and contributes exact zeros.  1 / |p| is kept
     // for the residual of phase 6 when the correspondences live in registers.
-    const double inv = fmin(rsqrt_nr<2>(n2), 1e12);
+    const double inv = fmin(rsqrt_nr<1>(n2), 1e12);  // ~2e-14: it only scales a weight
     if constexpr (IT > 0) invs[it] = inv;
     const double wi = (variant & DFEPE_W8PT_NO_ROWNORM) ? w : w * inv;
     const double k2 = wi * wi;

@@ -57,20 +57,20 @@ __device__ __forceinline__ void tri_pinv_apply(const double* td, const double* t
   // two blocks decouple and each is a principal sub-matrix of the positive semi-definite T - lam I that excludes the
   // largest component of its null vector: definite, pivots away from zero.
   double rp[9], gp[9], rm[9], gm[9];  // reciprocal pivots, eliminated right-hand sides
-  rp[0] = rcp_nr<2>(guard_den16(td[0] - lam));
+  rp[0] = rcp_nr<1>(guard_den16(td[0] - lam));
   gp[0] = g[0];
 #pragma unroll
   for (int k = 1; k < 9; ++k) {
     const double m = te[k - 1] * rp[k - 1];
-    rp[k] = rcp_nr<2>(guard_den16((td[k] - lam) - m * te[k - 1]));
+    rp[k] = rcp_nr<1>(guard_den16((td[k] - lam) - m * te[k - 1]));
     gp[k] = g[k] - m * gp[k - 1];
   }
-  rm[8] = rcp_nr<2>(guard_den16(td[8] - lam));
+  rm[8] = rcp_nr<1>(guard_den16(td[8] - lam));
   gm[8] = g[8];
 #pragma unroll
   for (int k = 7; k >= 0; --k) {
     const double m = te[k] * rm[k + 1];
-    rm[k] = rcp_nr<2>(guard_den16((td[k] - lam) - m * te[k]));
+    rm[k] = rcp_nr<1>(guard_den16((td[k] - lam) - m * te[k]));
     gm[k] = g[k] - m * gm[k + 1];
   }
 #pragma unroll

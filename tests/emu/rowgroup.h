@@ -101,6 +101,7 @@ inline T rg_butterfly(T v, Op op) {
 inline double rg_sum(double v) { return rg_butterfly(v, [](double a, double b) { return a + b; }); }
 inline float rg_sum(float v) { return rg_butterfly(v, [](float a, float b) { return a + b; }); }
 inline int rg_sum(int v) { return rg_butterfly(v, [](int a, int b) { return a + b; }); }
+inline int rg_count(bool p) { return rg_sum(p ? 1 : 0); }  // lanes of the row for which p holds
 inline float rg_max(float v) { return rg_butterfly(v, [](float a, float b) { return fmaxf(a, b); }); }
 
 template <int K0, int K1>
