@@ -231,6 +231,17 @@ int dfepe_cheirality(const float *E, const float *pre, const float *K, const flo
                      float *Rt_cam, int *winner, int *counts, void *stream);
 
 /*
+ * Fit + E-from-F + cheirality-checked pose in one call (BASELINE config 5: one weighted 8-point fit, then the pose of its F).
+ * Replaces: Fit.forward -> E = K^T T^T F T K (train_good_utils.py:356-358) -> utils_F._E_to_M_train (utils_F.py:679-763).
+ * Same outputs as dfepe_w8pt_fwd (DFEPE_W8PT_RAW_MATCHES required; DFEPE_W8PT_LOGITS optional; no `save`: forward only) followed
+ * by dfepe_cheirality(F_out, pre, ...), bit for bit; for 128 < N <= 2048 below 3072 pairs it is ONE launch (the cooperative
+ * workgroup of the fit goes on to decompose pre^T F pre and to triangulate its pair), otherwise the two launches.
+ */
+int dfepe_w8pt_pose_fwd(const float *matches, const float *weights, int B, int N, unsigned flags, float image_w, float image_h,
+                        float clamp_at, const float *K, const float *pre, float depth_thres, float *F_out, float *residual,
+                        float *epi_res, float *weights_out, float *Rt_cam, int *winner, int *counts, void *stream);
+
+/*
  * Reductions of the validation summary on the device.
  * Replaces: the numpy post-processing of write_metrics_summary (deepFEPE/train_good_utils.py:758-856) over the per-pair
  * results of val_rt (:553-646): epipolar-distance inlier ratios at 0.1 / 1.0 px, F1 of "est < th" against "gt < th",

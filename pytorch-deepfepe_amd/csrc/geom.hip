@@ -1,6 +1,7 @@
 // Stand-alone geometry entry points of the dsac_tools API: epipolar residual / metrics, small pose helpers,
 // cheirality-checked pose selection.  These sit on either side of the solver.
 #include "dfepe_common.h"
+#include "cheirality_body.h"
 
 namespace {
 
@@ -139,28 +140,6 @@ __device__ inline void quat_of(const double* R, double* q) {
   for (int k = 0; k < 4; ++k) q[k] = sc * v[k];
 }
 
-// the four-fold ambiguity of utils_F._get_M2s (utils_F.py:478-498): R1 = U W V^T, R2 = U W^T V^T (both negated when
-// det < 0), t = u3 / |u3|
-__device__ inline void decompose_E(const double* E, double* R1, double* R2, double* t) {
-  double U[9], S[3], V[9];
-  svd3_closed(E, U, S, V);
-  double UW[9], UWt[9];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    UW[3 * r + 0] = U[3 * r + 1]; UW[3 * r + 1] = -U[3 * r + 0]; UW[3 * r + 2] = U[3 * r + 2];
-    UWt[3 * r + 0] = -U[3 * r + 1]; UWt[3 * r + 1] = U[3 * r + 0]; UWt[3 * r + 2] = U[3 * r + 2];
-  }
-  mat3_mul_nt(UW, V, R1);
-  mat3_mul_nt(UWt, V, R2);
-  const double det = R1[0] * (R1[4] * R1[8] - R1[5] * R1[7]) - R1[1] * (R1[3] * R1[8] - R1[5] * R1[6]) +
-                     R1[2] * (R1[3] * R1[7] - R1[4] * R1[6]);
-  if (det < 0.0) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { R1[k] = -R1[k]; R2[k] = -R2[k]; }
-  }
-  const double un = sqrt(U[2] * U[2] + U[5] * U[5] + U[8] * U[8]);
-  t[0] = U[2] / un; t[1] = U[5] / un; t[2] = U[8] / un;
-}
 
 __global__ void __launch_bounds__(256)
 geo_misc_kernel(int kind, const float* __restrict__ in0, const float* __restrict__ in1, int n, float* __restrict__ out) {
@@ -222,290 +201,19 @@ geo_misc_kernel(int kind, const float* __restrict__ in0, const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------------
-// cheirality (utils_F._E_to_M_train, utils_F.py:679-763), one workgroup (4 wavefronts) per pair, one correspondence per lane
+// cheirality (utils_F._E_to_M_train, utils_F.py:679-763): body in cheirality_body.h (shared with the fused fit + pose kernel)
 // ------------------------------------------------------------------------------------------------------
-// Smallest eigenvector of a symmetric positive semi-definite 4x4 (the DLT normal matrix A^T A), in registers, two stages.
-// Stage 1 (smallest_eigvec4_pk), packed fp32, TWO matrices at once (v_pk_fma_f32: component 0 / 1 = rotation candidate 1 / 2):
-//   two Householder reflections -> tridiagonal T;  Laguerre's iteration from lam = 0 on det(T - lam I) through the
-//   three-term recurrence (for a real-rooted polynomial it climbs monotonically to the smallest root from below, cubic
-//   rate, and does not care whether the outliers' lam4 / lam3 is 1e-7 or 0.9: <= 6 steps on DLT matrices);
-//   eigenvector of T as the best-conditioned column of adj(T - lam I), whose entries are products of the leading and
-//   trailing principal minors the recurrence already yields (the vector a twisted factorisation gives -- its pivot gamma_r is
-//   smallest where the diagonal cofactor is largest -- without the divisions);  back-transformation.
-//   scripts/proto_eig4.py checks this route against numpy.linalg.eigh in fp64 (eigenvector error x gap 8e-16);
-//   scripts/proto_dlt_refine.py runs it in fp32: median eigenvector error 2e-7, 1e-4 at the 99.9th percentile.
-// Stage 2 (rqi_refine4) makes that an fp64 answer with ONE Rayleigh-quotient iteration on the fp64 matrix: cubic
-//   convergence, error <= 1e-9 on every DLT matrix of the prototype's scenes (25-50 % outliers), no cheirality decision
-//   different from eigh.  ~900 instructions per correspondence (both candidates) against ~1 200 for two fp64 tridiagonal
-//   solves (round 2's first version: 161 us at B = 4096, N = 1000) and ~4 000 for the cyclic Jacobi of round 1.
-__device__ __forceinline__ double guard_piv(double z, double tiny) { return (fabs(z) < tiny) ? ((z < 0.0) ? -tiny : tiny) : z; }
-
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef int i2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 f2s(float v) { return f2{v, v}; }
-__device__ __forceinline__ f2 pk_sel(i2 m, f2 a, f2 b) { return m ? a : b; }
-__device__ __forceinline__ f2 pk_abs(f2 a) { return __builtin_elementwise_abs(a); }
-__device__ __forceinline__ f2 pk_max(f2 a, f2 b) { return __builtin_elementwise_max(a, b); }
-__device__ __forceinline__ f2 pk_sqrt(f2 a) { return f2{hw_sqrt(a.x), hw_sqrt(a.y)}; }
-__device__ __forceinline__ f2 pk_rcp(f2 a) { return f2{hw_rcp(a.x), hw_rcp(a.y)}; }
-
-__device__ inline void smallest_eigvec4_pk(const f2* S /*4x4 row-major, symmetric, unit trace*/, f2* x) {
-  const f2 zero = f2s(0.0f), two = f2s(2.0f);
-  // ---- Householder 1 on (S10, S20, S30)
-  const f2 a0 = S[4], a1 = S[8], a2 = S[12];
-  const f2 n1 = pk_sqrt(a0 * a0 + a1 * a1 + a2 * a2);
-  const f2 alpha = pk_sel(a0 < zero, n1, -n1);
-  const f2 v0 = a0 - alpha, v1 = a1, v2 = a2;
-  const f2 vv = v0 * v0 + v1 * v1 + v2 * v2;
-  const i2 ok1 = vv > zero;
-  const f2 beta = pk_sel(ok1, two * pk_rcp(pk_max(vv, f2s(1e-30f))), zero);
-  const f2 p0 = beta * (S[5] * v0 + S[6] * v1 + S[7] * v2);
-  const f2 p1 = beta * (S[6] * v0 + S[10] * v1 + S[11] * v2);
-  const f2 p2 = beta * (S[7] * v0 + S[11] * v1 + S[15] * v2);
-  const f2 kc = f2s(0.5f) * beta * (p0 * v0 + p1 * v1 + p2 * v2);
-  const f2 q0 = p0 - kc * v0, q1 = p1 - kc * v1, q2 = p2 - kc * v2;
-  const f2 B00 = S[5] - two * v0 * q0;
-  const f2 B01 = S[6] - v0 * q1 - q0 * v1, B02 = S[7] - v0 * q2 - q0 * v2;
-  const f2 B11 = S[10] - two * v1 * q1, B12 = S[11] - v1 * q2 - q1 * v2, B22 = S[15] - two * v2 * q2;
-  // ---- Householder 2 on (B10, B20)
-  const f2 n2 = pk_sqrt(B01 * B01 + B02 * B02);
-  const f2 alpha2 = pk_sel(B01 < zero, n2, -n2);
-  const f2 w0 = B01 - alpha2, w1 = B02;
-  const f2 ww = w0 * w0 + w1 * w1;
-  const i2 ok2 = ww > zero;
-  const f2 beta2 = pk_sel(ok2, two * pk_rcp(pk_max(ww, f2s(1e-30f))), zero);
-  const f2 r0 = beta2 * (B11 * w0 + B12 * w1), r1 = beta2 * (B12 * w0 + B22 * w1);
-  const f2 k2 = f2s(0.5f) * beta2 * (r0 * w0 + r1 * w1);
-  const f2 s0 = r0 - k2 * w0, s1 = r1 - k2 * w1;
-  const f2 d0 = S[0], d1 = B00, d2 = B11 - two * w0 * s0, d3 = B22 - two * w1 * s1;
-  const f2 e0 = pk_sel(ok1, alpha, a0), e1 = pk_sel(ok2, alpha2, B01), e2 = B12 - w0 * s1 - s0 * w1;
-  const f2 f0 = e0 * e0, f1 = e1 * e1, f2_ = e2 * e2;
-  const f2 scale = pk_max(pk_max(pk_abs(d0), pk_abs(d1)), pk_max(pk_abs(d2), pk_abs(d3))) + pk_max(pk_abs(e0), pk_max(pk_abs(e1), pk_abs(e2)));
-  // ---- Laguerre from below (all roots are >= 0: the start lam = 0 is left of, or on, the smallest one); a step below the
-  // fp32 resolution of the spectrum ends the iteration
-  f2 lam = zero;
-  i2 done = i2{0, 0};
-  const f2 stop = f2s(1e-7f) * scale;
-  for (int it = 0; it < 10; ++it) {
-    const f2 c0 = d0 - lam, c1 = d1 - lam, c2 = d2 - lam, c3 = d3 - lam;
-    const f2 P2 = c1 * c0 - f0, D2 = -c1 - c0;
-    const f2 P3 = c2 * P2 - f1 * c0, D3 = c2 * D2 - P2 + f1, E3 = two * c2 - two * D2;
-    const f2 P4 = c3 * P3 - f2_ * P2, D4 = c3 * D3 - P3 - f2_ * D2, E4 = c3 * E3 - two * D3 - two * f2_;
-    const i2 good = (P4 > zero) & ~done;
-    const f2 ip = pk_sel(good, pk_rcp(pk_max(P4, f2s(1e-37f))), zero);
-    const f2 G = D4 * ip, H = G * G - E4 * ip;
-    const f2 den = G - pk_sqrt(pk_max(f2s(3.0f) * (f2s(4.0f) * H - G * G), zero));
-    const i2 stepok = good & (den < zero);
-    const f2 step = pk_sel(stepok, f2s(-4.0f) * pk_rcp(pk_sel(stepok, den, f2s(-1.0f))), zero);
-    const f2 nl = lam + step;
-    done = done | ~good | ~(step > stop) | (nl == lam);
-    lam = pk_sel(done, lam, nl);
-    if (__ballot(!(done.x && done.y)) == 0ull) break;  // wave-uniform exit
-  }
-  // ---- null vector of T - lam: the adjugate column with the largest diagonal cofactor
-  const f2 c0 = d0 - lam, c1 = d1 - lam, c2 = d2 - lam, c3 = d3 - lam;
-  const f2 P1 = c0, P2 = c1 * c0 - f0, P3 = c2 * P2 - f1 * P1;
-  const f2 Q3 = c3, Q2 = c2 * c3 - f2_, Q1 = c1 * Q2 - f1 * Q3;
-  const f2 g0 = pk_abs(Q1), g1 = pk_abs(P1 * Q2), g2 = pk_abs(P2 * Q3), g3 = pk_abs(P3);
-  const i2 b1 = g1 > g0;                  // best of (0, 1)
-  const f2 g01 = pk_sel(b1, g1, g0);
-  const i2 b3 = g3 > g2;                  // best of (2, 3)
-  const f2 g23 = pk_sel(b3, g3, g2);
-  const i2 hi = g23 > g01;                // r in {2, 3} else {0, 1}; ties keep the lower index
-  const f2 e01 = e0 * e1, e12 = e1 * e2, e012 = e01 * e2;
-  // columns r = 0..3 of the adjugate
-  const f2 y0 = pk_sel(hi, pk_sel(b3, -e012, e01 * Q3), pk_sel(b1, -e0 * Q2, Q1));
-  const f2 y1 = pk_sel(hi, pk_sel(b3, P1 * e12, -P1 * e1 * Q3), pk_sel(b1, P1 * Q2, -e0 * Q2));
-  f2 y2 = pk_sel(hi, pk_sel(b3, -P2 * e2, P2 * Q3), pk_sel(b1, -P1 * e1 * Q3, e01 * Q3));
-  f2 y3 = pk_sel(hi, pk_sel(b3, P3, -P2 * e2), pk_sel(b1, P1 * e12, -e012));
-  f2 yy1 = y1;
-  // ---- back-transformation x = H1 H2 y
-  const f2 t2 = beta2 * (w0 * y2 + w1 * y3);
-  y2 -= t2 * w0; y3 -= t2 * w1;
-  const f2 t1 = beta * (v0 * yy1 + v1 * y2 + v2 * y3);
-  yy1 -= t1 * v0; y2 -= t1 * v1; y3 -= t1 * v2;
-  x[0] = y0; x[1] = yy1; x[2] = y2; x[3] = y3;
-}
-
-// One Rayleigh-quotient iteration in fp64: y = (S - rho I)^-1 x0, rho = x0^T S x0 / x0^T x0, by LDL^T without pivoting (S - rho I
-// is positive semi-definite up to the error of rho: only the last pivot is small, and a floored pivot only scales y).
-// S symmetric 4x4 (upper triangle read), x0 any non-zero vector.  y is not normalised: the caller uses ratios.
-__device__ inline void rqi_refine4(const double* S, const double* x0, double* y) {
-  const double a = x0[0], b = x0[1], c = x0[2], d = x0[3];
-  const double nn = a * a + b * b + c * c + d * d;
-  const double Sa = S[0] * a + S[1] * b + S[2] * c + S[3] * d, Sb = S[1] * a + S[5] * b + S[6] * c + S[7] * d;
-  const double Sc = S[2] * a + S[6] * b + S[10] * c + S[11] * d, Sd = S[3] * a + S[7] * b + S[11] * c + S[15] * d;
-  const double rho = (nn > 0.0) ? (a * Sa + b * Sb + c * Sc + d * Sd) * rcp_nr<1>(nn) : 0.0;
-  const double tiny = 1e-30;
-  const double m00 = S[0] - rho, m11 = S[5] - rho, m22 = S[10] - rho, m33 = S[15] - rho;
-  const double D0 = guard_piv(m00, tiny), i0 = rcp_nr<1>(D0);
-  const double l10 = S[1] * i0, l20 = S[2] * i0, l30 = S[3] * i0;
-  const double D1 = guard_piv(m11 - l10 * S[1], tiny), i1 = rcp_nr<1>(D1);
-  const double u21 = S[6] - l20 * S[1], u31 = S[7] - l30 * S[1];  // (row i, col 1) after eliminating column 0
-  const double l21 = u21 * i1, l31 = u31 * i1;
-  const double D2 = guard_piv(m22 - l20 * S[2] - l21 * u21, tiny), i2_ = rcp_nr<1>(D2);
-  const double u32 = S[11] - l30 * S[2] - l31 * u21;
-  const double l32 = u32 * i2_;
-  const double D3 = guard_piv(m33 - l30 * S[3] - l31 * u31 - l32 * u32, tiny), i3 = rcp_nr<1>(D3);
-  // L z = x0
-  const double z0 = a, z1 = b - l10 * z0, z2 = c - l20 * z0 - l21 * z1, z3 = d - l30 * z0 - l31 * z1 - l32 * z2;
-  // D w = z, L^T y = w
-  const double w3 = z3 * i3, w2 = z2 * i2_, w1 = z1 * i1, w0 = z0 * i0;
-  y[3] = w3;
-  y[2] = w2 - l32 * y[3];
-  y[1] = w1 - l21 * y[2] - l31 * y[3];
-  y[0] = w0 - l10 * y[1] - l20 * y[2] - l30 * y[3];
-}
-
 __global__ void __launch_bounds__(256)
 cheirality_kernel(const float* __restrict__ E, const float* __restrict__ pre, const float* __restrict__ K,
                   const float* __restrict__ matches, int B, int N, float depth_thres, float* __restrict__ Rt_cam,
                   int* __restrict__ winner, int* __restrict__ counts) {
-  // one workgroup per pair; with W wavefronts each takes every W-th group of 64 correspondences and they meet in LDS
   __shared__ int wcnt[8][4];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
   const size_t pair = blockIdx.x;
-  double Ed[9], Kd[9], R[2][9], t[3];
+  float Ef[9];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) { Ed[k] = (double)E[pair * 9 + k]; Kd[k] = to_sgpr((double)K[pair * 9 + k]); }
-  if (pre != nullptr) {  // E-from-F fused: the matrix decomposed is pre^T E pre (E = F, pre = T K; train_good_utils.py:356-358)
-    double Ad[9], tmp[9], Ef[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Ad[k] = (double)pre[pair * 9 + k];
-    mat3_mul_tn(Ad, Ed, tmp);
-    mat3_mul(tmp, Ad, Ef);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Ed[k] = (double)(float)Ef[k];  // through fp32 like the stand-alone congruence kernel's output
-  }
-  decompose_E(Ed, R[0], R[1], t);
-  // per-pair (wave-uniform) quantities live in scalar registers; the per-correspondence DLT owns the VGPRs
-#pragma unroll
-  for (int k = 0; k < 9; ++k) { R[0][k] = to_sgpr(R[0][k]); R[1][k] = to_sgpr(R[1][k]); }
-#pragma unroll
-  for (int k = 0; k < 3; ++k) t[k] = to_sgpr(t[k]);
-  // the two candidate projection matrices K [R | t], formed once per pair (measured: parking them in scalar registers and
-  // capping the kernel at 128 VGPRs for four wavefronts per SIMD is slower -- SGPR spills and constant-bus moves in the loop)
-  double P2s[2][12];
-#pragma unroll
-  for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        P2s[rr][4 * r + c] = Kd[3 * r] * R[rr][c] + Kd[3 * r + 1] * R[rr][3 + c] + Kd[3 * r + 2] * R[rr][6 + c];
-      P2s[rr][4 * r + 3] = Kd[3 * r] * t[0] + Kd[3 * r + 1] * t[1] + Kd[3 * r + 2] * t[2];
-    }
-  int cnt[4] = {0, 0, 0, 0};
-  const int nw = blockDim.x >> 6;  // 4 wavefronts per pair for small batches (latency), 1 for large ones (throughput)
-  // the next group's correspondence is loaded (index clamped, no branch) before the current one is triangulated: ~1 600
-  // instructions of DLT work cover its latency
-  const float4* mrow = reinterpret_cast<const float4*>(matches) + pair * N;
-  float4 mnext = mrow[min(wave * WAVE + lane, N - 1)];
-  for (int base = wave * WAVE; base < N; base += nw * WAVE) {
-    const int i = base + lane;
-    const bool live = i < N;
-    const float4 m = mnext;
-    mnext = mrow[min(i + nw * WAVE, N - 1)];
-    // One DLT per rotation: flipping t negates the 4th column of the view-2 rows, hence the 4th component of the null
-    // vector, hence both depths exactly -- candidates (R,t) and (R,-t) are counted from the same triangulation.
-    // DLT rows: x*P[2]-P[0], y*P[2]-P[1] for both views (P1 = K [I|0]); the view-1 rows are shared by the two candidates.
-    const double x1 = m.x, y1 = m.y, x2 = m.z, y2 = m.w;
-    double A1[6];  // view-1 rows, columns 0..2 (column 3 is zero)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { A1[c] = x1 * Kd[6 + c] - Kd[c]; A1[3 + c] = y1 * Kd[6 + c] - Kd[3 + c]; }
-    double S1[6];  // their contribution to the upper-left 3x3 of A^T A: (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
-    S1[0] = A1[0] * A1[0] + A1[3] * A1[3]; S1[1] = A1[0] * A1[1] + A1[3] * A1[4]; S1[2] = A1[0] * A1[2] + A1[3] * A1[5];
-    S1[3] = A1[1] * A1[1] + A1[4] * A1[4]; S1[4] = A1[1] * A1[2] + A1[4] * A1[5]; S1[5] = A1[2] * A1[2] + A1[5] * A1[5];
-    // ---- fp64 normal matrices of both candidates, scaled to unit trace (the null vector does not care; the Newton seeds and the
-    // fp32 stage want O(1) operands whatever the pixel scale)
-    double S[2][16];
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const double* P2 = P2s[rr];
-      double A2[8];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { A2[c] = x2 * P2[8 + c] - P2[c]; A2[4 + c] = y2 * P2[8 + c] - P2[4 + c]; }
-      double* Sr = S[rr];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = r; c < 4; ++c) Sr[4 * r + c] = A2[r] * A2[c] + A2[4 + r] * A2[4 + c];
-      Sr[0] += S1[0]; Sr[1] += S1[1]; Sr[2] += S1[2]; Sr[5] += S1[3]; Sr[6] += S1[4]; Sr[10] += S1[5];
-      const double itr = rcp_nr<1>(fmax(Sr[0] + Sr[5] + Sr[10] + Sr[15], 1e-30));
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = r; c < 4; ++c) Sr[4 * r + c] *= itr;
-    }
-    // ---- stage 1: both smallest eigenvectors to fp32 accuracy, packed
-    f2 Sp[16], Xp[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = r; c < 4; ++c) { Sp[4 * r + c] = f2{(float)S[0][4 * r + c], (float)S[1][4 * r + c]}; Sp[4 * c + r] = Sp[4 * r + c]; }
-    smallest_eigvec4_pk(Sp, Xp);
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const double* Rc = R[rr];
-      // ---- stage 2: one Rayleigh-quotient iteration in fp64
-      const double x0[4] = {(double)Xp[0][rr], (double)Xp[1][rr], (double)Xp[2][rr], (double)Xp[3][rr]};
-      double X[4];
-      rqi_refine4(S[rr], x0, X);
-      // depths z1 = X2 / X3 and z2 = (R_3 . X_012 + t_3 X3) / X3 tested without the division: 0 < z < thr  <=>  z' w > 0 and
-      // |z'| < thr |w| for z = z' / w
-      const double wq = X[3];
-      const double z1n = X[2];
-      const double z2n = Rc[6] * X[0] + Rc[7] * X[1] + Rc[8] * X[2] + t[2] * wq;
-      const double thr = (double)depth_thres;
-      const double aw = thr * fabs(wq);
-      const bool inr = live && (fabs(z1n) < aw) && (fabs(z2n) < aw) && (wq != 0.0);
-      const bool s1p = (z1n > 0.0) == (wq > 0.0), s2p = (z2n > 0.0) == (wq > 0.0);
-      const bool nz = (z1n != 0.0) && (z2n != 0.0);
-      const bool pos = inr && nz && s1p && s2p;    // both depths in (0, thr)
-      const bool neg = inr && nz && !s1p && !s2p;  // both in (-thr, 0): the (R, -t) candidate sees them in (0, thr)
-      cnt[2 * rr] += __popcll(__ballot(pos));
-      cnt[2 * rr + 1] += __popcll(__ballot(neg));
-    }
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) wcnt[wave][c] = cnt[c];
-  }
-  __syncthreads();
-  if (wave != 0) return;
-  if (nw > 1) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      int tsum = 0;
-      for (int w = 0; w < nw; ++w) tsum += wcnt[w][c];
-      cnt[c] = tsum;
-    }
-  }
-  int win = 0;
-#pragma unroll
-  for (int c = 1; c < 4; ++c)
-    if (cnt[c] > cnt[win]) win = c;  // first maximum, like max(enumerate(...)) (utils_F.py:730)
-  if (lane == 0) {
-    if (counts != nullptr) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) counts[pair * 4 + c] = cnt[c];
-    }
-    if (winner != nullptr) winner[pair] = (cnt[win] > 0) ? win : -1;
-    // camera motion = inverse of [R|t]: [R^T | -R^T t]   (utils_misc._inv_Rt, utils_misc.py:115-121)
-    double Rc[9];  // selected by value: a runtime index into R would put the whole array into scratch memory
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Rc[k] = (win >> 1) ? R[1][k] : R[0][k];
-    const double sg = (win & 1) ? -1.0 : 1.0;
-    float* dst = Rt_cam + pair * 12;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) dst[4 * r + c] = (cnt[win] > 0) ? (float)Rc[3 * c + r] : 0.0f;
-      const double tc = -(Rc[r] * t[0] + Rc[3 + r] * t[1] + Rc[6 + r] * t[2]) * sg;
-      dst[4 * r + 3] = (cnt[win] > 0) ? (float)tc : 0.0f;
-    }
-  }
+  for (int k = 0; k < 9; ++k) Ef[k] = E[pair * 9 + k];
+  cheirality_pair(Ef, pre, K, matches, pair, N, depth_thres, Rt_cam, winner, counts, wcnt);
+  (void)B;
 }
 
 }  // namespace

@@ -7,6 +7,7 @@
 #include "w8pt16_body.h"
 #include "w8pt16_bwd_body.h"
 #include "loss_head_body.h"
+#include "cheirality_body.h"
 
 namespace {
 
@@ -58,6 +59,35 @@ w8pt16_coop_fwd_kernel(const float* pts1, const float* pts2, const float* wts, i
   A.clamp_at = clamp_at; A.F_out = F_out; A.residual = residual; A.epi_res = R.epi_res; A.save = R.save;
   A.weights_out = R.weights_out; A.logits_mode = R.logits_mode; A.variant = R.variant; A.row_per_pair = false;
   w8pt16_fwd_pair<IT, RAW, PLAIN, 16>(A, pair, nullptr, &co, (int)(threadIdx.x >> 4));
+}
+
+// Fit + E-from-F + cheirality-checked pose of one pair in ONE launch (BASELINE config 5 at small batch): the cooperative fit, then
+// the same workgroup decomposes pre^T F pre and triangulates its pair's correspondences (cheirality_body.h) -- no second launch,
+// no second ramp, F never leaves the CU.
+struct W8PoseRest {
+  const float* pre;
+  const float* K;
+  float depth_thres;
+  float* Rt_cam;
+  int* winner;
+  int* counts;
+};
+template <int IT>
+__global__ void __launch_bounds__(256, (IT <= 4 ? 2 : 1))
+w8pt16_coop_pose_kernel(const float* pts1, const float* pts2, const float* wts, int B, int Bm, int N, float hw_sx, float hw_sy,
+                        float clamp_at, float* F_out, float* residual, const W8FwdRest R, const W8PoseRest P) {
+  __shared__ W8Coop co;
+  __shared__ int wcnt[8][4];
+  const int pair = (int)blockIdx.x;
+  W8Args A;
+  A.pts1 = pts1; A.pts2 = pts2; A.wts = wts; A.B = B; A.Bm = Bm; A.N = N; A.hw_sx = hw_sx; A.hw_sy = hw_sy;
+  A.clamp_at = clamp_at; A.F_out = F_out; A.residual = residual; A.epi_res = R.epi_res; A.save = R.save;
+  A.weights_out = R.weights_out; A.logits_mode = R.logits_mode; A.variant = R.variant; A.row_per_pair = false;
+  w8pt16_fwd_pair<IT, true, true, 16>(A, pair, nullptr, &co, (int)(threadIdx.x >> 4));
+  float Ef[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Ef[k] = co.of[k];  // published by row 0 before the output phase: every thread has passed that barrier
+  cheirality_pair(Ef, P.pre, P.K, pts1, (size_t)pair, N, P.depth_thres, P.Rt_cam, P.winner, P.counts, wcnt);
 }
 
 struct W8BwdRest {
@@ -242,4 +272,38 @@ int dfepe_w8pt16_bwd_launch(const W8BwdArgs& A, bool raw, hipStream_t st) {
   else { if (pgrad) launch_bwd<false, true, true>(A, st); else launch_bwd<false, false, true>(A, st); }
   if (hipGetLastError() != hipSuccess) return DFEPE_ERR_HIP;
   return (A.pending_head != nullptr) ? dfepe_loss_head_from_workspace(A.pending_head, st) : DFEPE_OK;
+}
+
+// ---- fit + E-from-F + cheirality-checked pose --------------------------------------------------------------------------------
+extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float* weights, int B, int N, int n_weight_sets, unsigned flags,
+                              float image_w, float image_h, float clamp_at, float* F_out, float* residual, float* epi_res, float* save,
+                              float* weights_out, void* stream);
+extern "C" int dfepe_cheirality(const float* E, const float* pre, const float* K, const float* matches, int B, int N, float depth_thres,
+                                float* Rt_cam, int* winner, int* counts, void* stream);
+
+extern "C" int dfepe_w8pt_pose_fwd(const float* matches, const float* weights, int B, int N, unsigned flags, float image_w, float image_h,
+                                   float clamp_at, const float* K, const float* pre, float depth_thres, float* F_out, float* residual,
+                                   float* epi_res, float* weights_out, float* Rt_cam, int* winner, int* counts, void* stream) {
+  if (!(flags & DFEPE_W8PT_RAW_MATCHES) || (flags & ~(DFEPE_W8PT_RAW_MATCHES | DFEPE_W8PT_LOGITS | DFEPE_W8PT_ROW_PER_PAIR))) return DFEPE_ERR_INVALID_ARG;
+  if (B < 0 || N <= 0) return DFEPE_ERR_INVALID_ARG;
+  if (B == 0) return DFEPE_OK;
+  if (!matches || !weights || !K || !F_out || !residual || !Rt_cam || !(image_w > 0.f && image_h > 0.f)) return DFEPE_ERR_INVALID_ARG;
+  if (reinterpret_cast<uintptr_t>(matches) & 15u) return DFEPE_ERR_INVALID_ARG;
+  if (!use_coop(N, B, (flags & DFEPE_W8PT_ROW_PER_PAIR) != 0)) {  // any other shape: the two launches this one replaces
+    const int rc = dfepe_w8pt_fwd(matches, nullptr, weights, B, N, 1, flags, image_w, image_h, clamp_at, F_out, residual, epi_res, nullptr,
+                                  weights_out, stream);
+    if (rc != DFEPE_OK) return rc;
+    return dfepe_cheirality(F_out, pre, K, matches, B, N, depth_thres, Rt_cam, winner, counts, stream);
+  }
+  W8FwdRest R;
+  R.epi_res = epi_res; R.save = nullptr; R.weights_out = weights_out; R.logits_mode = (flags & DFEPE_W8PT_LOGITS) ? 1 : 0; R.variant = 0u;
+  W8PoseRest P;
+  P.pre = pre; P.K = K; P.depth_thres = depth_thres; P.Rt_cam = Rt_cam; P.winner = winner; P.counts = counts;
+  const dim3 grid(B), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const float sx = 2.0f / image_w, sy = 2.0f / image_h;
+  if (N <= 512) hipLaunchKernelGGL((w8pt16_coop_pose_kernel<2>), grid, block, 0, st, matches, nullptr, weights, B, B, N, sx, sy, clamp_at, F_out, residual, R, P);
+  else if (N <= 1024) hipLaunchKernelGGL((w8pt16_coop_pose_kernel<4>), grid, block, 0, st, matches, nullptr, weights, B, B, N, sx, sy, clamp_at, F_out, residual, R, P);
+  else hipLaunchKernelGGL((w8pt16_coop_pose_kernel<8>), grid, block, 0, st, matches, nullptr, weights, B, B, N, sx, sy, clamp_at, F_out, residual, R, P);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }

@@ -425,6 +425,35 @@ def cheirality(E: Tensor, K: Tensor, matches: Tensor, depth_thres: float = 50.0,
     return Rt, win, cnt
 
 
+def fit_pose(matches: Tensor, weights: Tensor, K: Tensor, image_w: float, image_h: float, depth_thres: float = 50.0,
+             pre: Optional[Tensor] = None, clamp_at: float = 0.5, want_epi: bool = True, logits: bool = False, row_per_pair: bool = False):
+    """One weighted 8-point fit and the cheirality-checked pose of its F (BASELINE config 5): w8pt_forward followed by
+    cheirality(F, K, matches, depth_thres, pre=pre), same numbers, ONE launch when a cooperative workgroup serves the pair
+    (128 < N <= 2048 below 3072 pairs).  Returns (F, residual, epi | None, weights_out | None, Rt_cam, winner, counts)."""
+    m, w, K = _prep(matches, "matches"), _prep(weights, "weights"), _prep(K, "K")
+    pre = None if pre is None else _prep(pre, "pre")
+    _shape(m, "matches (pixel x1,y1,x2,y2)", None, None, 4)
+    B, N = m.shape[0], m.shape[1]
+    _shape(w, "weights", B, N)
+    _shape(K, "K (one intrinsic matrix per pair)", B, 3, 3)
+    if pre is not None:
+        _shape(pre, "pre", B, 3, 3)
+    dev = m.device
+    F = torch.empty(B, 3, 3, device=dev)
+    residual = torch.empty(B, N, device=dev)
+    epi = torch.empty(B, N, device=dev) if want_epi else None
+    w_out = torch.empty(B, N, device=dev) if logits else None
+    Rt = torch.empty(B, 3, 4, device=dev)
+    win = torch.empty(B, device=dev, dtype=torch.int32)
+    cnt = torch.empty(B, 4, device=dev, dtype=torch.int32)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().dfepe_w8pt_pose_fwd(_ptr(m), _ptr(w), B, N, _flags(True, logits, row_per_pair), float(image_w), float(image_h), float(clamp_at),
+                                            _ptr(K), _ptr(pre), float(depth_thres), _ptr(F), _ptr(residual), _ptr(epi), _ptr(w_out), _ptr(Rt), _ptr(win),
+                                            _ptr(cnt), _stream())
+    _lib.check(rc, "dfepe_w8pt_pose_fwd")
+    return F, residual, epi, w_out, Rt, win, cnt
+
+
 # ------------------------------------------------------------------------------------------------
 # validation summary reductions ("next" row f-2)
 # ------------------------------------------------------------------------------------------------

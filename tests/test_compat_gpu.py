@@ -648,3 +648,22 @@ def test_dense_W_and_unnormalised_rows_match_the_reference(dfepe, oracle, golden
     out_n, _ = dfepe.compat.DeepFNet.Fit()(pts1, pts2, w.detach())
     a2, r2, _ = unit_align(out_n.cpu().numpy(), g["nosvdnorm_out_f64"])
     assert np.abs(a2 - r2).max() > 1e-4
+
+
+@pytest.mark.parametrize("B,N", [(24, 1000), (7, 300), (5, 100), (3, 2500)])
+def test_fused_fit_and_pose_equals_the_two_launches(dfepe, B, N):
+    """ops.fit_pose (dfepe_w8pt_pose_fwd: the cooperative fit's workgroup goes on to the cheirality check of its own pair) against
+    w8pt_forward + cheirality(pre=T K): the same F, residuals, counts, winner and camera motion, bit for bit -- also for shapes that
+    fall back to the two launches (N <= 128, N > 2048)."""
+    sc = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(B, N, seed=61, outlier_ratio=0.25, noise_px=0.5), DEV)
+    m = sc["matches_xy_ori"]
+    w = torch.softmax(sc["logits_layers"][0], dim=1).contiguous()
+    H, W = float(IMAGE_SIZE[0]), float(IMAGE_SIZE[1])
+    T = torch.tensor([[2.0 / W, 0.0, -1.0], [0.0, 2.0 / H, -1.0], [0.0, 0.0, 1.0]], device=DEV)
+    TK = (T @ sc["Ks"]).contiguous()
+    F0, r0, e0, _, _ = dfepe.ops.w8pt_forward(m, None, w, True, W, H, 0.5, True, False)
+    Rt0, win0, cnt0 = dfepe.ops.cheirality(F0, sc["Ks"], m, 50.0, pre=TK)
+    F1, r1, e1, _, Rt1, win1, cnt1 = dfepe.ops.fit_pose(m, w, sc["Ks"], W, H, 50.0, pre=TK)
+    for a, b in ((F0, F1), (r0, r1), (e0, e1), (Rt0, Rt1), (win0, win1), (cnt0, cnt1)):
+        assert torch.equal(a, b)
+    assert (win1 >= 0).float().mean().item() > 0.8
