@@ -4,6 +4,10 @@
 #pragma once
 #include "dfepe_common.h"
 
+// internal linkage on purpose: with external (inline) linkage hipcc keeps decompose_E / svd3_closed as real calls, which drags
+// the module's LDS and the full ABI into the kernel (35 instead of 23 us at 512 pairs)
+namespace {
+
 // the four-fold ambiguity of utils_F._get_M2s (utils_F.py:478-498): R1 = U W V^T, R2 = U W^T V^T (both negated when
 // det < 0), t = u3 / |u3|
 __device__ inline void decompose_E(const double* E, double* R1, double* R2, double* t) {
@@ -281,20 +285,21 @@ __device__ __forceinline__ void cheirality_pair(const float* E9, const float* __
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       int tsum = 0;
-      for (int w = 0; w < nw; ++w) tsum += wcnt[w][c];
-      cnt[c] = tsum;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) tsum += (w < nw) ? wcnt[w][c] : 0;  // fully unrolled: a runtime trip count here turns cnt[] into
+      cnt[c] = tsum;                                                   // a dynamically indexed array, which hipcc parks in LDS
     }
   }
-  int win = 0;
+  int win = 0, best = cnt[0];  // `best` instead of best: a runtime index would turn cnt[] into an array in (LDS-promoted) memory
 #pragma unroll
   for (int c = 1; c < 4; ++c)
-    if (cnt[c] > cnt[win]) win = c;  // first maximum, like max(enumerate(...)) (utils_F.py:730)
+    if (cnt[c] > best) { best = cnt[c]; win = c; }  // first maximum, like max(enumerate(...)) (utils_F.py:730)
   if (lane == 0) {
     if (counts != nullptr) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) counts[pair * 4 + c] = cnt[c];
     }
-    if (winner != nullptr) winner[pair] = (cnt[win] > 0) ? win : -1;
+    if (winner != nullptr) winner[pair] = (best > 0) ? win : -1;
     // camera motion = inverse of [R|t]: [R^T | -R^T t]   (utils_misc._inv_Rt, utils_misc.py:115-121)
     double Rc[9];  // selected by value: a runtime index into R would put the whole array into scratch memory
 #pragma unroll
@@ -304,10 +309,11 @@ __device__ __forceinline__ void cheirality_pair(const float* E9, const float* __
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) dst[4 * r + c] = (cnt[win] > 0) ? (float)Rc[3 * c + r] : 0.0f;
+      for (int c = 0; c < 3; ++c) dst[4 * r + c] = (best > 0) ? (float)Rc[3 * c + r] : 0.0f;
       const double tc = -(Rc[r] * t[0] + Rc[3 + r] * t[1] + Rc[6 + r] * t[2]) * sg;
-      dst[4 * r + 3] = (cnt[win] > 0) ? (float)tc : 0.0f;
+      dst[4 * r + 3] = (best > 0) ? (float)tc : 0.0f;
     }
   }
 }
 
+}  // namespace

@@ -73,9 +73,8 @@ def pose_step(B):
     w0 = torch.softmax(sc["logits_layers"][0], dim=1).contiguous()
     m = sc["matches_xy_ori"]
 
-    def body():
-        F, _, _, _, _ = d.ops.w8pt_forward(m, None, w0, True, W, H, 0.5, True, False)
-        d.ops.cheirality(F, sc["Ks"], m, 50.0, pre=TK)
+    def body():  # bench.py --config 5: one launch for the cooperative shapes (<= 3072 pairs), two otherwise
+        d.ops.fit_pose(m, w0, sc["Ks"], W, H, 50.0, pre=TK)
 
     fit = graph_time_us(lambda: d.ops.w8pt_forward(m, None, w0, True, W, H, 0.5, True, False))
     return graph_time_us(body), fit

@@ -8,7 +8,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O = os.path.join(REPO, "gpurun_out", f"prof_{tag}")
 P = os.path.join(REPO, "profiles")
 B, N, L, M = 4096, 100, 5, 100
-FIT_FWD, FIT_BWD, TAIL, HEAD = "w8pt16_fwd_kernel<7, true, true>", "w8pt16_bwd_kernel<7, true, false>", "loss_tail_kernel<7>", "loss_tail_head_kernel"
+FIT_FWD, FIT_BWD, TAIL, HEAD = "w8pt16_fwd_kernel<7, true, true>", "w8pt16_bwd_kernel<7, true, false, true>", "loss_tail_kernel<7>", "loss_tail_head_kernel"
 BWD_HEAD = "w8pt16_bwd_head_kernel<7, true>"  # the first backward fit of the step, with the deferred loss head in spare wavefronts
 HOT = (FIT_FWD, FIT_BWD, BWD_HEAD, TAIL, HEAD)
 
