@@ -20,7 +20,7 @@ extern "C" const char* dfepe_strerror(int code) {
 // the host emulation of tests/emu/ can only assume; this kernel applies every primitive to caller-provided data so that
 // tests/test_rowgroup_gpu.py can compare them with their definition on the hardware itself.
 namespace {
-constexpr int kSelftestOutputs = 14;
+constexpr int kSelftestOutputs = 14 + 2 + 9 + 9 + 2;
 __global__ void __launch_bounds__(64) rowgroup_selftest_kernel(const double* __restrict__ x, const double* __restrict__ y,
                                                                double* __restrict__ out) {
   const int t = (int)threadIdx.x;
@@ -42,6 +42,26 @@ __global__ void __launch_bounds__(64) rowgroup_selftest_kernel(const double* __r
   r[11] = rg_fma_bcast<3>(b, a, b);
   r[12] = (double)rg_sum(af);
   r[13] = (double)rg_bcast<9>(af) + (double)rg_bcast<12>(ai) + (double)rg_lane();
+  // the fused broadcast-FMA chains; every DPP operand below is produced by the instruction right in front of the chain (the
+  // hazard the chains pad for)
+  double m[9], n[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) { m[j] = a + (double)j * b; n[j] = b - (double)j; }
+  const double xa = a * b + 1.0;
+  r[14] = rg_dot_bcast<1>(xa, m);
+  const double xb = a - b;
+  r[15] = rg_dot_bcast<6>(xb, m);
+  const double xc = a * 3.0;
+  rg_axpy_bcast<3>(m, xc, b);
+#pragma unroll
+  for (int j = 0; j < 9; ++j) r[16 + j] = m[j];
+  const double xd = b * b, xe = a + 2.0;
+  rg_axpy2_bcast<1>(n, xd, a, xe, b);
+#pragma unroll
+  for (int j = 0; j < 9; ++j) r[25 + j] = n[j];
+  const double xf = a * a;
+  r[34] = rg_sum_to8<0>(xf);
+  r[35] = rg_sum_to8<5>(xf + 1.0);
 #pragma unroll
   for (int k = 0; k < kSelftestOutputs; ++k) out[k * 64 + t] = r[k];
 }

@@ -24,24 +24,25 @@ __device__ __forceinline__ double fast_rcp(double x) {
 }
 __device__ __forceinline__ double fast_sqrt(double x) { return (x > 0.0) ? x * fast_rsqrt(x) : 0.0; }
 
-// Branch-free variants for operands whose magnitude lies in the fp32 exponent range (everything the solver forms from
-// normalised coordinates and unit-trace matrices does): fp32 hardware seed on a clamped copy, Newton-Raphson in fp64
-// on the true operand.  STEPS = 1 gives ~1e-14 relative, 2 full fp64.  No range test, hence no divergent fall-back path:
-// outside the range the result is finite garbage (0 * seed), never NaN.
-template <int STEPS>
+// Branch-free variants: the fp64 hardware seed (v_rsq_f64 / v_rcp_f64: ~2^-23 relative on gfx950, scripts/ubench/seed_precision.hip)
+// plus Newton-Raphson in fp64.  STEPS = 1 gives ~1e-14 relative, 2 full fp64.  One 16-cycle instruction for the seed instead of the
+// fp32 detour (convert, clamp into the fp32 range, v_rsq_f32, convert back: five instructions of 5-8 cycles each).  No range test,
+// hence no divergent fall-back path.  SAFE (default): a zero (or a negative rounding residue) operand gives finite garbage times
+// zero, never NaN -- one v_max_f64 on the operand; callers whose operand is known to be positive and normal pass SAFE = false.
+template <int STEPS, bool SAFE = true>
 __device__ __forceinline__ double rsqrt_nr(double x) {
-  double y = (double)hw_rsq(fminf(fmaxf((float)x, 1e-37f), 1e37f));
+  double y = hw_rsq64(SAFE ? fmax(x, 1e-290) : x);
   const double h = -0.5 * x;
 #pragma unroll
   for (int k = 0; k < STEPS; ++k) y = fma(y, fma(h, y * y, 0.5), y);  // y (1.5 - x y^2 / 2) with inline constants only
   return y;
 }
-template <int STEPS>
-__device__ __forceinline__ double sqrt_nr(double x) { return x * rsqrt_nr<STEPS>(x); }  // 0 for x = 0
-template <int STEPS>
+template <int STEPS, bool SAFE = true>
+__device__ __forceinline__ double sqrt_nr(double x) { return x * rsqrt_nr<STEPS, SAFE>(x); }  // 0 for x = 0
+// SAFE: |x| is raised to 1e-290 (sign kept): 1 / 0 is a huge finite number, not NaN after the Newton step
+template <int STEPS, bool SAFE = true>
 __device__ __forceinline__ double rcp_nr(double x) {
-  const float xf = (float)x;
-  double y = (double)hw_rcp(copysignf(fminf(fmaxf(fabsf(xf), 1e-37f), 1e37f), xf));
+  double y = hw_rcp64(SAFE ? copysign(fmax(fabs(x), 1e-290), x) : x);
 #pragma unroll
   for (int k = 0; k < STEPS; ++k) y = fma(y, fma(-x, y, 1.0), y);  // y (2 - x y)
   return y;
@@ -195,7 +196,7 @@ __device__ __forceinline__ void sym3_null_vector(double c00, double c01, double 
   double x0 = a0, x1 = a1, x2 = a2, nx = na;
   if (nb > nx) { x0 = b0; x1 = b1; x2 = b2; nx = nb; }
   if (nd > nx) { x0 = d0; x1 = d1; x2 = d2; nx = nd; }
-  const double inv = (nx > 0.0) ? rsqrt_nr<2>(nx) : 0.0;
+  const double inv = (nx > 0.0) ? rsqrt_nr<2, false>(nx) : 0.0;
   n[0] = x0 * inv; n[1] = x1 * inv; n[2] = x2 * inv;
   if (!(nx > 0.0)) { n[0] = 0.0; n[1] = 0.0; n[2] = 1.0; }  // the zero matrix: any unit vector
   if constexpr (ROBUST) {
@@ -228,7 +229,7 @@ __device__ __forceinline__ void smallest_singular_triplet3(const double* F, doub
   for (int it = 0; it < 12; ++it) {
     const double p = fma(fma(c2 - x, x, -c1), x, c0);            // -x^3 + c2 x^2 - c1 x + c0
     const double dp = fma(fma(-3.0, x, 2.0 * c2), x, -c1);       // p'(x) < 0 left of the smallest root
-    const double dx = (dp < 0.0) ? -p * rcp_nr<2>(dp) : 0.0;
+    const double dx = (dp < 0.0) ? -p * rcp_nr<2, false>(dp) : 0.0;
     if (!(dx > 1e-17 * c2)) break;                                // also leaves on NaN; p <= 0: at (or rounded past) the root
     x += dx;
   }

@@ -69,9 +69,24 @@ struct W8Args {
   bool row_per_pair;  // host side only: never the cooperative workgroup (DFEPE_W8PT_ROW_PER_PAIR)
 };
 
-// phase markers for scripts/isa_phases.py (hipcc -DDFEPE_ISA_MARKS -S): comments in the assembly, nothing otherwise
-#ifdef DFEPE_ISA_MARKS
+// phase markers for scripts/isa_phases.py (hipcc -DDFEPE_ISA_MARKS -S): comments in the assembly, nothing otherwise;
+// -DDFEPE_PHASE_CLOCKS (scripts/ubench/fit_phases.hip only): lane 0 of every wavefront stamps the shader clock at each marker
+#if defined(DFEPE_ISA_MARKS)
 #define DFEPE_MARK(name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; MARK " name); __builtin_amdgcn_sched_barrier(0); } while (0)
+#elif defined(DFEPE_PHASE_CLOCKS)
+constexpr int dfepe_phase_id(const char* s) {  // P0 P1 P2 P3 P4 P4b P4c P4d P5 P5b P5s P6 Pend -> 0..12
+  return (s[1] == '0') ? 0 : (s[1] == '1') ? 1 : (s[1] == '2') ? 2 : (s[1] == '3') ? 3
+       : (s[1] == '4') ? ((s[2] == 0) ? 4 : (s[2] == 'b') ? 5 : (s[2] == 'c') ? 6 : 7)
+       : (s[1] == '5') ? ((s[2] == 0) ? 8 : (s[2] == 'b') ? 9 : 10) : (s[1] == '6') ? 11 : 12;
+}
+extern __device__ unsigned long long* g_dfepe_phase_clk;  // [wavefront][16]
+#define DFEPE_MARK(name)                                                                                              \
+  do {                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                \
+    const unsigned long long t_ = __builtin_readcyclecounter();                                                       \
+    if ((threadIdx.x & 63u) == 0u) g_dfepe_phase_clk[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + dfepe_phase_id(name)] = t_; \
+    __builtin_amdgcn_sched_barrier(0);                                                                                \
+  } while (0)
 #else
 #define DFEPE_MARK(name)
 #endif
@@ -250,32 +265,23 @@ __device__ __forceinline__ void eig9_select(double* Ar, const int l, const int k
     td[k] = rg_bcast<k>(Ar[k]);
     const double xk = (l > k) ? Ar[k] : 0.0;  // A[l][k] = A[k][l] (symmetric): the column below the diagonal
     const double x1 = rg_bcast<k + 1>(xk);
-    const double sig = rg_sum_range<k + 2, 8>(xk * xk);
+    const double sig = rg_sum_to8<k + 2>(xk * xk);
     const double nrm = sqrt_nr<2>(fma(x1, x1, sig));
     const bool ok = sig > 0.0;  // nothing to annihilate otherwise: H_k = I
     const double alpha = (x1 > 0.0) ? -nrm : nrm;
     const double vk1 = x1 - alpha;
     const double vtv = fma(vk1, vk1, sig);
-    const double beta = ok ? 2.0 * rcp_nr<2>(vtv) : 0.0;
+    const double beta = ok ? 2.0 * rcp_nr<2, false>(vtv) : 0.0;
     te[k] = ok ? alpha : x1;
     hb[k] = beta;
     const double v = ok ? ((l == k + 1) ? vk1 : ((l > k + 1) ? xk : 0.0)) : 0.0;
     hv[k] = v;
     // p = beta A v (rows > k), K = beta/2 v^T p, w = p - K v, A -= v w^T + w v^T
-    double p = 0.0;
-    static_for<k + 1, 9>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      p = rg_fma_bcast<j>(p, v, Ar[j]);
-    });
+    double p = rg_dot_bcast<k + 1>(v, Ar);  // one fused broadcast-FMA per term (rowgroup.h)
     p = (l > k) ? p * beta : 0.0;
-    const double K = 0.5 * beta * rg_sum_range<k + 1, 8>(v * p);
+    const double K = 0.5 * beta * rg_sum_to8<k + 1>(v * p);
     const double w = fma(-K, v, p);
-    const double nv = -v, nw = -w;
-    static_for<k + 1, 9>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      Ar[j] = rg_fma_bcast<j>(Ar[j], w, nv);
-      Ar[j] = rg_fma_bcast<j>(Ar[j], v, nw);
-    });
+    rg_axpy2_bcast<k + 1>(Ar, w, -v, v, -w);
   });
   td[7] = rg_bcast<7>(Ar[7]);
   td[8] = rg_bcast<8>(Ar[8]);
@@ -320,14 +326,14 @@ __device__ __forceinline__ void eig9_select(double* Ar, const int l, const int k
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     dp[k] = pivot_guard(dp[k]);
-    rp[k] = rcp_nr<1>(dp[k]);  // one Newton step from the fp32 seed: ~2e-14, far inside what the eigenvector needs
+    rp[k] = rcp_nr<1, false>(dp[k]);  // one Newton step from the fp32 seed: ~2e-14, far inside what the eigenvector needs
     dp[k + 1] = (td[k + 1] - lam) - te2[k] * rp[k];
   }
   dm[8] = td[8] - lam;
 #pragma unroll
   for (int k = 7; k >= 0; --k) {
     dm[k + 1] = pivot_guard(dm[k + 1]);
-    rm[k + 1] = rcp_nr<1>(dm[k + 1]);
+    rm[k + 1] = rcp_nr<1, false>(dm[k + 1]);
     dm[k] = (td[k] - lam) - te2[k] * rm[k + 1];
   }
   twist = 0;
@@ -346,7 +352,7 @@ __device__ __forceinline__ void eig9_select(double* Ar, const int l, const int k
   double zn = 0.0;
 #pragma unroll
   for (int k = 0; k < 9; ++k) zn = fma(z[k], z[k], zn);
-  zn = rsqrt_nr<2>(zn);
+  zn = rsqrt_nr<2, false>(zn);  // >= 1: z[twist] = 1
 #pragma unroll
   for (int k = 0; k < 9; ++k) { z[k] *= zn; f[k] = z[k]; }
 
@@ -354,16 +360,8 @@ __device__ __forceinline__ void eig9_select(double* Ar, const int l, const int k
   // f = H_0 H_1 ... H_6 z, every lane keeps the whole vector (the reflector components come in by broadcast)
   static_for<0, 7>([&](auto kc) {
     constexpr int k = 6 - decltype(kc)::value;
-    double s = 0.0;
-    static_for<k + 1, 9>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      s = rg_fma_bcast<j>(s, hv[k], f[j]);
-    });
-    s *= -hb[k];
-    static_for<k + 1, 9>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      f[j] = rg_fma_bcast<j>(f[j], hv[k], s);
-    });
+    const double s = -hb[k] * rg_dot_bcast<k + 1>(hv[k], f);
+    rg_axpy_bcast<k + 1>(f, hv[k], s);
   });
 }
 
@@ -575,7 +573,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     const double n2 = (a0 * a0 + a1 * a1 + a2 * a2) * (b0 * b0 + b1 * b1 + 1.0);  // |p|^2, finite (phase 0 dropped the rest)
     // (w / max(|p|, 1e-12))^2; a dropped or padding correspondence has w = 0 and contributes exact zeros.  1 / |p| is kept
     // for the residual of phase 6 when the correspondences live in registers.
-    const double inv = fmin(rsqrt_nr<1>(n2), 1e12);  // ~2e-14: it only scales a weight
+    const double inv = fmin(rsqrt_nr<1, !RAW>(n2), 1e12);  // ~2e-14: it only scales a weight; RAW: n2 >= 1
     if constexpr (IT > 0) invs[it] = inv;
     const double wi = (variant & DFEPE_W8PT_NO_ROWNORM) ? w : w * inv;
     const double k2 = wi * wi;
@@ -642,9 +640,9 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
       Ar[j] = (l < 9) ? m : 0.0;
     }
     const double dg = xch[6 * sym(r, r) + sym(c, c)];
-    tr = rg_sum_range<0, 8>(dg);
+    tr = rg_sum_to8<0>(dg);
   }
-  const double inv_tr = (tr > 0.0) ? rcp_nr<2>(tr) : 1.0;
+  const double inv_tr = (tr > 0.0) ? rcp_nr<2, false>(tr) : 1.0;
 #pragma unroll
   for (int j = 0; j < 9; ++j) Ar[j] *= inv_tr;
 
@@ -668,7 +666,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   for (int c = 1; c < 9; ++c)
     if (fabs(f[c]) > fabs(big)) big = f[c];
   const double sgn = (big < 0.0) ? -1.0 : 1.0;
-  const double fscale = sgn * rsqrt_nr<2>(fn2);
+  const double fscale = sgn * rsqrt_nr<2, false>(fn2);  // a unit vector up to rounding
 #pragma unroll
   for (int c = 0; c < 9; ++c) f[c] *= fscale;
 
@@ -803,4 +801,5 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
       }
     }
   });
+  DFEPE_MARK("Pend");
 }

@@ -57,20 +57,20 @@ __device__ __forceinline__ void tri_pinv_apply(const double* td, const double* t
   // two blocks decouple and each is a principal sub-matrix of the positive semi-definite T - lam I that excludes the
   // largest component of its null vector: definite, pivots away from zero.
   double rp[9], gp[9], rm[9], gm[9];  // reciprocal pivots, eliminated right-hand sides
-  rp[0] = rcp_nr<1>(guard_den16(td[0] - lam));
+  rp[0] = rcp_nr<1, false>(guard_den16(td[0] - lam));
   gp[0] = g[0];
 #pragma unroll
   for (int k = 1; k < 9; ++k) {
     const double m = te[k - 1] * rp[k - 1];
-    rp[k] = rcp_nr<1>(guard_den16((td[k] - lam) - m * te[k - 1]));
+    rp[k] = rcp_nr<1, false>(guard_den16((td[k] - lam) - m * te[k - 1]));
     gp[k] = g[k] - m * gp[k - 1];
   }
-  rm[8] = rcp_nr<1>(guard_den16(td[8] - lam));
+  rm[8] = rcp_nr<1, false>(guard_den16(td[8] - lam));
   gm[8] = g[8];
 #pragma unroll
   for (int k = 7; k >= 0; --k) {
     const double m = te[k] * rm[k + 1];
-    rm[k] = rcp_nr<1>(guard_den16((td[k] - lam) - m * te[k]));
+    rm[k] = rcp_nr<1, false>(guard_den16((td[k] - lam) - m * te[k]));
     gm[k] = g[k] - m * gm[k + 1];
   }
 #pragma unroll
@@ -249,14 +249,14 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
         for (int r = 0; r < 3; ++r) l2[r] = o[3 * r] * x1[0] + o[3 * r + 1] * x1[1] + o[3 * r + 2] * x1[2];
         const double dd = x1[0] * l1[0] + x1[1] * l1[1] + x1[2] * l1[2];
         const double n1 = sqrt_nr<1>(l1[0] * l1[0] + l1[1] * l1[1]), n2 = sqrt_nr<1>(l2[0] * l2[0] + l2[1] * l2[1]);
-        const double i1 = rcp_nr<1>(n1 + 1e-6), i2 = rcp_nr<1>(n2 + 1e-6);
+        const double i1 = rcp_nr<1, false>(n1 + 1e-6), i2 = rcp_nr<1, false>(n2 + 1e-6);
         const double S = i1 + i2, ad = fabs(dd);
         const double d = ad * S;
         // clamp(max=) passes the gradient up to and including the bound
         const double g = (d <= (double)A.clamp_at) ? (double)up_epi(it, i) : 0.0;
         const double sg = (dd > 0.0) ? 1.0 : ((dd < 0.0) ? -1.0 : 0.0);
-        const double k1 = (n1 > 0.0) ? ad * i1 * i1 * rcp_nr<1>(n1) : 0.0;
-        const double k2 = (n2 > 0.0) ? ad * i2 * i2 * rcp_nr<1>(n2) : 0.0;
+        const double k1 = (n1 > 0.0) ? ad * i1 * i1 * rcp_nr<1, false>(n1) : 0.0;
+        const double k2 = (n2 > 0.0) ? ad * i2 * i2 * rcp_nr<1, false>(n2) : 0.0;
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -369,31 +369,15 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
     for (int c = 0; c < 9; ++c) gt[c] = gf[c];
     static_for<0, 7>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
-      double s = 0.0;
-      static_for<k + 1, 9>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        s = rg_fma_bcast<j>(s, hv[k], gt[j]);
-      });
-      s *= -hb[k];
-      static_for<k + 1, 9>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        gt[j] = rg_fma_bcast<j>(gt[j], hv[k], s);
-      });
+      const double s = -hb[k] * rg_dot_bcast<k + 1>(hv[k], gt);  // fused broadcast-FMA chains (rowgroup.h)
+      rg_axpy_bcast<k + 1>(gt, hv[k], s);
     });
   DFEPE_MARK("B5_tripinv");
     tri_pinv_apply(td, te, lam, z, twist, gt, y);
     static_for<0, 7>([&](auto kc) {
       constexpr int k = 6 - decltype(kc)::value;
-      double s = 0.0;
-      static_for<k + 1, 9>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        s = rg_fma_bcast<j>(s, hv[k], y[j]);
-      });
-      s *= -hb[k];
-      static_for<k + 1, 9>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        y[j] = rg_fma_bcast<j>(y[j], hv[k], s);
-      });
+      const double s = -hb[k] * rg_dot_bcast<k + 1>(hv[k], y);
+      rg_axpy_bcast<k + 1>(y, hv[k], s);
     });
     const double sc = good ? -inv_tr : (double)NAN;
 #pragma unroll
@@ -499,7 +483,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
       const double b0 = s2 * ((double)p.x2 - c2x * z2), b1 = s2 * ((double)p.y2 - c2y * z2);
       const double n2 = (a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) * (b0 * b0 + b1 * b1 + 1.0);
       const bool ok = keep && (n2 > 1e-24);
-      const double inv = ok ? rsqrt_nr<1>(n2) : 0.0;
+      const double inv = ok ? rsqrt_nr<1, false>(n2) : 0.0;
       double ph[9];
 #pragma unroll
       for (int k = 0; k < 3; ++k) { ph[k] = b0 * a[k] * inv; ph[3 + k] = b1 * a[k] * inv; ph[6 + k] = a[k] * inv; }
@@ -523,12 +507,12 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
         for (int r = 0; r < 3; ++r) l2[r] = o[3 * r] * x1[0] + o[3 * r + 1] * x1[1] + o[3 * r + 2] * x1[2];
         const double dd = x1[0] * l1[0] + x1[1] * l1[1] + x1[2] * l1[2];
         const double n1 = sqrt_nr<1>(l1[0] * l1[0] + l1[1] * l1[1]), nn2 = sqrt_nr<1>(l2[0] * l2[0] + l2[1] * l2[1]);
-        const double i1 = rcp_nr<1>(n1 + 1e-6), i2 = rcp_nr<1>(nn2 + 1e-6);
+        const double i1 = rcp_nr<1, false>(n1 + 1e-6), i2 = rcp_nr<1, false>(nn2 + 1e-6);
         const double Ss = i1 + i2, ad = fabs(dd);
         const double g = (ad * Ss <= (double)A.clamp_at) ? gsc * (double)up_epi(it, i) : 0.0;
         const double sg = (dd > 0.0) ? 1.0 : ((dd < 0.0) ? -1.0 : 0.0);
-        const double k1 = (n1 > 0.0) ? ad * i1 * i1 * rcp_nr<1>(n1) : 0.0;
-        const double k2 = (nn2 > 0.0) ? ad * i2 * i2 * rcp_nr<1>(nn2) : 0.0;
+        const double k1 = (n1 > 0.0) ? ad * i1 * i1 * rcp_nr<1, false>(n1) : 0.0;
+        const double k2 = (nn2 > 0.0) ? ad * i2 * i2 * rcp_nr<1, false>(nn2) : 0.0;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           e1[c] = g * (sg * Ss * l1[c] - k2 * (l2[0] * o[c] + l2[1] * o[3 + c]));          // d n2 / d x1_c
@@ -554,7 +538,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
       }
       const double dx1 = (double)p.x1 - c1x, dy1 = (double)p.y1 - c1y, dx2 = (double)p.x2 - c2x, dy2 = (double)p.y2 - c2y;
       const double r1 = dx1 * dx1 + dy1 * dy1, r2 = dx2 * dx2 + dy2 * dy2;
-      const double ir1 = (r1 > 0.0) ? rsqrt_nr<1>(r1) : 0.0, ir2 = (r2 > 0.0) ? rsqrt_nr<1>(r2) : 0.0;
+      const double ir1 = (r1 > 0.0) ? rsqrt_nr<1, false>(r1) : 0.0, ir2 = (r2 > 0.0) ? rsqrt_nr<1, false>(r2) : 0.0;
       sums[0] += (float)(((double)p.x1 - c1x * z1) * ga0 + ((double)p.y1 - c1y * z1) * ga1);  // d/ds1 through the rows
       sums[1] += (float)(-s1 * z1 * ga0);
       sums[2] += (float)(-s1 * z1 * ga1);
@@ -579,7 +563,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const i
       if (!rec.valid) return;
       const double dx1 = (double)p.x1 - c1x, dy1 = (double)p.y1 - c1y, dx2 = (double)p.x2 - c2x, dy2 = (double)p.y2 - c2y;
       const double r1 = dx1 * dx1 + dy1 * dy1, r2 = dx2 * dx2 + dy2 * dy2;
-      const double ir1 = (r1 > 0.0) ? rsqrt_nr<1>(r1) : 0.0, ir2 = (r2 > 0.0) ? rsqrt_nr<1>(r2) : 0.0;
+      const double ir1 = (r1 > 0.0) ? rsqrt_nr<1, false>(r1) : 0.0, ir2 = (r2 > 0.0) ? rsqrt_nr<1, false>(r2) : 0.0;
       const float a1x = (float)(Gd1 * invN * dx1 * ir1 + Gc1x), a1y = (float)(Gd1 * invN * dy1 * ir1 + Gc1y);
       const float a2x = (float)(Gd2 * invN * dx2 * ir2 + Gc2x), a2y = (float)(Gd2 * invN * dy2 * ir2 + Gc2y);
       float p1x, p1y, p2x, p2y;  // the provisional values of the first pass

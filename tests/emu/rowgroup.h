@@ -33,6 +33,17 @@ struct float4 {
 inline float hw_rsq(float x) { return 1.0f / sqrtf(x); }
 inline float hw_rcp(float x) { return 1.0f / x; }
 inline float hw_sqrt(float x) { return sqrtf(x); }
+// the fp64 hardware seeds are good to ~2^-23: the emulation keeps 24 bits of the exact result, so that the Newton step counts of
+// dfepe_math.h are exercised with a seed no better than the hardware's
+inline double emu_seed24(double v) {
+  uint64_t u;
+  memcpy(&u, &v, 8);
+  u &= ~((1ull << 29) - 1ull);
+  memcpy(&v, &u, 8);
+  return v;
+}
+inline double hw_rsq64(double x) { return emu_seed24(1.0 / sqrt(x)); }
+inline double hw_rcp64(double x) { return emu_seed24(1.0 / x); }
 
 namespace emu {
 constexpr int kLanes = 16;
@@ -108,6 +119,33 @@ template <int K0, int K1>
 inline double rg_sum_range(double v) {
   if constexpr (K0 >= K1) return rg_bcast<K1>(v);
   else return rg_bcast<K0>(v) + rg_sum_range<K0 + 1, K1>(v);
+}
+
+// the fused chains of csrc/rowgroup.h, same order of operations (two partial sums over alternating lanes)
+template <int J0>
+inline double rg_dot_bcast(double x, const double* a) {
+  double acc[2] = {0.0, 0.0};
+  const double b[9] = {0.0, rg_bcast<1>(x), rg_bcast<2>(x), rg_bcast<3>(x), rg_bcast<4>(x), rg_bcast<5>(x), rg_bcast<6>(x), rg_bcast<7>(x), rg_bcast<8>(x)};
+  for (int j = J0; j <= 8; ++j) acc[(j - J0) & 1] = fma(b[j], a[j], acc[(j - J0) & 1]);
+  return (J0 == 8) ? acc[0] : acc[0] + acc[1];
+}
+template <int J0>
+inline void rg_axpy_bcast(double* a, double x1, double y1) {
+  const double b[9] = {0.0, rg_bcast<1>(x1), rg_bcast<2>(x1), rg_bcast<3>(x1), rg_bcast<4>(x1), rg_bcast<5>(x1), rg_bcast<6>(x1), rg_bcast<7>(x1), rg_bcast<8>(x1)};
+  for (int j = J0; j <= 8; ++j) a[j] = fma(b[j], y1, a[j]);
+}
+template <int J0>
+inline void rg_axpy2_bcast(double* a, double x1, double y1, double x2, double y2) {
+  rg_axpy_bcast<J0>(a, x1, y1);
+  rg_axpy_bcast<J0>(a, x2, y2);
+}
+template <int J0>
+inline double rg_sum_to8(double x) {
+  const double b[9] = {rg_bcast<0>(x), rg_bcast<1>(x), rg_bcast<2>(x), rg_bcast<3>(x), rg_bcast<4>(x), rg_bcast<5>(x), rg_bcast<6>(x), rg_bcast<7>(x), rg_bcast<8>(x)};
+  if (J0 == 8) return b[8];
+  double acc[2] = {b[J0], b[J0 + 1]};
+  for (int j = J0 + 2; j <= 8; ++j) acc[(j - J0) & 1] += b[j];
+  return acc[0] + acc[1];
 }
 
 template <int STEP>
