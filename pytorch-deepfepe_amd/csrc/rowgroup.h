@@ -174,7 +174,7 @@ __device__ __forceinline__ int rg_sum(int v) {
 // number of lanes of the row for which p holds: one ballot + a popcount of the row's 16 bits (rows of the wavefront that have
 // left a loop are masked off and contribute zeros to their own bits only)
 __device__ __forceinline__ int rg_count(bool p) {
-  const unsigned long long b = __ballot(p);
+  const unsigned long long b = __builtin_amdgcn_ballot_w64(p);  // the lane mask of p itself: no 0/1 value is materialised
   return __popc((unsigned)(b >> (threadIdx.x & 48u)) & 0xffffu);
 }
 __device__ __forceinline__ float rg_max(float v) {

@@ -204,17 +204,21 @@ __device__ __forceinline__ void rg_halve(double* a, bool upper) {
 // [1e-150, 1].  An exact zero counts as positive: its neighbours have opposite signs, so the count is the same.
 // "x lies at or below the smallest eigenvalue" = the count is zero = no term of the sequence is negative: one compare per term
 // and mask arithmetic on the scalar unit instead of counting sign changes (the case of every N >= 9: kth = 0)
+// (the sign bits of the nine terms are OR-ed as integers, two per v_or3_b32, instead of nine compares or a chain of fp64 minima;
+// a term that is exactly -0.0 cannot occur: the recurrence only produces a zero by cancellation, which rounds to +0.0)
 __device__ __forceinline__ bool sturm_none_below(const double* td, const double* te2, double x) {
+  typedef unsigned u32x2 __attribute__((vector_size(8)));
+  auto hi = [](double v) { return __builtin_bit_cast(u32x2, v)[1]; };  // the dword with the sign bit
   double pm2 = 1.0, pm1 = td[0] - x;
-  bool neg = pm1 < 0.0;
+  unsigned sg = hi(pm1);
 #pragma unroll
   for (int k = 1; k < 9; ++k) {
     const double p = fma(td[k] - x, pm1, -(te2[k - 1] * pm2));
-    neg = neg || (p < 0.0);
+    sg |= hi(p);
     pm2 = pm1;
     pm1 = p;
   }
-  return !neg;
+  return (int)sg >= 0;
 }
 __device__ __forceinline__ int sturm_count(const double* td, const double* te2, double x) {
   double pm2 = 1.0, pm1 = td[0] - x;
@@ -300,22 +304,28 @@ __device__ __forceinline__ void eig9_select(double* Ar, const int l, const int k
   const float kLog2_17 = 4.087462841250339f;
   auto pow17 = [&](int e) { return (double)exp2f((float)e * kLog2_17); };  // probe positions need no accuracy
   double lo = -1e-3, hi = 1.0 + 1e-3;
-  // probe still below the wanted eigenvalue?  kth = 0 (uniform over the launch: N >= 9) takes the cheaper test
-  auto below = [&](double x) { return (kth == 0) ? sturm_none_below(td, te2, x) : (sturm_count(td, te2, x) <= kth); };
-  {
-    const int m = rg_count(below(pow17(l - 16)));
-    lo = (m > 0) ? pow17(m - 17) : lo;
-    hi = (m < 16) ? pow17(m - 16) : hi;
-  }
   const double frac = (double)(l + 1) * (1.0 / 17.0);
-  for (int round = 0; round < 14; ++round) {
-    const double wdt = hi - lo;
-    if (!(wdt > 2e-16)) break;  // uniform over the row
-    const int m = rg_count(below(fma(wdt, frac, lo)));  // probes still below the wanted eigenvalue (monotone in l)
-    const double step = wdt * (1.0 / 17.0);
-    lo = fma(step, (double)m, lo);
-    hi = lo + step;
-  }
+  // probe still below the wanted eigenvalue?  kth = 0 (uniform over the launch: N >= 9) takes the cheaper test; the search is
+  // instantiated once per test so that the choice is made once, not in every round
+  auto search = [&](auto below) {
+    {
+      const int m = rg_count(below(pow17(l - 16)));
+      lo = (m > 0) ? pow17(m - 17) : lo;
+      hi = (m < 16) ? pow17(m - 16) : hi;
+    }
+    // the bracket shrinks 17x per round: at most 14 rounds from width 1 to 2e-16, so the width test alone ends the loop (a NaN
+    // leaves through the negated comparison)
+    for (;;) {
+      const double wdt = hi - lo;
+      if (!(wdt > 2e-16)) break;  // uniform over the row
+      const int m = rg_count(below(fma(wdt, frac, lo)));  // probes still below the wanted eigenvalue (monotone in l)
+      const double step = wdt * (1.0 / 17.0);
+      lo = fma(step, (double)m, lo);
+      hi = lo + step;
+    }
+  };
+  if (kth == 0) search([&](double x) { return sturm_none_below(td, te2, x); });
+  else search([&](double x) { return sturm_count(td, te2, x) <= kth; });
   lam = 0.5 * (lo + hi);
 
   DFEPE_MARK("P4c_twisted");
