@@ -226,13 +226,20 @@ __device__ __forceinline__ void smallest_singular_triplet3(const double* F, doub
   const double c1 = (b00 * b11 - b01 * b01) + (b00 * b22 - b02 * b02) + (b11 * b22 - b12 * b12);
   const double c0 = b00 * (b11 * b22 - b12 * b12) - b01 * (b01 * b22 - b12 * b02) + b02 * (b01 * b12 - b11 * b02);
   double x = 0.0;
-  for (int it = 0; it < 12; ++it) {
+  const double tol = 1e-17 * c2;
+  auto newton = [&]() {
     const double p = fma(fma(c2 - x, x, -c1), x, c0);            // -x^3 + c2 x^2 - c1 x + c0
     const double dp = fma(fma(-3.0, x, 2.0 * c2), x, -c1);       // p'(x) < 0 left of the smallest root
     const double dx = (dp < 0.0) ? -p * rcp_nr<2, false>(dp) : 0.0;
-    if (!(dx > 1e-17 * c2)) break;                                // also leaves on NaN; p <= 0: at (or rounded past) the root
-    x += dx;
-  }
+    return (dx > tol) ? dx : 0.0;                                 // 0 also on NaN; p <= 0: at (or rounded past) the root
+  };
+  // Four steps without a branch: the relative error goes (s3/s2)^2 -> its square -> ..., so a generic matrix is converged after
+  // three; the loop behind them (entered only while the fourth step still moved x) covers s3 ~ s2.  A data-dependent exit after
+  // every step costs more in exec-mask bookkeeping than the arithmetic it skips.
+  double dx = 0.0;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) { dx = newton(); x += dx; }
+  for (int it = 4; it < 12 && dx > 0.0; ++it) { dx = newton(); x += dx; }
   sym3_null_vector<ROBUST>(b00 - x, b01, b02, b11 - x, b12, b22 - x, v3);
   // D = F F^T
   const double d00 = F[0] * F[0] + F[1] * F[1] + F[2] * F[2], d01 = F[0] * F[3] + F[1] * F[4] + F[2] * F[5];

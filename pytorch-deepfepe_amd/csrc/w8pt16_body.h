@@ -729,40 +729,34 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   DFEPE_MARK("P5s_save");
   if (A.save != nullptr) {
     float* sv = static_cast<float*>(__builtin_assume_aligned(A.save, 16)) + (size_t)pair * DFEPE_SAVE_FLOATS;
-    // Everything but the reflector components is uniform over the row, so ONE lane per piece stores it with plain
-    // (wide) stores; picking "lane c writes element c" instead costs a select chain per element (~90 v_cndmask).
+    // Everything but the reflector components is uniform over the row.  ONE lane stores all of it in ONE exec region: with a
+    // lane per piece (round 2) the pieces were eight regions, and a lone wavefront pays ~9 cycles for every scalar instruction
+    // and branch around a region (scripts/ubench/lat2.hip) while the stores themselves cost the same whichever lane issues them;
+    // "lane c writes element c" costs a select chain per element (~90 v_cndmask).
     if (l == 0) {
 #pragma unroll
       for (int c = 0; c < 9; ++c) sv[S16_F + c] = (float)f[c];
-    } else if (l == 1) {
 #pragma unroll
       for (int c = 0; c < 9; ++c) sv[S16_Z + c] = (float)(sgn * z[c]);
-    } else if (l == 2) {
 #pragma unroll
       for (int c = 0; c < 9; ++c) reinterpret_cast<double*>(sv + S16_TD)[c] = td[c];
-    } else if (l == 3) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) reinterpret_cast<double*>(sv + S16_TE)[c] = te[c];
-    } else if (l == 4) {
+      reinterpret_cast<double*>(sv + S16_LAM)[0] = lam;
 #pragma unroll
       for (int c = 0; c < 3; ++c) { sv[S16_U3 + c] = (float)u3[c]; sv[S16_V3 + c] = (float)v3[c]; }
+      sv[S16_S3] = (float)s3;
 #pragma unroll
       for (int c = 0; c < 7; ++c) sv[S16_HB + c] = (float)hb[c];
-    }
-#pragma unroll
-    for (int k = 0; k < 7; ++k)  // lanes that hold no component of reflector k write a scratch slot: no branch per reflector
-      sv[(l > k && l < 9) ? S16_HV + s16_hv_off(k) + (l - k - 1) : S16_SCRATCH] = (float)hv[k];
-    if (l == 9) {
       sv[S16_T1 + 0] = (float)s1; sv[S16_T1 + 1] = (float)c1x; sv[S16_T1 + 2] = (float)c1y;
       sv[S16_T2 + 0] = (float)s2; sv[S16_T2 + 1] = (float)c2x; sv[S16_T2 + 2] = (float)c2y;
-    }
-    if (l == 10) {
-      sv[S16_S3] = (float)s3;
       sv[S16_TWIST] = (float)twist;
       sv[S16_INVTR] = (float)inv_tr;
       sv[S16_TAG] = S16_TAG_VALUE;
     }
-    if (l == 11) reinterpret_cast<double*>(sv + S16_LAM)[0] = lam;
+#pragma unroll
+    for (int k = 0; k < 7; ++k)  // lanes that hold no component of reflector k write a scratch slot: no branch per reflector
+      sv[(l > k && l < 9) ? S16_HV + s16_hv_off(k) + (l - k - 1) : S16_SCRATCH] = (float)hv[k];
   }
   if constexpr (ROWS > 1) {
     if (l < 9) { co->f[l] = f[l]; co->of[l] = of[l]; }

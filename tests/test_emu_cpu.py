@@ -76,7 +76,8 @@ def unit_align(a, ref):
 @pytest.mark.parametrize("B,N,outl,noise", [(24, 100, 0.2, 0.5), (8, 100, 0.4, 0.5), (8, 100, 0.0, 0.0), (6, 128, 0.2, 0.5),
                                             (6, 113, 0.2, 0.5), (6, 64, 0.2, 0.5), (6, 17, 0.2, 0.5), (6, 16, 0.2, 0.5),
                                             (6, 12, 0.2, 0.5), (6, 9, 0.2, 0.5), (6, 8, 0.2, 0.5), (4, 5, 0.2, 0.5),
-                                            (4, 129, 0.2, 0.5), (3, 1000, 0.2, 0.5), (3, 257, 0.4, 0.5)])
+                                            (4, 129, 0.2, 0.5), (3, 1000, 0.2, 0.5), (3, 257, 0.4, 0.5),
+                                            (5, 33, 0.2, 0.5), (5, 48, 0.2, 0.5), (5, 80, 0.2, 0.5), (5, 81, 0.2, 0.5), (5, 96, 0.2, 0.5)])
 def test_forward_body_matches_fp64_oracle(emu, dfepe, oracle, B, N, outl, noise):
     sc = dfepe.synth.make_scene(B, N, seed=7 * N + B, outlier_ratio=outl, noise_px=noise)
     m = sc["matches_xy_ori"].contiguous()
@@ -105,7 +106,7 @@ def relerr(a, b):
     return np.abs(a - b).max() / (np.abs(b).max() + 1e-300)
 
 
-@pytest.mark.parametrize("N,outl", [(100, 0.0), (100, 0.4), (128, 0.2), (20, 0.2), (9, 0.0), (300, 0.2), (1000, 0.2)])
+@pytest.mark.parametrize("N,outl", [(100, 0.0), (100, 0.4), (128, 0.2), (20, 0.2), (9, 0.0), (300, 0.2), (1000, 0.2), (40, 0.2), (75, 0.2), (96, 0.2)])
 @pytest.mark.parametrize("use_res,use_epi", [(False, False), (True, False), (True, True)])
 def test_backward_body_vs_oracle_autograd(emu, dfepe, oracle, N, outl, use_res, use_epi):
     """d/d(logits) of <F, GF> + <residual, GR> + <epi, GE> through the emulated w8pt16 forward + backward bodies against

@@ -53,7 +53,7 @@ def test_planar_degenerate_is_finite(dfepe, golden):
     assert res.abs().max().item() < 1e-4  # rank-deficient system: only residual-level parity is meaningful
 
 
-@pytest.mark.parametrize("B,N", [(1, 8), (3, 9), (5, 64), (7, 65), (4, 100), (2, 1000), (3, 1003), (9, 257)])
+@pytest.mark.parametrize("B,N", [(1, 8), (3, 9), (5, 64), (7, 65), (4, 100), (2, 1000), (3, 1003), (9, 257), (6, 33), (6, 48), (5, 80), (5, 96), (5, 112), (5, 113)])
 def test_raw_matches_path_and_shapes(dfepe, oracle, B, N):
     sc = dfepe.synth.make_scene(B, N, seed=100 + N, outlier_ratio=0.25, noise_px=0.5)
     m = sc["matches_xy_ori"]
