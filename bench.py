@@ -215,7 +215,11 @@ def main():
             out = dfepe.pipeline.hot_path_fused(m, logits, scene["Ks"], scene["pts1_virt_ori"], scene["pts2_virt_ori"], scene["qs_cam"],
                                                   scene["ts_cam"], scene["R_gt"], IMAGE_SIZE, clamp_at=0.02, qt=True, hw_T=hw_T,
                                                   balance_F=cfg["balance_F"], grad_pairs=B_total, defer_loss_head=not args.no_defer_head)
-            g, = torch.autograd.grad(out["loss"], logits)
+            # the seed d loss / d loss = 1 is a constant of the loop: allocated once (first eager warm-up step) instead of the
+            # ones_like() fill that autograd would otherwise launch in every step
+            if "seed" not in state:
+                state["seed"] = torch.ones_like(out["loss"])
+            g, = torch.autograd.grad(out["loss"], logits, grad_outputs=state["seed"])
             state["grad_logits"] = g           # d loss / d logits: what the estimator's backward / an optimizer consumes
             state["loss_vec"] = out["packed"]  # dist.pack_loss_sums layout (L+4 doubles): the ONLY data exchanged between ranks
             return out
@@ -569,7 +573,7 @@ def main():
                        "N": N, "depth": L, "outlier_ratio": outl, "parallelism": f"dp{world}", "hipgraph": graph is not None,
                        "launches_per_step": ((2 * L + 2) if args.no_defer_head else (2 * L + 1)) if kind == "train" else 2,
                        "loss_head": ("a launch of its own" if args.no_defer_head else
-                                     "batch sums of the loss finished in spare wavefronts of the first backward launch (defer_loss_head)")},
+                                     "batch sums of the loss finished in a spare wavefront of the first backward launch (defer_loss_head)")},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "accuracy": acc,

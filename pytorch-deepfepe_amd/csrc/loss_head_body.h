@@ -1,12 +1,14 @@
 // loss head of the fused loss tail: the batch sums of the per-workgroup partials that loss_tail_kernel leaves in its
 // workspace -> per-layer means, the clamped qt mix, the packed sums of the data-parallel exchange (same quantities as
 // dfepe_loss_head: train_good_utils.py:340-354 means, Train_model_pipeline.py:580-587 mixing).
-// Run by 256 threads (four wavefronts) of ONE workgroup -- either a launch of its own (loss_tail_head_kernel) or four extra
-// wavefronts in workgroup 0 of the first backward fit of the step (w8pt16_bwd_kernel<..., HEAD>), where it costs nothing: the
-// backward does not need the scalars, and a launch of its own is 7.4 us on the critical path of a 130 us step.
-// The four wavefronts meet through LDS with an arrival counter (workgroup-scope release / acquire: a wait on the memory
-// counters, no cache maintenance), not with a block barrier -- in the backward kernel the other wavefronts of the workgroup
-// never reach one.  Deterministic: fixed order of additions, no floating-point atomics.
+// Run by ONE wavefront -- either a launch of its own (loss_tail_head_kernel) or a spare wavefront in workgroup 0 of the first
+// backward fit of the step (w8pt16_bwd_head_kernel), where it should cost nothing: the backward does not need the scalars, and
+// a launch of its own is 7.4 us on the critical path of a 120 us step.  For that it has to be shorter than the fit beside it
+// (6 us), which the round-2 form (four wavefronts, a row of 48 doubles per thread, 15 wavefront sums through v_readlane, an LDS
+// arrival counter, one lane finishing) was not: 10.8 us.  Now: the partials are element-major ([48][workgroups], so a load
+// instruction of the wavefront touches 4 cache lines instead of 64), every lane adds the workgroups t, t + 64, ..., the 3 L sums
+// are reduced inside the wavefront with DPP only (row steps, then row_bcast:15 / row_bcast:31: the total arrives in lane 63, no
+// trip through the scalar file), and lane 63 finishes.  Deterministic: fixed order of additions, no floating-point atomics.
 #pragma once
 #include "dfepe_common.h"
 #include "loss_tail_body.h"
@@ -20,70 +22,87 @@ struct TailHead {
   double inv_BM, inv_BML, inv_BL;  // 1 / (B M), 1 / (B M L), 1 / (B L)
 };
 
-struct TailHeadLds {
-  double red[4][kTailParts];
-  unsigned arrived;  // zeroed by the caller before any of the four wavefronts can arrive
-};
+// sum over the 64 lanes of the wavefront, valid in lane 63 only
+__device__ __forceinline__ double wave_sum_lane63(double v) {
+  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);  // row_half_mirror
+  v += dpp_f64<0x140>(v);  // row_mirror: every lane holds its row's sum
+  union { double d; int i[2]; } a, r;
+  a.d = v;  // rows 1 and 3 add lane 15 of the row before them (row_bcast:15, row_mask 0xA; the other rows add the `old` zero)
+  r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x142, 0xa, 0xf, false);
+  r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x142, 0xa, 0xf, false);
+  v += r.d;
+  a.d = v;  // rows 2 and 3 add lane 31 (row_bcast:31, row_mask 0xC)
+  r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x143, 0xc, 0xf, false);
+  r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x143, 0xc, 0xf, false);
+  return v + r.d;
+}
 
-// t = 0..255: index of the thread among the four head wavefronts
-__device__ __forceinline__ void loss_head_run(const TailHead& H, const int t, TailHeadLds* lds) {
-  const int lane = t & 63, wave = t >> 6;
-  // every thread adds whole rows of partials (workgroups t, t + 256, ...): 24 independent 16-byte loads in flight per row;
-  // entries of layers >= L are zeros the tail kernel wrote
-  double v[3][kTailMaxLayers];
+// lane = 0..63: the lane of the head's wavefront.  partials: [kTailParts][nblocks], element (kind * kTailMaxLayers + layer).
+__device__ __forceinline__ void loss_head_run(const TailHead& H, const int lane) {
+  const int L = H.L, nb = H.nblocks;
+  // element e' = kind * L + layer of the compact list (3 L <= 48 entries), handled in groups of eight: one uniform branch per
+  // group, clamped (never out-of-range) loads inside
+  constexpr int kGroup = 8, kGroups = kTailParts / kGroup;
+  double acc[kTailParts];
 #pragma unroll
-  for (int kind = 0; kind < 3; ++kind)
+  for (int g = 0; g < kGroups; ++g) {
+    if (g * kGroup < 3 * L) {
+      const double* src[kGroup];
 #pragma unroll
-    for (int l = 0; l < kTailMaxLayers; ++l) v[kind][l] = 0.0;
-  for (int b = t; b < H.nblocks; b += 256) {
-    const double2* row = reinterpret_cast<const double2*>(H.partials + (size_t)b * kTailParts);
-    double2 r[kTailParts / 2];
-#pragma unroll
-    for (int k = 0; k < kTailParts / 2; ++k) r[k] = row[k];
-#pragma unroll
-    for (int k = 0; k < kTailParts / 2; ++k) {
-      v[(2 * k) / kTailMaxLayers][(2 * k) % kTailMaxLayers] += r[k].x;
-      v[(2 * k + 1) / kTailMaxLayers][(2 * k + 1) % kTailMaxLayers] += r[k].y;
-    }
-  }
-#pragma unroll
-  for (int kind = 0; kind < 3; ++kind)
-#pragma unroll
-    for (int l = 0; l < kTailMaxLayers; ++l) {
-      if (l < H.L) {
-        const double s = wave_sum(v[kind][l]);
-        if (lane == 0) lds->red[wave][kind * kTailMaxLayers + l] = s;
+      for (int j = 0; j < kGroup; ++j) {
+        const int e = g * kGroup + j;
+        const int ec = (e < 3 * L) ? e : 0;
+        const int kind = (ec >= L) + (ec >= 2 * L);
+        src[j] = H.partials + (size_t)(kind * kTailMaxLayers + (ec - kind * L)) * nb;
+        acc[e] = 0.0;
       }
+      for (int b = lane; b < nb; b += 256) {  // four workgroups per lane and trip: 32 independent loads in flight
+        const int b1 = b + 64, b2 = b + 128, b3 = b + 192;
+        double x0[kGroup], x1[kGroup], x2[kGroup], x3[kGroup];
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) {
+          x0[j] = src[j][b];
+          x1[j] = src[j][(b1 < nb) ? b1 : b];
+          x2[j] = src[j][(b2 < nb) ? b2 : b];
+          x3[j] = src[j][(b3 < nb) ? b3 : b];
+        }
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) {
+          const int e = g * kGroup + j;
+          acc[e] += (x0[j] + ((b1 < nb) ? x1[j] : 0.0)) + (((b2 < nb) ? x2[j] : 0.0) + ((b3 < nb) ? x3[j] : 0.0));
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kGroup; ++j) acc[g * kGroup + j] = wave_sum_lane63(acc[g * kGroup + j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < kGroup; ++j) acc[g * kGroup + j] = 0.0;
     }
-  // the last of the four wavefronts to arrive finishes (lane 0 of each wavefront counts; the result is broadcast)
-  unsigned prev = 0;
-  if (lane == 0) prev = __hip_atomic_fetch_add(&lds->arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-  prev = (unsigned)__builtin_amdgcn_readfirstlane((int)prev);
-  if (prev != 3u) return;
-  const int L = H.L;
-  auto tot = [&](int k) { return (lds->red[0][k] + lds->red[1][k]) + (lds->red[2][k] + lds->red[3][k]); };
-  // lane l < L finishes layer l, lane 0 the totals (reciprocals come from the host: no chain of fp64 divisions in one lane)
-  if (lane < L) {
-    const double f = tot(lane);
-    H.packed[lane] = f;
-    H.scalars[4 + lane] = (float)(f * H.inv_BM);  // losses.mean() of layer l
   }
-  if (lane == 0) {
-    double totF = 0.0, tq = 0.0, tt = 0.0;
-    for (int l = 0; l < L; ++l) {
-      totF += tot(l);
-      tq += tot(kTailMaxLayers + l);
-      tt += tot(2 * kTailMaxLayers + l);
+  if (lane != 63) return;
+  // lane 63 finishes (reciprocals come from the host: no fp64 division here)
+  double totF = 0.0, tq = 0.0, tt = 0.0;
+#pragma unroll
+  for (int e = 0; e < kTailParts; ++e) {
+    const double v = (e < 3 * L) ? acc[e] : 0.0;
+    totF += (e < L) ? v : 0.0;
+    tq += (e >= L && e < 2 * L) ? v : 0.0;
+    tt += (e >= 2 * L) ? v : 0.0;
+    if (e < kTailMaxLayers && e < L) {
+      H.packed[e] = v;
+      H.scalars[4 + e] = (float)(v * H.inv_BM);  // losses.mean() of layer e
     }
-    H.packed[L] = tq;
-    H.packed[L + 1] = tt;
-    H.packed[L + 2] = (double)H.B;
-    H.packed[L + 3] = (double)H.M;
-    const double loss_F = totF * H.inv_BML;
-    const double loss_qt = H.pose ? (tq * (double)H.balance_q + tt * (double)H.balance_t) * H.inv_BL : 0.0;
-    H.scalars[0] = (float)((double)H.balance_F * loss_F + loss_qt);
-    H.scalars[1] = (float)loss_F;
-    H.scalars[2] = (float)loss_qt;
-    H.scalars[3] = 0.0f;
   }
+  H.packed[L] = tq;
+  H.packed[L + 1] = tt;
+  H.packed[L + 2] = (double)H.B;
+  H.packed[L + 3] = (double)H.M;
+  const double loss_F = totF * H.inv_BML;
+  const double loss_qt = H.pose ? (tq * (double)H.balance_q + tt * (double)H.balance_t) * H.inv_BL : 0.0;
+  H.scalars[0] = (float)((double)H.balance_F * loss_F + loss_qt);
+  H.scalars[1] = (float)loss_F;
+  H.scalars[2] = (float)loss_qt;
+  H.scalars[3] = 0.0f;
 }

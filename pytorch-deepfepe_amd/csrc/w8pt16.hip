@@ -104,7 +104,7 @@ struct W8BwdRest {
   unsigned variant;
 };
 
-template <int IT, bool RAW, bool PGRAD, bool PLAIN>
+template <int IT, bool RAW, bool PGRAD, bool PLAIN, bool UP = true>
 __global__ void __launch_bounds__(256)
 w8pt16_bwd_kernel(const float* pts1, const float* pts2, const float* wts, int B, int Bm, int N, float hw_sx, float hw_sy,
                   float clamp_at, const float* save, const W8BwdRest R) {
@@ -116,7 +116,7 @@ w8pt16_bwd_kernel(const float* pts1, const float* pts2, const float* wts, int B,
   A.clamp_at = clamp_at; A.save = save; A.F_out = R.F_out; A.g_F = R.g_F; A.g_res = R.g_res; A.g_epi = R.g_epi;
   A.g_w_extra = R.g_w_extra; A.g_scale = R.g_scale; A.g_w = R.g_w; A.g_p1 = R.g_p1; A.g_p2 = R.g_p2;
   A.logits_mode = R.logits_mode; A.variant = R.variant; A.pending_head = nullptr; A.row_per_pair = false;
-  w8pt16_bwd_pair_impl<IT, RAW, PGRAD, PLAIN>(A, pair, nullptr);
+  w8pt16_bwd_pair_impl<IT, RAW, PGRAD, PLAIN, 1, UP>(A, pair, nullptr);
 }
 
 template <int IT, bool RAW>
@@ -133,23 +133,18 @@ w8pt16_coop_bwd_kernel(const float* pts1, const float* pts2, const float* wts, i
   w8pt16_bwd_pair_impl<IT, RAW, false, true, 16>(A, pair, nullptr, &co, (int)(threadIdx.x >> 4));
 }
 
-// The same backward fit with four more wavefronts per workgroup; in workgroup 0 they run the loss head that dfepe_loss_tail
-// deferred (loss_head_body.h), elsewhere they leave at once.  The head is off the step's critical path this way: nothing in
-// the backward needs its scalars, and the 512-thread workgroup (two wavefronts per SIMD: <= 256 registers) costs this ONE
+// The same backward fit with one more wavefront per workgroup; in workgroup 0 it runs the loss head that dfepe_loss_tail
+// deferred (loss_head_body.h), elsewhere it leaves at once.  The head is off the step's critical path this way: nothing in
+// the backward needs its scalars, and the 320-thread workgroup (two wavefronts on one SIMD: <= 256 registers) costs this ONE
 // launch of the step a few AGPR moves.
-template <int IT, bool RAW>
-__global__ void __launch_bounds__(512)
+template <int IT, bool RAW, bool UP = true>
+__global__ void __launch_bounds__(320)
 w8pt16_bwd_head_kernel(const float* pts1, const float* pts2, const float* wts, int B, int Bm, int N, float hw_sx, float hw_sy,
                        float clamp_at, const float* save, const W8BwdRest R, const TailHead* __restrict__ head) {
-  __shared__ TailHeadLds lds;
-  if (blockIdx.x == 0) {  // uniform over the workgroup: all eight wavefronts are still alive here
-    if (threadIdx.x == 0) lds.arrived = 0u;
-    __syncthreads();
-  }
   if (threadIdx.x >= 256u) {
     if (blockIdx.x == 0) {
       const TailHead H = *head;
-      loss_head_run(H, (int)threadIdx.x - 256, &lds);
+      loss_head_run(H, (int)threadIdx.x - 256);
     }
     return;
   }
@@ -161,7 +156,7 @@ w8pt16_bwd_head_kernel(const float* pts1, const float* pts2, const float* wts, i
   A.clamp_at = clamp_at; A.save = save; A.F_out = R.F_out; A.g_F = R.g_F; A.g_res = R.g_res; A.g_epi = R.g_epi;
   A.g_w_extra = R.g_w_extra; A.g_scale = R.g_scale; A.g_w = R.g_w; A.g_p1 = R.g_p1; A.g_p2 = R.g_p2;
   A.logits_mode = R.logits_mode; A.variant = 0u; A.pending_head = nullptr; A.row_per_pair = false;
-  w8pt16_bwd_pair_impl<IT, RAW, false>(A, pair, nullptr);
+  w8pt16_bwd_pair_impl<IT, RAW, false, true, 1, UP>(A, pair, nullptr);
 }
 
 template <bool RAW, bool PLAIN>
@@ -214,6 +209,21 @@ void launch_bwd(const W8BwdArgs& A, hipStream_t st) {
       return;
     }
   }
+  if constexpr (!PGRAD && PLAIN) {
+    if (!A.g_res && !A.g_epi && !A.g_w_extra) {  // g_F only: the instantiation without pass A and its loads
+#define DFEPE_BWD0(IT_)                                                                                                    \
+  hipLaunchKernelGGL((w8pt16_bwd_kernel<IT_, RAW, false, true, false>), grid, block, 0, st, A.pts1, A.pts2, A.wts, A.B, A.Bm, A.N, A.hw_sx, \
+                     A.hw_sy, A.clamp_at, A.save, R)
+      if (N > 128) DFEPE_BWD0(0);
+      else if (N <= 16) DFEPE_BWD0(1);
+      else if (N <= 32) DFEPE_BWD0(2);
+      else if (N <= 64) DFEPE_BWD0(4);
+      else if (N <= 112) DFEPE_BWD0(7);
+      else DFEPE_BWD0(8);
+#undef DFEPE_BWD0
+      return;
+    }
+  }
   if (N > 128) DFEPE_BWD(0);
   else if (N <= 16) DFEPE_BWD(1);
   else if (N <= 32) DFEPE_BWD(2);
@@ -226,21 +236,28 @@ void launch_bwd(const W8BwdArgs& A, hipStream_t st) {
 // with the deferred loss head riding along (no point gradients in this variant: the caller falls back to a head launch)
 template <bool RAW>
 void launch_bwd_head(const W8BwdArgs& A, hipStream_t st) {
-  const dim3 grid((A.B + kPairsPerBlock - 1) / kPairsPerBlock), block(512);
+  const dim3 grid((A.B + kPairsPerBlock - 1) / kPairsPerBlock), block(320);
   const int N = A.N;
   W8BwdRest R;
   R.F_out = A.F_out; R.g_F = A.g_F; R.g_res = A.g_res; R.g_epi = A.g_epi; R.g_w_extra = A.g_w_extra; R.g_scale = A.g_scale;
   R.g_w = A.g_w; R.g_p1 = A.g_p1; R.g_p2 = A.g_p2; R.logits_mode = A.logits_mode; R.variant = 0u;
   const TailHead* head = static_cast<const TailHead*>(A.pending_head);
-#define DFEPE_BWDH(IT_)                                                                                                   \
-  hipLaunchKernelGGL((w8pt16_bwd_head_kernel<IT_, RAW>), grid, block, 0, st, A.pts1, A.pts2, A.wts, A.B, A.Bm, A.N, A.hw_sx, \
+#define DFEPE_BWDH(IT_, UP_)                                                                                              \
+  hipLaunchKernelGGL((w8pt16_bwd_head_kernel<IT_, RAW, UP_>), grid, block, 0, st, A.pts1, A.pts2, A.wts, A.B, A.Bm, A.N, A.hw_sx, \
                      A.hw_sy, A.clamp_at, A.save, R, head)
-  if (N > 128) DFEPE_BWDH(0);
-  else if (N <= 16) DFEPE_BWDH(1);
-  else if (N <= 32) DFEPE_BWDH(2);
-  else if (N <= 64) DFEPE_BWDH(4);
-  else if (N <= 112) DFEPE_BWDH(7);
-  else DFEPE_BWDH(8);
+  if (!A.g_res && !A.g_epi && !A.g_w_extra) {  // g_F only (the step of the benchmark): no pass A, fewer registers
+    if (N > 128) DFEPE_BWDH(0, false);
+    else if (N <= 16) DFEPE_BWDH(1, false);
+    else if (N <= 32) DFEPE_BWDH(2, false);
+    else if (N <= 64) DFEPE_BWDH(4, false);
+    else if (N <= 112) DFEPE_BWDH(7, false);
+    else DFEPE_BWDH(8, false);
+  } else if (N > 128) DFEPE_BWDH(0, true);
+  else if (N <= 16) DFEPE_BWDH(1, true);
+  else if (N <= 32) DFEPE_BWDH(2, true);
+  else if (N <= 64) DFEPE_BWDH(4, true);
+  else if (N <= 112) DFEPE_BWDH(7, true);
+  else DFEPE_BWDH(8, true);
 #undef DFEPE_BWDH
 }
 

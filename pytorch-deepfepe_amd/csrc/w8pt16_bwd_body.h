@@ -100,9 +100,14 @@ struct W8BwdCoop {
   double u[9];        // the eigenvector adjoint, published by row 0
 };
 
-template <int IT, bool RAW, bool PGRAD, bool PLAIN = true, int ROWS = 1>
-__device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A, const int pair, double* /*xch*/, W8BwdCoop* co = nullptr,
+// UP = false: the caller has no upstream gradient besides g_F (g_residual, g_epi and g_weights_extra are all absent -- the
+// backward of a step whose weights are inputs, e.g. the benchmark's): pass A, the 3 loads per correspondence that feed it and the
+// registers that hold them are compiled out.
+template <int IT, bool RAW, bool PGRAD, bool PLAIN = true, int ROWS = 1, bool UP = true>
+__device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A0, const int pair, double* /*xch*/, W8BwdCoop* co = nullptr,
                                                      const int rowid = 0) {
+  W8BwdArgs A = A0;
+  if constexpr (!UP) { A.g_res = nullptr; A.g_epi = nullptr; A.g_w_extra = nullptr; }
   static_assert(PLAIN || !PGRAD, "the un-normalised-rows variant has no point gradients");
   static_assert(ROWS == 1 || (ROWS == 16 && IT > 0 && !PGRAD), "cooperative variant: correspondences in registers, weight gradients only");
   constexpr int S = 16 * ROWS;

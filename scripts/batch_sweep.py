@@ -57,10 +57,12 @@ def train_step(B, outl, balance_F):
     hw_T = torch.tensor([[2.0 / W, 0.0, -1.0], [0.0, 2.0 / H, -1.0], [0.0, 0.0, 1.0]], device=DEV)
     logits = sc["logits_layers"][:L].clone().requires_grad_(True)
 
+    seed = torch.ones((), device=DEV)
+
     def body():
         out = d.pipeline.hot_path_fused(sc["matches_xy_ori"], logits, sc["Ks"], sc["pts1_virt_ori"], sc["pts2_virt_ori"], sc["qs_cam"], sc["ts_cam"],
                                         sc["R_gt"], IMG, clamp_at=0.02, qt=True, hw_T=hw_T, balance_F=balance_F, grad_pairs=B, defer_loss_head=True)
-        torch.autograd.grad(out["loss"], logits)
+        torch.autograd.grad(out["loss"], logits, grad_outputs=seed.reshape(out["loss"].shape))
 
     return graph_time_us(body)
 
