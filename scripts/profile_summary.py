@@ -8,8 +8,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O = os.path.join(REPO, "gpurun_out", f"prof_{tag}")
 P = os.path.join(REPO, "profiles")
 B, N, L, M = 4096, 100, 5, 100
-FIT_FWD, FIT_BWD, TAIL, HEAD = "w8pt16_fwd_kernel<7, true, true>", "w8pt16_bwd_kernel<7, true, false, true>", "loss_tail_kernel<7>", "loss_tail_head_kernel"
-BWD_HEAD = "w8pt16_bwd_head_kernel<7, true>"  # the first backward fit of the step, with the deferred loss head in a spare wavefront
+FIT_FWD, FIT_BWD, TAIL, HEAD = "w8pt16_fwd_kernel<7, true, true>", "w8pt16_bwd_kernel<7, true, false, true, false>", "loss_tail_kernel<7>", "loss_tail_head_kernel"
+BWD_HEAD = "w8pt16_bwd_head_kernel<7, true, false>"  # the first backward fit of the step, with the deferred loss head in a spare wavefront
 HOT = (FIT_FWD, FIT_BWD, BWD_HEAD, TAIL, HEAD)
 
 
@@ -147,8 +147,10 @@ if valu and fwd_avg_us:
     floor_us = valu * 4 / 2.4e3  # ONE wavefront (four pairs) per SIMD, 4 issue cycles per wave64 VALU instruction, 2.4 GHz
     md += ["", f"VALU-issue floor of the forward fit at this occupancy: 4096 pairs = 1024 wavefronts = ONE per SIMD x {valu:.0f} VALU instructions x "
            f"4 cycles = {valu*4:.0f} cycles = {floor_us:.1f} us at 2.4 GHz, against {fwd_avg_us:.1f} us measured ({100*floor_us/fwd_avg_us:.0f} %): with a single "
-           "wavefront per SIMD every dependent-issue bubble, DPP wait state and memory wait is exposed (scripts/ubench/lat.hip: a lone wavefront "
-           "issues a dependent fp64 FMA every 5.2 cycles, an independent one every 4.1), so the lever is fewer instructions per pair.  "
+           "wavefront per SIMD every dependent-issue bubble, DPP wait state, scalar instruction, branch and memory wait is exposed "
+           "(scripts/ubench/lat.hip, lat2.hip: a lone wavefront issues a dependent fp64 FMA every 5.2 cycles, an independent one every 4.1; a scalar "
+           "instruction or a branch costs it ~9).  Round 3 showed which of these matter: removing 14 % of the vector instructions moved the "
+           "kernel by 3 %, removing 13 scalar instructions and 3 branches from each of the ~10 rounds of the one loop moved it by 8 %.  "
            "This is a fraction of the kernel's own instruction stream, not a roofline."]
     traffic[f"fit_fwd_valu_insts_per_wave_B{B}_N{N}"] = round(valu, 1)
 if clk_ghz:
