@@ -345,7 +345,10 @@ def main():
                              "frac_of_kernel_time_at_measured_rate": round(real_us / kdur_us, 3),
                              "source": "profiles/traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, SQ_BUSY_CU_CYCLES); 5.1 cycles per instruction "
                                        "from scripts/ubench/lat.hip",
-                             "note": "fraction of this kernel's own instruction stream, NOT a roofline"}
+                             "note": "fraction of this kernel's own instruction stream, NOT a roofline; a lone wavefront per SIMD also pays for "
+                                     "every scalar instruction and branch (~9 cycles each, scripts/ubench/lat2.hip): in round 3 a 14 % cut of "
+                                     "the vector instructions moved the kernel by 3 %, 13 scalar instructions and 3 branches out of each "
+                                     "multisection round by 8 %"}
             except Exception:
                 traffic = None
         # the same launch against the ALU peaks ("report both"): arithmetic this algorithm performs per pair, counted from
@@ -356,8 +359,9 @@ def main():
         alu_tf = B * flops_pair / (kdur_us * 1e-6) / 1e12
         alu = {"flops_per_pair": flops_pair, "achieved_TFLOPs": round(alu_tf, 2), "peak_fp64_vector_TFLOPs": 78.6, "frac_of_fp64_peak": round(alu_tf / 78.6, 4),
                "peak_fp32_vector_TFLOPs": 157.3, "frac_of_fp32_peak": round(alu_tf / 157.3, 4),
-               "note": "useful arithmetic of the tridiagonal eigen route, not issued instructions: the kernel is bound by vector ISSUE (see vector_issue), "
-                       "of which data movement inside the row (DPP), selects and conversions are about half"}
+               "note": "useful arithmetic of the tridiagonal eigen route, not issued instructions: the kernel is bound by the in-order issue of ONE "
+                       "wavefront per SIMD (see vector_issue) -- vector instructions, of which data movement inside the row (DPP), selects and "
+                       "conversions are about half, plus the dependency, scalar and branch bubbles nothing else on the SIMD can fill"}
         roofline = {"bound": "hbm", "kernel": kname, "alu": alu, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                     "avg_kernel_us": round(kdur_us, 2), "algorithmic_bytes_per_launch": alg_bytes,
