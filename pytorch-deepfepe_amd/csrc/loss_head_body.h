@@ -40,61 +40,67 @@ __device__ __forceinline__ double wave_sum_lane63(double v) {
 }
 
 // lane = 0..63: the lane of the head's wavefront.  partials: [kTailParts][nblocks], element (kind * kTailMaxLayers + layer).
+// The wavefront rides beside a fit wavefront on one SIMD of the first backward launch (w8pt16_bwd_head_kernel), so every instruction
+// here delays that fit: the 3 L <= 48 wanted elements are walked as a compact list in groups of eight (one uniform branch per group,
+// none per element), a workgroup count that is a multiple of 256 (every B that is a multiple of 4096) takes immediate load offsets
+// and no clamps, and lane 63 folds each group into the totals as soon as it is reduced.
 __device__ __forceinline__ void loss_head_run(const TailHead& H, const int lane) {
   const int L = H.L, nb = H.nblocks;
-  // element e' = kind * L + layer of the compact list (3 L <= 48 entries), handled in groups of eight: one uniform branch per
-  // group, clamped (never out-of-range) loads inside
   constexpr int kGroup = 8, kGroups = kTailParts / kGroup;
-  double acc[kTailParts];
+  const bool full = (nb & 255) == 0;  // uniform
+  double totF = 0.0, tq = 0.0, tt = 0.0;
 #pragma unroll
   for (int g = 0; g < kGroups; ++g) {
     if (g * kGroup < 3 * L) {
       const double* src[kGroup];
+      double acc[kGroup];
 #pragma unroll
       for (int j = 0; j < kGroup; ++j) {
         const int e = g * kGroup + j;
-        const int ec = (e < 3 * L) ? e : 0;
+        const int ec = (e < 3 * L) ? e : 0;                // uniform (scalar) arithmetic
         const int kind = (ec >= L) + (ec >= 2 * L);
-        src[j] = H.partials + (size_t)(kind * kTailMaxLayers + (ec - kind * L)) * nb;
-        acc[e] = 0.0;
+        src[j] = H.partials + (size_t)(kind * kTailMaxLayers + (ec - kind * L)) * nb + lane;
+        acc[j] = 0.0;
       }
-      for (int b = lane; b < nb; b += 256) {  // four workgroups per lane and trip: 32 independent loads in flight
-        const int b1 = b + 64, b2 = b + 128, b3 = b + 192;
-        double x0[kGroup], x1[kGroup], x2[kGroup], x3[kGroup];
+      if (full) {
+        for (int b = 0; b < nb; b += 256) {  // four workgroups per lane and trip: 32 independent loads in flight
+          double x0[kGroup], x1[kGroup], x2[kGroup], x3[kGroup];
 #pragma unroll
-        for (int j = 0; j < kGroup; ++j) {
-          x0[j] = src[j][b];
-          x1[j] = src[j][(b1 < nb) ? b1 : b];
-          x2[j] = src[j][(b2 < nb) ? b2 : b];
-          x3[j] = src[j][(b3 < nb) ? b3 : b];
+          for (int j = 0; j < kGroup; ++j) { x0[j] = src[j][b]; x1[j] = src[j][b + 64]; x2[j] = src[j][b + 128]; x3[j] = src[j][b + 192]; }
+#pragma unroll
+          for (int j = 0; j < kGroup; ++j) acc[j] += (x0[j] + x1[j]) + (x2[j] + x3[j]);
         }
+      } else {
+        for (int b = lane; b < nb; b += 64) {
+#pragma unroll
+          for (int j = 0; j < kGroup; ++j) acc[j] += src[j][b - lane];
+        }
+      }
+      // fold the group into the totals with arithmetic masks (uniform selects, no branch per element); lane 63 stores the per-layer
+      // sums in one exec region, strays (e >= L) aimed at a slot that is rewritten below
+      double v[kGroup];
+#pragma unroll
+      for (int j = 0; j < kGroup; ++j) {
+        const int e = g * kGroup + j;
+        v[j] = wave_sum_lane63(acc[j]);
+        totF = fma((e < L) ? 1.0 : 0.0, v[j], totF);
+        tq = fma((e >= L && e < 2 * L) ? 1.0 : 0.0, v[j], tq);
+        tt = fma((e >= 2 * L && e < 3 * L) ? 1.0 : 0.0, v[j], tt);
+      }
+      if (lane == 63) {
 #pragma unroll
         for (int j = 0; j < kGroup; ++j) {
           const int e = g * kGroup + j;
-          acc[e] += (x0[j] + ((b1 < nb) ? x1[j] : 0.0)) + (((b2 < nb) ? x2[j] : 0.0) + ((b3 < nb) ? x3[j] : 0.0));
+          if (e < kTailMaxLayers) {  // compile time: later groups hold no layer sums
+            H.packed[(e < L) ? e : L + 2] = v[j];
+            H.scalars[(e < L) ? 4 + e : 3] = (float)(v[j] * H.inv_BM);  // losses.mean() of layer e
+          }
         }
       }
-#pragma unroll
-      for (int j = 0; j < kGroup; ++j) acc[g * kGroup + j] = wave_sum_lane63(acc[g * kGroup + j]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < kGroup; ++j) acc[g * kGroup + j] = 0.0;
     }
   }
   if (lane != 63) return;
   // lane 63 finishes (reciprocals come from the host: no fp64 division here)
-  double totF = 0.0, tq = 0.0, tt = 0.0;
-#pragma unroll
-  for (int e = 0; e < kTailParts; ++e) {
-    const double v = (e < 3 * L) ? acc[e] : 0.0;
-    totF += (e < L) ? v : 0.0;
-    tq += (e >= L && e < 2 * L) ? v : 0.0;
-    tt += (e >= 2 * L) ? v : 0.0;
-    if (e < kTailMaxLayers && e < L) {
-      H.packed[e] = v;
-      H.scalars[4 + e] = (float)(v * H.inv_BM);  // losses.mean() of layer e
-    }
-  }
   H.packed[L] = tq;
   H.packed[L + 1] = tt;
   H.packed[L + 2] = (double)H.B;

@@ -11,6 +11,8 @@
 // registers for all layers) and the 3x3 work of each (pair, layer) in one lane (E, pose forward + adjoint).  Written against
 // rowgroup.h only (tests/emu/).
 #pragma once
+#include <type_traits>
+
 #include <rowgroup.h>  // angle brackets on purpose: tests/emu/ substitutes its host emulation through the include path
 
 #include "dfepe.h"
@@ -189,53 +191,67 @@ __device__ __forceinline__ void tail_floss_row(const TailArgs& A, const int pair
   // with balance_F = 0 (the reference's objective when if_qt_loss, Train_model_pipeline.py:580-587) the F-loss is evaluated but
   // carries no gradient: its adjoint (more than half of this function) is skipped
   const bool grad = A.g_F != nullptr && A.coef_F != 0.0f;
-  for (int ly = 0; ly < L; ++ly) {
-    float o[9];
+  // K layers at a time: the layers are independent of each other, and a lone wavefront on its SIMD (the F-loss wavefronts are the
+  // critical path of this kernel, scripts/tail_time.py) needs the second instruction stream to fill the dependent-issue bubbles of
+  // the first; it also halves the trips through the loop's scalar bookkeeping.
+  auto layers = [&](auto kc, const int ly0) {
+    constexpr int K = decltype(kc)::value;
+    float o[K][9], accf[K], gof[K][9];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) o[c] = ldsF[ly * 9 + c];
-    float accf = 0.0f;
-    float gof[9];
+    for (int k = 0; k < K; ++k) {
 #pragma unroll
-    for (int c = 0; c < 9; ++c) gof[c] = 0.0f;
+      for (int c = 0; c < 9; ++c) { o[k][c] = ldsF[(ly0 + k) * 9 + c]; gof[k][c] = 0.0f; }
+      accf[k] = 0.0f;
+    }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-      const TailEpi e = tail_epi_terms(x1[it], x2[it], o);
-      accf = fmaf(vm[it], fminf(e.d, A.clamp_at), accf);
-      if (grad) {
-        // d d / d F[r][c] = sg S x2[r] x1[c] - k1 l1[c] x2[r] [c<2] - k2 l2[r] x1[c] [r<2]
-        //                 = x2[r] a[c] - b[r] x1[c],  a[c] = sg S x1[c] - k1 l1[c] [c<2],  b[r] = k2 l2[r] [r<2]
-        const float mk = (e.d <= A.clamp_at) ? vm[it] : 0.0f;  // clamp(max=) passes the gradient up to and including the bound
-        const float S = e.i1 + e.i2, ad = fabsf(e.dd);
-        const float sg = (e.dd > 0.0f) ? mk : ((e.dd < 0.0f) ? -mk : 0.0f);
-        const float k1 = (e.n1 > 0.0f) ? mk * ad * e.i1 * e.i1 * hw_rcp(e.n1) : 0.0f;
-        const float k2 = (e.n2 > 0.0f) ? mk * ad * e.i2 * e.i2 * hw_rcp(e.n2) : 0.0f;
-        const float sS = sg * S;
-        const float a0 = fmaf(sS, x1[it][0], -k1 * e.l1[0]), a1 = fmaf(sS, x1[it][1], -k1 * e.l1[1]), a2 = sS * x1[it][2];
-        const float b0 = k2 * e.l2[0], b1 = k2 * e.l2[1];
-        const float av[3] = {a0, a1, a2};
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          gof[c] += fmaf(x2[it][0], av[c], -b0 * x1[it][c]);
-          gof[3 + c] += fmaf(x2[it][1], av[c], -b1 * x1[it][c]);
-          gof[6 + c] = fmaf(x2[it][2], av[c], gof[6 + c]);
+      for (int k = 0; k < K; ++k) {
+        const TailEpi e = tail_epi_terms(x1[it], x2[it], o[k]);
+        accf[k] = fmaf(vm[it], fminf(e.d, A.clamp_at), accf[k]);
+        if (grad) {
+          // d d / d F[r][c] = sg S x2[r] x1[c] - k1 l1[c] x2[r] [c<2] - k2 l2[r] x1[c] [r<2]
+          //                 = x2[r] a[c] - b[r] x1[c],  a[c] = sg S x1[c] - k1 l1[c] [c<2],  b[r] = k2 l2[r] [r<2]
+          const float mk = (e.d <= A.clamp_at) ? vm[it] : 0.0f;  // clamp(max=) passes the gradient up to and including the bound
+          const float S = e.i1 + e.i2, ad = fabsf(e.dd);
+          const float sg = (e.dd > 0.0f) ? mk : ((e.dd < 0.0f) ? -mk : 0.0f);
+          const float k1 = (e.n1 > 0.0f) ? mk * ad * e.i1 * e.i1 * hw_rcp(e.n1) : 0.0f;
+          const float k2 = (e.n2 > 0.0f) ? mk * ad * e.i2 * e.i2 * hw_rcp(e.n2) : 0.0f;
+          const float sS = sg * S;
+          const float a0 = fmaf(sS, x1[it][0], -k1 * e.l1[0]), a1 = fmaf(sS, x1[it][1], -k1 * e.l1[1]), a2 = sS * x1[it][2];
+          const float b0 = k2 * e.l2[0], b1 = k2 * e.l2[1];
+          const float av[3] = {a0, a1, a2};
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            gof[k][c] += fmaf(x2[it][0], av[c], -b0 * x1[it][c]);
+            gof[k][3 + c] += fmaf(x2[it][1], av[c], -b1 * x1[it][c]);
+            gof[k][6 + c] = fmaf(x2[it][2], av[c], gof[k][6 + c]);
+          }
         }
       }
     }
-    const float acc = rg_sum(accf);  // <= 128 terms of at most clamp_at each: fp32 like the reference's own sum
-    if (l == 0) {
-      A.loss_sum[(size_t)ly * B + pair] = acc;
-      part[ly] = (double)acc;
-    }
-    if (grad) {
-      float mine = 0.0f;
 #pragma unroll
-      for (int c = 0; c < 9; ++c) {
-        const float tot = rg_sum(gof[c]);
-        mine = (l == c) ? tot : mine;
+    for (int k = 0; k < K; ++k) {
+      const int ly = ly0 + k;
+      const float acc = rg_sum(accf[k]);  // <= 128 terms of at most clamp_at each: fp32 like the reference's own sum
+      if (l == 0) {
+        A.loss_sum[(size_t)ly * B + pair] = acc;
+        part[ly] = (double)acc;
       }
-      if (l < 9) gsum[ly * 9 + l] = mine;
+      if (grad) {
+        float mine = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+          const float tot = rg_sum(gof[k][c]);
+          mine = (l == c) ? tot : mine;
+        }
+        if (l < 9) gsum[ly * 9 + l] = mine;
+      }
     }
-  }
+  };
+  int ly = 0;
+  for (; ly + 1 < L; ly += 2) layers(std::integral_constant<int, 2>{}, ly);
+  if (ly < L) layers(std::integral_constant<int, 1>{}, ly);
 }
 __device__ __forceinline__ void tail_floss_finish(const TailArgs& A, const int pair, const float* gsum, const float* gpose /*[L][9]*/) {
   const int l = rg_lane();
