@@ -577,7 +577,7 @@ def main():
                        "N": N, "depth": L, "outlier_ratio": outl, "parallelism": f"dp{world}", "hipgraph": graph is not None,
                        "launches_per_step": ((2 * L + 2) if args.no_defer_head else (2 * L + 1)) if kind == "train" else 2,
                        "loss_head": ("a launch of its own" if args.no_defer_head else
-                                     "batch sums of the loss finished in a spare wavefront of the first backward launch (defer_loss_head)")},
+                                     "batch sums of the loss finished in spare wavefronts of the first backward launch (defer_loss_head)")},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "accuracy": acc,

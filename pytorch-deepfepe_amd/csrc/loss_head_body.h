@@ -1,14 +1,14 @@
 // loss head of the fused loss tail: the batch sums of the per-workgroup partials that loss_tail_kernel leaves in its
 // workspace -> per-layer means, the clamped qt mix, the packed sums of the data-parallel exchange (same quantities as
 // dfepe_loss_head: train_good_utils.py:340-354 means, Train_model_pipeline.py:580-587 mixing).
-// Run by ONE wavefront -- either a launch of its own (loss_tail_head_kernel) or a spare wavefront in workgroup 0 of the first
-// backward fit of the step (w8pt16_bwd_head_kernel), where it should cost nothing: the backward does not need the scalars, and
-// a launch of its own is 7.4 us on the critical path of a 120 us step.  For that it has to be shorter than the fit beside it
-// (6 us), which the round-2 form (four wavefronts, a row of 48 doubles per thread, 15 wavefront sums through v_readlane, an LDS
-// arrival counter, one lane finishing) was not: 10.8 us.  Now: the partials are element-major ([48][workgroups], so a load
-// instruction of the wavefront touches 4 cache lines instead of 64), every lane adds the workgroups t, t + 64, ..., the 3 L sums
-// are reduced inside the wavefront with DPP only (row steps, then row_bcast:15 / row_bcast:31: the total arrives in lane 63, no
-// trip through the scalar file), and lane 63 finishes.  Deterministic: fixed order of additions, no floating-point atomics.
+// Run by THREE wavefronts (one per kind of partial) -- either a launch of its own (loss_tail_head_kernel) or three spare wavefronts
+// in workgroup 0 of the first backward fit of the step (w8pt16_bwd_head_kernel), where it should cost nothing: the backward does
+// not need the scalars, and a launch of its own is 7 us on the critical path of a 115 us step.  For that each head wavefront has to
+// be much shorter than the fit wavefront it shares a SIMD with.  History: four wavefronts reading a row of 48 doubles per thread,
+// 15 wavefront sums through v_readlane and one lane finishing (round 2) made that launch 11.2 us against 6.1 for a plain backward
+// fit; one wavefront over element-major partials ([48][workgroups]: a load instruction touches 4 cache lines instead of 64) with
+// DPP-only reductions into lane 63 made it 8.45; a third of that work on each of three SIMDs is the present form.
+// Deterministic: fixed order of additions, no floating-point atomics.
 #pragma once
 #include "dfepe_common.h"
 #include "loss_tail_body.h"
@@ -39,27 +39,35 @@ __device__ __forceinline__ double wave_sum_lane63(double v) {
   return v + r.d;
 }
 
-// lane = 0..63: the lane of the head's wavefront.  partials: [kTailParts][nblocks], element (kind * kTailMaxLayers + layer).
-// The wavefront rides beside a fit wavefront on one SIMD of the first backward launch (w8pt16_bwd_head_kernel), so every instruction
-// here delays that fit: the 3 L <= 48 wanted elements are walked as a compact list in groups of eight (one uniform branch per group,
-// none per element), a workgroup count that is a multiple of 256 (every B that is a multiple of 4096) takes immediate load offsets
-// and no clamps, and lane 63 folds each group into the totals as soon as it is reduced.
-__device__ __forceinline__ void loss_head_run(const TailHead& H, const int lane) {
+struct TailHeadLds {
+  double tot[3];     // batch totals of the three kinds: F-loss sums, clamped q_l2, clamped t_l2
+  unsigned arrived;  // zeroed by the caller before any of the three wavefronts can arrive
+};
+
+// THREE wavefronts, one per kind of partial (wave = 0: per-layer F-loss sums, 1: clamp(q_l2), 2: clamp(t_l2)); lane = 0..63.
+// partials: [kTailParts][nblocks], element (kind * kTailMaxLayers + layer).  The wavefronts ride beside fit wavefronts on three
+// SIMDs of the first backward launch (w8pt16_bwd_head_kernel), so every instruction here delays a fit: one wavefront for all 3 L
+// elements cost the fit beside it 2.4 us, a third of the work on each of three SIMDs costs ~1.  The L <= 16 layers of a kind are
+// walked in groups of eight (one uniform branch per group, none per element; clamped loads, masked sums), a workgroup count that
+// is a multiple of 256 (every B that is a multiple of 4096) takes immediate load offsets and no clamps, the sums are reduced with
+// DPP only, and the three lanes 63 meet through LDS with an arrival counter (workgroup-scope release / acquire: no cache
+// maintenance, no block barrier -- in the backward kernel the other wavefronts of the workgroup never reach one); the last one
+// to arrive writes the scalars.
+__device__ __forceinline__ void loss_head_run(const TailHead& H, const int lane, const int kind, TailHeadLds* lds) {
   const int L = H.L, nb = H.nblocks;
-  constexpr int kGroup = 8, kGroups = kTailParts / kGroup;
+  constexpr int kGroup = 8, kGroups = kTailMaxLayers / kGroup;
   const bool full = (nb & 255) == 0;  // uniform
-  double totF = 0.0, tq = 0.0, tt = 0.0;
+  const double* base = H.partials + (size_t)kind * kTailMaxLayers * nb + lane;
+  double tot = 0.0;
 #pragma unroll
   for (int g = 0; g < kGroups; ++g) {
-    if (g * kGroup < 3 * L) {
+    if (g * kGroup < L) {
       const double* src[kGroup];
       double acc[kGroup];
 #pragma unroll
       for (int j = 0; j < kGroup; ++j) {
-        const int e = g * kGroup + j;
-        const int ec = (e < 3 * L) ? e : 0;                // uniform (scalar) arithmetic
-        const int kind = (ec >= L) + (ec >= 2 * L);
-        src[j] = H.partials + (size_t)(kind * kTailMaxLayers + (ec - kind * L)) * nb + lane;
+        const int l = g * kGroup + j;
+        src[j] = base + (size_t)((l < L) ? l : 0) * nb;  // uniform (scalar) arithmetic
         acc[j] = 0.0;
       }
       if (full) {
@@ -76,31 +84,30 @@ __device__ __forceinline__ void loss_head_run(const TailHead& H, const int lane)
           for (int j = 0; j < kGroup; ++j) acc[j] += src[j][b - lane];
         }
       }
-      // fold the group into the totals with arithmetic masks (uniform selects, no branch per element); lane 63 stores the per-layer
-      // sums in one exec region, strays (e >= L) aimed at a slot that is rewritten below
+      // fold the group into the kind's total with arithmetic masks (uniform selects, no branch per element); lane 63 of the F-loss
+      // wavefront stores the per-layer sums in one exec region, strays (l >= L) aimed at slots that are rewritten by the finisher
       double v[kGroup];
 #pragma unroll
       for (int j = 0; j < kGroup; ++j) {
-        const int e = g * kGroup + j;
         v[j] = wave_sum_lane63(acc[j]);
-        totF = fma((e < L) ? 1.0 : 0.0, v[j], totF);
-        tq = fma((e >= L && e < 2 * L) ? 1.0 : 0.0, v[j], tq);
-        tt = fma((e >= 2 * L && e < 3 * L) ? 1.0 : 0.0, v[j], tt);
+        tot = fma((g * kGroup + j < L) ? 1.0 : 0.0, v[j], tot);
       }
-      if (lane == 63) {
+      if (kind == 0 && lane == 63) {
 #pragma unroll
         for (int j = 0; j < kGroup; ++j) {
-          const int e = g * kGroup + j;
-          if (e < kTailMaxLayers) {  // compile time: later groups hold no layer sums
-            H.packed[(e < L) ? e : L + 2] = v[j];
-            H.scalars[(e < L) ? 4 + e : 3] = (float)(v[j] * H.inv_BM);  // losses.mean() of layer e
-          }
+          const int l = g * kGroup + j;
+          H.packed[(l < L) ? l : L + 2] = v[j];
+          H.scalars[(l < L) ? 4 + l : 3] = (float)(v[j] * H.inv_BM);  // losses.mean() of layer l
         }
       }
     }
   }
   if (lane != 63) return;
-  // lane 63 finishes (reciprocals come from the host: no fp64 division here)
+  lds->tot[kind] = tot;
+  const unsigned prev = __hip_atomic_fetch_add(&lds->arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (prev != 2u) return;
+  // the last lane 63 to arrive finishes (reciprocals come from the host: no fp64 division here)
+  const double totF = lds->tot[0], tq = lds->tot[1], tt = lds->tot[2];
   H.packed[L] = tq;
   H.packed[L + 1] = tt;
   H.packed[L + 2] = (double)H.B;

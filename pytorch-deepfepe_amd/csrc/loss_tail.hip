@@ -62,13 +62,21 @@ loss_tail_kernel(const float* F_layers, int L, int B, int M, int t_stride, const
 // The batch sums (loss_head_body.h).  A launch of its own: the kernel boundary is what makes the partials of all XCDs visible,
 // for less than an in-kernel "last workgroup" protocol costs in agent-scope fences on a multi-XCD part (measured: 24 us against
 // 5 us; a one-wavefront version: 14.7 us).  With defer_head the launch is left to the first backward fit of the step, which
-// runs the same code in a spare wavefront of its workgroup 0 (dfepe_w8pt_bwd, pending_loss_head).
-__global__ void __launch_bounds__(64) loss_tail_head_kernel(const TailHead H) { loss_head_run(H, (int)threadIdx.x); }
+// runs the same code in three spare wavefronts of its workgroup 0 (dfepe_w8pt_bwd, pending_loss_head).
+__global__ void __launch_bounds__(192) loss_tail_head_kernel(const TailHead H) {
+  __shared__ TailHeadLds lds;
+  if (threadIdx.x == 0) lds.arrived = 0u;
+  __syncthreads();
+  loss_head_run(H, (int)(threadIdx.x & 63u), (int)(threadIdx.x >> 6), &lds);
+}
 // the same from a descriptor in device memory (the fallback of a deferred head when the backward fit is served by the
 // wavefront-per-pair kernels)
-__global__ void __launch_bounds__(64) loss_tail_head_desc_kernel(const TailHead* Hp) {
+__global__ void __launch_bounds__(192) loss_tail_head_desc_kernel(const TailHead* Hp) {
+  __shared__ TailHeadLds lds;
+  if (threadIdx.x == 0) lds.arrived = 0u;
+  __syncthreads();
   const TailHead H = *Hp;
-  loss_head_run(H, (int)threadIdx.x);
+  loss_head_run(H, (int)(threadIdx.x & 63u), (int)(threadIdx.x >> 6), &lds);
 }
 
 }  // namespace
@@ -80,7 +88,7 @@ extern "C" size_t dfepe_loss_tail_workspace_bytes(int B) {
 
 // launches the pending loss head described in `workspace` (dfepe_loss_tail with defer_head) as a kernel of its own
 int dfepe_loss_head_from_workspace(const void* workspace_desc, hipStream_t st) {
-  hipLaunchKernelGGL(loss_tail_head_desc_kernel, dim3(1), dim3(64), 0, st, static_cast<const TailHead*>(workspace_desc));
+  hipLaunchKernelGGL(loss_tail_head_desc_kernel, dim3(1), dim3(192), 0, st, static_cast<const TailHead*>(workspace_desc));
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
@@ -123,6 +131,6 @@ extern "C" int dfepe_loss_tail(const float* F_layers, int L, int B, const float*
   else if (M <= 112) hipLaunchKernelGGL((loss_tail_kernel<7>), grid, block, 0, st, A.F_layers, A.L, A.B, A.M, A.t_stride, A.T1, A.T2, A.K, A.virt1, A, partials, H, wd);
   else hipLaunchKernelGGL((loss_tail_kernel<8>), grid, block, 0, st, A.F_layers, A.L, A.B, A.M, A.t_stride, A.T1, A.T2, A.K, A.virt1, A, partials, H, wd);
   if (defer_head) return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;  // the first backward fit runs the head
-  hipLaunchKernelGGL(loss_tail_head_kernel, dim3(1), dim3(64), 0, st, H);
+  hipLaunchKernelGGL(loss_tail_head_kernel, dim3(1), dim3(192), 0, st, H);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }

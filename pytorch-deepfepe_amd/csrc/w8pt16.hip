@@ -133,18 +133,23 @@ w8pt16_coop_bwd_kernel(const float* pts1, const float* pts2, const float* wts, i
   w8pt16_bwd_pair_impl<IT, RAW, false, true, 16>(A, pair, nullptr, &co, (int)(threadIdx.x >> 4));
 }
 
-// The same backward fit with one more wavefront per workgroup; in workgroup 0 it runs the loss head that dfepe_loss_tail
-// deferred (loss_head_body.h), elsewhere it leaves at once.  The head is off the step's critical path this way: nothing in
-// the backward needs its scalars, and the 320-thread workgroup (two wavefronts on one SIMD: <= 256 registers) costs this ONE
-// launch of the step a few AGPR moves.
+// The same backward fit with three more wavefronts per workgroup; in workgroup 0 they run the loss head that dfepe_loss_tail
+// deferred (loss_head_body.h: one wavefront per kind of partial), elsewhere they leave at once.  The head is off the step's
+// critical path this way: nothing in the backward needs its scalars; the 448-thread workgroup (two wavefronts on three of the
+// SIMDs) limits this ONE launch of the step to 256 registers.
 template <int IT, bool RAW, bool UP = true>
-__global__ void __launch_bounds__(320)
+__global__ void __launch_bounds__(448)
 w8pt16_bwd_head_kernel(const float* pts1, const float* pts2, const float* wts, int B, int Bm, int N, float hw_sx, float hw_sy,
                        float clamp_at, const float* save, const W8BwdRest R, const TailHead* __restrict__ head) {
+  __shared__ TailHeadLds lds;
+  if (blockIdx.x == 0) {  // uniform over the workgroup: all seven wavefronts are still alive here
+    if (threadIdx.x == 0) lds.arrived = 0u;
+    __syncthreads();
+  }
   if (threadIdx.x >= 256u) {
     if (blockIdx.x == 0) {
       const TailHead H = *head;
-      loss_head_run(H, (int)threadIdx.x - 256);
+      loss_head_run(H, (int)(threadIdx.x & 63u), (int)(threadIdx.x >> 6) - 4, &lds);
     }
     return;
   }
@@ -236,7 +241,7 @@ void launch_bwd(const W8BwdArgs& A, hipStream_t st) {
 // with the deferred loss head riding along (no point gradients in this variant: the caller falls back to a head launch)
 template <bool RAW>
 void launch_bwd_head(const W8BwdArgs& A, hipStream_t st) {
-  const dim3 grid((A.B + kPairsPerBlock - 1) / kPairsPerBlock), block(320);
+  const dim3 grid((A.B + kPairsPerBlock - 1) / kPairsPerBlock), block(448);
   const int N = A.N;
   W8BwdRest R;
   R.F_out = A.F_out; R.g_F = A.g_F; R.g_res = A.g_res; R.g_epi = A.g_epi; R.g_w_extra = A.g_w_extra; R.g_scale = A.g_scale;

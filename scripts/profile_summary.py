@@ -9,7 +9,7 @@ O = os.path.join(REPO, "gpurun_out", f"prof_{tag}")
 P = os.path.join(REPO, "profiles")
 B, N, L, M = 4096, 100, 5, 100
 FIT_FWD, FIT_BWD, TAIL, HEAD = "w8pt16_fwd_kernel<7, true, true>", "w8pt16_bwd_kernel<7, true, false, true, false>", "loss_tail_kernel<7>", "loss_tail_head_kernel"
-BWD_HEAD = "w8pt16_bwd_head_kernel<7, true, false>"  # the first backward fit of the step, with the deferred loss head in a spare wavefront
+BWD_HEAD = "w8pt16_bwd_head_kernel<7, true, false>"  # the first backward fit of the step, with the deferred loss head in spare wavefronts
 HOT = (FIT_FWD, FIT_BWD, BWD_HEAD, TAIL, HEAD)
 
 
@@ -72,7 +72,7 @@ for (k, g), ds in groups.items():
         else:
             what = "other batch size (full-model / sample checks)"
     elif k == BWD_HEAD:
-        what = "first backward fit of the step + the deferred loss head in a spare wavefront of workgroup 0 (320-thread workgroups)"
+        what = "first backward fit of the step + the deferred loss head in three spare wavefronts of workgroup 0 (448-thread workgroups)"
         step_sum += mean(ds) / 1e3
     elif k == HEAD:
         what = "loss head as a launch of its own: only the informational layers-batched variant (the timed step defers it)"
