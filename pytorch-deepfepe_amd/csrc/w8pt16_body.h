@@ -37,17 +37,17 @@
 #define S16_T2 3       // Hartley transform of image 2
 #define S16_F 6        // 9: the oriented unit eigenvector f (largest-magnitude component positive)
 #define S16_Z 15       // 9: z = H^T f, the eigenvector of the tridiagonal T (same orientation)
-#define S16_TWIST 24   // twist index of the factorisation (largest-residual-free row), as float
-#define S16_HV 26      // 35: reflector k = 0..6, components k+1..8, at offset 8k - k(k-1)/2
-#define S16_HB 61      // 7: beta_k  (H_k = I - beta_k v_k v_k^T)
+#define S16_HV 26      // 35: reflector k = 0..6, components k+1..8, at offset 8k - k(k-1)/2  (floats 24..63: nothing else, see below)
 #define S16_TD 68      // 9 doubles: diagonal of T  (T = H^T (M / trace M) H)
 #define S16_TE 86      // 8 doubles: off-diagonal of T
 #define S16_LAM 102    // 1 double: the selected eigenvalue of M / trace M
 #define S16_U3 104     // smallest singular triplet of F = reshape(f): u3 (3 floats)
 #define S16_V3 107     //                                              v3 (3 floats)
 #define S16_S3 110     //                                              s3 >= 0
+#define S16_TWIST 111  // twist index of the factorisation (largest-residual-free row), as float
+#define S16_HB 112     // 7: beta_k  (H_k = I - beta_k v_k v_k^T)
 #define S16_INVTR 125  // 1 / trace(M)
-#define S16_SCRATCH 126 // written with garbage (branch-free stores of the lanes that have nothing to contribute)
+#define S16_SCRATCH 126 // unused since round 3 (kept zero); float 24 takes the branch-free stray stores of the reflector lanes
 #define S16_TAG 127    // record tag: the backward poisons its output when handed anything but a record of this layout
 #define S16_TAG_VALUE 16.0f
 
@@ -729,34 +729,52 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   DFEPE_MARK("P5s_save");
   if (A.save != nullptr) {
     float* sv = static_cast<float*>(__builtin_assume_aligned(A.save, 16)) + (size_t)pair * DFEPE_SAVE_FLOATS;
-    // Everything but the reflector components is uniform over the row.  ONE lane stores all of it in ONE exec region: with a
-    // lane per piece (round 2) the pieces were eight regions, and a lone wavefront pays ~9 cycles for every scalar instruction
-    // and branch around a region (scripts/ubench/lat2.hip) while the stores themselves cost the same whichever lane issues them;
-    // "lane c writes element c" costs a select chain per element (~90 v_cndmask).
-    if (l == 0) {
+    // Everything but the reflector components is uniform over the row.  Under load a global store INSTRUCTION costs this lone
+    // wavefront 50-70 cycles whatever its width or the number of lanes behind it (scripts/ubench/lat2.hip), a select 5: so the
+    // uniform part (floats 0..23 and 64..127 of the record) leaves in TWO instructions -- lane s of {0, 1, 2, 8..15} assembles
+    // floats 8 s .. 8 s + 7 with one select per float (~95 v_cndmask) and stores them as two 16-byte pieces -- instead of the
+    // 26 stores a lane per piece needed (rounds 2-3).  Floats 24..63 hold only reflector components, which live in their lanes.
+    float slice[8];
 #pragma unroll
-      for (int c = 0; c < 9; ++c) sv[S16_F + c] = (float)f[c];
+    for (int c = 0; c < 8; ++c) slice[c] = 0.0f;
+    auto put = [&](const int idx, const float v) {  // idx is a literal after unrolling: slice[] is indexed at compile time
+      slice[idx & 7] = ((idx >> 3) == l) ? v : slice[idx & 7];
+    };
+    auto put2 = [&](const int idx, const double v) {  // a double in two consecutive floats
+      typedef float f32x2 __attribute__((vector_size(8)));
+      const f32x2 h = __builtin_bit_cast(f32x2, v);
+      put(idx, h[0]);
+      put(idx + 1, h[1]);
+    };
+    put(S16_T1 + 0, (float)s1); put(S16_T1 + 1, (float)c1x); put(S16_T1 + 2, (float)c1y);
+    put(S16_T2 + 0, (float)s2); put(S16_T2 + 1, (float)c2x); put(S16_T2 + 2, (float)c2y);
 #pragma unroll
-      for (int c = 0; c < 9; ++c) sv[S16_Z + c] = (float)(sgn * z[c]);
+    for (int c = 0; c < 9; ++c) { put(S16_F + c, (float)f[c]); put(S16_Z + c, (float)(sgn * z[c])); }
 #pragma unroll
-      for (int c = 0; c < 9; ++c) reinterpret_cast<double*>(sv + S16_TD)[c] = td[c];
+    for (int c = 0; c < 9; ++c) put2(S16_TD + 2 * c, td[c]);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) reinterpret_cast<double*>(sv + S16_TE)[c] = te[c];
-      reinterpret_cast<double*>(sv + S16_LAM)[0] = lam;
+    for (int c = 0; c < 8; ++c) put2(S16_TE + 2 * c, te[c]);
+    put2(S16_LAM, lam);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { sv[S16_U3 + c] = (float)u3[c]; sv[S16_V3 + c] = (float)v3[c]; }
-      sv[S16_S3] = (float)s3;
+    for (int c = 0; c < 3; ++c) { put(S16_U3 + c, (float)u3[c]); put(S16_V3 + c, (float)v3[c]); }
+    put(S16_S3, (float)s3);
+    put(S16_TWIST, (float)twist);
 #pragma unroll
-      for (int c = 0; c < 7; ++c) sv[S16_HB + c] = (float)hb[c];
-      sv[S16_T1 + 0] = (float)s1; sv[S16_T1 + 1] = (float)c1x; sv[S16_T1 + 2] = (float)c1y;
-      sv[S16_T2 + 0] = (float)s2; sv[S16_T2 + 1] = (float)c2x; sv[S16_T2 + 2] = (float)c2y;
-      sv[S16_TWIST] = (float)twist;
-      sv[S16_INVTR] = (float)inv_tr;
-      sv[S16_TAG] = S16_TAG_VALUE;
+    for (int c = 0; c < 7; ++c) put(S16_HB + c, (float)hb[c]);
+    put(S16_INVTR, (float)inv_tr);
+    put(S16_TAG, S16_TAG_VALUE);
+    static_assert(S16_Z + 9 <= 24 && S16_HV >= 24 && S16_HV + 35 <= 64 && S16_HB >= 64 && S16_TD >= 64, "slices 3..7 of the record hold reflector components only");
+    if (l < 3 || l >= 8) {
+      float4* dst = reinterpret_cast<float4*>(sv + 8 * l);
+      float4 q0, q1;
+      q0.x = slice[0]; q0.y = slice[1]; q0.z = slice[2]; q0.w = slice[3];
+      q1.x = slice[4]; q1.y = slice[5]; q1.z = slice[6]; q1.w = slice[7];
+      dst[0] = q0;
+      dst[1] = q1;
     }
 #pragma unroll
     for (int k = 0; k < 7; ++k)  // lanes that hold no component of reflector k write a scratch slot: no branch per reflector
-      sv[(l > k && l < 9) ? S16_HV + s16_hv_off(k) + (l - k - 1) : S16_SCRATCH] = (float)hv[k];
+      sv[(l > k && l < 9) ? S16_HV + s16_hv_off(k) + (l - k - 1) : 24] = (float)hv[k];
   }
   if constexpr (ROWS > 1) {
     if (l < 9) { co->f[l] = f[l]; co->of[l] = of[l]; }
