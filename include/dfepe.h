@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFEPE_VERSION 130 /* 0.3.0 */
+#define DFEPE_VERSION 131 /* 0.3.1 */
 
 #define DFEPE_OK 0
 #define DFEPE_ERR_INVALID_ARG (-1) /* null pointer, non-positive size, bad flag combination   */

@@ -49,7 +49,7 @@
 #define S16_INVTR 125  // 1 / trace(M)
 #define S16_SCRATCH 126 // unused since round 3 (kept zero); float 24 takes the branch-free stray stores of the reflector lanes
 #define S16_TAG 127    // record tag: the backward poisons its output when handed anything but a record of this layout
-#define S16_TAG_VALUE 16.0f
+#define S16_TAG_VALUE 17.0f  // 17: the round-3 layout (TWIST and HB behind S3)
 
 __host__ __device__ constexpr int s16_hv_off(int k) { return 8 * k - (k * (k - 1)) / 2; }
 

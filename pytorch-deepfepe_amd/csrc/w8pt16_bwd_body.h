@@ -147,7 +147,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A0, const 
   const float gs_in = ((A.g_scale != nullptr) ? A.g_scale : sv + S16_TAG)[l & 0];  // a vector load: the scalar cache would miss
   const int twist = (int)sv[S16_TWIST];
   const double inv_tr = sv[S16_INVTR];
-  const bool good = sv[S16_TAG] == S16_TAG_VALUE;  // a record of the other forward kernel would be misread: poison instead
+  const bool good = sv[S16_TAG] == S16_TAG_VALUE;  // a record of another layout (an older library) would be misread: poison instead
 
   // same unconditional loads and the same drop rule as the forward (w8pt16_fwd_pair, phase 0); IT = 0: any N, re-read per pass
   constexpr int ITR = (IT > 0) ? IT : 1;

@@ -121,7 +121,7 @@ def test_backward_body_vs_oracle_autograd(emu, dfepe, oracle, N, outl, use_res, 
     GR = torch.randn(B, N, generator=g) if use_res else None
     GE = torch.randn(B, N, generator=g) if use_epi else None
     F, res, epi, save, wout = emu_fwd(emu, m, None, logits, RAW | LOGITS)
-    assert (save[:, 127] == 16.0).all()
+    assert (save[:, 127] == 17.0).all()  # S16_TAG_VALUE: the round-3 record layout
     gL, _, _ = emu_bwd(emu, m, None, wout, RAW | LOGITS, save, F, GF, GR, GE)
     lo_in = logits.double().requires_grad_(True)
     wo = torch.softmax(lo_in, 1)
