@@ -55,6 +55,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--spinup", type=int, default=200, help="untimed steps in front of the warm-up steps (clock / cache settling)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
     ap.add_argument("--scaling", choices=("weak", "strong"), default=None, help="default: weak for configs 2-4, strong for config 5")
@@ -276,6 +277,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # untimed spin-up in front of the W warm-up steps: a few ms of the same step so that clocks and caches are those of a running
+    # job whatever W and K the caller picked (reported as "spinup_steps"; the timed region is exactly K steps of full work)
+    for _ in range(args.spinup):
+        run_step()
     for _ in range(args.warmup):
         run_step()
     barrier()
@@ -562,7 +567,7 @@ def main():
             "unit": "pairs/s",
             "n_gpus": world,
             "steps": args.steps,
-            "warmup": args.warmup,
+            "warmup": args.warmup, "spinup_steps": args.spinup,
             "ms_per_step": round(ms_per_step, 4),
             "ms_per_step_per_rank": per_rank_ms,
             "rccl_world_size": rccl_world,
