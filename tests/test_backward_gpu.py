@@ -203,8 +203,8 @@ def test_fused_step_equals_unfused_ops(dfepe):
 
 @pytest.mark.parametrize("B,N,batched", [(37, 100, False), (300, 100, True), (5, 200, False)])
 def test_deferred_loss_head_gives_the_same_step(dfepe, B, N, batched):
-    """defer_loss_head: the batch sums of the loss tail are finished by the first backward launch (four spare wavefronts of
-    its first workgroup for the row kernels; a launch behind it for the wavefront-per-pair kernels, N = 200 at B = 5) instead
+    """defer_loss_head: the batch sums of the loss tail are finished by the first backward launch (three spare wavefronts of
+    its first workgroup for the row kernels; a launch behind it for the cooperative kernels, N = 200 at B = 5) instead
     of a launch of their own.  After backward every output and the gradients are those of the undeferred step, bit for bit."""
     depth = 5
     sc = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(B, N, seed=41, outlier_ratio=0.3, depth_layers=depth), DEV)
@@ -226,6 +226,28 @@ def test_deferred_loss_head_gives_the_same_step(dfepe, B, N, batched):
         c = dfepe.pipeline.hot_path_fused(sc["matches_xy_ori"], sc["logits_layers"][:depth], sc["Ks"], sc["pts1_virt_ori"], sc["pts2_virt_ori"],
                                           sc["qs_cam"], sc["ts_cam"], sc["R_gt"], IMAGE_SIZE, 0.02, True, defer_loss_head=True)
     assert torch.equal(c["loss"], a["loss"]) and torch.equal(c["packed"], a["packed"])
+
+
+@pytest.mark.parametrize("B,depth", [(40, 9), (40, 16), (4096, 9), (4100, 3)])
+def test_loss_head_layer_groups_and_workgroup_counts(dfepe, B, depth):
+    """The loss head walks the layers of a kind in groups of eight and has a fast path for workgroup counts that are multiples
+    of 256 (B = 4096 -> 256 workgroups of the tail): more than eight layers, and workgroup counts on both sides of that
+    condition, deferred and not, against the sums formed from the per-pair outputs."""
+    N = 20
+    sc = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(B, N, seed=77 + depth, outlier_ratio=0.3, depth_layers=depth), DEV)
+    for defer in (False, True):
+        logits = sc["logits_layers"][:depth].detach().clone().requires_grad_(True)
+        o = dfepe.pipeline.hot_path_fused(sc["matches_xy_ori"], logits, sc["Ks"], sc["pts1_virt_ori"], sc["pts2_virt_ori"], sc["qs_cam"],
+                                          sc["ts_cam"], sc["R_gt"], IMAGE_SIZE, 0.02, True, defer_loss_head=defer)
+        o["loss"].backward()
+        torch.cuda.synchronize()
+        M = sc["pts1_virt_ori"].shape[1]
+        ref = dfepe.dist.pack_loss_sums(o["loss_sum"], M, o["q_l2"], o["t_l2"], 0.1, 0.5)
+        np.testing.assert_allclose(o["packed"].cpu().numpy(), ref.cpu().numpy(), rtol=1e-12)
+        np.testing.assert_allclose(o["loss_layers"].cpu().numpy(), (o["loss_sum"].double().sum(1) / (B * M)).cpu().numpy(), rtol=1e-6)
+        loss_F = o["loss_sum"].double().sum() / (B * M * depth)
+        loss_qt = (o["q_l2"].double().clamp(max=0.1).sum() * 1.0 + o["t_l2"].double().clamp(max=0.5).sum() * 0.1) / (B * depth)
+        np.testing.assert_allclose(o["loss"].item(), (loss_F + loss_qt).item(), rtol=1e-6)
 
 
 @pytest.mark.parametrize("qt,balance_F", [(True, 1.0), (True, 0.0), (False, 1.0), (True, 0.3)])
