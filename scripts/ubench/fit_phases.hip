@@ -64,9 +64,9 @@ int main() {
     if (c[0] < first) first = c[0];
     if (c[12] > last) last = c[12];
   }
-  printf("kernel (with stamps): %.2f us per launch (HIP events, 20 launches); first P0 stamp -> last end stamp over all %d wavefronts: %llu ticks\n",
+  printf("kernel (with stamps): %.2f us per launch (HIP events, 20 launches); first P0 stamp -> last end stamp over all %d wavefronts (several launches, not comparable): %llu cycles\n",
          ms * 1e3 / 20, waves, last - first);
-  printf("%-44s %10s %10s\n", "phase (ticks of the 100 MHz memory clock x ?)", "mean", "max");
+  printf("%-44s %10s %10s\n", "phase (shader-clock cycles)", "mean", "max");
   for (int k = 0; k < 12; ++k) printf("%-44s %10.1f %10.1f  (%4.1f %%)\n", names[k], sum[k] / waves, mx[k], 100.0 * sum[k] / sum[12]);
   printf("%-44s %10.1f %10.1f\n", "P0 .. end", sum[12] / waves, mx[12]);
   return 0;
