@@ -506,8 +506,8 @@ def main():
                 acc["F_fro_err_vs_fp32_reference_shaped_sample"] = {"max": float(e32.max()), "median": float(e32.median())}
             log("cpu baseline done", cpu)
 
-        # ---- secondary, informational: the whole DeepFNet step (estimator evaluated as channel-major GEMMs + fused
-        #      InstanceNorm/LeakyReLU, solver, F-loss, qt loss, backward to the estimator parameters) --------------------
+        # ---- secondary, informational: the whole DeepFNet step (estimator on the bf16 matrix cores with split operands and the
+        #      InstanceNorm/LeakyReLU epilogue, solver, F-loss, qt loss, backward to the estimator parameters) -----------
         if extras and not args.no_full_model and world == 1 and kind == "train" and args.config == 3:
             try:
                 net = dfepe.compat.DeepFNet.DeepFNet(depth=L, image_size=IMAGE_SIZE, if_quality=False).to(dev)

@@ -23,10 +23,13 @@ INCLUDE = os.path.abspath(os.path.join(HERE, "..", "include"))
 OBJDIR = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libdfepe_hip.so")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-ffp-contract=on",
-         "-mllvm", "-amdgpu-kernarg-preload-count=16",  # leading scalar kernel arguments arrive in SGPRs (w8pt16.hip)
-         f"-I{INCLUDE}", f"-I{CSRC}"]
-FLAGS += os.environ.get("DFEPE_EXTRA_FLAGS", "").split()  # experiment builds (A/B timing of a -D switch); empty for the product
+CFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-ffp-contract=on",
+          "-mllvm", "-amdgpu-kernarg-preload-count=16"]  # leading scalar kernel arguments arrive in SGPRs (w8pt16.hip)
+CFLAGS += os.environ.get("DFEPE_EXTRA_FLAGS", "").split()  # experiment builds (A/B timing of a -D switch); empty for the product
+FLAGS = CFLAGS + [f"-I{INCLUDE}", f"-I{CSRC}"]
+# what the stamps hash: the flags with the include directories relative to the repository, so that a relocated tree (the
+# snapshot on the GPU box, a scratch copy) reuses its prebuilt objects instead of recompiling all of them
+STAMP_FLAGS = " ".join(CFLAGS + ["-Iinclude", "-Icsrc"])
 
 
 def _hipcc() -> str:
@@ -64,7 +67,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJDIR, s[:-4] + ".o")
         objs.append(obj)
-        digest = _digest([src] + hdrs, " ".join(FLAGS))
+        digest = _digest([src] + hdrs, STAMP_FLAGS)
         if force or not os.path.exists(obj) or not _stamp_matches(obj + ".sha256", digest):
             jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
             stamps[obj] = digest

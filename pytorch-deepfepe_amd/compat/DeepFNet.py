@@ -93,8 +93,8 @@ class DeepFNet(nn.Module):
         self.if_img_w = if_img_w
         self.image_size = image_size
         self.depth = depth
-        # same parameters / state_dict as the reference's ErrorEstimator; evaluated as channel-major GEMMs + one fused
-        # InstanceNorm+LeakyReLU pass (falls back to the stock module when that layout does not apply)
+        # same parameters / state_dict as the reference's ErrorEstimator; evaluated on the bf16 matrix cores with fp32-accurate
+        # split operands, InstanceNorm + LeakyReLU in the GEMM epilogue (csrc/est_gemm.hip; other variants: fp32 library GEMMs)
         Est = FusedErrorEstimator if params.get("fused_estimator", True) else ErrorEstimator
         self.input_weights = Est(4 + quality_size)
         self.update_weights = Est(4 + quality_size + 3)  # + weights, epi_res, residual (DeepFNet.py:340)

@@ -112,15 +112,28 @@ def get_Rt_loss(E_ests_layers, Ks_cpu, x1_cpu, x2_cpu, delta_Rtijs_4_4_cpu, qs_c
     }
 
 
+_warned_opencv = False
+
+
 def val_rt(idx, K_np, x1_single_np, x2_single_np, E_est_np, E_gt_np, F_est_np, F_gt_np, delta_Rtijs_4_4_cpu_np, five_point,
-           if_opencv=True):
+           if_opencv=False):
     """Same call and same 9-tuple as the reference's per-pair validation worker (train_good_utils.py:553-646):
     (error_Rt_estW, epi_dist_mean_estW, error_Rt_opencv, epi_dist_mean_opencv, error_Rt_gt, epi_dist_mean_gt, idx, M_estW, M_opencv).
     The estimated-E and ground-truth-E legs go through utils_F.goodCorr_eval_nondecompose (the cheirality kernel in place of
     cv2.recoverPose) and utils_F.epi_distance_np.  The OpenCV five-point / eight-point RANSAC baseline (``if_opencv``,
     utils_opencv.recover_camera_opencv) is outside this build (OpenCV baselines): its three slots are None.
+    ``if_opencv`` defaults to False here (the reference's default is True): a caller that asks for the OpenCV leg gets one
+    warning saying that its slots stay None, instead of an unrelated TypeError when it indexes them later.
     One pair per call like the reference; val_rt_batch / validation_summary below are the batched forms."""
     from . import utils_F
+
+    global _warned_opencv
+    if if_opencv and not _warned_opencv:
+        import warnings
+
+        warnings.warn("val_rt(if_opencv=True): the OpenCV five-point / RANSAC baseline is not part of this build (SURVEY.md §2); "
+                      "error_Rt_opencv, epi_dist_mean_opencv and M_opencv are returned as None", RuntimeWarning, stacklevel=2)
+        _warned_opencv = True
 
     delta_Rtij_inv = np.linalg.inv(np.asarray(delta_Rtijs_4_4_cpu_np))[:3]
     M_estW, error_Rt_estW = utils_F.goodCorr_eval_nondecompose(x1_single_np, x2_single_np, np.asarray(E_est_np).astype(np.float64),

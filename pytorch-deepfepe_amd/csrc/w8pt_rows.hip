@@ -36,7 +36,10 @@ w8pt_rows_kernel(const float* __restrict__ rows, int B, int N, unsigned variant,
 #pragma unroll
     for (int u = 0; u < 9; ++u)
 #pragma unroll
-      for (int v = u; v < 9; ++v) acc[e++] = fma(r[u], r[v], acc[e]);
+      for (int v = u; v < 9; ++v) {
+        acc[e] = fma(r[u], r[v], acc[e]);
+        ++e;
+      }
   }
   // M[u][v] in every lane (45 row sums); lane i < 9 then keeps row i
   double Ar[9];

@@ -52,8 +52,8 @@ class _EstimatorFunction(torch.autograd.Function):
         B, C0, N = x.shape
         cols = B * N
         dev = x.device
-        st = _stream()
         with torch.cuda.device(dev):
+            st = _stream()  # the current stream of x's device, read under its guard
             xin = x.detach().float().permute(0, 2, 1).reshape(cols, C0).contiguous()
             acts = [_split(xin, cols, C0, _pad32(C0), 3)]  # planes of every layer's input, point-major [3, cols, C]
             rstds = []
@@ -78,8 +78,12 @@ class _EstimatorFunction(torch.autograd.Function):
             _lib.check(rc, "dfepe_est_head_fwd")
         ctx.cfg = cfg
         ctx.shape = (B, C0, N)
-        ctx.acts, ctx.rstds = acts, rstds  # device buffers of this node (planes are not autograd tensors)
-        ctx.save_for_backward(*[p for p in params if p is not None])
+        # the bf16 planes and the reciprocal deviations travel through save_for_backward like the parameters: autograd owns their
+        # lifetime (freed after the backward of a graph that is not retained, kept under retain_graph=True, and a second backward
+        # through a freed graph raises autograd's own error instead of a TypeError on a cleared attribute)
+        kept = [p for p in params if p is not None]
+        ctx.n_params = len(kept)
+        ctx.save_for_backward(*kept, *acts, *rstds)
         ctx.has_head_bias = bh is not None
         return logits.view(B, 1, N)
 
@@ -89,13 +93,15 @@ class _EstimatorFunction(torch.autograd.Function):
         lib = _lib.lib()
         B, C0, N = ctx.shape
         cols = B * N
-        saved = list(ctx.saved_tensors)
+        everything = list(ctx.saved_tensors)
+        saved = everything[:ctx.n_params]
+        acts = everything[ctx.n_params:ctx.n_params + n_hidden + 1]
+        rstds = everything[ctx.n_params + n_hidden + 1:]
         params = saved if ctx.has_head_bias else saved + [None]
-        acts, rstds = ctx.acts, ctx.rstds
         dev = g_logits.device
-        st = _stream()
         grads: List[Optional[Tensor]] = [None] * len(params)
         with torch.cuda.device(dev):
+            st = _stream()
             dl = g_logits.detach().float().reshape(cols).contiguous()
             Wh = params[4 * n_hidden]
             C = acts[-1].shape[2]
@@ -142,7 +148,6 @@ class _EstimatorFunction(torch.autograd.Function):
             gx = None
             if ctx.needs_input_grad[1]:
                 gx = dA[:, :C0].reshape(B, N, C0).permute(0, 2, 1).contiguous()
-        ctx.acts = ctx.rstds = None
         return (None, gx, *grads)
 
 

@@ -68,7 +68,7 @@ def test_deepfnet_full_model_matches_reference_golden(dfepe, golden):
                                 "weights", "residual_layers", "weights_layers"}
     # What sets the tolerances below: the estimator is ~0.8 GFLOP of fp32 GEMMs + InstanceNorms per pair, and two fp32
     # implementations of the SAME network differ by their summation order.  Measured here: this package's fused estimator
-    # (channel-major GEMMs) against its own stock-PyTorch estimator (conv1d, MIOpen) with identical parameters -- the distance
+    # (split-bf16 MFMA GEMMs) against its own stock-PyTorch estimator (conv1d, MIOpen) with identical parameters -- the distance
     # to the reference's run is required to stay within a small multiple of that fp32 reordering noise.
     net_b = dfepe.compat.DeepFNet.DeepFNet(depth=depth, image_size=IMAGE_SIZE, if_quality=False, if_cpu_svd=True, fused_estimator=False)
     net_b.load_state_dict(net.state_dict())

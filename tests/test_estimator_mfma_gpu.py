@@ -192,3 +192,22 @@ def test_whole_estimator_matches_the_stock_module_in_float64(dfepe, cin, B, seed
     fused.split_bf16 = False
     yc = fused(x.to(DEV))
     assert float((yc.detach() - yb.detach()).abs().max()) < 1e-4
+
+
+def test_backward_twice_with_retain_graph_and_the_standard_error_without(dfepe):
+    """the node's bf16 planes live in save_for_backward, so a retained graph can be walked twice (separate
+    loss_F / loss_qt backward calls, repeated torch.autograd.grad) with identical gradients, and a second walk through a freed
+    graph raises autograd's own error, not a TypeError on a cleared attribute."""
+    EE = dfepe.compat.ErrorEstimators
+    fused = EE.FusedErrorEstimator(4).to(DEV)
+    dfepe.synth.fill_params_deterministic(fused, seed=3)
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(3, 4, 100, generator=g).to(DEV).requires_grad_(True)
+    y = fused(x)
+    loss = (y * y).sum()
+    g1 = torch.autograd.grad(loss, [x] + list(fused.parameters()), retain_graph=True)
+    g2 = torch.autograd.grad(loss, [x] + list(fused.parameters()), retain_graph=False)
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError, match="backward through the graph a second time|already been freed"):
+        torch.autograd.grad(loss, [x])
