@@ -158,6 +158,86 @@ def event_time_us(fn, reps=50, rounds=5, warm=5, graph=True):
     return statistics.median(durs)
 
 
+def count_launches(fn):
+    """Kernel launches of one call of `fn` (torch.profiler sees every HIP kernel of the process, the ctypes launches included);
+    None when the profiler is unavailable."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+
+        fn()
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            fn()
+            torch.cuda.synchronize()
+        names = {}
+        for ev in prof.events():
+            if str(getattr(ev, "device_type", "")).endswith("CUDA") and "memcpy" not in ev.name.lower() and "memset" not in ev.name.lower():
+                names[ev.name] = names.get(ev.name, 0) + 1
+        n = sum(names.values())
+        ours = sum(c for k, c in names.items() if any(t in k for t in ("w8pt", "loss_tail", "floss", "pose_", "geo_misc", "deepf_input")))
+        return {"total": n, "hip_kernels_of_this_library": ours, "torch_glue": n - ours} if n else None
+    except Exception:
+        return None
+
+
+def measure_api_path(dfepe, scene, logits, L, balance_F, args, B, fused_ms, fused_grad):
+    """The reference's call sequence on the benchmark's batch, three ways: ground truth only at get_Rt_loss (the reference's
+    signature, stand-alone F-loss and pose kernels), ground truth also in loss_params (one fused tail launch), and the latter
+    with a linear probe estimator that gives every layer but the last the recurrent model's backward.  Each eager and as a
+    hipGraph replay."""
+    pl = dfepe.pipeline
+    out = {"what": "compat.DeepFNet.forward (estimators replaced by the benchmark's fixed per-layer logits) + compat.get_all_loss_DeepF + "
+                   "compat.get_Rt_loss + clamp(stack(...)).mean() * balance mixing in torch + backward to the logits; same batch, same "
+                   "objective as `value`"}
+    for key, gt_in, probe in (("reference_signature", False, False), ("pose_gt_in_loss_params", True, False),
+                              ("recurrent_shape", True, True)):
+        rows = [logits[l].detach().clone().unsqueeze(1).requires_grad_(True) for l in range(L)]
+        net = pl.make_api_net(L, IMAGE_SIZE, rows, recurrent_probe=probe)
+        st = {}
+
+        def body():
+            loss, outs, losses, geo = pl.reference_call_sequence(net, scene, L, balance_F=balance_F, pose_gt_in_loss_params=gt_in)
+            st["g"] = torch.autograd.grad(loss, rows, grad_outputs=st.setdefault("seed", torch.ones_like(loss)))
+            st["loss"] = loss
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        rec = {"launches": count_launches(body)}
+        if not probe and fused_grad is not None:
+            g = torch.stack([x.squeeze(1) for x in st["g"]])
+            rec["max_abs_grad_diff_vs_value_run"] = float((g - fused_grad).abs().max())
+            rec["grad_scale"] = float(fused_grad.abs().max())
+        n_e = max(20, min(args.steps, 100))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_e):
+            body()
+        torch.cuda.synchronize()
+        rec["eager_ms_per_step"] = round((time.perf_counter() - t0) * 1e3 / n_e, 4)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            body()
+        for _ in range(args.warmup + 20):
+            gr.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            gr.replay()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / args.steps
+        rec["hipgraph_ms_per_step"] = round(ms, 4)
+        rec["pairs_per_s"] = round(B / ms * 1e3, 1)
+        rec["vs_fused_entry_point"] = round(ms / fused_ms, 3)
+        out[key] = rec
+        del gr, net
+    return out
+
+
 def main():
     args = parse()
     launched = "RANK" in os.environ or "LOCAL_RANK" in os.environ
@@ -436,6 +516,17 @@ def main():
                                   "note": "all L layers' fits in one launch; only legal with fixed logits, not `value`"}
             log("variants done")
 
+        # ---- the same step through the reference's OWN call sequence: compat.DeepFNet (estimator replaced
+        #      by the same fixed per-layer logits) -> get_all_loss_DeepF -> get_Rt_loss -> the caller's clamp / balance lines ->
+        #      backward (Train_model_pipeline.py:495-595).  Never `value`; it says what a train_good.py user gets of it. ------
+        api_path = None
+        if extras and kind == "train" and world == 1:
+            try:
+                api_path = measure_api_path(dfepe, scene, logits, L, cfg["balance_F"], args, B, ms_per_step, state.get("grad_logits"))
+            except Exception as exc:  # informational only
+                api_path = {"error": repr(exc)[:300]}
+            log("api path done", api_path)
+
         # ---- CPU baseline: the oracle on a bounded sample of the same workload, on this box's host cores -----------------
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # contract: CPU baseline on rank 0 at N=1 only
@@ -587,6 +678,7 @@ def main():
             "cpu_baseline": cpu,
             "accuracy": acc,
             "block_stats": block_stats,
+            "api_path": api_path,
             "recurrent_backward": recurrent_bwd,
             "full_model": full_model,
             "layers_batched": layers_batched,

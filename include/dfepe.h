@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFEPE_VERSION 131 /* 0.3.1 */
+#define DFEPE_VERSION 140 /* 0.4.0 */
 
 #define DFEPE_OK 0
 #define DFEPE_ERR_INVALID_ARG (-1) /* null pointer, non-positive size, bad flag combination   */
@@ -217,6 +217,26 @@ int dfepe_loss_tail(const float *F_layers, int L, int B, const float *T1, const 
                     float *g_F_layers, double *packed, float *scalars, void *workspace, int defer_head, void *stream);
 
 /*
+ * The loss tail behind the reference's OWN call sequence (get_all_loss_DeepF, then get_Rt_loss, then the caller's clamp /
+ * balance mixing in torch, Train_model_pipeline.py:508-586): the coefficients of the loss are not known when the forward
+ * runs, so this variant of dfepe_loss_tail leaves, next to the same per-pair outputs, the three JACOBIANS of every
+ * (layer, pair):  J [L,B,27] = d loss_sum / dF (9) | d q_l2 / dF (9) | d t_l2 / dF (9)   (unclamped, unit upstream),
+ * and dfepe_loss_tail_bwd turns whatever upstream gradients autograd delivers into d loss / dF in one launch:
+ *   g_F[l,b] = g_loss_sum[l,b] J_F + g_q_l2[l,b] J_q + g_t_l2[l,b] J_t        (each upstream pointer may be NULL = zero)
+ * Replaces: torch.autograd through get_all_loss_DeepF's per-layer body (deepFEPE/train_good_utils.py:325-358) and
+ *           get_Rt_loss's per-sample loop (:96-239).  No batch sums here (the caller's torch means take them).
+ *   arguments as in dfepe_loss_tail, M <= 112 (else DFEPE_ERR_UNSUPPORTED); q_gt == NULL: no pose part (J_q = J_t = 0); want_floss_jac == 0: J_F = 0 and the F-loss
+ *   adjoint work is skipped (an objective without the F-loss, the reference's if_qt_loss)
+ */
+int dfepe_loss_tail_jac(const float *F_layers, int L, int B, const float *T1, const float *T2, int t_stride, const float *K,
+                        const float *virt1, const float *virt2, int M, float clamp_at,
+                        const float *q_gt, const float *t_gt, const float *R_gt, int want_floss_jac,
+                        float *loss_sum, float *E_layers, float *q_l2, float *t_l2, float *R_deg, float *t_deg, int *sel,
+                        float *J, void *stream);
+int dfepe_loss_tail_bwd(const float *J, int L, int B, const float *g_loss_sum, const float *g_q_l2, const float *g_t_l2,
+                        float *g_F_layers, void *stream);
+
+/*
  * Cheirality-checked pose from E.
  * Replaces: utils_F._E_to_M_train (deepFEPE/dsac_tools/utils_F.py:679-763): the four candidates of _get_M2s in
  * the order (R1,t),(R1,-t),(R2,t),(R2,-t), linear triangulation of every correspondence (the reference calls
@@ -292,8 +312,22 @@ int dfepe_epi_residual_bwd(const float *pts1, const float *pts2, const float *F,
  *   kind 5  congruence A^T F A              in0 = F [n,9], in1 = A [n,9] out [n,9]  (E = K^T T2^T F T1 K with A = T K when
  *                                                                                   T1 = T2: train_good_utils.py:356-358,366-369;
  *                                                                                   utils_F._F_to_E's K^T F K, utils_F.py:456)
+ *   kind 6  camera rotation of a scene motion  in0 = delta [n,16]       out [n,9] = inv(delta)[:3,:3]
+ *                                                                                  (get_Rt_loss, train_good_utils.py:134,170)
  */
 int dfepe_geo_misc(int kind, const float *in0, const float *in1, int n, float *out, void *stream);
+
+/*
+ * Inputs of the recurrent model from the pixel matches.
+ * Replaces: DeepFNet.get_input (deepFEPE/models/DeepFNet.py:362-391) with NormalizeAndExpand_HW (:93-120): the image-size
+ *           normalisation T_HW (x, y, 1) of both point sets and the estimator's input channels ((x+1)/2, (y+1)/2 of both images,
+ *           then the Q quality channels) -- about fifteen elementwise / bmm launches in the reference, one here.
+ *   matches [B,N,4] pixels (16-byte aligned); quality [B,N,Q] or NULL (Q = 0)
+ *   weight_in [B,C_out,N] or NULL: channels 0..3+Q are written (C_out >= 4+Q lets the caller own further channels of the buffer)
+ *   pts1, pts2 [B,N,3] or NULL: homogeneous normalised points (the arithmetic of dfepe_w8pt_fwd's DFEPE_W8PT_RAW_MATCHES prologue)
+ */
+int dfepe_deepf_input(const float *matches, const float *quality, int B, int N, int Q, float image_w, float image_h,
+                      float *weight_in, int C_out, float *pts1, float *pts2, void *stream);
 
 /*
  * InstanceNorm1d(affine) + LeakyReLU on rows of N contiguous floats ("next" row f-1: the part of the weight estimator

@@ -109,8 +109,24 @@ class DeepFNet(nn.Module):
         self.norm_HW = NormalizeAndExpand_HW(image_size, is_cuda, is_test)
         self.fit = Fit(is_cuda, is_test, if_cpu_svd)
 
+    def _T_hw(self, B, dev):
+        """The image-size transform as [B,3,3] (an expanded view of one cached device constant: no per-step host copy, so the
+        forward can be captured in a hipGraph)."""
+        key = (str(dev), float(self.image_size[0]), float(self.image_size[1]))
+        cache = self.__dict__.setdefault("_t_hw_cache", {})
+        if key not in cache:
+            H, W = float(self.image_size[0]), float(self.image_size[1])
+            cache[key] = torch.tensor([[2.0 / W, 0.0, -1.0], [0.0, 2.0 / H, -1.0], [0.0, 0.0, 1.0]], device=dev)
+        return cache[key].unsqueeze(0).expand(B, -1, -1)
+
     def get_input(self, data_batch, offsets=None, iter=None):
         pts = data_batch["matches_xy_ori"]
+        if offsets is None and not (torch.is_grad_enabled() and pts.requires_grad):
+            # the default path: ONE launch instead of ~15 elementwise / bmm ones (the matches are data, nothing to differentiate)
+            quality = data_batch["quality"] if self.if_quality else None
+            weight_in, pts1, pts2 = ops.deepf_input(pts, float(self.image_size[1]), float(self.image_size[0]), quality)
+            T = self._T_hw(pts.shape[0], pts.device)
+            return weight_in, pts1, pts2, T, T, pts
         if offsets is not None:  # (DeepFNet.py:369-373)
             pts = pts + offsets.permute(0, 2, 1)
         pts1, pts2, T1, T2 = self.norm_HW(pts)
@@ -122,14 +138,16 @@ class DeepFNet(nn.Module):
         weight_in = torch.cat(parts, 2).permute(0, 2, 1)
         return weight_in, pts1, pts2, T1, T2, pts
 
-    def _fit(self, matches, logits, data_batch, want_epi):
+    def _fit(self, matches, logits, data_batch, want_epi, dst=None):
         """logits [B,1,N] -> (out, residual[, epi], weights_prod [B,1,N]).  The softmax over N is fused into the solver
-        kernel unless per-correspondence image weights multiply it afterwards (if_img_w)."""
+        kernel unless per-correspondence image weights multiply it afterwards (if_img_w).  ``dst``: rows of the per-layer
+        stacks the outputs are written into (ops.w8pt_forward), so that the loss functions find every layer's F, epipolar
+        residual and weights in one buffer each (no torch.stack copies, train_good_utils.get_all_loss_DeepF)."""
         H, W = float(self.image_size[0]), float(self.image_size[1])
         if self.if_img_w:
             weights_prod = F.softmax(logits, dim=2) * data_batch["weights_im"]
             return ops.w8pt_raw(matches, weights_prod, W, H, clamp_at=0.5, want_epi=want_epi) + (weights_prod,)
-        outs = ops.w8pt_raw_logits(matches, logits, W, H, clamp_at=0.5, want_epi=want_epi)
+        outs = ops.w8pt_raw_logits(matches, logits, W, H, clamp_at=0.5, want_epi=want_epi, dst=dst)
         return outs[:-1] + (outs[-1].unsqueeze(1),)
 
     def forward(self, data_batch):
@@ -143,8 +161,13 @@ class DeepFNet(nn.Module):
         out_layers, epi_res_layers, residual_layers = [], [], []
         weights_layers, logits_layers = [], [logits]
         offsets_accu = None
+        # one buffer per kind of per-layer output; each fit writes its row (the python lists below hold those rows)
+        B, N, dev = matches.shape[0], matches.shape[1], matches.device
+        stacks = {"F": torch.empty(self.depth, B, 3, 3, device=dev), "weights": torch.empty(self.depth, B, N, device=dev),
+                  "epi": torch.empty(max(self.depth - 1, 1), B, N, device=dev)}
+        dst = lambda l: {k: (v, l) for k, v in stacks.items() if k != "epi" or l < self.depth - 1}
         for it in range(self.depth - 1):
-            out, residual, epi, weights_prod = self._fit(matches, logits, data_batch, True)
+            out, residual, epi, weights_prod = self._fit(matches, logits, data_batch, True, dst(it))
             weights_layers.append(weights_prod)
             out_layers.append(out)
             residual_layers.append(residual)
@@ -157,7 +180,7 @@ class DeepFNet(nn.Module):
                 net_in = torch.cat((pts_normalized_in, weights_prod, epi_res, residual.unsqueeze(1)), 1)
             logits = self.update_weights(net_in)
             logits_layers.append(logits)
-        out, residual, weights_prod = self._fit(matches, logits, data_batch, False)
+        out, residual, weights_prod = self._fit(matches, logits, data_batch, False, dst(self.depth - 1))
         weights_layers.append(weights_prod)
         residual_layers.append(residual)
         out_layers.append(out)

@@ -19,25 +19,143 @@ def get_unique(xs, topk, matches_good_unique_nums):
     return torch.stack(out)
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# host-side metrics that do not force a device synchronisation
+# ---------------------------------------------------------------------------------------------------------------------------
+LAZY_HOST_METRICS = True  # False: get_Rt_loss copies the angular errors to the host at once (exactly the reference's types)
+
+
+class _Lazy:
+    """A value of get_Rt_loss's dict that lives on the host in the reference (numpy arrays / python floats of the angular
+    errors, train_good_utils.py:173-178,272-293) and is only *logged* there.  Here the device-to-host copy happens on first use:
+    the training step has no `.cpu()` synchronisation (and can be captured in a hipGraph); whoever reads the value -- np.asarray,
+    float(), indexing, arithmetic, attribute access -- gets the reference's numpy array / float, computed from the device
+    buffer as it is at that moment."""
+
+    __array_priority__ = 100.0
+
+    def __init__(self, compute):
+        self._compute = compute
+
+    def _v(self):
+        return self._compute()
+
+    def __array__(self, dtype=None, copy=None):
+        a = np.asarray(self._v())
+        return a.astype(dtype) if dtype is not None else a
+
+    def __getattr__(self, name):  # shape, mean(), flatten(), ... of the realised value
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return getattr(self._v(), name)
+
+    def __float__(self):
+        return float(self._v())
+
+    def __len__(self):
+        return len(self._v())
+
+    def __iter__(self):
+        return iter(self._v())
+
+    def __getitem__(self, k):
+        return self._v()[k]
+
+    def __repr__(self):
+        return repr(self._v())
+
+    def __format__(self, spec):
+        return format(self._v(), spec)
+
+    def __bool__(self):
+        return bool(self._v())
+
+
+for _name in ("add", "sub", "mul", "truediv", "floordiv", "pow", "mod", "lt", "le", "gt", "ge", "eq", "ne"):
+    def _make(n):
+        return lambda self, other: getattr(np.asarray(self._v()), f"__{n}__")(other._v() if isinstance(other, _Lazy) else other)
+    setattr(_Lazy, f"__{_name}__", _make(_name))
+for _name in ("add", "sub", "mul", "truediv", "pow"):
+    def _make_r(n):
+        return lambda self, other: getattr(np.asarray(self._v()), f"__r{n}__")(other)
+    setattr(_Lazy, f"__r{_name}__", _make_r(_name))
+_Lazy.__neg__ = lambda self: -np.asarray(self._v())
+_Lazy.__abs__ = lambda self: abs(np.asarray(self._v()))
+_Lazy.__hash__ = lambda self: id(self)
+import numbers as _numbers
+
+_numbers.Real.register(_Lazy)  # np.isscalar() / tensorboard's make_np accept the lazy python floats
+
+
+class _HostCopy:
+    """One device tensor, copied to the host (float64 numpy) at most once per content."""
+
+    def __init__(self, t):
+        self.t = t
+        self.cache = None
+
+    def get(self):
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.DfepeError("a host-side metric of get_Rt_loss was read while its stream is being captured into a graph")
+        if self.cache is None:
+            self.cache = self.t.detach().cpu().numpy().astype(np.float64)
+        return self.cache
+
+    def refresh(self):
+        """Forget the host copy (after a graph replay rewrote the device buffer in place)."""
+        self.cache = None
+
+
+_last_tail = {}  # the fused tail of the latest get_all_loss_DeepF call that was given the ground truth (loss_params["pose_gt"])
+
+
 def get_all_loss_DeepF(outs, pts1_virt_ori, pts2_virt_ori, Ks, loss_params, get_residual_summaries=True):
     """F-loss on the virtual correspondences for every layer + E-from-F.  Returns, like the reference (:511-519),
-    (losses_dict, E_ests, F_ests, logits_softmax, residual_norm_layers, residual_norm_max_layers, E_ests_layers)."""
+    (losses_dict, E_ests, F_ests, logits_softmax, residual_norm_layers, residual_norm_max_layers, E_ests_layers).
+
+    ONE kernel launch for all layers (plus three tiny reductions for the means); per-layer lists are rows of one buffer
+    (ops.stack_rows / unstack_rows: no torch.stack copies, no SelectBackward fills in the backward).  Two keys beyond the
+    reference's loss_params, both optional:
+      "pose_gt": (qs_cam, ts_cam, delta_Rtijs_4_4) -- the ground truth that the get_Rt_loss call right after this one will be
+                 given.  With it the pose errors are formed in the SAME launch (dfepe_loss_tail_jac) and get_Rt_loss finds
+                 them ready; without it get_Rt_loss launches the pose kernel itself.  Same numbers either way.
+      "floss_grad": False -- promise that no gradient will be asked of loss_F / loss_layers (an objective of the pose terms
+                 only, the reference's if_qt_loss, Train_model_pipeline.py:580-587): skips the F-loss adjoint work of the launch."""
     if loss_params.get("if_tri_depth", False) or loss_params.get("if_sample_loss", False):
         raise NotImplementedError("if_tri_depth / if_sample_loss are outside the built hot path (all shipped configs disable them)")
     logits_softmax = outs["weights"]
     F_est_normalized, T1, T2 = outs["F_est"], outs["T1"], outs["T2"]
     out_layers, residual_layers, weights_layers = outs["out_layers"], outs["residual_layers"], outs["weights_layers"]
     depth = loss_params["depth"]
-    F_layers = torch.stack(list(out_layers[:depth]))  # [L,B,3,3]
+    F_layers = ops.stack_rows(out_layers[:depth])  # [L,B,3,3]; no copy when DeepFNet.forward wrote the layers into one buffer
     M = pts1_virt_ori.shape[1]
     B = F_layers.shape[1]
-    loss_sum, E_layers = ops.floss(F_layers, T1, T2, Ks, pts1_virt_ori, pts2_virt_ori, loss_params["clamp_at"])
-    per_pair = loss_sum / float(M)  # losses.mean(dim=1) per layer  [L,B]
-    loss_layers = [per_pair[i].mean() for i in range(depth)]
-    loss_F_all = sum(loss_layers) / len(loss_layers)
-    E_ests_layers = [E_layers[i] for i in range(depth)]
-    F_ests = T2.permute(0, 2, 1) @ F_est_normalized @ T1
-    E_ests = Ks.transpose(1, 2) @ F_ests @ Ks
+    gt = loss_params.get("pose_gt")
+    _last_tail.clear()
+    if gt is not None and M <= 112:
+        q_gt, t_gt, delta = (torch.as_tensor(x).to(F_layers.device) for x in gt)
+        R_gt = ops.camera_rotation(delta)
+        loss_sum, E_layers, qt, q_l2, t_l2, ang, _sel = ops.loss_tail_jac(F_layers, T1, T2, Ks, pts1_virt_ori, pts2_virt_ori, loss_params["clamp_at"],
+                                                                         q_gt, t_gt, R_gt, floss_grad=loss_params.get("floss_grad", True))
+        _last_tail.update(E=E_layers, gt=tuple(x.data_ptr() for x in (q_gt, t_gt, delta)), qt=qt, q_l2=q_l2, t_l2=t_l2, ang=ang)
+    else:
+        # without the ground truth the pose part cannot ride along: the stand-alone F-loss kernel, whose adjoint takes the
+        # gradient w.r.t. the E matrices that get_Rt_loss's pose kernel sends back (any number M of virtual points)
+        loss_sum, E_layers = ops.floss(F_layers, T1, T2, Ks, pts1_virt_ori, pts2_virt_ori, loss_params["clamp_at"])
+    per_pair = loss_sum * (1.0 / float(M))  # losses.mean(dim=1) per layer  [L,B]
+    layer_means = per_pair.mean(dim=1)      # losses.mean() per layer (:343-354)
+    loss_layers = list(layer_means.unbind(0))
+    loss_F_all = layer_means.mean()         # sum(loss_layers) / len(loss_layers) (:364)
+    E_ests_layers = list(ops.unstack_rows(E_layers))
+    same_T = T1 is T2 or (T1.data_ptr() == T2.data_ptr() and T1.stride() == T2.stride() and T1.shape == T2.shape)
+    if same_T and T1.dim() == 3:
+        F_ests = ops.congruence_diff(F_est_normalized, T1.contiguous() if T1.stride(0) != 0 else T1.expand(B, 3, 3).contiguous())
+    else:
+        F_ests = T2.permute(0, 2, 1) @ F_est_normalized @ T1
+    if len(out_layers) >= depth and F_est_normalized is out_layers[depth - 1]:
+        E_ests = E_ests_layers[-1]  # K^T T2^T F_est T1 K is exactly the last layer's E (:356-358 vs :366-369)
+    else:
+        E_ests = ops.congruence_diff(F_ests, Ks)
     losses_dict = {
         "loss_layers": loss_layers,
         "loss_F": loss_F_all,
@@ -47,9 +165,13 @@ def get_all_loss_DeepF(outs, pts1_virt_ori, pts2_virt_ori, Ks, loss_params, get_
     loss_epi_res_all = 0.0
     loss_epi_res_layers = []
     if depth > 1:
-        for epi_res, weights in zip(outs["epi_res_layers"], outs["weights_layers"]):
-            loss_epi_res_layers.append((epi_res * weights).mean())
-        loss_epi_res_all = sum(loss_epi_res_layers) / len(loss_epi_res_layers)
+        n = min(len(outs["epi_res_layers"]), len(outs["weights_layers"]))  # zip() of the reference (:429-438)
+        if n > 0:
+            epi = ops.stack_rows(outs["epi_res_layers"][:n])
+            w = ops.stack_rows(outs["weights_layers"][:n])
+            means = (epi * w).flatten(1).mean(dim=1)
+            loss_epi_res_layers = list(means.unbind(0))
+            loss_epi_res_all = means.mean()
     losses_dict.update({"loss_epi_res_layers": loss_epi_res_layers, "loss_epi_res": loss_epi_res_all})
 
     residual_norm_layers, residual_norm_max_layers = None, None
@@ -80,36 +202,61 @@ def get_all_loss_DeepF(outs, pts1_virt_ori, pts2_virt_ori, Ks, loss_params, get_
 def get_Rt_loss(E_ests_layers, Ks_cpu, x1_cpu, x2_cpu, delta_Rtijs_4_4_cpu, qs_cam, ts_cam, device="cpu"):
     """Pose loss from the per-layer essential matrices and the ground-truth camera motion.  Same 12-key dict as the
     reference (:272-293).  NB the reference stacks the *translation* list under "q_l2_error_list" (:276); that slip
-    is reproduced so downstream logging sees identical values.  Ks/x1/x2 are unused, as in the reference."""
-    E_layers = torch.stack(list(E_ests_layers))  # [L,B,3,3]
+    is reproduced so downstream logging sees identical values.  Ks/x1/x2 are unused, as in the reference.
+
+    One launch for all layers and pairs (none when get_all_loss_DeepF was given "pose_gt" and these are its E matrices), one
+    reduction for all means; the per-layer lists are rows of one buffer each, so the caller's
+    clamp(stack(q_l2_error_layers_list)).mean() (Train_model_pipeline.py:580-586) costs its own three kernels and nothing
+    more, forward or backward.  The angular errors (host-side numpy / floats in the reference) are copied to the host when first
+    read (LAZY_HOST_METRICS), not here: no device synchronisation in the training step."""
+    E_layers = ops.stack_rows(list(E_ests_layers))  # [L,B,3,3]; the very buffer get_all_loss_DeepF filled when the rows are its own
     if not E_layers.is_cuda:
         raise _lib.DfepeError("get_Rt_loss: E_ests_layers must live on the GPU")
     dev = E_layers.device
-    delta = torch.as_tensor(delta_Rtijs_4_4_cpu).to(dev).float()
-    R_gt = torch.linalg.inv(delta)[:, :3, :3].contiguous()
-    q_l2, t_l2, R_deg, t_deg, _ = ops.pose_errors(E_layers, torch.as_tensor(qs_cam).to(dev), torch.as_tensor(ts_cam).to(dev), R_gt)
+    q_gt, t_gt = torch.as_tensor(qs_cam).to(dev), torch.as_tensor(ts_cam).to(dev)
+    delta = torch.as_tensor(delta_Rtijs_4_4_cpu).to(dev)
+    lt = _last_tail
+    if lt and lt["E"].data_ptr() == E_layers.data_ptr() and lt["E"].shape == E_layers.shape and lt["gt"] == tuple(x.data_ptr() for x in (q_gt, t_gt, delta)):
+        qt, q_l2, t_l2, ang = lt["qt"], lt["q_l2"], lt["t_l2"], lt["ang"]  # formed by the launch of get_all_loss_DeepF
+    else:
+        R_gt = ops.camera_rotation(delta)
+        qt, q_l2, t_l2, ang, _ = ops.pose_errors_packed(E_layers, q_gt, t_gt, R_gt)
     L = E_layers.shape[0]
-    R_np, t_np = R_deg.cpu().numpy().astype(np.float64), t_deg.cpu().numpy().astype(np.float64)
-    t_l2_layers = [t_l2[i] for i in range(L)]
-    q_l2_layers = [q_l2[i] for i in range(L)]
-    t_means = [x.mean() for x in t_l2_layers]
-    q_means = [x.mean() for x in q_l2_layers]
-    R_means = [float(R_np[i].mean()) for i in range(L)]
-    tA_means = [float(t_np[i].mean()) for i in range(L)]
-    return {
-        "t_l2_error_mean": mean_list(t_means),
-        "q_l2_error_mean": mean_list(q_means),
-        "t_l2_error_list": torch.stack(t_means),
-        "q_l2_error_list": torch.stack(t_means),  # sic: reference train_good_utils.py:276
-        "R_angle_error_mean": mean_list(R_means),
-        "R_angle_error_list": np.array(R_means),
-        "t_angle_error_mean": mean_list(tA_means),
-        "t_angle_error_list": np.array(tA_means),
-        "R_angle_error_layers_list": [R_np[i] for i in range(L)],
-        "t_angle_error_layers_list": [t_np[i] for i in range(L)],
+    t_l2_layers = list(ops.unstack_rows(t_l2))
+    q_l2_layers = list(ops.unstack_rows(q_l2))
+    layer_means = qt.mean(dim=2)    # [2,L]: x.mean() of every layer, q then t
+    overall = layer_means.mean(dim=1)  # mean_list over the layers
+    host = _HostCopy(ang)
+    R_layers = [_Lazy(lambda i=i: host.get()[0, i]) for i in range(L)]
+    t_layers = [_Lazy(lambda i=i: host.get()[1, i]) for i in range(L)]
+    R_list = _Lazy(lambda: np.array([float(host.get()[0, i].mean()) for i in range(L)]))
+    tA_list = _Lazy(lambda: np.array([float(host.get()[1, i].mean()) for i in range(L)]))
+    R_mean = _Lazy(lambda: mean_list([float(host.get()[0, i].mean()) for i in range(L)]))
+    tA_mean = _Lazy(lambda: mean_list([float(host.get()[1, i].mean()) for i in range(L)]))
+    out = {
+        "t_l2_error_mean": overall[1],
+        "q_l2_error_mean": overall[0],
+        "t_l2_error_list": layer_means[1],
+        "q_l2_error_list": layer_means[1],  # sic: reference train_good_utils.py:276
+        "R_angle_error_mean": R_mean,
+        "R_angle_error_list": R_list,
+        "t_angle_error_mean": tA_mean,
+        "t_angle_error_list": tA_list,
+        "R_angle_error_layers_list": R_layers,
+        "t_angle_error_layers_list": t_layers,
         "t_l2_error_layers_list": t_l2_layers,
         "q_l2_error_layers_list": q_l2_layers,
     }
+    if not LAZY_HOST_METRICS and not torch.cuda.is_current_stream_capturing():
+        for k in ("R_angle_error_mean", "t_angle_error_mean"):
+            out[k] = float(out[k]._v())
+        for k in ("R_angle_error_list", "t_angle_error_list"):
+            out[k] = np.asarray(out[k]._v())
+        for k in ("R_angle_error_layers_list", "t_angle_error_layers_list"):
+            out[k] = [np.asarray(x._v()) for x in out[k]]
+    else:
+        out["_host_metrics"] = host  # .refresh() after a graph replay rewrote the device buffer
+    return out
 
 
 _warned_opencv = False

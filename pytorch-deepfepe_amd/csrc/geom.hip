@@ -180,6 +180,31 @@ geo_misc_kernel(int kind, const float* __restrict__ in0, const float* __restrict
       for (int c = 0; c < 3; ++c) Ed[3 * r + c] = U[3 * r] * V[3 * c] + U[3 * r + 1] * V[3 * c + 1];
 #pragma unroll
     for (int k = 0; k < 9; ++k) out[i * 9 + k] = (float)Ed[k];
+  } else if (kind == 6) {
+    // camera-motion rotation of a scene motion: inv(delta)[:3,:3] for a general 4x4 (cofactors of the full matrix, so the
+    // last row need not be (0,0,0,1)); np.linalg.inv(delta_Rtij)[:3,:3] of get_Rt_loss, train_good_utils.py:134,170
+    double m[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m[k] = (double)in0[i * 16 + k];
+    // 2x2 minors of the lower two rows / upper two rows
+    const double s0 = m[0] * m[5] - m[4] * m[1], s1 = m[0] * m[6] - m[4] * m[2], s2 = m[0] * m[7] - m[4] * m[3];
+    const double s3 = m[1] * m[6] - m[5] * m[2], s4 = m[1] * m[7] - m[5] * m[3], s5 = m[2] * m[7] - m[6] * m[3];
+    const double c5 = m[10] * m[15] - m[14] * m[11], c4 = m[9] * m[15] - m[13] * m[11], c3 = m[9] * m[14] - m[13] * m[10];
+    const double c2 = m[8] * m[15] - m[12] * m[11], c1 = m[8] * m[14] - m[12] * m[10], c0 = m[8] * m[13] - m[12] * m[9];
+    const double det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+    const double id = 1.0 / det;
+    double r[9];
+    r[0] = (m[5] * c5 - m[6] * c4 + m[7] * c3) * id;
+    r[1] = (-m[1] * c5 + m[2] * c4 - m[3] * c3) * id;
+    r[2] = (m[13] * s5 - m[14] * s4 + m[15] * s3) * id;
+    r[3] = (-m[4] * c5 + m[6] * c2 - m[7] * c1) * id;
+    r[4] = (m[0] * c5 - m[2] * c2 + m[3] * c1) * id;
+    r[5] = (-m[12] * s5 + m[14] * s2 - m[15] * s1) * id;
+    r[6] = (m[4] * c4 - m[5] * c2 + m[7] * c0) * id;
+    r[7] = (-m[0] * c4 + m[1] * c2 - m[3] * c0) * id;
+    r[8] = (m[12] * s4 - m[13] * s2 + m[15] * s0) * id;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out[i * 9 + k] = (float)r[k];
   } else if (kind == 5) {
     double F[9], A[9], tmp[9], E[9];
 #pragma unroll
@@ -216,7 +241,42 @@ cheirality_kernel(const float* __restrict__ E, const float* __restrict__ pre, co
   (void)B;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// DeepFNet.get_input (DeepFNet.py:362-391) with NormalizeAndExpand_HW (:93-120): one thread per correspondence
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+deepf_input_kernel(const float4* __restrict__ matches, const float* __restrict__ quality, int B, int N, int Q, float sx, float sy,
+                   float* __restrict__ weight_in, int C_out, float* __restrict__ pts1, float* __restrict__ pts2) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)B * N) return;
+  const size_t b = idx / (size_t)N;
+  const int i = (int)(idx - b * (size_t)N);
+  const float4 m = matches[idx];
+  // the same arithmetic as the fit kernels' fused prologue (global_point<RAW>): T_HW (x, y, 1)
+  const float x1 = fmaf(m.x, sx, -1.0f), y1 = fmaf(m.y, sy, -1.0f), x2 = fmaf(m.z, sx, -1.0f), y2 = fmaf(m.w, sy, -1.0f);
+  if (pts1 != nullptr) { pts1[idx * 3] = x1; pts1[idx * 3 + 1] = y1; pts1[idx * 3 + 2] = 1.0f; }
+  if (pts2 != nullptr) { pts2[idx * 3] = x2; pts2[idx * 3 + 1] = y2; pts2[idx * 3 + 2] = 1.0f; }
+  if (weight_in == nullptr) return;
+  const float c0 = (x1 + 1.0f) * 0.5f, c1 = (y1 + 1.0f) * 0.5f, c2 = (x2 + 1.0f) * 0.5f, c3 = (y2 + 1.0f) * 0.5f;  // (:375-378)
+  float* w = weight_in + b * (size_t)C_out * N + i;
+  w[0] = c0; w[(size_t)N] = c1; w[2 * (size_t)N] = c2; w[3 * (size_t)N] = c3;
+  for (int q = 0; q < Q; ++q) w[(size_t)(4 + q) * N] = quality[idx * Q + q];
+}
+
 }  // namespace
+
+extern "C" int dfepe_deepf_input(const float* matches, const float* quality, int B, int N, int Q, float image_w, float image_h,
+                                 float* weight_in, int C_out, float* pts1, float* pts2, void* stream) {
+  if (B < 0 || N <= 0 || Q < 0 || !(image_w > 0.f) || !(image_h > 0.f)) return DFEPE_ERR_INVALID_ARG;
+  if (B == 0) return DFEPE_OK;
+  if (!matches || (Q > 0 && !quality) || (reinterpret_cast<uintptr_t>(matches) & 15u)) return DFEPE_ERR_INVALID_ARG;
+  if (weight_in && C_out < 4 + Q) return DFEPE_ERR_INVALID_ARG;
+  const size_t n = (size_t)B * N;
+  hipLaunchKernelGGL(deepf_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4*>(matches), quality, B, N, Q, 2.0f / image_w, 2.0f / image_h, weight_in, C_out,
+                     pts1, pts2);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
 
 extern "C" int dfepe_epi_residual_fwd(const float* pts1, const float* pts2, const float* F, int B, int N, float clamp_at,
                                       float* out, void* stream) {
@@ -250,7 +310,7 @@ extern "C" int dfepe_epi_metrics(int kind, const float* F, const float* X, const
 }
 
 extern "C" int dfepe_geo_misc(int kind, const float* in0, const float* in1, int n, float* out, void* stream) {
-  if (kind < 0 || kind > 5 || n < 0) return DFEPE_ERR_INVALID_ARG;
+  if (kind < 0 || kind > 6 || n < 0) return DFEPE_ERR_INVALID_ARG;
   if (n == 0) return DFEPE_OK;
   if (!in0 || !out || ((kind == 1 || kind == 2 || kind == 5) && !in1)) return DFEPE_ERR_INVALID_ARG;
   hipLaunchKernelGGL(geo_misc_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), kind, in0, in1, n, out);

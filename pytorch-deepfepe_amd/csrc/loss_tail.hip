@@ -19,7 +19,7 @@ static_assert(sizeof(TailHead) <= kTailDescBytes, "descriptor slot too small");
 // (In one row per pair, one part after the other, the kernel took 17 us.)
 // Leading scalar / pointer arguments: preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count, see w8pt16.hip); the
 // kernel reads them instead of the copies inside A.
-template <int IT>
+template <int IT, bool JAC = false>
 __global__ void __launch_bounds__(512)
 loss_tail_kernel(const float* F_layers, int L, int B, int M, int t_stride, const float* T1, const float* T2, const float* K,
                  const float* virt1, const TailArgs A0, double* __restrict__ partials, const TailHead Hd, const int write_desc) {
@@ -35,19 +35,22 @@ loss_tail_kernel(const float* F_layers, int L, int B, int M, int t_stride, const
     Hd.packed[threadIdx.x] = __longlong_as_double(0x7FF8000000000000LL);
     Hd.scalars[threadIdx.x] = __uint_as_float(0x7FC00000u);
   }
-  for (int e = (int)threadIdx.x; e < kPairsPerBlock * kTailParts; e += (int)blockDim.x) (&part[0][0])[e] = 0.0;
-  __syncthreads();
+  if (!JAC) {
+    for (int e = (int)threadIdx.x; e < kPairsPerBlock * kTailParts; e += (int)blockDim.x) (&part[0][0])[e] = 0.0;
+    __syncthreads();
+  }
   const bool floss_wave = threadIdx.x < 256u;  // uniform per wavefront
   const int row = (int)(threadIdx.x >> 4) & 15;
   if (floss_wave) {
-    if (pair0 + row < B) tail_floss_row<IT>(A, pair0 + row, lds[row], part[row], lds[row] + kTailMaxLayers * 9);
+    if (pair0 + row < B) tail_floss_row<IT, JAC>(A, pair0 + row, lds[row], part[row], lds[row] + kTailMaxLayers * 9);
   } else {
     const int item = (int)threadIdx.x - 256;  // layer-major: item = layer * 16 + pair-in-workgroup
     const int layer = item >> 4, prow = item & 15;
     if (layer < L && pair0 + prow < B)
-      tail_pose_item(A, pair0 + prow, layer, lds[prow] + 2 * kTailMaxLayers * 9 + layer * 9, &part[prow][kTailMaxLayers + layer],
-                     &part[prow][2 * kTailMaxLayers + layer]);
+      tail_pose_item<JAC>(A, pair0 + prow, layer, lds[prow] + 2 * kTailMaxLayers * 9 + layer * 9, &part[prow][kTailMaxLayers + layer],
+                          &part[prow][2 * kTailMaxLayers + layer]);
   }
+  if (JAC) return;  // the Jacobians went straight to memory: no meeting point, no batch sums
   __syncthreads();
   if (floss_wave && pair0 + row < B) tail_floss_finish(A, pair0 + row, lds[row] + kTailMaxLayers * 9, lds[row] + 2 * kTailMaxLayers * 9);
   // per-workgroup partial sums of the loss head, rows added in fixed order
@@ -77,6 +80,23 @@ __global__ void __launch_bounds__(192) loss_tail_head_desc_kernel(const TailHead
   __syncthreads();
   const TailHead H = *Hp;
   loss_head_run(H, (int)(threadIdx.x & 63u), (int)(threadIdx.x >> 6), &lds);
+}
+
+// d loss / dF of every (layer, pair) from the Jacobians of a dfepe_loss_tail_jac launch and whatever upstream gradients the
+// caller's own loss mixing produced: one thread per matrix entry.
+__global__ void __launch_bounds__(256)
+loss_tail_bwd_kernel(const float* __restrict__ J, size_t n_items, const float* __restrict__ g_ls, const float* __restrict__ g_q,
+                     const float* __restrict__ g_t, float* __restrict__ g_F) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_items * 9) return;
+  const size_t item = idx / 9;
+  const int c = (int)(idx - item * 9);
+  const float* j = J + item * 27 + c;
+  float g = 0.0f;
+  if (g_ls != nullptr) g = g_ls[item] * j[0];
+  if (g_q != nullptr) g = fmaf(g_q[item], j[9], g);
+  if (g_t != nullptr) g = fmaf(g_t[item], j[18], g);
+  g_F[idx] = g;
 }
 
 }  // namespace
@@ -115,7 +135,7 @@ extern "C" int dfepe_loss_tail(const float* F_layers, int L, int B, const float*
   A.coef_q = (float)((double)balance_q / ((double)L * grad_pairs));
   A.coef_t = (float)((double)balance_t / ((double)L * grad_pairs));
   A.loss_sum = loss_sum; A.E_layers = E_layers; A.q_l2 = q_l2; A.t_l2 = t_l2; A.R_deg = R_deg; A.t_deg = t_deg; A.sel = sel;
-  A.g_F = g_F_layers;
+  A.g_F = g_F_layers; A.J = nullptr;
   double* partials = reinterpret_cast<double*>(static_cast<char*>(workspace) + kTailDescBytes);
   // 4 F-loss wavefronts + one lane per (pair, layer): 16 L lanes, rounded up to wavefronts
   const dim3 grid((B + kPairsPerBlock - 1) / kPairsPerBlock), block(256 + 64 * ((kPairsPerBlock * L + 63) / 64));
@@ -132,5 +152,48 @@ extern "C" int dfepe_loss_tail(const float* F_layers, int L, int B, const float*
   else hipLaunchKernelGGL((loss_tail_kernel<8>), grid, block, 0, st, A.F_layers, A.L, A.B, A.M, A.t_stride, A.T1, A.T2, A.K, A.virt1, A, partials, H, wd);
   if (defer_head) return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;  // the first backward fit runs the head
   hipLaunchKernelGGL(loss_tail_head_kernel, dim3(1), dim3(192), 0, st, H);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+extern "C" int dfepe_loss_tail_jac(const float* F_layers, int L, int B, const float* T1, const float* T2, int t_stride,
+                                   const float* K, const float* virt1, const float* virt2, int M, float clamp_at,
+                                   const float* q_gt, const float* t_gt, const float* R_gt, int want_floss_jac, float* loss_sum,
+                                   float* E_layers, float* q_l2, float* t_l2, float* R_deg, float* t_deg, int* sel, float* J,
+                                   void* stream) {
+  if (L <= 0 || L > kTailMaxLayers || B <= 0 || M <= 0) return DFEPE_ERR_INVALID_ARG;
+  // dfepe_floss_fwd/bwd + dfepe_pose_fwd/bwd serve larger grids of virtual points (eight points per lane plus the Jacobian
+  // bookkeeping would not fit the 256 registers of this 512-thread workgroup without scratch)
+  if (M > 112) return DFEPE_ERR_UNSUPPORTED;
+  if (t_stride != 0 && t_stride != 9) return DFEPE_ERR_INVALID_ARG;
+  if (!F_layers || !T1 || !T2 || !K || !virt1 || !virt2 || !loss_sum || !E_layers || !J) return DFEPE_ERR_INVALID_ARG;
+  if (q_gt && (!t_gt || !q_l2 || !t_l2)) return DFEPE_ERR_INVALID_ARG;
+  if (R_deg && !R_gt) return DFEPE_ERR_INVALID_ARG;
+  TailArgs A;
+  A.F_layers = F_layers; A.L = L; A.B = B; A.M = M; A.t_stride = t_stride; A.T1 = T1; A.T2 = T2; A.K = K;
+  A.virt1 = virt1; A.virt2 = virt2; A.clamp_at = clamp_at; A.q_gt = q_gt; A.t_gt = t_gt; A.R_gt = R_gt;
+  A.clamp_q = 0.f; A.clamp_t = 0.f;
+  A.coef_F = want_floss_jac ? 1.0f : 0.0f; A.coef_q = 0.f; A.coef_t = 0.f;
+  A.loss_sum = loss_sum; A.E_layers = E_layers; A.q_l2 = q_l2; A.t_l2 = t_l2; A.R_deg = R_deg; A.t_deg = t_deg; A.sel = sel;
+  A.g_F = nullptr; A.J = J;
+  const dim3 grid((B + kPairsPerBlock - 1) / kPairsPerBlock), block(256 + 64 * ((kPairsPerBlock * L + 63) / 64));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  TailHead H = {};
+#define DFEPE_TAIL_JAC(IT_) hipLaunchKernelGGL((loss_tail_kernel<IT_, true>), grid, block, 0, st, A.F_layers, A.L, A.B, A.M, A.t_stride, A.T1, A.T2, A.K, A.virt1, A, nullptr, H, 0)
+  if (M <= 16) DFEPE_TAIL_JAC(1);
+  else if (M <= 32) DFEPE_TAIL_JAC(2);
+  else if (M <= 64) DFEPE_TAIL_JAC(4);
+  else DFEPE_TAIL_JAC(7);
+#undef DFEPE_TAIL_JAC
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+extern "C" int dfepe_loss_tail_bwd(const float* J, int L, int B, const float* g_loss_sum, const float* g_q_l2, const float* g_t_l2,
+                                   float* g_F_layers, void* stream) {
+  if (L <= 0 || B < 0) return DFEPE_ERR_INVALID_ARG;
+  if (B == 0) return DFEPE_OK;
+  if (!J || !g_F_layers) return DFEPE_ERR_INVALID_ARG;
+  const size_t n = (size_t)L * B;
+  hipLaunchKernelGGL(loss_tail_bwd_kernel, dim3((unsigned)((n * 9 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), J, n,
+                     g_loss_sum, g_q_l2, g_t_l2, g_F_layers);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }

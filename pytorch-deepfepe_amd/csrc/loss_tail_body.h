@@ -45,6 +45,7 @@ struct TailArgs {
   float* t_deg;
   int* sel;
   float* g_F;         // [L,B,9] or nullptr (forward only)
+  float* J;           // JAC instantiations only: [L,B,27] = d loss_sum / dF | d q_l2 / dF | d t_l2 / dF of every (layer, pair)
 };
 
 // Per-point epipolar terms in fp32 (the reference computes the F-loss in fp32, train_good_utils.py:340-342; utils_F.py:402-411)
@@ -77,6 +78,10 @@ __device__ __forceinline__ void tail_eval_point(const float* v, const double* T,
 // ---- the 3x3 part of ONE (pair, layer): E = K^T T2^T F T1 K, its pose errors and their adjoint ----------------------------
 // Plain single-lane code (no row primitives).  gpose: 9 floats, the pose part of d loss / d F of this (pair, layer);
 // part_q / part_t: where clamp(q_l2), clamp(t_l2) of this item go for the loss-head sums.
+// JAC: instead of the adjoint for the launch's own coefficients, the two Jacobians d q_l2 / dF and d t_l2 / dF (unclamped) go to
+// A.J[.., 9..26] -- the caller mixes clamps and balances itself (Train_model_pipeline.py:580-586) and dfepe_loss_tail_bwd applies
+// whatever upstream gradients arrive.
+template <bool JAC = false>
 __device__ __forceinline__ void tail_pose_item(const TailArgs& A, const int pair, const int layer, float* gpose, double* part_q,
                                                double* part_t) {
   const int B = A.B;
@@ -116,8 +121,17 @@ __device__ __forceinline__ void tail_pose_item(const TailArgs& A, const int pair
   mat3_mul(tmp, Cm, e);
   float Ef[9];
 #pragma unroll
-  for (int c = 0; c < 9; ++c) { Ef[c] = (float)e[c]; A.E_layers[lb * 9 + c] = Ef[c]; gpose[c] = 0.0f; }
-  if (!has_pose) return;
+  for (int c = 0; c < 9; ++c) {
+    Ef[c] = (float)e[c]; A.E_layers[lb * 9 + c] = Ef[c];
+    if (!JAC) gpose[c] = 0.0f;
+  }
+  if (!has_pose) {
+    if (JAC) {
+#pragma unroll
+      for (int c = 9; c < 27; ++c) A.J[lb * 27 + c] = 0.0f;
+    }
+    return;
+  }
   Pose P;
   pose_forward(Ef, qg, tg, P);  // on the fp32 E, like dfepe_pose_fwd on E_layers
   const double qe = P.qe[P.qi], te = P.te[P.ti];
@@ -126,6 +140,20 @@ __device__ __forceinline__ void tail_pose_item(const TailArgs& A, const int pair
   if (A.sel != nullptr) A.sel[lb] = P.qi | (P.ti << 1);
   if (A.R_deg != nullptr && A.R_gt != nullptr) A.R_deg[lb] = (float)pose_R_deg(P, Rg);
   if (A.t_deg != nullptr) A.t_deg[lb] = (float)pose_t_deg(P);
+  if (JAC) {
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      double gE[9], add[9];
+      pose_backward(P, qg, which == 0 ? 1.0 : 0.0, which == 0 ? 0.0 : 1.0, gE);
+#pragma unroll
+      for (int c = 0; c < 9; ++c) gE[c] = (double)(float)gE[c];  // like dfepe_pose_bwd's fp32 g_E
+      mat3_mul(Am, gE, tmp);
+      mat3_mul_nt(tmp, Cm, add);
+#pragma unroll
+      for (int c = 0; c < 9; ++c) A.J[lb * 27 + 9 + 9 * which + c] = (float)add[c];
+    }
+    return;
+  }
   *part_q = (double)fminf(fmaxf((float)qe, 0.0f), A.clamp_q);
   *part_t = (double)fminf(fmaxf((float)te, 0.0f), A.clamp_t);
   if (A.g_F != nullptr) {
@@ -149,7 +177,7 @@ __device__ __forceinline__ void tail_pose_item(const TailArgs& A, const int pair
 // gsum[ly] and writes loss_sum / part[ly].  Phase 2 (tail_floss_finish), after the pose items of this pair are done:
 // g_F = coef_F * gsum + gpose (lane c < 9 reads back what it wrote).
 // ldsF, gsum: kTailMaxLayers * 9 floats each, private to the row.
-template <int IT>
+template <int IT, bool JAC = false>
 __device__ __forceinline__ void tail_floss_row(const TailArgs& A, const int pair, float* ldsF, double* part, float* gsum) {
   const int l = rg_lane();
   const int L = A.L, B = A.B, M = A.M;
@@ -190,7 +218,8 @@ __device__ __forceinline__ void tail_floss_row(const TailArgs& A, const int pair
   rg_sync();
   // with balance_F = 0 (the reference's objective when if_qt_loss, Train_model_pipeline.py:580-587) the F-loss is evaluated but
   // carries no gradient: its adjoint (more than half of this function) is skipped
-  const bool grad = A.g_F != nullptr && A.coef_F != 0.0f;
+  // JAC: the gradient sums are the Jacobian d loss_sum / dF itself (A.J[.., 0..8]); coef_F == 0 there means "not wanted" (zeros)
+  const bool grad = (JAC || A.g_F != nullptr) && A.coef_F != 0.0f;
   // K layers at a time: the layers are independent of each other, and a lone wavefront on its SIMD (the F-loss wavefronts are the
   // critical path of this kernel, scripts/tail_time.py) needs the second instruction stream to fill the dependent-issue bubbles of
   // the first; it also halves the trips through the loop's scalar bookkeeping.
@@ -236,17 +265,18 @@ __device__ __forceinline__ void tail_floss_row(const TailArgs& A, const int pair
       const float acc = rg_sum(accf[k]);  // <= 128 terms of at most clamp_at each: fp32 like the reference's own sum
       if (l == 0) {
         A.loss_sum[(size_t)ly * B + pair] = acc;
-        part[ly] = (double)acc;
+        if (!JAC) part[ly] = (double)acc;
       }
+      float mine = 0.0f;
       if (grad) {
-        float mine = 0.0f;
 #pragma unroll
         for (int c = 0; c < 9; ++c) {
           const float tot = rg_sum(gof[k][c]);
           mine = (l == c) ? tot : mine;
         }
-        if (l < 9) gsum[ly * 9 + l] = mine;
+        if (!JAC && l < 9) gsum[ly * 9 + l] = mine;
       }
+      if (JAC && l < 9) A.J[((size_t)ly * B + pair) * 27 + l] = mine;
     }
   };
   int ly = 0;

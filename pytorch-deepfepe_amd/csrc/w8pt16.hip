@@ -238,8 +238,10 @@ void launch_bwd(const W8BwdArgs& A, hipStream_t st) {
 #undef DFEPE_BWD
 }
 
-// with the deferred loss head riding along (no point gradients in this variant: the caller falls back to a head launch)
-template <bool RAW>
+// with the deferred loss head riding along.  Built for the ONE shape that uses it: pixel matches and g_F only (the captured
+// solver-only step of pipeline.hot_path_fused; 250 registers at N = 100).  The 448-thread workgroup caps the launch at 256
+// registers, and the instantiations with pass A (g_residual / g_epi, the recurrent model's backward) or homogeneous points need
+// more (they spilled 24..208 bytes of scratch in round 3): those shapes take the plain launch plus a head launch of its own.
 void launch_bwd_head(const W8BwdArgs& A, hipStream_t st) {
   const dim3 grid((A.B + kPairsPerBlock - 1) / kPairsPerBlock), block(448);
   const int N = A.N;
@@ -247,22 +249,15 @@ void launch_bwd_head(const W8BwdArgs& A, hipStream_t st) {
   R.F_out = A.F_out; R.g_F = A.g_F; R.g_res = A.g_res; R.g_epi = A.g_epi; R.g_w_extra = A.g_w_extra; R.g_scale = A.g_scale;
   R.g_w = A.g_w; R.g_p1 = A.g_p1; R.g_p2 = A.g_p2; R.logits_mode = A.logits_mode; R.variant = 0u;
   const TailHead* head = static_cast<const TailHead*>(A.pending_head);
-#define DFEPE_BWDH(IT_, UP_)                                                                                              \
-  hipLaunchKernelGGL((w8pt16_bwd_head_kernel<IT_, RAW, UP_>), grid, block, 0, st, A.pts1, A.pts2, A.wts, A.B, A.Bm, A.N, A.hw_sx, \
+#define DFEPE_BWDH(IT_)                                                                                                    \
+  hipLaunchKernelGGL((w8pt16_bwd_head_kernel<IT_, true, false>), grid, block, 0, st, A.pts1, A.pts2, A.wts, A.B, A.Bm, A.N, A.hw_sx, \
                      A.hw_sy, A.clamp_at, A.save, R, head)
-  if (!A.g_res && !A.g_epi && !A.g_w_extra) {  // g_F only (the step of the benchmark): no pass A, fewer registers
-    if (N > 128) DFEPE_BWDH(0, false);
-    else if (N <= 16) DFEPE_BWDH(1, false);
-    else if (N <= 32) DFEPE_BWDH(2, false);
-    else if (N <= 64) DFEPE_BWDH(4, false);
-    else if (N <= 112) DFEPE_BWDH(7, false);
-    else DFEPE_BWDH(8, false);
-  } else if (N > 128) DFEPE_BWDH(0, true);
-  else if (N <= 16) DFEPE_BWDH(1, true);
-  else if (N <= 32) DFEPE_BWDH(2, true);
-  else if (N <= 64) DFEPE_BWDH(4, true);
-  else if (N <= 112) DFEPE_BWDH(7, true);
-  else DFEPE_BWDH(8, true);
+  if (N > 128) DFEPE_BWDH(0);
+  else if (N <= 16) DFEPE_BWDH(1);
+  else if (N <= 32) DFEPE_BWDH(2);
+  else if (N <= 64) DFEPE_BWDH(4);
+  else if (N <= 112) DFEPE_BWDH(7);
+  else DFEPE_BWDH(8);
 #undef DFEPE_BWDH
 }
 
@@ -286,8 +281,8 @@ int dfepe_w8pt16_bwd_launch(const W8BwdArgs& A, bool raw, hipStream_t st) {
     if (hipGetLastError() != hipSuccess) return DFEPE_ERR_HIP;
     return (A.pending_head != nullptr) ? dfepe_loss_head_from_workspace(A.pending_head, st) : DFEPE_OK;
   }
-  if (A.pending_head != nullptr && !pgrad && !use_coop(A.N, A.B, A.row_per_pair)) {
-    if (raw) launch_bwd_head<true>(A, st); else launch_bwd_head<false>(A, st);
+  if (A.pending_head != nullptr && raw && !pgrad && !A.g_res && !A.g_epi && !A.g_w_extra && !use_coop(A.N, A.B, A.row_per_pair)) {
+    launch_bwd_head(A, st);
     return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
   }
   if (raw) { if (pgrad) launch_bwd<true, true, true>(A, st); else launch_bwd<true, false, true>(A, st); }

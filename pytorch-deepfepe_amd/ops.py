@@ -40,6 +40,81 @@ def save_floats() -> int:
 
 
 # ------------------------------------------------------------------------------------------------
+# per-layer stacks without copies.  The reference's API speaks in python lists of per-layer tensors (out_layers,
+# E_ests_layers, q_l2_error_layers_list ...; DeepFNet.py:534-548, train_good_utils.py:272-293) and glues them with
+# torch.stack; the kernels want one [L, ...] buffer.  These helpers let both views share the memory: the rows of a stack are
+# handed out as separate autograd outputs (no SelectBackward that would zero-fill and copy a full stack per row in the
+# backward), and a list whose tensors turn out to be the rows of one buffer is re-assembled without a copy kernel.
+# ------------------------------------------------------------------------------------------------
+def row_of(stack: Tensor, l: int) -> Tensor:
+    """Row l of a contiguous [L, ...] buffer as a tensor of its own over the same memory (not an autograd view of it)."""
+    n = stack[0].numel()
+    t = torch.empty(0, dtype=stack.dtype, device=stack.device)
+    t.set_(stack.untyped_storage(), stack.storage_offset() + l * n, tuple(stack.shape[1:]), None)
+    return t
+
+
+def alias_rows(rows) -> Optional[Tensor]:
+    """[len(rows), *shape] tensor over the memory of ``rows`` when they are equally shaped contiguous tensors lying back to
+    back in one buffer, in order; None otherwise (the caller then copies)."""
+    if len(rows) == 0 or rows[0] is None:
+        return None
+    r0 = rows[0]
+    n = r0.numel()
+    if n == 0:
+        return None
+    base = r0.untyped_storage().data_ptr()
+    for l, r in enumerate(rows):
+        if (r is None or r.shape != r0.shape or r.dtype != r0.dtype or r.device != r0.device or not r.is_contiguous()
+                or r.untyped_storage().data_ptr() != base or r.storage_offset() != r0.storage_offset() + l * n):
+            return None
+    t = torch.empty(0, dtype=r0.dtype, device=r0.device)
+    t.set_(r0.untyped_storage(), r0.storage_offset(), (len(rows),) + tuple(r0.shape), None)
+    return t
+
+
+class _StackRowsFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *rows):
+        a = alias_rows(rows)
+        return torch.stack(rows) if a is None else a
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g.unbind(0))
+
+
+class _UnstackRowsFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.meta = (x.shape, x.dtype, x.device)
+        ctx.set_materialize_grads(False)
+        x = x if x.is_contiguous() else x.contiguous()
+        return tuple(row_of(x, l) for l in range(x.shape[0]))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        shape, dtype, dev = ctx.meta
+        if all(g is None for g in gs):
+            return None
+        a = alias_rows(gs)  # torch.stack's backward hands out the rows of one gradient buffer: taken as it is
+        if a is not None:
+            return a
+        return torch.stack([torch.zeros(shape[1:], dtype=dtype, device=dev) if g is None else g for g in gs])
+
+
+def stack_rows(rows) -> Tensor:
+    """torch.stack(rows) without the copy when the rows already are the consecutive slices of one buffer."""
+    rows = list(rows)
+    return _StackRowsFunction.apply(*rows)
+
+
+def unstack_rows(x: Tensor):
+    """The rows of x [L, ...] as a tuple of L tensors over x's memory, each an autograd output of its own."""
+    return _UnstackRowsFunction.apply(x)
+
+
+# ------------------------------------------------------------------------------------------------
 # weighted 8-point fit
 # ------------------------------------------------------------------------------------------------
 def _flags(raw: bool, logits: bool, row_per_pair: bool = False, extra: int = 0) -> int:
@@ -49,19 +124,32 @@ def _flags(raw: bool, logits: bool, row_per_pair: bool = False, extra: int = 0) 
 
 def w8pt_forward(pts1: Tensor, pts2: Optional[Tensor], weights: Tensor, raw: bool, image_w: float, image_h: float,
                  clamp_at: float, want_epi: bool, want_save: bool, logits: bool = False, F_out: Optional[Tensor] = None,
-                 row_per_pair: bool = False, extra_flags: int = 0):
+                 row_per_pair: bool = False, extra_flags: int = 0, dst: Optional[dict] = None):
     """Raw (non-differentiable) launch.  weights (or logits when ``logits``) [B,N].
     Returns F [B,3,3], residual [B,N], epi [B,N]|None, save|None, weights_out [B,N]|None.  ``F_out`` lets the caller
     provide the destination (e.g. one [B,3,3] slice of a per-layer stack).  ``row_per_pair`` forces one 16-lane row per pair
-    where a cooperative workgroup per pair (N > 128 at small batch) would run: same function, same ``save`` record."""
+    where a cooperative workgroup per pair (N > 128 at small batch) would run: same function, same ``save`` record.
+    ``dst``: {"F" | "residual" | "epi" | "weights": (stack, l)} writes that output into row l of the caller's per-layer stack."""
     L = _lib.lib()
     B, N = weights.shape
     dev = weights.device
-    F = torch.empty(B, 3, 3, device=dev, dtype=torch.float32) if F_out is None else F_out
-    residual = torch.empty(B, N, device=dev, dtype=torch.float32)
-    epi = torch.empty(B, N, device=dev, dtype=torch.float32) if want_epi else None
+    dst = dst or {}
+
+    def out(name, shape, want=True):
+        if not want:
+            return None
+        if name in dst:
+            stack, l = dst[name]
+            if tuple(stack.shape[1:]) != tuple(shape) or stack.dtype != torch.float32 or not stack.is_contiguous():
+                raise ValueError(f"dst[{name!r}] must be a contiguous float32 stack of {tuple(shape)} rows, got {tuple(stack.shape)}")
+            return row_of(stack, l)
+        return torch.empty(*shape, device=dev, dtype=torch.float32)
+
+    F = out("F", (B, 3, 3)) if F_out is None else F_out
+    residual = out("residual", (B, N))
+    epi = out("epi", (B, N), want_epi)
     save = torch.empty(B, L.dfepe_save_floats(), device=dev, dtype=torch.float32) if want_save else None
-    w_out = torch.empty(B, N, device=dev, dtype=torch.float32) if logits else None
+    w_out = out("weights", (B, N), logits)
     with torch.cuda.device(dev):
         rc = L.dfepe_w8pt_fwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, 1, _flags(raw, logits, row_per_pair, extra_flags), float(image_w),
                               float(image_h), float(clamp_at), _ptr(F), _ptr(residual), _ptr(epi), _ptr(save), _ptr(w_out), _stream())
@@ -136,10 +224,10 @@ def _cf(t: Optional[Tensor]) -> Optional[Tensor]:
 
 class _W8ptFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pts1, pts2, weights, raw, image_w, image_h, clamp_at, want_epi, logits, extra_flags=0):
+    def forward(ctx, pts1, pts2, weights, raw, image_w, image_h, clamp_at, want_epi, logits, extra_flags=0, dst=None):
         ctx.set_materialize_grads(False)  # unused outputs (e.g. the last layer's epi) must not cost a zero-fill
         F, residual, epi, save, w_out = w8pt_forward(pts1, pts2, weights, raw, image_w, image_h, clamp_at, want_epi,
-                                                     want_save=True, logits=logits, extra_flags=extra_flags)
+                                                     want_save=True, logits=logits, extra_flags=extra_flags, dst=dst)
         ctx.extra_flags = extra_flags
         ctx.save_for_backward(pts1, pts2 if pts2 is not None else pts1.new_empty(0), w_out if logits else weights, save, F)
         ctx.cfg = (raw, image_w, image_h, clamp_at, want_epi, logits)
@@ -158,15 +246,15 @@ class _W8ptFunction(torch.autograd.Function):
         gEpi = rest.pop(0) if want_epi else None
         gWout = rest.pop(0) if logits else None
         if gF is None and gRes is None and gEpi is None and gWout is None:
-            return (None,) * 10
+            return (None,) * 11
         want_pts = ctx.needs_input_grad[0] or (not raw and ctx.needs_input_grad[1])
         res = w8pt_backward(pts1, pts2 if pts2.numel() else None, weights, raw, image_w, image_h, clamp_at, save, F,
                             _cf(gF), _cf(gRes), _cf(gEpi), logits=logits, gW_extra=_cf(gWout), want_pts=want_pts,
                             extra_flags=ctx.extra_flags)
         if want_pts:
             gW, gP1, gP2 = res
-            return gP1, gP2, gW, None, None, None, None, None, None, None
-        return None, None, res, None, None, None, None, None, None, None
+            return gP1, gP2, gW, None, None, None, None, None, None, None, None
+        return None, None, res, None, None, None, None, None, None, None, None
 
 
 def w8pt(pts1: Tensor, pts2: Tensor, weights: Tensor, clamp_at: float = 0.5, want_epi: bool = False, normalize_rows: bool = True):
@@ -193,13 +281,14 @@ def w8pt_raw(matches: Tensor, weights: Tensor, image_w: float, image_h: float, c
 
 
 def w8pt_raw_logits(matches: Tensor, logits: Tensor, image_w: float, image_h: float, clamp_at: float = 0.5,
-                    want_epi: bool = True):
+                    want_epi: bool = True, dst: Optional[dict] = None):
     """As w8pt_raw but takes the estimator's logits and fuses F.softmax(dim=N); additionally returns the weights
-    (differentiable: the next estimator layer consumes them).  Returns (F, residual[, epi], weights)."""
+    (differentiable: the next estimator layer consumes them).  Returns (F, residual[, epi], weights).
+    ``dst`` (see w8pt_forward): rows of the caller's per-layer stacks to write the outputs into."""
     m = _prep(matches, "matches")
     l = _prep(logits.reshape(logits.shape[0], -1), "logits")
     _shape(m, "matches (pixel x1,y1,x2,y2)", l.shape[0], l.shape[1], 4)
-    return _W8ptFunction.apply(m, None, l, True, float(image_w), float(image_h), clamp_at, want_epi, True)
+    return _W8ptFunction.apply(m, None, l, True, float(image_w), float(image_h), clamp_at, want_epi, True, 0, dst)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -268,30 +357,44 @@ def floss(F_layers: Tensor, T1: Tensor, T2: Tensor, K: Tensor, virt1: Tensor, vi
 # ------------------------------------------------------------------------------------------------
 # pose loss
 # ------------------------------------------------------------------------------------------------
+def _sum_opt(a: Optional[Tensor], b: Optional[Tensor]) -> Optional[Tensor]:
+    if a is None:
+        return b
+    return a if b is None else a + b
+
+
 class _PoseFunction(torch.autograd.Function):
+    """Outputs: qt [2,L,B] (q_l2 | t_l2 in one buffer, so that one reduction serves both), its two halves q_l2, t_l2 [L,B] as
+    outputs of their own over the same memory, ang [2,L,B] = R_deg | t_deg and sel [L,B] (not differentiable)."""
+
     @staticmethod
     def forward(ctx, E_layers, q_gt, t_gt, R_gt):
         lib = _lib.lib()
         L, B = E_layers.shape[0], E_layers.shape[1]
         dev = E_layers.device
-        q_l2 = torch.empty(L, B, device=dev, dtype=torch.float32)
-        t_l2 = torch.empty(L, B, device=dev, dtype=torch.float32)
-        R_deg = torch.empty(L, B, device=dev, dtype=torch.float32)
-        t_deg = torch.empty(L, B, device=dev, dtype=torch.float32)
+        ctx.set_materialize_grads(False)
+        qt = torch.empty(2, L, B, device=dev, dtype=torch.float32)
+        ang = torch.empty(2, L, B, device=dev, dtype=torch.float32)
         sel = torch.empty(L, B, device=dev, dtype=torch.int32)
+        q_l2, t_l2 = row_of(qt, 0), row_of(qt, 1)
         with torch.cuda.device(dev):
             rc = lib.dfepe_pose_fwd(_ptr(E_layers), L, B, _ptr(q_gt), _ptr(t_gt), _ptr(R_gt), _ptr(q_l2), _ptr(t_l2),
-                                    _ptr(R_deg), _ptr(t_deg), _ptr(sel), _stream())
+                                    _ptr(ang[0]), _ptr(ang[1]), _ptr(sel), _stream())
         _lib.check(rc, "dfepe_pose_fwd")
         ctx.save_for_backward(E_layers, q_gt, t_gt)
-        ctx.mark_non_differentiable(R_deg, t_deg, sel)
-        return q_l2, t_l2, R_deg, t_deg, sel
+        ctx.mark_non_differentiable(ang, sel)
+        return qt, q_l2, t_l2, ang, sel
 
     @staticmethod
-    def backward(ctx, g_q, g_t, _a, _b, _c):
+    def backward(ctx, g_qt, g_q, g_t, _a, _b):
         E_layers, q_gt, t_gt = ctx.saved_tensors
         lib = _lib.lib()
         L, B = E_layers.shape[0], E_layers.shape[1]
+        if g_qt is not None:
+            g_qt = g_qt.contiguous().float()
+            g_q, g_t = _sum_opt(g_q, g_qt[0]), _sum_opt(g_t, g_qt[1])
+        if g_q is None and g_t is None:
+            return None, None, None, None
         gE = torch.empty_like(E_layers)
         g_q = None if g_q is None else g_q.contiguous().float()
         g_t = None if g_t is None else g_t.contiguous().float()
@@ -302,15 +405,117 @@ class _PoseFunction(torch.autograd.Function):
         return gE, None, None, None
 
 
-def pose_errors(E_layers: Tensor, q_gt: Tensor, t_gt: Tensor, R_gt: Tensor):
-    """E_layers [L,B,3,3]; q_gt [B,4(,1)], t_gt [B,3(,1)], R_gt [B,3,3] (camera motion).
-    Returns q_l2, t_l2 (differentiable w.r.t. E), R_deg, t_deg, sel — all [L,B]."""
+def _pose_args(E_layers: Tensor, q_gt: Tensor, t_gt: Tensor, R_gt: Tensor):
     _shape(E_layers, "E_layers", None, None, 3, 3)
     B = E_layers.shape[1]
     if q_gt.numel() != 4 * B or t_gt.numel() != 3 * B or R_gt.numel() != 9 * B:
         raise ValueError(f"q_gt / t_gt / R_gt must hold {B} quaternions / translations / rotations, got {tuple(q_gt.shape)}, {tuple(t_gt.shape)}, {tuple(R_gt.shape)}")
-    return _PoseFunction.apply(_prep(E_layers, "E_layers"), _prep(q_gt.reshape(B, 4), "q_gt"),
-                               _prep(t_gt.reshape(B, 3), "t_gt"), _prep(R_gt.reshape(B, 3, 3), "R_gt"))
+    return _prep(E_layers, "E_layers"), _prep(q_gt.reshape(B, 4), "q_gt"), _prep(t_gt.reshape(B, 3), "t_gt"), _prep(R_gt.reshape(B, 3, 3), "R_gt")
+
+
+def pose_errors(E_layers: Tensor, q_gt: Tensor, t_gt: Tensor, R_gt: Tensor):
+    """E_layers [L,B,3,3]; q_gt [B,4(,1)], t_gt [B,3(,1)], R_gt [B,3,3] (camera motion).
+    Returns q_l2, t_l2 (differentiable w.r.t. E), R_deg, t_deg, sel — all [L,B]."""
+    _, q_l2, t_l2, ang, sel = _PoseFunction.apply(*_pose_args(E_layers, q_gt, t_gt, R_gt))
+    return q_l2, t_l2, ang[0], ang[1], sel
+
+
+def pose_errors_packed(E_layers: Tensor, q_gt: Tensor, t_gt: Tensor, R_gt: Tensor):
+    """As pose_errors, returning the buffers the kernel filled: (qt [2,L,B] = q_l2 | t_l2, q_l2, t_l2, ang [2,L,B] = R_deg | t_deg,
+    sel); qt, q_l2 and t_l2 are differentiable and share memory."""
+    return _PoseFunction.apply(*_pose_args(E_layers, q_gt, t_gt, R_gt))
+
+
+class _TailJacFunction(torch.autograd.Function):
+    """get_all_loss_DeepF's per-layer body and get_Rt_loss's loop as ONE launch (dfepe_loss_tail_jac) with a one-launch adjoint
+    for whatever upstream gradients arrive (dfepe_loss_tail_bwd): the reference's callers mix clamps and balances themselves
+    (Train_model_pipeline.py:580-586), so no coefficient is baked in.  Outputs: loss_sum [L,B], E_layers [L,B,3,3], and -- with
+    ground truth -- qt [2,L,B], q_l2, t_l2, ang [2,L,B], sel as in _PoseFunction."""
+
+    @staticmethod
+    def forward(ctx, F_layers, T1c, T2c, t_stride, K, virt1, virt2, clamp_at, q_gt, t_gt, R_gt, want_floss_jac):
+        lib = _lib.lib()
+        L, B = F_layers.shape[0], F_layers.shape[1]
+        M = virt1.shape[1]
+        dev = F_layers.device
+        ctx.set_materialize_grads(False)
+        loss_sum = torch.empty(L, B, device=dev, dtype=torch.float32)
+        E_layers = torch.empty(L, B, 3, 3, device=dev, dtype=torch.float32)
+        J = torch.empty(L, B, 27, device=dev, dtype=torch.float32)
+        pose = q_gt is not None
+        qt = torch.empty(2, L, B, device=dev, dtype=torch.float32) if pose else None
+        ang = torch.empty(2, L, B, device=dev, dtype=torch.float32) if pose else None
+        sel = torch.empty(L, B, device=dev, dtype=torch.int32) if pose else None
+        q_l2 = row_of(qt, 0) if pose else None
+        t_l2 = row_of(qt, 1) if pose else None
+        with torch.cuda.device(dev):
+            rc = lib.dfepe_loss_tail_jac(_ptr(F_layers), L, B, _ptr(T1c), _ptr(T2c), t_stride, _ptr(K), _ptr(virt1), _ptr(virt2), M,
+                                         float(clamp_at), _ptr(q_gt), _ptr(t_gt), _ptr(R_gt), 1 if want_floss_jac else 0, _ptr(loss_sum),
+                                         _ptr(E_layers), _ptr(q_l2), _ptr(t_l2), _ptr(ang[0]) if pose else None,
+                                         _ptr(ang[1]) if pose else None, _ptr(sel), _ptr(J), _stream())
+        _lib.check(rc, "dfepe_loss_tail_jac")
+        ctx.save_for_backward(J, F_layers, T1c, T2c, K, virt1, virt2)
+        ctx.cfg = (t_stride, float(clamp_at), bool(want_floss_jac))
+        if pose:
+            ctx.mark_non_differentiable(ang, sel)
+            return loss_sum, E_layers, qt, q_l2, t_l2, ang, sel
+        return loss_sum, E_layers
+
+    @staticmethod
+    def backward(ctx, g_loss_sum, g_E, g_qt=None, g_q=None, g_t=None, _a=None, _b=None):
+        J, F_layers, T1c, T2c, K, virt1, virt2 = ctx.saved_tensors
+        t_stride, clamp_at, want_floss_jac = ctx.cfg
+        lib = _lib.lib()
+        L, B = J.shape[0], J.shape[1]
+        if g_qt is not None:
+            g_qt = g_qt.contiguous().float()
+            g_q, g_t = _sum_opt(g_q, g_qt[0]), _sum_opt(g_t, g_qt[1])
+        if g_loss_sum is None and g_E is None and g_q is None and g_t is None:
+            return (None,) * 12
+        if g_loss_sum is not None and not want_floss_jac:
+            raise _lib.DfepeError("the F-loss Jacobian was switched off for this call (loss_params['floss_grad'] = False) but a gradient "
+                                  "arrived on loss_F / loss_layers")
+        c = lambda g: None if g is None else g.contiguous().float()
+        g_loss_sum, g_q, g_t = c(g_loss_sum), c(g_q), c(g_t)
+        gF = torch.empty(L, B, 3, 3, device=J.device, dtype=torch.float32)
+        with torch.cuda.device(J.device):
+            rc = lib.dfepe_loss_tail_bwd(_ptr(J), L, B, _ptr(g_loss_sum), _ptr(g_q), _ptr(g_t), _ptr(gF), _stream())
+            _lib.check(rc, "dfepe_loss_tail_bwd")
+            if g_E is not None:  # a gradient on the E matrices themselves (none of the reference's losses has one): the stand-alone adjoint
+                gF2 = torch.empty_like(gF)
+                rc = lib.dfepe_floss_bwd(_ptr(F_layers), L, B, _ptr(T1c), _ptr(T2c), t_stride, _ptr(K), _ptr(virt1), _ptr(virt2),
+                                         virt1.shape[1], clamp_at, None, 0.0, None, _ptr(c(g_E)), _ptr(gF2), _stream())
+                _lib.check(rc, "dfepe_floss_bwd")
+                gF = gF + gF2
+        return (gF,) + (None,) * 11
+
+
+def _floss_args(F_layers, T1, T2, K, virt1, virt2):
+    F_layers, K, virt1, virt2 = _prep(F_layers, "F_layers"), _prep(K, "K"), _prep(virt1, "virt1"), _prep(virt2, "virt2")
+    _shape(F_layers, "F_layers", None, None, 3, 3)
+    B = F_layers.shape[1]
+    _shape(K, "K (one intrinsic matrix per pair)", B, 3, 3)
+    _shape(virt1, "virt1 (homogeneous pixel points)", B, None, 3)
+    _shape(virt2, "virt2", B, virt1.shape[1], 3)
+    for T in (T1, T2):
+        if not ((T.dim() == 2 and tuple(T.shape) == (3, 3)) or (T.dim() == 3 and T.shape[0] in (1, B) and tuple(T.shape[1:]) == (3, 3))):
+            raise ValueError(f"T1/T2 must be [3,3], [1,3,3] or [{B},3,3], got {tuple(T.shape)}")
+    T1c, st1 = _t_arg(T1, B)
+    T2c, st2 = _t_arg(T2, B)
+    if st1 != st2:
+        T1c, T2c, st1 = T1c.expand(B, 3, 3).contiguous(), T2c.expand(B, 3, 3).contiguous(), 9
+    return F_layers, T1c, T2c, st1, K, virt1, virt2
+
+
+def loss_tail_jac(F_layers: Tensor, T1: Tensor, T2: Tensor, K: Tensor, virt1: Tensor, virt2: Tensor, clamp_at: float,
+                  q_gt: Optional[Tensor] = None, t_gt: Optional[Tensor] = None, R_gt: Optional[Tensor] = None, floss_grad: bool = True):
+    """F-loss sums + E-from-F (+ pose errors when the ground truth is given) of every layer in one launch, differentiable for any
+    upstream gradients.  Returns (loss_sum, E_layers) or (loss_sum, E_layers, qt, q_l2, t_l2, ang, sel) (see _TailJacFunction).
+    Needs M <= 112 virtual points (raises DfepeError 'unsupported' otherwise: use floss + pose_errors)."""
+    F_layers, T1c, T2c, st, K, virt1, virt2 = _floss_args(F_layers, T1, T2, K, virt1, virt2)
+    if q_gt is not None:
+        _, q_gt, t_gt, R_gt = _pose_args(F_layers, q_gt, t_gt, R_gt)
+    return _TailJacFunction.apply(F_layers, T1c, T2c, st, K, virt1, virt2, float(clamp_at), q_gt, t_gt, R_gt, bool(floss_grad))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -365,7 +570,7 @@ def epi_metrics(kind: int, F: Tensor, X: Tensor, Y: Tensor, clamp_at: Optional[f
     return out
 
 
-_GEO_OUT = {0: 4, 1: 1, 2: 1, 3: 9, 4: 21, 5: 9}
+_GEO_OUT = {0: 4, 1: 1, 2: 1, 3: 9, 4: 21, 5: 9, 6: 9}
 
 
 def geo_misc(kind: int, in0: Tensor, in1: Optional[Tensor] = None) -> Tensor:
@@ -398,6 +603,53 @@ def project_essential(E: Tensor) -> Tensor:
 def congruence(F: Tensor, A: Tensor) -> Tensor:
     """A^T F A for batches of 3x3 matrices: E = K^T T^T F T K with A = T K (train_good_utils.py:356-358), or K^T F K."""
     return geo_misc(5, F.reshape(-1, 9), A.reshape(-1, 9)).reshape(-1, 3, 3)
+
+
+class _CongruenceFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, F, A):
+        ctx.save_for_backward(A)
+        return geo_misc(5, F.reshape(-1, 9), A.reshape(-1, 9)).reshape(-1, 3, 3)
+
+    @staticmethod
+    def backward(ctx, g):
+        A, = ctx.saved_tensors
+        return geo_misc(5, g.reshape(-1, 9), A.transpose(1, 2).reshape(-1, 9)).reshape(-1, 3, 3), None  # A g A^T
+
+
+def congruence_diff(F: Tensor, A: Tensor) -> Tensor:
+    """A^T F A like congruence, differentiable w.r.t. F (F_ests = T^T F_est T of get_all_loss_DeepF, train_good_utils.py:366)."""
+    return _CongruenceFunction.apply(_prep(F, "F"), _prep(A, "A"))
+
+
+def camera_rotation(delta_4x4: Tensor) -> Tensor:
+    """inv(delta)[:, :3, :3] for scene motions delta [B,4,4]: the ground-truth camera rotation of get_Rt_loss
+    (train_good_utils.py:134,170), one launch, no LAPACK round trip / host synchronisation."""
+    d = _prep(delta_4x4, "delta_Rtijs_4_4")
+    _shape(d, "delta_Rtijs_4_4", None, 4, 4)
+    return geo_misc(6, d.reshape(-1, 16)).reshape(-1, 3, 3)
+
+
+def deepf_input(matches: Tensor, image_w: float, image_h: float, quality: Optional[Tensor] = None, want_pts: bool = True):
+    """DeepFNet.get_input in one launch (DeepFNet.py:362-391): matches [B,N,4] pixels (+ quality [B,N,Q]) ->
+    (weight_in [B,4+Q,N], pts1 [B,N,3], pts2 [B,N,3]); not differentiable (the matches are data)."""
+    m = _prep(matches, "matches")
+    _shape(m, "matches (pixel x1,y1,x2,y2)", None, None, 4)
+    B, N = m.shape[0], m.shape[1]
+    Q = 0
+    if quality is not None:
+        quality = _prep(quality, "quality")
+        _shape(quality, "quality", B, N, None)
+        Q = quality.shape[2]
+    dev = m.device
+    w_in = torch.empty(B, 4 + Q, N, device=dev, dtype=torch.float32)
+    p1 = torch.empty(B, N, 3, device=dev, dtype=torch.float32) if want_pts else None
+    p2 = torch.empty(B, N, 3, device=dev, dtype=torch.float32) if want_pts else None
+    with torch.cuda.device(dev):
+        rc = _lib.lib().dfepe_deepf_input(_ptr(m), _ptr(quality), B, N, Q, float(image_w), float(image_h), _ptr(w_in), 4 + Q, _ptr(p1), _ptr(p2),
+                                          _stream())
+    _lib.check(rc, "dfepe_deepf_input")
+    return w_in, p1, p2
 
 
 def decompose_essential(E: Tensor):

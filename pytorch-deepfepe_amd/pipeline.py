@@ -250,3 +250,86 @@ def hot_path_step(scene: Dict[str, Tensor], image_size: Sequence[int], depth: in
         out["loss"].backward()
         out["grad_logits"] = logits.grad
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# the same step through the reference's OWN call sequence (what train_good.py's agent runs, Train_model_pipeline.py:495-595):
+#     outs = net(data_batch); get_all_loss_DeepF(outs, ...); get_Rt_loss(E_ests_layers, ...); caller-side clamp / balance; backward
+# with the weight estimator replaced by given per-layer logits, so that what is measured / compared is the solver path behind
+# that API and nothing else.  bench.py times it next to hot_path_fused ("api_path"), tests/test_api_path_gpu.py requires the two
+# to agree.
+# ------------------------------------------------------------------------------------------------------------------------
+class FixedLogitsEstimator(torch.nn.Module):
+    """Stand-in for compat.ErrorEstimators.ErrorEstimator: call k returns rows[k mod len(rows)] ([B,1,N] logits) whatever its input."""
+
+    def __init__(self, rows):
+        super().__init__()
+        self.rows = list(rows)
+        self.k = 0
+
+    def forward(self, data):
+        r = self.rows[self.k % len(self.rows)]
+        self.k += 1
+        return r
+
+
+class LinearProbeEstimator(FixedLogitsEstimator):
+    """Given logits plus a fixed linear read-out of the three recurrent input channels (weights, in-loop epipolar residual,
+    residual: channels 4..6 of update_weights' input, DeepFNet.py:484-489).  Not a model of anything -- the cheapest estimator
+    through which gradients reach residual / epi_res / weights of the previous fit, i.e. one that makes every layer but the last
+    run the backward the real recurrent model runs (w8pt_bwd with g_residual, g_epi and the weights gradient)."""
+
+    def __init__(self, rows, coef=(0.5, -2.0, 40.0)):
+        super().__init__(rows)
+        self.coef = tuple(float(c) for c in coef)
+
+    def forward(self, data):
+        base = super().forward(data)
+        if getattr(self, "_c", None) is None or self._c.device != data.device:  # one host copy, on the first (eager) call
+            self._c = data.new_tensor(self.coef).view(1, 3, 1)
+        return base + (data[:, 4:7, :] * self._c).sum(dim=1, keepdim=True)
+
+
+def make_api_net(depth: int, image_size: Sequence[int], logits_rows: Sequence[Tensor], recurrent_probe: bool = False):
+    """compat.DeepFNet whose two estimators hand out ``logits_rows`` (depth tensors [B,1,N]; leaves that require grad give
+    d loss / d logits): layer 0 from input_weights, layers 1.. from the successive update_weights calls (DeepFNet.py:441,510).
+    ``recurrent_probe``: update_weights is a LinearProbeEstimator, so the step has the recurrent model's backward shape."""
+    from .compat.DeepFNet import DeepFNet
+
+    net = DeepFNet(depth=depth, image_size=image_size, if_quality=False)
+    net.input_weights = FixedLogitsEstimator(logits_rows[:1])
+    net.update_weights = (LinearProbeEstimator if recurrent_probe else FixedLogitsEstimator)(logits_rows[1:] if depth > 1 else logits_rows[:1])
+    return net
+
+
+def reference_call_sequence(net, scene: Dict[str, Tensor], depth: int, clamp_at: float = 0.02, clamp_q: float = 0.1, clamp_t: float = 0.5,
+                            balance_q: float = 1.0, balance_t: float = 0.1, balance_F: float = 1.0, pose_gt_in_loss_params: bool = False,
+                            get_residual_summaries: bool = False):
+    """One forward of the reference's training step (Train_model_pipeline.py:495-586) on a synth.make_scene batch that lives on
+    the GPU.  Returns (loss, outs, losses_dict, geo_errors_dict).  ``balance_F = 0`` is the reference's if_qt_loss objective
+    (the F-loss evaluated, not added, :587).  ``pose_gt_in_loss_params``: hand the ground truth to get_all_loss_DeepF as well
+    (loss_params["pose_gt"]), which fuses the pose errors into its launch."""
+    from .compat import train_good_utils as tgu
+
+    batch = {"matches_xy_ori": scene["matches_xy_ori"], "matches_good_unique_nums": None, "t_scene_scale": None}
+    loss_params = {"model": "GoodCorresNet_layers_deepF", "clamp_at": clamp_at, "depth": depth, "good_num": scene["matches_xy_ori"].shape[1],
+                   "if_img_feat": False, "matches_good_unique_nums": None, "topK": 8, "if_sample_loss": False, "if_tri_depth": False}
+    if pose_gt_in_loss_params:
+        loss_params["pose_gt"] = (scene["qs_cam"], scene["ts_cam"], scene["delta_Rtijs_4_4"])
+        if balance_F == 0.0:
+            loss_params["floss_grad"] = False
+    for est in (net.input_weights, net.update_weights):
+        if isinstance(est, FixedLogitsEstimator):
+            est.k = 0
+    outs = net(batch)
+    losses_dict, E_ests, F_ests, logits_weights, _, _, E_ests_layers = tgu.get_all_loss_DeepF(
+        outs, scene["pts1_virt_ori"], scene["pts2_virt_ori"], scene["Ks"], loss_params, get_residual_summaries=get_residual_summaries)
+    geo = tgu.get_Rt_loss(E_ests_layers, scene["Ks"], None, None, scene["delta_Rtijs_4_4"], scene["qs_cam"], scene["ts_cam"],
+                          device=scene["matches_xy_ori"].device)
+    # the caller's own lines (Train_model_pipeline.py:580-586)
+    loss_q = torch.clamp(torch.stack(geo["q_l2_error_layers_list"]), 0.0, clamp_q).mean()
+    loss_t = torch.clamp(torch.stack(geo["t_l2_error_layers_list"]), 0.0, clamp_t).mean()
+    loss = loss_q * balance_q + loss_t * balance_t
+    if balance_F != 0.0:
+        loss = loss + losses_dict["loss_F"] * balance_F
+    return loss, outs, losses_dict, geo

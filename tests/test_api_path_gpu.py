@@ -1,0 +1,218 @@
+"""The fast step behind the reference's OWN call sequence:
+    outs = net(data_batch) -> get_all_loss_DeepF -> get_Rt_loss -> the caller's clamp / balance mix -> backward
+(Train_model_pipeline.py:495-595) must be the same computation as pipeline.hot_path_fused -- the entry point bench.py times and
+the full-size oracle tests pin -- on the same inputs, at the benchmark's size, with and without the ground truth handed to
+get_all_loss_DeepF (one fused launch vs. the two stand-alone kernels), eager and captured in a hipGraph; the per-kernel pieces
+that path is made of against plain torch; and the backward the recurrent model runs (g_residual / g_epi on every layer but the
+last) against the fp64 oracle at the benchmark's size.  GPU box only."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+IMAGE_SIZE = [376, 1241, 3]
+DEV = "cuda:0"
+
+
+def _leaves(scene, L):
+    return [scene["logits_layers"][l].detach().clone().unsqueeze(1).requires_grad_(True) for l in range(L)]
+
+
+def _api(dfepe, d, L, gt_in, balance_F=1.0, rows=None):
+    rows = _leaves(d, L) if rows is None else rows
+    net = dfepe.pipeline.make_api_net(L, IMAGE_SIZE, rows)
+    loss, outs, losses, geo = dfepe.pipeline.reference_call_sequence(net, d, L, balance_F=balance_F, pose_gt_in_loss_params=gt_in)
+    grads = torch.autograd.grad(loss, rows)
+    return loss, outs, losses, geo, torch.stack([g.squeeze(1) for g in grads])
+
+
+@pytest.mark.parametrize("B,balance_F", [(4096, 1.0), (4096, 0.0), (37, 1.0)])
+def test_reference_call_sequence_equals_the_fused_step(dfepe, B, balance_F):
+    """Same scene through compat.DeepFNet + get_all_loss_DeepF + get_Rt_loss + the caller's mixing, and through hot_path_fused:
+    loss, per-layer F / E / pose errors and d loss / d logits agree to 1e-6 (they are the same kernels for the fits; the tails
+    differ: one launch with baked coefficients there, Jacobians + the caller's torch ops here, or the stand-alone kernels)."""
+    N, L = 100, 5
+    sc = dfepe.synth.make_scene(B, N, seed=31, outlier_ratio=0.2, noise_px=0.5, depth_layers=L)
+    d = dfepe.pipeline.scene_to_device(sc, DEV)
+    fused = dfepe.pipeline.hot_path_step(d, IMAGE_SIZE, L, 0.02, qt=True, balance_F=balance_F)
+    gmax = float(fused["grad_logits"].abs().max())
+    for gt_in in (False, True):
+        loss, outs, losses, geo, g = _api(dfepe, d, L, gt_in, balance_F)
+        assert abs(loss.item() - fused["loss"].item()) < 1e-6 * max(1.0, abs(fused["loss"].item())), gt_in
+        for l in range(L):
+            assert torch.equal(outs["out_layers"][l], fused["F_layers"][l]), (gt_in, l)  # the same fit kernel on the same inputs
+        np.testing.assert_allclose(torch.stack(geo["q_l2_error_layers_list"]).detach().cpu().numpy(), fused["q_l2"].cpu().numpy(), atol=1e-6, rtol=1e-6)
+        np.testing.assert_allclose(torch.stack(geo["t_l2_error_layers_list"]).detach().cpu().numpy(), fused["t_l2"].cpu().numpy(), atol=1e-6, rtol=1e-6)
+        np.testing.assert_allclose(np.stack(geo["R_angle_error_layers_list"]), fused["R_deg"].cpu().numpy(), atol=1e-5)
+        np.testing.assert_allclose(np.stack(geo["t_angle_error_layers_list"]), fused["t_deg"].cpu().numpy(), atol=1e-5)
+        np.testing.assert_allclose(losses["loss_F"].item(), fused["loss_F"].item(), rtol=2e-6)
+        np.testing.assert_allclose(torch.stack(losses["loss_layers"]).detach().cpu().numpy(), fused["loss_layers"].cpu().numpy(), rtol=2e-6)
+        err = float((g - fused["grad_logits"]).abs().max())
+        assert err < 1e-6 * gmax, (gt_in, err, gmax)
+        # per pair: relative to that pair's own gradient
+        pp = (g - fused["grad_logits"]).flatten(2).norm(dim=2) / fused["grad_logits"].flatten(2).norm(dim=2).clamp_min(1e-30)
+        assert float(pp.max()) < 5e-5, (gt_in, float(pp.max()))
+
+
+def test_both_tails_give_identical_gradients_and_the_fused_one_is_found_by_get_Rt_loss(dfepe):
+    """loss_params['pose_gt'] moves the pose errors into get_all_loss_DeepF's launch; get_Rt_loss then launches nothing of its
+    own (its q / t rows are that node's outputs) -- and falls back to its own kernel when handed a different ground truth."""
+    B, N, L = 64, 100, 3
+    d = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(B, N, seed=5, outlier_ratio=0.3, noise_px=0.5, depth_layers=L), DEV)
+    tgu = dfepe.compat.train_good_utils
+    la, _, _, geo_a, ga = _api(dfepe, d, L, False)
+    lb, _, _, geo_b, gb = _api(dfepe, d, L, True)
+    assert torch.stack(geo_b["q_l2_error_layers_list"]).grad_fn is not None
+    assert geo_b["q_l2_error_layers_list"][0].data_ptr() == tgu._last_tail["q_l2"].data_ptr()  # the fused launch's buffer
+    assert geo_a["q_l2_error_layers_list"][0].data_ptr() != tgu._last_tail["q_l2"].data_ptr()
+    assert abs(la.item() - lb.item()) < 1e-7
+    assert float((ga - gb).abs().max()) < 1e-6 * float(ga.abs().max())
+    # another ground truth than the one get_all_loss_DeepF was promised: get_Rt_loss must not use the cached errors
+    rows = _leaves(d, L)
+    net = dfepe.pipeline.make_api_net(L, IMAGE_SIZE, rows)
+    batch = {"matches_xy_ori": d["matches_xy_ori"], "matches_good_unique_nums": None, "t_scene_scale": None}
+    lp = {"depth": L, "clamp_at": 0.02, "if_tri_depth": False, "if_sample_loss": False, "topK": 8, "matches_good_unique_nums": None,
+          "pose_gt": (d["qs_cam"], d["ts_cam"], d["delta_Rtijs_4_4"])}
+    outs = net(batch)
+    E_layers = tgu.get_all_loss_DeepF(outs, d["pts1_virt_ori"], d["pts2_virt_ori"], d["Ks"], lp, get_residual_summaries=False)[6]
+    other_q = d["qs_cam"].roll(1, 0).contiguous()
+    geo = tgu.get_Rt_loss(E_layers, None, None, None, d["delta_Rtijs_4_4"], other_q, d["ts_cam"], device=DEV)
+    want = dfepe.ops.pose_errors(torch.stack(E_layers), other_q, d["ts_cam"], d["R_gt"])[0]
+    np.testing.assert_allclose(torch.stack(geo["q_l2_error_layers_list"]).detach().cpu().numpy(), want.detach().cpu().numpy(), atol=1e-6)
+
+
+def test_tail_jacobians_reproduce_the_standalone_adjoints_for_any_upstream(dfepe):
+    """dfepe_loss_tail_jac + dfepe_loss_tail_bwd against dfepe_floss_fwd/bwd + dfepe_pose_fwd/bwd (both pinned by the oracle in
+    test_backward_gpu.py) for random upstream gradients on loss_sum, q_l2 and t_l2, each alone and together, M = 37 and 100."""
+    g = torch.Generator().manual_seed(3)
+    for M, L, B in ((100, 5, 50), (37, 2, 19), (112, 16, 5)):
+        d = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(B, 60, seed=M, outlier_ratio=0.2, noise_px=0.5, depth_layers=1, M_virt=M), DEV)
+        H, W = float(IMAGE_SIZE[0]), float(IMAGE_SIZE[1])
+        T = torch.tensor([[2.0 / W, 0.0, -1.0], [0.0, 2.0 / H, -1.0], [0.0, 0.0, 1.0]], device=DEV)
+        Tinv = torch.linalg.inv(T.double())
+        Fn = (Tinv.T @ d["F_gt"].double() @ Tinv)
+        Fn = Fn / Fn.flatten(1).norm(dim=1)[:, None, None]
+        Fl = torch.stack([Fn + 0.003 * (l + 1) * torch.randn(B, 3, 3, generator=g, dtype=torch.float64).to(DEV) for l in range(L)]).float()
+        up = [torch.randn(L, B, generator=g).to(DEV) for _ in range(3)]
+        for use in ((1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 1)):
+            Fa = Fl.clone().requires_grad_(True)
+            ls, E, qt, q, t, ang, sel = dfepe.ops.loss_tail_jac(Fa, T, T, d["Ks"], d["pts1_virt_ori"], d["pts2_virt_ori"], 0.02, d["qs_cam"], d["ts_cam"], d["R_gt"])
+            Fb = Fl.clone().requires_grad_(True)
+            ls2, E2 = dfepe.ops.floss(Fb, T, T, d["Ks"], d["pts1_virt_ori"], d["pts2_virt_ori"], 0.02)
+            q2, t2, R2, t2d, sel2 = dfepe.ops.pose_errors(E2, d["qs_cam"], d["ts_cam"], d["R_gt"])
+            assert torch.equal(E, E2) and torch.equal(sel, sel2)
+            np.testing.assert_allclose(ls.detach().cpu().numpy(), ls2.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)
+            np.testing.assert_allclose(q.detach().cpu().numpy(), q2.detach().cpu().numpy(), atol=1e-7)
+            np.testing.assert_allclose(ang[0].cpu().numpy(), R2.cpu().numpy(), atol=1e-6)
+            (use[0] * (ls * up[0]).sum() + use[1] * (q * up[1]).sum() + use[2] * (t * up[2]).sum()).backward()
+            (use[0] * (ls2 * up[0]).sum() + use[1] * (q2 * up[1]).sum() + use[2] * (t2 * up[2]).sum()).backward()
+            scale = float(Fb.grad.abs().max())
+            assert float((Fa.grad - Fb.grad).abs().max()) < 2e-5 * scale, (M, use)
+        # a gradient on E itself (no loss of the reference has one) takes the stand-alone adjoint on top
+        Fa = Fl.clone().requires_grad_(True)
+        ls, E = dfepe.ops.loss_tail_jac(Fa, T, T, d["Ks"], d["pts1_virt_ori"], d["pts2_virt_ori"], 0.02)[:2]
+        GE = torch.randn(L, B, 3, 3, generator=g).to(DEV)
+        ((E * GE).sum() + (ls * up[0]).sum()).backward()
+        Fb = Fl.clone().requires_grad_(True)
+        ls2, E2 = dfepe.ops.floss(Fb, T, T, d["Ks"], d["pts1_virt_ori"], d["pts2_virt_ori"], 0.02)
+        ((E2 * GE).sum() + (ls2 * up[0]).sum()).backward()
+        assert float((Fa.grad - Fb.grad).abs().max()) < 2e-5 * float(Fb.grad.abs().max())
+    with pytest.raises(dfepe._lib.DfepeError, match="unsupported|not supported"):
+        d = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(4, 20, seed=1, M_virt=120), DEV)
+        dfepe.ops.loss_tail_jac(torch.randn(1, 4, 3, 3, device=DEV), T, T, d["Ks"], d["pts1_virt_ori"], d["pts2_virt_ori"], 0.02)
+
+
+def test_input_kernel_and_camera_rotation_match_torch(dfepe):
+    g = torch.Generator().manual_seed(0)
+    B, N = 9, 133
+    m = torch.rand(B, N, 4, generator=g) * torch.tensor([1241.0, 376.0, 1241.0, 376.0])
+    qual = torch.rand(B, N, 2, generator=g)
+    norm = dfepe.compat.DeepFNet.NormalizeAndExpand_HW(IMAGE_SIZE)
+    p1, p2, T1, T2 = norm(m.to(DEV))
+    for q in (None, qual.to(DEV)):
+        w_in, a, b = dfepe.ops.deepf_input(m.to(DEV), IMAGE_SIZE[1], IMAGE_SIZE[0], q)
+        np.testing.assert_allclose(a.cpu().numpy(), p1.permute(0, 2, 1).cpu().numpy(), atol=2e-7)
+        np.testing.assert_allclose(b.cpu().numpy(), p2.permute(0, 2, 1).cpu().numpy(), atol=2e-7)
+        parts = [(p1.permute(0, 2, 1)[:, :, :2] + 1) / 2, (p2.permute(0, 2, 1)[:, :, :2] + 1) / 2] + ([] if q is None else [q])
+        np.testing.assert_allclose(w_in.cpu().numpy(), torch.cat(parts, 2).permute(0, 2, 1).cpu().numpy(), atol=2e-7)
+    net = dfepe.compat.DeepFNet.DeepFNet(depth=2, image_size=IMAGE_SIZE, if_quality=True, quality_size=2)
+    w_in, a, b, T1n, T2n, pts = net.get_input({"matches_xy_ori": m.to(DEV), "quality": qual.to(DEV)})
+    assert w_in.shape == (B, 6, N) and T1n.shape == (B, 3, 3) and torch.equal(T1n, T1.to(DEV)) and pts.shape == (B, N, 4)
+    # scene motions: rigid, and a general last row
+    sc = dfepe.synth.make_scene(16, 10, seed=3)
+    delta = sc["delta_Rtijs_4_4"].clone()
+    delta[3:6, 3, :] = torch.tensor([0.1, -0.2, 0.05, 1.3])
+    R = dfepe.ops.camera_rotation(delta.to(DEV))
+    np.testing.assert_allclose(R.cpu().numpy(), torch.linalg.inv(delta.double())[:, :3, :3].numpy(), atol=2e-6)
+
+
+def test_no_host_sync_and_graph_capture_of_the_api_step(dfepe):
+    """The whole reference call sequence + backward is capturable in a hipGraph (no .cpu(), no pageable host copies), replays
+    rewrite the outputs in place, and the lazily copied angular errors follow the replays after refresh()."""
+    B, N, L = 256, 100, 5
+    d = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(B, N, seed=9, outlier_ratio=0.2, noise_px=0.5, depth_layers=L), DEV)
+    rows = _leaves(d, L)
+    net = dfepe.pipeline.make_api_net(L, IMAGE_SIZE, rows)
+    state = {}
+
+    def step():
+        loss, outs, losses, geo = dfepe.pipeline.reference_call_sequence(net, d, L, pose_gt_in_loss_params=True)
+        state["g"] = torch.autograd.grad(loss, rows, grad_outputs=state.setdefault("seed", torch.ones_like(loss)))
+        state["loss"], state["geo"] = loss, geo
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    eager_loss, eager_g = state["loss"].item(), [x.clone() for x in state["g"]]
+    eager_R = np.asarray(state["geo"]["R_angle_error_layers_list"][-1]).copy()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    geo = state["geo"]
+    with torch.no_grad():
+        for r in rows:  # other logits: the replay must recompute from the rows' current contents
+            r.mul_(0.5)
+    graph.replay()
+    torch.cuda.synchronize()
+    changed = state["loss"].item()
+    assert changed != eager_loss
+    with torch.no_grad():
+        for r in rows:
+            r.mul_(2.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert abs(state["loss"].item() - eager_loss) < 1e-7
+    for a, b in zip(state["g"], eager_g):
+        assert torch.equal(a, b)
+    geo["_host_metrics"].refresh()
+    np.testing.assert_array_equal(np.asarray(geo["R_angle_error_layers_list"][-1]), eager_R)
+    assert isinstance(float(geo["R_angle_error_mean"]), float) and np.isscalar(geo["t_angle_error_mean"])
+
+
+def test_recurrent_backward_at_bench_size_vs_fp64_oracle(dfepe, oracle):
+    """The backward four of the model's five layers run -- upstream gradients on residual and the in-loop epipolar residual as
+    well as on F (the next estimator layer consumes them, DeepFNet.py:464-512) -- at B = 4096, N = 100, against fp64 autograd of
+    the oracle on a 256-pair subsample (every 16th pair); VERDICT r3: that instantiation had only met the oracle at B <= 300."""
+    B, N = 4096, 100
+    sc = dfepe.synth.make_scene(B, N, seed=77, outlier_ratio=0.2, noise_px=0.5)
+    g = torch.Generator().manual_seed(8)
+    GF, GR, GE, GW = torch.randn(B, 3, 3, generator=g), torch.randn(B, N, generator=g), torch.randn(B, N, generator=g), torch.randn(B, N, generator=g)
+    logits = sc["logits_layers"][0].to(DEV).requires_grad_(True)
+    F, res, epi, w = dfepe.ops.w8pt_raw_logits(sc["matches_xy_ori"].to(DEV), logits, IMAGE_SIZE[1], IMAGE_SIZE[0], clamp_at=0.5, want_epi=True)
+    ((F * GF.to(DEV)).sum() + (res * GR.to(DEV)).sum() + (epi * GE.to(DEV)).sum() + (w * GW.to(DEV)).sum()).backward()
+    idx = torch.arange(0, B, 16)
+    lo = sc["logits_layers"][0][idx].double().requires_grad_(True)
+    wo = torch.softmax(lo, 1)
+    p1, p2, _ = oracle.normalize_hw(sc["matches_xy_ori"][idx].double(), IMAGE_SIZE)
+    o_out, o_res, _ = oracle.fit_forward(p1, p2, wo.unsqueeze(1))
+    s = torch.sign((o_out.detach() * F.detach().cpu().double()[idx]).flatten(1).sum(1))
+    (((s[:, None, None] * o_out) * GF[idx].double()).sum() + ((s[:, None] * o_res) * GR[idx].double()).sum()
+     + (oracle.compute_epi_residual(p1, p2, o_out, 0.5) * GE[idx].double()).sum() + (wo * GW[idx].double()).sum()).backward()
+    ours, ref = logits.grad.cpu().double()[idx], lo.grad
+    per_pair = (ours - ref).norm(dim=1) / ref.norm(dim=1).clamp_min(1e-30)
+    assert float(per_pair.median()) < 1e-5
+    assert float(per_pair.kthvalue(int(0.98 * per_pair.numel()))[0]) < 2e-3

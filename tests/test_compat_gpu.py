@@ -54,8 +54,8 @@ def test_deepfnet_full_model_matches_reference_golden(dfepe, golden):
     layer = {"i": 0}
     orig_fit = net._fit
 
-    def fit_with_reference_gauge(matches, logits, data_batch, want_epi):
-        outs = orig_fit(matches, logits, data_batch, want_epi)
+    def fit_with_reference_gauge(matches, logits, data_batch, want_epi, dst=None):
+        outs = orig_fit(matches, logits, data_batch, want_epi, dst)
         ref = torch.from_numpy(g["net_out_layers"][layer["i"]]).to(DEV)
         s = torch.sign((outs[0].detach() * ref).flatten(1).sum(1))
         layer["i"] += 1
@@ -76,8 +76,8 @@ def test_deepfnet_full_model_matches_reference_golden(dfepe, golden):
     layer_b = {"i": 0}
     fit_b = net_b._fit
 
-    def fit_b_gauge(matches, logits, data_batch, want_epi):
-        o = fit_b(matches, logits, data_batch, want_epi)
+    def fit_b_gauge(matches, logits, data_batch, want_epi, dst=None):
+        o = fit_b(matches, logits, data_batch, want_epi, dst)
         ref = torch.from_numpy(g["net_out_layers"][layer_b["i"]]).to(DEV)
         sg = torch.sign((o[0].detach() * ref).flatten(1).sum(1))
         layer_b["i"] += 1

@@ -1,0 +1,118 @@
+"""Host logic of the reference-API path that needs no GPU: the zero-copy per-layer stacks (ops.stack_rows / unstack_rows: the
+reference's API speaks in python lists of per-layer tensors, the kernels in one [L, ...] buffer), the lazily copied host metrics
+of get_Rt_loss, and the code-object check that no kernel of the library uses scratch memory (two instantiations
+of the head-carrying backward spilled unnoticed)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_stack_rows_aliases_a_buffer_and_copies_otherwise(dfepe):
+    ops = dfepe.ops
+    buf = torch.arange(24.0).reshape(3, 2, 4).clone()
+    rows = [ops.row_of(buf, l) for l in range(3)]
+    assert all(r._base is None and r.data_ptr() == buf[l].data_ptr() and torch.equal(r, buf[l]) for l, r in enumerate(rows))
+    a = ops.alias_rows(rows)
+    assert a is not None and a.data_ptr() == buf.data_ptr() and a.shape == buf.shape and torch.equal(a, buf)
+    assert ops.alias_rows(rows[::-1]) is None and ops.alias_rows([rows[0], rows[2]]) is None  # order / gaps
+    assert ops.alias_rows([rows[0], torch.zeros(2, 4)]) is None and ops.alias_rows([rows[0], rows[1].double()]) is None
+    assert ops.alias_rows([buf[:, :, :2][0], buf[:, :, :2][1]]) is None  # non-contiguous rows
+    assert ops.alias_rows([]) is None and ops.alias_rows([None]) is None
+    v = [buf[l].unsqueeze(0) for l in range(3)]  # views of the rows (DeepFNet's epi_res.unsqueeze(1)) still alias
+    assert ops.alias_rows(v).data_ptr() == buf.data_ptr()
+    s = ops.stack_rows(rows)
+    assert s.data_ptr() == buf.data_ptr()
+    s2 = ops.stack_rows([torch.ones(2), torch.zeros(2)])
+    assert torch.equal(s2, torch.tensor([[1.0, 1.0], [0.0, 0.0]]))
+
+
+def test_rows_carry_gradients_like_stack_and_unbind(dfepe):
+    ops = dfepe.ops
+
+    class Fill(torch.autograd.Function):  # a producer that writes its result into row l of the caller's stack (like the fit kernels)
+        @staticmethod
+        def forward(ctx, w, dst):
+            out = ops.row_of(*dst)
+            out.copy_(w * 2)
+            return out
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 2, None
+
+    g = torch.Generator().manual_seed(0)
+    ws = [torch.randn(4, generator=g, requires_grad=True) for _ in range(3)]
+    buf = torch.empty(3, 4)
+    rows = [Fill.apply(ws[l], (buf, l)) for l in range(3)]
+    S = ops.stack_rows(rows)
+    assert S.data_ptr() == buf.data_ptr() and S.requires_grad
+    E = S * 3
+    rows2 = ops.unstack_rows(E)
+    assert rows2[1].data_ptr() == E[1].data_ptr() and all(r.grad_fn is not None for r in rows2)
+    assert ops.stack_rows(rows2).data_ptr() == E.data_ptr()  # what get_Rt_loss does with get_all_loss_DeepF's E_ests_layers
+    loss = torch.clamp(torch.stack(rows2), 0, 0.5).mean() + 0.1 * ops.stack_rows(rows2).sum() + rows2[2].sum()
+    loss.backward()
+    ref = [w.detach().clone().requires_grad_() for w in ws]
+    st = torch.stack([w * 6 for w in ref])
+    (torch.clamp(st, 0, 0.5).mean() + 0.1 * st.sum() + st[2].sum()).backward()
+    for a, b in zip(ws, ref):
+        assert torch.allclose(a.grad, b.grad)
+    # a single row used: the others get exact zeros; nothing used: no gradient at all
+    ws3 = [w.detach().clone().requires_grad_() for w in ws]
+    r3 = ops.unstack_rows(ops.stack_rows([w * 2 for w in ws3]) * 3)
+    r3[1].sum().backward()
+    assert torch.equal(ws3[0].grad, torch.zeros(4)) and torch.equal(ws3[1].grad, torch.full((4,), 6.0))
+    # the gradient of torch.stack(rows) arrives as the rows of one buffer and is taken without a copy
+    seen = {}
+    x = torch.randn(3, 5, requires_grad=True)
+    y = x * 1.0
+    y.register_hook(lambda gr: seen.__setitem__("ptr", gr.data_ptr()))
+    up = torch.randn(3, 5)
+    stacked = torch.stack(ops.unstack_rows(y))
+    stacked.register_hook(lambda gr: seen.__setitem__("up", gr.data_ptr()))
+    (stacked * up).sum().backward()
+    assert seen["ptr"] == seen["up"] and torch.allclose(x.grad, up)
+
+
+def test_lazy_host_metrics_behave_like_the_references_numpy_values(dfepe):
+    tgu = dfepe.compat.train_good_utils
+    calls = {"n": 0}
+
+    def fetch():
+        calls["n"] += 1
+        return np.array([0.02, 3.0, 0.7])
+
+    x = tgu._Lazy(fetch)
+    assert calls["n"] == 0  # nothing is read until somebody looks
+    # the uses Train_model_pipeline.py:823-885 makes of the per-layer error arrays and their means
+    assert np.amax(x) == 3.0 and np.max(x) == 3.0 and x.flatten().shape == (3,)
+    np.testing.assert_array_equal(np.clip(x, 0.0, 1.0), [0.02, 1.0, 0.7])
+    np.testing.assert_array_equal(np.hstack((x[x < 0.05], np.zeros(1))), [0.02, 0.0])
+    assert np.stack([x, x]).shape == (2, 3) and len(x) == 3 and list(x) == [0.02, 3.0, 0.7] and x.mean() == pytest.approx(1.24)
+    np.testing.assert_array_equal(x * 2, [0.04, 6.0, 1.4])
+    np.testing.assert_array_equal(2 * x, [0.04, 6.0, 1.4])
+    m = tgu._Lazy(lambda: 1.5)
+    assert float(m) == 1.5 and np.isscalar(m) and "%.2f" % m == "1.50" and f"{m:.1f}" == "1.5" and m + 1 == 2.5 and m < 2
+    np.testing.assert_array_equal(np.array([m]), [1.5])
+    assert calls["n"] > 0
+
+
+def test_no_kernel_of_the_library_uses_scratch_memory():
+    """Code-object metadata of every object the library is linked from (scripts/kernel_resources.py): private segment and
+    spill counts must be zero -- a spilling instantiation is a performance bug that no parity test sees."""
+    repo = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    sys.path.insert(0, os.path.join(repo, "scripts"))
+    try:
+        import kernel_resources
+    finally:
+        sys.path.pop(0)
+    objdir = os.path.join(repo, "pytorch-deepfepe_amd", "csrc", "build")
+    if not os.path.isdir(objdir) or not any(f.endswith(".o") for f in os.listdir(objdir)):
+        pytest.skip("no objects under csrc/build (the library was built elsewhere)")
+    ks = kernel_resources.kernels(objdir)
+    assert len(ks) > 100
+    bad = [(k["name"][:90], k["scratch"], k["spill"]) for k in ks if k["scratch"] or k["spill"]]
+    assert not bad, bad
