@@ -222,7 +222,8 @@ int dfepe_loss_tail(const float *F_layers, int L, int B, const float *T1, const 
  * runs, so this variant of dfepe_loss_tail leaves, next to the same per-pair outputs, the three JACOBIANS of every
  * (layer, pair):  J [L,B,27] = d loss_sum / dF (9) | d q_l2 / dF (9) | d t_l2 / dF (9)   (unclamped, unit upstream),
  * and dfepe_loss_tail_bwd turns whatever upstream gradients autograd delivers into d loss / dF in one launch:
- *   g_F[l,b] = g_loss_sum[l,b] J_F + g_q_l2[l,b] J_q + g_t_l2[l,b] J_t        (each upstream pointer may be NULL = zero)
+ *   g_F[l,b] = g_loss_sum[l,b] J_F + g_q_l2[l,b] J_q + g_t_l2[l,b] J_t        (each upstream pointer may be NULL = zero;
+ *   gradients that arrive on the batch statistics of dfepe_loss_stats enter through g_mean_* / g_all_*, see there)
  * Replaces: torch.autograd through get_all_loss_DeepF's per-layer body (deepFEPE/train_good_utils.py:325-358) and
  *           get_Rt_loss's per-sample loop (:96-239).  No batch sums here (the caller's torch means take them).
  *   arguments as in dfepe_loss_tail, M <= 112 (else DFEPE_ERR_UNSUPPORTED); q_gt == NULL: no pose part (J_q = J_t = 0); want_floss_jac == 0: J_F = 0 and the F-loss
@@ -234,7 +235,23 @@ int dfepe_loss_tail_jac(const float *F_layers, int L, int B, const float *T1, co
                         float *loss_sum, float *E_layers, float *q_l2, float *t_l2, float *R_deg, float *t_deg, int *sel,
                         float *J, void *stream);
 int dfepe_loss_tail_bwd(const float *J, int L, int B, const float *g_loss_sum, const float *g_q_l2, const float *g_t_l2,
-                        float *g_F_layers, void *stream);
+                        const float *g_mean_loss, const float *g_all_loss, const float *g_mean_q, const float *g_all_q,
+                        const float *g_mean_t, const float *g_all_t, float stat_loss_scale, float *g_F_layers, void *stream);
+
+/*
+ * Batch statistics of the per-pair loss terms in one launch.
+ * Replaces: the per-layer `.mean()` calls and python sums of get_all_loss_DeepF (deepFEPE/train_good_utils.py:343-364: losses.mean()
+ *           per layer, loss_F = sum / len, loss_min_layers / loss_min_batch :375-376, loss_epi_res :429-438) and of get_Rt_loss
+ *           (:272-283: x.mean() per layer, mean_list) -- a dozen small reductions in the reference's style, one launch here.
+ *   up to four sets k of rows x_k [rows_k, C] (rows_k = 0: absent; rows_k <= 64), C = pairs
+ *   out: for every present set in order, rows_k floats = scale_k * mean over C of each row, then 1 float = the mean of those
+ *   row_min0 [rows0] or NULL: scale0 * min over C of each row of set 0; col_min0 [C] or NULL: scale0 * min over the rows of set 0
+ * dfepe_loss_tail_bwd's g_mean_* [L] / g_all_* [1] take the gradients of such row means / of their mean for the sets loss_sum
+ * (scale = stat_loss_scale), q_l2, t_l2 directly: no expansion of a mean's gradient to [L,B] in between.
+ */
+int dfepe_loss_stats(const float *x0, int rows0, float scale0, const float *x1, int rows1, float scale1,
+                     const float *x2, int rows2, float scale2, const float *x3, int rows3, float scale3, int C,
+                     float *out, float *row_min0, float *col_min0, void *stream);
 
 /*
  * Cheirality-checked pose from E.
@@ -323,11 +340,17 @@ int dfepe_geo_misc(int kind, const float *in0, const float *in1, int n, float *o
  *           normalisation T_HW (x, y, 1) of both point sets and the estimator's input channels ((x+1)/2, (y+1)/2 of both images,
  *           then the Q quality channels) -- about fifteen elementwise / bmm launches in the reference, one here.
  *   matches [B,N,4] pixels (16-byte aligned); quality [B,N,Q] or NULL (Q = 0)
- *   weight_in [B,C_out,N] or NULL: channels 0..3+Q are written (C_out >= 4+Q lets the caller own further channels of the buffer)
+ *   weight_in or NULL: element (copy k, channel c < 4+Q, pair b, point i) goes to
+ *     weight_in[k * copy_stride + c * channel_stride + b * batch_stride + i], k < n_copies.  The reference's [B,4+Q,N] tensor is
+ *     channel_stride = N, batch_stride = (4+Q) N; channel-major storage [C,B,N] (channel_stride = B N, batch_stride = N) lets the
+ *     fit kernels write the recurrent channels (weights, epipolar residual, residual) of the next estimator input as plain
+ *     [B,N] blocks, and n_copies fills the point channels of every layer's input buffer in this one launch (no torch.cat per
+ *     layer, DeepFNet.py:484-489)
  *   pts1, pts2 [B,N,3] or NULL: homogeneous normalised points (the arithmetic of dfepe_w8pt_fwd's DFEPE_W8PT_RAW_MATCHES prologue)
  */
 int dfepe_deepf_input(const float *matches, const float *quality, int B, int N, int Q, float image_w, float image_h,
-                      float *weight_in, int C_out, float *pts1, float *pts2, void *stream);
+                      float *weight_in, size_t channel_stride, size_t batch_stride, int n_copies, size_t copy_stride,
+                      float *pts1, float *pts2, void *stream);
 
 /*
  * InstanceNorm1d(affine) + LeakyReLU on rows of N contiguous floats ("next" row f-1: the part of the weight estimator

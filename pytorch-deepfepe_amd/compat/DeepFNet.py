@@ -119,14 +119,16 @@ class DeepFNet(nn.Module):
             cache[key] = torch.tensor([[2.0 / W, 0.0, -1.0], [0.0, 2.0 / H, -1.0], [0.0, 0.0, 1.0]], device=dev)
         return cache[key].unsqueeze(0).expand(B, -1, -1)
 
-    def get_input(self, data_batch, offsets=None, iter=None):
+    def _inputs(self, data_batch, offsets=None, recurrent_copies=0):
+        """get_input plus, on the default path, the channel-major buffers of the later estimator calls (ops.deepf_input)."""
         pts = data_batch["matches_xy_ori"]
         if offsets is None and not (torch.is_grad_enabled() and pts.requires_grad):
             # the default path: ONE launch instead of ~15 elementwise / bmm ones (the matches are data, nothing to differentiate)
             quality = data_batch["quality"] if self.if_quality else None
-            weight_in, pts1, pts2 = ops.deepf_input(pts, float(self.image_size[1]), float(self.image_size[0]), quality)
+            weight_in, pts1, pts2, stores = ops.deepf_input(pts, float(self.image_size[1]), float(self.image_size[0]), quality,
+                                                            recurrent_copies=recurrent_copies)
             T = self._T_hw(pts.shape[0], pts.device)
-            return weight_in, pts1, pts2, T, T, pts
+            return weight_in, pts1, pts2, T, T, pts, stores
         if offsets is not None:  # (DeepFNet.py:369-373)
             pts = pts + offsets.permute(0, 2, 1)
         pts1, pts2, T1, T2 = self.norm_HW(pts)
@@ -136,7 +138,10 @@ class DeepFNet(nn.Module):
         if self.if_quality:
             parts.append(data_batch["quality"])
         weight_in = torch.cat(parts, 2).permute(0, 2, 1)
-        return weight_in, pts1, pts2, T1, T2, pts
+        return weight_in, pts1, pts2, T1, T2, pts, None
+
+    def get_input(self, data_batch, offsets=None, iter=None):
+        return self._inputs(data_batch, offsets)[:6]
 
     def _fit(self, matches, logits, data_batch, want_epi, dst=None):
         """logits [B,1,N] -> (out, residual[, epi], weights_prod [B,1,N]).  The softmax over N is fused into the solver
@@ -153,7 +158,8 @@ class DeepFNet(nn.Module):
     def forward(self, data_batch):
         matches = data_batch["matches_xy_ori"]
         _require_gpu(matches, "DeepFNet")
-        pts_normalized_in, pts1, pts2, T1, T2, _ = self.get_input(data_batch)
+        plain = not self.if_learn_offsets and not self.if_img_w
+        pts_normalized_in, pts1, pts2, T1, T2, _, stores = self._inputs(data_batch, recurrent_copies=(self.depth - 1) if plain else 0)
         logits = self.input_weights(pts_normalized_in)
         _ = data_batch["matches_good_unique_nums"]  # read like the reference does (DeepFNet.py:449,453)
         _ = data_batch["t_scene_scale"]
@@ -161,11 +167,20 @@ class DeepFNet(nn.Module):
         out_layers, epi_res_layers, residual_layers = [], [], []
         weights_layers, logits_layers = [], [logits]
         offsets_accu = None
-        # one buffer per kind of per-layer output; each fit writes its row (the python lists below hold those rows)
+        # Where the per-layer outputs live.  F of every layer: one [L,B,3,3] buffer (the loss functions take it as it is).  With the
+        # channel-major estimator inputs of ops.deepf_input (``stores`` [L-1,C,B,N]) the weights, epipolar residual and residual
+        # of layer l are written straight into channels c0.. of stores[l]: the next estimator call reads its input without a
+        # torch.cat, and the same channel of consecutive layers is a strided stack for the loss functions.
         B, N, dev = matches.shape[0], matches.shape[1], matches.device
-        stacks = {"F": torch.empty(self.depth, B, 3, 3, device=dev), "weights": torch.empty(self.depth, B, N, device=dev),
-                  "epi": torch.empty(max(self.depth - 1, 1), B, N, device=dev)}
-        dst = lambda l: {k: (v, l) for k, v in stacks.items() if k != "epi" or l < self.depth - 1}
+        F_stack = torch.empty(self.depth, B, 3, 3, device=dev)
+        c0 = pts_normalized_in.shape[1]
+
+        def dst(l):
+            d = {"F": (F_stack, l)}
+            if stores is not None and l < self.depth - 1:
+                d.update({"weights": (stores[l], c0), "epi": (stores[l], c0 + 1), "residual": (stores[l], c0 + 2)})
+            return d
+
         for it in range(self.depth - 1):
             out, residual, epi, weights_prod = self._fit(matches, logits, data_batch, True, dst(it))
             weights_layers.append(weights_prod)
@@ -173,7 +188,11 @@ class DeepFNet(nn.Module):
             residual_layers.append(residual)
             epi_res = epi.unsqueeze(1)
             epi_res_layers.append(epi_res)
-            net_in = torch.cat((pts_normalized_in, weights_prod, epi_res, residual.unsqueeze(1)), 1)
+            rec = [weights_prod.squeeze(1), epi, residual]
+            if stores is not None and all(r.data_ptr() == stores[it][c0 + k].data_ptr() and r.is_contiguous() for k, r in enumerate(rec)):
+                net_in = ops.estimator_input(stores[it], c0, rec)  # the three rows are where the fit kernel left them
+            else:
+                net_in = torch.cat((pts_normalized_in, weights_prod, epi_res, residual.unsqueeze(1)), 1)
             if self.if_learn_offsets:  # (DeepFNet.py:490-507): the later fits see the corrected matches
                 offsets_accu = self.update_offsets(net_in)
                 pts_normalized_in, pts1, pts2, T1, T2, matches = self.get_input(data_batch, offsets_accu, it)

@@ -106,6 +106,31 @@ class _HostCopy:
         self.cache = None
 
 
+class _GeoErrors(dict):
+    """get_Rt_loss's dict (exactly the reference's twelve keys) with one attribute: host_metrics, the pending host copy of the
+    angular errors (None when they were copied at once)."""
+
+    host_metrics = None
+
+
+_dense_T_cache = {}
+
+
+def _dense_T(T, B):
+    """[B,3,3] contiguous copy of an expanded (stride-0) image-size transform, made once per (buffer, B): DeepFNet hands out
+    views of one cached constant, and a copy kernel per step for it would be a launch spent on a constant."""
+    if T.stride(0) != 0:
+        return T if T.is_contiguous() else T.contiguous()
+    key = (T.data_ptr(), int(B), str(T.device))
+    hit = _dense_T_cache.get(key)
+    if hit is None or hit[0] is not T.untyped_storage():
+        if len(_dense_T_cache) > 16:
+            _dense_T_cache.clear()
+        hit = (T.untyped_storage(), T.expand(B, 3, 3).contiguous())
+        _dense_T_cache[key] = hit
+    return hit[1]
+
+
 _last_tail = {}  # the fused tail of the latest get_all_loss_DeepF call that was given the ground truth (loss_params["pose_gt"])
 
 
@@ -132,24 +157,35 @@ def get_all_loss_DeepF(outs, pts1_virt_ori, pts2_virt_ori, Ks, loss_params, get_
     B = F_layers.shape[1]
     gt = loss_params.get("pose_gt")
     _last_tail.clear()
+    # loss_epi_res (:429-438, logged only): sum_n epi_res * weights of every (layer, pair) in one launch; its means ride in the
+    # statistics launch below
+    epidot, n_epi, N_pts = None, 0, 1
+    if depth > 1:
+        n_epi = min(len(outs["epi_res_layers"]), len(outs["weights_layers"]))  # zip() of the reference
+        if n_epi > 0:
+            epi = ops.stack_rows(outs["epi_res_layers"][:n_epi])  # [n,B,1,N], strided views when the layers share a buffer
+            w = ops.stack_rows(outs["weights_layers"][:n_epi])
+            N_pts = epi.shape[-1]
+            epidot = torch.linalg.vecdot(epi.reshape(n_epi, B, N_pts), w.reshape(n_epi, B, N_pts))  # [n,B]
     if gt is not None and M <= 112:
         q_gt, t_gt, delta = (torch.as_tensor(x).to(F_layers.device) for x in gt)
         R_gt = ops.camera_rotation(delta)
-        loss_sum, E_layers, qt, q_l2, t_l2, ang, _sel = ops.loss_tail_jac(F_layers, T1, T2, Ks, pts1_virt_ori, pts2_virt_ori, loss_params["clamp_at"],
-                                                                         q_gt, t_gt, R_gt, floss_grad=loss_params.get("floss_grad", True))
-        _last_tail.update(E=E_layers, gt=tuple(x.data_ptr() for x in (q_gt, t_gt, delta)), qt=qt, q_l2=q_l2, t_l2=t_l2, ang=ang)
+        r = ops.loss_tail_jac(F_layers, T1, T2, Ks, pts1_virt_ori, pts2_virt_ori, loss_params["clamp_at"], q_gt, t_gt, R_gt,
+                              floss_grad=loss_params.get("floss_grad", True), extra=epidot, extra_scale=1.0 / N_pts)
+        E_layers, m_loss, o_loss, row_min, col_min, m_epi, o_epi = (r[k] for k in ("E_layers", "m_loss", "o_loss", "row_min", "col_min", "m_extra", "o_extra"))
+        _last_tail.update(E=E_layers, gt=tuple(x.data_ptr() for x in (q_gt, t_gt, delta)), **{k: r[k] for k in ("q_l2", "t_l2", "ang", "m_q", "o_q", "m_t", "o_t")})
     else:
         # without the ground truth the pose part cannot ride along: the stand-alone F-loss kernel, whose adjoint takes the
         # gradient w.r.t. the E matrices that get_Rt_loss's pose kernel sends back (any number M of virtual points)
         loss_sum, E_layers = ops.floss(F_layers, T1, T2, Ks, pts1_virt_ori, pts2_virt_ori, loss_params["clamp_at"])
-    per_pair = loss_sum * (1.0 / float(M))  # losses.mean(dim=1) per layer  [L,B]
-    layer_means = per_pair.mean(dim=1)      # losses.mean() per layer (:343-354)
-    loss_layers = list(layer_means.unbind(0))
-    loss_F_all = layer_means.mean()         # sum(loss_layers) / len(loss_layers) (:364)
+        ((m_loss, o_loss), _, _, (m_epi, o_epi)), row_min, col_min = ops.loss_stats(
+            [(loss_sum, 1.0 / M), None, None, None if epidot is None else (epidot, 1.0 / N_pts)], want_min=True)
+    loss_layers = list(m_loss.unbind(0))  # losses.mean() per layer (:343-354)
+    loss_F_all = o_loss                   # sum(loss_layers) / len(loss_layers) (:364)
     E_ests_layers = list(ops.unstack_rows(E_layers))
     same_T = T1 is T2 or (T1.data_ptr() == T2.data_ptr() and T1.stride() == T2.stride() and T1.shape == T2.shape)
     if same_T and T1.dim() == 3:
-        F_ests = ops.congruence_diff(F_est_normalized, T1.contiguous() if T1.stride(0) != 0 else T1.expand(B, 3, 3).contiguous())
+        F_ests = ops.congruence_diff(F_est_normalized, _dense_T(T1, B))
     else:
         F_ests = T2.permute(0, 2, 1) @ F_est_normalized @ T1
     if len(out_layers) >= depth and F_est_normalized is out_layers[depth - 1]:
@@ -159,19 +195,14 @@ def get_all_loss_DeepF(outs, pts1_virt_ori, pts2_virt_ori, Ks, loss_params, get_
     losses_dict = {
         "loss_layers": loss_layers,
         "loss_F": loss_F_all,
-        "loss_min_layers": per_pair.min(dim=1)[0],
-        "loss_min_batch": per_pair.min(dim=0)[0],
+        "loss_min_layers": row_min,  # per_pair.min(dim=1)[0] (:375); these two carry no gradient here (logged only)
+        "loss_min_batch": col_min,   # per_pair.min(dim=0)[0] (:376)
     }
     loss_epi_res_all = 0.0
     loss_epi_res_layers = []
-    if depth > 1:
-        n = min(len(outs["epi_res_layers"]), len(outs["weights_layers"]))  # zip() of the reference (:429-438)
-        if n > 0:
-            epi = ops.stack_rows(outs["epi_res_layers"][:n])
-            w = ops.stack_rows(outs["weights_layers"][:n])
-            means = (epi * w).flatten(1).mean(dim=1)
-            loss_epi_res_layers = list(means.unbind(0))
-            loss_epi_res_all = means.mean()
+    if m_epi is not None:
+        loss_epi_res_layers = list(m_epi.unbind(0))
+        loss_epi_res_all = o_epi
     losses_dict.update({"loss_epi_res_layers": loss_epi_res_layers, "loss_epi_res": loss_epi_res_all})
 
     residual_norm_layers, residual_norm_max_layers = None, None
@@ -216,16 +247,15 @@ def get_Rt_loss(E_ests_layers, Ks_cpu, x1_cpu, x2_cpu, delta_Rtijs_4_4_cpu, qs_c
     q_gt, t_gt = torch.as_tensor(qs_cam).to(dev), torch.as_tensor(ts_cam).to(dev)
     delta = torch.as_tensor(delta_Rtijs_4_4_cpu).to(dev)
     lt = _last_tail
+    L = E_layers.shape[0]
     if lt and lt["E"].data_ptr() == E_layers.data_ptr() and lt["E"].shape == E_layers.shape and lt["gt"] == tuple(x.data_ptr() for x in (q_gt, t_gt, delta)):
-        qt, q_l2, t_l2, ang = lt["qt"], lt["q_l2"], lt["t_l2"], lt["ang"]  # formed by the launch of get_all_loss_DeepF
+        q_l2, t_l2, ang, m_q, o_q, m_t, o_t = (lt[k] for k in ("q_l2", "t_l2", "ang", "m_q", "o_q", "m_t", "o_t"))  # get_all_loss_DeepF's launches
     else:
         R_gt = ops.camera_rotation(delta)
-        qt, q_l2, t_l2, ang, _ = ops.pose_errors_packed(E_layers, q_gt, t_gt, R_gt)
-    L = E_layers.shape[0]
+        _, q_l2, t_l2, ang, _ = ops.pose_errors_packed(E_layers, q_gt, t_gt, R_gt)
+        ((m_q, o_q), (m_t, o_t), _, _), _, _ = ops.loss_stats([(q_l2, 1.0), (t_l2, 1.0)])
     t_l2_layers = list(ops.unstack_rows(t_l2))
     q_l2_layers = list(ops.unstack_rows(q_l2))
-    layer_means = qt.mean(dim=2)    # [2,L]: x.mean() of every layer, q then t
-    overall = layer_means.mean(dim=1)  # mean_list over the layers
     host = _HostCopy(ang)
     R_layers = [_Lazy(lambda i=i: host.get()[0, i]) for i in range(L)]
     t_layers = [_Lazy(lambda i=i: host.get()[1, i]) for i in range(L)]
@@ -233,11 +263,11 @@ def get_Rt_loss(E_ests_layers, Ks_cpu, x1_cpu, x2_cpu, delta_Rtijs_4_4_cpu, qs_c
     tA_list = _Lazy(lambda: np.array([float(host.get()[1, i].mean()) for i in range(L)]))
     R_mean = _Lazy(lambda: mean_list([float(host.get()[0, i].mean()) for i in range(L)]))
     tA_mean = _Lazy(lambda: mean_list([float(host.get()[1, i].mean()) for i in range(L)]))
-    out = {
-        "t_l2_error_mean": overall[1],
-        "q_l2_error_mean": overall[0],
-        "t_l2_error_list": layer_means[1],
-        "q_l2_error_list": layer_means[1],  # sic: reference train_good_utils.py:276
+    out = _GeoErrors({
+        "t_l2_error_mean": o_t,      # mean_list of the per-layer means (:272-273)
+        "q_l2_error_mean": o_q,
+        "t_l2_error_list": m_t,
+        "q_l2_error_list": m_t,      # sic: reference train_good_utils.py:276
         "R_angle_error_mean": R_mean,
         "R_angle_error_list": R_list,
         "t_angle_error_mean": tA_mean,
@@ -246,7 +276,7 @@ def get_Rt_loss(E_ests_layers, Ks_cpu, x1_cpu, x2_cpu, delta_Rtijs_4_4_cpu, qs_c
         "t_angle_error_layers_list": t_layers,
         "t_l2_error_layers_list": t_l2_layers,
         "q_l2_error_layers_list": q_l2_layers,
-    }
+    })
     if not LAZY_HOST_METRICS and not torch.cuda.is_current_stream_capturing():
         for k in ("R_angle_error_mean", "t_angle_error_mean"):
             out[k] = float(out[k]._v())
@@ -255,7 +285,7 @@ def get_Rt_loss(E_ests_layers, Ks_cpu, x1_cpu, x2_cpu, delta_Rtijs_4_4_cpu, qs_c
         for k in ("R_angle_error_layers_list", "t_angle_error_layers_list"):
             out[k] = [np.asarray(x._v()) for x in out[k]]
     else:
-        out["_host_metrics"] = host  # .refresh() after a graph replay rewrote the device buffer
+        out.host_metrics = host  # .refresh() after a graph replay rewrote the device buffer
     return out
 
 

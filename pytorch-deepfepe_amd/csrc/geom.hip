@@ -246,7 +246,8 @@ cheirality_kernel(const float* __restrict__ E, const float* __restrict__ pre, co
 // ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 deepf_input_kernel(const float4* __restrict__ matches, const float* __restrict__ quality, int B, int N, int Q, float sx, float sy,
-                   float* __restrict__ weight_in, int C_out, float* __restrict__ pts1, float* __restrict__ pts2) {
+                   float* __restrict__ weight_in, size_t channel_stride, size_t batch_stride, int n_copies, size_t copy_stride,
+                   float* __restrict__ pts1, float* __restrict__ pts2) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)B * N) return;
   const size_t b = idx / (size_t)N;
@@ -258,23 +259,26 @@ deepf_input_kernel(const float4* __restrict__ matches, const float* __restrict__
   if (pts2 != nullptr) { pts2[idx * 3] = x2; pts2[idx * 3 + 1] = y2; pts2[idx * 3 + 2] = 1.0f; }
   if (weight_in == nullptr) return;
   const float c0 = (x1 + 1.0f) * 0.5f, c1 = (y1 + 1.0f) * 0.5f, c2 = (x2 + 1.0f) * 0.5f, c3 = (y2 + 1.0f) * 0.5f;  // (:375-378)
-  float* w = weight_in + b * (size_t)C_out * N + i;
-  w[0] = c0; w[(size_t)N] = c1; w[2 * (size_t)N] = c2; w[3 * (size_t)N] = c3;
-  for (int q = 0; q < Q; ++q) w[(size_t)(4 + q) * N] = quality[idx * Q + q];
+  for (int k = 0; k < n_copies; ++k) {
+    float* w = weight_in + (size_t)k * copy_stride + b * batch_stride + i;
+    w[0] = c0; w[channel_stride] = c1; w[2 * channel_stride] = c2; w[3 * channel_stride] = c3;
+    for (int q = 0; q < Q; ++q) w[(size_t)(4 + q) * channel_stride] = quality[idx * Q + q];
+  }
 }
 
 }  // namespace
 
 extern "C" int dfepe_deepf_input(const float* matches, const float* quality, int B, int N, int Q, float image_w, float image_h,
-                                 float* weight_in, int C_out, float* pts1, float* pts2, void* stream) {
+                                 float* weight_in, size_t channel_stride, size_t batch_stride, int n_copies, size_t copy_stride,
+                                 float* pts1, float* pts2, void* stream) {
   if (B < 0 || N <= 0 || Q < 0 || !(image_w > 0.f) || !(image_h > 0.f)) return DFEPE_ERR_INVALID_ARG;
   if (B == 0) return DFEPE_OK;
   if (!matches || (Q > 0 && !quality) || (reinterpret_cast<uintptr_t>(matches) & 15u)) return DFEPE_ERR_INVALID_ARG;
-  if (weight_in && C_out < 4 + Q) return DFEPE_ERR_INVALID_ARG;
+  if (weight_in && (n_copies < 1 || channel_stride < 1 || batch_stride < 1)) return DFEPE_ERR_INVALID_ARG;
   const size_t n = (size_t)B * N;
   hipLaunchKernelGGL(deepf_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     reinterpret_cast<const float4*>(matches), quality, B, N, Q, 2.0f / image_w, 2.0f / image_h, weight_in, C_out,
-                     pts1, pts2);
+                     reinterpret_cast<const float4*>(matches), quality, B, N, Q, 2.0f / image_w, 2.0f / image_h, weight_in,
+                     channel_stride, batch_stride, n_copies, copy_stride, pts1, pts2);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 

@@ -83,20 +83,91 @@ __global__ void __launch_bounds__(192) loss_tail_head_desc_kernel(const TailHead
 }
 
 // d loss / dF of every (layer, pair) from the Jacobians of a dfepe_loss_tail_jac launch and whatever upstream gradients the
-// caller's own loss mixing produced: one thread per matrix entry.
+// caller's own loss mixing produced: one thread per matrix entry.  Upstream per element (g_ls, g_q, g_t: [L,B]) and / or per
+// statistic of dfepe_loss_stats (m_*: [L] gradients of the row means, o_*: [1] gradient of the mean of the row means; a gradient g
+// on the mean of row l is g / B on each of its elements, one on the mean of the row means g / (L B)).
 __global__ void __launch_bounds__(256)
-loss_tail_bwd_kernel(const float* __restrict__ J, size_t n_items, const float* __restrict__ g_ls, const float* __restrict__ g_q,
-                     const float* __restrict__ g_t, float* __restrict__ g_F) {
+loss_tail_bwd_kernel(const float* __restrict__ J, int L, int B, const float* __restrict__ g_ls, const float* __restrict__ g_q,
+                     const float* __restrict__ g_t, const float* __restrict__ m_ls, const float* __restrict__ o_ls,
+                     const float* __restrict__ m_q, const float* __restrict__ o_q, const float* __restrict__ m_t,
+                     const float* __restrict__ o_t, float scale_ls, float* __restrict__ g_F) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n_items = (size_t)L * B;
   if (idx >= n_items * 9) return;
   const size_t item = idx / 9;
   const int c = (int)(idx - item * 9);
+  const int l = (int)(item / (size_t)B);
   const float* j = J + item * 27 + c;
-  float g = 0.0f;
-  if (g_ls != nullptr) g = g_ls[item] * j[0];
-  if (g_q != nullptr) g = fmaf(g_q[item], j[9], g);
-  if (g_t != nullptr) g = fmaf(g_t[item], j[18], g);
-  g_F[idx] = g;
+  const float invB = 1.0f / (float)B, invL = 1.0f / (float)L;
+  // gradient of an element = its own + (that of its row's mean + that of the mean of the row means / L) / B
+  auto stat = [&](const float* m, const float* o) { return ((m != nullptr) ? m[l] : 0.0f) + ((o != nullptr) ? o[0] * invL : 0.0f); };
+  const float a = fmaf(stat(m_ls, o_ls), scale_ls * invB, (g_ls != nullptr) ? g_ls[item] : 0.0f);
+  const float q = fmaf(stat(m_q, o_q), invB, (g_q != nullptr) ? g_q[item] : 0.0f);
+  const float t = fmaf(stat(m_t, o_t), invB, (g_t != nullptr) ? g_t[item] : 0.0f);
+  g_F[idx] = fmaf(a, j[0], fmaf(q, j[9], t * j[18]));
+}
+
+// ---- batch statistics of the per-pair loss terms: the means (and minima) get_all_loss_DeepF / get_Rt_loss return ------------
+// Up to four sets of rows [R_k, C] (C = pairs); one 1024-thread workgroup per set walks its rows: row means (times the set's
+// scale), the mean of the row means, for set 0 also the row minima and the column minima.  Fixed order of additions (thread t
+// adds columns t, t + 1024, ... in fp64, wavefront sums, then the sixteen wavefront totals in order): deterministic.
+struct StatSets {
+  const float* x[4];
+  int rows[4];
+  float scale[4];
+};
+constexpr int kStatMaxRows = 64;
+
+__global__ void __launch_bounds__(1024)
+loss_stats_kernel(const StatSets S, int C, float* __restrict__ out, float* __restrict__ row_min, float* __restrict__ col_min) {
+  __shared__ double wsum[16];
+  __shared__ float wmin[16];
+  __shared__ double rowmean[kStatMaxRows];
+  const int k = (int)blockIdx.x;
+  const int R = S.rows[k];
+  if (R <= 0) return;
+  int off = 0;
+  for (int j = 0; j < k; ++j) off += (S.rows[j] > 0) ? S.rows[j] + 1 : 0;
+  const float* x = S.x[k];
+  const double scale = (double)S.scale[k];
+  const int t = (int)threadIdx.x, wave = t >> 6, lane = t & 63;
+  const bool mins = (k == 0) && (row_min != nullptr || col_min != nullptr);
+  for (int r = 0; r < R; ++r) {
+    const float* row = x + (size_t)r * C;
+    double acc = 0.0;
+    float mn = INFINITY;
+    for (int c = t; c < C; c += 1024) {
+      const float v = row[c];
+      acc += (double)v;
+      if (mins) {
+        mn = fminf(mn, v);
+        if (col_min != nullptr) {
+          const float sv = (float)((double)v * scale);
+          col_min[c] = (r == 0) ? sv : fminf(col_min[c], sv);  // the same thread owns column c in every row
+        }
+      }
+    }
+    acc = wave_sum(acc);
+    if (mins) mn = -wave_max(-mn);
+    if (lane == 0) { wsum[wave] = acc; wmin[wave] = mn; }
+    __syncthreads();
+    if (t == 0) {
+      double s = 0.0;
+      float m = INFINITY;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) { s += wsum[w]; m = fminf(m, wmin[w]); }
+      const double mean = s * scale / (double)C;
+      rowmean[r] = mean;
+      out[off + r] = (float)mean;
+      if (mins && row_min != nullptr) row_min[r] = (float)((double)m * scale);
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    double s = 0.0;
+    for (int r = 0; r < R; ++r) s += rowmean[r];
+    out[off + R] = (float)(s / (double)R);
+  }
 }
 
 }  // namespace
@@ -188,12 +259,31 @@ extern "C" int dfepe_loss_tail_jac(const float* F_layers, int L, int B, const fl
 }
 
 extern "C" int dfepe_loss_tail_bwd(const float* J, int L, int B, const float* g_loss_sum, const float* g_q_l2, const float* g_t_l2,
-                                   float* g_F_layers, void* stream) {
+                                   const float* g_mean_loss, const float* g_all_loss, const float* g_mean_q, const float* g_all_q,
+                                   const float* g_mean_t, const float* g_all_t, float stat_loss_scale, float* g_F_layers,
+                                   void* stream) {
   if (L <= 0 || B < 0) return DFEPE_ERR_INVALID_ARG;
   if (B == 0) return DFEPE_OK;
   if (!J || !g_F_layers) return DFEPE_ERR_INVALID_ARG;
   const size_t n = (size_t)L * B;
-  hipLaunchKernelGGL(loss_tail_bwd_kernel, dim3((unsigned)((n * 9 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), J, n,
-                     g_loss_sum, g_q_l2, g_t_l2, g_F_layers);
+  hipLaunchKernelGGL(loss_tail_bwd_kernel, dim3((unsigned)((n * 9 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), J, L, B,
+                     g_loss_sum, g_q_l2, g_t_l2, g_mean_loss, g_all_loss, g_mean_q, g_all_q, g_mean_t, g_all_t, stat_loss_scale, g_F_layers);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+extern "C" int dfepe_loss_stats(const float* x0, int rows0, float scale0, const float* x1, int rows1, float scale1, const float* x2,
+                                int rows2, float scale2, const float* x3, int rows3, float scale3, int C, float* out,
+                                float* row_min0, float* col_min0, void* stream) {
+  if (C <= 0 || !out) return DFEPE_ERR_INVALID_ARG;
+  StatSets S;
+  const float* xs[4] = {x0, x1, x2, x3};
+  const int rs[4] = {rows0, rows1, rows2, rows3};
+  const float sc[4] = {scale0, scale1, scale2, scale3};
+  for (int k = 0; k < 4; ++k) {
+    if (rs[k] < 0 || rs[k] > kStatMaxRows || (rs[k] > 0 && !xs[k])) return DFEPE_ERR_INVALID_ARG;
+    S.x[k] = xs[k]; S.rows[k] = rs[k]; S.scale[k] = sc[k];
+  }
+  if ((row_min0 || col_min0) && rows0 <= 0) return DFEPE_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(loss_stats_kernel, dim3(4), dim3(1024), 0, static_cast<hipStream_t>(stream), S, C, out, row_min0, col_min0);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }

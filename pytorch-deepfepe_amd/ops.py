@@ -55,8 +55,9 @@ def row_of(stack: Tensor, l: int) -> Tensor:
 
 
 def alias_rows(rows) -> Optional[Tensor]:
-    """[len(rows), *shape] tensor over the memory of ``rows`` when they are equally shaped contiguous tensors lying back to
-    back in one buffer, in order; None otherwise (the caller then copies)."""
+    """[len(rows), *shape] tensor over the memory of ``rows`` when they are equally shaped contiguous tensors lying at a uniform
+    distance from each other in one buffer, in order (back to back: the result is contiguous; further apart -- e.g. the same
+    channel of consecutive per-layer buffers -- it is a strided view); None otherwise (the caller then copies)."""
     if len(rows) == 0 or rows[0] is None:
         return None
     r0 = rows[0]
@@ -64,12 +65,15 @@ def alias_rows(rows) -> Optional[Tensor]:
     if n == 0:
         return None
     base = r0.untyped_storage().data_ptr()
+    step = n if len(rows) == 1 else (rows[1].storage_offset() - r0.storage_offset() if rows[1] is not None else -1)
+    if step < n:
+        return None
     for l, r in enumerate(rows):
         if (r is None or r.shape != r0.shape or r.dtype != r0.dtype or r.device != r0.device or not r.is_contiguous()
-                or r.untyped_storage().data_ptr() != base or r.storage_offset() != r0.storage_offset() + l * n):
+                or r.untyped_storage().data_ptr() != base or r.storage_offset() != r0.storage_offset() + l * step):
             return None
     t = torch.empty(0, dtype=r0.dtype, device=r0.device)
-    t.set_(r0.untyped_storage(), r0.storage_offset(), (len(rows),) + tuple(r0.shape), None)
+    t.set_(r0.untyped_storage(), r0.storage_offset(), (len(rows),) + tuple(r0.shape), (step,) + tuple(r0.stride()))
     return t
 
 
@@ -426,14 +430,100 @@ def pose_errors_packed(E_layers: Tensor, q_gt: Tensor, t_gt: Tensor, R_gt: Tenso
     return _PoseFunction.apply(*_pose_args(E_layers, q_gt, t_gt, R_gt))
 
 
-class _TailJacFunction(torch.autograd.Function):
-    """get_all_loss_DeepF's per-layer body and get_Rt_loss's loop as ONE launch (dfepe_loss_tail_jac) with a one-launch adjoint
-    for whatever upstream gradients arrive (dfepe_loss_tail_bwd): the reference's callers mix clamps and balances themselves
-    (Train_model_pipeline.py:580-586), so no coefficient is baked in.  Outputs: loss_sum [L,B], E_layers [L,B,3,3], and -- with
-    ground truth -- qt [2,L,B], q_l2, t_l2, ang [2,L,B], sel as in _PoseFunction."""
+def _slice_of(buf: Tensor, off: int, n: int) -> Tensor:
+    """buf[off:off+n] of a contiguous 1-D buffer as a tensor of its own over the same memory (not an autograd view)."""
+    t = torch.empty(0, dtype=buf.dtype, device=buf.device)
+    t.set_(buf.untyped_storage(), buf.storage_offset() + off, (n,), None)
+    return t
+
+
+def _stats_launch(sets, C: int, want_min: bool):
+    """sets: four (tensor [R,C] | None, scale).  One dfepe_loss_stats launch -> (per set: (means [R_k], overall [] scalar) over one
+    buffer, or (None, None); row_min; col_min)."""
+    dev = next(x for x, _ in sets if x is not None).device
+    total = sum(x.shape[0] + 1 for x, _ in sets if x is not None)
+    out = torch.empty(total, device=dev, dtype=torch.float32)
+    x0 = sets[0][0]
+    row_min = torch.empty(x0.shape[0], device=dev, dtype=torch.float32) if want_min else None
+    col_min = torch.empty(C, device=dev, dtype=torch.float32) if want_min else None
+    args = []
+    for x, sc in sets:
+        args += [_ptr(x), 0 if x is None else x.shape[0], float(sc)]
+    with torch.cuda.device(dev):
+        rc = _lib.lib().dfepe_loss_stats(*args, C, _ptr(out), _ptr(row_min), _ptr(col_min), _stream())
+    _lib.check(rc, "dfepe_loss_stats")
+    blocks, off = [], 0
+    for x, _ in sets:
+        if x is None:
+            blocks.append((None, None))
+        else:
+            R = x.shape[0]
+            blocks.append((_slice_of(out, off, R), _slice_of(out, off + R, 1).view(())))
+            off += R + 1
+    return blocks, row_min, col_min
+
+
+def _stat_block_grad(gm: Optional[Tensor], go: Optional[Tensor], R: int, C: int, scale: float) -> Optional[Tensor]:
+    """Gradient w.r.t. the [R,C] rows of a dfepe_loss_stats set from the gradients of its R row means and of their mean."""
+    if gm is None and go is None:
+        return None
+    coef = _sum_opt(gm, None if go is None else (go * (1.0 / R)).reshape(1).expand(R)) * (scale / C)
+    return coef.unsqueeze(1).expand(R, C)
+
+
+class _LossStatsFunction(torch.autograd.Function):
+    """dfepe_loss_stats as a differentiable op on up to four [R_k, C] row sets (set 0 optionally with its minima, which carry no
+    gradient).  Outputs: (means [R_k], overall scalar) per set (None, None for absent sets), then row_min, col_min."""
 
     @staticmethod
-    def forward(ctx, F_layers, T1c, T2c, t_stride, K, virt1, virt2, clamp_at, q_gt, t_gt, R_gt, want_floss_jac):
+    def forward(ctx, want_min, x0, s0, x1, s1, x2, s2, x3, s3):
+        ctx.set_materialize_grads(False)
+        sets = [(x0, s0), (x1, s1), (x2, s2), (x3, s3)]
+        C = x0.shape[1]
+        ctx.meta = [(None if x is None else x.shape[0], float(sc)) for x, sc in sets]
+        ctx.C = C
+        blocks, row_min, col_min = _stats_launch(sets, C, want_min)
+        if want_min:
+            ctx.mark_non_differentiable(row_min, col_min)
+        return tuple(t for blk in blocks for t in blk) + (row_min, col_min)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        out = [None]
+        for k, (R, sc) in enumerate(ctx.meta):
+            out += [None if R is None else _stat_block_grad(gs[2 * k], gs[2 * k + 1], R, ctx.C, sc), None]
+        return tuple(out)
+
+
+def loss_stats(sets, want_min: bool = False):
+    """sets: up to four (x [R,C], scale) pairs (None for an absent set), the first one present.  Returns (blocks, row_min, col_min):
+    blocks[k] = (means [R_k] = scale_k * mean over C of every row, overall = the mean of those) or (None, None); the minima
+    (set 0, times scale_0, no gradient) only with want_min."""
+    sets = list(sets) + [None] * (4 - len(sets))
+    flat = []
+    C = sets[0][0].shape[1]
+    for s in sets:
+        if s is None:
+            flat += [None, 0.0]
+        else:
+            x = _prep(s[0], "rows")
+            _shape(x, "rows", None, C)
+            flat += [x, float(s[1])]
+    res = _LossStatsFunction.apply(bool(want_min), *flat)
+    return [(res[2 * k], res[2 * k + 1]) for k in range(4)], res[8], res[9]
+
+
+class _TailJacFunction(torch.autograd.Function):
+    """get_all_loss_DeepF's per-layer body and get_Rt_loss's loop as ONE launch (dfepe_loss_tail_jac) plus ONE for every batch
+    statistic the two functions return (dfepe_loss_stats), with a one-launch adjoint for whatever upstream gradients arrive
+    (dfepe_loss_tail_bwd): the reference's callers mix clamps and balances themselves (Train_model_pipeline.py:580-586), so no
+    coefficient is baked in.  Outputs (None where absent): loss_sum [L,B], E_layers [L,B,3,3], m_loss [L] / o_loss [] (per-layer
+    means of loss_sum / M and loss_F), row_min [L], col_min [B] (loss_min_layers / loss_min_batch), m_x / o_x (statistics of the
+    optional fourth row set ``extra`` [n,B]), and -- with ground truth -- qt [2,L,B], q_l2, t_l2, ang [2,L,B], sel as in
+    _PoseFunction, m_q / o_q, m_t / o_t."""
+
+    @staticmethod
+    def forward(ctx, F_layers, T1c, T2c, t_stride, K, virt1, virt2, clamp_at, q_gt, t_gt, R_gt, want_floss_jac, extra, extra_scale):
         lib = _lib.lib()
         L, B = F_layers.shape[0], F_layers.shape[1]
         M = virt1.shape[1]
@@ -454,32 +544,35 @@ class _TailJacFunction(torch.autograd.Function):
                                          _ptr(E_layers), _ptr(q_l2), _ptr(t_l2), _ptr(ang[0]) if pose else None,
                                          _ptr(ang[1]) if pose else None, _ptr(sel), _ptr(J), _stream())
         _lib.check(rc, "dfepe_loss_tail_jac")
+        ((m_loss, o_loss), (m_q, o_q), (m_t, o_t), (m_x, o_x)), row_min, col_min = _stats_launch(
+            [(loss_sum, 1.0 / M), (q_l2, 1.0), (t_l2, 1.0), (extra, extra_scale)], B, True)
         ctx.save_for_backward(J, F_layers, T1c, T2c, K, virt1, virt2)
-        ctx.cfg = (t_stride, float(clamp_at), bool(want_floss_jac))
+        ctx.cfg = (t_stride, float(clamp_at), bool(want_floss_jac), 1.0 / M, None if extra is None else (extra.shape[0], float(extra_scale)))
+        ctx.mark_non_differentiable(row_min, col_min)
         if pose:
             ctx.mark_non_differentiable(ang, sel)
-            return loss_sum, E_layers, qt, q_l2, t_l2, ang, sel
-        return loss_sum, E_layers
+        return loss_sum, E_layers, m_loss, o_loss, row_min, col_min, m_x, o_x, qt, q_l2, t_l2, ang, sel, m_q, o_q, m_t, o_t
 
     @staticmethod
-    def backward(ctx, g_loss_sum, g_E, g_qt=None, g_q=None, g_t=None, _a=None, _b=None):
+    def backward(ctx, g_loss_sum, g_E, gm_loss, go_loss, _rm, _cm, gm_x, go_x, g_qt, g_q, g_t, _a, _b, gm_q, go_q, gm_t, go_t):
         J, F_layers, T1c, T2c, K, virt1, virt2 = ctx.saved_tensors
-        t_stride, clamp_at, want_floss_jac = ctx.cfg
+        t_stride, clamp_at, want_floss_jac, loss_scale, extra_meta = ctx.cfg
         lib = _lib.lib()
         L, B = J.shape[0], J.shape[1]
         if g_qt is not None:
             g_qt = g_qt.contiguous().float()
             g_q, g_t = _sum_opt(g_q, g_qt[0]), _sum_opt(g_t, g_qt[1])
-        if g_loss_sum is None and g_E is None and g_q is None and g_t is None:
-            return (None,) * 12
-        if g_loss_sum is not None and not want_floss_jac:
+        g_extra = None if extra_meta is None else _stat_block_grad(gm_x, go_x, extra_meta[0], B, extra_meta[1])
+        if all(g is None for g in (g_loss_sum, g_E, g_q, g_t, gm_loss, go_loss, gm_q, go_q, gm_t, go_t)):
+            return (None,) * 12 + (g_extra, None)
+        if (g_loss_sum is not None or gm_loss is not None or go_loss is not None) and not want_floss_jac:
             raise _lib.DfepeError("the F-loss Jacobian was switched off for this call (loss_params['floss_grad'] = False) but a gradient "
                                   "arrived on loss_F / loss_layers")
         c = lambda g: None if g is None else g.contiguous().float()
-        g_loss_sum, g_q, g_t = c(g_loss_sum), c(g_q), c(g_t)
         gF = torch.empty(L, B, 3, 3, device=J.device, dtype=torch.float32)
         with torch.cuda.device(J.device):
-            rc = lib.dfepe_loss_tail_bwd(_ptr(J), L, B, _ptr(g_loss_sum), _ptr(g_q), _ptr(g_t), _ptr(gF), _stream())
+            rc = lib.dfepe_loss_tail_bwd(_ptr(J), L, B, _ptr(c(g_loss_sum)), _ptr(c(g_q)), _ptr(c(g_t)), _ptr(c(gm_loss)), _ptr(c(go_loss)),
+                                         _ptr(c(gm_q)), _ptr(c(go_q)), _ptr(c(gm_t)), _ptr(c(go_t)), float(loss_scale), _ptr(gF), _stream())
             _lib.check(rc, "dfepe_loss_tail_bwd")
             if g_E is not None:  # a gradient on the E matrices themselves (none of the reference's losses has one): the stand-alone adjoint
                 gF2 = torch.empty_like(gF)
@@ -487,7 +580,7 @@ class _TailJacFunction(torch.autograd.Function):
                                          virt1.shape[1], clamp_at, None, 0.0, None, _ptr(c(g_E)), _ptr(gF2), _stream())
                 _lib.check(rc, "dfepe_floss_bwd")
                 gF = gF + gF2
-        return (gF,) + (None,) * 11
+        return (gF,) + (None,) * 11 + (g_extra, None)
 
 
 def _floss_args(F_layers, T1, T2, K, virt1, virt2):
@@ -508,14 +601,24 @@ def _floss_args(F_layers, T1, T2, K, virt1, virt2):
 
 
 def loss_tail_jac(F_layers: Tensor, T1: Tensor, T2: Tensor, K: Tensor, virt1: Tensor, virt2: Tensor, clamp_at: float,
-                  q_gt: Optional[Tensor] = None, t_gt: Optional[Tensor] = None, R_gt: Optional[Tensor] = None, floss_grad: bool = True):
-    """F-loss sums + E-from-F (+ pose errors when the ground truth is given) of every layer in one launch, differentiable for any
-    upstream gradients.  Returns (loss_sum, E_layers) or (loss_sum, E_layers, qt, q_l2, t_l2, ang, sel) (see _TailJacFunction).
+                  q_gt: Optional[Tensor] = None, t_gt: Optional[Tensor] = None, R_gt: Optional[Tensor] = None, floss_grad: bool = True,
+                  extra: Optional[Tensor] = None, extra_scale: float = 1.0) -> dict:
+    """F-loss sums + E-from-F (+ pose errors when the ground truth is given) of every layer in one launch and every batch
+    statistic of them in a second one, differentiable for any upstream gradients.  Returns a dict: loss_sum [L,B], E_layers,
+    m_loss [L] / o_loss (per-layer means of loss_sum / M, their mean), row_min [L], col_min [B], m_extra / o_extra (statistics of the
+    optional row set ``extra`` [n,B], times extra_scale) and, with ground truth, qt, q_l2, t_l2, ang, sel, m_q, o_q, m_t, o_t.
     Needs M <= 112 virtual points (raises DfepeError 'unsupported' otherwise: use floss + pose_errors)."""
     F_layers, T1c, T2c, st, K, virt1, virt2 = _floss_args(F_layers, T1, T2, K, virt1, virt2)
     if q_gt is not None:
         _, q_gt, t_gt, R_gt = _pose_args(F_layers, q_gt, t_gt, R_gt)
-    return _TailJacFunction.apply(F_layers, T1c, T2c, st, K, virt1, virt2, float(clamp_at), q_gt, t_gt, R_gt, bool(floss_grad))
+    if extra is not None:
+        extra = _prep(extra, "extra")
+        _shape(extra, "extra rows", None, F_layers.shape[1])
+    r = _TailJacFunction.apply(F_layers, T1c, T2c, st, K, virt1, virt2, float(clamp_at), q_gt, t_gt, R_gt, bool(floss_grad), extra,
+                               float(extra_scale))
+    keys = ("loss_sum", "E_layers", "m_loss", "o_loss", "row_min", "col_min", "m_extra", "o_extra", "qt", "q_l2", "t_l2", "ang", "sel",
+            "m_q", "o_q", "m_t", "o_t")
+    return dict(zip(keys, r))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -630,9 +733,13 @@ def camera_rotation(delta_4x4: Tensor) -> Tensor:
     return geo_misc(6, d.reshape(-1, 16)).reshape(-1, 3, 3)
 
 
-def deepf_input(matches: Tensor, image_w: float, image_h: float, quality: Optional[Tensor] = None, want_pts: bool = True):
+def deepf_input(matches: Tensor, image_w: float, image_h: float, quality: Optional[Tensor] = None, want_pts: bool = True,
+                recurrent_copies: int = 0, recurrent_channels: int = 3):
     """DeepFNet.get_input in one launch (DeepFNet.py:362-391): matches [B,N,4] pixels (+ quality [B,N,Q]) ->
-    (weight_in [B,4+Q,N], pts1 [B,N,3], pts2 [B,N,3]); not differentiable (the matches are data)."""
+    (weight_in [B,4+Q,N], pts1 [B,N,3], pts2 [B,N,3], stores); not differentiable (the matches are data).
+    ``recurrent_copies`` = n > 0: the same launch also fills the point (and quality) channels of n channel-major buffers
+    ``stores`` [n, 4+Q+recurrent_channels, B, N] -- the inputs of the later estimator calls (DeepFNet.py:484-489), whose remaining
+    channels the fit kernels write as plain [B,N] blocks; weight_in then is a [B,4+Q,N] view of one more such buffer."""
     m = _prep(matches, "matches")
     _shape(m, "matches (pixel x1,y1,x2,y2)", None, None, 4)
     B, N = m.shape[0], m.shape[1]
@@ -642,14 +749,50 @@ def deepf_input(matches: Tensor, image_w: float, image_h: float, quality: Option
         _shape(quality, "quality", B, N, None)
         Q = quality.shape[2]
     dev = m.device
-    w_in = torch.empty(B, 4 + Q, N, device=dev, dtype=torch.float32)
     p1 = torch.empty(B, N, 3, device=dev, dtype=torch.float32) if want_pts else None
     p2 = torch.empty(B, N, 3, device=dev, dtype=torch.float32) if want_pts else None
+    lib = _lib.lib()
+    if recurrent_copies > 0:
+        C = 4 + Q + recurrent_channels
+        buf = torch.empty(recurrent_copies + 1, C, B, N, device=dev, dtype=torch.float32)  # copy 0 serves the first estimator call
+        with torch.cuda.device(dev):
+            rc = lib.dfepe_deepf_input(_ptr(m), _ptr(quality), B, N, Q, float(image_w), float(image_h), _ptr(buf), B * N, N,
+                                       recurrent_copies + 1, C * B * N, _ptr(p1), _ptr(p2), _stream())
+        _lib.check(rc, "dfepe_deepf_input")
+        return buf[0, :4 + Q].permute(1, 0, 2), p1, p2, buf[1:]
+    w_in = torch.empty(B, 4 + Q, N, device=dev, dtype=torch.float32)
     with torch.cuda.device(dev):
-        rc = _lib.lib().dfepe_deepf_input(_ptr(m), _ptr(quality), B, N, Q, float(image_w), float(image_h), _ptr(w_in), 4 + Q, _ptr(p1), _ptr(p2),
-                                          _stream())
+        rc = lib.dfepe_deepf_input(_ptr(m), _ptr(quality), B, N, Q, float(image_w), float(image_h), _ptr(w_in), N, (4 + Q) * N, 1, 0,
+                                   _ptr(p1), _ptr(p2), _stream())
     _lib.check(rc, "dfepe_deepf_input")
-    return w_in, p1, p2
+    return w_in, p1, p2, None
+
+
+class _EstimatorInputFunction(torch.autograd.Function):
+    """The [B,C,N] input of an update_weights call (DeepFNet.py:484-489: cat of the point channels, weights, epipolar residual,
+    residual) WITHOUT the cat: ``store`` [C,B,N] already holds the point channels (deepf_input) and the three recurrent channels
+    (the fit kernel wrote its outputs there: ``rec`` are those very rows); the result is the channel-major buffer seen as [B,C,N].
+    Backward: the gradient's three recurrent channels go to the rows."""
+
+    @staticmethod
+    def forward(ctx, store, first, *rec):
+        ctx.first = first
+        out = torch.empty(0, dtype=store.dtype, device=store.device)
+        C, B, N = store.shape
+        out.set_(store.untyped_storage(), store.storage_offset(), (B, C, N), (N, B * N, 1))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None) + tuple(g[:, ctx.first + k, :] for k in range(g.shape[1] - ctx.first))
+
+
+def estimator_input(store: Tensor, first: int, rec_rows) -> Tensor:
+    """See _EstimatorInputFunction: store [C,B,N] channel-major, rec_rows = the [B,N] tensors living in store[first:], in order."""
+    for k, r in enumerate(rec_rows):
+        if r.data_ptr() != store[first + k].data_ptr() or r.shape != store.shape[1:]:
+            raise ValueError("estimator_input: the recurrent rows must be the channels of the store they were written into")
+    return _EstimatorInputFunction.apply(store, first, *rec_rows)
 
 
 def decompose_essential(E: Tensor):

@@ -96,7 +96,8 @@ def test_tail_jacobians_reproduce_the_standalone_adjoints_for_any_upstream(dfepe
         up = [torch.randn(L, B, generator=g).to(DEV) for _ in range(3)]
         for use in ((1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 1)):
             Fa = Fl.clone().requires_grad_(True)
-            ls, E, qt, q, t, ang, sel = dfepe.ops.loss_tail_jac(Fa, T, T, d["Ks"], d["pts1_virt_ori"], d["pts2_virt_ori"], 0.02, d["qs_cam"], d["ts_cam"], d["R_gt"])
+            r = dfepe.ops.loss_tail_jac(Fa, T, T, d["Ks"], d["pts1_virt_ori"], d["pts2_virt_ori"], 0.02, d["qs_cam"], d["ts_cam"], d["R_gt"])
+            ls, E, q, t, ang, sel = (r[k] for k in ("loss_sum", "E_layers", "q_l2", "t_l2", "ang", "sel"))
             Fb = Fl.clone().requires_grad_(True)
             ls2, E2 = dfepe.ops.floss(Fb, T, T, d["Ks"], d["pts1_virt_ori"], d["pts2_virt_ori"], 0.02)
             q2, t2, R2, t2d, sel2 = dfepe.ops.pose_errors(E2, d["qs_cam"], d["ts_cam"], d["R_gt"])
@@ -110,12 +111,31 @@ def test_tail_jacobians_reproduce_the_standalone_adjoints_for_any_upstream(dfepe
             assert float((Fa.grad - Fb.grad).abs().max()) < 2e-5 * scale, (M, use)
         # a gradient on E itself (no loss of the reference has one) takes the stand-alone adjoint on top
         Fa = Fl.clone().requires_grad_(True)
-        ls, E = dfepe.ops.loss_tail_jac(Fa, T, T, d["Ks"], d["pts1_virt_ori"], d["pts2_virt_ori"], 0.02)[:2]
+        r = dfepe.ops.loss_tail_jac(Fa, T, T, d["Ks"], d["pts1_virt_ori"], d["pts2_virt_ori"], 0.02)
+        ls, E = r["loss_sum"], r["E_layers"]
+        assert r["q_l2"] is None and r["m_q"] is None
         GE = torch.randn(L, B, 3, 3, generator=g).to(DEV)
         ((E * GE).sum() + (ls * up[0]).sum()).backward()
         Fb = Fl.clone().requires_grad_(True)
         ls2, E2 = dfepe.ops.floss(Fb, T, T, d["Ks"], d["pts1_virt_ori"], d["pts2_virt_ori"], 0.02)
         ((E2 * GE).sum() + (ls2 * up[0]).sum()).backward()
+        assert float((Fa.grad - Fb.grad).abs().max()) < 2e-5 * float(Fb.grad.abs().max())
+        # the batch statistics of the same launch pair, and gradients arriving on them (what loss_F / the per-layer means send back)
+        Fa = Fl.clone().requires_grad_(True)
+        r = dfepe.ops.loss_tail_jac(Fa, T, T, d["Ks"], d["pts1_virt_ori"], d["pts2_virt_ori"], 0.02, d["qs_cam"], d["ts_cam"], d["R_gt"])
+        Fb = Fl.clone().requires_grad_(True)
+        ls2, E2 = dfepe.ops.floss(Fb, T, T, d["Ks"], d["pts1_virt_ori"], d["pts2_virt_ori"], 0.02)
+        q2, t2 = dfepe.ops.pose_errors(E2, d["qs_cam"], d["ts_cam"], d["R_gt"])[:2]
+        pp = ls2 / M
+        np.testing.assert_allclose(r["m_loss"].detach().cpu().numpy(), pp.mean(1).detach().cpu().numpy(), rtol=2e-6)
+        np.testing.assert_allclose(r["o_loss"].item(), pp.mean(1).mean().item(), rtol=2e-6)
+        np.testing.assert_allclose(r["row_min"].cpu().numpy(), pp.min(1)[0].detach().cpu().numpy(), rtol=1e-6)
+        np.testing.assert_allclose(r["col_min"].cpu().numpy(), pp.min(0)[0].detach().cpu().numpy(), rtol=1e-6)
+        np.testing.assert_allclose(r["m_q"].detach().cpu().numpy(), q2.mean(1).detach().cpu().numpy(), rtol=2e-6)
+        np.testing.assert_allclose(r["o_t"].item(), t2.mean(1).mean().item(), rtol=2e-6)
+        cm, co = torch.randn(L, generator=g).to(DEV), 1.7
+        ((r["m_loss"] * cm).sum() + co * r["o_loss"] + 0.3 * r["o_q"] + (r["m_t"] * cm).sum() + (r["q_l2"] * up[1]).sum()).backward()
+        ((pp.mean(1) * cm).sum() + co * pp.mean(1).mean() + 0.3 * q2.mean(1).mean() + (t2.mean(1) * cm).sum() + (q2 * up[1]).sum()).backward()
         assert float((Fa.grad - Fb.grad).abs().max()) < 2e-5 * float(Fb.grad.abs().max())
     with pytest.raises(dfepe._lib.DfepeError, match="unsupported|not supported"):
         d = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(4, 20, seed=1, M_virt=120), DEV)
@@ -130,11 +150,24 @@ def test_input_kernel_and_camera_rotation_match_torch(dfepe):
     norm = dfepe.compat.DeepFNet.NormalizeAndExpand_HW(IMAGE_SIZE)
     p1, p2, T1, T2 = norm(m.to(DEV))
     for q in (None, qual.to(DEV)):
-        w_in, a, b = dfepe.ops.deepf_input(m.to(DEV), IMAGE_SIZE[1], IMAGE_SIZE[0], q)
-        np.testing.assert_allclose(a.cpu().numpy(), p1.permute(0, 2, 1).cpu().numpy(), atol=2e-7)
-        np.testing.assert_allclose(b.cpu().numpy(), p2.permute(0, 2, 1).cpu().numpy(), atol=2e-7)
         parts = [(p1.permute(0, 2, 1)[:, :, :2] + 1) / 2, (p2.permute(0, 2, 1)[:, :, :2] + 1) / 2] + ([] if q is None else [q])
-        np.testing.assert_allclose(w_in.cpu().numpy(), torch.cat(parts, 2).permute(0, 2, 1).cpu().numpy(), atol=2e-7)
+        want = torch.cat(parts, 2).permute(0, 2, 1).cpu().numpy()
+        for copies in (0, 3):
+            w_in, a, b, stores = dfepe.ops.deepf_input(m.to(DEV), IMAGE_SIZE[1], IMAGE_SIZE[0], q, recurrent_copies=copies)
+            np.testing.assert_allclose(a.cpu().numpy(), p1.permute(0, 2, 1).cpu().numpy(), atol=2e-7)
+            np.testing.assert_allclose(b.cpu().numpy(), p2.permute(0, 2, 1).cpu().numpy(), atol=2e-7)
+            np.testing.assert_allclose(w_in.cpu().numpy(), want, atol=2e-7)
+            if copies:  # channel-major buffers of the later estimator calls: point (+ quality) channels filled, three left to the fits
+                C = want.shape[1]
+                assert stores.shape == (copies, C + 3, B, N)
+                for k in range(copies):
+                    np.testing.assert_array_equal(stores[k, :C].permute(1, 0, 2).cpu().numpy(), w_in.cpu().numpy())
+                rows = [dfepe.ops.row_of(stores[1], C + j) for j in range(3)]
+                for j, r in enumerate(rows):
+                    r.fill_(float(j + 1))
+                x = dfepe.ops.estimator_input(stores[1], C, rows)
+                assert x.shape == (B, C + 3, N) and float(x[:, C + 2].min()) == 3.0 and float(x[:, C].max()) == 1.0
+                np.testing.assert_array_equal(x[:, :C].cpu().numpy(), w_in.cpu().numpy())
     net = dfepe.compat.DeepFNet.DeepFNet(depth=2, image_size=IMAGE_SIZE, if_quality=True, quality_size=2)
     w_in, a, b, T1n, T2n, pts = net.get_input({"matches_xy_ori": m.to(DEV), "quality": qual.to(DEV)})
     assert w_in.shape == (B, 6, N) and T1n.shape == (B, 3, 3) and torch.equal(T1n, T1.to(DEV)) and pts.shape == (B, N, 4)
@@ -188,7 +221,7 @@ def test_no_host_sync_and_graph_capture_of_the_api_step(dfepe):
     assert abs(state["loss"].item() - eager_loss) < 1e-7
     for a, b in zip(state["g"], eager_g):
         assert torch.equal(a, b)
-    geo["_host_metrics"].refresh()
+    geo.host_metrics.refresh()
     np.testing.assert_array_equal(np.asarray(geo["R_angle_error_layers_list"][-1]), eager_R)
     assert isinstance(float(geo["R_angle_error_mean"]), float) and np.isscalar(geo["t_angle_error_mean"])
 
@@ -216,3 +249,31 @@ def test_recurrent_backward_at_bench_size_vs_fp64_oracle(dfepe, oracle):
     per_pair = (ours - ref).norm(dim=1) / ref.norm(dim=1).clamp_min(1e-30)
     assert float(per_pair.median()) < 1e-5
     assert float(per_pair.kthvalue(int(0.98 * per_pair.numel()))[0]) < 2e-3
+
+
+def test_loss_stats_matches_torch_reductions_and_differentiates(dfepe):
+    g = torch.Generator().manual_seed(11)
+    for C in (1, 37, 4096, 5000):
+        xs = [torch.rand(R, C, generator=g).to(DEV).requires_grad_(True) for R in (5, 3, 16, 4)]
+        sc = (0.01, 1.0, 2.5, 0.1)
+        for present in ((0,), (0, 1, 2), (0, 3), (0, 1, 2, 3)):
+            sets = [(xs[k], sc[k]) if k in present else None for k in range(4)]
+            blocks, rmin, cmin = dfepe.ops.loss_stats(sets, want_min=True)
+            total = 0.0
+            ref = 0.0
+            for k in range(4):
+                if k not in present:
+                    assert blocks[k] == (None, None)
+                    continue
+                m, o = blocks[k]
+                want = xs[k].double().mean(1) * sc[k]
+                np.testing.assert_allclose(m.detach().cpu().numpy(), want.detach().cpu().numpy(), rtol=3e-7)
+                np.testing.assert_allclose(o.item(), want.mean().item(), rtol=3e-7)
+                total = total + (m * (k + 1.0)).sum() + 0.5 * o
+                ref = ref + (xs[k].mean(1) * sc[k] * (k + 1.0)).sum() + 0.5 * (xs[k].mean(1) * sc[k]).mean()
+            np.testing.assert_allclose(rmin.cpu().numpy(), (xs[0].min(1)[0] * sc[0]).detach().cpu().numpy(), rtol=1e-6)
+            np.testing.assert_allclose(cmin.cpu().numpy(), (xs[0].min(0)[0] * sc[0]).detach().cpu().numpy(), rtol=1e-6)
+            ga = torch.autograd.grad(total, [xs[k] for k in present])
+            gb = torch.autograd.grad(ref, [xs[k] for k in present])
+            for a, b in zip(ga, gb):
+                np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-12)

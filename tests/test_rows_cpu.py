@@ -17,7 +17,11 @@ def test_stack_rows_aliases_a_buffer_and_copies_otherwise(dfepe):
     assert all(r._base is None and r.data_ptr() == buf[l].data_ptr() and torch.equal(r, buf[l]) for l, r in enumerate(rows))
     a = ops.alias_rows(rows)
     assert a is not None and a.data_ptr() == buf.data_ptr() and a.shape == buf.shape and torch.equal(a, buf)
-    assert ops.alias_rows(rows[::-1]) is None and ops.alias_rows([rows[0], rows[2]]) is None  # order / gaps
+    assert ops.alias_rows(rows[::-1]) is None  # order
+    big = torch.arange(48.0).reshape(6, 2, 4).clone()
+    every_other = ops.alias_rows([ops.row_of(big, l) for l in (0, 2, 4)])  # a uniform distance: a strided stack (the same channel
+    assert every_other is not None and not every_other.is_contiguous() and torch.equal(every_other, big[::2])  # of consecutive buffers)
+    assert ops.alias_rows([ops.row_of(big, l) for l in (0, 2, 5)]) is None  # uneven distances
     assert ops.alias_rows([rows[0], torch.zeros(2, 4)]) is None and ops.alias_rows([rows[0], rows[1].double()]) is None
     assert ops.alias_rows([buf[:, :, :2][0], buf[:, :, :2][1]]) is None  # non-contiguous rows
     assert ops.alias_rows([]) is None and ops.alias_rows([None]) is None
