@@ -353,6 +353,17 @@ int dfepe_deepf_input(const float *matches, const float *quality, int B, int N, 
                       float *pts1, float *pts2, void *stream);
 
 /*
+ * Per-pair dot products of two per-layer stacks: out[l,b] = sum_n a[l,b,n] * b[l,b,n].
+ * Replaces: the `epi_res * weights` products under loss_epi_res (deepFEPE/train_good_utils.py:429-438), whose means
+ *           dfepe_loss_stats then takes as one more row set.
+ *   a, b: n_layers blocks of [B,N] floats, block l at a + l * a_layer_stride (resp. b + l * b_layer_stride): the layers may
+ *   live in separate per-layer buffers a fixed distance apart (the channel-major estimator inputs of dfepe_deepf_input);
+ *   out [n_layers,B]
+ */
+int dfepe_row_dot(const float *a, size_t a_layer_stride, const float *b, size_t b_layer_stride, int n_layers, int B, int N,
+                  float *out, void *stream);
+
+/*
  * InstanceNorm1d(affine) + LeakyReLU on rows of N contiguous floats ("next" row f-1: the part of the weight estimator
  * between its 1x1 convolutions, deepFEPE/models/ErrorEstimators.py:47-64; the convolutions themselves are GEMMs).
  *   Y, A, gA, gY: [(c*R + r)*N + n]  (channel-major: c < C channels, r < R rows per channel, N points), 16-byte aligned;

@@ -47,6 +47,7 @@ _SIGNATURES = {
     "dfepe_loss_tail_bwd": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P]),
     "dfepe_loss_stats": (c_int, [_P, c_int, c_float, _P, c_int, c_float, _P, c_int, c_float, _P, c_int, c_float, c_int, _P, _P, _P, _P]),
     "dfepe_deepf_input": (c_int, [_P, _P, c_int, c_int, c_int, c_float, c_float, _P, c_size_t, c_size_t, c_int, c_size_t, _P, _P, _P]),
+    "dfepe_row_dot": (c_int, [_P, c_size_t, _P, c_size_t, c_int, c_int, c_int, _P, _P]),
     "dfepe_cheirality": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, _P, _P, _P, _P]),
     "dfepe_w8pt_pose_fwd": (c_int, [_P, _P, c_int, c_int, c_uint, c_float, c_float, c_float, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dfepe_metrics_summary_bytes": (c_size_t, []),

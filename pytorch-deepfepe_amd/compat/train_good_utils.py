@@ -166,7 +166,7 @@ def get_all_loss_DeepF(outs, pts1_virt_ori, pts2_virt_ori, Ks, loss_params, get_
             epi = ops.stack_rows(outs["epi_res_layers"][:n_epi])  # [n,B,1,N], strided views when the layers share a buffer
             w = ops.stack_rows(outs["weights_layers"][:n_epi])
             N_pts = epi.shape[-1]
-            epidot = torch.linalg.vecdot(epi.reshape(n_epi, B, N_pts), w.reshape(n_epi, B, N_pts))  # [n,B]
+            epidot = ops.row_dot(epi.squeeze(2) if epi.dim() == 4 else epi, w.squeeze(2) if w.dim() == 4 else w)  # [n,B]
     if gt is not None and M <= 112:
         q_gt, t_gt, delta = (torch.as_tensor(x).to(F_layers.device) for x in gt)
         R_gt = ops.camera_rotation(delta)

@@ -266,7 +266,34 @@ deepf_input_kernel(const float4* __restrict__ matches, const float* __restrict__
   }
 }
 
+// sum_n a[l,b,n] b[l,b,n] of every (layer, pair): one 16-lane row per item, the layers of each operand a fixed distance apart
+__global__ void __launch_bounds__(256)
+row_dot_kernel(const float* __restrict__ a, size_t a_layer_stride, const float* __restrict__ b, size_t b_layer_stride, int n_layers,
+               int B, int N, float* __restrict__ out) {
+  const size_t item = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (item >= (size_t)n_layers * B) return;
+  const int l = (int)(item / (size_t)B);
+  const size_t p = item - (size_t)l * B;
+  const float* x = a + (size_t)l * a_layer_stride + p * N;
+  const float* y = b + (size_t)l * b_layer_stride + p * N;
+  float acc = 0.0f;
+  for (int i = (int)(threadIdx.x & 15u); i < N; i += 16) acc = fmaf(x[i], y[i], acc);
+  acc = rg_sum(acc);
+  if ((threadIdx.x & 15u) == 0) out[item] = acc;
+}
+
 }  // namespace
+
+extern "C" int dfepe_row_dot(const float* a, size_t a_layer_stride, const float* b, size_t b_layer_stride, int n_layers, int B, int N,
+                             float* out, void* stream) {
+  if (n_layers < 0 || B < 0 || N <= 0) return DFEPE_ERR_INVALID_ARG;
+  if (n_layers == 0 || B == 0) return DFEPE_OK;
+  if (!a || !b || !out) return DFEPE_ERR_INVALID_ARG;
+  const size_t n = (size_t)n_layers * B;
+  hipLaunchKernelGGL(row_dot_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, static_cast<hipStream_t>(stream), a, a_layer_stride, b,
+                     b_layer_stride, n_layers, B, N, out);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
 
 extern "C" int dfepe_deepf_input(const float* matches, const float* quality, int B, int N, int Q, float image_w, float image_h,
                                  float* weight_in, size_t channel_stride, size_t batch_stride, int n_copies, size_t copy_stride,

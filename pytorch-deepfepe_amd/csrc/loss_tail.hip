@@ -120,8 +120,9 @@ constexpr int kStatMaxRows = 64;
 
 __global__ void __launch_bounds__(1024)
 loss_stats_kernel(const StatSets S, int C, float* __restrict__ out, float* __restrict__ row_min, float* __restrict__ col_min) {
-  __shared__ double wsum[16];
-  __shared__ float wmin[16];
+  constexpr int kG = 8;  // rows walked together: their loads are independent, one pass over the columns serves all of them
+  __shared__ double wsum[kG][16];
+  __shared__ float wmin[kG][16];
   __shared__ double rowmean[kStatMaxRows];
   const int k = (int)blockIdx.x;
   const int R = S.rows[k];
@@ -132,34 +133,45 @@ loss_stats_kernel(const StatSets S, int C, float* __restrict__ out, float* __res
   const double scale = (double)S.scale[k];
   const int t = (int)threadIdx.x, wave = t >> 6, lane = t & 63;
   const bool mins = (k == 0) && (row_min != nullptr || col_min != nullptr);
-  for (int r = 0; r < R; ++r) {
-    const float* row = x + (size_t)r * C;
-    double acc = 0.0;
-    float mn = INFINITY;
+  for (int r0 = 0; r0 < R; r0 += kG) {
+    double acc[kG];
+    float mn[kG];
+#pragma unroll
+    for (int j = 0; j < kG; ++j) { acc[j] = 0.0; mn[j] = INFINITY; }
     for (int c = t; c < C; c += 1024) {
-      const float v = row[c];
-      acc += (double)v;
-      if (mins) {
-        mn = fminf(mn, v);
-        if (col_min != nullptr) {
-          const float sv = (float)((double)v * scale);
-          col_min[c] = (r == 0) ? sv : fminf(col_min[c], sv);  // the same thread owns column c in every row
+      float v[kG];
+#pragma unroll
+      for (int j = 0; j < kG; ++j) v[j] = x[(size_t)((r0 + j < R) ? r0 + j : r0) * C + c];
+      float cm = INFINITY;
+#pragma unroll
+      for (int j = 0; j < kG; ++j) {
+        if (r0 + j < R) {
+          acc[j] += (double)v[j];
+          mn[j] = fminf(mn[j], v[j]);
+          cm = fminf(cm, v[j]);
         }
       }
+      if (mins && col_min != nullptr) {  // the same thread owns column c in every group of rows
+        const float sv = (float)((double)cm * scale);
+        col_min[c] = (r0 == 0) ? sv : fminf(col_min[c], sv);
+      }
     }
-    acc = wave_sum(acc);
-    if (mins) mn = -wave_max(-mn);
-    if (lane == 0) { wsum[wave] = acc; wmin[wave] = mn; }
+#pragma unroll
+    for (int j = 0; j < kG; ++j) {
+      const double s = wave_sum(acc[j]);
+      const float m = -wave_max(-mn[j]);
+      if (lane == 0) { wsum[j][wave] = s; wmin[j][wave] = m; }
+    }
     __syncthreads();
-    if (t == 0) {
+    if (t < kG && r0 + t < R) {
       double s = 0.0;
       float m = INFINITY;
 #pragma unroll
-      for (int w = 0; w < 16; ++w) { s += wsum[w]; m = fminf(m, wmin[w]); }
+      for (int w = 0; w < 16; ++w) { s += wsum[t][w]; m = fminf(m, wmin[t][w]); }
       const double mean = s * scale / (double)C;
-      rowmean[r] = mean;
-      out[off + r] = (float)mean;
-      if (mins && row_min != nullptr) row_min[r] = (float)((double)m * scale);
+      rowmean[r0 + t] = mean;
+      out[off + r0 + t] = (float)mean;
+      if (mins && row_min != nullptr) row_min[r0 + t] = (float)((double)m * scale);
     }
     __syncthreads();
   }

@@ -80,12 +80,14 @@ def alias_rows(rows) -> Optional[Tensor]:
 class _StackRowsFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, *rows):
+        ctx.set_materialize_grads(False)  # an unused stack must not send rows of zeros back (a zero-fill, and kernels that then
+        ctx.n = len(rows)                 # run their gradient paths for nothing)
         a = alias_rows(rows)
         return torch.stack(rows) if a is None else a
 
     @staticmethod
     def backward(ctx, g):
-        return tuple(g.unbind(0))
+        return (None,) * ctx.n if g is None else tuple(g.unbind(0))
 
 
 class _UnstackRowsFunction(torch.autograd.Function):
@@ -548,9 +550,7 @@ class _TailJacFunction(torch.autograd.Function):
             [(loss_sum, 1.0 / M), (q_l2, 1.0), (t_l2, 1.0), (extra, extra_scale)], B, True)
         ctx.save_for_backward(J, F_layers, T1c, T2c, K, virt1, virt2)
         ctx.cfg = (t_stride, float(clamp_at), bool(want_floss_jac), 1.0 / M, None if extra is None else (extra.shape[0], float(extra_scale)))
-        ctx.mark_non_differentiable(row_min, col_min)
-        if pose:
-            ctx.mark_non_differentiable(ang, sel)
+        ctx.mark_non_differentiable(*([row_min, col_min] + ([ang, sel] if pose else [])))  # ONE call: a second one replaces the first
         return loss_sum, E_layers, m_loss, o_loss, row_min, col_min, m_x, o_x, qt, q_l2, t_l2, ang, sel, m_q, o_q, m_t, o_t
 
     @staticmethod
@@ -706,6 +706,36 @@ def project_essential(E: Tensor) -> Tensor:
 def congruence(F: Tensor, A: Tensor) -> Tensor:
     """A^T F A for batches of 3x3 matrices: E = K^T T^T F T K with A = T K (train_good_utils.py:356-358), or K^T F K."""
     return geo_misc(5, F.reshape(-1, 9), A.reshape(-1, 9)).reshape(-1, 3, 3)
+
+
+class _RowDotFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.set_materialize_grads(False)
+        n, B, N = a.shape
+        out = torch.empty(n, B, device=a.device, dtype=torch.float32)
+        with torch.cuda.device(a.device):
+            rc = _lib.lib().dfepe_row_dot(_ptr(a), a.stride(0), _ptr(b), b.stride(0), n, B, N, _ptr(out), _stream())
+        _lib.check(rc, "dfepe_row_dot")
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None
+        a, b = ctx.saved_tensors
+        g = g.unsqueeze(2)
+        return (g * b if ctx.needs_input_grad[0] else None), (g * a if ctx.needs_input_grad[1] else None)
+
+
+def row_dot(a: Tensor, b: Tensor) -> Tensor:
+    """out[l,b] = sum_n a[l,b,n] * b[l,b,n] for two [n,B,N] stacks whose layers are contiguous [B,N] blocks (any distance apart:
+    the strided stacks of alias_rows are taken as they are).  One launch; differentiable (plain torch products in the backward)."""
+    if a.shape != b.shape or a.dim() != 3:
+        raise ValueError(f"row_dot: two [n,B,N] stacks expected, got {tuple(a.shape)}, {tuple(b.shape)}")
+    fix = lambda t: t if (t.is_cuda and t.dtype == torch.float32 and t.stride(2) == 1 and t.stride(1) == t.shape[2]) else _prep(t, "stack")
+    return _RowDotFunction.apply(fix(a), fix(b))
 
 
 class _CongruenceFunction(torch.autograd.Function):

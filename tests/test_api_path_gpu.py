@@ -277,3 +277,19 @@ def test_loss_stats_matches_torch_reductions_and_differentiates(dfepe):
             gb = torch.autograd.grad(ref, [xs[k] for k in present])
             for a, b in zip(ga, gb):
                 np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-12)
+
+
+def test_row_dot_on_contiguous_and_strided_stacks(dfepe):
+    g = torch.Generator().manual_seed(2)
+    n, B, N = 4, 37, 100
+    buf = torch.randn(n, 7, B, N, generator=g).to(DEV)  # per-layer channel-major buffers: channel 5 of every layer is a strided stack
+    a = dfepe.ops.alias_rows([dfepe.ops.row_of(buf[l], 5).unsqueeze(1) for l in range(n)])
+    assert a is not None and not a.is_contiguous() and a.shape == (n, B, 1, N)
+    b = torch.randn(n, B, N, generator=g).to(DEV).requires_grad_(True)
+    a_leaf = a.squeeze(2).clone().requires_grad_(True)
+    out = dfepe.ops.row_dot(a.squeeze(2), b)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), (a.squeeze(2).double() * b.double()).sum(2).detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    up = torch.randn(n, B, generator=g).to(DEV)
+    (dfepe.ops.row_dot(a_leaf, b) * up).sum().backward()
+    np.testing.assert_allclose(b.grad.cpu().numpy(), (up[:, :, None] * a_leaf.detach()).cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(a_leaf.grad.cpu().numpy(), (up[:, :, None] * b.detach()).cpu().numpy(), rtol=1e-6)
