@@ -270,6 +270,8 @@ def main():
     cfg = dict(CONFIGS[args.config])
     scaling = args.scaling or cfg["scaling"]
     B_cfg = args.batch if args.batch is not None else cfg["B"]
+    if args.config == 4 and scaling == "strong" and args.batch is None:
+        B_cfg = 32768  # BASELINE config 4 as north_star words it: 32768 pairs, batch-sharded over the ranks (8 x 4096)
     N = args.npoints if args.npoints is not None else cfg["N"]
     L = args.depth if args.depth is not None else cfg["depth"]
     outl = args.outliers if args.outliers is not None else cfg["outliers"]
@@ -291,11 +293,21 @@ def main():
     w0 = torch.softmax(scene["logits_layers"][0], dim=1).contiguous()
     TK = (hw_T @ scene["Ks"]).contiguous()  # per-pair constant of E = (T K)^T F (T K), formed once
 
+    # the only exchange of the data-parallel path: (L+4) doubles over RCCL/xGMI per step (steps without a loss exchange nothing).
+    # Default ("graph"): the all-reduce is part of the step -- a branch tail -> [loss head -> all_reduce] parallel to the five backward
+    # fits, captured in the same hipGraph (pipeline.hot_path_fused(loss_exchange=...)): nothing in the backward needs the scalars, so
+    # neither the head nor the collective's latency is on the step's critical path.  DFEPE_BENCH_EXCHANGE=sync: in stream order after
+    # every replay (round 3); =overlap: the double-buffered staging exchange of dist.OverlappedLossExchange (+29 us on one rank).
+    has_loss = kind == "train"
+    exchange_mode = os.environ.get("DFEPE_BENCH_EXCHANGE", "graph") if (dist is not None and has_loss) else "none"
+    loss_exchange = (lambda p: dist.all_reduce(p)) if exchange_mode == "graph" else None
+
     if kind == "train":
         def step_body():
             out = dfepe.pipeline.hot_path_fused(m, logits, scene["Ks"], scene["pts1_virt_ori"], scene["pts2_virt_ori"], scene["qs_cam"],
                                                   scene["ts_cam"], scene["R_gt"], IMAGE_SIZE, clamp_at=0.02, qt=True, hw_T=hw_T,
-                                                  balance_F=cfg["balance_F"], grad_pairs=B_total, defer_loss_head=not args.no_defer_head)
+                                                  balance_F=cfg["balance_F"], grad_pairs=B_total, defer_loss_head=not args.no_defer_head,
+                                                  loss_exchange=loss_exchange)
             # the seed d loss / d loss = 1 is a constant of the loop: allocated once (first eager warm-up step) instead of the
             # ones_like() fill that autograd would otherwise launch in every step
             if "seed" not in state:
@@ -332,13 +344,7 @@ def main():
             last = step_body()
     log("graph captured" if graph is not None else "eager mode")
 
-    # the only exchange of the data-parallel path: (L+4) doubles over RCCL/xGMI per step (steps without a loss exchange nothing)
-    # Default: the plain in-stream all-reduce.  DFEPE_BENCH_EXCHANGE=overlap switches to the double-buffered asynchronous
-    # exchange (dist.OverlappedLossExchange); on a 1-rank RCCL group (--force-dist) its staging copy and event traffic cost
-    # more (+29 us/step) than the collective it hides (+9 us/step), so it stays opt-in until measured on 8 GPUs.
-    has_loss = kind == "train"
-    sync_exchange = os.environ.get("DFEPE_BENCH_EXCHANGE", "sync") != "overlap"
-    exchange = dfepe.dist.OverlappedLossExchange(L + 4, dev, depth=2) if (dist is not None and has_loss and not sync_exchange) else None
+    exchange = dfepe.dist.OverlappedLossExchange(L + 4, dev, depth=2) if exchange_mode == "overlap" else None
 
     def run_step():
         if graph is not None:
@@ -347,7 +353,7 @@ def main():
             step_body()
         if exchange is not None:
             exchange.exchange(state["loss_vec"])
-        elif dist is not None and has_loss:
+        elif exchange_mode == "sync":
             dist.all_reduce(state["loss_vec"])
 
     def barrier():
@@ -671,9 +677,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg["what"].format(B=B_cfg, N=N, L=L), "baseline_config": args.config, "B_per_gpu": B, "B_total": B_total,
                        "N": N, "depth": L, "outlier_ratio": outl, "parallelism": f"dp{world}", "hipgraph": graph is not None,
-                       "launches_per_step": ((2 * L + 2) if args.no_defer_head else (2 * L + 1)) if kind == "train" else 2,
-                       "loss_head": ("a launch of its own" if args.no_defer_head else
-                                     "batch sums of the loss finished in spare wavefronts of the first backward launch (defer_loss_head)")},
+                       "launches_per_step": ((2 * L + 2) if (args.no_defer_head or exchange_mode == "graph") else (2 * L + 1)) if kind == "train" else 2,
+                       "loss_head": ("a launch on the exchange stream, followed by the all-reduce: a branch of the step's graph parallel to the backward fits"
+                                     if exchange_mode == "graph" else "a launch of its own" if args.no_defer_head else
+                                     "batch sums of the loss finished in spare wavefronts of the first backward launch (defer_loss_head)"),
+                       "loss_exchange": {"graph": "all_reduce(SUM) of L+4 doubles captured in the step's hipGraph, parallel to the backward",
+                                         "sync": "all_reduce(SUM) of L+4 doubles in stream order after every step",
+                                         "overlap": "double-buffered asynchronous all_reduce (dist.OverlappedLossExchange)",
+                                         "none": None}[exchange_mode]},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "accuracy": acc,

@@ -215,6 +215,10 @@ int dfepe_loss_tail(const float *F_layers, int L, int B, const float *T1, const 
                     float balance_F, float balance_q, float balance_t, double grad_pairs,
                     float *loss_sum, float *E_layers, float *q_l2, float *t_l2, float *R_deg, float *t_deg, int *sel,
                     float *g_F_layers, double *packed, float *scalars, void *workspace, int defer_head, void *stream);
+/* The pending loss head of a dfepe_loss_tail(..., defer_head = 1) call as a launch of its own, on any stream ordered after that
+ * call (instead of riding in a dfepe_w8pt_bwd launch): lets the head and the data-parallel all-reduce of `packed` that follows it
+ * run on a side stream while the backward fits run on the main one.  `workspace`: the one given to dfepe_loss_tail. */
+int dfepe_loss_head_pending(const void *workspace, void *stream);
 
 /*
  * The loss tail behind the reference's OWN call sequence (get_all_loss_DeepF, then get_Rt_loss, then the caller's clamp /

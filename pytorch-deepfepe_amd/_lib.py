@@ -42,6 +42,7 @@ _SIGNATURES = {
     "dfepe_loss_tail_workspace_bytes": (c_size_t, [c_int]),
     "dfepe_loss_tail": (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, c_float, _P, _P, _P, c_float, c_float, c_float, c_float,
                                 c_float, c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
+    "dfepe_loss_head_pending": (c_int, [_P, _P]),
     "dfepe_loss_tail_jac": (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, c_float, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P,
                                     _P, _P]),
     "dfepe_loss_tail_bwd": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P]),

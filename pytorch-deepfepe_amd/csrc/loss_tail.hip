@@ -195,6 +195,14 @@ int dfepe_loss_head_from_workspace(const void* workspace_desc, hipStream_t st) {
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
+// C-ABI form of the above: the head of a dfepe_loss_tail(..., defer_head = 1) call as a launch of its own on ANY stream that is
+// ordered after that call -- e.g. a side stream that then carries the data-parallel all-reduce of `packed`, in parallel with the
+// backward fits on the main stream (a fork / join inside one captured hipGraph).
+extern "C" int dfepe_loss_head_pending(const void* workspace, void* stream) {
+  if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15u)) return DFEPE_ERR_INVALID_ARG;
+  return dfepe_loss_head_from_workspace(workspace, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int dfepe_loss_tail(const float* F_layers, int L, int B, const float* T1, const float* T2, int t_stride,
                                const float* K, const float* virt1, const float* virt2, int M, float clamp_at,
                                const float* q_gt, const float* t_gt, const float* R_gt, float clamp_q, float clamp_t,

@@ -52,6 +52,17 @@ def hot_path_forward(matches: Tensor, logits_layers: Tensor, Ks: Tensor, virt1: 
     return out
 
 
+_exchange_streams = {}
+
+
+def _exchange_stream(dev):
+    """One side stream per device for the loss head + exchange branch."""
+    key = str(dev)
+    if key not in _exchange_streams:
+        _exchange_streams[key] = torch.cuda.Stream(device=dev)
+    return _exchange_streams[key]
+
+
 def _tail_workspace(dev, B: int) -> Tensor:
     """Scratch of dfepe_loss_tail (per-workgroup partial sums, and the descriptor of a deferred head): ~100 KB from the caching
     allocator per call, so that it belongs to the stream / graph-capture pool the call runs in (a cached buffer shared between
@@ -67,7 +78,7 @@ class _HotPathFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, matches, logits_layers, Ks, virt1, virt2, q_gt, t_gt, R_gt, hw_T, cfg):
-        (H, W, clamp_at, qt, clamp_q, clamp_t, balance_q, balance_t, batched, balance_F, fused_tail, grad_pairs, defer_head) = cfg
+        (H, W, clamp_at, qt, clamp_q, clamp_t, balance_q, balance_t, batched, balance_F, fused_tail, grad_pairs, defer_head, exchange) = cfg
         ctx.set_materialize_grads(False)  # 13 auxiliary outputs: do not let autograd zero-fill [L,B,N] gradients for them
         lib = _lib.lib()
         L, B, N = logits_layers.shape
@@ -111,9 +122,11 @@ class _HotPathFunction(torch.autograd.Function):
                 gF = torch.empty(L, B, 3, 3, device=dev)
                 # deferred loss head: packed / scalars are finished by the first backward launch (off the critical path); the
                 # workspace then carries the head's descriptor from here to there, so it belongs to this call alone
-                defer = bool(defer_head and ctx.needs_input_grad[1])
+                will_backward = bool(ctx.needs_input_grad[1])
+                branch = exchange is not None and will_backward  # head + exchange on a side stream, beside the backward
+                defer = bool((defer_head and will_backward) or branch)
                 ws = _tail_workspace(dev, B)
-                ctx.pending_ws = ws if defer else None
+                ctx.pending_ws = ws if (defer and not branch) else None
                 rc = lib.dfepe_loss_tail(F_layers.data_ptr(), L, B, hw_T.data_ptr(), hw_T.data_ptr(), 0, Ks.data_ptr(), virt1.data_ptr(),
                                          virt2.data_ptr(), M, clamp_at, ops._ptr(q_gt if qt else None), ops._ptr(t_gt if qt else None),
                                          ops._ptr(R_gt if qt else None), clamp_q, clamp_t, balance_F, balance_q, balance_t,
@@ -121,6 +134,21 @@ class _HotPathFunction(torch.autograd.Function):
                                          ops._ptr(t_l2), ops._ptr(R_deg), ops._ptr(t_deg), ops._ptr(sel), gF.data_ptr(),
                                          packed.data_ptr(), scalars.data_ptr(), ws.data_ptr(), 1 if defer else 0, st)
                 _lib.check(rc, "dfepe_loss_tail")
+                ctx.join_stream = None
+                if branch:
+                    # fork: tail -> [head -> exchange(packed)] on the exchange stream  ||  [L x w8pt_bwd] on this one; the backward
+                    # joins.  Nothing in the backward needs the batch scalars, so the ~5 us head and the latency of the collective
+                    # leave the step's critical path; inside a hipGraph capture the two become parallel branches of the graph.
+                    fn, side = exchange
+                    main = torch.cuda.current_stream()
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        _lib.check(lib.dfepe_loss_head_pending(ws.data_ptr(), side.cuda_stream), "dfepe_loss_head_pending")
+                        fn(packed)
+                    ctx.join_stream = side
+                    ctx.keep = (ws, packed, scalars)  # used on the side stream: alive until the join
+                elif exchange is not None:  # forward only: head already ran in this stream (defer = 0); exchange in stream order
+                    exchange[0](packed)
             else:
                 rc = lib.dfepe_floss_fwd(F_layers.data_ptr(), L, B, hw_T.data_ptr(), hw_T.data_ptr(), 0, Ks.data_ptr(), virt1.data_ptr(),
                                          virt2.data_ptr(), M, clamp_at, loss_sum.data_ptr(), E_layers.data_ptr(), st)
@@ -134,6 +162,8 @@ class _HotPathFunction(torch.autograd.Function):
                 _lib.check(rc, "dfepe_loss_head")
                 if balance_F != 1.0:  # dfepe_loss_head mixes loss_F + loss_qt; any other balance is one more tiny op here
                     scalars[0:1].copy_(scalars[1:2] * balance_F + (scalars[2:3] if qt else 0.0))
+                if exchange is not None:
+                    exchange[0](packed)
         saved = [matches, weights, Ks, virt1, virt2, q_gt, t_gt, hw_T, F_layers, E_layers, saves]
         if gF is not None:
             saved.append(gF)
@@ -148,7 +178,7 @@ class _HotPathFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, *unused):
         matches, weights, Ks, virt1, virt2, q_gt, t_gt, hw_T, F_layers, E_layers, saves = ctx.saved_tensors[:11]
-        (H, W, clamp_at, qt, clamp_q, clamp_t, balance_q, balance_t, batched, balance_F, _ft, grad_pairs, _dh) = ctx.cfg
+        (H, W, clamp_at, qt, clamp_q, clamp_t, balance_q, balance_t, batched, balance_F, _ft, grad_pairs, _dh, _ex) = ctx.cfg
         lib = _lib.lib()
         L, B, N = weights.shape
         M = virt1.shape[1]
@@ -192,6 +222,10 @@ class _HotPathFunction(torch.autograd.Function):
                                             saves[l].data_ptr(), F_layers[l].data_ptr(), gF[l].data_ptr(), None, None, None, gs_ptr,
                                             g_logits[l].data_ptr(), None, None, pend_ptr if l == 0 else None, st)
                     _lib.check(rc, "dfepe_w8pt_bwd")
+            join = getattr(ctx, "join_stream", None)
+            if join is not None:  # the head / exchange branch meets the backward here
+                torch.cuda.current_stream().wait_stream(join)
+                ctx.join_stream = ctx.keep = None
         return None, g_logits, None, None, None, None, None, None, None, None
 
 
@@ -199,7 +233,8 @@ def hot_path_fused(matches: Tensor, logits_layers: Tensor, Ks: Tensor, virt1: Te
                    t_gt: Tensor, R_gt: Tensor, image_size: Sequence[int], clamp_at: float = 0.02, qt: bool = True,
                    clamp_q: float = 0.1, clamp_t: float = 0.5, balance_q: float = 1.0, balance_t: float = 0.1,
                    hw_T: Optional[Tensor] = None, layers_batched: bool = False, balance_F: float = 1.0, fused_tail: bool = True,
-                   grad_pairs: Optional[int] = None, defer_loss_head: bool = False) -> Dict[str, Tensor]:
+                   grad_pairs: Optional[int] = None, defer_loss_head: bool = False, loss_exchange=None,
+                   exchange_stream: Optional["torch.cuda.Stream"] = None) -> Dict[str, Tensor]:
     """Same contract and same numbers as hot_path_forward, 12 kernel launches instead of ~120:
     loss = balance_F * loss_F + loss_qt.  The reference's pipeline drops the F-loss from the objective when if_qt_loss
     (Train_model_pipeline.py:580-587, `loss += loss_F * balance_F` commented out): that is balance_F = 0; the solver-only
@@ -210,15 +245,25 @@ def hot_path_fused(matches: Tensor, logits_layers: Tensor, Ks: Tensor, virt1: Te
     ``defer_loss_head``: the batch sums behind ``loss`` / ``loss_F`` / ``loss_qt`` / ``loss_layers`` / ``packed`` are finished
     by the first backward launch instead of a launch of their own (11 launches, the ~7 us head off the critical path).  Those
     tensors are then valid only AFTER ``loss.backward()`` -- for steps that run forward and backward back to back (a captured
-    graph); everything per pair (F, E, loss_sum, pose errors) and the gradients do not depend on it."""
+    graph); everything per pair (F, E, loss_sum, pose errors) and the gradients do not depend on it.
+    ``loss_exchange`` (with ``exchange_stream``): a callable applied to ``packed`` -- the data-parallel all-reduce of the L+4 loss
+    sums, ``lambda p: torch.distributed.all_reduce(p)`` -- on a side stream right behind the loss head, as a branch PARALLEL to the
+    backward fits, which join it at their end: tail -> [head -> all_reduce] || [L x w8pt_bwd].  Like defer_loss_head the batch scalars are
+    valid after the backward; unlike it they are then already the reduced ones.  Capturable (RCCL collectives are), in which
+    case the branch is a parallel branch of the hipGraph.  Without a backward to follow the exchange runs in stream order."""
     L, B, N = logits_layers.shape
     H, W = float(image_size[0]), float(image_size[1])
     dev = matches.device
     if hw_T is None:
         hw_T = torch.tensor([[2.0 / W, 0.0, -1.0], [0.0, 2.0 / H, -1.0], [0.0, 0.0, 1.0]], device=dev)
     f32 = lambda t: ops._prep(t, "input")
+    exchange = None
+    if loss_exchange is not None:
+        if not fused_tail:
+            raise _lib.DfepeError("loss_exchange rides behind the fused loss tail (fused_tail=True)")
+        exchange = (loss_exchange, exchange_stream if exchange_stream is not None else _exchange_stream(dev))
     cfg = (H, W, float(clamp_at), bool(qt), float(clamp_q), float(clamp_t), float(balance_q), float(balance_t), bool(layers_batched),
-           float(balance_F), bool(fused_tail), grad_pairs, bool(defer_loss_head))
+           float(balance_F), bool(fused_tail), grad_pairs, bool(defer_loss_head), exchange)
     res = _HotPathFunction.apply(f32(matches), f32(logits_layers), f32(Ks), f32(virt1), f32(virt2), f32(q_gt.reshape(B, 4)),
                                  f32(t_gt.reshape(B, 3)), f32(R_gt.reshape(B, 3, 3)), f32(hw_T), cfg)
     loss, F_layers, residuals, epis, weights, E_layers, loss_sum, packed, scalars = res[:9]

@@ -165,6 +165,78 @@ def test_one_rank_rccl_group_behind_a_graph_replay(dfepe):
         dist.destroy_process_group()
 
 
+def test_all_reduce_captured_as_a_branch_parallel_to_the_backward(dfepe):
+    """tail -> [loss head -> all_reduce(packed)] on a side stream || [L x w8pt_bwd], joined at the end of the
+    backward, eager and captured in ONE hipGraph with a real (one-rank) RCCL communicator: the packed vector, every batch scalar and
+    d loss / d logits are bit-identical to the plain step, and the replay costs about what the step without any exchange costs."""
+    import time
+
+    import torch.distributed as dist
+
+    L, B = 5, 4096
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        sc = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(B, 100, seed=6, outlier_ratio=0.2, depth_layers=L), DEV)
+        eager = _fused(dfepe, sc, L)
+        H, W = float(IMAGE_SIZE[0]), float(IMAGE_SIZE[1])
+        hw_T = torch.tensor([[2.0 / W, 0.0, -1.0], [0.0, 2.0 / H, -1.0], [0.0, 0.0, 1.0]], device=DEV)
+        logits = sc["logits_layers"][:L].clone().requires_grad_(True)
+        calls = {"n": 0}
+
+        def exchange(p):
+            calls["n"] += 1
+            dist.all_reduce(p)
+
+        def make_step(with_exchange, state):
+            def step_body():
+                out = dfepe.pipeline.hot_path_fused(sc["matches_xy_ori"], logits, sc["Ks"], sc["pts1_virt_ori"], sc["pts2_virt_ori"], sc["qs_cam"],
+                                                    sc["ts_cam"], sc["R_gt"], IMAGE_SIZE, 0.02, True, hw_T=hw_T, grad_pairs=B,
+                                                    defer_loss_head=True, loss_exchange=exchange if with_exchange else None)
+                state["g"], = torch.autograd.grad(out["loss"], logits, grad_outputs=state.setdefault("seed", torch.ones_like(out["loss"])))
+                return out
+            return step_body
+
+        times = {}
+        for with_exchange in (False, True):
+            state = {}
+            body = make_step(with_exchange, state)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                out = body()  # eager: the branch runs on the exchange stream, the backward joins it
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            for k in ("loss", "loss_F", "loss_qt", "loss_layers", "packed", "q_l2", "F_layers"):
+                assert torch.equal(out[k], eager[k]), (with_exchange, k)
+            assert torch.equal(state["g"], eager["grad_logits"])
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = body()
+            for rep in range(3):
+                for t in (out["loss"], out["packed"], state["g"]):
+                    t.detach().fill_(float("nan"))
+                graph.replay()
+                torch.cuda.synchronize()
+                for k in ("loss", "loss_F", "loss_qt", "loss_layers", "packed", "q_l2", "F_layers"):
+                    assert torch.equal(out[k], eager[k]), (with_exchange, k, rep)  # world size 1: the sum over ranks is the rank's own
+                assert torch.equal(state["g"], eager["grad_logits"]), (with_exchange, rep)
+            for _ in range(200):
+                graph.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(300):
+                graph.replay()
+            torch.cuda.synchronize()
+            times[with_exchange] = (time.perf_counter() - t0) / 300 * 1e6
+        assert calls["n"] >= 2  # once eagerly, once while capturing
+        print(f"captured step: {times[False]:.1f} us without exchange, {times[True]:.1f} us with the all-reduce branch")
+        assert times[True] < times[False] + 15.0  # measured: +1..3 us (the branch is off the critical path); generous for a noisy box
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("flags", [["--gpus", "1", "--launcher", "torchrun"], ["--gpus", "1", "--force-dist"]])
 def test_bench_launches_its_own_ranks(flags):
