@@ -294,20 +294,21 @@ def main():
     TK = (hw_T @ scene["Ks"]).contiguous()  # per-pair constant of E = (T K)^T F (T K), formed once
 
     # the only exchange of the data-parallel path: (L+4) doubles over RCCL/xGMI per step (steps without a loss exchange nothing).
-    # Default ("graph"): the all-reduce is part of the step -- a branch tail -> [loss head -> all_reduce] parallel to the five backward
-    # fits, captured in the same hipGraph (pipeline.hot_path_fused(loss_exchange=...)): nothing in the backward needs the scalars, so
-    # neither the head nor the collective's latency is on the step's critical path.  DFEPE_BENCH_EXCHANGE=sync: in stream order after
-    # every replay (round 3); =overlap: the double-buffered staging exchange of dist.OverlappedLossExchange (+29 us on one rank).
+    # Default ("graph"): the all-reduce is the last node of the step's hipGraph (pipeline.hot_path_fused(loss_exchange=...)): the host
+    # enqueues nothing per step but the replay.  scripts/exchange_probe.py on a one-rank RCCL group, us per step over the plain step:
+    # in the graph +0, eager in stream order after the replay (DFEPE_BENCH_EXCHANGE=sync, round 3) +10, as a graph branch parallel
+    # to the backward (=branch) +33, lagged on RCCL's stream with event waits (=overlap: dist.OverlappedLossExchange) +26..29 --
+    # every cross-stream edge costs this stack more than the 72-byte collective it would hide.
     has_loss = kind == "train"
     exchange_mode = os.environ.get("DFEPE_BENCH_EXCHANGE", "graph") if (dist is not None and has_loss) else "none"
-    loss_exchange = (lambda p: dist.all_reduce(p)) if exchange_mode == "graph" else None
+    loss_exchange = (lambda p: dist.all_reduce(p)) if exchange_mode in ("graph", "branch") else None
 
     if kind == "train":
         def step_body():
             out = dfepe.pipeline.hot_path_fused(m, logits, scene["Ks"], scene["pts1_virt_ori"], scene["pts2_virt_ori"], scene["qs_cam"],
                                                   scene["ts_cam"], scene["R_gt"], IMAGE_SIZE, clamp_at=0.02, qt=True, hw_T=hw_T,
                                                   balance_F=cfg["balance_F"], grad_pairs=B_total, defer_loss_head=not args.no_defer_head,
-                                                  loss_exchange=loss_exchange)
+                                                  loss_exchange=loss_exchange, exchange_branch=exchange_mode == "branch")
             # the seed d loss / d loss = 1 is a constant of the loop: allocated once (first eager warm-up step) instead of the
             # ones_like() fill that autograd would otherwise launch in every step
             if "seed" not in state:
@@ -677,11 +678,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg["what"].format(B=B_cfg, N=N, L=L), "baseline_config": args.config, "B_per_gpu": B, "B_total": B_total,
                        "N": N, "depth": L, "outlier_ratio": outl, "parallelism": f"dp{world}", "hipgraph": graph is not None,
-                       "launches_per_step": ((2 * L + 2) if (args.no_defer_head or exchange_mode == "graph") else (2 * L + 1)) if kind == "train" else 2,
+                       "launches_per_step": ((2 * L + 2) if (args.no_defer_head or exchange_mode == "branch") else (2 * L + 1)) if kind == "train" else 2,
                        "loss_head": ("a launch on the exchange stream, followed by the all-reduce: a branch of the step's graph parallel to the backward fits"
-                                     if exchange_mode == "graph" else "a launch of its own" if args.no_defer_head else
+                                     if exchange_mode == "branch" else "a launch of its own" if args.no_defer_head else
                                      "batch sums of the loss finished in spare wavefronts of the first backward launch (defer_loss_head)"),
-                       "loss_exchange": {"graph": "all_reduce(SUM) of L+4 doubles captured in the step's hipGraph, parallel to the backward",
+                       "loss_exchange": {"graph": "all_reduce(SUM) of L+4 doubles captured as the last node of the step's hipGraph",
+                                         "branch": "all_reduce(SUM) of L+4 doubles captured in the step's hipGraph as a branch parallel to the backward",
                                          "sync": "all_reduce(SUM) of L+4 doubles in stream order after every step",
                                          "overlap": "double-buffered asynchronous all_reduce (dist.OverlappedLossExchange)",
                                          "none": None}[exchange_mode]},

@@ -123,7 +123,7 @@ class _HotPathFunction(torch.autograd.Function):
                 # deferred loss head: packed / scalars are finished by the first backward launch (off the critical path); the
                 # workspace then carries the head's descriptor from here to there, so it belongs to this call alone
                 will_backward = bool(ctx.needs_input_grad[1])
-                branch = exchange is not None and will_backward  # head + exchange on a side stream, beside the backward
+                branch = exchange is not None and exchange[1] is not None and will_backward  # head + exchange on a side stream
                 defer = bool((defer_head and will_backward) or branch)
                 ws = _tail_workspace(dev, B)
                 ctx.pending_ws = ws if (defer and not branch) else None
@@ -147,6 +147,8 @@ class _HotPathFunction(torch.autograd.Function):
                         fn(packed)
                     ctx.join_stream = side
                     ctx.keep = (ws, packed, scalars)  # used on the side stream: alive until the join
+                elif exchange is not None and will_backward:  # in stream order behind the last backward fit (the head may ride in the first)
+                    ctx.exchange_after = (exchange[0], packed)
                 elif exchange is not None:  # forward only: head already ran in this stream (defer = 0); exchange in stream order
                     exchange[0](packed)
             else:
@@ -226,6 +228,10 @@ class _HotPathFunction(torch.autograd.Function):
             if join is not None:  # the head / exchange branch meets the backward here
                 torch.cuda.current_stream().wait_stream(join)
                 ctx.join_stream = ctx.keep = None
+            after = getattr(ctx, "exchange_after", None)
+            if after is not None:  # the step's last enqueue: by now the head (riding in the first backward launch) has finished packed
+                after[0](after[1])
+                ctx.exchange_after = None
         return None, g_logits, None, None, None, None, None, None, None, None
 
 
@@ -234,7 +240,7 @@ def hot_path_fused(matches: Tensor, logits_layers: Tensor, Ks: Tensor, virt1: Te
                    clamp_q: float = 0.1, clamp_t: float = 0.5, balance_q: float = 1.0, balance_t: float = 0.1,
                    hw_T: Optional[Tensor] = None, layers_batched: bool = False, balance_F: float = 1.0, fused_tail: bool = True,
                    grad_pairs: Optional[int] = None, defer_loss_head: bool = False, loss_exchange=None,
-                   exchange_stream: Optional["torch.cuda.Stream"] = None) -> Dict[str, Tensor]:
+                   exchange_branch: bool = False, exchange_stream: Optional["torch.cuda.Stream"] = None) -> Dict[str, Tensor]:
     """Same contract and same numbers as hot_path_forward, 12 kernel launches instead of ~120:
     loss = balance_F * loss_F + loss_qt.  The reference's pipeline drops the F-loss from the objective when if_qt_loss
     (Train_model_pipeline.py:580-587, `loss += loss_F * balance_F` commented out): that is balance_F = 0; the solver-only
@@ -246,11 +252,15 @@ def hot_path_fused(matches: Tensor, logits_layers: Tensor, Ks: Tensor, virt1: Te
     by the first backward launch instead of a launch of their own (11 launches, the ~7 us head off the critical path).  Those
     tensors are then valid only AFTER ``loss.backward()`` -- for steps that run forward and backward back to back (a captured
     graph); everything per pair (F, E, loss_sum, pose errors) and the gradients do not depend on it.
-    ``loss_exchange`` (with ``exchange_stream``): a callable applied to ``packed`` -- the data-parallel all-reduce of the L+4 loss
-    sums, ``lambda p: torch.distributed.all_reduce(p)`` -- on a side stream right behind the loss head, as a branch PARALLEL to the
-    backward fits, which join it at their end: tail -> [head -> all_reduce] || [L x w8pt_bwd].  Like defer_loss_head the batch scalars are
-    valid after the backward; unlike it they are then already the reduced ones.  Capturable (RCCL collectives are), in which
-    case the branch is a parallel branch of the hipGraph.  Without a backward to follow the exchange runs in stream order."""
+    ``loss_exchange``: a callable applied to ``packed`` -- the data-parallel all-reduce of the L+4 loss sums,
+    ``lambda p: torch.distributed.all_reduce(p)`` -- as PART of the step, so that a captured step carries its collective in its
+    hipGraph (RCCL collectives are capturable) and the host enqueues nothing per step but the replay.  Default placement: in
+    stream order behind the last backward fit (forward only: behind the loss head).  ``exchange_branch=True`` instead forks it
+    onto ``exchange_stream`` right behind the loss head, parallel to the backward fits, which join it at their end:
+    tail -> [head -> all_reduce] || [L x w8pt_bwd].  Measured on this stack (scripts/exchange_probe.py, one-rank RCCL, B = 4096):
+    the in-order node costs nothing measurable, the branch +33 us per step (cross-stream edges of a hipGraph, like stream-event
+    waits outside one, cost 18-30 us each here -- more than the 72-byte collective they would hide), so the branch is the option,
+    not the default.  Either way ``packed`` holds the reduced sums after the backward."""
     L, B, N = logits_layers.shape
     H, W = float(image_size[0]), float(image_size[1])
     dev = matches.device
@@ -261,7 +271,7 @@ def hot_path_fused(matches: Tensor, logits_layers: Tensor, Ks: Tensor, virt1: Te
     if loss_exchange is not None:
         if not fused_tail:
             raise _lib.DfepeError("loss_exchange rides behind the fused loss tail (fused_tail=True)")
-        exchange = (loss_exchange, exchange_stream if exchange_stream is not None else _exchange_stream(dev))
+        exchange = (loss_exchange, (exchange_stream if exchange_stream is not None else _exchange_stream(dev)) if exchange_branch else None)
     cfg = (H, W, float(clamp_at), bool(qt), float(clamp_q), float(clamp_t), float(balance_q), float(balance_t), bool(layers_batched),
            float(balance_F), bool(fused_tail), grad_pairs, bool(defer_loss_head), exchange)
     res = _HotPathFunction.apply(f32(matches), f32(logits_layers), f32(Ks), f32(virt1), f32(virt2), f32(q_gt.reshape(B, 4)),
