@@ -1,5 +1,6 @@
 """Mirror of the hot-path functions of deepFEPE/dsac_tools/utils_F.py, evaluated by libdfepe_hip.so.
 Signatures follow the reference; tensors must live on the GPU."""
+import numpy as np
 import torch
 
 from .. import _lib, ops
@@ -81,6 +82,52 @@ def _E_to_F(E, K):
     E, K = _gpu(E), _gpu(K)
     Ki = torch.linalg.inv(K)
     return Ki.transpose(-1, -2) @ E @ Ki
+
+
+def E_to_F_np(E, K):
+    """F = K^-T E K^-1 in numpy, single [3,3] or batched [B,3,3] (utils_F.py:471-476).  The reference's batched branch drops its
+    result (no assignment, :475) and then fails on the return; here it returns the value that line computes, with the
+    transposition written as the batched transpose it means."""
+    E, K = np.asarray(E), np.asarray(K)
+    Kinv = np.linalg.inv(K)
+    if E.ndim == 2:
+        return Kinv.T @ E @ Kinv
+    return np.transpose(Kinv, (0, 2, 1)) @ E @ Kinv
+
+
+def _E_F_from_Rt(R_th, t_th, K_th, tensor_input=False):
+    """(E, F) of a relative pose, E = [t]_x R, F = K^-T E K^-1; numpy inputs are promoted to float64 tensors unless
+    ``tensor_input`` (utils_F.py:820-833).  R [3,3] / t [3,1] / K [3,3] or batched [B,...].  Plain small torch ops on whatever
+    device the inputs live on, differentiable like the reference's."""
+    from . import utils_misc
+
+    if not tensor_input:
+        K_th = torch.from_numpy(np.asarray(K_th)).to(torch.float64)
+        R_th = torch.from_numpy(np.asarray(R_th)).to(torch.float64)
+        t_th = torch.from_numpy(np.asarray(t_th)).to(torch.float64)
+    E_gt_th = utils_misc._skew_symmetric(t_th) @ R_th
+    Kinv = torch.inverse(K_th)
+    if R_th.dim() == 2:
+        F_gt_th = torch.matmul(torch.matmul(Kinv.t(), E_gt_th), Kinv)
+    else:
+        F_gt_th = Kinv.transpose(1, 2) @ E_gt_th @ Kinv
+    return E_gt_th, F_gt_th
+
+
+def E_F_from_Rt_np(R, t, K):
+    """numpy twin of _E_F_from_Rt (utils_F.py:835-846): the ground-truth convention of the data sets.  The
+    reference's batched branch calls ndarray.transpose(1, 2) on a 3-D array (:845), which raises; the batched transpose it
+    means is used here."""
+    from . import utils_misc
+
+    R, t, K = np.asarray(R), np.asarray(t), np.asarray(K)
+    E_gt = utils_misc.skew_symmetric_np(t) @ R
+    Kinv = np.linalg.inv(K)
+    if R.ndim == 2:
+        F_gt = Kinv.T @ E_gt @ Kinv
+    else:
+        F_gt = np.transpose(Kinv, (0, 2, 1)) @ E_gt @ Kinv
+    return E_gt, F_gt
 
 
 def _no_grad_here(what, *tensors):

@@ -47,3 +47,69 @@ def invert_Rt(R21, t21):
     calls np.linalg.inv, this is the closed form of the same matrix)."""
     Rt = utils_misc.inv_Rt_np(np.hstack((np.asarray(R21), np.asarray(t21).reshape(3, 1))))
     return Rt[:, :3], Rt[:, 3:4]
+
+
+# ---- the small host-side helpers of the module (plain numpy / elementwise torch like the reference's: no kernel needed) --------
+def R_to_q_np(matrix):
+    """Rotation matrix [3,3] -> unit quaternion [4,1] float32 with q0 >= 0: the trace method on R^T with its four branches
+    (utils_geo.py:88-117; the numpy twin of _R_to_q and what the synthetic ground truth of SURVEY §8d is built with)."""
+    m = np.asarray(matrix).conj().transpose()
+    if m[2, 2] < 0:
+        if m[0, 0] > m[1, 1]:
+            t = 1 + m[0, 0] - m[1, 1] - m[2, 2]
+            q = [m[1, 2] - m[2, 1], t, m[0, 1] + m[1, 0], m[2, 0] + m[0, 2]]
+        else:
+            t = 1 - m[0, 0] + m[1, 1] - m[2, 2]
+            q = [m[2, 0] - m[0, 2], m[0, 1] + m[1, 0], t, m[1, 2] + m[2, 1]]
+    else:
+        if m[0, 0] < -m[1, 1]:
+            t = 1 - m[0, 0] - m[1, 1] + m[2, 2]
+            q = [m[0, 1] - m[1, 0], m[2, 0] + m[0, 2], m[1, 2] + m[2, 1], t]
+        else:
+            t = 1 + m[0, 0] + m[1, 1] + m[2, 2]
+            q = [t, m[1, 2] - m[2, 1], m[2, 0] - m[0, 2], m[0, 1] - m[1, 0]]
+    q = np.array(q, dtype=np.float32)
+    q *= 0.5 / np.sqrt(t)
+    if q[0] < 0.0:
+        q = -q
+    return q.reshape(-1, 1)
+
+
+def q_matrix_np(q):
+    """Left-multiplication matrix of the quaternion q [4,1] (utils_geo.py:119-126)."""
+    a, b, c, d = (q[i, 0] for i in range(4))
+    return np.array([[a, -b, -c, -d], [b, a, -d, c], [c, d, a, -b], [d, -c, b, a]])
+
+
+def q_bar_matrix_np(q):
+    """Right-multiplication matrix of the quaternion q [4,1] (utils_geo.py:128-135)."""
+    a, b, c, d = (q[i, 0] for i in range(4))
+    return np.array([[a, -b, -c, -d], [b, a, d, -c], [c, -d, a, b], [d, c, -b, a]])
+
+
+def q_to_R_np(q):
+    """Quaternion [4,1] -> rotation matrix [3,3]; q is normalised first with the reference's +1e-10 (utils_geo.py:137-147)."""
+    q = np.asarray(q)
+    q = q / (np.linalg.norm(q) + 1e-10)
+    product_matrix = np.dot(q_matrix_np(q), q_bar_matrix_np(q).conj().transpose())
+    return product_matrix[1:][:, 1:]
+
+
+def _rot_angle_error(R0, R1):
+    """acos(clamp((tr(R0 R1^T) - 1) / 2)) in degrees, torch in / 0-dim torch out, differentiable like the reference's
+    (utils_geo.py:158-163)."""
+    rot_error = torch.acos(torch.clamp((torch.trace(R0 @ (R1.t())) - 1) / 2, -1.0, 1.0))
+    return rot_error / np.pi * 180.0
+
+
+def dotproducts(v1s, v2s):
+    return np.sum(v1s * v2s, axis=1, keepdims=True)
+
+
+def vectors_angle(v1s, v2s):
+    """Row-wise angle in degrees between v1s and v2s [N,3] -> [N,1]; unlike vector_angle, no epsilons and no clipping
+    (utils_geo.py:184-190)."""
+    dot_v1sv2s = dotproducts(v1s, v2s)
+    length_v1s = np.sqrt(dotproducts(v1s, v1s))
+    length_v2s = np.sqrt(dotproducts(v2s, v2s))
+    return np.arccos(dot_v1sv2s / (length_v1s * length_v2s)) / np.pi * 180.0
