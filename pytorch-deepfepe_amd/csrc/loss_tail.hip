@@ -16,7 +16,10 @@ static_assert(sizeof(TailHead) <= kTailDescBytes, "descriptor slot too small");
 // lane per (pair, layer) -- 16 L items, layer-major so that a wavefront's lanes run the same layer.  The two parts are
 // independent until the final g_F = coef_F * (F-loss part) + (pose part), so they run CONCURRENTLY on the same SIMDs: B = 4096
 // is one F-loss wavefront per SIMD, and a lone wavefront leaves a quarter of the issue slots and every memory wait unused.
-// (In one row per pair, one part after the other, the kernel took 17 us.)
+// (In one row per pair, one part after the other, the kernel took 17 us.  Round 4 tried TEN wavefronts -- two F-loss wavefronts per
+// SIMD, each with half of the layers of its pairs: three wavefronts then share two of the SIMDs, which caps the kernel at 168
+// registers; the F-loss row (virtual points of both images in registers through the fp64 transform) and the pose lane each need
+// ~200, the build spilled 130-220 bytes per lane and the launch took 19.7 us instead of 12.8: reverted.)
 // Leading scalar / pointer arguments: preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count, see w8pt16.hip); the
 // kernel reads them instead of the copies inside A.
 template <int IT, bool JAC = false>

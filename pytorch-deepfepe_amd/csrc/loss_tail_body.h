@@ -177,8 +177,12 @@ __device__ __forceinline__ void tail_pose_item(const TailArgs& A, const int pair
 // gsum[ly] and writes loss_sum / part[ly].  Phase 2 (tail_floss_finish), after the pose items of this pair are done:
 // g_F = coef_F * gsum + gpose (lane c < 9 reads back what it wrote).
 // ldsF, gsum: kTailMaxLayers * 9 floats each, private to the row.
-template <int IT, bool JAC = false>
-__device__ __forceinline__ void tail_floss_row(const TailArgs& A, const int pair, float* ldsF, double* part, float* gsum) {
+// ly_begin .. ly_end: the layers this row works on (the kernel gives each half of a pair's layers to a row in a different
+// wavefront, both rows transforming the pair's virtual points: two shorter instruction streams per SIMD instead of one long one);
+// KL: layers walked together by one row (2 = a second independent stream for a wavefront that is alone on its SIMD).
+template <int IT, bool JAC = false, int KL = 2>
+__device__ __forceinline__ void tail_floss_row(const TailArgs& A, const int pair, float* ldsF, double* part, float* gsum,
+                                               const int ly_begin = 0, const int ly_end_in = -1) {
   const int l = rg_lane();
   const int L = A.L, B = A.B, M = A.M;
   // every global load first: transforms, the pair's virtual points (index clamped, masked afterwards), F of every layer
@@ -279,9 +283,12 @@ __device__ __forceinline__ void tail_floss_row(const TailArgs& A, const int pair
       if (JAC && l < 9) A.J[((size_t)ly * B + pair) * 27 + l] = mine;
     }
   };
-  int ly = 0;
-  for (; ly + 1 < L; ly += 2) layers(std::integral_constant<int, 2>{}, ly);
-  if (ly < L) layers(std::integral_constant<int, 1>{}, ly);
+  const int ly_end = (ly_end_in < 0) ? L : ly_end_in;
+  int ly = ly_begin;
+  if constexpr (KL >= 2) {
+    for (; ly + 1 < ly_end; ly += 2) layers(std::integral_constant<int, 2>{}, ly);
+  }
+  for (; ly < ly_end; ++ly) layers(std::integral_constant<int, 1>{}, ly);
 }
 __device__ __forceinline__ void tail_floss_finish(const TailArgs& A, const int pair, const float* gsum, const float* gpose /*[L][9]*/) {
   const int l = rg_lane();
