@@ -1,5 +1,7 @@
 """Mirror of the two loss functions of deepFEPE/train_good_utils.py on the hot path:
 get_all_loss_DeepF (:298-520) and get_Rt_loss (:64-295), same arguments and return structures."""
+import threading
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -131,7 +133,15 @@ def _dense_T(T, B):
     return hit[1]
 
 
-_last_tail = {}  # the fused tail of the latest get_all_loss_DeepF call that was given the ground truth (loss_params["pose_gt"])
+class _PerThread(threading.local):
+    """The fused tail of this thread's latest get_all_loss_DeepF call that was given the ground truth (loss_params["pose_gt"]);
+    per thread because nn.DataParallel runs one python thread per GPU through these functions (train_good.py:311-312)."""
+
+    def __init__(self):
+        self.tail = {}
+
+
+_state = _PerThread()
 
 
 def get_all_loss_DeepF(outs, pts1_virt_ori, pts2_virt_ori, Ks, loss_params, get_residual_summaries=True):
@@ -156,7 +166,7 @@ def get_all_loss_DeepF(outs, pts1_virt_ori, pts2_virt_ori, Ks, loss_params, get_
     M = pts1_virt_ori.shape[1]
     B = F_layers.shape[1]
     gt = loss_params.get("pose_gt")
-    _last_tail.clear()
+    _last_tail = _state.tail = {}
     # loss_epi_res (:429-438, logged only): sum_n epi_res * weights of every (layer, pair) in one launch; its means ride in the
     # statistics launch below
     epidot, n_epi, N_pts = None, 0, 1
@@ -246,10 +256,11 @@ def get_Rt_loss(E_ests_layers, Ks_cpu, x1_cpu, x2_cpu, delta_Rtijs_4_4_cpu, qs_c
     dev = E_layers.device
     q_gt, t_gt = torch.as_tensor(qs_cam).to(dev), torch.as_tensor(ts_cam).to(dev)
     delta = torch.as_tensor(delta_Rtijs_4_4_cpu).to(dev)
-    lt = _last_tail
+    lt = _state.tail
     L = E_layers.shape[0]
     if lt and lt["E"].data_ptr() == E_layers.data_ptr() and lt["E"].shape == E_layers.shape and lt["gt"] == tuple(x.data_ptr() for x in (q_gt, t_gt, delta)):
         q_l2, t_l2, ang, m_q, o_q, m_t, o_t = (lt[k] for k in ("q_l2", "t_l2", "ang", "m_q", "o_q", "m_t", "o_t"))  # get_all_loss_DeepF's launches
+        _state.tail = {}  # consumed: do not keep the step's graph alive until the next call
     else:
         R_gt = ops.camera_rotation(delta)
         _, q_l2, t_l2, ang, _ = ops.pose_errors_packed(E_layers, q_gt, t_gt, R_gt)

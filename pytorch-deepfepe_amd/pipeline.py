@@ -334,15 +334,16 @@ class LinearProbeEstimator(FixedLogitsEstimator):
     through which gradients reach residual / epi_res / weights of the previous fit, i.e. one that makes every layer but the last
     run the backward the real recurrent model runs (w8pt_bwd with g_residual, g_epi and the weights gradient)."""
 
-    def __init__(self, rows, coef=(0.5, -2.0, 40.0)):
+    def __init__(self, rows, coef=(0.5, -2.0, 40.0), first_channel=4):
         super().__init__(rows)
         self.coef = tuple(float(c) for c in coef)
+        self.first = int(first_channel)  # 4 + quality channels
 
     def forward(self, data):
         base = super().forward(data)
         if getattr(self, "_c", None) is None or self._c.device != data.device:  # one host copy, on the first (eager) call
             self._c = data.new_tensor(self.coef).view(1, 3, 1)
-        return base + (data[:, 4:7, :] * self._c).sum(dim=1, keepdim=True)
+        return base + (data[:, self.first:self.first + 3, :] * self._c).sum(dim=1, keepdim=True)
 
 
 def make_api_net(depth: int, image_size: Sequence[int], logits_rows: Sequence[Tensor], recurrent_probe: bool = False):

@@ -63,8 +63,8 @@ def test_both_tails_give_identical_gradients_and_the_fused_one_is_found_by_get_R
     la, _, _, geo_a, ga = _api(dfepe, d, L, False)
     lb, _, _, geo_b, gb = _api(dfepe, d, L, True)
     assert torch.stack(geo_b["q_l2_error_layers_list"]).grad_fn is not None
-    assert geo_b["q_l2_error_layers_list"][0].data_ptr() == tgu._last_tail["q_l2"].data_ptr()  # the fused launch's buffer
-    assert geo_a["q_l2_error_layers_list"][0].data_ptr() != tgu._last_tail["q_l2"].data_ptr()
+    assert geo_b["q_l2_error_layers_list"][0].data_ptr() == tgu._state.tail["q_l2"].data_ptr()  # the fused launch's buffer
+    assert geo_a["q_l2_error_layers_list"][0].data_ptr() != tgu._state.tail["q_l2"].data_ptr()
     assert abs(la.item() - lb.item()) < 1e-7
     assert float((ga - gb).abs().max()) < 1e-6 * float(ga.abs().max())
     # another ground truth than the one get_all_loss_DeepF was promised: get_Rt_loss must not use the cached errors
@@ -293,3 +293,49 @@ def test_row_dot_on_contiguous_and_strided_stacks(dfepe):
     (dfepe.ops.row_dot(a_leaf, b) * up).sum().backward()
     np.testing.assert_allclose(b.grad.cpu().numpy(), (up[:, :, None] * a_leaf.detach()).cpu().numpy(), rtol=1e-6)
     np.testing.assert_allclose(a_leaf.grad.cpu().numpy(), (up[:, :, None] * b.detach()).cpu().numpy(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("quality,depth", [(0, 3), (2, 3), (0, 1), (2, 2)])
+def test_deepfnet_without_cat_equals_the_cat_path(dfepe, quality, depth):
+    """DeepFNet.forward's default path (estimator inputs channel-major, the fit kernels writing the three recurrent channels in place,
+    no torch.cat per layer) against the same model forced onto the reference-shaped path (fresh output tensors + torch.cat), with an
+    estimator stand-in that reads the recurrent channels: same outputs, same gradients w.r.t. the logits; quality channels included."""
+    B, N = 21, 100
+    d = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(B, N, seed=3, outlier_ratio=0.2, noise_px=0.5, depth_layers=max(depth, 1)), DEV)
+    g = torch.Generator().manual_seed(1)
+    qual = torch.rand(B, N, max(quality, 1), generator=g).to(DEV)
+    up = [torch.randn(B, 3, 3, generator=g).to(DEV) for _ in range(depth)]
+    res = {}
+    for mode in ("stores", "cat"):
+        rows = [d["logits_layers"][l].detach().clone().unsqueeze(1).requires_grad_(True) for l in range(depth)]
+        net = dfepe.compat.DeepFNet.DeepFNet(depth=depth, image_size=IMAGE_SIZE, if_quality=quality > 0, quality_size=quality)
+        net.input_weights = dfepe.pipeline.FixedLogitsEstimator(rows[:1])
+        net.update_weights = dfepe.pipeline.LinearProbeEstimator(rows[1:] or rows[:1], first_channel=4 + quality)
+        seen = []
+        if mode == "cat":
+            orig = net._fit
+
+            def fresh(matches, logits, data_batch, want_epi, dst=None, _o=orig):
+                return tuple(t * 1.0 for t in _o(matches, logits, data_batch, want_epi, None))  # new tensors: nothing lives in the stores
+
+            net._fit = fresh
+        hook = net.update_weights.register_forward_pre_hook(lambda mod, inp: seen.append(inp[0].detach().clone()))
+        batch = {"matches_xy_ori": d["matches_xy_ori"], "matches_good_unique_nums": None, "t_scene_scale": None}
+        if quality:
+            batch["quality"] = qual
+        outs = net(batch)
+        hook.remove()
+        loss = sum((outs["out_layers"][l] * up[l]).sum() for l in range(depth)) + sum(r.sum() * 1e-3 for r in outs["residual_layers"])
+        grads = torch.autograd.grad(loss, rows)
+        res[mode] = (outs, grads, seen)
+    (oa, ga, sa), (ob, gb, sb) = res["stores"], res["cat"]
+    assert len(sa) == depth - 1 == len(sb)
+    for x, y in zip(sa, sb):
+        assert x.shape == (B, 4 + quality + 3, N) and torch.equal(x, y)  # the estimator saw the same [B,C,N] input either way
+    for l in range(depth):
+        assert torch.equal(oa["out_layers"][l], ob["out_layers"][l]) and torch.equal(oa["weights_layers"][l], ob["weights_layers"][l])
+        assert torch.equal(oa["residual_layers"][l], ob["residual_layers"][l])
+        np.testing.assert_allclose(ga[l].cpu().numpy(), gb[l].cpu().numpy(), rtol=1e-5, atol=1e-7 * float(gb[l].abs().max()))
+    if depth > 1:
+        assert dfepe.ops.alias_rows(oa["epi_res_layers"]) is not None and dfepe.ops.alias_rows(oa["weights_layers"][:depth - 1]) is not None
+    assert dfepe.ops.alias_rows(oa["out_layers"]).is_contiguous()
