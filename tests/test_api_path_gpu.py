@@ -60,11 +60,23 @@ def test_both_tails_give_identical_gradients_and_the_fused_one_is_found_by_get_R
     B, N, L = 64, 100, 3
     d = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(B, N, seed=5, outlier_ratio=0.3, noise_px=0.5, depth_layers=L), DEV)
     tgu = dfepe.compat.train_good_utils
-    la, _, _, geo_a, ga = _api(dfepe, d, L, False)
-    lb, _, _, geo_b, gb = _api(dfepe, d, L, True)
+    calls = {"n": 0}
+    real = dfepe.ops.pose_errors_packed
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    dfepe.ops.pose_errors_packed = counting
+    try:
+        la, _, _, geo_a, ga = _api(dfepe, d, L, False)
+        assert calls["n"] == 1  # the reference's signature: get_Rt_loss launches the pose kernel
+        lb, _, _, geo_b, gb = _api(dfepe, d, L, True)
+        assert calls["n"] == 1  # with pose_gt it finds the errors of get_all_loss_DeepF's launch
+    finally:
+        dfepe.ops.pose_errors_packed = real
     assert torch.stack(geo_b["q_l2_error_layers_list"]).grad_fn is not None
-    assert geo_b["q_l2_error_layers_list"][0].data_ptr() == tgu._state.tail["q_l2"].data_ptr()  # the fused launch's buffer
-    assert geo_a["q_l2_error_layers_list"][0].data_ptr() != tgu._state.tail["q_l2"].data_ptr()
+    assert tgu._state.tail == {}  # consumed by get_Rt_loss: the step's graph is not kept alive
     assert abs(la.item() - lb.item()) < 1e-7
     assert float((ga - gb).abs().max()) < 1e-6 * float(ga.abs().max())
     # another ground truth than the one get_all_loss_DeepF was promised: get_Rt_loss must not use the cached errors
