@@ -174,7 +174,7 @@ def count_launches(fn):
             if str(getattr(ev, "device_type", "")).endswith("CUDA") and "memcpy" not in ev.name.lower() and "memset" not in ev.name.lower():
                 names[ev.name] = names.get(ev.name, 0) + 1
         n = sum(names.values())
-        ours = sum(c for k, c in names.items() if any(t in k for t in ("w8pt", "loss_tail", "loss_stats", "floss", "pose_", "geo_misc", "deepf_input")))
+        ours = sum(c for k, c in names.items() if any(t in k for t in ("w8pt", "loss_tail", "loss_stats", "floss", "pose_", "geo_misc", "deepf_input", "row_dot")))
         return {"total": n, "hip_kernels_of_this_library": ours, "torch_glue": n - ours} if n else None
     except Exception:
         return None

@@ -42,7 +42,7 @@ with profile(activities=[ProfilerActivity.CUDA]) as prof:
     torch.cuda.synchronize()
 evs = [e for e in prof.events() if str(getattr(e, "device_type", "")).endswith("CUDA")]
 evs.sort(key=lambda e: e.time_range.start)
-ours = ("w8pt", "loss_tail", "loss_stats", "floss", "pose_", "geo_misc", "deepf_input")
+ours = ("w8pt", "loss_tail", "loss_stats", "floss", "pose_", "geo_misc", "deepf_input", "row_dot")
 n_ours = 0
 for i, e in enumerate(evs):
     mine = any(t in e.name for t in ours)
