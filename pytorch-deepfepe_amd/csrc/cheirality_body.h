@@ -56,7 +56,10 @@ __device__ __forceinline__ f2 pk_max(f2 a, f2 b) { return __builtin_elementwise_
 __device__ __forceinline__ f2 pk_sqrt(f2 a) { return f2{hw_sqrt(a.x), hw_sqrt(a.y)}; }
 __device__ __forceinline__ f2 pk_rcp(f2 a) { return f2{hw_rcp(a.x), hw_rcp(a.y)}; }
 
-__device__ inline void smallest_eigvec4_pk(const f2* S /*4x4 row-major, symmetric, unit trace*/, f2* x) {
+// gapprod (optional): |d det(T - lam I) / d lam| at the returned eigenvalue = (lam1 - lam4)(lam2 - lam4)(lam3 - lam4) for a unit-trace
+// matrix: the quantity that bounds the error of x (see cheirality_pair: the fp32 stage decides a correspondence on its own only
+// where that bound leaves its depth tests unambiguous).
+__device__ inline void smallest_eigvec4_pk(const f2* S /*4x4 row-major, symmetric, unit trace*/, f2* x, f2* gapprod = nullptr) {
   const f2 zero = f2s(0.0f), two = f2s(2.0f);
   // ---- Householder 1 on (S10, S20, S30)
   const f2 a0 = S[4], a1 = S[8], a2 = S[12];
@@ -112,6 +115,10 @@ __device__ inline void smallest_eigvec4_pk(const f2* S /*4x4 row-major, symmetri
   // ---- null vector of T - lam: the adjugate column with the largest diagonal cofactor
   const f2 c0 = d0 - lam, c1 = d1 - lam, c2 = d2 - lam, c3 = d3 - lam;
   const f2 P1 = c0, P2 = c1 * c0 - f0, P3 = c2 * P2 - f1 * P1;
+  if (gapprod != nullptr) {  // derivative of the characteristic polynomial by the same recurrence the iteration uses
+    const f2 D2 = -c1 - c0, D3 = c2 * D2 - P2 + f1;
+    *gapprod = pk_abs(c3 * D3 - P3 - f2_ * D2);
+  }
   const f2 Q3 = c3, Q2 = c2 * c3 - f2_, Q1 = c1 * Q2 - f1 * Q3;
   const f2 g0 = pk_abs(Q1), g1 = pk_abs(P1 * Q2), g2 = pk_abs(P2 * Q3), g3 = pk_abs(P3);
   const i2 b1 = g1 > g0;                  // best of (0, 1)
@@ -164,13 +171,19 @@ __device__ inline void rqi_refine4(const double* S, const double* x0, double* y)
   y[0] = w0 - l10 * y[1] - l20 * y[2] - l30 * y[3];
 }
 
+constexpr int kCheirQueue = 128;  // ints of LDS per wavefront: indices of the correspondences waiting for the fp64 route (< 64 + 64)
+struct CheirLds {
+  int wcnt[8][4];
+  int queue[8 * kCheirQueue];
+};
+
 // One workgroup per pair (every thread of the workgroup must call; W = blockDim.x / 64 wavefronts each take every W-th group of 64
 // correspondences and meet in `wcnt`, LDS owned by the caller).  E9: the matrix to decompose (or F when `pre` is given: then
 // pre^T E9 pre is decomposed), identical in every thread.
 __device__ __forceinline__ void cheirality_pair(const float* E9, const float* __restrict__ pre, const float* __restrict__ K,
                                                 const float* __restrict__ matches, const size_t pair, const int N, const float depth_thres,
                                                 float* __restrict__ Rt_cam, int* __restrict__ winner, int* __restrict__ counts,
-                                                int (*wcnt)[4]) {
+                                                int (*wcnt)[4], int* queue) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
   double Ed[9], Kd[9], R[2][9], t[3];
@@ -205,34 +218,37 @@ __device__ __forceinline__ void cheirality_pair(const float* E9, const float* __
     }
   int cnt[4] = {0, 0, 0, 0};
   const int nw = blockDim.x >> 6;  // 4 wavefronts per pair for small batches (latency), 1 for large ones (throughput)
-  // the next group's correspondence is loaded (index clamped, no branch) before the current one is triangulated: ~1 600
-  // instructions of DLT work cover its latency
   const float4* mrow = reinterpret_cast<const float4*>(matches) + pair * N;
-  float4 mnext = mrow[min(wave * WAVE + lane, N - 1)];
-  for (int base = wave * WAVE; base < N; base += nw * WAVE) {
-    const int i = base + lane;
-    const bool live = i < N;
-    const float4 m = mnext;
-    mnext = mrow[min(i + nw * WAVE, N - 1)];
-    // One DLT per rotation: flipping t negates the 4th column of the view-2 rows, hence the 4th component of the null
-    // vector, hence both depths exactly -- candidates (R,t) and (R,-t) are counted from the same triangulation.
-    // DLT rows: x*P[2]-P[0], y*P[2]-P[1] for both views (P1 = K [I|0]); the view-1 rows are shared by the two candidates.
-    const double x1 = m.x, y1 = m.y, x2 = m.z, y2 = m.w;
-    double A1[6];  // view-1 rows, columns 0..2 (column 3 is zero)
+  // the rows of one correspondence in fp64 (formed where they are used, from the fp32 pixel coordinates)
+  auto rows1 = [&](const float4& m, double* A1) {  // view-1 rows, columns 0..2 (column 3 is zero)
+    const double x1 = m.x, y1 = m.y;
 #pragma unroll
     for (int c = 0; c < 3; ++c) { A1[c] = x1 * Kd[6 + c] - Kd[c]; A1[3 + c] = y1 * Kd[6 + c] - Kd[3 + c]; }
-    double S1[6];  // their contribution to the upper-left 3x3 of A^T A: (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+  };
+  auto rows2 = [&](const float4& m, const int rr, double* A2) {  // view-2 rows of candidate rr
+    const double x2 = m.z, y2 = m.w;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { A2[c] = x2 * P2s[rr][8 + c] - P2s[rr][c]; A2[4 + c] = y2 * P2s[rr][8 + c] - P2s[rr][4 + c]; }
+  };
+  // One DLT per rotation: flipping t negates the 4th column of the view-2 rows, hence the 4th component of the null
+  // vector, hence both depths exactly -- candidates (R,t) and (R,-t) are counted from the same triangulation.
+  // DLT rows: x*P[2]-P[0], y*P[2]-P[1] for both views (P1 = K [I|0]); the view-1 rows are shared by the two candidates.
+  //
+  // ---- the fp64 route (rounds 2-3: every correspondence; round 4: only the ambiguous ones, see below): normal matrices of both
+  // candidates in fp64, scaled to unit trace (the null vector does not care; the Newton seeds and the fp32 stage want O(1) operands
+  // whatever the pixel scale), both smallest eigenvectors to fp32 accuracy (packed), ONE Rayleigh-quotient iteration in fp64 each
+  // (cubic convergence: <= 1e-9 from the fp32 vector's 2e-7 median / 1e-4 tail error), division-free depth tests.
+  auto dlt_fp64 = [&](const float4& m, const bool live) {
+    double A1[6];
+    rows1(m, A1);
+    double S1[6];  // view-1 contribution to the upper-left 3x3 of A^T A: (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
     S1[0] = A1[0] * A1[0] + A1[3] * A1[3]; S1[1] = A1[0] * A1[1] + A1[3] * A1[4]; S1[2] = A1[0] * A1[2] + A1[3] * A1[5];
     S1[3] = A1[1] * A1[1] + A1[4] * A1[4]; S1[4] = A1[1] * A1[2] + A1[4] * A1[5]; S1[5] = A1[2] * A1[2] + A1[5] * A1[5];
-    // ---- fp64 normal matrices of both candidates, scaled to unit trace (the null vector does not care; the Newton seeds and the
-    // fp32 stage want O(1) operands whatever the pixel scale)
     double S[2][16];
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
-      const double* P2 = P2s[rr];
       double A2[8];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { A2[c] = x2 * P2[8 + c] - P2[c]; A2[4 + c] = y2 * P2[8 + c] - P2[4 + c]; }
+      rows2(m, rr, A2);
       double* Sr = S[rr];
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -245,7 +261,6 @@ __device__ __forceinline__ void cheirality_pair(const float* E9, const float* __
 #pragma unroll
         for (int c = r; c < 4; ++c) Sr[4 * r + c] *= itr;
     }
-    // ---- stage 1: both smallest eigenvectors to fp32 accuracy, packed
     f2 Sp[16], Xp[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -255,7 +270,6 @@ __device__ __forceinline__ void cheirality_pair(const float* E9, const float* __
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
       const double* Rc = R[rr];
-      // ---- stage 2: one Rayleigh-quotient iteration in fp64
       const double x0[4] = {(double)Xp[0][rr], (double)Xp[1][rr], (double)Xp[2][rr], (double)Xp[3][rr]};
       double X[4];
       rqi_refine4(S[rr], x0, X);
@@ -274,6 +288,115 @@ __device__ __forceinline__ void cheirality_pair(const float* E9, const float* __
       cnt[2 * rr] += __popcll(__ballot(pos));
       cnt[2 * rr + 1] += __popcll(__ballot(neg));
     }
+  };
+  // ---- ROUND 4: the fp32 stage decides on its own wherever it safely can.  Every correspondence goes through the FAST PATH -- the
+  // whole eigenproblem of both candidates in packed fp32: normal matrices from the fp32-rounded rows, stage 1 -- and the depth
+  // tests on that vector.  Measured (scripts/proto_cheirality_margin.py, a numpy twin of this path; 6 scene families, 288 000 tests
+  // against numpy.linalg.eigh): the fp32 vector decides every test like the fp64 one, and its error obeys
+  //     |x~ - x| <= 2.9e-8 / ((lam1 - lam4)(lam2 - lam4)(lam3 - lam4))        (unit trace, unit vectors; 99.9th percentile 1.5e-8)
+  // so a correspondence is AMBIGUOUS when one of its test quantities lies within delta = 8 x 4e-8 / gapprod (at least 1e-6) times
+  // |x| of its bound (0.1-2 % of them, depending on how good E is).  The ambiguous ones are not decided here: their indices go to
+  // a per-wavefront queue in LDS and take the fp64 route above 64 at a time -- a full wavefront of them, not the group of 64 they
+  // happened to sit in (forcing the whole group through the fp64 stage sent 39 % of the groups of the benchmark's config 5 there:
+  // 99 us against 83 us for the fast path alone and 124 us for the fp64 route alone, scripts/ab_cheirality.sh).
+  int qn = 0;  // queued indices of this wavefront (uniform)
+  int* q = queue + wave * kCheirQueue;
+  // the next group's correspondence is loaded (index clamped, no branch) before the current one is triangulated
+  float4 mnext = mrow[min(wave * WAVE + lane, N - 1)];
+  for (int base = wave * WAVE; base < N; base += nw * WAVE) {
+    const int i = base + lane;
+    const bool live = i < N;
+    const float4 m = mnext;
+    mnext = mrow[min(i + nw * WAVE, N - 1)];
+    f2 Xp[4];
+    bool amb_lane = false;
+    bool pos_f[2], neg_f[2];
+    {
+      float A1f[6];
+      {
+        double A1[6];
+        rows1(m, A1);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) A1f[c] = (float)A1[c];
+      }
+      const float s00 = A1f[0] * A1f[0] + A1f[3] * A1f[3], s01 = A1f[0] * A1f[1] + A1f[3] * A1f[4], s02 = A1f[0] * A1f[2] + A1f[3] * A1f[5];
+      const float s11 = A1f[1] * A1f[1] + A1f[4] * A1f[4], s12 = A1f[1] * A1f[2] + A1f[4] * A1f[5], s22 = A1f[2] * A1f[2] + A1f[5] * A1f[5];
+      f2 A2p[8];
+      {
+        double Aa[8], Ab[8];
+        rows2(m, 0, Aa);
+        rows2(m, 1, Ab);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) A2p[c] = f2{(float)Aa[c], (float)Ab[c]};
+      }
+      f2 Sp[16];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = r; c < 4; ++c) Sp[4 * r + c] = A2p[r] * A2p[c] + A2p[4 + r] * A2p[4 + c];
+      Sp[0] += f2s(s00); Sp[1] += f2s(s01); Sp[2] += f2s(s02); Sp[5] += f2s(s11); Sp[6] += f2s(s12); Sp[10] += f2s(s22);
+      const f2 itr = pk_rcp(pk_max(Sp[0] + Sp[5] + Sp[10] + Sp[15], f2s(1e-30f)));
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = r; c < 4; ++c) { Sp[4 * r + c] *= itr; Sp[4 * c + r] = Sp[4 * r + c]; }
+      f2 gp;
+      smallest_eigvec4_pk(Sp, Xp, &gp);
+      const float thrf = depth_thres;
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const float X0 = Xp[0][rr], X1 = Xp[1][rr], X2 = Xp[2][rr], X3 = Xp[3][rr];
+        const float nrm = hw_sqrt(X0 * X0 + X1 * X1 + X2 * X2 + X3 * X3);
+        // R and t live in scalar registers as doubles: used as they are (fp32 copies would be loop-invariant VECTOR registers)
+        const float z2n = (float)(R[rr][6] * (double)X0 + R[rr][7] * (double)X1 + R[rr][8] * (double)X2 + t[2] * (double)X3);
+        const float aw = thrf * fabsf(X3);
+        const float g = gp[rr];
+        const float dl = fmaxf(3.2e-7f * hw_rcp(fmaxf(g, 1e-30f)), 1e-6f) * nrm;
+        // (1 + thr) dl and (2 + thr) dl as FMAs on the scalar thr: no loop-invariant vector register for the sums; `|`, not `||`:
+        // mask arithmetic on the scalar unit instead of a branch per term
+        const float m1 = fmaf(thrf, dl, dl), m2 = fmaf(thrf, dl, dl + dl);
+        const bool amb = !(g > 0.0f) | !(nrm > 0.0f) | !(nrm < 1e30f) | (fabsf(X3) < dl) | (fabsf(X2) < dl) | (fabsf(z2n) < dl + dl) |
+                         (fabsf(fabsf(X2) - aw) < m1) | (fabsf(fabsf(z2n) - aw) < m2);
+        amb_lane = amb_lane | (amb & live);
+        const bool inr = live & (fabsf(X2) < aw) & (fabsf(z2n) < aw);
+        const bool s1p = (X2 > 0.0f) == (X3 > 0.0f), s2p = (z2n > 0.0f) == (X3 > 0.0f);
+        pos_f[rr] = inr & s1p & s2p;      // both depths in (0, thr); zeros are ambiguous and never decided here
+        neg_f[rr] = inr & !s1p & !s2p;    // both in (-thr, 0): the (R, -t) candidate sees them in (0, thr)
+      }
+    }
+#if defined(DFEPE_CHEIR_ALWAYS_FAST)   // A/B timing builds only (scripts/ab_cheirality.sh): lower / upper bound of the adaptive kernel
+    amb_lane = false;
+#elif defined(DFEPE_CHEIR_ALWAYS_SLOW)
+    amb_lane = live;
+#endif
+    const unsigned long long amask = __ballot(amb_lane);
+    // a lane that is safe for BOTH candidates counts now; an ambiguous lane counts nothing here (both candidates again in fp64)
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      cnt[2 * rr] += __popcll(__ballot(pos_f[rr] & !amb_lane));
+      cnt[2 * rr + 1] += __popcll(__ballot(neg_f[rr] & !amb_lane));
+    }
+    if (amask != 0ull) {  // wave-uniform
+      const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(amask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)amask, 0u));
+      if (amb_lane) q[qn + pos] = i;
+      qn += __popcll(amask);
+      if (qn >= WAVE) {  // a full wavefront of ambiguous correspondences: through the fp64 route, the rest moves to the front
+        wave_sync();
+        const int qi = q[lane];
+        const int rest = qn - WAVE;
+        const int carry = (lane < rest) ? q[WAVE + lane] : 0;
+        wave_sync();
+        if (lane < rest) q[lane] = carry;
+        qn = rest;
+        dlt_fp64(mrow[qi], true);
+      }
+    }
+  }
+  if (qn > 0) {  // what is left in the queue (uniform)
+    wave_sync();
+    const bool live = lane < qn;
+    const int qi = live ? q[lane] : 0;
+    dlt_fp64(mrow[qi], live);
   }
   if (lane == 0) {
 #pragma unroll

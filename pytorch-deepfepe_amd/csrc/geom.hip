@@ -228,16 +228,16 @@ geo_misc_kernel(int kind, const float* __restrict__ in0, const float* __restrict
 // ------------------------------------------------------------------------------------------------------
 // cheirality (utils_F._E_to_M_train, utils_F.py:679-763): body in cheirality_body.h (shared with the fused fit + pose kernel)
 // ------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)  // three wavefronts per SIMD (<= 168 registers): the kernel is bound by VALU throughput
 cheirality_kernel(const float* __restrict__ E, const float* __restrict__ pre, const float* __restrict__ K,
                   const float* __restrict__ matches, int B, int N, float depth_thres, float* __restrict__ Rt_cam,
                   int* __restrict__ winner, int* __restrict__ counts) {
-  __shared__ int wcnt[8][4];
+  __shared__ CheirLds cl;
   const size_t pair = blockIdx.x;
   float Ef[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) Ef[k] = E[pair * 9 + k];
-  cheirality_pair(Ef, pre, K, matches, pair, N, depth_thres, Rt_cam, winner, counts, wcnt);
+  cheirality_pair(Ef, pre, K, matches, pair, N, depth_thres, Rt_cam, winner, counts, cl.wcnt, cl.queue);
   (void)B;
 }
 

@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256, (IT <= 4 ? 2 : 1))
 w8pt16_coop_pose_kernel(const float* pts1, const float* pts2, const float* wts, int B, int Bm, int N, float hw_sx, float hw_sy,
                         float clamp_at, float* F_out, float* residual, const W8FwdRest R, const W8PoseRest P) {
   __shared__ W8Coop co;
-  __shared__ int wcnt[8][4];
+  __shared__ CheirLds cl;
   const int pair = (int)blockIdx.x;
   W8Args A;
   A.pts1 = pts1; A.pts2 = pts2; A.wts = wts; A.B = B; A.Bm = Bm; A.N = N; A.hw_sx = hw_sx; A.hw_sy = hw_sy;
@@ -87,7 +87,7 @@ w8pt16_coop_pose_kernel(const float* pts1, const float* pts2, const float* wts, 
   float Ef[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) Ef[k] = co.of[k];  // published by row 0 before the output phase: every thread has passed that barrier
-  cheirality_pair(Ef, P.pre, P.K, pts1, (size_t)pair, N, P.depth_thres, P.Rt_cam, P.winner, P.counts, wcnt);
+  cheirality_pair(Ef, P.pre, P.K, pts1, (size_t)pair, N, P.depth_thres, P.Rt_cam, P.winner, P.counts, cl.wcnt, cl.queue);
 }
 
 struct W8BwdRest {
