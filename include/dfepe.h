@@ -267,6 +267,9 @@ int dfepe_loss_stats(const float *x0, int rows0, float scale0, const float *x1, 
  *     E-from-F (E = K^T T^T F T K, train_good_utils.py:356-358) into this launch
  *   Rt_cam [B,12]  inverse (camera motion) of the winner, zeros when no candidate has a valid point
  *   winner [B] int32 (-1 when none); counts [B,4] int32
+ * Arithmetic: the DLT null vector of every (correspondence, rotation) in packed fp32; a correspondence whose depth tests lie
+ * within that vector's a-posteriori error bound of a threshold is decided by the fp64 route instead (fp64 normal matrix + one
+ * Rayleigh-quotient iteration), so the counts are those of an fp64 DLT.
  */
 int dfepe_cheirality(const float *E, const float *pre, const float *K, const float *matches, int B, int N, float depth_thres,
                      float *Rt_cam, int *winner, int *counts, void *stream);
