@@ -141,22 +141,36 @@ loss_stats_kernel(const StatSets S, int C, float* __restrict__ out, float* __res
     float mn[kG];
 #pragma unroll
     for (int j = 0; j < kG; ++j) { acc[j] = 0.0; mn[j] = INFINITY; }
-    for (int c = t; c < C; c += 1024) {
-      float v[kG];
+    // four column strips per trip, every load of the trip issued before the first use (index clamped, contribution masked): C = 4096
+    // is ONE memory round trip for this workgroup instead of four dependent ones (the rows were just written by another kernel on
+    // other XCDs: every trip is a miss in this XCD's L2)
+    constexpr int kU = 4;
+    for (int c0 = t; c0 < C; c0 += 1024 * kU) {
+      float v[kU][kG];
 #pragma unroll
-      for (int j = 0; j < kG; ++j) v[j] = x[(size_t)((r0 + j < R) ? r0 + j : r0) * C + c];
-      float cm = INFINITY;
+      for (int u = 0; u < kU; ++u) {
+        const int c = c0 + 1024 * u, cc = (c < C) ? c : C - 1;
 #pragma unroll
-      for (int j = 0; j < kG; ++j) {
-        if (r0 + j < R) {
-          acc[j] += (double)v[j];
-          mn[j] = fminf(mn[j], v[j]);
-          cm = fminf(cm, v[j]);
-        }
+        for (int j = 0; j < kG; ++j) v[u][j] = x[(size_t)((r0 + j < R) ? r0 + j : r0) * C + cc];
       }
-      if (mins && col_min != nullptr) {  // the same thread owns column c in every group of rows
-        const float sv = (float)((double)cm * scale);
-        col_min[c] = (r0 == 0) ? sv : fminf(col_min[c], sv);
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int c = c0 + 1024 * u;
+        if (c < C) {
+          float cm = INFINITY;
+#pragma unroll
+          for (int j = 0; j < kG; ++j) {
+            if (r0 + j < R) {
+              acc[j] += (double)v[u][j];
+              mn[j] = fminf(mn[j], v[u][j]);
+              cm = fminf(cm, v[u][j]);
+            }
+          }
+          if (mins && col_min != nullptr) {  // the same thread owns column c in every group of rows
+            const float sv = (float)((double)cm * scale);
+            col_min[c] = (r0 == 0) ? sv : fminf(col_min[c], sv);
+          }
+        }
       }
     }
 #pragma unroll
