@@ -37,11 +37,6 @@ __global__ void __launch_bounds__(256)
 w8pt16_fwd_kernel(const float* pts1, const float* pts2, const float* wts, int B, int Bm, int N, float hw_sx, float hw_sy,
                   float clamp_at, float* F_out, float* residual, const W8FwdRest R) {
   __shared__ double xch[kPairsPerBlock * 36];
-  // looped kernel on pixel matches: the first kHeadIts x 16 correspondences of every pair stay in LDS after the first pass
-  // (w8pt16_body.h: pcache) -- 128 KB of the CU's 160, one workgroup per CU, which is what 300 registers allow anyway
-  constexpr bool kHead = (IT == 0) && RAW;
-  constexpr int kHeadIts = 32;
-  __shared__ float4 head[kHead ? kPairsPerBlock * kHeadIts * 16 : 1];
   const int row = (int)(threadIdx.x >> 4);
   const int pair = (int)blockIdx.x * kPairsPerBlock + row;
   if (pair >= B) return;  // a whole row leaves; rows never wait for each other
@@ -49,8 +44,7 @@ w8pt16_fwd_kernel(const float* pts1, const float* pts2, const float* wts, int B,
   A.pts1 = pts1; A.pts2 = pts2; A.wts = wts; A.B = B; A.Bm = Bm; A.N = N; A.hw_sx = hw_sx; A.hw_sy = hw_sy;
   A.clamp_at = clamp_at; A.F_out = F_out; A.residual = residual; A.epi_res = R.epi_res; A.save = R.save;
   A.weights_out = R.weights_out; A.logits_mode = R.logits_mode; A.variant = R.variant; A.row_per_pair = false;
-  if constexpr (kHead) w8pt16_fwd_pair<IT, RAW, PLAIN>(A, pair, xch + row * 36, nullptr, 0, head + row * kHeadIts * 16, kHeadIts);
-  else w8pt16_fwd_pair<IT, RAW, PLAIN>(A, pair, xch + row * 36);
+  w8pt16_fwd_pair<IT, RAW, PLAIN>(A, pair, xch + row * 36);
 }
 
 // Cooperative variant: one 256-thread workgroup (16 rows) per pair, for N > 128 (w8pt16_body.h: W8Coop).

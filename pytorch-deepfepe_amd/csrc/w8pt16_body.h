@@ -118,9 +118,8 @@ struct RawRec {
 // decode(it, raw) does all dependent arithmetic.  The next chunk's loads are issued before the current chunk is decoded and
 // consumed, so their latency (a wavefront alone on its SIMD has nothing else to hide it behind) overlaps a chunk of work.
 constexpr int kPointChunk = 8;
-// it0: first iteration (IT = 0 only; a multiple of kPointChunk where ranges are chained: a range processes whole chunks).
 template <int IT, class Load, class Decode, class Fn>
-__device__ __forceinline__ void for_points(int nit, Load&& load, Decode&& decode, Fn&& fn, int it0 = 0) {
+__device__ __forceinline__ void for_points(int nit, Load&& load, Decode&& decode, Fn&& fn) {
   if constexpr (IT > 0) {
     static_for<0, IT>([&](auto c) {
       constexpr int it = decltype(c)::value;
@@ -130,8 +129,8 @@ __device__ __forceinline__ void for_points(int nit, Load&& load, Decode&& decode
   } else {
     RawRec cur[kPointChunk], nxt[kPointChunk];
 #pragma unroll
-    for (int j = 0; j < kPointChunk; ++j) cur[j] = load(it0 + j);
-    for (int base = it0; base < nit; base += kPointChunk) {
+    for (int j = 0; j < kPointChunk; ++j) cur[j] = load(j);
+    for (int base = 0; base < nit; base += kPointChunk) {
 #pragma unroll
       for (int j = 0; j < kPointChunk; ++j) nxt[j] = load(base + kPointChunk + j);
 #pragma unroll
@@ -394,16 +393,14 @@ struct W8Coop {
 
 // ---- forward, one pair ---------------------------------------------------------------------------------------
 // IT = ceil(N / 16) correspondences per lane, kept in registers (N <= 128); IT = 0: any N, correspondences re-read per phase.
+// (Round 4 measured what the re-reading costs: with the first 512 correspondences of every pair LDS-resident after the first pass --
+// 128 KB per workgroup, bit-identical outputs, fabric traffic of the N = 1000 launch down by a third -- the launch took 68.9 us at
+// 4096 pairs against 66-72 us without, and 131 against 126 us at 8192, where the LDS now admits one workgroup per CU.  The looped
+// kernel is bound by the issue of its 21 000 instructions per wavefront, not by the 4.6 TB/s of re-reads it generates.  Reverted.)
 // xch: 36 doubles of LDS owned by this pair.
 // PLAIN: none of the textbook-solver variant flags is set (the hot instantiation carries no test for them).
-// pcache / pcache_its (IT = 0, RAW, ROWS = 1 only): LDS of this pair for its first 16 * pcache_its correspondences (pcache_its a
-// multiple of kPointChunk).  The looped kernel walks the correspondences four times (centroids, mean distances, moments, outputs);
-// sixteen pairs x 16 KB do not fit a CU's LDS at N = 1000, but half of each pair does: the first pass leaves that half in LDS and
-// the later passes read it from there, so it crosses the memory fabric once instead of four times.  Lane l reads back exactly the
-// elements it wrote itself: no barrier, no cross-lane traffic.
 template <int IT, bool RAW, bool PLAIN, int ROWS = 1>
-__device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair, double* xch, W8Coop* co = nullptr, const int rowid = 0,
-                                                float4* pcache = nullptr, const int pcache_its = 0) {
+__device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair, double* xch, W8Coop* co = nullptr, const int rowid = 0) {
   static_assert(ROWS == 1 || (ROWS == 16 && IT > 0), "one row per pair, or the 16 rows of a workgroup with the correspondences in registers");
   constexpr int S = 16 * ROWS;  // lanes per pair
   const int l = rg_lane();
@@ -540,68 +537,29 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     return r;
   };
   const bool hartley = (variant & DFEPE_W8PT_NO_HARTLEY) == 0;
-  // ---- the LDS-resident head of the pair (looped kernel on pixel matches only; see the function comment) -----------------------
-  int cits = 0;  // iterations served from LDS
-  if constexpr (IT == 0 && RAW && ROWS == 1) {
-    if (pcache != nullptr && hartley) cits = (pcache_its < nit) ? pcache_its : ((nit / kPointChunk) * kPointChunk);
-  }
-  auto point_load_lds = [&](int it) {  // coordinates from LDS (iteration clamped into the resident range: the look-ahead of the last
-    RawRec r;                          // chunk is discarded), weight-like value from memory as in point_load
-    if constexpr (IT == 0 && RAW) {
-      const int itc = (it < cits) ? it : cits - 1;
-      const float4 m = pcache[itc * 16 + l];
-      r.v[0] = m.x; r.v[1] = m.y; r.v[2] = m.z; r.v[3] = m.w;
-      const int i = it * S + L;
-      const float* wp = (A.logits_mode && wstage == 2 && A.weights_out != nullptr) ? A.weights_out + (size_t)pair * N : wsrc;
-      r.v[kWi] = wp[(i < N) ? i : N - 1];
-    }
-    return r;
-  };
-  auto point_fill = [&](int it, const RawRec& raw) {  // first pass: leave the coordinates in LDS on the way
-    if constexpr (IT == 0 && RAW) {
-      if (it < cits) {
-        float4 m;
-        m.x = raw.v[0]; m.y = raw.v[1]; m.z = raw.v[2]; m.w = raw.v[3];
-        pcache[it * 16 + l] = m;
-      }
-    }
-    return point(it, raw);
-  };
-  // one pass over the pair's correspondences; `first`: the pass that fills the LDS head
-  auto pass = [&](auto&& body, const bool first) {
-    if constexpr (IT == 0 && RAW && ROWS == 1) {
-      if (cits > 0) {
-        if (first) for_points<IT>(cits, point_load, point_fill, body);
-        else for_points<IT>(cits, point_load_lds, point, body);
-        if (cits < nit) for_points<IT>(nit, point_load, point, body, cits);
-        return;
-      }
-    }
-    for_points<IT>(nit, point_load, point, body);
-  };
   const double invN = 1.0 / (double)N;
   double c1x = 0.0, c1y = 0.0, c2x = 0.0, c2y = 0.0, s1 = 1.0, s2 = 1.0;
   if (hartley) {
     double sx1 = 0, sy1 = 0, sx2 = 0, sy2 = 0;
     float sme = 0.0f;
-    pass([&](int it, const PRec& r) {  // padding / dropped correspondences hold zeros
+    for_points<IT>(nit, point_load, point, [&](int it, const PRec& r) {  // padding / dropped correspondences hold zeros
       const Pt& p = r.p;
       sx1 += (double)p.x1; sy1 += (double)p.y1; sx2 += (double)p.x2; sy2 += (double)p.y2;
       sme += r.ws;
-    }, true);
+    });
     if (IT == 0 && A.logits_mode) linv = 1.0f / rg_sum(sme);
     c1x = psum(sx1, 2) * invN; c1y = psum(sy1, 3) * invN; c2x = psum(sx2, 4) * invN; c2y = psum(sy2, 5) * invN;
   DFEPE_MARK("P1");
     // ---- phase 1: Hartley scale (mean distance to the centroid) -------------------------------------------------
     double d1 = 0, d2 = 0;
-    pass([&](int it, const PRec& r) {
+    for_points<IT>(nit, point_load, point, [&](int it, const PRec& r) {
       const Pt& p = r.p;
       const double vm = r.valid ? 1.0 : 0.0;  // arithmetic mask: no branch around the square roots
       const double ax = (double)p.x1 - c1x, ay = (double)p.y1 - c1y;
       const double bx = (double)p.x2 - c2x, by = (double)p.y2 - c2y;
       d1 = fma(vm, sqrt_nr<1>(ax * ax + ay * ay), d1);
       d2 = fma(vm, sqrt_nr<1>(bx * bx + by * by), d2);
-    }, false);
+    });
     // Fit.normalize uses the literal 1.4142, not sqrt(2) (DeepFNet.py:168); utils_F._normalize_XY uses np.sqrt(2)
     const double hscale = (variant & DFEPE_W8PT_SQRT2) ? 1.4142135623730951 : 1.4142;
     s1 = hscale * rcp_nr<2>(psum(d1, 6) * invN);
@@ -620,7 +578,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   double invs[IT > 0 ? IT : 1];
 #pragma unroll
   for (int e = 0; e < 36; ++e) acc[e] = 0.0;
-  pass([&](int it, const PRec& r) {
+  for_points<IT>(nit, point_load, point, [&](int it, const PRec& r) {
     const Pt& p = r.p;
     const double w = (double)r.w;
     const double z1 = p.z1, z2 = p.z2;
@@ -642,7 +600,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     if constexpr (IT == 0) {
       if (A.logits_mode && A.weights_out != nullptr && r.valid) A.weights_out[(size_t)pair * N + it * S + L] = r.ws;
     }
-  }, false);
+  });
   wstage = 2;
 
   DFEPE_MARK("P3");
@@ -836,7 +794,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   // ---- phase 6: per-correspondence outputs ----------------------------------------------------------------------
   float* rdst = A.residual + (size_t)pair * N;
   float* edst = (A.epi_res != nullptr) ? A.epi_res + (size_t)pair * N : nullptr;
-  pass([&](int it, const PRec& rec) {
+  for_points<IT>(nit, point_load, point, [&](int it, const PRec& rec) {
     const int i = it * S + L;
     const Pt& p = rec.p;
     const float wf = rec.w;
@@ -868,6 +826,6 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
         if (A.logits_mode && A.weights_out != nullptr) A.weights_out[(size_t)pair * N + i] = wsm[it];
       }
     }
-  }, false);
+  });
   DFEPE_MARK("Pend");
 }

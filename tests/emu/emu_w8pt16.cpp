@@ -73,29 +73,9 @@ int dispatch(const Args& A, int B, int N, bool raw) {
   return 0;
 }
 
-// The looped kernel on pixel matches keeps the head of the pair in LDS after its first pass (w8pt16.hip: head[]).  Here that memory
-// is a host buffer shared by the 16 fibres of the row, with the kernel's geometry (32 iterations = 512 correspondences); the env
-// variable DFEPE_EMU_HEAD_ITS overrides the length (0 = no resident head: every pass re-reads memory), so that the tests can
-// require both forms to agree bit for bit.
-inline int emu_head_its() {
-  const char* e = std::getenv("DFEPE_EMU_HEAD_ITS");
-  return e ? std::atoi(e) : 32;
-}
 template <int IT, bool RAW>
 struct FwdBody {
   static void run(const W8Args& A, int pair, double* xch) {
-    if constexpr (IT == 0 && RAW) {
-      static thread_local std::vector<float4> head;
-      const int its = emu_head_its();
-      if (its > 0) {
-        // sized once, never cleared: every fibre of the row passes through here when it starts, possibly after an earlier fibre has
-        // already filled its elements (lane l only ever touches elements it * 16 + l)
-        if (head.size() < (size_t)its * 16) head.resize((size_t)its * 16);
-        if (A.variant == 0) w8pt16_fwd_pair<IT, RAW, true>(A, pair, xch, nullptr, 0, head.data(), its);
-        else w8pt16_fwd_pair<IT, RAW, false>(A, pair, xch, nullptr, 0, head.data(), its);
-        return;
-      }
-    }
     if (A.variant == 0) w8pt16_fwd_pair<IT, RAW, true>(A, pair, xch); else w8pt16_fwd_pair<IT, RAW, false>(A, pair, xch);
   }
 };

@@ -275,28 +275,3 @@ def test_loss_tail_body_degenerate_matrices_stay_finite(emu, dfepe, oracle):
     for bidx in (2, 3, 5):
         np.testing.assert_allclose(q_l2[:, bidx].numpy(), pose["q_l2"][:, bidx].numpy(), atol=5e-6)
         np.testing.assert_allclose(t_l2[:, bidx].numpy(), pose["t_l2"][:, bidx].numpy(), atol=5e-6)
-
-
-@pytest.mark.parametrize("N,flags_extra", [(129, 0), (300, 0), (511, 0), (512, 0), (513, 0), (700, 0), (1000, 0), (1000, "weights"), (2100, 0)])
-def test_looped_fit_with_its_head_in_lds_equals_the_re_reading_form(emu, dfepe, N, flags_extra, monkeypatch):
-    """Round 4: the looped kernel (N > 128) on pixel matches leaves the first 512 correspondences of a pair in LDS during its first pass
-    and reads them from there in the later three (w8pt16_body.h: pcache).  Same arithmetic on the same values: every output must be
-    bit-identical to the form that re-reads memory in every pass -- for N below, at and above the resident length, with logits
-    (softmax fused, weights_out written) and with plain weights, and for a head shorter than the kernel's."""
-    sc = dfepe.synth.make_scene(3, N, seed=N, outlier_ratio=0.3, noise_px=0.5)
-    m = sc["matches_xy_ori"].contiguous()
-    m[1, 5, 2] = float("nan")  # a dropped correspondence inside the resident head
-    if N > 600:
-        m[2, 590, 0] = float("inf")  # and one behind it
-    x = sc["logits_layers"][0].contiguous() if flags_extra == 0 else torch.softmax(sc["logits_layers"][0], 1).contiguous()
-    fl = RAW | (LOGITS if flags_extra == 0 else 0)
-    outs = {}
-    for its in ("0", "32", "8"):
-        monkeypatch.setenv("DFEPE_EMU_HEAD_ITS", its)
-        outs[its] = emu_fwd(emu, m, None, x, fl)
-    for its in ("32", "8"):
-        for a, b in zip(outs["0"], outs[its]):
-            if a is None:
-                assert b is None
-                continue
-            assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)), (N, its)
