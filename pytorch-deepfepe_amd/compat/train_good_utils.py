@@ -125,10 +125,10 @@ def _dense_T(T, B):
         return T if T.is_contiguous() else T.contiguous()
     key = (T.data_ptr(), int(B), str(T.device))
     hit = _dense_T_cache.get(key)
-    if hit is None or hit[0] is not T.untyped_storage():
+    if hit is None or hit[0]._version != T._version:
         if len(_dense_T_cache) > 16:
             _dense_T_cache.clear()
-        hit = (T.untyped_storage(), T.expand(B, 3, 3).contiguous())
+        hit = (T, T.expand(B, 3, 3).contiguous())  # T itself is kept: its memory cannot be recycled under the key while the entry lives
         _dense_T_cache[key] = hit
     return hit[1]
 
@@ -148,8 +148,8 @@ def get_all_loss_DeepF(outs, pts1_virt_ori, pts2_virt_ori, Ks, loss_params, get_
     """F-loss on the virtual correspondences for every layer + E-from-F.  Returns, like the reference (:511-519),
     (losses_dict, E_ests, F_ests, logits_softmax, residual_norm_layers, residual_norm_max_layers, E_ests_layers).
 
-    ONE kernel launch for all layers (plus three tiny reductions for the means); per-layer lists are rows of one buffer
-    (ops.stack_rows / unstack_rows: no torch.stack copies, no SelectBackward fills in the backward).  Two keys beyond the
+    ONE kernel launch for all layers plus ONE for every batch mean / minimum of the returned dict (dfepe_loss_stats); per-layer
+    lists are rows of one buffer (ops.stack_rows / unstack_rows: no torch.stack copies, no SelectBackward fills in the backward).  Two keys beyond the
     reference's loss_params, both optional:
       "pose_gt": (qs_cam, ts_cam, delta_Rtijs_4_4) -- the ground truth that the get_Rt_loss call right after this one will be
                  given.  With it the pose errors are formed in the SAME launch (dfepe_loss_tail_jac) and get_Rt_loss finds
