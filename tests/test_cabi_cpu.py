@@ -56,6 +56,20 @@ def test_argument_validation_without_launching(dfepe):
                                                None, None, None, None, None, None, None, None, None, None, None, 0, None)
     assert tail(5, 4, 100) == -1 and tail(0, 4, 100) == -1 and tail(5, 4, 200) == -3  # null pointers; no layers; grid too large for the fused kernel
     assert L.dfepe_loss_tail_workspace_bytes(4096) >= 256 * 48 * 8 + 256  # partials + the descriptor slot of a deferred head
+    # the round-4 entry points behind the reference's call sequence
+    jac = lambda L_, B_, M_: L.dfepe_loss_tail_jac(None, L_, B_, None, None, 0, None, None, None, M_, 0.02, None, None, None, 1, None, None, None, None,
+                                                  None, None, None, None, None)
+    assert jac(5, 4, 100) == -1 and jac(17, 4, 100) == -1 and jac(5, 4, 113) == -3  # null pointers; too many layers; more points than a row keeps
+    assert L.dfepe_loss_tail_bwd(None, 5, 4, None, None, None, None, None, None, None, None, None, 0.01, None, None) == -1
+    assert L.dfepe_loss_tail_bwd(None, 5, 0, None, None, None, None, None, None, None, None, None, 0.01, None, None) == 0
+    assert L.dfepe_loss_head_pending(None, None) == -1
+    stats = lambda r0, C: L.dfepe_loss_stats(None, r0, 1.0, None, 0, 1.0, None, 0, 1.0, None, 0, 1.0, C, None, None, None, None)
+    assert stats(5, 4096) == -1 and stats(65, 4096) == -1 and stats(5, 0) == -1
+    assert L.dfepe_row_dot(None, 0, None, 0, 4, 8, 100, None, None) == -1 and L.dfepe_row_dot(None, 0, None, 0, 0, 8, 100, None, None) == 0
+    assert L.dfepe_row_dot(None, 0, None, 0, 4, 8, 0, None, None) == -1
+    inp = lambda B_, N_, Q_, W_: L.dfepe_deepf_input(None, None, B_, N_, Q_, W_, 376.0, None, 0, 0, 1, 0, None, None, None)
+    assert inp(4, 100, 0, 1241.0) == -1 and inp(0, 100, 0, 1241.0) == 0 and inp(4, 100, 0, 0.0) == -1 and inp(4, 100, -1, 1241.0) == -1
+    assert L.dfepe_geo_misc(7, None, None, 4, None, None) == -1 and L.dfepe_geo_misc(6, None, None, 0, None, None) == 0
 
 
 def test_no_cpu_fallback(dfepe):
