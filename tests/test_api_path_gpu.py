@@ -351,3 +351,50 @@ def test_deepfnet_without_cat_equals_the_cat_path(dfepe, quality, depth):
     if depth > 1:
         assert dfepe.ops.alias_rows(oa["epi_res_layers"]) is not None and dfepe.ops.alias_rows(oa["weights_layers"][:depth - 1]) is not None
     assert dfepe.ops.alias_rows(oa["out_layers"]).is_contiguous()
+
+
+@pytest.mark.parametrize("B,N,L,M,balance_F", [(19, 100, 1, 100, 1.0), (33, 20, 2, 37, 1.0), (21, 128, 3, 100, 0.0), (17, 100, 5, 120, 1.0),
+                                              (5, 100, 16, 100, 1.0), (40, 300, 2, 100, 1.0)])
+def test_reference_call_sequence_over_shapes(dfepe, B, N, L, M, balance_F):
+    """The API path against the fused step away from the benchmark's shape: depth 1 (no in-loop residual, no loss_epi_res), 16 layers
+    (the most a tail launch stacks), few / many correspondences (N = 300: the cooperative fit), M = 37 and M = 120 virtual points (the
+    latter is beyond the Jacobian tail: the stand-alone kernels serve it whether or not the ground truth was handed over), the
+    qt-only objective with the F-loss adjoint switched off."""
+    sc = dfepe.synth.make_scene(B, N, seed=B + N, outlier_ratio=0.25, noise_px=0.5, depth_layers=L, M_virt=M)
+    d = dfepe.pipeline.scene_to_device(sc, DEV)
+    fused = dfepe.pipeline.hot_path_step(d, IMAGE_SIZE, L, 0.02, qt=True, balance_F=balance_F)
+    gmax = float(fused["grad_logits"].abs().max())
+    for gt_in in (False, True):
+        loss, outs, losses, geo, g = _api(dfepe, d, L, gt_in, balance_F)
+        assert abs(loss.item() - fused["loss"].item()) < 2e-6 * max(1.0, abs(fused["loss"].item())), (gt_in, loss.item(), fused["loss"].item())
+        np.testing.assert_allclose(torch.stack(losses["loss_layers"]).detach().cpu().numpy(), fused["loss_layers"].cpu().numpy(), rtol=3e-6)
+        np.testing.assert_allclose(torch.stack(geo["t_l2_error_layers_list"]).detach().cpu().numpy(), fused["t_l2"].cpu().numpy(), atol=1e-6, rtol=1e-6)
+        assert float((g - fused["grad_logits"]).abs().max()) < 2e-6 * gmax, (gt_in,)
+        assert len(losses["loss_epi_res_layers"]) == L - 1
+        if L > 1:
+            want = torch.stack([(outs["epi_res_layers"][l] * outs["weights_layers"][l]).mean() for l in range(L - 1)])
+            np.testing.assert_allclose(torch.stack(losses["loss_epi_res_layers"]).detach().cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-5)
+            np.testing.assert_allclose(float(losses["loss_epi_res"]), float(want.mean()), rtol=1e-5)
+        else:
+            assert losses["loss_epi_res"] == 0.0
+        pp = fused["loss_sum"] / M
+        np.testing.assert_allclose(losses["loss_min_batch"].cpu().numpy(), pp.min(0)[0].cpu().numpy(), rtol=1e-6)
+        np.testing.assert_allclose(losses["loss_min_layers"].cpu().numpy(), pp.min(1)[0].cpu().numpy(), rtol=1e-6)
+        np.testing.assert_allclose(float(geo["R_angle_error_mean"]), fused["R_deg"].double().mean(1).mean().item(), rtol=1e-6)
+        assert np.asarray(geo["t_angle_error_list"]).shape == (L,)
+
+
+def test_residual_summaries_on_the_stacked_outputs(dfepe):
+    """get_residual_summaries=True (the logging-only reductions, train_good_utils.py:441-509) on a DeepFNet output whose layers live in
+    stacks / channel-major buffers: plain torch on the row tensors, finite and equal to the same reductions on copies."""
+    B, N, L = 12, 100, 3
+    d = dfepe.pipeline.scene_to_device(dfepe.synth.make_scene(B, N, seed=2, outlier_ratio=0.2, depth_layers=L), DEV)
+    rows = _leaves(d, L)
+    net = dfepe.pipeline.make_api_net(L, IMAGE_SIZE, rows)
+    outs = net({"matches_xy_ori": d["matches_xy_ori"], "matches_good_unique_nums": None, "t_scene_scale": None})
+    lp = {"depth": L, "clamp_at": 0.02, "if_tri_depth": False, "if_sample_loss": False, "topK": 8, "matches_good_unique_nums": [N] * B}
+    losses, *_ = dfepe.compat.train_good_utils.get_all_loss_DeepF(outs, d["pts1_virt_ori"], d["pts2_virt_ori"], d["Ks"], lp, get_residual_summaries=True)
+    want = sum(r.clone().norm(p=2, dim=1).mean() for r in outs["residual_layers"]) / L
+    np.testing.assert_allclose(float(losses["loss_residual"]), float(want), rtol=1e-6)
+    for k in ("loss_residual_topK", "loss_regW_clip", "loss_regW_entro", "loss_regW_entro_topK"):
+        assert torch.isfinite(torch.as_tensor(losses[k])).all()
