@@ -6,6 +6,10 @@
 #include "loss_tail_body.h"
 #include "loss_head_body.h"
 
+#ifndef DFEPE_TAIL_KL
+#define DFEPE_TAIL_KL 2  // layers a lone F-loss wavefront walks together (A/B: -DDFEPE_TAIL_KL=3)
+#endif
+
 namespace {
 
 constexpr int kPairsPerBlock = 16;
@@ -45,7 +49,7 @@ loss_tail_kernel(const float* F_layers, int L, int B, int M, int t_stride, const
   const bool floss_wave = threadIdx.x < 256u;  // uniform per wavefront
   const int row = (int)(threadIdx.x >> 4) & 15;
   if (floss_wave) {
-    if (pair0 + row < B) tail_floss_row<IT, JAC>(A, pair0 + row, lds[row], part[row], lds[row] + kTailMaxLayers * 9);
+    if (pair0 + row < B) tail_floss_row<IT, JAC, DFEPE_TAIL_KL>(A, pair0 + row, lds[row], part[row], lds[row] + kTailMaxLayers * 9);
   } else {
     const int item = (int)threadIdx.x - 256;  // layer-major: item = layer * 16 + pair-in-workgroup
     const int layer = item >> 4, prow = item & 15;

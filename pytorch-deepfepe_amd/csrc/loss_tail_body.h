@@ -285,6 +285,9 @@ __device__ __forceinline__ void tail_floss_row(const TailArgs& A, const int pair
   };
   const int ly_end = (ly_end_in < 0) ? L : ly_end_in;
   int ly = ly_begin;
+  if constexpr (KL >= 3) {
+    for (; ly + 2 < ly_end; ly += 3) layers(std::integral_constant<int, 3>{}, ly);
+  }
   if constexpr (KL >= 2) {
     for (; ly + 1 < ly_end; ly += 2) layers(std::integral_constant<int, 2>{}, ly);
   }
