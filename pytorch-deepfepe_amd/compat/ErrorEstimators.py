@@ -37,10 +37,11 @@ class ErrorEstimator(nn.Module):
 class FusedErrorEstimator(ErrorEstimator):
     """Same parameters / state_dict as ErrorEstimator, MI355X-shaped evaluation ("next" row f-1 of SURVEY.md §8).
 
-    Default (``split_bf16 = True``, N = 100 points per pair): the whole stack runs on the bf16 matrix cores with fp32-accurate
-    split operands -- csrc/est_gemm.hip through ``estimator.estimator_forward``: per layer ONE kernel (GEMM + InstanceNorm +
-    LeakyReLU in its epilogue) forward, three backward (normalisation adjoint, weight-gradient GEMM, data-gradient GEMM).
-    ``split_bf16 = False`` (or any other N) keeps the native-fp32 evaluation described next:
+    Default (``split_bf16 = True``): the whole stack runs on the bf16 matrix cores with fp32-accurate split operands --
+    csrc/est_gemm.hip through ``estimator.estimator_forward``: per layer ONE kernel (GEMM + InstanceNorm + LeakyReLU in its
+    epilogue) forward at N = 100 points per pair, two (plain product, then normalisation + activation + split) at any other
+    N >= 2 -- the SIFT configurations' 1000-2000 --; three backward (normalisation adjoint, weight-gradient GEMM, data-gradient
+    GEMM).  ``split_bf16 = False`` keeps the native-fp32 evaluation described next:
     activations live channel-major as [C, B*N], every 1x1 convolution is ONE large GEMM W[C_out,C_in] @ X[C_in, B*N]
     (rocBLAS / hipBLASLt through torch.mm) instead of B small ones, and InstanceNorm + LeakyReLU is one fused HIP pass
     (ops.inorm_lrelu).  The biases of the convolutions that feed an InstanceNorm cancel in the normalisation and are

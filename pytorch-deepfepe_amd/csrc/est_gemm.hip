@@ -475,6 +475,171 @@ est_in_bwd_kernel(const float* __restrict__ dA, const float* __restrict__ dlogit
   }
 }
 
+// ---- any number of points per pair: InstanceNorm + LeakyReLU + split behind the plain product, and its adjoint ---------------
+// The fused epilogue above is built around 100 points per pair.  For another N (the reference's SIFT configurations carry up to
+// 2000 correspondences, deepFEPE/configs/*.yaml, at batch sizes of 4-12) a layer is the plain product est_gemm_nt<EPI_F32>
+// followed by this kernel: one workgroup = one pair x 64 channels, 32 channel pairs x 32 row groups striding the pair's columns,
+// four independent rows in flight per thread (with a dozen pairs the grid is a few hundred workgroups at most: the time is the
+// chain of dependent load latencies, so the rows are spread over 1024 threads and the loads unrolled).  Three passes over the
+// pair's fp32 block (mean; squared deviations from it -- the same two-pass variance as the epilogue --; normalise + activate +
+// split): N x 64 x 4 bytes, L2-resident between the passes.
+constexpr int kRG = 32;   // row groups of a workgroup
+constexpr int kRU = 4;    // rows a thread has in flight
+
+__device__ __forceinline__ void pair_reduce2(float (&red)[kRG][64], int rg, int cp, float a, float b, float& A, float& B) {
+  __syncthreads();  // the previous reduction's readers are done
+  red[rg][2 * cp] = a; red[rg][2 * cp + 1] = b;
+  __syncthreads();
+  A = 0.f; B = 0.f;
+#pragma unroll
+  for (int q = 0; q < kRG; ++q) { A += red[q][2 * cp]; B += red[q][2 * cp + 1]; }
+}
+
+__global__ void __launch_bounds__(1024)
+est_norm_fwd_n_kernel(const float* __restrict__ Y, int ldy, int C, int N, size_t ncols, const float* __restrict__ gamma,
+                      const float* __restrict__ beta, float eps, float slope, bf16_t* __restrict__ planes, size_t plane_stride,
+                      float* __restrict__ rstd) {
+  __shared__ float red[kRG][64];
+  const int pair = (int)blockIdx.x, cb = (int)blockIdx.y * 64;
+  const int cp = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int ch = cb + 2 * cp;
+  const bool chok = ch < C;
+  const int chc = chok ? ch : 0;
+  const size_t col0 = (size_t)pair * N;
+  const float inv_n = 1.0f / (float)N;
+  const float* Yc = Y + col0 * ldy + chc;
+  float s0 = 0.f, s1 = 0.f;
+  for (int rb = rg; rb < N; rb += kRG * kRU) {
+    f32x2 y[kRU];
+#pragma unroll
+    for (int u = 0; u < kRU; ++u) { const int rl = rb + kRG * u; y[u] = *reinterpret_cast<const f32x2*>(Yc + (size_t)(rl < N ? rl : rb) * ldy); }
+#pragma unroll
+    for (int u = 0; u < kRU; ++u) { const bool live = rb + kRG * u < N; s0 += live ? y[u][0] : 0.f; s1 += live ? y[u][1] : 0.f; }
+  }
+  float S0, S1;
+  pair_reduce2(red, rg, cp, s0, s1, S0, S1);
+  const float mu0 = S0 * inv_n, mu1 = S1 * inv_n;
+  float q0 = 0.f, q1 = 0.f;
+  for (int rb = rg; rb < N; rb += kRG * kRU) {
+    f32x2 y[kRU];
+#pragma unroll
+    for (int u = 0; u < kRU; ++u) { const int rl = rb + kRG * u; y[u] = *reinterpret_cast<const f32x2*>(Yc + (size_t)(rl < N ? rl : rb) * ldy); }
+#pragma unroll
+    for (int u = 0; u < kRU; ++u) {
+      const bool live = rb + kRG * u < N;
+      const float d0 = y[u][0] - mu0, d1 = y[u][1] - mu1;
+      q0 += live ? d0 * d0 : 0.f; q1 += live ? d1 * d1 : 0.f;
+    }
+  }
+  float Q0, Q1;
+  pair_reduce2(red, rg, cp, q0, q1, Q0, Q1);
+  const float r0 = 1.0f / sqrtf(Q0 * inv_n + eps), r1 = 1.0f / sqrtf(Q1 * inv_n + eps);  // biased variance, like F.instance_norm
+  if (rg == 0 && chok) { rstd[(size_t)pair * C + ch] = r0; rstd[(size_t)pair * C + ch + 1] = r1; }
+  const float k0 = r0 * gamma[chc], k1 = r1 * gamma[chc + 1], b0 = beta[chc], b1 = beta[chc + 1];
+  if (!chok) return;
+  for (int rb = rg; rb < N; rb += kRG * kRU) {
+    f32x2 y[kRU];
+#pragma unroll
+    for (int u = 0; u < kRU; ++u) { const int rl = rb + kRG * u; y[u] = *reinterpret_cast<const f32x2*>(Yc + (size_t)(rl < N ? rl : rb) * ldy); }
+#pragma unroll
+    for (int u = 0; u < kRU; ++u) {
+      const int rl = rb + kRG * u;
+      if (rl >= N) break;
+      const float z0 = fmaf(y[u][0] - mu0, k0, b0), z1 = fmaf(y[u][1] - mu1, k1, b1);
+      unsigned p0, p1, p2;
+      split3((z0 > 0.f) ? z0 : z0 * slope, (z1 > 0.f) ? z1 : z1 * slope, p0, p1, p2);
+      const size_t at = kb_index(col0 + rl, ch, ncols);
+      *reinterpret_cast<unsigned*>(planes + at) = p0;
+      *reinterpret_cast<unsigned*>(planes + plane_stride + at) = p1;
+      *reinterpret_cast<unsigned*>(planes + 2 * plane_stride + at) = p2;
+    }
+  }
+}
+
+// The adjoint for any N: est_in_bwd_kernel's arithmetic with the pair's columns strided instead of held in registers -- one pass
+// for the two sums, one that recomputes d z and x^ from the same inputs and writes dY.
+__global__ void __launch_bounds__(1024)
+est_in_bwd_n_kernel(const float* __restrict__ dA, const float* __restrict__ dlogit, const float* __restrict__ w_head,
+                    const bf16_t* __restrict__ planes, size_t plane_stride, const float* __restrict__ rstd,
+                    const float* __restrict__ gamma, const float* __restrict__ beta, float slope, int C, int N, size_t ncols,
+                    bf16_t* __restrict__ dYp, size_t dy_plane, float* __restrict__ dgamma_part, float* __restrict__ dbeta_part) {
+  __shared__ float red[kRG][64];
+  const int pair = (int)blockIdx.x, cb = (int)blockIdx.y * 64;
+  const int cp = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int ch = cb + 2 * cp;
+  const bool chok = ch < C;
+  const int chc = chok ? ch : 0;
+  const float g0 = gamma[chc], g1 = gamma[chc + 1], b0 = beta[chc], b1 = beta[chc + 1];
+  const float ig0 = (fabsf(g0) > 1e-30f) ? 1.0f / g0 : 0.0f, ig1 = (fabsf(g1) > 1e-30f) ? 1.0f / g1 : 0.0f;
+  const float islope = 1.0f / slope;
+  const float wh0 = dA ? 0.f : w_head[chc], wh1 = dA ? 0.f : w_head[chc + 1];
+  const size_t col0 = (size_t)pair * N;
+  struct Raw { unsigned u0, u1, u2; float d0, d1; };
+  auto load = [&](int rl) {
+    const size_t col = col0 + rl;
+    const size_t at = kb_index(col, chc, ncols);
+    Raw r;
+    r.u0 = *reinterpret_cast<const unsigned*>(planes + at);
+    r.u1 = *reinterpret_cast<const unsigned*>(planes + plane_stride + at);
+    r.u2 = *reinterpret_cast<const unsigned*>(planes + 2 * plane_stride + at);
+    if (dA != nullptr) {
+      const f32x2 d = *reinterpret_cast<const f32x2*>(dA + col * C + chc);
+      r.d0 = d[0]; r.d1 = d[1];
+    } else {
+      const float dl = dlogit[col];
+      r.d0 = dl * wh0; r.d1 = dl * wh1;
+    }
+    return r;
+  };
+  auto item = [&](const Raw& r, float& e0, float& e1, float& x0, float& x1) {
+    const float a0 = (bf16_lo(r.u0) + bf16_lo(r.u1)) + bf16_lo(r.u2), a1 = (bf16_hi(r.u0) + bf16_hi(r.u1)) + bf16_hi(r.u2);
+    const float z0 = (a0 > 0.f) ? a0 : a0 * islope, z1 = (a1 > 0.f) ? a1 : a1 * islope;
+    e0 = (a0 > 0.f) ? r.d0 : r.d0 * slope; e1 = (a1 > 0.f) ? r.d1 : r.d1 * slope;
+    x0 = (z0 - b0) * ig0; x1 = (z1 - b1) * ig1;
+  };
+  float s10 = 0.f, s11 = 0.f, s20 = 0.f, s21 = 0.f;
+  for (int rb = rg; rb < N; rb += kRG * kRU) {
+    Raw r[kRU];
+#pragma unroll
+    for (int u = 0; u < kRU; ++u) { const int rl = rb + kRG * u; r[u] = load(rl < N ? rl : rb); }
+#pragma unroll
+    for (int u = 0; u < kRU; ++u) {
+      float e0, e1, x0, x1;
+      item(r[u], e0, e1, x0, x1);
+      if (rb + kRG * u >= N) { e0 = 0.f; e1 = 0.f; }
+      s10 += e0; s11 += e1; s20 = fmaf(e0, x0, s20); s21 = fmaf(e1, x1, s21);
+    }
+  }
+  float S10, S11, S20, S21;
+  pair_reduce2(red, rg, cp, s10, s11, S10, S11);
+  pair_reduce2(red, rg, cp, s20, s21, S20, S21);
+  if (!chok) return;
+  if (rg == 0) {
+    dbeta_part[(size_t)pair * C + ch] = S10; dbeta_part[(size_t)pair * C + ch + 1] = S11;
+    dgamma_part[(size_t)pair * C + ch] = S20; dgamma_part[(size_t)pair * C + ch + 1] = S21;
+  }
+  const float inv_n = 1.0f / (float)N;
+  const float k0 = rstd[(size_t)pair * C + ch] * g0, k1 = rstd[(size_t)pair * C + ch + 1] * g1;
+  const float m10 = S10 * inv_n, m11 = S11 * inv_n, m20 = S20 * inv_n, m21 = S21 * inv_n;
+  for (int rb = rg; rb < N; rb += kRG * kRU) {
+    Raw r[kRU];
+#pragma unroll
+    for (int u = 0; u < kRU; ++u) { const int rl = rb + kRG * u; r[u] = load(rl < N ? rl : rb); }
+#pragma unroll
+    for (int u = 0; u < kRU; ++u) {
+      const int rl = rb + kRG * u;
+      if (rl >= N) break;
+      float e0, e1, x0, x1;
+      item(r[u], e0, e1, x0, x1);
+      unsigned p0, p1;
+      split2(k0 * (e0 - m10 - x0 * m20), k1 * (e1 - m11 - x1 * m21), p0, p1);
+      const size_t at = kb_index(col0 + rl, ch, ncols);
+      *reinterpret_cast<unsigned*>(dYp + at) = p0;
+      *reinterpret_cast<unsigned*>(dYp + dy_plane + at) = p1;
+    }
+  }
+}
+
 // ---- head: logits[col] = sum_c w[c] a[col][c] + b (Conv1d(256 -> 1)); one 16-lane row per column ----------------------------
 __global__ void __launch_bounds__(256)
 est_head_fwd_kernel(const bf16_t* __restrict__ planes, size_t plane_stride, int C, int ncols, const float* __restrict__ w,
@@ -618,6 +783,35 @@ extern "C" int dfepe_est_in_bwd(const float* dA, const float* dlogit, const floa
   hipLaunchKernelGGL(est_in_bwd_kernel, grid, block, 0, static_cast<hipStream_t>(stream), dA, dlogit, w_head,
                      static_cast<const bf16_t*>(planes), plane_stride, rstd, gamma, beta, slope, C, ncols, static_cast<bf16_t*>(dY), dy_plane,
                      dgamma_part, dbeta_part);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+// InstanceNorm + LeakyReLU + split of a plain product, N points per pair (any N >= 1): Y fp32 [n_pairs * N][ldy]
+extern "C" int dfepe_est_norm_fwd(const float* Y, int ldy, int C, long n_pairs, int N, const float* gamma, const float* beta, float eps,
+                                  float slope, void* planes_out, size_t out_plane, float* rstd, void* stream) {
+  if (!Y || !gamma || !beta || !planes_out || !rstd || C <= 0 || (C & 31) || ldy < C || (ldy & 1) || n_pairs < 0 || N <= 0)
+    return DFEPE_ERR_INVALID_ARG;
+  if (!(slope > 0.f)) return DFEPE_ERR_UNSUPPORTED;  // the backward inverts the activation
+  if (n_pairs == 0) return DFEPE_OK;
+  if (n_pairs > 0x7fffffffL) return DFEPE_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)n_pairs, (C + 63) / 64), block(kRG * 32);
+  hipLaunchKernelGGL(est_norm_fwd_n_kernel, grid, block, 0, static_cast<hipStream_t>(stream), Y, ldy, C, N, (size_t)n_pairs * N, gamma, beta,
+                     eps, slope, static_cast<bf16_t*>(planes_out), out_plane, rstd);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+// dfepe_est_in_bwd for N points per pair (any N >= 1; ncols = n_pairs * N)
+extern "C" int dfepe_est_in_bwd_n(const float* dA, const float* dlogit, const float* w_head, const void* planes, size_t plane_stride,
+                                  const float* rstd, const float* gamma, const float* beta, float slope, int C, long n_pairs, int N, void* dY,
+                                  size_t dy_plane, float* dgamma_part, float* dbeta_part, void* stream) {
+  if ((!dA && !(dlogit && w_head)) || !planes || !rstd || !gamma || !beta || !dY || !dgamma_part || !dbeta_part) return DFEPE_ERR_INVALID_ARG;
+  if (C <= 0 || (C & 31) || n_pairs < 0 || N <= 0 || !(slope > 0.f)) return DFEPE_ERR_INVALID_ARG;
+  if (n_pairs == 0) return DFEPE_OK;
+  if (n_pairs > 0x7fffffffL) return DFEPE_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)n_pairs, (C + 63) / 64), block(kRG * 32);
+  hipLaunchKernelGGL(est_in_bwd_n_kernel, grid, block, 0, static_cast<hipStream_t>(stream), dA, dlogit, w_head,
+                     static_cast<const bf16_t*>(planes), plane_stride, rstd, gamma, beta, slope, C, N, (size_t)n_pairs * N,
+                     static_cast<bf16_t*>(dY), dy_plane, dgamma_part, dbeta_part);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 

@@ -3,8 +3,9 @@
 ``estimator_forward(x, layers, head)`` evaluates the Conv1d(k=1) -> InstanceNorm1d(affine) -> LeakyReLU stack of
 ErrorEstimator (deepFEPE/models/ErrorEstimators.py:47-64) with the kernels of csrc/est_gemm.hip: every fp32 operand travels as
 three bf16 planes (a = a0 + a1 + a2, exact), a forward product is six bf16 MFMAs with fp32 accumulation (fp32-class accuracy),
-a backward product three; InstanceNorm + LeakyReLU + the split into planes are the forward GEMM's epilogue.  One autograd node
-for the whole stack; parameters and inputs are the module's own fp32 tensors.  PyTorch is plumbing here (allocation, the
+a backward product three; InstanceNorm + LeakyReLU + the split into planes are the forward GEMM's epilogue for N = 100 points per
+pair, and a kernel of their own behind the plain product for any other N (the SIFT configurations' 1000-2000).  One autograd
+node for the whole stack; parameters and inputs are the module's own fp32 tensors.  PyTorch is plumbing here (allocation, the
 tiny weight transposes, the sums over split-K / per-pair partials)."""
 from __future__ import annotations
 
@@ -20,8 +21,13 @@ BF16 = torch.bfloat16
 
 
 def supported(x: Tensor) -> bool:
-    """The fused kernels are built for N = dfepe_est_points() (100) points per pair."""
-    return x.is_cuda and x.dim() == 3 and x.shape[2] == _lib.lib().dfepe_est_points() and x.shape[0] > 0
+    """Any [B, C, N] on the GPU with B >= 1, N >= 2 (N = dfepe_est_points() takes the fused epilogue, see _fused; a single point
+    per pair is left to the stock stack, whose InstanceNorm1d raises on it like the reference's)."""
+    return x.is_cuda and x.dim() == 3 and x.shape[0] > 0 and x.shape[2] > 1 and x.shape[0] * x.shape[2] < 2 ** 31
+
+
+def _fused(N: int) -> bool:
+    return N == _lib.lib().dfepe_est_points()
 
 
 def _pad32(c: int) -> int:
@@ -64,9 +70,19 @@ class _EstimatorFunction(torch.autograd.Function):
                 Wp = _split(W.detach().float().reshape(Co, Ci).contiguous(), Co, Ci, K, 3)
                 out = torch.empty(3, cols, Co, device=dev, dtype=BF16)
                 rstd = torch.empty(B, Co, device=dev, dtype=torch.float32)
-                rc = lib.dfepe_est_layer_fwd(_ptr(Wp), Co * K, _ptr(acts[-1]), cols * K, Co, cols, K, _ptr(gamma.detach().float().contiguous()),
-                                             _ptr(beta.detach().float().contiguous()), float(eps), float(slope), _ptr(out), cols * Co, _ptr(rstd), st)
-                _lib.check(rc, "dfepe_est_layer_fwd")
+                g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+                if _fused(N):
+                    rc = lib.dfepe_est_layer_fwd(_ptr(Wp), Co * K, _ptr(acts[-1]), cols * K, Co, cols, K, _ptr(g32), _ptr(b32), float(eps),
+                                                 float(slope), _ptr(out), cols * Co, _ptr(rstd), st)
+                    _lib.check(rc, "dfepe_est_layer_fwd")
+                else:  # the plain product (six bf16 products, fp32 out), then the statistics over each pair's N columns
+                    Y = torch.empty(cols, Co, device=dev, dtype=torch.float32)
+                    rc = lib.dfepe_est_gemm_nt(_ptr(Wp), Co * K, _ptr(acts[-1]), cols * K, Co, cols, K, 3, _ptr(Y), Co, st)
+                    _lib.check(rc, "dfepe_est_gemm_nt")
+                    rc = lib.dfepe_est_norm_fwd(_ptr(Y), Co, Co, B, N, _ptr(g32), _ptr(b32), float(eps), float(slope), _ptr(out), cols * Co,
+                                                _ptr(rstd), st)
+                    _lib.check(rc, "dfepe_est_norm_fwd")
+                    del Y
                 acts.append(out)
                 rstds.append(rstd)
             Wh, bh = params[4 * n_hidden], params[4 * n_hidden + 1]
@@ -122,10 +138,17 @@ class _EstimatorFunction(torch.autograd.Function):
                 dY = torch.empty(2, cols, Co, device=dev, dtype=BF16)
                 dg = torch.empty(B, Co, device=dev, dtype=torch.float32)
                 db = torch.empty(B, Co, device=dev, dtype=torch.float32)
-                rc = lib.dfepe_est_in_bwd(_ptr(dA), _ptr(dl if dA is None else None), _ptr(wh if dA is None else None), _ptr(a_out), cols * Co,
-                                          _ptr(rstds[l]), _ptr(gamma.detach().float().contiguous()), _ptr(beta.detach().float().contiguous()),
-                                          float(slope), Co, cols, _ptr(dY), cols * Co, _ptr(dg), _ptr(db), st)
-                _lib.check(rc, "dfepe_est_in_bwd")
+                g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+                if _fused(N):
+                    rc = lib.dfepe_est_in_bwd(_ptr(dA), _ptr(dl if dA is None else None), _ptr(wh if dA is None else None), _ptr(a_out), cols * Co,
+                                              _ptr(rstds[l]), _ptr(g32), _ptr(b32), float(slope), Co, cols, _ptr(dY), cols * Co, _ptr(dg), _ptr(db),
+                                              st)
+                    _lib.check(rc, "dfepe_est_in_bwd")
+                else:
+                    rc = lib.dfepe_est_in_bwd_n(_ptr(dA), _ptr(dl if dA is None else None), _ptr(wh if dA is None else None), _ptr(a_out),
+                                                cols * Co, _ptr(rstds[l]), _ptr(g32), _ptr(b32), float(slope), Co, B, N, _ptr(dY), cols * Co,
+                                                _ptr(dg), _ptr(db), st)
+                    _lib.check(rc, "dfepe_est_in_bwd_n")
                 grads[4 * l + 2] = dg.sum(0).to(gamma.dtype)
                 grads[4 * l + 3] = db.sum(0).to(beta.dtype)
                 grads[4 * l + 1] = torch.zeros_like(bconv)  # the bias cancels in the instance normalisation: exact zero, like the reference's autograd
@@ -153,10 +176,10 @@ class _EstimatorFunction(torch.autograd.Function):
 
 def estimator_forward(x: Tensor, hidden: Sequence[Tuple[Tensor, Tensor, Tensor, Tensor]], head: Tuple[Tensor, Optional[Tensor]],
                       eps: float = 1e-5, slope: float = 0.01) -> Tensor:
-    """x [B, C0, N=100] fp32 on the GPU -> logits [B, 1, N].  hidden: per layer (conv weight, conv bias, InstanceNorm weight,
+    """x [B, C0, N] fp32 on the GPU -> logits [B, 1, N].  hidden: per layer (conv weight, conv bias, InstanceNorm weight,
     InstanceNorm bias); head: (conv weight [1,C,1], bias or None)."""
     if not supported(x):
-        raise _lib.DfepeError(f"estimator_forward: needs a GPU tensor [B, C, {_lib.lib().dfepe_est_points()}], got {tuple(x.shape)} on {x.device}")
+        raise _lib.DfepeError(f"estimator_forward: needs a GPU tensor [B >= 1, C, N >= 2], got {tuple(x.shape)} on {x.device}")
     flat: List[Optional[Tensor]] = []
     for layer in hidden:
         flat.extend(layer)

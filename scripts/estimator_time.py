@@ -1,11 +1,12 @@
 """Forward / forward+backward time of ONE ErrorEstimator call: stock PyTorch, the native-fp32 fused evaluation (library GEMMs +
 inorm kernel) and the split-bf16 matrix-core chain (csrc/est_gemm.hip), plus the accuracy of each against float64.
-   python scripts/estimator_time.py [B]"""
+   python scripts/estimator_time.py [B [N]]      (N = 100: the fused epilogue; any other N: plain product + norm kernel)"""
 import importlib, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 d = importlib.import_module("pytorch-deepfepe_amd")
 EE = d.compat.ErrorEstimators
-B, N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096, 100
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 FL = 2.0 * B * N * (7 * 64 + 64 * 128 + 128 * 1024 + 1024 * 512 + 512 * 256 + 256)
 variants = [("stock", EE.ErrorEstimator, None), ("fused fp32", EE.FusedErrorEstimator, False), ("split-bf16 MFMA", EE.FusedErrorEstimator, True)]
 x0 = torch.rand(B, 7, N, device="cuda")
@@ -37,7 +38,7 @@ for name, cls, split in variants:
     ex = float((x8.grad.cpu().double() - xs.grad).abs().max() / xs.grad.abs().max())
     pw = dict(m.named_parameters())["fw.9.weight"].grad.cpu().double(); rw = dict(ref.named_parameters())["fw.9.weight"].grad
     ew = float((pw - rw).norm() / rw.norm())
-    print(f"{name:18s} B={B}: fwd {df*1e3:7.2f} ms ({FL/df/1e12:6.1f} TF/s-equiv), fwd+bwd {dt*1e3:7.2f} ms ({3*FL/dt/1e12:6.1f}); "
+    print(f"{name:18s} B={B} N={N}: fwd {df*1e3:7.2f} ms ({FL/df/1e12:6.1f} TF/s-equiv), fwd+bwd {dt*1e3:7.2f} ms ({3*FL/dt/1e12:6.1f}); "
           f"vs fp64: logits {el:.1e}, d/dx {ex:.1e}, dW(1024x512) rel-norm {ew:.1e}; peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
     del m, x
     torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()

@@ -31,7 +31,7 @@ def test_library_builds_and_exports_every_declared_symbol(dfepe):
 
 def test_version_strerror_and_save_layout(dfepe):
     L = dfepe._lib.lib()
-    assert L.dfepe_version() == 140
+    assert L.dfepe_version() == 141
     assert L.dfepe_save_floats() == 128
     assert L.dfepe_strerror(0) == b"ok"
     assert b"invalid" in L.dfepe_strerror(-1)
@@ -70,6 +70,9 @@ def test_argument_validation_without_launching(dfepe):
     inp = lambda B_, N_, Q_, W_: L.dfepe_deepf_input(None, None, B_, N_, Q_, W_, 376.0, None, 0, 0, 1, 0, None, None, None)
     assert inp(4, 100, 0, 1241.0) == -1 and inp(0, 100, 0, 1241.0) == 0 and inp(4, 100, 0, 0.0) == -1 and inp(4, 100, -1, 1241.0) == -1
     assert L.dfepe_geo_misc(7, None, None, 4, None, None) == -1 and L.dfepe_geo_misc(6, None, None, 0, None, None) == 0
+    # the estimator's normalisation for any number of points per pair: null pointers, channel counts off the 32 grid, N < 1
+    assert L.dfepe_est_norm_fwd(None, 64, 64, 2, 1000, None, None, 1e-5, 0.01, None, 0, None, None) == -1
+    assert L.dfepe_est_in_bwd_n(None, None, None, None, 0, None, None, None, 0.01, 64, 2, 1000, None, 0, None, None, None) == -1
 
 
 def test_no_cpu_fallback(dfepe):

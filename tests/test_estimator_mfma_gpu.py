@@ -211,3 +211,112 @@ def test_backward_twice_with_retain_graph_and_the_standard_error_without(dfepe):
         assert torch.equal(a, b)
     with pytest.raises(RuntimeError, match="backward through the graph a second time|already been freed"):
         torch.autograd.grad(loss, [x])
+
+
+# ---- any number of points per pair (the reference's SIFT configurations: 1000-2000 correspondences) -----------------------------
+@pytest.mark.parametrize("C,N,pairs", [(64, 37, 3), (128, 1000, 2), (1024, 256, 2), (256, 2000, 1), (32, 1, 4), (64, 100, 2)])
+def test_norm_forward_any_points_matches_float64(dfepe, C, N, pairs):
+    """dfepe_est_norm_fwd on a plain product Y [pairs * N, ld]: planes = split(leaky_relu(instance_norm(Y))), rstd."""
+    lib = dfepe._lib.lib()
+    cols, ld = pairs * N, C + 8
+    g = torch.Generator().manual_seed(C + N)
+    Yd = (torch.randn(cols, ld, generator=g) * 3 + 40.0).to(DEV)  # a mean far above the deviation: the two-pass variance matters
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV)
+    beta = (0.3 * torch.randn(C, generator=g)).to(DEV)
+    out = torch.zeros(3, cols, C, device=DEV, dtype=torch.bfloat16)
+    rstd = torch.zeros(pairs, C, device=DEV)
+    rc = lib.dfepe_est_norm_fwd(Yd.data_ptr(), ld, C, pairs, N, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.01, out.data_ptr(), cols * C,
+                                rstd.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    Y = Yd[:, :C].double().view(pairs, N, C).permute(0, 2, 1)
+    var = Y.var(2, unbiased=False)
+    ref = torch.nn.functional.leaky_relu((Y - Y.mean(2, keepdim=True)) / torch.sqrt(var + 1e-5)[..., None] * gamma.double()[None, :, None]
+                                         + beta.double()[None, :, None], 0.01)  # F.instance_norm refuses N = 1
+    got = planes_to_f64(out).view(pairs, N, C).permute(0, 2, 1)
+    assert float((got - ref).abs().max()) < 2e-5 * float(ref.abs().max())  # fp32 rounding of (y - mean) at |y| ~ 40: 4e-6 of the deviation
+    assert relerr(rstd, 1.0 / torch.sqrt(var + 1e-5)) < 5e-6
+
+
+@pytest.mark.parametrize("C,N,pairs,head", [(64, 37, 3, False), (256, 1000, 2, True), (1024, 250, 2, False), (64, 100, 2, True)])
+def test_instance_norm_adjoint_any_points(dfepe, C, N, pairs, head):
+    lib = dfepe._lib.lib()
+    cols = pairs * N
+    g = torch.Generator().manual_seed(C + N)
+    Y = (torch.randn(pairs, C, N, generator=g, dtype=torch.float64) * 2 + 0.5).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g, dtype=torch.float64)).requires_grad_(True)
+    beta = (0.3 * torch.randn(C, generator=g, dtype=torch.float64)).requires_grad_(True)
+    a = torch.nn.functional.leaky_relu(torch.nn.functional.instance_norm(Y, weight=gamma, bias=beta, eps=1e-5), 0.01)
+    if head:
+        dl = torch.randn(cols, generator=g, dtype=torch.float64)
+        wh = torch.randn(C, generator=g, dtype=torch.float64)
+        G = (dl.view(pairs, 1, N) * wh.view(1, C, 1))
+    else:
+        G = torch.randn(pairs, C, N, generator=g, dtype=torch.float64)
+    (a * G).sum().backward()
+    P = _split(dfepe, a.detach().permute(0, 2, 1).reshape(cols, C).float().to(DEV), C)
+    rstd = (1.0 / torch.sqrt(Y.detach().var(2, unbiased=False) + 1e-5)).float().to(DEV).contiguous()
+    dA = G.permute(0, 2, 1).reshape(cols, C).float().to(DEV).contiguous()
+    dY = torch.zeros(2, cols, C, device=DEV, dtype=torch.bfloat16)
+    dg, db = torch.zeros(pairs, C, device=DEV), torch.zeros(pairs, C, device=DEV)
+    gm, bt = gamma.detach().float().to(DEV), beta.detach().float().to(DEV)
+    if head:
+        dl_d, wh_d = dl.float().to(DEV), wh.float().to(DEV)
+        rc = lib.dfepe_est_in_bwd_n(None, dl_d.data_ptr(), wh_d.data_ptr(), P.data_ptr(), cols * C, rstd.data_ptr(), gm.data_ptr(), bt.data_ptr(),
+                                    0.01, C, pairs, N, dY.data_ptr(), cols * C, dg.data_ptr(), db.data_ptr(), None)
+    else:
+        rc = lib.dfepe_est_in_bwd_n(dA.data_ptr(), None, None, P.data_ptr(), cols * C, rstd.data_ptr(), gm.data_ptr(), bt.data_ptr(), 0.01, C,
+                                    pairs, N, dY.data_ptr(), cols * C, dg.data_ptr(), db.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert relerr(planes_to_f64(dY).cpu(), Y.grad.permute(0, 2, 1).reshape(cols, C)) < 5e-5
+    assert relerr(dg.sum(0).cpu(), gamma.grad) < 5e-5
+    assert relerr(db.sum(0).cpu(), beta.grad) < 5e-5
+
+
+@pytest.mark.parametrize("cin,B,N", [(4, 2, 37), (7, 3, 256), (4, 1, 1000), (7, 2, 2000), (4, 16, 8)])
+def test_whole_estimator_at_other_point_counts(dfepe, cin, B, N):
+    """The split-bf16 stack away from N = 100 (plain product + dfepe_est_norm_fwd forward, dfepe_est_in_bwd_n backward) against
+    the stock module in float64.  Logits to the fp32 class.  Gradients: with thousands of columns some pre-activation of the
+    float64 run always lies within fp32 rounding of the LeakyReLU kink, where ANY fp32 evaluation may take the other branch (see
+    the N = 100 test's note) -- so every gradient is held to 2e-3 of its norm (one flipped element among >= 1e5), and to the
+    two-plane class 1e-4 when the float64 run keeps every pre-activation 2e-6 away from the kink."""
+    EE = dfepe.compat.ErrorEstimators
+    stock = EE.ErrorEstimator(cin)
+    dfepe.synth.fill_params_deterministic(stock, seed=9)
+    fused = EE.FusedErrorEstimator(cin).to(DEV)
+    fused.load_state_dict(stock.state_dict())
+    stock = stock.double()
+    margin = [float("inf")]
+    hooks = [m.register_forward_hook(lambda _m, _i, o: margin.__setitem__(0, min(margin[0], float(o.abs().min()))))
+             for m in stock.fw if isinstance(m, torch.nn.InstanceNorm1d)]
+    g = torch.Generator().manual_seed(N)
+    x = torch.rand(B, cin, N, generator=g)
+    G = torch.randn(B, 1, N, generator=g)
+    xa = x.double().requires_grad_(True)
+    xb = x.to(DEV).requires_grad_(True)
+    ya = stock(xa)
+    for h in hooks:
+        h.remove()
+    yb = fused(xb)
+    assert yb.shape == (B, 1, N)
+    assert float((yb.detach().cpu().double() - ya.detach()).abs().max()) < 1e-5
+    (ya * G.double()).sum().backward()
+    (yb * G.to(DEV)).sum().backward()
+    strict = margin[0] > 2e-6
+    pa, pb = dict(stock.named_parameters()), dict(fused.named_parameters())
+    pairs = [("input", xb.grad.cpu().double(), xa.grad)] + [(n, pb[n].grad.cpu().double(), pa[n].grad) for n in pa]
+    for name, got, ref in pairs:
+        if float(ref.norm()) < 1e-9:  # biases that cancel in an InstanceNorm
+            assert float(got.abs().max()) < 1e-6, name
+            continue
+        err = float((got - ref).norm() / ref.norm())
+        assert err < (1e-4 if strict else 2e-3), (name, err, margin[0])
+
+
+def test_one_point_per_pair_raises_like_the_reference(dfepe):
+    """InstanceNorm1d over a single value per channel: the stock stack raises ("Expected more than 1 spatial element when
+    training"); the fused estimator declines N = 1 and lets the same error come up."""
+    fused = dfepe.compat.ErrorEstimators.FusedErrorEstimator(4).to(DEV)
+    with pytest.raises(ValueError, match="more than 1 spatial element"):
+        fused(torch.rand(3, 4, 1, device=DEV))
