@@ -257,6 +257,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU implementation)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # the steps are captured on side streams while the parameters' AccumulateGrad nodes were made on the default one: intended
+    quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+    if quiet is not None:
+        quiet(False)
     dist = None
     if world > 1 or args.force_dist or launched:
         import torch.distributed as dist_mod
