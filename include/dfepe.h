@@ -400,7 +400,10 @@ int dfepe_inorm_lrelu_bwd(const float *Y, const float *gA, const float *gamma, c
  *                        dlogit[col] * w_head[c]), the layer's output planes [3], rstd, gamma, beta; per-pair d gamma / d beta
  *   dfepe_est_norm_fwd   any N points per pair (the reference's SIFT configurations: up to 2000): planes [3] and rstd from the
  *                        plain product Y fp32 [n_pairs * N][ldy] of dfepe_est_gemm_nt -- InstanceNorm (biased variance, two-pass),
- *                        affine, LeakyReLU, split; dfepe_est_layer_fwd is this fused into the product for N = dfepe_est_points()
+ *                        affine, LeakyReLU, split; dfepe_est_layer_fwd is this fused into the product for N = dfepe_est_points().
+ *                        splits = 1: one launch, a workgroup per (pair, 64 channels); splits in 2..64 (a dozen pairs do not fill the
+ *                        chip): each pair's rows over `splits` workgroups in two launches (partial mean / squared deviations, merged
+ *                        pairwise; then the normalisation), part = workspace of n_pairs * splits * 2 * C floats
  *   dfepe_est_in_bwd_n   dfepe_est_in_bwd for any N (ncols = n_pairs * N)
  *   dfepe_est_head_fwd   logits[col] = sum_c w[c] a[col][c] + bias[0]   (the last Conv1d(C -> 1))
  *   dfepe_est_head_dw    part[blocks][C] = partial sums of d w = sum_col dlogit[col] a[col][c]
@@ -419,10 +422,10 @@ int dfepe_est_in_bwd(const float *dA, const float *dlogit, const float *w_head, 
                      const float *rstd, const float *gamma, const float *beta, float slope, int C, int ncols, void *dY,
                      size_t dy_plane, float *dgamma_part, float *dbeta_part, void *stream);
 int dfepe_est_norm_fwd(const float *Y, int ldy, int C, long n_pairs, int N, const float *gamma, const float *beta, float eps,
-                       float slope, void *planes_out, size_t out_plane, float *rstd, void *stream);
+                       float slope, void *planes_out, size_t out_plane, float *rstd, int splits, float *part, void *stream);
 int dfepe_est_in_bwd_n(const float *dA, const float *dlogit, const float *w_head, const void *planes, size_t plane_stride,
                        const float *rstd, const float *gamma, const float *beta, float slope, int C, long n_pairs, int N, void *dY,
-                       size_t dy_plane, float *dgamma_part, float *dbeta_part, void *stream);
+                       size_t dy_plane, float *dgamma_part, float *dbeta_part, int splits, float *part, void *stream);
 int dfepe_est_head_fwd(const void *planes, size_t plane_stride, int C, int ncols, const float *w, const float *bias, float *logits,
                        void *stream);
 int dfepe_est_head_dw(const void *planes, size_t plane_stride, int C, int ncols, int blocks, const float *dlogit, float *part,

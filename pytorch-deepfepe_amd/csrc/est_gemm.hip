@@ -495,56 +495,90 @@ __device__ __forceinline__ void pair_reduce2(float (&red)[kRG][64], int rg, int 
   for (int q = 0; q < kRG; ++q) { A += red[q][2 * cp]; B += red[q][2 * cp + 1]; }
 }
 
+// MODE 0: the whole pair in one workgroup (grid.z = 1).  With a dozen pairs that is too few workgroups, so the pair's rows can be
+// split over grid.z = S workgroups and two launches: MODE 1 leaves each split's mean and sum of squared deviations from it in
+// part[pair][split][2][C], MODE 2 merges the S partials (Chan's pairwise formula: M2 = sum M2_s + sum n_s (m_s - m)^2, as accurate
+// as the two-pass form) and normalises its own rows.
+template <int MODE>
 __global__ void __launch_bounds__(1024)
 est_norm_fwd_n_kernel(const float* __restrict__ Y, int ldy, int C, int N, size_t ncols, const float* __restrict__ gamma,
                       const float* __restrict__ beta, float eps, float slope, bf16_t* __restrict__ planes, size_t plane_stride,
-                      float* __restrict__ rstd) {
+                      float* __restrict__ rstd, float* __restrict__ part) {
   __shared__ float red[kRG][64];
   const int pair = (int)blockIdx.x, cb = (int)blockIdx.y * 64;
+  const int S = (int)gridDim.z, sp = (int)blockIdx.z;
+  const int R = (N + S - 1) / S;
+  const int r0 = sp * R, r1 = (r0 + R < N) ? r0 + R : N;  // this workgroup's rows (possibly none in the last split)
   const int cp = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int ch = cb + 2 * cp;
   const bool chok = ch < C;
   const int chc = chok ? ch : 0;
   const size_t col0 = (size_t)pair * N;
-  const float inv_n = 1.0f / (float)N;
   const float* Yc = Y + col0 * ldy + chc;
-  float s0 = 0.f, s1 = 0.f;
-  for (int rb = rg; rb < N; rb += kRG * kRU) {
-    f32x2 y[kRU];
+  float mu0, mu1, Q0, Q1;
+  if (MODE != 2) {
+    const float inv_n = 1.0f / (float)((r1 > r0) ? r1 - r0 : 1);
+    float s0 = 0.f, s1 = 0.f;
+    for (int rb = r0 + rg; rb < r1; rb += kRG * kRU) {
+      f32x2 y[kRU];
 #pragma unroll
-    for (int u = 0; u < kRU; ++u) { const int rl = rb + kRG * u; y[u] = *reinterpret_cast<const f32x2*>(Yc + (size_t)(rl < N ? rl : rb) * ldy); }
+      for (int u = 0; u < kRU; ++u) { const int rl = rb + kRG * u; y[u] = *reinterpret_cast<const f32x2*>(Yc + (size_t)(rl < r1 ? rl : rb) * ldy); }
 #pragma unroll
-    for (int u = 0; u < kRU; ++u) { const bool live = rb + kRG * u < N; s0 += live ? y[u][0] : 0.f; s1 += live ? y[u][1] : 0.f; }
-  }
-  float S0, S1;
-  pair_reduce2(red, rg, cp, s0, s1, S0, S1);
-  const float mu0 = S0 * inv_n, mu1 = S1 * inv_n;
-  float q0 = 0.f, q1 = 0.f;
-  for (int rb = rg; rb < N; rb += kRG * kRU) {
-    f32x2 y[kRU];
+      for (int u = 0; u < kRU; ++u) { const bool live = rb + kRG * u < r1; s0 += live ? y[u][0] : 0.f; s1 += live ? y[u][1] : 0.f; }
+    }
+    float S0, S1;
+    pair_reduce2(red, rg, cp, s0, s1, S0, S1);
+    mu0 = S0 * inv_n; mu1 = S1 * inv_n;
+    float q0 = 0.f, q1 = 0.f;
+    for (int rb = r0 + rg; rb < r1; rb += kRG * kRU) {
+      f32x2 y[kRU];
 #pragma unroll
-    for (int u = 0; u < kRU; ++u) { const int rl = rb + kRG * u; y[u] = *reinterpret_cast<const f32x2*>(Yc + (size_t)(rl < N ? rl : rb) * ldy); }
+      for (int u = 0; u < kRU; ++u) { const int rl = rb + kRG * u; y[u] = *reinterpret_cast<const f32x2*>(Yc + (size_t)(rl < r1 ? rl : rb) * ldy); }
 #pragma unroll
-    for (int u = 0; u < kRU; ++u) {
-      const bool live = rb + kRG * u < N;
-      const float d0 = y[u][0] - mu0, d1 = y[u][1] - mu1;
-      q0 += live ? d0 * d0 : 0.f; q1 += live ? d1 * d1 : 0.f;
+      for (int u = 0; u < kRU; ++u) {
+        const bool live = rb + kRG * u < r1;
+        const float d0 = y[u][0] - mu0, d1 = y[u][1] - mu1;
+        q0 += live ? d0 * d0 : 0.f; q1 += live ? d1 * d1 : 0.f;
+      }
+    }
+    pair_reduce2(red, rg, cp, q0, q1, Q0, Q1);
+    if (MODE == 1) {
+      if (rg == 0 && chok) {
+        float* P = part + ((size_t)pair * S + sp) * 2 * C + ch;
+        P[0] = mu0; P[1] = mu1; P[C] = Q0; P[C + 1] = Q1;
+      }
+      return;
+    }
+  } else {
+    const float* P = part + (size_t)pair * S * 2 * C + chc;
+    float a0 = 0.f, a1 = 0.f;
+    for (int t = 0; t < S; ++t) {
+      const int n_t = ((t + 1) * R < N ? (t + 1) * R : N) - t * R;
+      if (n_t > 0) { a0 = fmaf((float)n_t, P[(size_t)t * 2 * C], a0); a1 = fmaf((float)n_t, P[(size_t)t * 2 * C + 1], a1); }
+    }
+    mu0 = a0 / (float)N; mu1 = a1 / (float)N;
+    Q0 = 0.f; Q1 = 0.f;
+    for (int t = 0; t < S; ++t) {
+      const int n_t = ((t + 1) * R < N ? (t + 1) * R : N) - t * R;
+      if (n_t > 0) {
+        const float d0 = P[(size_t)t * 2 * C] - mu0, d1 = P[(size_t)t * 2 * C + 1] - mu1;
+        Q0 += P[(size_t)t * 2 * C + C] + (float)n_t * d0 * d0; Q1 += P[(size_t)t * 2 * C + C + 1] + (float)n_t * d1 * d1;
+      }
     }
   }
-  float Q0, Q1;
-  pair_reduce2(red, rg, cp, q0, q1, Q0, Q1);
-  const float r0 = 1.0f / sqrtf(Q0 * inv_n + eps), r1 = 1.0f / sqrtf(Q1 * inv_n + eps);  // biased variance, like F.instance_norm
-  if (rg == 0 && chok) { rstd[(size_t)pair * C + ch] = r0; rstd[(size_t)pair * C + ch + 1] = r1; }
-  const float k0 = r0 * gamma[chc], k1 = r1 * gamma[chc + 1], b0 = beta[chc], b1 = beta[chc + 1];
+  const float inv_N = 1.0f / (float)N;
+  const float rs0 = 1.0f / sqrtf(Q0 * inv_N + eps), rs1 = 1.0f / sqrtf(Q1 * inv_N + eps);  // biased variance, like F.instance_norm
+  if (rg == 0 && sp == 0 && chok) { rstd[(size_t)pair * C + ch] = rs0; rstd[(size_t)pair * C + ch + 1] = rs1; }
+  const float k0 = rs0 * gamma[chc], k1 = rs1 * gamma[chc + 1], b0 = beta[chc], b1 = beta[chc + 1];
   if (!chok) return;
-  for (int rb = rg; rb < N; rb += kRG * kRU) {
+  for (int rb = r0 + rg; rb < r1; rb += kRG * kRU) {
     f32x2 y[kRU];
 #pragma unroll
-    for (int u = 0; u < kRU; ++u) { const int rl = rb + kRG * u; y[u] = *reinterpret_cast<const f32x2*>(Yc + (size_t)(rl < N ? rl : rb) * ldy); }
+    for (int u = 0; u < kRU; ++u) { const int rl = rb + kRG * u; y[u] = *reinterpret_cast<const f32x2*>(Yc + (size_t)(rl < r1 ? rl : rb) * ldy); }
 #pragma unroll
     for (int u = 0; u < kRU; ++u) {
       const int rl = rb + kRG * u;
-      if (rl >= N) break;
+      if (rl >= r1) break;
       const float z0 = fmaf(y[u][0] - mu0, k0, b0), z1 = fmaf(y[u][1] - mu1, k1, b1);
       unsigned p0, p1, p2;
       split3((z0 > 0.f) ? z0 : z0 * slope, (z1 > 0.f) ? z1 : z1 * slope, p0, p1, p2);
@@ -557,14 +591,20 @@ est_norm_fwd_n_kernel(const float* __restrict__ Y, int ldy, int C, int N, size_t
 }
 
 // The adjoint for any N: est_in_bwd_kernel's arithmetic with the pair's columns strided instead of held in registers -- one pass
-// for the two sums, one that recomputes d z and x^ from the same inputs and writes dY.
+// for the two sums, one that recomputes d z and x^ from the same inputs and writes dY.  MODE as above: 1 leaves the split's two
+// sums in part[pair][split][2][C], 2 adds the S partials up and writes its own rows.
+template <int MODE>
 __global__ void __launch_bounds__(1024)
 est_in_bwd_n_kernel(const float* __restrict__ dA, const float* __restrict__ dlogit, const float* __restrict__ w_head,
                     const bf16_t* __restrict__ planes, size_t plane_stride, const float* __restrict__ rstd,
                     const float* __restrict__ gamma, const float* __restrict__ beta, float slope, int C, int N, size_t ncols,
-                    bf16_t* __restrict__ dYp, size_t dy_plane, float* __restrict__ dgamma_part, float* __restrict__ dbeta_part) {
+                    bf16_t* __restrict__ dYp, size_t dy_plane, float* __restrict__ dgamma_part, float* __restrict__ dbeta_part,
+                    float* __restrict__ part) {
   __shared__ float red[kRG][64];
   const int pair = (int)blockIdx.x, cb = (int)blockIdx.y * 64;
+  const int S = (int)gridDim.z, sp = (int)blockIdx.z;
+  const int R = (N + S - 1) / S;
+  const int r0 = sp * R, r1 = (r0 + R < N) ? r0 + R : N;
   const int cp = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int ch = cb + 2 * cp;
   const bool chok = ch < C;
@@ -597,38 +637,54 @@ est_in_bwd_n_kernel(const float* __restrict__ dA, const float* __restrict__ dlog
     e0 = (a0 > 0.f) ? r.d0 : r.d0 * slope; e1 = (a1 > 0.f) ? r.d1 : r.d1 * slope;
     x0 = (z0 - b0) * ig0; x1 = (z1 - b1) * ig1;
   };
-  float s10 = 0.f, s11 = 0.f, s20 = 0.f, s21 = 0.f;
-  for (int rb = rg; rb < N; rb += kRG * kRU) {
-    Raw r[kRU];
+  float S10, S11, S20, S21;
+  if (MODE != 2) {
+    float s10 = 0.f, s11 = 0.f, s20 = 0.f, s21 = 0.f;
+    for (int rb = r0 + rg; rb < r1; rb += kRG * kRU) {
+      Raw r[kRU];
 #pragma unroll
-    for (int u = 0; u < kRU; ++u) { const int rl = rb + kRG * u; r[u] = load(rl < N ? rl : rb); }
+      for (int u = 0; u < kRU; ++u) { const int rl = rb + kRG * u; r[u] = load(rl < r1 ? rl : rb); }
 #pragma unroll
-    for (int u = 0; u < kRU; ++u) {
-      float e0, e1, x0, x1;
-      item(r[u], e0, e1, x0, x1);
-      if (rb + kRG * u >= N) { e0 = 0.f; e1 = 0.f; }
-      s10 += e0; s11 += e1; s20 = fmaf(e0, x0, s20); s21 = fmaf(e1, x1, s21);
+      for (int u = 0; u < kRU; ++u) {
+        float e0, e1, x0, x1;
+        item(r[u], e0, e1, x0, x1);
+        if (rb + kRG * u >= r1) { e0 = 0.f; e1 = 0.f; }
+        s10 += e0; s11 += e1; s20 = fmaf(e0, x0, s20); s21 = fmaf(e1, x1, s21);
+      }
+    }
+    pair_reduce2(red, rg, cp, s10, s11, S10, S11);
+    pair_reduce2(red, rg, cp, s20, s21, S20, S21);
+    if (MODE == 1) {
+      if (rg == 0 && chok) {
+        float* P = part + ((size_t)pair * S + sp) * 2 * C + ch;
+        P[0] = S10; P[1] = S11; P[C] = S20; P[C + 1] = S21;
+      }
+      return;
+    }
+  } else {
+    const float* P = part + (size_t)pair * S * 2 * C + chc;
+    S10 = 0.f; S11 = 0.f; S20 = 0.f; S21 = 0.f;
+    for (int t = 0; t < S; ++t) {
+      S10 += P[(size_t)t * 2 * C]; S11 += P[(size_t)t * 2 * C + 1];
+      S20 += P[(size_t)t * 2 * C + C]; S21 += P[(size_t)t * 2 * C + C + 1];
     }
   }
-  float S10, S11, S20, S21;
-  pair_reduce2(red, rg, cp, s10, s11, S10, S11);
-  pair_reduce2(red, rg, cp, s20, s21, S20, S21);
   if (!chok) return;
-  if (rg == 0) {
+  if (rg == 0 && sp == 0) {
     dbeta_part[(size_t)pair * C + ch] = S10; dbeta_part[(size_t)pair * C + ch + 1] = S11;
     dgamma_part[(size_t)pair * C + ch] = S20; dgamma_part[(size_t)pair * C + ch + 1] = S21;
   }
   const float inv_n = 1.0f / (float)N;
   const float k0 = rstd[(size_t)pair * C + ch] * g0, k1 = rstd[(size_t)pair * C + ch + 1] * g1;
   const float m10 = S10 * inv_n, m11 = S11 * inv_n, m20 = S20 * inv_n, m21 = S21 * inv_n;
-  for (int rb = rg; rb < N; rb += kRG * kRU) {
+  for (int rb = r0 + rg; rb < r1; rb += kRG * kRU) {
     Raw r[kRU];
 #pragma unroll
-    for (int u = 0; u < kRU; ++u) { const int rl = rb + kRG * u; r[u] = load(rl < N ? rl : rb); }
+    for (int u = 0; u < kRU; ++u) { const int rl = rb + kRG * u; r[u] = load(rl < r1 ? rl : rb); }
 #pragma unroll
     for (int u = 0; u < kRU; ++u) {
       const int rl = rb + kRG * u;
-      if (rl >= N) break;
+      if (rl >= r1) break;
       float e0, e1, x0, x1;
       item(r[u], e0, e1, x0, x1);
       unsigned p0, p1;
@@ -786,32 +842,53 @@ extern "C" int dfepe_est_in_bwd(const float* dA, const float* dlogit, const floa
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
-// InstanceNorm + LeakyReLU + split of a plain product, N points per pair (any N >= 1): Y fp32 [n_pairs * N][ldy]
+// InstanceNorm + LeakyReLU + split of a plain product, N points per pair (any N >= 1): Y fp32 [n_pairs * N][ldy].  splits = 1:
+// one launch, a workgroup per (pair, 64 channels); splits = 2..64 (few pairs): the pair's rows over `splits` workgroups, two
+// launches, part = workspace of n_pairs * splits * 2 * C floats.
 extern "C" int dfepe_est_norm_fwd(const float* Y, int ldy, int C, long n_pairs, int N, const float* gamma, const float* beta, float eps,
-                                  float slope, void* planes_out, size_t out_plane, float* rstd, void* stream) {
+                                  float slope, void* planes_out, size_t out_plane, float* rstd, int splits, float* part, void* stream) {
   if (!Y || !gamma || !beta || !planes_out || !rstd || C <= 0 || (C & 31) || ldy < C || (ldy & 1) || n_pairs < 0 || N <= 0)
     return DFEPE_ERR_INVALID_ARG;
+  if (splits < 1 || splits > 64 || (splits > 1 && !part)) return DFEPE_ERR_INVALID_ARG;
   if (!(slope > 0.f)) return DFEPE_ERR_UNSUPPORTED;  // the backward inverts the activation
   if (n_pairs == 0) return DFEPE_OK;
   if (n_pairs > 0x7fffffffL) return DFEPE_ERR_UNSUPPORTED;
-  const dim3 grid((unsigned)n_pairs, (C + 63) / 64), block(kRG * 32);
-  hipLaunchKernelGGL(est_norm_fwd_n_kernel, grid, block, 0, static_cast<hipStream_t>(stream), Y, ldy, C, N, (size_t)n_pairs * N, gamma, beta,
-                     eps, slope, static_cast<bf16_t*>(planes_out), out_plane, rstd);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)n_pairs, (C + 63) / 64, splits), block(kRG * 32);
+  const size_t ncols = (size_t)n_pairs * N;
+  bf16_t* P = static_cast<bf16_t*>(planes_out);
+  if (splits == 1) {
+    hipLaunchKernelGGL(est_norm_fwd_n_kernel<0>, grid, block, 0, st, Y, ldy, C, N, ncols, gamma, beta, eps, slope, P, out_plane, rstd, part);
+  } else {
+    hipLaunchKernelGGL(est_norm_fwd_n_kernel<1>, grid, block, 0, st, Y, ldy, C, N, ncols, gamma, beta, eps, slope, P, out_plane, rstd, part);
+    hipLaunchKernelGGL(est_norm_fwd_n_kernel<2>, grid, block, 0, st, Y, ldy, C, N, ncols, gamma, beta, eps, slope, P, out_plane, rstd, part);
+  }
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
-// dfepe_est_in_bwd for N points per pair (any N >= 1; ncols = n_pairs * N)
+// dfepe_est_in_bwd for N points per pair (any N >= 1; ncols = n_pairs * N); splits / part as in dfepe_est_norm_fwd
 extern "C" int dfepe_est_in_bwd_n(const float* dA, const float* dlogit, const float* w_head, const void* planes, size_t plane_stride,
                                   const float* rstd, const float* gamma, const float* beta, float slope, int C, long n_pairs, int N, void* dY,
-                                  size_t dy_plane, float* dgamma_part, float* dbeta_part, void* stream) {
+                                  size_t dy_plane, float* dgamma_part, float* dbeta_part, int splits, float* part, void* stream) {
   if ((!dA && !(dlogit && w_head)) || !planes || !rstd || !gamma || !beta || !dY || !dgamma_part || !dbeta_part) return DFEPE_ERR_INVALID_ARG;
   if (C <= 0 || (C & 31) || n_pairs < 0 || N <= 0 || !(slope > 0.f)) return DFEPE_ERR_INVALID_ARG;
+  if (splits < 1 || splits > 64 || (splits > 1 && !part)) return DFEPE_ERR_INVALID_ARG;
   if (n_pairs == 0) return DFEPE_OK;
   if (n_pairs > 0x7fffffffL) return DFEPE_ERR_UNSUPPORTED;
-  const dim3 grid((unsigned)n_pairs, (C + 63) / 64), block(kRG * 32);
-  hipLaunchKernelGGL(est_in_bwd_n_kernel, grid, block, 0, static_cast<hipStream_t>(stream), dA, dlogit, w_head,
-                     static_cast<const bf16_t*>(planes), plane_stride, rstd, gamma, beta, slope, C, N, (size_t)n_pairs * N,
-                     static_cast<bf16_t*>(dY), dy_plane, dgamma_part, dbeta_part);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)n_pairs, (C + 63) / 64, splits), block(kRG * 32);
+  const size_t ncols = (size_t)n_pairs * N;
+  const bf16_t* P = static_cast<const bf16_t*>(planes);
+  bf16_t* D = static_cast<bf16_t*>(dY);
+  if (splits == 1) {
+    hipLaunchKernelGGL(est_in_bwd_n_kernel<0>, grid, block, 0, st, dA, dlogit, w_head, P, plane_stride, rstd, gamma, beta, slope, C, N, ncols, D,
+                       dy_plane, dgamma_part, dbeta_part, part);
+  } else {
+    hipLaunchKernelGGL(est_in_bwd_n_kernel<1>, grid, block, 0, st, dA, dlogit, w_head, P, plane_stride, rstd, gamma, beta, slope, C, N, ncols, D,
+                       dy_plane, dgamma_part, dbeta_part, part);
+    hipLaunchKernelGGL(est_in_bwd_n_kernel<2>, grid, block, 0, st, dA, dlogit, w_head, P, plane_stride, rstd, gamma, beta, slope, C, N, ncols, D,
+                       dy_plane, dgamma_part, dbeta_part, part);
+  }
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 

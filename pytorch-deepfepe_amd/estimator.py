@@ -42,6 +42,15 @@ def _split(src: Tensor, rows: int, c_src: int, c: int, n_planes: int) -> Tensor:
     return out
 
 
+def _row_splits(pairs: int, c: int, n: int) -> int:
+    """Workgroups a pair's rows are spread over in the N-generic normalisation kernels: 1 when (pair, 64-channel) workgroups
+    alone fill the chip, otherwise enough to reach ~1024 workgroups with at least 128 rows (one unrolled trip) each."""
+    blocks = pairs * ((c + 63) // 64)
+    if blocks >= 512 or n < 256:
+        return 1
+    return max(1, min(64, n // 128, (1024 + blocks - 1) // blocks))
+
+
 def _slices_for(cout: int, cin: int) -> int:
     tiles = ((cout + 127) // 128) * ((cin + 127) // 128)
     return max(1, min(512, 768 // tiles))
@@ -79,8 +88,10 @@ class _EstimatorFunction(torch.autograd.Function):
                     Y = torch.empty(cols, Co, device=dev, dtype=torch.float32)
                     rc = lib.dfepe_est_gemm_nt(_ptr(Wp), Co * K, _ptr(acts[-1]), cols * K, Co, cols, K, 3, _ptr(Y), Co, st)
                     _lib.check(rc, "dfepe_est_gemm_nt")
+                    sp = _row_splits(B, Co, N)
+                    part = torch.empty(B * sp * 2 * Co, device=dev, dtype=torch.float32) if sp > 1 else None
                     rc = lib.dfepe_est_norm_fwd(_ptr(Y), Co, Co, B, N, _ptr(g32), _ptr(b32), float(eps), float(slope), _ptr(out), cols * Co,
-                                                _ptr(rstd), st)
+                                                _ptr(rstd), sp, _ptr(part), st)
                     _lib.check(rc, "dfepe_est_norm_fwd")
                     del Y
                 acts.append(out)
@@ -145,9 +156,11 @@ class _EstimatorFunction(torch.autograd.Function):
                                               st)
                     _lib.check(rc, "dfepe_est_in_bwd")
                 else:
+                    sp = _row_splits(B, Co, N)
+                    part = torch.empty(B * sp * 2 * Co, device=dev, dtype=torch.float32) if sp > 1 else None
                     rc = lib.dfepe_est_in_bwd_n(_ptr(dA), _ptr(dl if dA is None else None), _ptr(wh if dA is None else None), _ptr(a_out),
                                                 cols * Co, _ptr(rstds[l]), _ptr(g32), _ptr(b32), float(slope), Co, B, N, _ptr(dY), cols * Co,
-                                                _ptr(dg), _ptr(db), st)
+                                                _ptr(dg), _ptr(db), sp, _ptr(part), st)
                     _lib.check(rc, "dfepe_est_in_bwd_n")
                 grads[4 * l + 2] = dg.sum(0).to(gamma.dtype)
                 grads[4 * l + 3] = db.sum(0).to(beta.dtype)

@@ -1,5 +1,6 @@
 """Launch the kernels of the other BASELINE configurations and of the weight estimator a few times (for rocprofv3 kernel-trace and
---pmc passes): config 5 (N = 1000: fit + cheirality) at 4096 and at 512 pairs, one split-bf16 estimator call forward + backward."""
+--pmc passes): config 5 (N = 1000: fit + cheirality) at 4096 and at 512 pairs, one split-bf16 estimator call forward + backward at
+4096 x 100 points (fused epilogue) and one at 12 x 2000 (plain product + est_norm_fwd_n / est_in_bwd_n)."""
 import importlib, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 d = importlib.import_module("pytorch-deepfepe_amd")
@@ -18,6 +19,14 @@ if what in ("all", "est"):
     m = d.compat.ErrorEstimators.FusedErrorEstimator(7).cuda(); d.synth.fill_params_deterministic(m, 1)
     x = torch.rand(4096, 7, 100, device="cuda", requires_grad=True)
     G = torch.randn(4096, 1, 100, device="cuda")
+    for _ in range(2):
+        m.zero_grad(set_to_none=True); x.grad = None
+        (m(x) * G).sum().backward()
+    torch.cuda.synchronize()
+if what in ("all", "estn"):
+    m = d.compat.ErrorEstimators.FusedErrorEstimator(7).cuda(); d.synth.fill_params_deterministic(m, 1)
+    x = torch.rand(12, 7, 2000, device="cuda", requires_grad=True)
+    G = torch.randn(12, 1, 2000, device="cuda")
     for _ in range(2):
         m.zero_grad(set_to_none=True); x.grad = None
         (m(x) * G).sum().backward()

@@ -4,8 +4,8 @@
 TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_other_$TAG; rm -rf $O; mkdir -p $O
-timeout 200 rocprofv3 --kernel-trace --output-format csv -d $O/trace -o p -- python $R/scripts/pmc_probe_other.py > $O/trace.log 2>&1
-pmc() { name=$1; shift; timeout 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc_$name -o p -- python $R/scripts/pmc_probe_other.py > $O/pmc_$name.log 2>&1; }
+timeout 150 rocprofv3 --kernel-trace --output-format csv -d $O/trace -o p -- python $R/scripts/pmc_probe_other.py > $O/trace.log 2>&1
+pmc() { name=$1; shift; timeout 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc_$name -o p -- python $R/scripts/pmc_probe_other.py > $O/pmc_$name.log 2>&1; }
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 pmc sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY

@@ -71,8 +71,8 @@ def test_argument_validation_without_launching(dfepe):
     assert inp(4, 100, 0, 1241.0) == -1 and inp(0, 100, 0, 1241.0) == 0 and inp(4, 100, 0, 0.0) == -1 and inp(4, 100, -1, 1241.0) == -1
     assert L.dfepe_geo_misc(7, None, None, 4, None, None) == -1 and L.dfepe_geo_misc(6, None, None, 0, None, None) == 0
     # the estimator's normalisation for any number of points per pair: null pointers, channel counts off the 32 grid, N < 1
-    assert L.dfepe_est_norm_fwd(None, 64, 64, 2, 1000, None, None, 1e-5, 0.01, None, 0, None, None) == -1
-    assert L.dfepe_est_in_bwd_n(None, None, None, None, 0, None, None, None, 0.01, 64, 2, 1000, None, 0, None, None, None) == -1
+    assert L.dfepe_est_norm_fwd(None, 64, 64, 2, 1000, None, None, 1e-5, 0.01, None, 0, None, 1, None, None) == -1
+    assert L.dfepe_est_in_bwd_n(None, None, None, None, 0, None, None, None, 0.01, 64, 2, 1000, None, 0, None, None, 1, None, None) == -1
 
 
 def test_no_cpu_fallback(dfepe):

@@ -214,9 +214,11 @@ def test_backward_twice_with_retain_graph_and_the_standard_error_without(dfepe):
 
 
 # ---- any number of points per pair (the reference's SIFT configurations: 1000-2000 correspondences) -----------------------------
-@pytest.mark.parametrize("C,N,pairs", [(64, 37, 3), (128, 1000, 2), (1024, 256, 2), (256, 2000, 1), (32, 1, 4), (64, 100, 2)])
-def test_norm_forward_any_points_matches_float64(dfepe, C, N, pairs):
-    """dfepe_est_norm_fwd on a plain product Y [pairs * N, ld]: planes = split(leaky_relu(instance_norm(Y))), rstd."""
+@pytest.mark.parametrize("C,N,pairs,splits", [(64, 37, 3, 1), (128, 1000, 2, 1), (1024, 256, 2, 2), (256, 2000, 1, 15), (32, 1, 4, 1), (64, 100, 2, 1),
+                                              (128, 1000, 2, 7), (64, 5, 2, 4), (64, 2000, 3, 64)])
+def test_norm_forward_any_points_matches_float64(dfepe, C, N, pairs, splits):
+    """dfepe_est_norm_fwd on a plain product Y [pairs * N, ld]: planes = split(leaky_relu(instance_norm(Y))), rstd -- in one
+    launch (splits = 1) and with each pair's rows over several workgroups (partials merged pairwise; a split may be empty)."""
     lib = dfepe._lib.lib()
     cols, ld = pairs * N, C + 8
     g = torch.Generator().manual_seed(C + N)
@@ -225,8 +227,9 @@ def test_norm_forward_any_points_matches_float64(dfepe, C, N, pairs):
     beta = (0.3 * torch.randn(C, generator=g)).to(DEV)
     out = torch.zeros(3, cols, C, device=DEV, dtype=torch.bfloat16)
     rstd = torch.zeros(pairs, C, device=DEV)
+    part = torch.full((pairs * splits * 2 * C,), float("nan"), device=DEV)
     rc = lib.dfepe_est_norm_fwd(Yd.data_ptr(), ld, C, pairs, N, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.01, out.data_ptr(), cols * C,
-                                rstd.data_ptr(), None)
+                                rstd.data_ptr(), splits, part.data_ptr() if splits > 1 else None, None)
     assert rc == 0
     torch.cuda.synchronize()
     Y = Yd[:, :C].double().view(pairs, N, C).permute(0, 2, 1)
@@ -238,8 +241,9 @@ def test_norm_forward_any_points_matches_float64(dfepe, C, N, pairs):
     assert relerr(rstd, 1.0 / torch.sqrt(var + 1e-5)) < 5e-6
 
 
-@pytest.mark.parametrize("C,N,pairs,head", [(64, 37, 3, False), (256, 1000, 2, True), (1024, 250, 2, False), (64, 100, 2, True)])
-def test_instance_norm_adjoint_any_points(dfepe, C, N, pairs, head):
+@pytest.mark.parametrize("C,N,pairs,head,splits", [(64, 37, 3, False, 1), (256, 1000, 2, True, 1), (1024, 250, 2, False, 1), (64, 100, 2, True, 1),
+                                                   (256, 1000, 2, True, 7), (64, 2000, 2, False, 16), (64, 5, 2, False, 4)])
+def test_instance_norm_adjoint_any_points(dfepe, C, N, pairs, head, splits):
     lib = dfepe._lib.lib()
     cols = pairs * N
     g = torch.Generator().manual_seed(C + N)
@@ -260,13 +264,15 @@ def test_instance_norm_adjoint_any_points(dfepe, C, N, pairs, head):
     dY = torch.zeros(2, cols, C, device=DEV, dtype=torch.bfloat16)
     dg, db = torch.zeros(pairs, C, device=DEV), torch.zeros(pairs, C, device=DEV)
     gm, bt = gamma.detach().float().to(DEV), beta.detach().float().to(DEV)
+    part_t = torch.full((pairs * splits * 2 * C,), float("nan"), device=DEV)
+    part = part_t.data_ptr() if splits > 1 else None
     if head:
         dl_d, wh_d = dl.float().to(DEV), wh.float().to(DEV)
         rc = lib.dfepe_est_in_bwd_n(None, dl_d.data_ptr(), wh_d.data_ptr(), P.data_ptr(), cols * C, rstd.data_ptr(), gm.data_ptr(), bt.data_ptr(),
-                                    0.01, C, pairs, N, dY.data_ptr(), cols * C, dg.data_ptr(), db.data_ptr(), None)
+                                    0.01, C, pairs, N, dY.data_ptr(), cols * C, dg.data_ptr(), db.data_ptr(), splits, part, None)
     else:
         rc = lib.dfepe_est_in_bwd_n(dA.data_ptr(), None, None, P.data_ptr(), cols * C, rstd.data_ptr(), gm.data_ptr(), bt.data_ptr(), 0.01, C,
-                                    pairs, N, dY.data_ptr(), cols * C, dg.data_ptr(), db.data_ptr(), None)
+                                    pairs, N, dY.data_ptr(), cols * C, dg.data_ptr(), db.data_ptr(), splits, part, None)
     assert rc == 0
     torch.cuda.synchronize()
     assert relerr(planes_to_f64(dY).cpu(), Y.grad.permute(0, 2, 1).reshape(cols, C)) < 5e-5
