@@ -310,7 +310,20 @@ est_gemm_tn_kernel(const bf16_t* __restrict__ dY, size_t dy_plane, int Cout, con
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kOpBytes];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
-  const int m0 = (int)blockIdx.x * 128, n0 = (int)blockIdx.y * 128, slice = (int)blockIdx.z;
+  // XCD-aware order (-DDFEPE_TN_NO_XCD builds the launch-order variant for A/B timing): consecutive workgroup ids go round-robin to the 8 XCDs; all output tiles of one column slice
+  // stream the same columns of dY and X, so a slice's tiles are given consecutive slots of ONE XCD and its L2 serves the re-reads
+  // (in launch order the eight Cout tiles of a (Cin tile, slice) sat on eight different XCDs: X crossed the fabric eight times)
+  int bx = (int)blockIdx.x, by = (int)blockIdx.y, slice = (int)blockIdx.z;
+#ifndef DFEPE_TN_NO_XCD
+  if ((gridDim.z & 7) == 0) {
+    const int nx = (int)gridDim.x, tiles = nx * (int)gridDim.y;
+    const int id = bx + nx * (by + (int)gridDim.y * slice);
+    const int xcd = id & 7, j = id >> 3, t = j % tiles;
+    slice = (j / tiles) * 8 + xcd;
+    bx = t % nx; by = t / nx;
+  }
+#endif
+  const int m0 = bx * 128, n0 = by * 128;
   const int kbeg = slice * cols_per_slice;
   int kend = kbeg + cols_per_slice;
   kend = (kend < ncols) ? kend : ncols;
