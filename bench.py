@@ -343,10 +343,29 @@ def main():
     torch.cuda.synchronize()
     log("eager warm-up done")
     graph = None
+    exchange_fallback = None
     if not args.no_graph:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            last = step_body()
+        captured = 1
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                last = step_body()
+        except Exception as exc:  # only a captured collective is allowed to fail: the step then keeps it outside the graph
+            if exchange_mode not in ("graph", "branch"):
+                raise
+            captured, graph, exchange_fallback = 0, None, repr(exc)[:200]
+            log("capturing the step with the all-reduce inside failed:", exchange_fallback)
+            torch.cuda.synchronize()
+        if exchange_mode in ("graph", "branch"):
+            # every rank must run the same variant: agree on the weakest outcome, outside any capture
+            flag = torch.tensor([captured], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                exchange_fallback = exchange_fallback or "another rank failed to capture the all-reduce"
+                exchange_mode, loss_exchange = "sync", None  # step_body reads loss_exchange at call time
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    last = step_body()
     log("graph captured" if graph is not None else "eager mode")
 
     exchange = dfepe.dist.OverlappedLossExchange(L + 4, dev, depth=2) if exchange_mode == "overlap" else None
@@ -690,7 +709,8 @@ def main():
                                          "branch": "all_reduce(SUM) of L+4 doubles captured in the step's hipGraph as a branch parallel to the backward",
                                          "sync": "all_reduce(SUM) of L+4 doubles in stream order after every step",
                                          "overlap": "double-buffered asynchronous all_reduce (dist.OverlappedLossExchange)",
-                                         "none": None}[exchange_mode]},
+                                         "none": None}[exchange_mode],
+                       "loss_exchange_fallback": exchange_fallback},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "accuracy": acc,
