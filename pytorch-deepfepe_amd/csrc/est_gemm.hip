@@ -413,8 +413,9 @@ est_gemm_tn_kernel(const bf16_t* __restrict__ dY, size_t dy_plane, int Cout, con
 // ---- InstanceNorm + LeakyReLU adjoint, point-major ----------------------------------------------------------------------------
 // One workgroup = one pair (100 columns) x 64 channels: 32 channel pairs x 8 row groups of 13 columns.  Inputs: the upstream
 // gradient dA [cols][C] fp32 -- or, for the layer under the head, its rank-one form dlogit[col] * w_head[c] --, the layer's
-// output planes (a = lrelu(z), z = gamma x^ + beta: z and x^ are recovered from them), rstd, gamma, beta.  Outputs: dY as two
-// planes, and the pair's contributions to d gamma / d beta ([pair][C] each, summed by the caller).
+// output planes (a = lrelu(z), z = gamma x^ + beta: z and x^ are recovered from them -- from the two leading planes, 2^-17 of a: the
+// third would be 2 of the 14 bytes per element this HBM-bound kernel moves, for digits the two-plane products downstream drop),
+// rstd, gamma, beta.  Outputs: dY as two planes, and the pair's contributions to d gamma / d beta ([pair][C] each, summed by the caller).
 __global__ void __launch_bounds__(256)
 est_in_bwd_kernel(const float* __restrict__ dA, const float* __restrict__ dlogit, const float* __restrict__ w_head,
                   const bf16_t* __restrict__ planes, size_t plane_stride, const float* __restrict__ rstd,
@@ -441,8 +442,12 @@ est_in_bwd_kernel(const float* __restrict__ dA, const float* __restrict__ dlogit
     const size_t at = kb_index(col, chc, (size_t)ncols);
     const unsigned u0 = *reinterpret_cast<const unsigned*>(planes + at);
     const unsigned u1 = *reinterpret_cast<const unsigned*>(planes + plane_stride + at);
+#ifdef DFEPE_INBWD_3PLANES
     const unsigned u2 = *reinterpret_cast<const unsigned*>(planes + 2 * plane_stride + at);
     const float a0 = (bf16_lo(u0) + bf16_lo(u1)) + bf16_lo(u2), a1 = (bf16_hi(u0) + bf16_hi(u1)) + bf16_hi(u2);
+#else  // two planes: a to 2^-17, the class of the two-plane products this gradient feeds; the sign of a is its leading plane's
+    const float a0 = bf16_lo(u0) + bf16_lo(u1), a1 = bf16_hi(u0) + bf16_hi(u1);
+#endif
     float d0, d1;
     if (dA != nullptr) {
       const f32x2 d = *reinterpret_cast<const f32x2*>(dA + col * C + chc);
@@ -634,7 +639,11 @@ est_in_bwd_n_kernel(const float* __restrict__ dA, const float* __restrict__ dlog
     Raw r;
     r.u0 = *reinterpret_cast<const unsigned*>(planes + at);
     r.u1 = *reinterpret_cast<const unsigned*>(planes + plane_stride + at);
+#ifdef DFEPE_INBWD_3PLANES
     r.u2 = *reinterpret_cast<const unsigned*>(planes + 2 * plane_stride + at);
+#else
+    r.u2 = 0u;
+#endif
     if (dA != nullptr) {
       const f32x2 d = *reinterpret_cast<const f32x2*>(dA + col * C + chc);
       r.d0 = d[0]; r.d1 = d[1];
@@ -741,14 +750,31 @@ est_head_dw_kernel(const bf16_t* __restrict__ planes, size_t plane_stride, int C
     const int ch = cb + 2 * cp;
     float s0 = 0.f, s1 = 0.f;
     if (ch < C) {
-      for (int col = c0 + cg; col < c1; col += 8) {
+      // two leading planes (a to 2^-17: a gradient), four columns in flight per thread
+      int col = c0 + cg;
+      for (; col + 24 < c1; col += 32) {
+        unsigned u0[4], u1[4];
+        float d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const size_t at = kb_index((size_t)(col + 8 * u), ch, (size_t)ncols);
+          u0[u] = *reinterpret_cast<const unsigned*>(planes + at);
+          u1[u] = *reinterpret_cast<const unsigned*>(planes + plane_stride + at);
+          d[u] = dlogit[col + 8 * u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          s0 = fmaf(bf16_lo(u0[u]) + bf16_lo(u1[u]), d[u], s0);
+          s1 = fmaf(bf16_hi(u0[u]) + bf16_hi(u1[u]), d[u], s1);
+        }
+      }
+      for (; col < c1; col += 8) {
         const size_t at = kb_index((size_t)col, ch, (size_t)ncols);
         const unsigned u0 = *reinterpret_cast<const unsigned*>(planes + at);
         const unsigned u1 = *reinterpret_cast<const unsigned*>(planes + plane_stride + at);
-        const unsigned u2 = *reinterpret_cast<const unsigned*>(planes + 2 * plane_stride + at);
         const float d = dlogit[col];
-        s0 = fmaf((bf16_lo(u0) + bf16_lo(u1)) + bf16_lo(u2), d, s0);
-        s1 = fmaf((bf16_hi(u0) + bf16_hi(u1)) + bf16_hi(u2), d, s1);
+        s0 = fmaf(bf16_lo(u0) + bf16_lo(u1), d, s0);
+        s1 = fmaf(bf16_hi(u0) + bf16_hi(u1), d, s1);
       }
     }
     red[cg][2 * cp] = s0; red[cg][2 * cp + 1] = s1;
