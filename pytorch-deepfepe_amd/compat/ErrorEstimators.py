@@ -46,8 +46,8 @@ class FusedErrorEstimator(ErrorEstimator):
     (rocBLAS / hipBLASLt through torch.mm) instead of B small ones, and InstanceNorm + LeakyReLU is one fused HIP pass
     (ops.inorm_lrelu).  The biases of the convolutions that feed an InstanceNorm cancel in the normalisation and are
     skipped in the arithmetic; they stay in the autograd graph with the exact zero gradient the reference computes for them
-    (so DistributedDataParallel sees every parameter used and the optimizer state matches).  Falls back to the stock path for the batch-norm
-    variant and for N not a multiple of 4 or above 512."""
+    (so DistributedDataParallel sees every parameter used and the optimizer state matches).  The split-bf16 path serves any head width (1, or the 4 of ``update_offsets``); the batch-norm variant
+    always takes the stock path, and so does the native-fp32 evaluation for N not a multiple of 4 or above 512."""
 
     split_bf16 = True
 
@@ -63,7 +63,7 @@ class FusedErrorEstimator(ErrorEstimator):
                 hidden.append((mods[i].weight, mods[i].bias, mods[i + 1].weight, mods[i + 1].bias))
                 i += 3
             head, inorm, act = mods[i], mods[1], mods[2]
-            if i == len(mods) - 1 and head.weight.shape[0] == 1 and act.negative_slope > 0 and all(m.affine for m in mods if isinstance(m, nn.InstanceNorm1d)):
+            if i == len(mods) - 1 and act.negative_slope > 0 and all(m.affine for m in mods if isinstance(m, nn.InstanceNorm1d)):
                 return estimator.estimator_forward(data, hidden, (head.weight, head.bias), eps=inorm.eps, slope=act.negative_slope)
         if has_bn or (N % 4) or N > 512 or not data.is_cuda:
             return super().forward(data)

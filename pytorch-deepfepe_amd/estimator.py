@@ -58,7 +58,7 @@ def _slices_for(cout: int, cin: int) -> int:
 
 class _EstimatorFunction(torch.autograd.Function):
     """args: x [B, C0, N], then per hidden layer (conv weight [Co,Ci,1], conv bias [Co], gamma [Co], beta [Co]), then the head's
-    (weight [1,C,1], bias [1] or None); cfg = (n_hidden, eps, slope)."""
+    (weight [O,C,1], bias [O] or None; O = 1 for the weight heads, 4 for update_offsets); cfg = (n_hidden, eps, slope)."""
 
     @staticmethod
     def forward(ctx, cfg, x, *params):
@@ -98,11 +98,14 @@ class _EstimatorFunction(torch.autograd.Function):
                 rstds.append(rstd)
             Wh, bh = params[4 * n_hidden], params[4 * n_hidden + 1]
             C = acts[-1].shape[2]
-            wh = Wh.detach().float().reshape(-1).contiguous()
-            logits = torch.empty(cols, device=dev, dtype=torch.float32)
-            rc = lib.dfepe_est_head_fwd(_ptr(acts[-1]), cols * C, C, cols, _ptr(wh), _ptr(None if bh is None else bh.detach().float().contiguous()),
-                                        _ptr(logits), st)
-            _lib.check(rc, "dfepe_est_head_fwd")
+            n_out = Wh.shape[0]  # 1: the weight heads; 4: update_offsets (if_learn_offsets, models/DeepFNet.py:330,342)
+            wh = Wh.detach().float().reshape(n_out, C).contiguous()
+            bh32 = None if bh is None else bh.detach().float().contiguous()
+            logits = torch.empty(n_out, cols, device=dev, dtype=torch.float32)
+            for o in range(n_out):  # a GEMV per output channel over the same planes
+                rc = lib.dfepe_est_head_fwd(_ptr(acts[-1]), cols * C, C, cols, _ptr(wh[o]), _ptr(None if bh32 is None else bh32[o:o + 1]),
+                                            _ptr(logits[o]), st)
+                _lib.check(rc, "dfepe_est_head_fwd")
         ctx.cfg = cfg
         ctx.shape = (B, C0, N)
         # the bf16 planes and the reciprocal deviations travel through save_for_backward like the parameters: autograd owns their
@@ -112,7 +115,7 @@ class _EstimatorFunction(torch.autograd.Function):
         ctx.n_params = len(kept)
         ctx.save_for_backward(*kept, *acts, *rstds)
         ctx.has_head_bias = bh is not None
-        return logits.view(B, 1, N)
+        return logits.view(B, 1, N) if n_out == 1 else logits.view(n_out, B, N).permute(1, 0, 2).contiguous()
 
     @staticmethod
     def backward(ctx, g_logits):
@@ -129,18 +132,24 @@ class _EstimatorFunction(torch.autograd.Function):
         grads: List[Optional[Tensor]] = [None] * len(params)
         with torch.cuda.device(dev):
             st = _stream()
-            dl = g_logits.detach().float().reshape(cols).contiguous()
             Wh = params[4 * n_hidden]
             C = acts[-1].shape[2]
-            wh = Wh.detach().float().reshape(-1).contiguous()
+            n_out = Wh.shape[0]
+            dl = g_logits.detach().float().permute(1, 0, 2).reshape(n_out, cols).contiguous()  # [n_out, cols]
+            wh = Wh.detach().float().reshape(n_out, C).contiguous()
             nblk = 512
-            part = torch.empty(nblk, C, device=dev, dtype=torch.float32)
-            rc = lib.dfepe_est_head_dw(_ptr(acts[-1]), cols * C, C, cols, nblk, _ptr(dl), _ptr(part), st)
-            _lib.check(rc, "dfepe_est_head_dw")
-            grads[4 * n_hidden] = part.sum(0).reshape(Wh.shape).to(Wh.dtype)
+            part = torch.empty(n_out, nblk, C, device=dev, dtype=torch.float32)
+            for o in range(n_out):
+                rc = lib.dfepe_est_head_dw(_ptr(acts[-1]), cols * C, C, cols, nblk, _ptr(dl[o]), _ptr(part[o]), st)
+                _lib.check(rc, "dfepe_est_head_dw")
+            grads[4 * n_hidden] = part.sum(1).reshape(Wh.shape).to(Wh.dtype)
             if ctx.has_head_bias:
-                grads[4 * n_hidden + 1] = dl.sum().reshape(1).to(params[4 * n_hidden + 1].dtype)
-            dA = None  # fp32 [cols, C_l]: gradient w.r.t. the output of hidden layer l (None: the rank-one head form)
+                grads[4 * n_hidden + 1] = dl.sum(1).to(params[4 * n_hidden + 1].dtype)
+            # fp32 [cols, C_l]: gradient w.r.t. the output of hidden layer l.  None under a one-channel head: est_in_bwd forms the
+            # rank-one dlogit[col] * w_head[c] itself; several output channels sum their rank-one terms here
+            dA = None if n_out == 1 else torch.mm(dl.t(), wh)
+            if n_out == 1:
+                dl, wh = dl[0], wh[0]
             for l in range(n_hidden - 1, -1, -1):
                 W, bconv, gamma, beta = params[4 * l:4 * l + 4]
                 Co, Ci = W.shape[0], W.shape[1]
@@ -189,8 +198,8 @@ class _EstimatorFunction(torch.autograd.Function):
 
 def estimator_forward(x: Tensor, hidden: Sequence[Tuple[Tensor, Tensor, Tensor, Tensor]], head: Tuple[Tensor, Optional[Tensor]],
                       eps: float = 1e-5, slope: float = 0.01) -> Tensor:
-    """x [B, C0, N] fp32 on the GPU -> logits [B, 1, N].  hidden: per layer (conv weight, conv bias, InstanceNorm weight,
-    InstanceNorm bias); head: (conv weight [1,C,1], bias or None)."""
+    """x [B, C0, N] fp32 on the GPU -> logits [B, O, N].  hidden: per layer (conv weight, conv bias, InstanceNorm weight,
+    InstanceNorm bias); head: (conv weight [O,C,1], bias [O] or None)."""
     if not supported(x):
         raise _lib.DfepeError(f"estimator_forward: needs a GPU tensor [B >= 1, C, N >= 2], got {tuple(x.shape)} on {x.device}")
     flat: List[Optional[Tensor]] = []

@@ -326,3 +326,35 @@ def test_one_point_per_pair_raises_like_the_reference(dfepe):
     fused = dfepe.compat.ErrorEstimators.FusedErrorEstimator(4).to(DEV)
     with pytest.raises(ValueError, match="more than 1 spatial element"):
         fused(torch.rand(3, 4, 1, device=DEV))
+
+
+@pytest.mark.parametrize("N,B", [(100, 5), (300, 3)])
+def test_four_output_head_matches_float64(dfepe, N, B):
+    """update_offsets = ErrorEstimator(C, output_size=4) (models/DeepFNet.py:330,342, if_learn_offsets): the same hidden stack, a
+    head with four output channels -- four GEMVs over the last layer's planes forward, their rank-one terms summed into the
+    upstream gradient of the last InstanceNorm backward."""
+    EE = dfepe.compat.ErrorEstimators
+    stock = EE.ErrorEstimator(7, output_size=4)
+    dfepe.synth.fill_params_deterministic(stock, seed=8)
+    fused = EE.FusedErrorEstimator(7, output_size=4).to(DEV)
+    fused.load_state_dict(stock.state_dict())
+    stock = stock.double()
+    g = torch.Generator().manual_seed(N)
+    x = torch.rand(B, 7, N, generator=g)
+    G = torch.randn(B, 4, N, generator=g)
+    xa = x.double().requires_grad_(True)
+    xb = x.to(DEV).requires_grad_(True)
+    ya, yb = stock(xa), fused(xb)
+    assert yb.shape == (B, 4, N) and yb.is_contiguous()
+    assert float((yb.detach().cpu().double() - ya.detach()).abs().max()) < 1e-5
+    (ya * G.double()).sum().backward()
+    (yb * G.to(DEV)).sum().backward()
+    pa, pb = dict(stock.named_parameters()), dict(fused.named_parameters())
+    for name, got, ref in [("input", xb.grad.cpu().double(), xa.grad)] + [(n, pb[n].grad.cpu().double(), pa[n].grad) for n in pa]:
+        if float(ref.norm()) < 1e-9:
+            assert float(got.abs().max()) < 1e-6, name
+            continue
+        assert float((got - ref).norm() / ref.norm()) < 2e-3, name  # a LeakyReLU branch flip at most (see the N != 100 test); typically 1e-5
+    # and it is the matrix-core path that ran, not the stock stack: the native-fp32 switch gives the same numbers to fp32 rounding
+    fused.split_bf16 = False
+    assert float((fused(x.to(DEV)).detach() - yb.detach()).abs().max()) < 1e-4
