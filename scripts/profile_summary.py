@@ -8,9 +8,11 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O = os.path.join(REPO, "gpurun_out", f"prof_{tag}")
 P = os.path.join(REPO, "profiles")
 B, N, L, M = 4096, 100, 5, 100
-FIT_FWD, FIT_BWD, TAIL, HEAD = "w8pt16_fwd_kernel<7, true, true>", "w8pt16_bwd_kernel<7, true, false, true, false>", "loss_tail_kernel<7>", "loss_tail_head_kernel"
+FIT_FWD, FIT_BWD, TAIL, HEAD = "w8pt16_fwd_kernel<7, true, true>", "w8pt16_bwd_kernel<7, true, false, true, false>", "loss_tail_kernel<7, false>", "loss_tail_head_kernel"
 BWD_HEAD = "w8pt16_bwd_head_kernel<7, true, false>"  # the first backward fit of the step, with the deferred loss head in spare wavefronts
-HOT = (FIT_FWD, FIT_BWD, BWD_HEAD, TAIL, HEAD)
+# kernels only the reference's call sequence runs (bench.py: api_path), not the timed step
+API = ("loss_tail_kernel<7, true>", "loss_tail_bwd_kernel", "loss_stats_kernel", "row_dot_kernel", "deepf_input_kernel")
+HOT = (FIT_FWD, FIT_BWD, BWD_HEAD, TAIL, HEAD) + API
 
 
 def short(name):
@@ -76,6 +78,8 @@ for (k, g), ds in groups.items():
         step_sum += mean(ds) / 1e3
     elif k == HEAD:
         what = "loss head as a launch of its own: only the informational layers-batched variant (the timed step defers it)"
+    elif k in API:
+        what = "`api_path` only (behind DeepFNet.forward / get_all_loss_DeepF / get_Rt_loss; not in the timed step)"
     else:
         what = "once per step"
         step_sum += mean(ds) / 1e3
