@@ -30,7 +30,10 @@
 //                 stored planes), writes dY as two planes.  (Run as the data-gradient GEMM's epilogue instead -- dA kept in the
 //                 accumulators -- it needs x^ or a second pass over the planes on top of 104 accumulator registers: it spilled
 //                 and measured 12.05 against 11.95 ms per call for the two kernels; this kernel streams at 5 TB/s.)
-//   est_head_*    the last Conv1d(256 -> 1) and its adjoint pieces (a GEMV: VALU, HBM-bound).
+//   est_norm_fwd_n / est_in_bwd_n   the same normalisation + activation + split, and its adjoint, for ANY number of points per
+//                 pair behind the plain product (EPI_F32): a workgroup per (pair, 64 channels), or the pair's rows over several
+//                 workgroups in two launches when a dozen pairs would not fill the chip.
+//   est_head_*    the last Conv1d(256 -> O) and its adjoint pieces (a GEMV per output channel: VALU, HBM-bound).
 #include "dfepe_common.h"
 
 namespace {
