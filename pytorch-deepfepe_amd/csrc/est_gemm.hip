@@ -90,6 +90,9 @@ __device__ __forceinline__ size_t kb_index(size_t row, int ch, size_t rows) { re
 __device__ __forceinline__ int chunk_swz(int rowgroup) { return (0x78 >> (2 * (rowgroup & 3))) & 3; }
 
 enum { EPI_F32 = 0, EPI_IN = 1 };
+#ifndef DFEPE_NT2_BLOCKS
+#define DFEPE_NT2_BLOCKS 3  // workgroups per CU the two-plane (data-gradient) product is compiled for
+#endif
 
 struct EpiArgs {
   // EPI_F32: out[col][m] fp32, ld = ldc
@@ -115,7 +118,7 @@ struct EpiArgs {
 // per CU: 1.47 vs 1.43 ms with two planes (206 registers), spills with three.  The step is bound by instruction issue around the
 // MFMAs (DMA setup, fragment reads, barriers), not by an exposed load latency.
 template <int NPA, int NPB, int ORDER, int EPI>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, (NPA == 2 && NPB == 2) ? DFEPE_NT2_BLOCKS : 2)
 est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* __restrict__ B, size_t b_plane, int M, int ncols, int K,
                    const EpiArgs E) {
   constexpr int kABytes = NPA * BM * 64, kBBytes = NPB * BN * 64;
@@ -182,15 +185,25 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
   auto mfma_phase = [&](const unsigned char* lds, const bf16x8 (&a)[2][NPA]) {
     // the column tile's B fragments are fetched one tile ahead of the MFMAs that consume them (two register sets): the LDS
     // latency of tile nt + 1 hides behind the twelve MFMAs of tile nt instead of stalling every tile
-    bf16x8 b[2][NPB];
+    // (the two-plane product compiled for three workgroups per CU has 168 registers: one fragment set, fetched per tile -- the
+    // third wavefront on the SIMD covers the LDS latency the second set would)
+    constexpr bool kAhead = !(NPA == 2 && NPB == 2 && DFEPE_NT2_BLOCKS > 2);
+    bf16x8 b[kAhead ? 2 : 1][NPB];
+    if (kAhead) {
 #pragma unroll
-    for (int p = 0; p < NPB; ++p) b[0][p] = *reinterpret_cast<const bf16x8*>(lds + kABytes + ((p * BN + c) * 4 + (g ^ fsw)) * 16);
+      for (int p = 0; p < NPB; ++p) b[0][p] = *reinterpret_cast<const bf16x8*>(lds + kABytes + ((p * BN + c) * 4 + (g ^ fsw)) * 16);
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      if (nt + 1 < NT) {
+      if (kAhead) {
+        if (nt + 1 < NT) {
 #pragma unroll
-        for (int p = 0; p < NPB; ++p)
-          b[(nt + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(lds + kABytes + ((p * BN + (nt + 1) * 16 + c) * 4 + (g ^ fsw)) * 16);
+          for (int p = 0; p < NPB; ++p)
+            b[(nt + 1) & (kAhead ? 1 : 0)][p] = *reinterpret_cast<const bf16x8*>(lds + kABytes + ((p * BN + (nt + 1) * 16 + c) * 4 + (g ^ fsw)) * 16);
+        }
+      } else {
+#pragma unroll
+        for (int p = 0; p < NPB; ++p) b[0][p] = *reinterpret_cast<const bf16x8*>(lds + kABytes + ((p * BN + nt * 16 + c) * 4 + (g ^ fsw)) * 16);
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this tile's MFMAs (the scheduler would sink it to its first use)
       // smallest terms first; the two row tiles alternate, so that no MFMA waits for the one issued just before it
@@ -202,7 +215,7 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
           if (i < NPA && j < NPB) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][i], b[nt & 1][j], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][i], b[kAhead ? (nt & 1) : 0][j], acc[mt][nt], 0, 0, 0);
           }
         }
       __builtin_amdgcn_sched_barrier(0);
