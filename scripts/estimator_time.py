@@ -5,6 +5,8 @@ import importlib, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 d = importlib.import_module("pytorch-deepfepe_amd")
 EE = d.compat.ErrorEstimators
+if os.environ.get("TN_BLOCKS"):  # A/B of the weight-gradient GEMM's split-K granularity
+    d.estimator.TN_BLOCKS = int(os.environ["TN_BLOCKS"])
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 FL = 2.0 * B * N * (7 * 64 + 64 * 128 + 128 * 1024 + 1024 * 512 + 512 * 256 + 256)
