@@ -183,7 +183,9 @@ def get_all_loss_DeepF(outs, pts1_virt_ori, pts2_virt_ori, Ks, loss_params, get_
         r = ops.loss_tail_jac(F_layers, T1, T2, Ks, pts1_virt_ori, pts2_virt_ori, loss_params["clamp_at"], q_gt, t_gt, R_gt,
                               floss_grad=loss_params.get("floss_grad", True), extra=epidot, extra_scale=1.0 / N_pts)
         E_layers, m_loss, o_loss, row_min, col_min, m_epi, o_epi = (r[k] for k in ("E_layers", "m_loss", "o_loss", "row_min", "col_min", "m_extra", "o_extra"))
-        _last_tail.update(E=E_layers, gt=tuple(x.data_ptr() for x in (q_gt, t_gt, delta)), **{k: r[k] for k in ("q_l2", "t_l2", "ang", "m_q", "o_q", "m_t", "o_t")})
+        # the caller's own objects and their device copies are HELD until get_Rt_loss consumes the entry: an address or an id()
+        # recycled for other values in between can then not pass for "the same ground truth"
+        _last_tail.update(E=E_layers, gt_src=tuple(gt), gt_dev=(q_gt, t_gt, delta), **{k: r[k] for k in ("q_l2", "t_l2", "ang", "m_q", "o_q", "m_t", "o_t")})
     else:
         # without the ground truth the pose part cannot ride along: the stand-alone F-loss kernel, whose adjoint takes the
         # gradient w.r.t. the E matrices that get_Rt_loss's pose kernel sends back (any number M of virtual points)
@@ -240,6 +242,15 @@ def get_all_loss_DeepF(outs, pts1_virt_ori, pts2_virt_ori, Ks, loss_params, get_
     return losses_dict, E_ests, F_ests, logits_softmax, residual_norm_layers, residual_norm_max_layers, E_ests_layers
 
 
+def _same_gt(entry, given, on_device):
+    """Is the ground truth handed to get_Rt_loss the one get_all_loss_DeepF's fused launch was given?  Yes when they are the very
+    same objects, or device tensors over the same memory with the same layout as the (still held) ones of that launch."""
+    if all(a is b for a, b in zip(entry["gt_src"], given)):
+        return True
+    return all(torch.is_tensor(g) and g.is_cuda and d.data_ptr() == k.data_ptr() and d.shape == k.shape and d.stride() == k.stride() and d.dtype == k.dtype
+               for g, d, k in zip(given, on_device, entry["gt_dev"]))
+
+
 def get_Rt_loss(E_ests_layers, Ks_cpu, x1_cpu, x2_cpu, delta_Rtijs_4_4_cpu, qs_cam, ts_cam, device="cpu"):
     """Pose loss from the per-layer essential matrices and the ground-truth camera motion.  Same 12-key dict as the
     reference (:272-293).  NB the reference stacks the *translation* list under "q_l2_error_list" (:276); that slip
@@ -258,7 +269,7 @@ def get_Rt_loss(E_ests_layers, Ks_cpu, x1_cpu, x2_cpu, delta_Rtijs_4_4_cpu, qs_c
     delta = torch.as_tensor(delta_Rtijs_4_4_cpu).to(dev)
     lt = _state.tail
     L = E_layers.shape[0]
-    if lt and lt["E"].data_ptr() == E_layers.data_ptr() and lt["E"].shape == E_layers.shape and lt["gt"] == tuple(x.data_ptr() for x in (q_gt, t_gt, delta)):
+    if lt and lt["E"].data_ptr() == E_layers.data_ptr() and lt["E"].shape == E_layers.shape and _same_gt(lt, (qs_cam, ts_cam, delta_Rtijs_4_4_cpu), (q_gt, t_gt, delta)):
         q_l2, t_l2, ang, m_q, o_q, m_t, o_t = (lt[k] for k in ("q_l2", "t_l2", "ang", "m_q", "o_q", "m_t", "o_t"))  # get_all_loss_DeepF's launches
         _state.tail = {}  # consumed: do not keep the step's graph alive until the next call
     else:
