@@ -57,7 +57,8 @@ TN_BLOCKS = 768  # workgroups of a weight-gradient launch: three per CU in one r
 
 def _slices_for(cout: int, cin: int) -> int:
     tiles = ((cout + 127) // 128) * ((cin + 127) // 128)
-    return max(1, min(512, TN_BLOCKS // tiles))
+    s = max(1, min(512, TN_BLOCKS // tiles))
+    return s - s % 8 if s >= 8 else s  # a multiple of eight: one slice group per XCD (est_gemm_tn's block order needs it)
 
 
 class _EstimatorFunction(torch.autograd.Function):

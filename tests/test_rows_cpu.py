@@ -120,3 +120,37 @@ def test_no_kernel_of_the_library_uses_scratch_memory():
     assert len(ks) > 100
     bad = [(k["name"][:90], k["scratch"], k["spill"]) for k in ks if k["scratch"] or k["spill"]]
     assert not bad, bad
+
+
+def test_estimator_launch_geometry_helpers(dfepe):
+    """Host-side choices of the estimator: the weight-gradient GEMM's split-K slices stay a multiple of eight whenever a launch
+    has more than one slice per XCD to place (est_gemm_tn's XCD-aware order needs it and falls back to launch order otherwise) and
+    fill TN_BLOCKS workgroups; the N-generic normalisation splits a pair's rows only when (pair, channel-block) workgroups do not
+    fill the chip, never below one unrolled trip (128 rows) per split, never beyond the kernel's 64."""
+    est = dfepe.estimator
+    for cout, cin in [(64, 32), (128, 64), (1024, 128), (512, 1024), (256, 512), (1024, 1024), (256, 32)]:
+        tiles = ((cout + 127) // 128) * ((cin + 127) // 128)
+        s = est._slices_for(cout, cin)
+        assert 1 <= s <= 512 and s * tiles <= max(est.TN_BLOCKS, tiles)
+        assert s % 8 == 0 or s < 8, (cout, cin, s)
+    assert est._row_splits(4096, 1024, 100) == 1      # the benchmark's shape never splits
+    assert est._row_splits(128, 1024, 1000) == 1      # 2048 workgroups already
+    assert est._row_splits(12, 64, 2000) == 15        # 12 workgroups -> 15 splits of >= 128 rows
+    assert est._row_splits(12, 1024, 2000) == 6       # 192 workgroups -> ~1024
+    assert est._row_splits(1, 64, 100000) == 64       # the kernel's limit
+    assert est._row_splits(2, 64, 200) == 1           # too few rows to split
+    for pairs, c, n in [(1, 32, 256), (3, 64, 300), (8, 256, 1000), (12, 512, 2000)]:
+        s = est._row_splits(pairs, c, n)
+        assert 1 <= s <= 64 and (s == 1 or n // s >= 128)
+
+
+def test_fused_tail_is_reused_only_for_the_announced_ground_truth(dfepe):
+    """get_Rt_loss takes the pose errors of get_all_loss_DeepF's fused launch only when it is handed the very objects that launch
+    was given (or device tensors over the same memory): equal VALUES in other objects recompute -- slower, never wrong."""
+    tgu = dfepe.compat.train_good_utils
+    q, t, d = torch.zeros(4, 4), torch.zeros(4, 3), torch.eye(4).repeat(4, 1, 1)
+    entry = {"gt_src": (q, t, d), "gt_dev": (q, t, d)}
+    assert tgu._same_gt(entry, (q, t, d), (q, t, d))
+    assert not tgu._same_gt(entry, (q.clone(), t, d), (q.clone(), t, d))          # another object, on the host: no identity, no device memory
+    assert not tgu._same_gt(entry, (q.numpy(), t, d), (q, t, d))                  # numpy view of the same memory: still not the object
+    assert not tgu._same_gt(entry, (t, q, d), (t, q, d))                          # order
