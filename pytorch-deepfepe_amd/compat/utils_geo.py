@@ -49,67 +49,67 @@ def invert_Rt(R21, t21):
     return Rt[:, :3], Rt[:, 3:4]
 
 
-# ---- the small host-side helpers of the module (plain numpy / elementwise torch like the reference's: no kernel needed) --------
+# ---- the small host-side helpers of the module (numpy / elementwise torch, batched over leading dimensions) --------------------
 def R_to_q_np(matrix):
-    """Rotation matrix [3,3] -> unit quaternion [4,1] float32 with q0 >= 0: the trace method on R^T with its four branches
-    (utils_geo.py:88-117; the numpy twin of _R_to_q and what the synthetic ground truth of SURVEY §8d is built with)."""
-    m = np.asarray(matrix).conj().transpose()
-    if m[2, 2] < 0:
-        if m[0, 0] > m[1, 1]:
-            t = 1 + m[0, 0] - m[1, 1] - m[2, 2]
-            q = [m[1, 2] - m[2, 1], t, m[0, 1] + m[1, 0], m[2, 0] + m[0, 2]]
-        else:
-            t = 1 - m[0, 0] + m[1, 1] - m[2, 2]
-            q = [m[2, 0] - m[0, 2], m[0, 1] + m[1, 0], t, m[1, 2] + m[2, 1]]
-    else:
-        if m[0, 0] < -m[1, 1]:
-            t = 1 - m[0, 0] - m[1, 1] + m[2, 2]
-            q = [m[0, 1] - m[1, 0], m[2, 0] + m[0, 2], m[1, 2] + m[2, 1], t]
-        else:
-            t = 1 + m[0, 0] + m[1, 1] + m[2, 2]
-            q = [t, m[1, 2] - m[2, 1], m[2, 0] - m[0, 2], m[0, 1] - m[1, 0]]
-    q = np.array(q, dtype=np.float32)
-    q *= 0.5 / np.sqrt(t)
-    if q[0] < 0.0:
-        q = -q
-    return q.reshape(-1, 1)
+    """Rotation matrix [3,3] -> unit quaternion [4,1] float32 with q0 >= 0 (utils_geo.py:88-117: the numpy twin of _R_to_q,
+    what the ground truth of SURVEY §8d is built with).  A stack [n,3,3] gives [n,4,1].  The candidate table and the
+    reference's branch rule live in synth.shepperd_rows; the float32 rounding happens where the reference's does (the picked
+    row is rounded to float32 BEFORE the scale 1/(2 sqrt(pivot)) is applied in double)."""
+    from ..synth import shepperd_rows
+
+    S, k = shepperd_rows(np.asarray(matrix))
+    row = np.take_along_axis(S, k[..., None, None], axis=-2)[..., 0, :]
+    half_inv = 0.5 / np.sqrt(np.take_along_axis(row, k[..., None], axis=-1))
+    q = (row.astype(np.float32).astype(half_inv.dtype) * half_inv).astype(np.float32)
+    q = np.where(q[..., :1] < 0.0, -q, q)
+    return q[..., None]
+
+
+def _quat_blocks(q, sign):
+    """[[a, -v^T], [v, a I + sign [v]_x]] for q = (a, v) given as [4,1]: sign +1 is the matrix of q (x) . , -1 of . (x) q."""
+    q = np.asarray(q)
+    a, v = q[0, 0], q[1:, :]
+    out = np.empty((4, 4), dtype=q.dtype)
+    out[0, 0], out[0, 1:], out[1:, 0] = a, -v[:, 0], v[:, 0]
+    out[1:, 1:] = a * np.eye(3, dtype=q.dtype) + sign * utils_misc.skew_symmetric_np(v)
+    return out
 
 
 def q_matrix_np(q):
     """Left-multiplication matrix of the quaternion q [4,1] (utils_geo.py:119-126)."""
-    a, b, c, d = (q[i, 0] for i in range(4))
-    return np.array([[a, -b, -c, -d], [b, a, -d, c], [c, d, a, -b], [d, -c, b, a]])
+    return _quat_blocks(q, 1.0)
 
 
 def q_bar_matrix_np(q):
     """Right-multiplication matrix of the quaternion q [4,1] (utils_geo.py:128-135)."""
-    a, b, c, d = (q[i, 0] for i in range(4))
-    return np.array([[a, -b, -c, -d], [b, a, d, -c], [c, -d, a, b], [d, c, -b, a]])
+    return _quat_blocks(q, -1.0)
 
 
 def q_to_R_np(q):
-    """Quaternion [4,1] -> rotation matrix [3,3]; q is normalised first with the reference's +1e-10 (utils_geo.py:137-147)."""
+    """Quaternion [4,1] (or [n,4,1]) -> rotation matrix [3,3] ([n,3,3]); q is normalised first with the reference's +1e-10
+    (utils_geo.py:137-147, which multiplies the two 4x4 matrices above; this is the vector part of that product written out:
+    (a^2 - v.v) I + 2 v v^T + 2 a [v]_x)."""
     q = np.asarray(q)
-    q = q / (np.linalg.norm(q) + 1e-10)
-    product_matrix = np.dot(q_matrix_np(q), q_bar_matrix_np(q).conj().transpose())
-    return product_matrix[1:][:, 1:]
+    q = q / (np.sqrt(np.sum(q * q, axis=(-2, -1), keepdims=True)) + 1e-10)
+    a, v = q[..., :1, :], q[..., 1:, :]
+    vx = np.cross(v[..., None, :, 0], -np.eye(3, dtype=q.dtype))  # rows e_i x v... = [v]_x
+    eye = np.eye(3, dtype=q.dtype)
+    return (a * a - np.sum(v * v, axis=-2, keepdims=True)) * eye + 2.0 * (v * np.swapaxes(v, -1, -2)) + 2.0 * a * vx
 
 
 def _rot_angle_error(R0, R1):
-    """acos(clamp((tr(R0 R1^T) - 1) / 2)) in degrees, torch in / 0-dim torch out, differentiable like the reference's
-    (utils_geo.py:158-163)."""
-    rot_error = torch.acos(torch.clamp((torch.trace(R0 @ (R1.t())) - 1) / 2, -1.0, 1.0))
-    return rot_error / np.pi * 180.0
+    """Rotation angle of R0 R1^T in degrees, torch in / 0-dim torch out, differentiable like the reference's
+    (utils_geo.py:158-163): tr(R0 R1^T) is the elementwise inner product <R0, R1>."""
+    return torch.rad2deg(torch.acos(((R0 * R1).sum() - 1.0).div(2.0).clamp(-1.0, 1.0)))
 
 
 def dotproducts(v1s, v2s):
-    return np.sum(v1s * v2s, axis=1, keepdims=True)
+    """Row-wise inner products [N,D],[N,D] -> [N,1] (utils_geo.py:181-182)."""
+    return np.einsum("nd,nd->n", v1s, v2s)[:, None]
 
 
 def vectors_angle(v1s, v2s):
     """Row-wise angle in degrees between v1s and v2s [N,3] -> [N,1]; unlike vector_angle, no epsilons and no clipping
     (utils_geo.py:184-190)."""
-    dot_v1sv2s = dotproducts(v1s, v2s)
-    length_v1s = np.sqrt(dotproducts(v1s, v1s))
-    length_v2s = np.sqrt(dotproducts(v2s, v2s))
-    return np.arccos(dot_v1sv2s / (length_v1s * length_v2s)) / np.pi * 180.0
+    cos = dotproducts(v1s, v2s) / (np.linalg.norm(v1s, axis=1, keepdims=True) * np.linalg.norm(v2s, axis=1, keepdims=True))
+    return np.degrees(np.arccos(cos))

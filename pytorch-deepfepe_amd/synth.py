@@ -39,31 +39,36 @@ def _expm_so3(omega: torch.Tensor) -> torch.Tensor:
     return eye + s * Kx + (1 - c) * (Kx @ Kx)
 
 
-def rotation_to_quaternion_np(R: np.ndarray) -> np.ndarray:
-    """Trace-method quaternion (w,x,y,z), w >= 0, of a 3x3 rotation.
+def shepperd_rows(R: np.ndarray):
+    """The symmetric 4x4 matrix S(R) whose rows are the four un-normalised quaternion candidates (w,x,y,z) of Shepperd's
+    trace method, for R [...,3,3]: diagonal 1 +- R00 +- R11 +- R22 (the pivot 4 q_k^2), first row / column the antisymmetric
+    part of R (4 q_w q_k), the rest its symmetric off-diagonal sums (4 q_j q_k).  Row k is 4 q_k * q, so any row with a
+    safely positive pivot gives q after division by 2 sqrt(pivot).  Returns (S [...,4,4], k [...]): k is the row the
+    dataset-side helper of the reference picks (deepFEPE/dsac_tools/utils_geo.py:88-117: R22 < 0 ? (R00 > R11 ? x : y) :
+    (R00 < -R11 ? z : w)); pivots are summed left to right like there, so values agree to the bit."""
+    R = np.asarray(R)
+    d0, d1, d2 = R[..., 0, 0], R[..., 1, 1], R[..., 2, 2]
+    S = np.empty(R.shape[:-2] + (4, 4), dtype=np.result_type(R.dtype, np.float32))
+    S[..., 0, 0] = 1 + d0 + d1 + d2
+    S[..., 1, 1] = 1 + d0 - d1 - d2
+    S[..., 2, 2] = 1 - d0 + d1 - d2
+    S[..., 3, 3] = 1 - d0 - d1 + d2
+    for k, (i, j) in enumerate(((2, 1), (0, 2), (1, 0)), start=1):  # (i, j, k-1) cyclic
+        S[..., 0, k] = S[..., k, 0] = R[..., i, j] - R[..., j, i]
+        a, b = (k % 3) + 1, ((k + 1) % 3) + 1  # the two other vector components
+        S[..., a, b] = S[..., b, a] = R[..., j, i] + R[..., i, j]
+    pick = np.where(d2 < 0, np.where(d0 > d1, 1, 2), np.where(d0 < -d1, 3, 0))
+    return S, pick
 
-    Same branch structure as the dataset-side helper the reference uses for its ground truth
-    (deepFEPE/dsac_tools/utils_geo.py:88-117), restated.
-    """
-    m = R.T
-    if m[2, 2] < 0:
-        if m[0, 0] > m[1, 1]:
-            t = 1 + m[0, 0] - m[1, 1] - m[2, 2]
-            q = [m[1, 2] - m[2, 1], t, m[0, 1] + m[1, 0], m[2, 0] + m[0, 2]]
-        else:
-            t = 1 - m[0, 0] + m[1, 1] - m[2, 2]
-            q = [m[2, 0] - m[0, 2], m[0, 1] + m[1, 0], t, m[1, 2] + m[2, 1]]
-    else:
-        if m[0, 0] < -m[1, 1]:
-            t = 1 - m[0, 0] - m[1, 1] + m[2, 2]
-            q = [m[0, 1] - m[1, 0], m[2, 0] + m[0, 2], m[1, 2] + m[2, 1], t]
-        else:
-            t = 1 + m[0, 0] + m[1, 1] + m[2, 2]
-            q = [t, m[1, 2] - m[2, 1], m[2, 0] - m[0, 2], m[0, 1] - m[1, 0]]
-    q = np.asarray(q, dtype=np.float64) * (0.5 / math.sqrt(t))
-    if q[0] < 0:
-        q = -q
-    return q
+
+def rotation_to_quaternion_np(R: np.ndarray) -> np.ndarray:
+    """Trace-method quaternion (w,x,y,z), w >= 0, of rotations R [...,3,3] -> [...,4] float64 (the branch rule of the helper
+    the reference builds its ground truth with, deepFEPE/dsac_tools/utils_geo.py:88-117; see shepperd_rows)."""
+    S, k = shepperd_rows(np.asarray(R, dtype=np.float64))
+    row = np.take_along_axis(S, k[..., None, None], axis=-2)[..., 0, :]
+    piv = np.take_along_axis(row, k[..., None], axis=-1)
+    q = row * (0.5 / np.sqrt(piv))
+    return np.where(q[..., :1] < 0, -q, q)
 
 
 def make_scene(
