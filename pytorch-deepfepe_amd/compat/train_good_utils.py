@@ -1,6 +1,7 @@
 """Mirror of the two loss functions of deepFEPE/train_good_utils.py on the hot path:
 get_all_loss_DeepF (:298-520) and get_Rt_loss (:64-295), same arguments and return structures."""
 import threading
+import weakref
 
 import numpy as np
 import torch
@@ -24,7 +25,10 @@ def get_unique(xs, topk, matches_good_unique_nums):
 # ---------------------------------------------------------------------------------------------------------------------------
 # host-side metrics that do not force a device synchronisation
 # ---------------------------------------------------------------------------------------------------------------------------
-LAZY_HOST_METRICS = True  # False: get_Rt_loss copies the angular errors to the host at once (exactly the reference's types)
+LAZY_HOST_METRICS = False  # False (default): get_Rt_loss copies the angular errors to the host at once and returns exactly the
+# reference's types (numpy arrays / python floats; one device synchronisation per call, like the reference's .cpu().numpy()).
+# True -- an opt-in of graph-capturing callers (pipeline.CapturedStep, bench.py) -- defers that copy to the first read (_Lazy).
+# While the current stream is being captured the values are always lazy: a copy to the host cannot be captured.
 
 
 class _Lazy:
@@ -72,6 +76,18 @@ class _Lazy:
     def __bool__(self):
         return bool(self._v())
 
+    def __reduce__(self):  # pickle / torch.save / copy.deepcopy store the realised numpy array or float, not the closure
+        return (_realised, (self._v(),))
+
+
+def _realised(v):
+    return v
+
+
+class _LazyScalar(_Lazy):
+    """A lazy python float (the two *_angle_error_mean values): np.isscalar() and tensorboard's make_np accept it.  Only this
+    subclass is registered as numbers.Real; the array-valued lazies are not."""
+
 
 for _name in ("add", "sub", "mul", "truediv", "floordiv", "pow", "mod", "lt", "le", "gt", "ge", "eq", "ne"):
     def _make(n):
@@ -86,7 +102,7 @@ _Lazy.__abs__ = lambda self: abs(np.asarray(self._v()))
 _Lazy.__hash__ = lambda self: id(self)
 import numbers as _numbers
 
-_numbers.Real.register(_Lazy)  # np.isscalar() / tensorboard's make_np accept the lazy python floats
+_numbers.Real.register(_LazyScalar)
 
 
 class _HostCopy:
@@ -113,6 +129,22 @@ class _GeoErrors(dict):
     angular errors (None when they were copied at once)."""
 
     host_metrics = None
+    _LAZY_KEYS = ("R_angle_error_mean", "t_angle_error_mean", "R_angle_error_list", "t_angle_error_list",
+                  "R_angle_error_layers_list", "t_angle_error_layers_list")
+
+    def realise(self):
+        """Replace every lazy value by the reference's own type (python float / numpy array / list of numpy arrays), read from
+        the device buffer as it is now: one device-to-host copy.  Returns self.  A capturing caller runs this after a replay
+        (host_metrics.refresh() first) when it wants to log or pickle the dict."""
+        for k in self._LAZY_KEYS:
+            v = self[k]
+            if isinstance(v, list):
+                self[k] = [np.asarray(x._v()) if isinstance(x, _Lazy) else x for x in v]
+            elif isinstance(v, _LazyScalar):
+                self[k] = float(v._v())
+            elif isinstance(v, _Lazy):
+                self[k] = np.asarray(v._v())
+        return self
 
 
 _dense_T_cache = {}
@@ -195,6 +227,12 @@ def get_all_loss_DeepF(outs, pts1_virt_ori, pts2_virt_ori, Ks, loss_params, get_
     loss_layers = list(m_loss.unbind(0))  # losses.mean() per layer (:343-354)
     loss_F_all = o_loss                   # sum(loss_layers) / len(loss_layers) (:364)
     E_ests_layers = list(ops.unstack_rows(E_layers))
+    if _last_tail:
+        # get_Rt_loss takes the fused launch's errors only for THESE row objects (not for detached copies or rows rebuilt over the
+        # same memory: those must not inherit a graph to F); and when the rows die unconsumed the entry -- which holds the step's
+        # autograd graph -- goes with them instead of waiting for the next call
+        _last_tail["rows"] = [weakref.ref(r) for r in E_ests_layers]
+        weakref.finalize(E_ests_layers[0], _last_tail.clear)
     same_T = T1 is T2 or (T1.data_ptr() == T2.data_ptr() and T1.stride() == T2.stride() and T1.shape == T2.shape)
     if same_T and T1.dim() == 3:
         F_ests = ops.congruence_diff(F_est_normalized, _dense_T(T1, B))
@@ -242,6 +280,11 @@ def get_all_loss_DeepF(outs, pts1_virt_ori, pts2_virt_ori, Ks, loss_params, get_
     return losses_dict, E_ests, F_ests, logits_softmax, residual_norm_layers, residual_norm_max_layers, E_ests_layers
 
 
+def _same_rows(entry, given):
+    refs = entry.get("rows", ())
+    return len(refs) == len(given) and all(ref() is g for ref, g in zip(refs, given))
+
+
 def _same_gt(entry, given, on_device):
     """Is the ground truth handed to get_Rt_loss the one get_all_loss_DeepF's fused launch was given?  Yes when they are the very
     same objects, or device tensors over the same memory with the same layout as the (still held) ones of that launch."""
@@ -261,7 +304,8 @@ def get_Rt_loss(E_ests_layers, Ks_cpu, x1_cpu, x2_cpu, delta_Rtijs_4_4_cpu, qs_c
     clamp(stack(q_l2_error_layers_list)).mean() (Train_model_pipeline.py:580-586) costs its own three kernels and nothing
     more, forward or backward.  The angular errors (host-side numpy / floats in the reference) are copied to the host when first
     read (LAZY_HOST_METRICS), not here: no device synchronisation in the training step."""
-    E_layers = ops.stack_rows(list(E_ests_layers))  # [L,B,3,3]; the very buffer get_all_loss_DeepF filled when the rows are its own
+    E_ests_layers = list(E_ests_layers)
+    E_layers = ops.stack_rows(E_ests_layers)  # [L,B,3,3]; the very buffer get_all_loss_DeepF filled when the rows are its own
     if not E_layers.is_cuda:
         raise _lib.DfepeError("get_Rt_loss: E_ests_layers must live on the GPU")
     dev = E_layers.device
@@ -269,7 +313,7 @@ def get_Rt_loss(E_ests_layers, Ks_cpu, x1_cpu, x2_cpu, delta_Rtijs_4_4_cpu, qs_c
     delta = torch.as_tensor(delta_Rtijs_4_4_cpu).to(dev)
     lt = _state.tail
     L = E_layers.shape[0]
-    if lt and lt["E"].data_ptr() == E_layers.data_ptr() and lt["E"].shape == E_layers.shape and _same_gt(lt, (qs_cam, ts_cam, delta_Rtijs_4_4_cpu), (q_gt, t_gt, delta)):
+    if lt and _same_rows(lt, E_ests_layers) and _same_gt(lt, (qs_cam, ts_cam, delta_Rtijs_4_4_cpu), (q_gt, t_gt, delta)):
         q_l2, t_l2, ang, m_q, o_q, m_t, o_t = (lt[k] for k in ("q_l2", "t_l2", "ang", "m_q", "o_q", "m_t", "o_t"))  # get_all_loss_DeepF's launches
         _state.tail = {}  # consumed: do not keep the step's graph alive until the next call
     else:
@@ -283,8 +327,8 @@ def get_Rt_loss(E_ests_layers, Ks_cpu, x1_cpu, x2_cpu, delta_Rtijs_4_4_cpu, qs_c
     t_layers = [_Lazy(lambda i=i: host.get()[1, i]) for i in range(L)]
     R_list = _Lazy(lambda: np.array([float(host.get()[0, i].mean()) for i in range(L)]))
     tA_list = _Lazy(lambda: np.array([float(host.get()[1, i].mean()) for i in range(L)]))
-    R_mean = _Lazy(lambda: mean_list([float(host.get()[0, i].mean()) for i in range(L)]))
-    tA_mean = _Lazy(lambda: mean_list([float(host.get()[1, i].mean()) for i in range(L)]))
+    R_mean = _LazyScalar(lambda: mean_list([float(host.get()[0, i].mean()) for i in range(L)]))
+    tA_mean = _LazyScalar(lambda: mean_list([float(host.get()[1, i].mean()) for i in range(L)]))
     out = _GeoErrors({
         "t_l2_error_mean": o_t,      # mean_list of the per-layer means (:272-273)
         "q_l2_error_mean": o_q,
@@ -299,15 +343,9 @@ def get_Rt_loss(E_ests_layers, Ks_cpu, x1_cpu, x2_cpu, delta_Rtijs_4_4_cpu, qs_c
         "t_l2_error_layers_list": t_l2_layers,
         "q_l2_error_layers_list": q_l2_layers,
     })
+    out.host_metrics = host  # .refresh() after a graph replay rewrote the device buffer
     if not LAZY_HOST_METRICS and not torch.cuda.is_current_stream_capturing():
-        for k in ("R_angle_error_mean", "t_angle_error_mean"):
-            out[k] = float(out[k]._v())
-        for k in ("R_angle_error_list", "t_angle_error_list"):
-            out[k] = np.asarray(out[k]._v())
-        for k in ("R_angle_error_layers_list", "t_angle_error_layers_list"):
-            out[k] = [np.asarray(x._v()) for x in out[k]]
-    else:
-        out.host_metrics = host  # .refresh() after a graph replay rewrote the device buffer
+        out.realise()
     return out
 
 
@@ -315,14 +353,14 @@ _warned_opencv = False
 
 
 def val_rt(idx, K_np, x1_single_np, x2_single_np, E_est_np, E_gt_np, F_est_np, F_gt_np, delta_Rtijs_4_4_cpu_np, five_point,
-           if_opencv=False):
+           if_opencv=True):
     """Same call and same 9-tuple as the reference's per-pair validation worker (train_good_utils.py:553-646):
     (error_Rt_estW, epi_dist_mean_estW, error_Rt_opencv, epi_dist_mean_opencv, error_Rt_gt, epi_dist_mean_gt, idx, M_estW, M_opencv).
     The estimated-E and ground-truth-E legs go through utils_F.goodCorr_eval_nondecompose (the cheirality kernel in place of
     cv2.recoverPose) and utils_F.epi_distance_np.  The OpenCV five-point / eight-point RANSAC baseline (``if_opencv``,
     utils_opencv.recover_camera_opencv) is outside this build (OpenCV baselines): its three slots are None.
-    ``if_opencv`` defaults to False here (the reference's default is True): a caller that asks for the OpenCV leg gets one
-    warning saying that its slots stay None, instead of an unrelated TypeError when it indexes them later.
+    ``if_opencv`` keeps the reference's default (True); a caller that asks for the OpenCV leg -- explicitly or by that default --
+    gets one warning saying that its slots stay None, instead of an unrelated TypeError when it indexes them later.
     One pair per call like the reference; val_rt_batch / validation_summary below are the batched forms."""
     from . import utils_F
 

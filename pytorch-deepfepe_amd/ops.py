@@ -83,10 +83,17 @@ class _StackRowsFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)  # an unused stack must not send rows of zeros back (a zero-fill, and kernels that then
         ctx.n = len(rows)                 # run their gradient paths for nothing)
         a = alias_rows(rows)
-        return torch.stack(rows) if a is None else a
+        if a is None:
+            return torch.stack(rows)
+        # the result is a tensor of its own over the rows' memory, so autograd's version counters of the rows do not cover it.
+        # The rows are therefore saved: an in-place write to any of them between here and the backward makes the saved-tensor
+        # check below raise ("modified by an inplace operation") instead of silently corrupting what a kernel saved of the stack
+        ctx.save_for_backward(*rows)
+        return a
 
     @staticmethod
     def backward(ctx, g):
+        ctx.saved_tensors  # the version check of every aliased row (no-op when the rows were copied)
         return (None,) * ctx.n if g is None else tuple(g.unbind(0))
 
 
@@ -96,7 +103,10 @@ class _UnstackRowsFunction(torch.autograd.Function):
         ctx.meta = (x.shape, x.dtype, x.device)
         ctx.set_materialize_grads(False)
         x = x if x.is_contiguous() else x.contiguous()
-        return tuple(row_of(x, l) for l in range(x.shape[0]))
+        # real views of x: they share x's version counter, and autograd forbids in-place writes to the outputs of a function that
+        # returns several views ("...is a view and is being modified inplace"), so a caller cannot silently overwrite a row of a
+        # stack that some kernel saved for its backward.  Their grad_fn is still THIS node (no SelectBackward per row).
+        return tuple(x[l] for l in range(x.shape[0]))
 
     @staticmethod
     def backward(ctx, *gs):
@@ -116,7 +126,8 @@ def stack_rows(rows) -> Tensor:
 
 
 def unstack_rows(x: Tensor):
-    """The rows of x [L, ...] as a tuple of L tensors over x's memory, each an autograd output of its own."""
+    """The rows of x [L, ...] as a tuple of L views of x, each an autograd output of its own (and, like the outputs of
+    torch.unbind, not writable in place while gradients are tracked)."""
     return _UnstackRowsFunction.apply(x)
 
 

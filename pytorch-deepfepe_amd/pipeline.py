@@ -147,6 +147,13 @@ class _HotPathFunction(torch.autograd.Function):
                         fn(packed)
                     ctx.join_stream = side
                     ctx.keep = (ws, packed, scalars)  # used on the side stream: alive until the join
+                    if not torch.cuda.is_current_stream_capturing():
+                        # should the backward (= the join) never run -- loss discarded, an exception in between -- ctx dies and
+                        # the caching allocator must not hand these blocks out again on the main stream while the head or the
+                        # collective still uses them on the side stream.  (Inside a capture the graph's pool owns the memory, and
+                        # a forward captured without its backward leaves the fork unjoined: the capture fails loudly.)
+                        for t in ctx.keep:
+                            t.record_stream(side)
                 elif exchange is not None and will_backward:  # in stream order behind the last backward fit (the head may ride in the first)
                     ctx.exchange_after = (exchange[0], packed)
                 elif exchange is not None:  # forward only: head already ran in this stream (defer = 0); exchange in stream order

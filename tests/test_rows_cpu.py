@@ -98,10 +98,61 @@ def test_lazy_host_metrics_behave_like_the_references_numpy_values(dfepe):
     assert np.stack([x, x]).shape == (2, 3) and len(x) == 3 and list(x) == [0.02, 3.0, 0.7] and x.mean() == pytest.approx(1.24)
     np.testing.assert_array_equal(x * 2, [0.04, 6.0, 1.4])
     np.testing.assert_array_equal(2 * x, [0.04, 6.0, 1.4])
-    m = tgu._Lazy(lambda: 1.5)
+    m = tgu._LazyScalar(lambda: 1.5)
     assert float(m) == 1.5 and np.isscalar(m) and "%.2f" % m == "1.50" and f"{m:.1f}" == "1.5" and m + 1 == 2.5 and m < 2
     np.testing.assert_array_equal(np.array([m]), [1.5])
     assert calls["n"] > 0
+    assert not np.isscalar(x)  # only the scalar lazies count as numbers.Real
+    # pickle / torch.save / deepcopy store the realised value, not the closure
+    import copy
+    import io
+    import pickle
+
+    back = pickle.loads(pickle.dumps({"a": x, "m": m}))
+    assert isinstance(back["a"], np.ndarray) and isinstance(back["m"], float) and back["m"] == 1.5
+    np.testing.assert_array_equal(back["a"], [0.02, 3.0, 0.7])
+    bio = io.BytesIO()
+    torch.save({"a": x}, bio)
+    assert isinstance(copy.deepcopy(m), float)
+    # the dict of get_Rt_loss: reference types by default (LAZY_HOST_METRICS is off), realise() converts a lazy dict in place
+    assert tgu.LAZY_HOST_METRICS is False
+    geo = tgu._GeoErrors({"R_angle_error_mean": m, "t_angle_error_mean": m, "R_angle_error_list": x, "t_angle_error_list": x,
+                          "R_angle_error_layers_list": [x, x], "t_angle_error_layers_list": [x], "q_l2_error_mean": torch.zeros(())})
+    geo.realise()
+    assert type(geo["R_angle_error_mean"]) is float and type(geo["R_angle_error_list"]) is np.ndarray
+    assert all(type(a) is np.ndarray for a in geo["R_angle_error_layers_list"]) and torch.is_tensor(geo["q_l2_error_mean"])
+    pickle.dumps(dict(geo))
+
+
+def test_in_place_writes_to_aliased_rows_raise_instead_of_corrupting_saved_stacks(dfepe):
+    """the per-layer rows and the [L, ...] stacks share memory.  A caller's in-place write to a row must not
+    silently change what a kernel saved of the stack: rows handed out by unstack_rows are real autograd views (the write itself
+    raises, like on the outputs of torch.unbind), and a stack re-assembled from rows checks the rows' version counters in its
+    backward."""
+    ops = dfepe.ops
+    x = torch.randn(3, 4, requires_grad=True)
+    rows = ops.unstack_rows(x * 2.0)
+    assert all(r._is_view() for r in rows)
+    with pytest.raises(RuntimeError, match="modified inplace|in-place"):
+        rows[1].mul_(2.0)
+    # without gradient tracking the rows are plain views and writable (a no-grad evaluation loop may normalise in place)
+    with torch.no_grad():
+        free = ops.unstack_rows(torch.ones(2, 3))
+        free[0].mul_(3.0)
+    # rows written by producers into one buffer, re-assembled without a copy, saved by a consumer, then overwritten by the caller
+    buf = torch.zeros(3, 4)
+    prods = []
+    for l in range(3):
+        r = ops.row_of(buf, l)
+        r.copy_(torch.full((4,), float(l)))
+        prods.append(r.requires_grad_())
+    S = ops.stack_rows(prods)
+    assert S.data_ptr() == buf.data_ptr()
+    loss = (S * S).sum()  # MulBackward saves S, the alias
+    with torch.no_grad():
+        prods[2].add_(1.0)  # the caller "post-processes" a layer's output in place
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        loss.backward()
 
 
 def test_no_kernel_of_the_library_uses_scratch_memory():
