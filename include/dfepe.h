@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFEPE_VERSION 141 /* 0.4.0 */
+#define DFEPE_VERSION 150 /* 0.5.0 */
 
 #define DFEPE_OK 0
 #define DFEPE_ERR_INVALID_ARG (-1) /* null pointer, non-positive size, bad flag combination   */
@@ -273,6 +273,11 @@ int dfepe_loss_stats(const float *x0, int rows0, float scale0, const float *x1, 
  */
 int dfepe_cheirality(const float *E, const float *pre, const float *K, const float *matches, int B, int N, float depth_thres,
                      float *Rt_cam, int *winner, int *counts, void *stream);
+/* The same with flags.  DFEPE_CHEIR_FP64_ONLY: every correspondence takes the fp64 route (no packed-fp32 decisions): the build the
+ * adaptive default is tested against for EXACT equality of the counts (tests/test_fullsize_gpu.py), and its upper bound in time. */
+#define DFEPE_CHEIR_FP64_ONLY 1u
+int dfepe_cheirality_ex(const float *E, const float *pre, const float *K, const float *matches, int B, int N, float depth_thres,
+                        unsigned flags, float *Rt_cam, int *winner, int *counts, void *stream);
 
 /*
  * Fit + E-from-F + cheirality-checked pose in one call (BASELINE config 5: one weighted 8-point fit, then the pose of its F).

@@ -24,6 +24,7 @@ W8PT_ROW_PER_PAIR = 64
 W8PT16_MAX_N = 128
 TAIL_MAX_LAYERS = 16  # dfepe_loss_tail: layers per launch (kTailMaxLayers, csrc/loss_tail_body.h)
 EPI_HOMOGENEOUS = 8
+CHEIR_FP64_ONLY = 1
 
 _P = c_void_p
 _SIGNATURES = {
@@ -50,6 +51,7 @@ _SIGNATURES = {
     "dfepe_deepf_input": (c_int, [_P, _P, c_int, c_int, c_int, c_float, c_float, _P, c_size_t, c_size_t, c_int, c_size_t, _P, _P, _P]),
     "dfepe_row_dot": (c_int, [_P, c_size_t, _P, c_size_t, c_int, c_int, c_int, _P, _P]),
     "dfepe_cheirality": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, _P, _P, _P, _P]),
+    "dfepe_cheirality_ex": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_uint, _P, _P, _P, _P]),
     "dfepe_w8pt_pose_fwd": (c_int, [_P, _P, c_int, c_int, c_uint, c_float, c_float, c_float, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dfepe_metrics_summary_bytes": (c_size_t, []),
     "dfepe_metrics_summary": (c_int, [_P, _P, c_size_t, _P, _P, c_int, _P, _P]),

@@ -2,6 +2,8 @@
 // deepFEPE/dsac_tools/utils_F.py:679-763; candidates of utils_F._get_M2s :478-498).  Shared by the stand-alone kernel (geom.hip)
 // and the fused fit + E-from-F + pose kernel of the cooperative fit (w8pt16.hip).
 #pragma once
+#include <type_traits>
+
 #include "dfepe_common.h"
 
 // internal linkage on purpose: with external (inline) linkage hipcc keeps decompose_E / svd3_closed as real calls, which drags
@@ -49,25 +51,46 @@ __device__ __forceinline__ double guard_piv(double z, double tiny) { return (fab
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef int i2 __attribute__((ext_vector_type(2)));
+// the stage-1 eigenvector routine is written once for a value type V = f2 (two matrices at once, v_pk_*_f32) or float (one matrix:
+// the fp64 route, which handles one rotation candidate at a time to stay inside 128 registers); M = its comparison-mask type
 __device__ __forceinline__ f2 f2s(float v) { return f2{v, v}; }
+template <class V> __device__ __forceinline__ V vsplat(float v);
+template <> __device__ __forceinline__ f2 vsplat<f2>(float v) { return f2{v, v}; }
+template <> __device__ __forceinline__ float vsplat<float>(float v) { return v; }
+__device__ __forceinline__ i2 m_lt(f2 a, f2 b) { return a < b; }
+__device__ __forceinline__ i2 m_gt(f2 a, f2 b) { return a > b; }
+__device__ __forceinline__ i2 m_eq(f2 a, f2 b) { return a == b; }
+__device__ __forceinline__ int m_lt(float a, float b) { return (a < b) ? -1 : 0; }
+__device__ __forceinline__ int m_gt(float a, float b) { return (a > b) ? -1 : 0; }
+__device__ __forceinline__ int m_eq(float a, float b) { return (a == b) ? -1 : 0; }
+__device__ __forceinline__ bool m_all(i2 m) { return m.x && m.y; }
+__device__ __forceinline__ bool m_all(int m) { return m != 0; }
 __device__ __forceinline__ f2 pk_sel(i2 m, f2 a, f2 b) { return m ? a : b; }
+__device__ __forceinline__ float pk_sel(int m, float a, float b) { return m ? a : b; }
 __device__ __forceinline__ f2 pk_abs(f2 a) { return __builtin_elementwise_abs(a); }
+__device__ __forceinline__ float pk_abs(float a) { return fabsf(a); }
 __device__ __forceinline__ f2 pk_max(f2 a, f2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ float pk_max(float a, float b) { return fmaxf(a, b); }
 __device__ __forceinline__ f2 pk_sqrt(f2 a) { return f2{hw_sqrt(a.x), hw_sqrt(a.y)}; }
+__device__ __forceinline__ float pk_sqrt(float a) { return hw_sqrt(a); }
 __device__ __forceinline__ f2 pk_rcp(f2 a) { return f2{hw_rcp(a.x), hw_rcp(a.y)}; }
+__device__ __forceinline__ float pk_rcp(float a) { return hw_rcp(a); }
 
 // gapprod (optional): |d det(T - lam I) / d lam| at the returned eigenvalue = (lam1 - lam4)(lam2 - lam4)(lam3 - lam4) for a unit-trace
 // matrix: the quantity that bounds the error of x (see cheirality_pair: the fp32 stage decides a correspondence on its own only
 // where that bound leaves its depth tests unambiguous).
+template <class f2>  // f2 (packed pair) or float: see the helpers above
 __device__ inline void smallest_eigvec4_pk(const f2* S /*4x4 row-major, symmetric, unit trace*/, f2* x, f2* gapprod = nullptr) {
+  typedef decltype(m_lt(f2{}, f2{})) i2;
+  auto f2s = [](float v) { return vsplat<f2>(v); };
   const f2 zero = f2s(0.0f), two = f2s(2.0f);
   // ---- Householder 1 on (S10, S20, S30)
   const f2 a0 = S[4], a1 = S[8], a2 = S[12];
   const f2 n1 = pk_sqrt(a0 * a0 + a1 * a1 + a2 * a2);
-  const f2 alpha = pk_sel(a0 < zero, n1, -n1);
+  const f2 alpha = pk_sel(m_lt(a0, zero), n1, -n1);
   const f2 v0 = a0 - alpha, v1 = a1, v2 = a2;
   const f2 vv = v0 * v0 + v1 * v1 + v2 * v2;
-  const i2 ok1 = vv > zero;
+  const i2 ok1 = m_gt(vv, zero);
   const f2 beta = pk_sel(ok1, two * pk_rcp(pk_max(vv, f2s(1e-30f))), zero);
   const f2 p0 = beta * (S[5] * v0 + S[6] * v1 + S[7] * v2);
   const f2 p1 = beta * (S[6] * v0 + S[10] * v1 + S[11] * v2);
@@ -79,10 +102,10 @@ __device__ inline void smallest_eigvec4_pk(const f2* S /*4x4 row-major, symmetri
   const f2 B11 = S[10] - two * v1 * q1, B12 = S[11] - v1 * q2 - q1 * v2, B22 = S[15] - two * v2 * q2;
   // ---- Householder 2 on (B10, B20)
   const f2 n2 = pk_sqrt(B01 * B01 + B02 * B02);
-  const f2 alpha2 = pk_sel(B01 < zero, n2, -n2);
+  const f2 alpha2 = pk_sel(m_lt(B01, zero), n2, -n2);
   const f2 w0 = B01 - alpha2, w1 = B02;
   const f2 ww = w0 * w0 + w1 * w1;
-  const i2 ok2 = ww > zero;
+  const i2 ok2 = m_gt(ww, zero);
   const f2 beta2 = pk_sel(ok2, two * pk_rcp(pk_max(ww, f2s(1e-30f))), zero);
   const f2 r0 = beta2 * (B11 * w0 + B12 * w1), r1 = beta2 * (B12 * w0 + B22 * w1);
   const f2 k2 = f2s(0.5f) * beta2 * (r0 * w0 + r1 * w1);
@@ -94,23 +117,23 @@ __device__ inline void smallest_eigvec4_pk(const f2* S /*4x4 row-major, symmetri
   // ---- Laguerre from below (all roots are >= 0: the start lam = 0 is left of, or on, the smallest one); a step below the
   // fp32 resolution of the spectrum ends the iteration
   f2 lam = zero;
-  i2 done = i2{0, 0};
+  i2 done = m_lt(zero, zero);  // all false
   const f2 stop = f2s(1e-7f) * scale;
   for (int it = 0; it < 10; ++it) {
     const f2 c0 = d0 - lam, c1 = d1 - lam, c2 = d2 - lam, c3 = d3 - lam;
     const f2 P2 = c1 * c0 - f0, D2 = -c1 - c0;
     const f2 P3 = c2 * P2 - f1 * c0, D3 = c2 * D2 - P2 + f1, E3 = two * c2 - two * D2;
     const f2 P4 = c3 * P3 - f2_ * P2, D4 = c3 * D3 - P3 - f2_ * D2, E4 = c3 * E3 - two * D3 - two * f2_;
-    const i2 good = (P4 > zero) & ~done;
+    const i2 good = m_gt(P4, zero) & ~done;
     const f2 ip = pk_sel(good, pk_rcp(pk_max(P4, f2s(1e-37f))), zero);
     const f2 G = D4 * ip, H = G * G - E4 * ip;
     const f2 den = G - pk_sqrt(pk_max(f2s(3.0f) * (f2s(4.0f) * H - G * G), zero));
-    const i2 stepok = good & (den < zero);
+    const i2 stepok = good & m_lt(den, zero);
     const f2 step = pk_sel(stepok, f2s(-4.0f) * pk_rcp(pk_sel(stepok, den, f2s(-1.0f))), zero);
     const f2 nl = lam + step;
-    done = done | ~good | ~(step > stop) | (nl == lam);
+    done = done | ~good | ~m_gt(step, stop) | m_eq(nl, lam);
     lam = pk_sel(done, lam, nl);
-    if (__ballot(!(done.x && done.y)) == 0ull) break;  // wave-uniform exit
+    if (__ballot(!m_all(done)) == 0ull) break;  // wave-uniform exit
   }
   // ---- null vector of T - lam: the adjugate column with the largest diagonal cofactor
   const f2 c0 = d0 - lam, c1 = d1 - lam, c2 = d2 - lam, c3 = d3 - lam;
@@ -121,11 +144,11 @@ __device__ inline void smallest_eigvec4_pk(const f2* S /*4x4 row-major, symmetri
   }
   const f2 Q3 = c3, Q2 = c2 * c3 - f2_, Q1 = c1 * Q2 - f1 * Q3;
   const f2 g0 = pk_abs(Q1), g1 = pk_abs(P1 * Q2), g2 = pk_abs(P2 * Q3), g3 = pk_abs(P3);
-  const i2 b1 = g1 > g0;                  // best of (0, 1)
+  const i2 b1 = m_gt(g1, g0);               // best of (0, 1)
   const f2 g01 = pk_sel(b1, g1, g0);
-  const i2 b3 = g3 > g2;                  // best of (2, 3)
+  const i2 b3 = m_gt(g3, g2);               // best of (2, 3)
   const f2 g23 = pk_sel(b3, g3, g2);
-  const i2 hi = g23 > g01;                // r in {2, 3} else {0, 1}; ties keep the lower index
+  const i2 hi = m_gt(g23, g01);               // r in {2, 3} else {0, 1}; ties keep the lower index
   const f2 e01 = e0 * e1, e12 = e1 * e2, e012 = e01 * e2;
   // columns r = 0..3 of the adjugate
   const f2 y0 = pk_sel(hi, pk_sel(b3, -e012, e01 * Q3), pk_sel(b1, -e0 * Q2, Q1));
@@ -173,6 +196,7 @@ __device__ inline void rqi_refine4(const double* S, const double* x0, double* y)
 
 constexpr int kCheirQueue = 128;  // ints of LDS per wavefront: indices of the correspondences waiting for the fp64 route (< 64 + 64)
 struct CheirLds {
+  double pose[21];  // R1, R2, t of the pair: parked here during the correspondence loop, which needs only their third rows
   int wcnt[8][4];
   int queue[8 * kCheirQueue];
 };
@@ -180,10 +204,15 @@ struct CheirLds {
 // One workgroup per pair (every thread of the workgroup must call; W = blockDim.x / 64 wavefronts each take every W-th group of 64
 // correspondences and meet in `wcnt`, LDS owned by the caller).  E9: the matrix to decompose (or F when `pre` is given: then
 // pre^T E9 pre is decomposed), identical in every thread.
+// FP64_ONLY: every correspondence through the fp64 route (DFEPE_CHEIR_FP64_ONLY: the reference build the adaptive one is tested
+// against for exact equality of the counts; also its upper bound in time).
+template <bool FP64_ONLY = false>
 __device__ __forceinline__ void cheirality_pair(const float* E9, const float* __restrict__ pre, const float* __restrict__ K,
                                                 const float* __restrict__ matches, const size_t pair, const int N, const float depth_thres,
                                                 float* __restrict__ Rt_cam, int* __restrict__ winner, int* __restrict__ counts,
-                                                int (*wcnt)[4], int* queue) {
+                                                CheirLds& cl) {
+  int (*wcnt)[4] = cl.wcnt;
+  int* queue = cl.queue;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
   double Ed[9], Kd[9], R[2][9], t[3];
@@ -204,8 +233,19 @@ __device__ __forceinline__ void cheirality_pair(const float* E9, const float* __
   for (int k = 0; k < 9; ++k) { R[0][k] = to_sgpr(R[0][k]); R[1][k] = to_sgpr(R[1][k]); }
 #pragma unroll
   for (int k = 0; k < 3; ++k) t[k] = to_sgpr(t[k]);
-  // the two candidate projection matrices K [R | t], formed once per pair (measured: parking them in scalar registers and
-  // capping the kernel at 128 VGPRs for four wavefronts per SIMD is slower -- SGPR spills and constant-bus moves in the loop)
+  // scalar-register budget of the loop: K (18), the two projection matrices (48), the third rows of R1 / R2 and t_z (14); the
+  // rest of the decomposition is only needed for the winner's output and waits in LDS (every wavefront holds the same values)
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { cl.pose[k] = R[0][k]; cl.pose[9 + k] = R[1][k]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cl.pose[18 + k] = t[k];
+  }
+  const double Rz[2][3] = {{R[0][6], R[0][7], R[0][8]}, {R[1][6], R[1][7], R[1][8]}};
+  const double tz = t[2];
+  // the two candidate projection matrices K [R | t], formed once per pair and parked in scalar registers (48 SGPRs) since round 5:
+  // with them out of the vector file the packed-fp32 body needs < 128 VGPRs, i.e. FOUR wavefronts per SIMD (round 2 measured the
+  // same parking as slower -- but with the all-fp64 body of that round, which then spilled)
   double P2s[2][12];
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr)
@@ -213,8 +253,8 @@ __device__ __forceinline__ void cheirality_pair(const float* E9, const float* __
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
       for (int c = 0; c < 3; ++c)
-        P2s[rr][4 * r + c] = Kd[3 * r] * R[rr][c] + Kd[3 * r + 1] * R[rr][3 + c] + Kd[3 * r + 2] * R[rr][6 + c];
-      P2s[rr][4 * r + 3] = Kd[3 * r] * t[0] + Kd[3 * r + 1] * t[1] + Kd[3 * r + 2] * t[2];
+        P2s[rr][4 * r + c] = to_sgpr(Kd[3 * r] * R[rr][c] + Kd[3 * r + 1] * R[rr][3 + c] + Kd[3 * r + 2] * R[rr][6 + c]);
+      P2s[rr][4 * r + 3] = to_sgpr(Kd[3 * r] * t[0] + Kd[3 * r + 1] * t[1] + Kd[3 * r + 2] * t[2]);
     }
   int cnt[4] = {0, 0, 0, 0};
   const int nw = blockDim.x >> 6;  // 4 wavefronts per pair for small batches (latency), 1 for large ones (throughput)
@@ -238,46 +278,44 @@ __device__ __forceinline__ void cheirality_pair(const float* E9, const float* __
   // candidates in fp64, scaled to unit trace (the null vector does not care; the Newton seeds and the fp32 stage want O(1) operands
   // whatever the pixel scale), both smallest eigenvectors to fp32 accuracy (packed), ONE Rayleigh-quotient iteration in fp64 each
   // (cubic convergence: <= 1e-9 from the fp32 vector's 2e-7 median / 1e-4 tail error), division-free depth tests.
+  // Round 5: ONE candidate at a time (the packed stage-1 routine instantiated for plain floats), the second candidate's
+  // instructions fenced behind the first's, so that the route's working set -- one fp64 normal matrix, not two -- fits the 128
+  // registers of the fast path around it.
   auto dlt_fp64 = [&](const float4& m, const bool live) {
-    double A1[6];
-    rows1(m, A1);
-    double S1[6];  // view-1 contribution to the upper-left 3x3 of A^T A: (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
-    S1[0] = A1[0] * A1[0] + A1[3] * A1[3]; S1[1] = A1[0] * A1[1] + A1[3] * A1[4]; S1[2] = A1[0] * A1[2] + A1[3] * A1[5];
-    S1[3] = A1[1] * A1[1] + A1[4] * A1[4]; S1[4] = A1[1] * A1[2] + A1[4] * A1[5]; S1[5] = A1[2] * A1[2] + A1[5] * A1[5];
-    double S[2][16];
+    auto candidate = [&](auto rc) {
+      constexpr int rr = decltype(rc)::value;
+      double Sr[16];
+      {
+        double A1[6], A2[8];
+        rows1(m, A1);
+        rows2(m, rr, A2);
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      double A2[8];
-      rows2(m, rr, A2);
-      double* Sr = S[rr];
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = r; c < 4; ++c) Sr[4 * r + c] = A2[r] * A2[c] + A2[4 + r] * A2[4 + c];
-      Sr[0] += S1[0]; Sr[1] += S1[1]; Sr[2] += S1[2]; Sr[5] += S1[3]; Sr[6] += S1[4]; Sr[10] += S1[5];
+          for (int c = r; c < 4; ++c) Sr[4 * r + c] = A2[r] * A2[c] + A2[4 + r] * A2[4 + c];
+        // view-1 contribution to the upper-left 3x3 of A^T A (its rows have no 4th column)
+        Sr[0] += A1[0] * A1[0] + A1[3] * A1[3]; Sr[1] += A1[0] * A1[1] + A1[3] * A1[4]; Sr[2] += A1[0] * A1[2] + A1[3] * A1[5];
+        Sr[5] += A1[1] * A1[1] + A1[4] * A1[4]; Sr[6] += A1[1] * A1[2] + A1[4] * A1[5]; Sr[10] += A1[2] * A1[2] + A1[5] * A1[5];
+      }
       const double itr = rcp_nr<1>(fmax(Sr[0] + Sr[5] + Sr[10] + Sr[15], 1e-30));
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = r; c < 4; ++c) Sr[4 * r + c] *= itr;
-    }
-    f2 Sp[16], Xp[4];
+      float Sf[16], Xf[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int c = r; c < 4; ++c) { Sp[4 * r + c] = f2{(float)S[0][4 * r + c], (float)S[1][4 * r + c]}; Sp[4 * c + r] = Sp[4 * r + c]; }
-    smallest_eigvec4_pk(Sp, Xp);
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const double* Rc = R[rr];
-      const double x0[4] = {(double)Xp[0][rr], (double)Xp[1][rr], (double)Xp[2][rr], (double)Xp[3][rr]};
+        for (int c = r; c < 4; ++c) { Sf[4 * r + c] = (float)Sr[4 * r + c]; Sf[4 * c + r] = Sf[4 * r + c]; }
+      smallest_eigvec4_pk<float>(Sf, Xf);
+      const double x0[4] = {(double)Xf[0], (double)Xf[1], (double)Xf[2], (double)Xf[3]};
       double X[4];
-      rqi_refine4(S[rr], x0, X);
+      rqi_refine4(Sr, x0, X);
       // depths z1 = X2 / X3 and z2 = (R_3 . X_012 + t_3 X3) / X3 tested without the division: 0 < z < thr  <=>  z' w > 0 and
       // |z'| < thr |w| for z = z' / w
       const double wq = X[3];
       const double z1n = X[2];
-      const double z2n = Rc[6] * X[0] + Rc[7] * X[1] + Rc[8] * X[2] + t[2] * wq;
+      const double z2n = Rz[rr][0] * X[0] + Rz[rr][1] * X[1] + Rz[rr][2] * X[2] + tz * wq;
       const double thr = (double)depth_thres;
       const double aw = thr * fabs(wq);
       const bool inr = live && (fabs(z1n) < aw) && (fabs(z2n) < aw) && (wq != 0.0);
@@ -287,7 +325,10 @@ __device__ __forceinline__ void cheirality_pair(const float* E9, const float* __
       const bool neg = inr && nz && !s1p && !s2p;  // both in (-thr, 0): the (R, -t) candidate sees them in (0, thr)
       cnt[2 * rr] += __popcll(__ballot(pos));
       cnt[2 * rr + 1] += __popcll(__ballot(neg));
-    }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    candidate(std::integral_constant<int, 0>{});
+    candidate(std::integral_constant<int, 1>{});
   };
   // ---- ROUND 4: the fp32 stage decides on its own wherever it safely can.  Every correspondence goes through the FAST PATH -- the
   // whole eigenproblem of both candidates in packed fp32: normal matrices from the fp32-rounded rows, stage 1 -- and the depth
@@ -308,6 +349,10 @@ __device__ __forceinline__ void cheirality_pair(const float* E9, const float* __
     const bool live = i < N;
     const float4 m = mnext;
     mnext = mrow[min(i + nw * WAVE, N - 1)];
+    if constexpr (FP64_ONLY) {
+      dlt_fp64(m, live);
+      continue;
+    }
     f2 Xp[4];
     bool amb_lane = false;
     bool pos_f[2], neg_f[2];
@@ -348,7 +393,7 @@ __device__ __forceinline__ void cheirality_pair(const float* E9, const float* __
         const float X0 = Xp[0][rr], X1 = Xp[1][rr], X2 = Xp[2][rr], X3 = Xp[3][rr];
         const float nrm = hw_sqrt(X0 * X0 + X1 * X1 + X2 * X2 + X3 * X3);
         // R and t live in scalar registers as doubles: used as they are (fp32 copies would be loop-invariant VECTOR registers)
-        const float z2n = (float)(R[rr][6] * (double)X0 + R[rr][7] * (double)X1 + R[rr][8] * (double)X2 + t[2] * (double)X3);
+        const float z2n = (float)(Rz[rr][0] * (double)X0 + Rz[rr][1] * (double)X1 + Rz[rr][2] * (double)X2 + tz * (double)X3);
         const float aw = thrf * fabsf(X3);
         const float g = gp[rr];
         const float dl = fmaxf(3.2e-7f * hw_rcp(fmaxf(g, 1e-30f)), 1e-6f) * nrm;
@@ -364,10 +409,8 @@ __device__ __forceinline__ void cheirality_pair(const float* E9, const float* __
         neg_f[rr] = inr & !s1p & !s2p;    // both in (-thr, 0): the (R, -t) candidate sees them in (0, thr)
       }
     }
-#if defined(DFEPE_CHEIR_ALWAYS_FAST)   // A/B timing builds only (scripts/ab_cheirality.sh): lower / upper bound of the adaptive kernel
-    amb_lane = false;
-#elif defined(DFEPE_CHEIR_ALWAYS_SLOW)
-    amb_lane = live;
+#if defined(DFEPE_CHEIR_ALWAYS_FAST)   // A/B timing builds only (scripts/ab_cheirality.sh): the lower bound of the adaptive kernel
+    amb_lane = false;                  // (its upper bound is the FP64_ONLY instantiation, DFEPE_CHEIR_FP64_ONLY at run time)
 #endif
     const unsigned long long amask = __ballot(amb_lane);
     // a lane that is safe for BOTH candidates counts now; an ambiguous lane counts nothing here (both candidates again in fp64)
@@ -424,16 +467,18 @@ __device__ __forceinline__ void cheirality_pair(const float* E9, const float* __
     }
     if (winner != nullptr) winner[pair] = (best > 0) ? win : -1;
     // camera motion = inverse of [R|t]: [R^T | -R^T t]   (utils_misc._inv_Rt, utils_misc.py:115-121)
-    double Rc[9];  // selected by value: a runtime index into R would put the whole array into scratch memory
+    double Rc[9], tw[3];  // the winner's rotation and the translation, back from LDS (written before the loop, barrier above)
 #pragma unroll
-    for (int k = 0; k < 9; ++k) Rc[k] = (win >> 1) ? R[1][k] : R[0][k];
+    for (int k = 0; k < 9; ++k) Rc[k] = cl.pose[9 * (win >> 1) + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tw[k] = cl.pose[18 + k];
     const double sg = (win & 1) ? -1.0 : 1.0;
     float* dst = Rt_cam + pair * 12;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) dst[4 * r + c] = (best > 0) ? (float)Rc[3 * c + r] : 0.0f;
-      const double tc = -(Rc[r] * t[0] + Rc[3 + r] * t[1] + Rc[6 + r] * t[2]) * sg;
+      const double tc = -(Rc[r] * tw[0] + Rc[3 + r] * tw[1] + Rc[6 + r] * tw[2]) * sg;
       dst[4 * r + 3] = (best > 0) ? (float)tc : 0.0f;
     }
   }

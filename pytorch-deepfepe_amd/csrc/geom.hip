@@ -228,7 +228,11 @@ geo_misc_kernel(int kind, const float* __restrict__ in0, const float* __restrict
 // ------------------------------------------------------------------------------------------------------
 // cheirality (utils_F._E_to_M_train, utils_F.py:679-763): body in cheirality_body.h (shared with the fused fit + pose kernel)
 // ------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 3)  // three wavefronts per SIMD (<= 168 registers): the kernel is bound by VALU throughput
+// <= 128 registers = FOUR wavefronts per SIMD (round 5; rounds 2-4: 166 registers, three): the projection matrices live in scalar
+// registers and the fp64 route handles one rotation candidate at a time, so the packed-fp32 body sets the register count.  The bound
+// also admits two 8-wavefront workgroups per CU: a pair's 1000 correspondences are then two groups of 64 per wavefront, not four.
+template <bool FP64_ONLY>
+__global__ void __launch_bounds__(512, 2)
 cheirality_kernel(const float* __restrict__ E, const float* __restrict__ pre, const float* __restrict__ K,
                   const float* __restrict__ matches, int B, int N, float depth_thres, float* __restrict__ Rt_cam,
                   int* __restrict__ winner, int* __restrict__ counts) {
@@ -237,7 +241,7 @@ cheirality_kernel(const float* __restrict__ E, const float* __restrict__ pre, co
   float Ef[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) Ef[k] = E[pair * 9 + k];
-  cheirality_pair(Ef, pre, K, matches, pair, N, depth_thres, Rt_cam, winner, counts, cl.wcnt, cl.queue);
+  cheirality_pair<FP64_ONLY>(Ef, pre, K, matches, pair, N, depth_thres, Rt_cam, winner, counts, cl);
   (void)B;
 }
 
@@ -348,16 +352,25 @@ extern "C" int dfepe_geo_misc(int kind, const float* in0, const float* in1, int 
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
-extern "C" int dfepe_cheirality(const float* E, const float* pre, const float* K, const float* matches, int B, int N,
-                                float depth_thres, float* Rt_cam, int* winner, int* counts, void* stream) {
-  if (B < 0 || N <= 0) return DFEPE_ERR_INVALID_ARG;
+extern "C" int dfepe_cheirality_ex(const float* E, const float* pre, const float* K, const float* matches, int B, int N,
+                                   float depth_thres, unsigned flags, float* Rt_cam, int* winner, int* counts, void* stream) {
+  if (B < 0 || N <= 0 || (flags & ~DFEPE_CHEIR_FP64_ONLY)) return DFEPE_ERR_INVALID_ARG;
   if (B == 0) return DFEPE_OK;
   if (!E || !K || !matches || !Rt_cam) return DFEPE_ERR_INVALID_ARG;
   if (reinterpret_cast<uintptr_t>(matches) & 15u) return DFEPE_ERR_INVALID_ARG;
-  // wavefronts per pair: throughput wants one (B >= 2048: every SIMD already holds >= 2 pairs), latency wants four (eight would
-  // not help: at 170 registers a CU holds eight wavefronts either way, i.e. two 4-wavefront pairs or one 8-wavefront pair)
-  const int threads = (B >= 2048) ? 64 : 256;
-  hipLaunchKernelGGL(cheirality_kernel, dim3(B), dim3(threads), 0, static_cast<hipStream_t>(stream), E, pre, K, matches,
-                     B, N, depth_thres, Rt_cam, winner, counts);
+  // wavefronts per pair: throughput wants one (B >= 2048: every SIMD already holds >= 2 pairs), latency wants as many as the pair
+  // has groups of 64 correspondences, up to eight (at <= 128 registers a CU holds two such workgroups)
+  const int groups = (N + 63) / 64;
+  const int threads = (B >= 2048) ? 64 : 64 * (groups < 8 ? groups : 8);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (flags & DFEPE_CHEIR_FP64_ONLY)
+    hipLaunchKernelGGL(cheirality_kernel<true>, dim3(B), dim3(threads), 0, st, E, pre, K, matches, B, N, depth_thres, Rt_cam, winner, counts);
+  else
+    hipLaunchKernelGGL(cheirality_kernel<false>, dim3(B), dim3(threads), 0, st, E, pre, K, matches, B, N, depth_thres, Rt_cam, winner, counts);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+extern "C" int dfepe_cheirality(const float* E, const float* pre, const float* K, const float* matches, int B, int N,
+                                float depth_thres, float* Rt_cam, int* winner, int* counts, void* stream) {
+  return dfepe_cheirality_ex(E, pre, K, matches, B, N, depth_thres, 0u, Rt_cam, winner, counts, stream);
 }

@@ -87,7 +87,7 @@ w8pt16_coop_pose_kernel(const float* pts1, const float* pts2, const float* wts, 
   float Ef[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) Ef[k] = co.of[k];  // published by row 0 before the output phase: every thread has passed that barrier
-  cheirality_pair(Ef, P.pre, P.K, pts1, (size_t)pair, N, P.depth_thres, P.Rt_cam, P.winner, P.counts, cl.wcnt, cl.queue);
+  cheirality_pair(Ef, P.pre, P.K, pts1, (size_t)pair, N, P.depth_thres, P.Rt_cam, P.winner, P.counts, cl);
 }
 
 struct W8BwdRest {

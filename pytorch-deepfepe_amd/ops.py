@@ -841,9 +841,11 @@ def decompose_essential(E: Tensor):
     return o[:, 0:9].reshape(-1, 3, 3), o[:, 9:18].reshape(-1, 3, 3), o[:, 18:21]
 
 
-def cheirality(E: Tensor, K: Tensor, matches: Tensor, depth_thres: float = 50.0, pre: Optional[Tensor] = None):
+def cheirality(E: Tensor, K: Tensor, matches: Tensor, depth_thres: float = 50.0, pre: Optional[Tensor] = None, fp64_only: bool = False):
     """E, K [B,3,3], matches [B,N,4] pixels -> (Rt_cam [B,3,4], winner [B] int32, counts [B,4] int32).
-    ``pre`` [B,3,3]: decompose pre^T E pre instead (E = F and pre = T K fuses E-from-F into the launch)."""
+    ``pre`` [B,3,3]: decompose pre^T E pre instead (E = F and pre = T K fuses E-from-F into the launch).
+    ``fp64_only``: every correspondence through the fp64 route (DFEPE_CHEIR_FP64_ONLY: the reference the adaptive default is
+    tested against for exact equality of the counts)."""
     E, K, m = _prep(E, "E"), _prep(K, "K"), _prep(matches, "matches")
     pre = None if pre is None else _prep(pre, "pre")
     _shape(m, "matches (pixel x1,y1,x2,y2)", None, None, 4)
@@ -856,8 +858,9 @@ def cheirality(E: Tensor, K: Tensor, matches: Tensor, depth_thres: float = 50.0,
     win = torch.empty(B, device=m.device, dtype=torch.int32)
     cnt = torch.empty(B, 4, device=m.device, dtype=torch.int32)
     with torch.cuda.device(m.device):
-        rc = _lib.lib().dfepe_cheirality(_ptr(E), _ptr(pre), _ptr(K), _ptr(m), B, N, float(depth_thres), _ptr(Rt), _ptr(win), _ptr(cnt), _stream())
-    _lib.check(rc, "dfepe_cheirality")
+        rc = _lib.lib().dfepe_cheirality_ex(_ptr(E), _ptr(pre), _ptr(K), _ptr(m), B, N, float(depth_thres),
+                                            _lib.CHEIR_FP64_ONLY if fp64_only else 0, _ptr(Rt), _ptr(win), _ptr(cnt), _stream())
+    _lib.check(rc, "dfepe_cheirality_ex")
     return Rt, win, cnt
 
 

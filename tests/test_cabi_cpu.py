@@ -31,7 +31,7 @@ def test_library_builds_and_exports_every_declared_symbol(dfepe):
 
 def test_version_strerror_and_save_layout(dfepe):
     L = dfepe._lib.lib()
-    assert L.dfepe_version() == 141
+    assert L.dfepe_version() == 150
     assert L.dfepe_save_floats() == 128
     assert L.dfepe_strerror(0) == b"ok"
     assert b"invalid" in L.dfepe_strerror(-1)
