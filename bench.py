@@ -51,7 +51,7 @@ CONFIGS = {
 }
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
@@ -76,7 +76,7 @@ def parse():
                     help="auto: a plain `python bench.py --gpus N` (no RANK in the environment) with N > 1 re-executes itself under "
                          "torch.distributed.run with N ranks; torchrun: do that even for N = 1 (exercises the launch path on a 1-GPU box); "
                          "none: never re-execute")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def _free_port():
@@ -115,6 +115,28 @@ def self_launch(args):
     env.setdefault("OMP_NUM_THREADS", "8")
     log("self-launch:", " ".join(cmd))
     return subprocess.run(cmd, env=env).returncode
+
+
+def resolve_workload(args, rank, world, shard_range):
+    """What this rank runs: the BASELINE config's shape with the command-line overrides, and the rank's share of it.  Weak scaling:
+    `batch` pairs per GPU (config 4's 8 x 4096 = 32768 at --gpus 8); strong: `batch` pairs in total, contiguous shards
+    (dist.shard_range), `--config 4 --scaling strong` = BASELINE config 4 as north_star words it (32768 pairs over the ranks).
+    grad_pairs = the pairs the batch means of the loss run over = the GLOBAL batch (the reference's means divide by it)."""
+    cfg = dict(CONFIGS[args.config])
+    scaling = args.scaling or cfg["scaling"]
+    B_cfg = args.batch if args.batch is not None else cfg["B"]
+    if args.config == 4 and scaling == "strong" and args.batch is None:
+        B_cfg = 32768
+    N = args.npoints if args.npoints is not None else cfg["N"]
+    L = args.depth if args.depth is not None else cfg["depth"]
+    outl = args.outliers if args.outliers is not None else cfg["outliers"]
+    if scaling == "strong":
+        a, b = shard_range(B_cfg, rank, world)
+        B, B_total = b - a, B_cfg
+    else:
+        B, B_total = B_cfg, B_cfg * world
+    return {"cfg": cfg, "scaling": scaling, "B_cfg": B_cfg, "N": N, "L": L, "outliers": outl, "kind": cfg["kind"], "B": B, "B_total": B_total,
+            "grad_pairs": B_total}
 
 
 def log(*a):
@@ -213,12 +235,50 @@ def measure_api_path(dfepe, scene, logits, L, balance_F, args, B, fused_ms, fuse
             rec["max_abs_grad_diff_vs_value_run"] = float((g - fused_grad).abs().max())
             rec["grad_scale"] = float(fused_grad.abs().max())
         n_e = max(20, min(args.steps, 100))
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n_e):
-            body()
-        torch.cuda.synchronize()
-        rec["eager_ms_per_step"] = round((time.perf_counter() - t0) * 1e3 / n_e, 4)
+        tgu = dfepe.compat.train_good_utils
+
+        def eager_ms():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_e):
+                body()
+            torch.cuda.synchronize()
+            return round((time.perf_counter() - t0) * 1e3 / n_e, 4)
+
+        # the package default returns the reference's host types from get_Rt_loss (one device-to-host copy per step, like the
+        # reference's .cpu().numpy()); LAZY_HOST_METRICS defers that copy to the first read (no synchronisation in the step)
+        rec["eager_ms_per_step"] = eager_ms()
+        tgu.LAZY_HOST_METRICS = True
+        try:
+            rec["eager_lazy_host_metrics_ms_per_step"] = eager_ms()
+            # compat.CapturedStep: what a caller of the reference's eager sequence gets without building a graph itself -- the helper
+            # captures forward + losses + the caller's mixing + backward on its third call and replays from then on, copying every
+            # batch into its static inputs (two different batches alternate here, so each replay pays its copy-in)
+            if not probe:
+                def fwd_loss(sc):
+                    return pl.reference_call_sequence(net, sc, L, balance_F=balance_F, pose_gt_in_loss_params=gt_in)[0], None
+                keys = ("matches_xy_ori", "pts1_virt_ori", "pts2_virt_ori", "Ks", "delta_Rtijs_4_4", "qs_cam", "ts_cam")
+                two = [{k: scene[k] for k in keys}, {k: scene[k].clone() for k in keys}]
+                helper = dfepe.compat.CapturedStep(fwd_loss, rows, warmup=2)
+                for k in range(args.warmup + 8):
+                    helper(two[k & 1])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for k in range(args.steps):
+                    helper(two[k & 1])
+                torch.cuda.synchronize()
+                hms = (time.perf_counter() - t0) * 1e3 / args.steps
+                rec["captured_helper_ms_per_step"] = round(hms, 4)
+                rec["captured_helper"] = {"eager_steps": helper.n_eager, "captures": helper.n_captures, "replays": helper.n_replays,
+                                          "note": "compat.CapturedStep(forward_and_loss, params): copy-in of a fresh batch + one hipGraph replay per call"}
+                if fused_grad is not None:
+                    gh = torch.stack([x.grad.squeeze(1) for x in rows])
+                    rec["captured_helper"]["max_abs_grad_diff_vs_value_run"] = float((gh - fused_grad).abs().max())
+                for x in rows:
+                    x.grad = None
+                del helper
+        finally:
+            tgu.LAZY_HOST_METRICS = False
         gr = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gr):
             body()
@@ -271,21 +331,8 @@ def main():
         dist = dist_mod
 
     dfepe = importlib.import_module("pytorch-deepfepe_amd")
-    cfg = dict(CONFIGS[args.config])
-    scaling = args.scaling or cfg["scaling"]
-    B_cfg = args.batch if args.batch is not None else cfg["B"]
-    if args.config == 4 and scaling == "strong" and args.batch is None:
-        B_cfg = 32768  # BASELINE config 4 as north_star words it: 32768 pairs, batch-sharded over the ranks (8 x 4096)
-    N = args.npoints if args.npoints is not None else cfg["N"]
-    L = args.depth if args.depth is not None else cfg["depth"]
-    outl = args.outliers if args.outliers is not None else cfg["outliers"]
-    kind = cfg["kind"]
-    if scaling == "strong":  # the batch is fixed; ranks take contiguous shards (dist.shard_range)
-        a, b = dfepe.dist.shard_range(B_cfg, rank, world)
-        B = b - a
-        B_total = B_cfg
-    else:
-        B, B_total = B_cfg, B_cfg * world
+    wl = resolve_workload(args, rank, world, dfepe.dist.shard_range)
+    cfg, scaling, B_cfg, N, L, outl, kind, B, B_total = (wl[k] for k in ("cfg", "scaling", "B_cfg", "N", "L", "outliers", "kind", "B", "B_total"))
     # every rank generates only its own pairs (seeded per rank): the shards are independent by construction
     scene = dfepe.pipeline.scene_to_device(
         dfepe.synth.make_scene(B, N, seed=1000 + rank, outlier_ratio=outl, noise_px=0.5, depth_layers=L), dev)
@@ -710,7 +757,8 @@ def main():
                                          "sync": "all_reduce(SUM) of L+4 doubles in stream order after every step",
                                          "overlap": "double-buffered asynchronous all_reduce (dist.OverlappedLossExchange)",
                                          "none": None}[exchange_mode],
-                       "loss_exchange_fallback": exchange_fallback},
+                       "loss_exchange_fallback": exchange_fallback,
+                       "env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "DFEPE_BENCH_EXCHANGE", "NCCL_DEBUG")}},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "accuracy": acc,

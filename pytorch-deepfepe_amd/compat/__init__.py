@@ -11,6 +11,9 @@ argument order, defaults, return arity, tensor layouts and dict keys, backed by 
     deepFEPE.dsac_tools.dsac            ->   compat.dsac            (DSAC hypothesis loop, all hypotheses per launch)
     superpoint.models.model_wrap        ->   compat.model_wrap      (PointTracker.nn_match_two_way only)
 
+    (no counterpart: the reference's agent is eager)  compat.CapturedStep  (its training step as one replayed hipGraph)
+
 See INTEGRATION.md for how train_good.py is pointed at these.
 """
-from . import DeepFNet, ErrorEstimators, dsac, model_wrap, train_good_utils, utils_F, utils_geo, utils_misc  # noqa: F401
+from . import DeepFNet, ErrorEstimators, captured, dsac, model_wrap, train_good_utils, utils_F, utils_geo, utils_misc  # noqa: F401
+from .captured import CapturedStep  # noqa: F401

@@ -1,0 +1,248 @@
+"""CapturedStep -- the reference's EAGER training step, replayed as one hipGraph.
+
+The reference's agent runs, per batch (deepFEPE/Train_model_pipeline.py:495-595):
+
+    outs = self.net(data_batch)
+    losses_dict, ..., E_ests_layers = get_all_loss_DeepF(outs, pts1_virt_ori, pts2_virt_ori, Ks, loss_params, ...)
+    geo_errors_dict = get_Rt_loss(E_ests_layers, ..., delta_Rtijs_4_4, qs_cam, ts_cam, ...)
+    loss = clamp(stack(q_l2_error_layers_list)).mean() * balance_q + ...        # the caller's own mixing lines
+    self.optimizer.zero_grad(); loss.backward(); self.optimizer.step()
+
+Behind this package's mirrors that sequence is ~50 kernel launches of 5-13 us each; issued one by one from Python it is bound by
+the host (~1.7 ms at B = 4096 against 0.24 ms of GPU work).  It is capturable -- no host synchronisation, no allocation outside
+the caching allocator -- but train_good.py never builds a graph.  This helper does it for the caller, in three lines:
+
+    step = compat.CapturedStep(forward_and_loss, net.parameters())   # forward_and_loss(batch) -> (loss, aux): the lines above
+    for batch in loader:                                             # up to, NOT including, loss.backward()
+        optimizer.zero_grad()
+        loss, aux = step(batch)      # forward + loss + backward; .grad of every parameter is filled
+        optimizer.step()
+
+The first ``warmup`` calls of a batch signature (shapes, dtypes, non-tensor values) run eagerly -- they are real steps, their
+results are returned like any other -- the next one captures forward + loss + backward into a hipGraph over STATIC copies of the
+batch's tensors (device copies; host tensors and numpy arrays are uploaded into them before every replay), and from then on a call
+is: copy the batch in, replay, hand out the same (static) ``loss`` / ``aux`` objects with their new contents.  A batch with another
+signature gets a graph of its own (all graphs share one memory pool).  Contract (the usual one of whole-step graph capture):
+  * ``forward_and_loss`` must be a pure function of the batch and the parameters' CURRENT VALUES: no host-side branching on tensor
+    values, no .item() / .cpu(); python-side state it mutates is not replayed.
+  * the optimizer updates parameters in place (every torch.optim one does); gradients are OVERWRITTEN by every replay, not
+    accumulated, and ``optimizer.zero_grad(set_to_none=True)`` is harmless: the step re-attaches its static .grad tensors.
+  * ``loss`` / ``aux`` are rewritten by the next call: copy what must outlive it.  Host-side metrics of get_Rt_loss found in
+    ``aux`` are lazy while captured (no device synchronisation inside the step); ``step.realise(aux)`` turns them into the
+    reference's numpy arrays / floats, read from the buffers as they are after the latest replay.
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, Dict, Iterable, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+def _flatten(obj, path=()):
+    """(path, leaf) pairs of a nest of dicts / lists / tuples, in a deterministic order."""
+    if isinstance(obj, dict):
+        for k in sorted(obj, key=repr):
+            yield from _flatten(obj[k], path + (("k", k),))
+    elif isinstance(obj, (list, tuple)):
+        for i, v in enumerate(obj):
+            yield from _flatten(v, path + (("i", i),))
+    else:
+        yield path, obj
+
+
+def _rebuild(obj, leaves: Dict[tuple, Any], path=()):
+    if isinstance(obj, dict):
+        return {k: _rebuild(v, leaves, path + (("k", k),)) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        seq = [_rebuild(v, leaves, path + (("i", i),)) for i, v in enumerate(obj)]
+        return seq if isinstance(obj, list) else (type(obj)(*seq) if hasattr(obj, "_fields") else tuple(seq))
+    return leaves.get(path, obj)
+
+
+def _is_array(x) -> bool:
+    return torch.is_tensor(x) or isinstance(x, np.ndarray)
+
+
+def _leaf_key(x):
+    if torch.is_tensor(x):
+        return ("T", tuple(x.shape), str(x.dtype), bool(x.requires_grad))
+    if isinstance(x, np.ndarray):
+        return ("N", tuple(x.shape), str(x.dtype))
+    try:
+        hash(x)
+        return ("V", x)
+    except TypeError:
+        return ("O", id(x))
+
+
+class _Entry:
+    """One captured signature: static inputs, graph, static outputs, static gradients."""
+
+    __slots__ = ("seen", "static", "graph", "out", "grads", "batch")
+
+    def __init__(self):
+        self.seen = 0
+        self.static: Dict[tuple, torch.Tensor] = {}
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.out = None
+        self.grads: List[Optional[torch.Tensor]] = []
+        self.batch = None
+
+
+class CapturedStep:
+    def __init__(self, forward_and_loss: Callable[[Any], Tuple[torch.Tensor, Any]], parameters: Iterable[torch.nn.Parameter] = (),
+                 device: Optional[torch.device] = None, warmup: int = 2, max_graphs: int = 8, enabled: bool = True):
+        self.fn = forward_and_loss
+        self.params = [p for p in parameters]
+        self.device = torch.device(device) if device is not None else (self.params[0].device if self.params else torch.device("cuda", torch.cuda.current_device()))
+        if self.device.type != "cuda":
+            raise _lib.DfepeError("CapturedStep: the step runs on the GPU (this package has no CPU path)")
+        self.warmup = max(1, int(warmup))  # at least one eager step: it sizes the allocator and runs every lazy initialisation
+        self.max_graphs = int(max_graphs)
+        self.enabled = bool(enabled)
+        self._entries: Dict[tuple, _Entry] = {}
+        self._pool = None
+        self._stream = torch.cuda.Stream(device=self.device)
+        self.n_eager = self.n_captures = self.n_replays = 0
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _signature(self, batch) -> tuple:
+        return tuple((path, _leaf_key(x)) for path, x in _flatten(batch))
+
+    def _to_device(self, x):
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(x)
+        return x.to(self.device, non_blocking=True)
+
+    def _zero_grads(self):
+        for p in self.params:
+            p.grad = None
+
+    def _run(self, batch):
+        loss, aux = self.fn(batch)
+        loss.backward()
+        return loss, aux
+
+    def _eager(self, batch):
+        """One ordinary step on the helper's stream (the stream the capture will use: the caching allocator then recycles the
+        warm-up's blocks for the capture, and the parameters' gradient accumulators are bound to one stream throughout)."""
+        cur = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            dev_batch = _rebuild(batch, {path: self._to_device(x) for path, x in _flatten(batch) if _is_array(x)})
+            out = self._run(dev_batch)
+        cur.wait_stream(self._stream)
+        self.n_eager += 1
+        return out
+
+    def _capture(self, ent: _Entry, batch):
+        from . import train_good_utils as tgu
+
+        cur = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            for path, x in _flatten(batch):
+                if _is_array(x):
+                    src = self._to_device(x)
+                    buf = torch.empty_like(src).copy_(src)
+                    if torch.is_tensor(x) and x.requires_grad:
+                        buf.requires_grad_(True)
+                    ent.static[path] = buf
+            ent.batch = _rebuild(batch, ent.static)
+            self._zero_grads()  # the captured backward then WRITES each gradient into memory of the graph's pool
+        torch.cuda.synchronize(self.device)
+        ent.graph = torch.cuda.CUDAGraph()
+        lazy = tgu.LAZY_HOST_METRICS
+        tgu.LAZY_HOST_METRICS = True
+        try:
+            with torch.cuda.graph(ent.graph, pool=self._pool, stream=self._stream):
+                ent.out = self._run(ent.batch)
+        finally:
+            tgu.LAZY_HOST_METRICS = lazy
+        if self._pool is None:
+            self._pool = ent.graph.pool()
+        ent.grads = [p.grad for p in self.params]
+        self.n_captures += 1
+
+    def _replay(self, ent: _Entry, batch, fresh: bool):
+        cur = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            if not fresh:  # the capture call has just filled the static inputs with this very batch
+                dsts, srcs = [], []
+                for path, x in _flatten(batch):
+                    if _is_array(x):
+                        dst = ent.static[path].detach()
+                        if torch.is_tensor(x) and x.data_ptr() == dst.data_ptr():
+                            continue  # the caller filled the static buffer itself (step.static_inputs(batch))
+                        dsts.append(dst)
+                        srcs.append(self._to_device(x))
+                if dsts:
+                    try:
+                        torch._foreach_copy_(dsts, srcs, non_blocking=True)  # one multi-tensor launch instead of one per tensor
+                    except (AttributeError, RuntimeError, TypeError):
+                        for dst, src in zip(dsts, srcs):
+                            dst.copy_(src, non_blocking=True)
+            ent.graph.replay()
+        cur.wait_stream(self._stream)
+        for p, g in zip(self.params, ent.grads):
+            p.grad = g  # survives the caller's zero_grad(set_to_none=True)
+        self._refresh(ent.out[1])
+        self.n_replays += 1
+        return ent.out
+
+    @staticmethod
+    def _refresh(aux):
+        for _, x in _flatten(aux):
+            hm = getattr(x, "host_metrics", None)
+            if hm is not None and hasattr(hm, "refresh"):
+                hm.refresh()
+        hm = getattr(aux, "host_metrics", None)  # aux itself may be get_Rt_loss's dict
+        if hm is not None and hasattr(hm, "refresh"):
+            hm.refresh()
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def __call__(self, batch):
+        if not self.enabled:
+            return self._eager(batch)
+        key = self._signature(batch)
+        ent = self._entries.get(key)
+        if ent is None:
+            if len(self._entries) >= self.max_graphs:  # a stream of ever-changing shapes: stay eager instead of hoarding graphs
+                return self._eager(batch)
+            ent = self._entries[key] = _Entry()
+        if ent.graph is None:
+            if ent.seen < self.warmup:
+                ent.seen += 1
+                return self._eager(batch)
+            self._capture(ent, batch)
+            return self._replay(ent, batch, fresh=True)
+        return self._replay(ent, batch, fresh=False)
+
+    def static_inputs(self, batch):
+        """The static input nest of the graph that serves ``batch``'s signature (None before its capture): a loader that writes the
+        next batch straight into these tensors and passes them back saves the copy-in."""
+        ent = self._entries.get(self._signature(batch))
+        return None if ent is None or ent.graph is None else ent.batch
+
+    @staticmethod
+    def realise(aux):
+        """Every get_Rt_loss dict inside ``aux`` (or ``aux`` itself) -> the reference's numpy / float types, read now (one device
+        synchronisation); returns ``aux``."""
+        seen = [aux] if hasattr(aux, "realise") else []
+        if isinstance(aux, (dict, list, tuple)):
+            stack = [aux]
+            while stack:
+                cur = stack.pop()
+                vals = cur.values() if isinstance(cur, dict) else cur
+                for v in vals:
+                    if hasattr(v, "realise") and hasattr(v, "host_metrics"):
+                        seen.append(v)
+                    elif isinstance(v, (dict, list, tuple)) and not hasattr(v, "realise"):
+                        stack.append(v)
+        for g in seen:
+            g.realise()
+        return aux

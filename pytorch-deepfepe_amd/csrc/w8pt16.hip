@@ -7,6 +7,8 @@
 #include "w8pt16_body.h"
 #include "w8pt16_bwd_body.h"
 #include "loss_head_body.h"
+#include <cstdlib>
+
 #include "cheirality_body.h"
 
 namespace {
@@ -306,7 +308,9 @@ extern "C" int dfepe_w8pt_pose_fwd(const float* matches, const float* weights, i
   if (B == 0) return DFEPE_OK;
   if (!matches || !weights || !K || !F_out || !residual || !Rt_cam || !(image_w > 0.f && image_h > 0.f)) return DFEPE_ERR_INVALID_ARG;
   if (reinterpret_cast<uintptr_t>(matches) & 15u) return DFEPE_ERR_INVALID_ARG;
-  if (!use_coop(N, B, (flags & DFEPE_W8PT_ROW_PER_PAIR) != 0)) {  // any other shape: the two launches this one replaces
+  // A/B switch (measurement only, read once): DFEPE_POSE_LAUNCHES=2 forces the two launches, =1 the fused one where it exists
+  static const int forced_launches = [] { const char* e = getenv("DFEPE_POSE_LAUNCHES"); return e ? atoi(e) : 0; }();
+  if (forced_launches == 2 || !use_coop(N, B, (flags & DFEPE_W8PT_ROW_PER_PAIR) != 0)) {  // any other shape: the two launches this one replaces
     const int rc = dfepe_w8pt_fwd(matches, nullptr, weights, B, N, 1, flags, image_w, image_h, clamp_at, F_out, residual, epi_res, nullptr,
                                   weights_out, stream);
     if (rc != DFEPE_OK) return rc;

@@ -71,21 +71,22 @@ def test_shard_range_partitions_every_batch():
         d.dist.shard_range(8, 2, 2)
 
 
-@pytest.mark.timeout(300)
-def test_two_rank_loss_reduction_matches_single_process():
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("B,world", [(7, 2), (19, 8)])  # uneven shards; 8 ranks = the node bench.py --gpus 8 runs on
+def test_loss_reduction_over_ranks_matches_single_process(B, world):
     sys.path.insert(0, REPO)
     dfepe = importlib.import_module("pytorch-deepfepe_amd")
     oracle = importlib.import_module("oracle.deepf_oracle")
-    B, N, depth, world = 7, 40, 3, 2  # odd batch: uneven shards
+    N, depth = 40, 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, B, N, depth, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=240)
+    got = q.get(timeout=480)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     full = dfepe.synth.make_scene(B, N, seed=77, outlier_ratio=0.2, depth_layers=depth, dtype=torch.float64)
     ref = oracle.hot_path_step(full, IMAGE_SIZE, depth, 0.02, qt=True, mode="batched", backward=False)
@@ -161,3 +162,34 @@ def test_bench_self_launch_command_is_the_drivers_invocation():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     if not torch.cuda.is_available():
         assert r.returncode != 0 and "GPU" in r.stderr
+
+
+def test_bench_plumbing_of_the_eight_gpu_runs():
+    """The first real 8-GPU run must not fail on plumbing: argument parsing + workload resolution of every rank
+    for the driver's weak-scaling command and for BASELINE config 4 / 5 as strong scaling, and the re-launch command a plain
+    `python bench.py --gpus 8 --config 4 --scaling strong` turns itself into."""
+    sys.path.insert(0, REPO)
+    bench = importlib.import_module("bench")
+    d = importlib.import_module("pytorch-deepfepe_amd")
+    # the driver's command: weak scaling, 4096 pairs per GPU, 8 x 4096 = BASELINE config 4's 32768 in total
+    args = bench.parse(["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    for r in range(8):
+        wl = bench.resolve_workload(args, r, 8, d.dist.shard_range)
+        assert (wl["B"], wl["B_total"], wl["N"], wl["L"], wl["scaling"], wl["kind"], wl["grad_pairs"]) == (4096, 32768, 100, 5, "weak", "train", 32768)
+    # config 4 as north_star words it: 32768 pairs batch-sharded over the ranks, means over the GLOBAL batch
+    args = bench.parse(["--gpus", "8", "--config", "4", "--scaling", "strong"])
+    shards = [bench.resolve_workload(args, r, 8, d.dist.shard_range) for r in range(8)]
+    assert all(w["B"] == 4096 and w["B_total"] == 32768 and w["grad_pairs"] == 32768 and w["cfg"]["balance_F"] == 0.0 and w["outliers"] == 0.4 for w in shards)
+    # config 5: 4096 x 1000 in total, strong by default; an uneven world size still partitions the batch
+    args = bench.parse(["--gpus", "8", "--config", "5"])
+    assert [bench.resolve_workload(args, r, 8, d.dist.shard_range)["B"] for r in range(8)] == [512] * 8
+    args = bench.parse(["--gpus", "3", "--config", "5"])
+    assert sum(bench.resolve_workload(args, r, 3, d.dist.shard_range)["B"] for r in range(3)) == 4096
+    # an explicit --batch: per GPU when weak, in total when strong
+    args = bench.parse(["--gpus", "2", "--batch", "1000"])
+    assert bench.resolve_workload(args, 1, 2, d.dist.shard_range)["B_total"] == 2000
+    args = bench.parse(["--gpus", "2", "--batch", "1001", "--scaling", "strong"])
+    assert [bench.resolve_workload(args, r, 2, d.dist.shard_range)["B"] for r in range(2)] == [501, 500]
+    cmd = bench.launch_command(["--gpus", "8", "--config", "4", "--scaling", "strong", "--launcher=auto"], 8, 12345)
+    assert cmd[cmd.index(os.path.join(REPO, "bench.py")) + 1:] == ["--gpus", "8", "--config", "4", "--scaling", "strong", "--launcher", "none"]
+    assert "--nproc-per-node=8" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
