@@ -273,11 +273,18 @@ int dfepe_loss_stats(const float *x0, int rows0, float scale0, const float *x1, 
  */
 int dfepe_cheirality(const float *E, const float *pre, const float *K, const float *matches, int B, int N, float depth_thres,
                      float *Rt_cam, int *winner, int *counts, void *stream);
-/* The same with flags.  DFEPE_CHEIR_FP64_ONLY: every correspondence takes the fp64 route (no packed-fp32 decisions): the build the
- * adaptive default is tested against for EXACT equality of the counts (tests/test_fullsize_gpu.py), and its upper bound in time. */
+/* The same with flags and an optional workspace.
+ * DFEPE_CHEIR_FP64_ONLY: every correspondence takes the fp64 route (no packed-fp32 decisions): the build the adaptive default is
+ *   tested against for EXACT equality of the counts (tests/test_fullsize_gpu.py), and its upper bound in time.
+ * workspace: NULL, or dfepe_cheirality_workspace_bytes(B) bytes of device memory (8-byte aligned, overwritten).  With it the
+ *   per-pair constants of the correspondence loop (the decomposition of E, the two candidate projection matrices K [R|t]) are
+ *   formed by a preparation launch with one LANE per pair and fetched by the main kernel through scalar loads, instead of being
+ *   re-derived by every wavefront (a closed-form fp64 SVD issued for 64 lanes: ~12 % of the launch at one wavefront per pair).
+ *   Same outputs bit for bit. */
 #define DFEPE_CHEIR_FP64_ONLY 1u
+size_t dfepe_cheirality_workspace_bytes(int B);
 int dfepe_cheirality_ex(const float *E, const float *pre, const float *K, const float *matches, int B, int N, float depth_thres,
-                        unsigned flags, float *Rt_cam, int *winner, int *counts, void *stream);
+                        unsigned flags, void *workspace, float *Rt_cam, int *winner, int *counts, void *stream);
 
 /*
  * Fit + E-from-F + cheirality-checked pose in one call (BASELINE config 5: one weighted 8-point fit, then the pose of its F).
@@ -285,10 +292,11 @@ int dfepe_cheirality_ex(const float *E, const float *pre, const float *K, const 
  * Same outputs as dfepe_w8pt_fwd (DFEPE_W8PT_RAW_MATCHES required; DFEPE_W8PT_LOGITS optional; no `save`: forward only) followed
  * by dfepe_cheirality(F_out, pre, ...), bit for bit; for 128 < N <= 2048 below 3072 pairs it is ONE launch (the cooperative
  * workgroup of the fit goes on to decompose pre^T F pre and to triangulate its pair), otherwise the two launches.
+ * workspace: NULL or dfepe_cheirality_workspace_bytes(B) bytes, handed to dfepe_cheirality_ex when the two launches run.
  */
 int dfepe_w8pt_pose_fwd(const float *matches, const float *weights, int B, int N, unsigned flags, float image_w, float image_h,
                         float clamp_at, const float *K, const float *pre, float depth_thres, float *F_out, float *residual,
-                        float *epi_res, float *weights_out, float *Rt_cam, int *winner, int *counts, void *stream);
+                        float *epi_res, float *weights_out, float *Rt_cam, int *winner, int *counts, void *workspace, void *stream);
 
 /*
  * Reductions of the validation summary on the device.

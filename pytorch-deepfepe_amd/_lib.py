@@ -51,8 +51,9 @@ _SIGNATURES = {
     "dfepe_deepf_input": (c_int, [_P, _P, c_int, c_int, c_int, c_float, c_float, _P, c_size_t, c_size_t, c_int, c_size_t, _P, _P, _P]),
     "dfepe_row_dot": (c_int, [_P, c_size_t, _P, c_size_t, c_int, c_int, c_int, _P, _P]),
     "dfepe_cheirality": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, _P, _P, _P, _P]),
-    "dfepe_cheirality_ex": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_uint, _P, _P, _P, _P]),
-    "dfepe_w8pt_pose_fwd": (c_int, [_P, _P, c_int, c_int, c_uint, c_float, c_float, c_float, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dfepe_cheirality_workspace_bytes": (c_size_t, [c_int]),
+    "dfepe_cheirality_ex": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_uint, _P, _P, _P, _P, _P]),
+    "dfepe_w8pt_pose_fwd": (c_int, [_P, _P, c_int, c_int, c_uint, c_float, c_float, c_float, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dfepe_metrics_summary_bytes": (c_size_t, []),
     "dfepe_metrics_summary": (c_int, [_P, _P, c_size_t, _P, _P, c_int, _P, _P]),
     "dfepe_epi_metrics": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_float, c_float, _P, _P]),

@@ -165,29 +165,28 @@ class CapturedStep:
         if self._pool is None:
             self._pool = ent.graph.pool()
         ent.grads = [p.grad for p in self.params]
+        cur.wait_stream(self._stream)  # the static inputs were filled on the helper's stream; the replays run on the caller's
         self.n_captures += 1
 
     def _replay(self, ent: _Entry, batch, fresh: bool):
-        cur = torch.cuda.current_stream(self.device)
-        self._stream.wait_stream(cur)
-        with torch.cuda.stream(self._stream):
-            if not fresh:  # the capture call has just filled the static inputs with this very batch
-                dsts, srcs = [], []
-                for path, x in _flatten(batch):
-                    if _is_array(x):
-                        dst = ent.static[path].detach()
-                        if torch.is_tensor(x) and x.data_ptr() == dst.data_ptr():
-                            continue  # the caller filled the static buffer itself (step.static_inputs(batch))
-                        dsts.append(dst)
-                        srcs.append(self._to_device(x))
-                if dsts:
-                    try:
-                        torch._foreach_copy_(dsts, srcs, non_blocking=True)  # one multi-tensor launch instead of one per tensor
-                    except (AttributeError, RuntimeError, TypeError):
-                        for dst, src in zip(dsts, srcs):
-                            dst.copy_(src, non_blocking=True)
-            ent.graph.replay()
-        cur.wait_stream(self._stream)
+        # on the CALLER's current stream: a captured graph replays on any stream, and a hop to the helper's stream and back would
+        # cost two cross-stream edges per step (18-30 us each on this stack) for nothing
+        if not fresh:  # the capture call has just filled the static inputs with this very batch
+            dsts, srcs = [], []
+            for path, x in _flatten(batch):
+                if _is_array(x):
+                    dst = ent.static[path].detach()
+                    if torch.is_tensor(x) and x.data_ptr() == dst.data_ptr():
+                        continue  # the caller filled the static buffer itself (step.static_inputs(batch))
+                    dsts.append(dst)
+                    srcs.append(self._to_device(x))
+            if dsts:
+                try:
+                    torch._foreach_copy_(dsts, srcs, non_blocking=True)  # one multi-tensor launch instead of one per tensor
+                except (AttributeError, RuntimeError, TypeError):
+                    for dst, src in zip(dsts, srcs):
+                        dst.copy_(src, non_blocking=True)
+        ent.graph.replay()
         for p, g in zip(self.params, ent.grads):
             p.grad = g  # survives the caller's zero_grad(set_to_none=True)
         self._refresh(ent.out[1])

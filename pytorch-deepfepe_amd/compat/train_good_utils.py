@@ -111,6 +111,7 @@ class _HostCopy:
     def __init__(self, t):
         self.t = t
         self.cache = None
+        self._means = None
 
     def get(self):
         if torch.cuda.is_current_stream_capturing():
@@ -119,9 +120,16 @@ class _HostCopy:
             self.cache = self.t.detach().cpu().numpy().astype(np.float64)
         return self.cache
 
+    def means(self):
+        """[2, L]: the batch mean of every (kind, layer) row, one vectorised reduction per host copy."""
+        if self._means is None or self.cache is None:
+            self._means = self.get().mean(axis=2)
+        return self._means
+
     def refresh(self):
         """Forget the host copy (after a graph replay rewrote the device buffer in place)."""
         self.cache = None
+        self._means = None
 
 
 class _GeoErrors(dict):
@@ -325,10 +333,10 @@ def get_Rt_loss(E_ests_layers, Ks_cpu, x1_cpu, x2_cpu, delta_Rtijs_4_4_cpu, qs_c
     host = _HostCopy(ang)
     R_layers = [_Lazy(lambda i=i: host.get()[0, i]) for i in range(L)]
     t_layers = [_Lazy(lambda i=i: host.get()[1, i]) for i in range(L)]
-    R_list = _Lazy(lambda: np.array([float(host.get()[0, i].mean()) for i in range(L)]))
-    tA_list = _Lazy(lambda: np.array([float(host.get()[1, i].mean()) for i in range(L)]))
-    R_mean = _LazyScalar(lambda: mean_list([float(host.get()[0, i].mean()) for i in range(L)]))
-    tA_mean = _LazyScalar(lambda: mean_list([float(host.get()[1, i].mean()) for i in range(L)]))
+    R_list = _Lazy(lambda: host.means()[0].copy())   # np.array([layer.mean() for layer in ...]) (:288-291)
+    tA_list = _Lazy(lambda: host.means()[1].copy())
+    R_mean = _LazyScalar(lambda: mean_list([float(v) for v in host.means()[0]]))
+    tA_mean = _LazyScalar(lambda: mean_list([float(v) for v in host.means()[1]]))
     out = _GeoErrors({
         "t_l2_error_mean": o_t,      # mean_list of the per-layer means (:272-273)
         "q_l2_error_mean": o_q,

@@ -195,8 +195,15 @@ __device__ inline void rqi_refine4(const double* S, const double* x0, double* y)
 }
 
 constexpr int kCheirQueue = 128;  // ints of LDS per wavefront: indices of the correspondences waiting for the fp64 route (< 64 + 64)
+// What the correspondence loop needs of a pair, all in doubles: R1 (0..8), R2 (9..17), t (18..20), the two candidate projection
+// matrices K [R | t] (21..32, 33..44), K (45..53).  Formed ONCE per pair -- by dfepe_cheirality_ex's preparation launch (one LANE per
+// pair, into the caller's workspace; the main kernel then fetches it with scalar loads), or by wavefront 0 of the pair's workgroup
+// (into LDS) -- instead of once per wavefront: it is a per-pair scalar computation (closed-form fp64 SVD of E, ~1 400 vector
+// instructions when issued for 64 lanes), 12 % of the kernel at one wavefront per pair and half of it at eight.
+constexpr int kCheirPrep = 56;
+constexpr int kPrepR = 0, kPrepT = 18, kPrepP = 21, kPrepK = 45;
 struct CheirLds {
-  double pose[21];  // R1, R2, t of the pair: parked here during the correspondence loop, which needs only their third rows
+  double prep[kCheirPrep];
   int wcnt[8][4];
   int queue[8 * kCheirQueue];
 };
@@ -204,58 +211,76 @@ struct CheirLds {
 // One workgroup per pair (every thread of the workgroup must call; W = blockDim.x / 64 wavefronts each take every W-th group of 64
 // correspondences and meet in `wcnt`, LDS owned by the caller).  E9: the matrix to decompose (or F when `pre` is given: then
 // pre^T E9 pre is decomposed), identical in every thread.
-// FP64_ONLY: every correspondence through the fp64 route (DFEPE_CHEIR_FP64_ONLY: the reference build the adaptive one is tested
-// against for exact equality of the counts; also its upper bound in time).
-template <bool FP64_ONLY = false>
-__device__ __forceinline__ void cheirality_pair(const float* E9, const float* __restrict__ pre, const float* __restrict__ K,
-                                                const float* __restrict__ matches, const size_t pair, const int N, const float depth_thres,
-                                                float* __restrict__ Rt_cam, int* __restrict__ winner, int* __restrict__ counts,
-                                                CheirLds& cl) {
-  int (*wcnt)[4] = cl.wcnt;
-  int* queue = cl.queue;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
-  double Ed[9], Kd[9], R[2][9], t[3];
+__device__ inline void cheir_prepare(const float* E9, const float* pre9 /* this pair's, or nullptr */, const float* K9, double* out /* kCheirPrep */) {
+  double Ed[9], Kd[9], R1[9], R2[9], t[3];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) { Ed[k] = (double)E9[k]; Kd[k] = to_sgpr((double)K[pair * 9 + k]); }
-  if (pre != nullptr) {  // E-from-F fused: the matrix decomposed is pre^T E pre (E = F, pre = T K; train_good_utils.py:356-358)
+  for (int k = 0; k < 9; ++k) { Ed[k] = (double)E9[k]; Kd[k] = (double)K9[k]; }
+  if (pre9 != nullptr) {  // E-from-F fused: the matrix decomposed is pre^T E pre (E = F, pre = T K; train_good_utils.py:356-358)
     double Ad[9], tmp[9], Ef[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) Ad[k] = (double)pre[pair * 9 + k];
+    for (int k = 0; k < 9; ++k) Ad[k] = (double)pre9[k];
     mat3_mul_tn(Ad, Ed, tmp);
     mat3_mul(tmp, Ad, Ef);
 #pragma unroll
     for (int k = 0; k < 9; ++k) Ed[k] = (double)(float)Ef[k];  // through fp32 like the stand-alone congruence kernel's output
   }
-  decompose_E(Ed, R[0], R[1], t);
-  // per-pair (wave-uniform) quantities live in scalar registers; the per-correspondence DLT owns the VGPRs
+  decompose_E(Ed, R1, R2, t);
 #pragma unroll
-  for (int k = 0; k < 9; ++k) { R[0][k] = to_sgpr(R[0][k]); R[1][k] = to_sgpr(R[1][k]); }
+  for (int k = 0; k < 9; ++k) { out[kPrepR + k] = R1[k]; out[kPrepR + 9 + k] = R2[k]; out[kPrepK + k] = Kd[k]; }
 #pragma unroll
-  for (int k = 0; k < 3; ++k) t[k] = to_sgpr(t[k]);
-  // scalar-register budget of the loop: K (18), the two projection matrices (48), the third rows of R1 / R2 and t_z (14); the
-  // rest of the decomposition is only needed for the winner's output and waits in LDS (every wavefront holds the same values)
-  if (threadIdx.x == 0) {
+  for (int k = 0; k < 3; ++k) out[kPrepT + k] = t[k];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { cl.pose[k] = R[0][k]; cl.pose[9 + k] = R[1][k]; }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) cl.pose[18 + k] = t[k];
-  }
-  const double Rz[2][3] = {{R[0][6], R[0][7], R[0][8]}, {R[1][6], R[1][7], R[1][8]}};
-  const double tz = t[2];
-  // the two candidate projection matrices K [R | t], formed once per pair and parked in scalar registers (48 SGPRs) since round 5:
-  // with them out of the vector file the packed-fp32 body needs < 128 VGPRs, i.e. FOUR wavefronts per SIMD (round 2 measured the
-  // same parking as slower -- but with the all-fp64 body of that round, which then spilled)
-  double P2s[2][12];
-#pragma unroll
-  for (int rr = 0; rr < 2; ++rr)
+  for (int rr = 0; rr < 2; ++rr) {
+    const double* R = rr ? R2 : R1;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
-        P2s[rr][4 * r + c] = to_sgpr(Kd[3 * r] * R[rr][c] + Kd[3 * r + 1] * R[rr][3 + c] + Kd[3 * r + 2] * R[rr][6 + c]);
-      P2s[rr][4 * r + 3] = to_sgpr(Kd[3 * r] * t[0] + Kd[3 * r + 1] * t[1] + Kd[3 * r + 2] * t[2]);
+      for (int c = 0; c < 3; ++c) out[kPrepP + 12 * rr + 4 * r + c] = Kd[3 * r] * R[c] + Kd[3 * r + 1] * R[3 + c] + Kd[3 * r + 2] * R[6 + c];
+      out[kPrepP + 12 * rr + 4 * r + 3] = Kd[3 * r] * t[0] + Kd[3 * r + 1] * t[1] + Kd[3 * r + 2] * t[2];
     }
+  }
+  out[54] = out[55] = 0.0;
+}
+
+// FP64_ONLY: every correspondence through the fp64 route (DFEPE_CHEIR_FP64_ONLY: the reference build the adaptive one is tested
+// against for exact equality of the counts; also its upper bound in time).
+// WS: the pair's constants come from the workspace `ws` (filled by cheir_prepare in a launch of its own) instead of being formed here.
+template <bool FP64_ONLY = false, bool WS = false>
+__device__ __forceinline__ void cheirality_pair(const float* E9, const float* __restrict__ pre, const float* __restrict__ K,
+                                                const float* __restrict__ matches, const size_t pair, const int N, const float depth_thres,
+                                                float* __restrict__ Rt_cam, int* __restrict__ winner, int* __restrict__ counts,
+                                                CheirLds& cl, const double* __restrict__ ws = nullptr) {
+  int (*wcnt)[4] = cl.wcnt;
+  int* queue = cl.queue;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
+  // ---- the pair's constants (see kCheirPrep) into scalar registers: from the workspace a preparation launch filled (uniform
+  // address: scalar loads), else formed by wavefront 0 and shared through LDS
+  const double* wsp = ws + pair * kCheirPrep;  // WS only
+  if constexpr (!WS) {
+    if (wave == 0) {
+      double mine[kCheirPrep];
+      cheir_prepare(E9, pre != nullptr ? pre + pair * 9 : nullptr, K + pair * 9, mine);
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 54; ++k) cl.prep[k] = mine[k];
+      }
+    }
+    __syncthreads();
+  }
+  auto prep = [&](const int k) { if constexpr (WS) return wsp[k]; else return cl.prep[k]; };
+  // scalar-register budget of the loop: K (18), the two projection matrices (48), the third rows of R1 / R2 and t_z (14); the rest
+  // of the decomposition is only needed for the winner's output and is re-read there
+  double Kd[9], P2s[2][12];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Kd[k] = to_sgpr(prep(kPrepK + k));
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+    for (int k = 0; k < 12; ++k) P2s[rr][k] = to_sgpr(prep(kPrepP + 12 * rr + k));
+  const double Rz[2][3] = {{to_sgpr(prep(kPrepR + 6)), to_sgpr(prep(kPrepR + 7)), to_sgpr(prep(kPrepR + 8))},
+                           {to_sgpr(prep(kPrepR + 15)), to_sgpr(prep(kPrepR + 16)), to_sgpr(prep(kPrepR + 17))}};
+  const double tz = to_sgpr(prep(kPrepT + 2));
   int cnt[4] = {0, 0, 0, 0};
   const int nw = blockDim.x >> 6;  // 4 wavefronts per pair for small batches (latency), 1 for large ones (throughput)
   const float4* mrow = reinterpret_cast<const float4*>(matches) + pair * N;
@@ -467,11 +492,11 @@ __device__ __forceinline__ void cheirality_pair(const float* E9, const float* __
     }
     if (winner != nullptr) winner[pair] = (best > 0) ? win : -1;
     // camera motion = inverse of [R|t]: [R^T | -R^T t]   (utils_misc._inv_Rt, utils_misc.py:115-121)
-    double Rc[9], tw[3];  // the winner's rotation and the translation, back from LDS (written before the loop, barrier above)
+    double Rc[9], tw[3];  // the winner's rotation and the translation
 #pragma unroll
-    for (int k = 0; k < 9; ++k) Rc[k] = cl.pose[9 * (win >> 1) + k];
+    for (int k = 0; k < 9; ++k) Rc[k] = prep(kPrepR + 9 * (win >> 1) + k);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) tw[k] = cl.pose[18 + k];
+    for (int k = 0; k < 3; ++k) tw[k] = prep(kPrepT + k);
     const double sg = (win & 1) ? -1.0 : 1.0;
     float* dst = Rt_cam + pair * 12;
 #pragma unroll

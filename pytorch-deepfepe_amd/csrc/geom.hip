@@ -231,18 +231,35 @@ geo_misc_kernel(int kind, const float* __restrict__ in0, const float* __restrict
 // <= 128 registers = FOUR wavefronts per SIMD (round 5; rounds 2-4: 166 registers, three): the projection matrices live in scalar
 // registers and the fp64 route handles one rotation candidate at a time, so the packed-fp32 body sets the register count.  The bound
 // also admits two 8-wavefront workgroups per CU: a pair's 1000 correspondences are then two groups of 64 per wavefront, not four.
-template <bool FP64_ONLY>
+template <bool FP64_ONLY, bool WS>
 __global__ void __launch_bounds__(512, 2)
 cheirality_kernel(const float* __restrict__ E, const float* __restrict__ pre, const float* __restrict__ K,
-                  const float* __restrict__ matches, int B, int N, float depth_thres, float* __restrict__ Rt_cam,
-                  int* __restrict__ winner, int* __restrict__ counts) {
+                  const float* __restrict__ matches, int B, int N, float depth_thres, const double* __restrict__ ws,
+                  float* __restrict__ Rt_cam, int* __restrict__ winner, int* __restrict__ counts) {
   __shared__ CheirLds cl;
   const size_t pair = blockIdx.x;
   float Ef[9];
+  if constexpr (!WS) {
 #pragma unroll
-  for (int k = 0; k < 9; ++k) Ef[k] = E[pair * 9 + k];
-  cheirality_pair<FP64_ONLY>(Ef, pre, K, matches, pair, N, depth_thres, Rt_cam, winner, counts, cl);
+    for (int k = 0; k < 9; ++k) Ef[k] = E[pair * 9 + k];
+  }
+  cheirality_pair<FP64_ONLY, WS>(Ef, pre, K, matches, pair, N, depth_thres, Rt_cam, winner, counts, cl, ws);
   (void)B;
+}
+
+// the per-pair constants of the loop (cheirality_body.h: kCheirPrep doubles per pair), one LANE per pair
+__global__ void __launch_bounds__(64)
+cheirality_prepare_kernel(const float* __restrict__ E, const float* __restrict__ pre, const float* __restrict__ K, int B,
+                          double* __restrict__ ws) {
+  const int pair = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (pair >= B) return;
+  float Ef[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Ef[k] = E[(size_t)pair * 9 + k];
+  double out[kCheirPrep];
+  cheir_prepare(Ef, pre != nullptr ? pre + (size_t)pair * 9 : nullptr, K + (size_t)pair * 9, out);
+#pragma unroll
+  for (int k = 0; k < kCheirPrep; ++k) ws[(size_t)pair * kCheirPrep + k] = out[k];
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -352,25 +369,34 @@ extern "C" int dfepe_geo_misc(int kind, const float* in0, const float* in1, int 
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
+extern "C" size_t dfepe_cheirality_workspace_bytes(int B) { return (B > 0) ? (size_t)B * kCheirPrep * sizeof(double) : 0; }
+
 extern "C" int dfepe_cheirality_ex(const float* E, const float* pre, const float* K, const float* matches, int B, int N,
-                                   float depth_thres, unsigned flags, float* Rt_cam, int* winner, int* counts, void* stream) {
+                                   float depth_thres, unsigned flags, void* workspace, float* Rt_cam, int* winner, int* counts,
+                                   void* stream) {
   if (B < 0 || N <= 0 || (flags & ~DFEPE_CHEIR_FP64_ONLY)) return DFEPE_ERR_INVALID_ARG;
   if (B == 0) return DFEPE_OK;
   if (!E || !K || !matches || !Rt_cam) return DFEPE_ERR_INVALID_ARG;
-  if (reinterpret_cast<uintptr_t>(matches) & 15u) return DFEPE_ERR_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(matches) & 15u) || (reinterpret_cast<uintptr_t>(workspace) & 7u)) return DFEPE_ERR_INVALID_ARG;
   // wavefronts per pair: throughput wants one (B >= 2048: every SIMD already holds >= 2 pairs), latency wants as many as the pair
   // has groups of 64 correspondences, up to eight (at <= 128 registers a CU holds two such workgroups)
   const int groups = (N + 63) / 64;
   const int threads = (B >= 2048) ? 64 : 64 * (groups < 8 ? groups : 8);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (flags & DFEPE_CHEIR_FP64_ONLY)
-    hipLaunchKernelGGL(cheirality_kernel<true>, dim3(B), dim3(threads), 0, st, E, pre, K, matches, B, N, depth_thres, Rt_cam, winner, counts);
-  else
-    hipLaunchKernelGGL(cheirality_kernel<false>, dim3(B), dim3(threads), 0, st, E, pre, K, matches, B, N, depth_thres, Rt_cam, winner, counts);
+  double* ws = static_cast<double*>(workspace);
+  const bool f64 = (flags & DFEPE_CHEIR_FP64_ONLY) != 0;
+  if (ws != nullptr) {
+    hipLaunchKernelGGL(cheirality_prepare_kernel, dim3((B + 63) / 64), dim3(64), 0, st, E, pre, K, B, ws);
+    if (f64) hipLaunchKernelGGL((cheirality_kernel<true, true>), dim3(B), dim3(threads), 0, st, E, pre, K, matches, B, N, depth_thres, ws, Rt_cam, winner, counts);
+    else hipLaunchKernelGGL((cheirality_kernel<false, true>), dim3(B), dim3(threads), 0, st, E, pre, K, matches, B, N, depth_thres, ws, Rt_cam, winner, counts);
+  } else {
+    if (f64) hipLaunchKernelGGL((cheirality_kernel<true, false>), dim3(B), dim3(threads), 0, st, E, pre, K, matches, B, N, depth_thres, ws, Rt_cam, winner, counts);
+    else hipLaunchKernelGGL((cheirality_kernel<false, false>), dim3(B), dim3(threads), 0, st, E, pre, K, matches, B, N, depth_thres, ws, Rt_cam, winner, counts);
+  }
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
 extern "C" int dfepe_cheirality(const float* E, const float* pre, const float* K, const float* matches, int B, int N,
                                 float depth_thres, float* Rt_cam, int* winner, int* counts, void* stream) {
-  return dfepe_cheirality_ex(E, pre, K, matches, B, N, depth_thres, 0u, Rt_cam, winner, counts, stream);
+  return dfepe_cheirality_ex(E, pre, K, matches, B, N, depth_thres, 0u, nullptr, Rt_cam, winner, counts, stream);
 }

@@ -297,12 +297,11 @@ int dfepe_w8pt16_bwd_launch(const W8BwdArgs& A, bool raw, hipStream_t st) {
 extern "C" int dfepe_w8pt_fwd(const float* pts1, const float* pts2, const float* weights, int B, int N, int n_weight_sets, unsigned flags,
                               float image_w, float image_h, float clamp_at, float* F_out, float* residual, float* epi_res, float* save,
                               float* weights_out, void* stream);
-extern "C" int dfepe_cheirality(const float* E, const float* pre, const float* K, const float* matches, int B, int N, float depth_thres,
-                                float* Rt_cam, int* winner, int* counts, void* stream);
 
 extern "C" int dfepe_w8pt_pose_fwd(const float* matches, const float* weights, int B, int N, unsigned flags, float image_w, float image_h,
                                    float clamp_at, const float* K, const float* pre, float depth_thres, float* F_out, float* residual,
-                                   float* epi_res, float* weights_out, float* Rt_cam, int* winner, int* counts, void* stream) {
+                                   float* epi_res, float* weights_out, float* Rt_cam, int* winner, int* counts, void* workspace,
+                                   void* stream) {
   if (!(flags & DFEPE_W8PT_RAW_MATCHES) || (flags & ~(DFEPE_W8PT_RAW_MATCHES | DFEPE_W8PT_LOGITS | DFEPE_W8PT_ROW_PER_PAIR))) return DFEPE_ERR_INVALID_ARG;
   if (B < 0 || N <= 0) return DFEPE_ERR_INVALID_ARG;
   if (B == 0) return DFEPE_OK;
@@ -314,7 +313,7 @@ extern "C" int dfepe_w8pt_pose_fwd(const float* matches, const float* weights, i
     const int rc = dfepe_w8pt_fwd(matches, nullptr, weights, B, N, 1, flags, image_w, image_h, clamp_at, F_out, residual, epi_res, nullptr,
                                   weights_out, stream);
     if (rc != DFEPE_OK) return rc;
-    return dfepe_cheirality(F_out, pre, K, matches, B, N, depth_thres, Rt_cam, winner, counts, stream);
+    return dfepe_cheirality_ex(F_out, pre, K, matches, B, N, depth_thres, 0u, workspace, Rt_cam, winner, counts, stream);
   }
   W8FwdRest R;
   R.epi_res = epi_res; R.save = nullptr; R.weights_out = weights_out; R.logits_mode = (flags & DFEPE_W8PT_LOGITS) ? 1 : 0; R.variant = 0u;

@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from .ops import _ptr, _stream
+from .ops import _on, _ptr, _stream
 
 Tensor = torch.Tensor
 BF16 = torch.bfloat16
@@ -72,7 +72,7 @@ class _EstimatorFunction(torch.autograd.Function):
         B, C0, N = x.shape
         cols = B * N
         dev = x.device
-        with torch.cuda.device(dev):
+        with _on(dev):
             st = _stream()  # the current stream of x's device, read under its guard
             xin = x.detach().float().permute(0, 2, 1).reshape(cols, C0).contiguous()
             acts = [_split(xin, cols, C0, _pad32(C0), 3)]  # planes of every layer's input, point-major [3, cols, C]
@@ -135,7 +135,7 @@ class _EstimatorFunction(torch.autograd.Function):
         params = saved if ctx.has_head_bias else saved + [None]
         dev = g_logits.device
         grads: List[Optional[Tensor]] = [None] * len(params)
-        with torch.cuda.device(dev):
+        with _on(dev):
             st = _stream()
             Wh = params[4 * n_hidden]
             C = acts[-1].shape[2]

@@ -15,8 +15,37 @@ def _ptr(t: Optional[Tensor]):
     return None if t is None else t.data_ptr()
 
 
+# Host cost of a launch (scripts/eager_profile.py: the reference's eager call sequence is host-bound, ~50 launches per step):
+# torch.cuda.current_stream().cuda_stream builds a Stream object per call (~10 us) and torch.cuda.device() is a python context
+# manager doing two device queries (~8 us) -- the raw C entry points below do the same in well under a microsecond each.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> int:
+    """The current HIP stream of the current device, as the integer handle the C ABI takes."""
+    if _raw_stream is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _on(dev):
+    """`with _on(t.device):` = `with torch.cuda.device(t.device):` without the context-manager cost when that device is already
+    the current one (every call of a single-GPU process, and of a rank that called torch.cuda.set_device)."""
+    if _cur_device is not None and dev.index is not None and dev.index == _cur_device():
+        return _NO_GUARD
+    return torch.cuda.device(dev)
 
 
 def _prep(t: Tensor, name: str) -> Tensor:
@@ -167,7 +196,7 @@ def w8pt_forward(pts1: Tensor, pts2: Optional[Tensor], weights: Tensor, raw: boo
     epi = out("epi", (B, N), want_epi)
     save = torch.empty(B, L.dfepe_save_floats(), device=dev, dtype=torch.float32) if want_save else None
     w_out = out("weights", (B, N), logits)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = L.dfepe_w8pt_fwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, 1, _flags(raw, logits, row_per_pair, extra_flags), float(image_w),
                               float(image_h), float(clamp_at), _ptr(F), _ptr(residual), _ptr(epi), _ptr(save), _ptr(w_out), _stream())
     _lib.check(rc, "dfepe_w8pt_fwd")
@@ -186,7 +215,7 @@ def w8pt_backward(pts1, pts2, weights, raw, image_w, image_h, clamp_at, save, F,
     if want_pts:
         gP1 = torch.empty_like(pts1)
         gP2 = None if raw else torch.empty_like(pts2)
-    with torch.cuda.device(weights.device):
+    with _on(weights.device):
         rc = L.dfepe_w8pt_bwd(_ptr(pts1), _ptr(pts2), _ptr(weights), B, N, 1, _flags(raw, logits, row_per_pair, extra_flags), float(image_w), float(image_h),
                               float(clamp_at), _ptr(save), _ptr(F), _ptr(gF), _ptr(gRes), _ptr(gEpi), _ptr(gW_extra), _ptr(g_scale), _ptr(gW),
                               _ptr(gP1), _ptr(gP2), _ptr(pending_loss_head), _stream())
@@ -209,7 +238,7 @@ def eight_point(X: Tensor, Y: Tensor, w: Optional[Tensor], essential: bool, norm
     residual = torch.empty(B, N, device=X.device)
     flags = (_lib.W8PT_SQRT2 | _lib.W8PT_NO_ROWNORM | (_lib.W8PT_FORCE_110 if essential else 0) |
              (0 if normalize else _lib.W8PT_NO_HARTLEY))
-    with torch.cuda.device(X.device):
+    with _on(X.device):
         rc = L.dfepe_w8pt_fwd(_ptr(p1), _ptr(p2), _ptr(wt), B, N, 1, flags, 0.0, 0.0, 0.5, _ptr(F), _ptr(residual), None, None, None,
                               _stream())
     _lib.check(rc, "dfepe_w8pt_fwd")
@@ -229,7 +258,7 @@ def eight_point_rows(rows: Tensor, T1: Optional[Tensor], T2: Optional[Tensor], e
         _shape(T1, "T1", B, 3, 3)
         _shape(T2, "T2", B, 3, 3)
     F = torch.empty(B, 3, 3, device=rows.device)
-    with torch.cuda.device(rows.device):
+    with _on(rows.device):
         rc = _lib.lib().dfepe_w8pt_rows_fwd(_ptr(rows), B, N, _lib.W8PT_FORCE_110 if essential else 0, _ptr(T1), _ptr(T2), _ptr(F), _stream())
     _lib.check(rc, "dfepe_w8pt_rows_fwd")
     return F
@@ -333,7 +362,7 @@ class _FlossFunction(torch.autograd.Function):
             T1c, T2c, st1 = T1c.expand(B, 3, 3).contiguous(), T2c.expand(B, 3, 3).contiguous(), 9
         loss_sum = torch.empty(L, B, device=F_layers.device, dtype=torch.float32)
         E_layers = torch.empty(L, B, 3, 3, device=F_layers.device, dtype=torch.float32)
-        with torch.cuda.device(F_layers.device):
+        with _on(F_layers.device):
             rc = lib.dfepe_floss_fwd(_ptr(F_layers), L, B, _ptr(T1c), _ptr(T2c), st1, _ptr(K), _ptr(virt1), _ptr(virt2), M,
                                      float(clamp_at), _ptr(loss_sum), _ptr(E_layers), _stream())
         _lib.check(rc, "dfepe_floss_fwd")
@@ -350,7 +379,7 @@ class _FlossFunction(torch.autograd.Function):
         gF = torch.empty_like(F_layers)
         g_loss_sum = None if g_loss_sum is None else g_loss_sum.contiguous().float()
         g_E = None if g_E is None else g_E.contiguous().float()
-        with torch.cuda.device(F_layers.device):
+        with _on(F_layers.device):
             rc = lib.dfepe_floss_bwd(_ptr(F_layers), L, B, _ptr(T1c), _ptr(T2c), st, _ptr(K), _ptr(virt1), _ptr(virt2),
                                      virt1.shape[1], clamp_at, _ptr(g_loss_sum), 0.0, None, _ptr(g_E), _ptr(gF), _stream())
         _lib.check(rc, "dfepe_floss_bwd")
@@ -394,7 +423,7 @@ class _PoseFunction(torch.autograd.Function):
         ang = torch.empty(2, L, B, device=dev, dtype=torch.float32)
         sel = torch.empty(L, B, device=dev, dtype=torch.int32)
         q_l2, t_l2 = row_of(qt, 0), row_of(qt, 1)
-        with torch.cuda.device(dev):
+        with _on(dev):
             rc = lib.dfepe_pose_fwd(_ptr(E_layers), L, B, _ptr(q_gt), _ptr(t_gt), _ptr(R_gt), _ptr(q_l2), _ptr(t_l2),
                                     _ptr(ang[0]), _ptr(ang[1]), _ptr(sel), _stream())
         _lib.check(rc, "dfepe_pose_fwd")
@@ -415,7 +444,7 @@ class _PoseFunction(torch.autograd.Function):
         gE = torch.empty_like(E_layers)
         g_q = None if g_q is None else g_q.contiguous().float()
         g_t = None if g_t is None else g_t.contiguous().float()
-        with torch.cuda.device(E_layers.device):
+        with _on(E_layers.device):
             rc = lib.dfepe_pose_bwd(_ptr(E_layers), L, B, _ptr(q_gt), _ptr(t_gt), _ptr(g_q), _ptr(g_t), 0.0, 0.0, 0.0, 0.0, None,
                                     _ptr(gE), _stream())
         _lib.check(rc, "dfepe_pose_bwd")
@@ -462,7 +491,7 @@ def _stats_launch(sets, C: int, want_min: bool):
     args = []
     for x, sc in sets:
         args += [_ptr(x), 0 if x is None else x.shape[0], float(sc)]
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = _lib.lib().dfepe_loss_stats(*args, C, _ptr(out), _ptr(row_min), _ptr(col_min), _stream())
     _lib.check(rc, "dfepe_loss_stats")
     blocks, off = [], 0
@@ -551,7 +580,7 @@ class _TailJacFunction(torch.autograd.Function):
         sel = torch.empty(L, B, device=dev, dtype=torch.int32) if pose else None
         q_l2 = row_of(qt, 0) if pose else None
         t_l2 = row_of(qt, 1) if pose else None
-        with torch.cuda.device(dev):
+        with _on(dev):
             rc = lib.dfepe_loss_tail_jac(_ptr(F_layers), L, B, _ptr(T1c), _ptr(T2c), t_stride, _ptr(K), _ptr(virt1), _ptr(virt2), M,
                                          float(clamp_at), _ptr(q_gt), _ptr(t_gt), _ptr(R_gt), 1 if want_floss_jac else 0, _ptr(loss_sum),
                                          _ptr(E_layers), _ptr(q_l2), _ptr(t_l2), _ptr(ang[0]) if pose else None,
@@ -581,7 +610,7 @@ class _TailJacFunction(torch.autograd.Function):
                                   "arrived on loss_F / loss_layers")
         c = lambda g: None if g is None else g.contiguous().float()
         gF = torch.empty(L, B, 3, 3, device=J.device, dtype=torch.float32)
-        with torch.cuda.device(J.device):
+        with _on(J.device):
             rc = lib.dfepe_loss_tail_bwd(_ptr(J), L, B, _ptr(c(g_loss_sum)), _ptr(c(g_q)), _ptr(c(g_t)), _ptr(c(gm_loss)), _ptr(c(go_loss)),
                                          _ptr(c(gm_q)), _ptr(c(go_q)), _ptr(c(gm_t)), _ptr(c(go_t)), float(loss_scale), _ptr(gF), _stream())
             _lib.check(rc, "dfepe_loss_tail_bwd")
@@ -640,7 +669,7 @@ class _EpiResidualFunction(torch.autograd.Function):
     def forward(ctx, pts1, pts2, F, clamp_at):
         B, N = pts1.shape[0], pts1.shape[1]
         out = torch.empty(B, N, device=pts1.device, dtype=torch.float32)
-        with torch.cuda.device(pts1.device):
+        with _on(pts1.device):
             rc = _lib.lib().dfepe_epi_residual_fwd(_ptr(pts1), _ptr(pts2), _ptr(F), B, N, float(clamp_at), _ptr(out), _stream())
         _lib.check(rc, "dfepe_epi_residual_fwd")
         ctx.save_for_backward(pts1, pts2, F)
@@ -653,7 +682,7 @@ class _EpiResidualFunction(torch.autograd.Function):
         B, N = pts1.shape[0], pts1.shape[1]
         gF = torch.empty_like(F)
         g = g.contiguous().float()
-        with torch.cuda.device(pts1.device):
+        with _on(pts1.device):
             rc = _lib.lib().dfepe_epi_residual_bwd(_ptr(pts1), _ptr(pts2), _ptr(F), B, N, ctx.clamp_at, _ptr(g), _ptr(gF), _stream())
         _lib.check(rc, "dfepe_epi_residual_bwd")
         return None, None, gF, None
@@ -678,7 +707,7 @@ def epi_metrics(kind: int, F: Tensor, X: Tensor, Y: Tensor, clamp_at: Optional[f
     kind = int(kind) | (_lib.EPI_HOMOGENEOUS if X.shape[2] == 3 else 0)
     clamp_at = -1.0 if clamp_at is None else float(clamp_at)
     out = torch.empty((3, B, N) if (kind & 7) == 2 else (B, N), device=X.device, dtype=torch.float32)
-    with torch.cuda.device(X.device):
+    with _on(X.device):
         rc = _lib.lib().dfepe_epi_metrics(int(kind), _ptr(F), _ptr(X), _ptr(Y), B, N, float(clamp_at), float(eps), _ptr(out), _stream())
     _lib.check(rc, "dfepe_epi_metrics")
     return out
@@ -692,7 +721,7 @@ def geo_misc(kind: int, in0: Tensor, in1: Optional[Tensor] = None) -> Tensor:
     in1 = None if in1 is None else _prep(in1, "in1")
     n = in0.shape[0]
     out = torch.empty(n, _GEO_OUT[kind], device=in0.device, dtype=torch.float32)
-    with torch.cuda.device(in0.device):
+    with _on(in0.device):
         rc = _lib.lib().dfepe_geo_misc(int(kind), _ptr(in0), _ptr(in1), n, _ptr(out), _stream())
     _lib.check(rc, "dfepe_geo_misc")
     return out
@@ -725,7 +754,7 @@ class _RowDotFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         n, B, N = a.shape
         out = torch.empty(n, B, device=a.device, dtype=torch.float32)
-        with torch.cuda.device(a.device):
+        with _on(a.device):
             rc = _lib.lib().dfepe_row_dot(_ptr(a), a.stride(0), _ptr(b), b.stride(0), n, B, N, _ptr(out), _stream())
         _lib.check(rc, "dfepe_row_dot")
         ctx.save_for_backward(a, b)
@@ -796,13 +825,13 @@ def deepf_input(matches: Tensor, image_w: float, image_h: float, quality: Option
     if recurrent_copies > 0:
         C = 4 + Q + recurrent_channels
         buf = torch.empty(recurrent_copies + 1, C, B, N, device=dev, dtype=torch.float32)  # copy 0 serves the first estimator call
-        with torch.cuda.device(dev):
+        with _on(dev):
             rc = lib.dfepe_deepf_input(_ptr(m), _ptr(quality), B, N, Q, float(image_w), float(image_h), _ptr(buf), B * N, N,
                                        recurrent_copies + 1, C * B * N, _ptr(p1), _ptr(p2), _stream())
         _lib.check(rc, "dfepe_deepf_input")
         return buf[0, :4 + Q].permute(1, 0, 2), p1, p2, buf[1:]
     w_in = torch.empty(B, 4 + Q, N, device=dev, dtype=torch.float32)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.dfepe_deepf_input(_ptr(m), _ptr(quality), B, N, Q, float(image_w), float(image_h), _ptr(w_in), N, (4 + Q) * N, 1, 0,
                                    _ptr(p1), _ptr(p2), _stream())
     _lib.check(rc, "dfepe_deepf_input")
@@ -841,11 +870,18 @@ def decompose_essential(E: Tensor):
     return o[:, 0:9].reshape(-1, 3, 3), o[:, 9:18].reshape(-1, 3, 3), o[:, 18:21]
 
 
-def cheirality(E: Tensor, K: Tensor, matches: Tensor, depth_thres: float = 50.0, pre: Optional[Tensor] = None, fp64_only: bool = False):
+def _cheirality_workspace(B: int, dev) -> Tensor:
+    """Per-call scratch of dfepe_cheirality_ex (the per-pair constants its preparation launch leaves for the main kernel)."""
+    return torch.empty((_lib.lib().dfepe_cheirality_workspace_bytes(B) + 7) // 8, dtype=torch.float64, device=dev)
+
+
+def cheirality(E: Tensor, K: Tensor, matches: Tensor, depth_thres: float = 50.0, pre: Optional[Tensor] = None, fp64_only: bool = False,
+               prepared: bool = True):
     """E, K [B,3,3], matches [B,N,4] pixels -> (Rt_cam [B,3,4], winner [B] int32, counts [B,4] int32).
     ``pre`` [B,3,3]: decompose pre^T E pre instead (E = F and pre = T K fuses E-from-F into the launch).
     ``fp64_only``: every correspondence through the fp64 route (DFEPE_CHEIR_FP64_ONLY: the reference the adaptive default is
-    tested against for exact equality of the counts)."""
+    tested against for exact equality of the counts).  ``prepared``: form the per-pair constants in a preparation launch (one lane
+    per pair) instead of in every wavefront of the main kernel; same outputs bit for bit."""
     E, K, m = _prep(E, "E"), _prep(K, "K"), _prep(matches, "matches")
     pre = None if pre is None else _prep(pre, "pre")
     _shape(m, "matches (pixel x1,y1,x2,y2)", None, None, 4)
@@ -857,9 +893,10 @@ def cheirality(E: Tensor, K: Tensor, matches: Tensor, depth_thres: float = 50.0,
     Rt = torch.empty(B, 3, 4, device=m.device, dtype=torch.float32)
     win = torch.empty(B, device=m.device, dtype=torch.int32)
     cnt = torch.empty(B, 4, device=m.device, dtype=torch.int32)
-    with torch.cuda.device(m.device):
+    ws = _cheirality_workspace(B, m.device) if prepared else None
+    with _on(m.device):
         rc = _lib.lib().dfepe_cheirality_ex(_ptr(E), _ptr(pre), _ptr(K), _ptr(m), B, N, float(depth_thres),
-                                            _lib.CHEIR_FP64_ONLY if fp64_only else 0, _ptr(Rt), _ptr(win), _ptr(cnt), _stream())
+                                            _lib.CHEIR_FP64_ONLY if fp64_only else 0, _ptr(ws), _ptr(Rt), _ptr(win), _ptr(cnt), _stream())
     _lib.check(rc, "dfepe_cheirality_ex")
     return Rt, win, cnt
 
@@ -885,10 +922,11 @@ def fit_pose(matches: Tensor, weights: Tensor, K: Tensor, image_w: float, image_
     Rt = torch.empty(B, 3, 4, device=dev)
     win = torch.empty(B, device=dev, dtype=torch.int32)
     cnt = torch.empty(B, 4, device=dev, dtype=torch.int32)
-    with torch.cuda.device(dev):
+    ws = _cheirality_workspace(B, dev)
+    with _on(dev):
         rc = _lib.lib().dfepe_w8pt_pose_fwd(_ptr(m), _ptr(w), B, N, _flags(True, logits, row_per_pair), float(image_w), float(image_h), float(clamp_at),
                                             _ptr(K), _ptr(pre), float(depth_thres), _ptr(F), _ptr(residual), _ptr(epi), _ptr(w_out), _ptr(Rt), _ptr(win),
-                                            _ptr(cnt), _stream())
+                                            _ptr(cnt), _ptr(ws), _stream())
     _lib.check(rc, "dfepe_w8pt_pose_fwd")
     return F, residual, epi, w_out, Rt, win, cnt
 
@@ -916,7 +954,7 @@ def metrics_summary(epi_est: Tensor, epi_gt: Optional[Tensor], err_q: Tensor, er
     L = _lib.lib()
     nbytes = int(L.dfepe_metrics_summary_bytes())
     out = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=e.device)
-    with torch.cuda.device(e.device):
+    with _on(e.device):
         rc = L.dfepe_metrics_summary(_ptr(e) if e.numel() else None, _ptr(g), e.numel(), _ptr(q), _ptr(t), q.numel(), _ptr(out), _stream())
     _lib.check(rc, "dfepe_metrics_summary")
     raw = out.cpu().numpy().tobytes()[:nbytes]
@@ -946,7 +984,7 @@ class _InormLReLUFunction(torch.autograd.Function):
         C, R, N = Y.shape
         A = torch.empty_like(Y)
         stats = torch.empty(C * R, 2, device=Y.device, dtype=torch.float32)
-        with torch.cuda.device(Y.device):
+        with _on(Y.device):
             rc = _lib.lib().dfepe_inorm_lrelu_fwd(_ptr(Y), _ptr(gamma), _ptr(beta), C, R, N, float(eps), float(slope), _ptr(A),
                                                   _ptr(stats), _stream())
         _lib.check(rc, "dfepe_inorm_lrelu_fwd")
@@ -963,7 +1001,7 @@ class _InormLReLUFunction(torch.autograd.Function):
         gY = torch.empty_like(Y)
         rg = torch.empty(C, R, device=Y.device, dtype=torch.float32)
         rb = torch.empty(C, R, device=Y.device, dtype=torch.float32)
-        with torch.cuda.device(Y.device):
+        with _on(Y.device):
             rc = _lib.lib().dfepe_inorm_lrelu_bwd(_ptr(Y), _ptr(gA), _ptr(gamma), _ptr(beta), _ptr(stats), C, R, N, ctx.slope,
                                                   _ptr(gY), _ptr(rg), _ptr(rb), _stream())
         _lib.check(rc, "dfepe_inorm_lrelu_bwd")
@@ -1002,7 +1040,7 @@ def nn_match_two_way(desc1: Tensor, desc2: Tensor, nn_thresh: float):
     sc = torch.empty(B, max(N1, 1), device=dev, dtype=torch.float32)
     cnt = torch.empty(B, device=dev, dtype=torch.int32)
     ws = torch.empty(max(int(L.dfepe_nn_match_workspace_bytes(B, N1, N2)) // 8, 1), device=dev, dtype=torch.int64)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = L.dfepe_nn_match_two_way(_ptr(d1), _ptr(d2), B, N1, N2, D, float(nn_thresh), _ptr(ws), _ptr(m1), _ptr(m2), _ptr(sc),
                                       _ptr(cnt), _stream())
     _lib.check(rc, "dfepe_nn_match_two_way")
@@ -1024,7 +1062,7 @@ def gather_matches(pts1: Tensor, pts2: Tensor, off1: Optional[Tensor], off2: Opt
     xs = torch.empty(B, n_out, 4, device=dev)
     offs = torch.empty(B, n_out, 4, device=dev) if o1 is not None else None
     q = torch.empty(B, n_out, 1, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = _lib.lib().dfepe_gather_matches(_ptr(p1), _ptr(p2), _ptr(o1), _ptr(o2), B, N1, N2, _ptr(m_idx1), _ptr(m_idx2), _ptr(score),
                                              _ptr(choice), n_out, _ptr(xs), _ptr(offs), _ptr(q), _stream())
     _lib.check(rc, "dfepe_gather_matches")

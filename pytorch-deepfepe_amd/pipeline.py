@@ -95,7 +95,7 @@ class _HotPathFunction(torch.autograd.Function):
         flags = _lib.W8PT_RAW_MATCHES | _lib.W8PT_LOGITS
         st = ops._stream()
         gF = None
-        with torch.cuda.device(dev):
+        with ops._on(dev):
             if batched:  # the L weightings of the same pairs in ONE launch (n_weight_sets = L): no per-layer launch tails
                 rc = lib.dfepe_w8pt_fwd(matches.data_ptr(), None, logits_layers.data_ptr(), B, N, L, flags, W, H, 0.5,
                                         F_layers.data_ptr(), residuals.data_ptr(), epis.data_ptr(), saves.data_ptr(),
@@ -199,7 +199,7 @@ class _HotPathFunction(torch.autograd.Function):
         flags = _lib.W8PT_RAW_MATCHES | _lib.W8PT_LOGITS
         g_logits = torch.empty(L, B, N, device=dev)
         n = float(grad_pairs if grad_pairs else B)
-        with torch.cuda.device(dev):
+        with ops._on(dev):
             if ctx.fused_tail:
                 gF = ctx.saved_tensors[11]  # d loss / d F with unit upstream; w8pt_bwd applies g_scale
                 gs_ptr = g_scale.data_ptr()

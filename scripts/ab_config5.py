@@ -20,7 +20,14 @@ for path in sys.argv[1:3]:
     L.dfepe_cheirality.restype = I
     L.dfepe_cheirality.argtypes = [P, P, P, P, I, I, F, P, P, P, P]
     L.dfepe_w8pt_pose_fwd.restype = I
-    L.dfepe_w8pt_pose_fwd.argtypes = [P, P, I, I, U, F, F, F, P, P, F, P, P, P, P, P, P, P, P]
+    new_abi = hasattr(L, "dfepe_cheirality_ex")
+    L.dfepe_w8pt_pose_fwd.argtypes = [P, P, I, I, U, F, F, F, P, P, F, P, P, P, P, P, P, P] + ([P, P] if new_abi else [P])
+    if new_abi:
+        L.dfepe_cheirality_ex.restype = I
+        L.dfepe_cheirality_ex.argtypes = [P, P, P, P, I, I, F, U, P, P, P, P, P]
+        L.dfepe_cheirality_workspace_bytes.restype = ctypes.c_size_t
+        L.dfepe_cheirality_workspace_bytes.argtypes = [I]
+    L.new_abi = new_abi
     L.dfepe_w8pt_fwd.restype = I
     L.dfepe_w8pt_fwd.argtypes = [P, P, P, I, I, I, U, F, F, F, P, P, P, P, P, P]
     libs.append(L)
@@ -68,21 +75,31 @@ for B in sizes:
     def fit(L):
         assert L.dfepe_w8pt_fwd(m.data_ptr(), None, w0.data_ptr(), B, N, 1, 1, W, H, 0.5, Fo.data_ptr(), res.data_ptr(), epi.data_ptr(), None, None, st()) == 0
 
+    wsb = [torch.empty(B * 56, device=dev, dtype=torch.float64) if L.new_abi else None for L in libs]
+
     def cheir(k):
+        L, (Rt, win, cnt) = libs[k], outs[k]
+        if L.new_abi:  # with the preparation launch (the package's default)
+            assert L.dfepe_cheirality_ex(Fo.data_ptr(), TK.data_ptr(), K.data_ptr(), m.data_ptr(), B, N, 50.0, 0, wsb[k].data_ptr(), Rt.data_ptr(), win.data_ptr(), cnt.data_ptr(), st()) == 0
+        else:
+            assert L.dfepe_cheirality(Fo.data_ptr(), TK.data_ptr(), K.data_ptr(), m.data_ptr(), B, N, 50.0, Rt.data_ptr(), win.data_ptr(), cnt.data_ptr(), st()) == 0
+
+    def cheir_noprep(k):
         L, (Rt, win, cnt) = libs[k], outs[k]
         assert L.dfepe_cheirality(Fo.data_ptr(), TK.data_ptr(), K.data_ptr(), m.data_ptr(), B, N, 50.0, Rt.data_ptr(), win.data_ptr(), cnt.data_ptr(), st()) == 0
 
     def both(k):
         L, (Rt, win, cnt) = libs[k], outs[k]
+        tail = (wsb[k].data_ptr(), st()) if L.new_abi else (st(),)
         assert L.dfepe_w8pt_pose_fwd(m.data_ptr(), w0.data_ptr(), B, N, 1, W, H, 0.5, K.data_ptr(), TK.data_ptr(), 50.0, Fo.data_ptr(), res.data_ptr(),
-                                     epi.data_ptr(), None, Rt.data_ptr(), win.data_ptr(), cnt.data_ptr(), st()) == 0
+                                     epi.data_ptr(), None, Rt.data_ptr(), win.data_ptr(), cnt.data_ptr(), *tail) == 0
 
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         fit(libs[1])
         res_t = {}
-        for name, fn in (("fit alone", lambda k: fit(libs[k])), ("cheirality alone", cheir), ("fit + pose call", both)):
+        for name, fn in (("fit alone", lambda k: fit(libs[k])), ("cheirality alone", cheir), ("cheirality, in-kernel prep", cheir_noprep), ("fit + pose call", both)):
             ts = [[], []]
             for rnd in range(3):
                 for k in range(2):
@@ -91,7 +108,7 @@ for B in sizes:
         torch.cuda.synchronize()
     torch.cuda.current_stream().wait_stream(side)
     for name, (a, b) in res_t.items():
-        print(f"B={B:5d} N={N}  {name:18s}  A {a:8.2f} us   B {b:8.2f} us   B/A {b / a:.3f}", flush=True)
+        print(f"B={B:5d} N={N}  {name:27s}  A {a:8.2f} us   B {b:8.2f} us   B/A {b / a:.3f}", flush=True)
     cheir(0); cheir(1)
     torch.cuda.synchronize()
     ca, cb = outs[0][2], outs[1][2]

@@ -111,5 +111,8 @@ def test_cheirality_adaptive_counts_equal_the_fp64_route_exactly(dfepe, B, N, ou
         diff = (a[2] != b[2]).any(dim=1)
         assert not bool(diff.any()), (int(diff.sum()), a[2][diff][:4].tolist(), b[2][diff][:4].tolist())
         assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])
+        # the per-pair constants from the preparation launch (default) or formed inside the main kernel: the same bits
+        c = dfepe.ops.cheirality(E, d["Ks"], d["matches_xy_ori"], thr, prepared=False)
+        assert torch.equal(a[2], c[2]) and torch.equal(a[1], c[1]) and torch.equal(a[0], c[0])
         n_amb_pairs += int((a[2].sum(1) > 0).sum())
     assert n_amb_pairs > B  # the scenes are not degenerate: most pairs have correspondences in front of some candidate
