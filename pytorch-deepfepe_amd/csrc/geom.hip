@@ -1,6 +1,8 @@
 // Stand-alone geometry entry points of the dsac_tools API: epipolar residual / metrics, small pose helpers,
 // cheirality-checked pose selection.  These sit on either side of the solver.
 #include "dfepe_common.h"
+#include <cstdlib>
+
 #include "cheirality_body.h"
 
 namespace {
@@ -378,10 +380,14 @@ extern "C" int dfepe_cheirality_ex(const float* E, const float* pre, const float
   if (B == 0) return DFEPE_OK;
   if (!E || !K || !matches || !Rt_cam) return DFEPE_ERR_INVALID_ARG;
   if ((reinterpret_cast<uintptr_t>(matches) & 15u) || (reinterpret_cast<uintptr_t>(workspace) & 7u)) return DFEPE_ERR_INVALID_ARG;
-  // wavefronts per pair: throughput wants one (B >= 2048: every SIMD already holds >= 2 pairs), latency wants as many as the pair
-  // has groups of 64 correspondences, up to eight (at <= 128 registers a CU holds two such workgroups)
+  // wavefronts per pair: throughput wants one (B >= 2048: every SIMD already holds >= 2 pairs), latency wants several -- four:
+  // eight were measured slower at 512 x 1000 (24.8 against 20.7 us: every wavefront ends with a pass of its own few ambiguous
+  // correspondences through the fp64 route, which costs what a full group of 64 does, and a pair has eight such passes then)
   const int groups = (N + 63) / 64;
-  const int threads = (B >= 2048) ? 64 : 64 * (groups < 8 ? groups : 8);
+  // (A/B switch, read once: DFEPE_CHEIR_WAVES = wavefronts per pair below 2048 pairs)
+  static const int forced_waves = [] { const char* e = getenv("DFEPE_CHEIR_WAVES"); return e ? atoi(e) : 0; }();
+  const int wmax = (forced_waves >= 1 && forced_waves <= 8) ? forced_waves : 4;
+  const int threads = (B >= 2048) ? 64 : 64 * (groups < wmax ? groups : wmax);
   hipStream_t st = static_cast<hipStream_t>(stream);
   double* ws = static_cast<double*>(workspace);
   const bool f64 = (flags & DFEPE_CHEIR_FP64_ONLY) != 0;

@@ -20,6 +20,13 @@ constexpr int kCoopMaxN = 2048;  // cooperative workgroup per pair: N / 256 corr
 constexpr int kCoopMaxPairs = 3072;
 // the forward and the backward agree on this by construction (same N, same pair count, same flag), and the `save` record is the
 // same either way
+// the lean forward fit (<= 256 registers) from this many pairs on: 8192 pairs are two wavefronts per SIMD.  DFEPE_FIT_LEAN = 0 / 1 in the
+// environment forces it off / on (A/B timing; the outputs are bit-identical either way)
+constexpr int kLeanMinPairs = 8192;
+static bool use_lean(int pairs) {
+  static const int forced = [] { const char* e = getenv("DFEPE_FIT_LEAN"); return e ? atoi(e) : -1; }();
+  return forced < 0 ? pairs >= kLeanMinPairs : forced != 0;
+}
 static bool use_coop(int N, int pairs, bool row_per_pair) { return N > 128 && N <= kCoopMaxN && pairs <= kCoopMaxPairs && !row_per_pair; }
 
 // Kernel arguments (forward and backward alike): what a wavefront needs before it can issue its global loads comes first, as plain scalars / pointers --
@@ -47,6 +54,23 @@ w8pt16_fwd_kernel(const float* pts1, const float* pts2, const float* wts, int B,
   A.clamp_at = clamp_at; A.F_out = F_out; A.residual = residual; A.epi_res = R.epi_res; A.save = R.save;
   A.weights_out = R.weights_out; A.logits_mode = R.logits_mode; A.variant = R.variant; A.row_per_pair = false;
   w8pt16_fwd_pair<IT, RAW, PLAIN>(A, pair, xch + row * 36);
+}
+
+// The same kernel in <= 256 registers (w8pt16_body.h: LEAN): two wavefronts per SIMD.  Taken from kLeanMinPairs pairs on, where a
+// SIMD has a second wavefront to hold (at 4096 pairs = one wavefront per SIMD the few extra instructions would only cost).
+template <int IT, bool RAW, bool PLAIN>
+__global__ void __launch_bounds__(256, 2)
+w8pt16_fwd_lean_kernel(const float* pts1, const float* pts2, const float* wts, int B, int Bm, int N, float hw_sx, float hw_sy,
+                       float clamp_at, float* F_out, float* residual, const W8FwdRest R) {
+  __shared__ double xch[kPairsPerBlock * 36];
+  const int row = (int)(threadIdx.x >> 4);
+  const int pair = (int)blockIdx.x * kPairsPerBlock + row;
+  if (pair >= B) return;
+  W8Args A;
+  A.pts1 = pts1; A.pts2 = pts2; A.wts = wts; A.B = B; A.Bm = Bm; A.N = N; A.hw_sx = hw_sx; A.hw_sy = hw_sy;
+  A.clamp_at = clamp_at; A.F_out = F_out; A.residual = residual; A.epi_res = R.epi_res; A.save = R.save;
+  A.weights_out = R.weights_out; A.logits_mode = R.logits_mode; A.variant = R.variant; A.row_per_pair = false;
+  w8pt16_fwd_pair<IT, RAW, PLAIN, 1, true>(A, pair, xch + row * 36);
 }
 
 // Cooperative variant: one 256-thread workgroup (16 rows) per pair, for N > 128 (w8pt16_body.h: W8Coop).
@@ -188,7 +212,14 @@ void launch_fwd(const W8Args& A, hipStream_t st) {
   else if (N <= 16) DFEPE_FWD(1);
   else if (N <= 32) DFEPE_FWD(2);
   else if (N <= 64) DFEPE_FWD(4);
-  else if (N <= 112) DFEPE_FWD(7);
+  else if (use_lean(A.B)) {  // 65 .. 128 correspondences at >= kLeanMinPairs pairs: the <= 256-register build, two wavefronts per SIMD
+#define DFEPE_LFWD(IT_)                                                                                                    \
+  hipLaunchKernelGGL((w8pt16_fwd_lean_kernel<IT_, RAW, PLAIN>), grid, block, 0, st, A.pts1, A.pts2, A.wts, A.B, A.Bm, A.N, A.hw_sx, \
+                     A.hw_sy, A.clamp_at, A.F_out, A.residual, R)
+    if (N <= 112) DFEPE_LFWD(7);
+    else DFEPE_LFWD(8);
+#undef DFEPE_LFWD
+  } else if (N <= 112) DFEPE_FWD(7);
   else DFEPE_FWD(8);
 #undef DFEPE_FWD
 }

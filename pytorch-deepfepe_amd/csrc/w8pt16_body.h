@@ -331,34 +331,47 @@ __device__ __forceinline__ void eig9_select(double* Ar, const int l, const int k
   DFEPE_MARK("P4c_twisted");
   // eigenvector of T by twisted factorisation: pivots from the top (dp) and from the bottom (dm), twist where
   // gamma_k = dp_k + dm_k - (d_k - lam) is smallest in magnitude
-  double dp[9], dm[9], rp[9], rm[9];
-  dp[0] = td[0] - lam;
+  // The bottom-up sweep first, keeping only what the rest needs of it: its pivots (for the twist search) and the products
+  // te[k-1] / dm[k] (for z below the twist).  The top-down sweep then runs FUSED with the twist search -- gamma_k is formed the
+  // moment dp_k exists, after which that pivot of the bottom-up sweep is dead -- and keeps te[k] / dp[k] only: ~18 live doubles at
+  // the peak instead of the 36 of two stored sweeps (round 5: what a <= 256-register build of the N <= 112 kernel needed).
+  // Same operations in the same order as two stored sweeps: bit-identical z.
+  double dmv[9], cm[9], cp[8];
+  {
+    double d = td[8] - lam;  // dm[8]
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    dp[k] = pivot_guard(dp[k]);
-    rp[k] = rcp_nr<1, false>(dp[k]);  // one Newton step from the fp32 seed: ~2e-14, far inside what the eigenvector needs
-    dp[k + 1] = (td[k + 1] - lam) - te2[k] * rp[k];
-  }
-  dm[8] = td[8] - lam;
-#pragma unroll
-  for (int k = 7; k >= 0; --k) {
-    dm[k + 1] = pivot_guard(dm[k + 1]);
-    rm[k + 1] = rcp_nr<1, false>(dm[k + 1]);
-    dm[k] = (td[k] - lam) - te2[k] * rm[k + 1];
+    for (int k = 7; k >= 0; --k) {
+      d = pivot_guard(d);
+      dmv[k + 1] = d;
+      const double r = rcp_nr<1, false>(d);
+      cm[k + 1] = te[k] * r;
+      d = (td[k] - lam) - te2[k] * r;
+    }
+    dmv[0] = d;
   }
   twist = 0;
-  double gbest = fabs(dp[0] + dm[0] - (td[0] - lam));
+  double gbest;
+  {
+    double d = td[0] - lam;  // dp[0]
 #pragma unroll
-  for (int k = 1; k < 9; ++k) {
-    const double g = fabs(dp[k] + dm[k] - (td[k] - lam));
-    if (g < gbest) { gbest = g; twist = k; }
+    for (int k = 0; k < 9; ++k) {
+      if (k < 8) d = pivot_guard(d);
+      const double g = fabs(d + dmv[k] - (td[k] - lam));
+      if (k == 0) gbest = g;
+      else if (g < gbest) { gbest = g; twist = k; }
+      if (k < 8) {
+        const double r = rcp_nr<1, false>(d);  // one Newton step from the fp64 seed: ~2e-14, far inside what the eigenvector needs
+        cp[k] = te[k] * r;
+        d = (td[k + 1] - lam) - te2[k] * r;
+      }
+    }
   }
 #pragma unroll
   for (int k = 0; k < 9; ++k) z[k] = (k == twist) ? 1.0 : 0.0;
 #pragma unroll
-  for (int k = 7; k >= 0; --k) z[k] = (k < twist) ? -(te[k] * rp[k]) * z[k + 1] : z[k];
+  for (int k = 7; k >= 0; --k) z[k] = (k < twist) ? -cp[k] * z[k + 1] : z[k];
 #pragma unroll
-  for (int k = 1; k < 9; ++k) z[k] = (k > twist) ? -(te[k - 1] * rm[k]) * z[k - 1] : z[k];
+  for (int k = 1; k < 9; ++k) z[k] = (k > twist) ? -cm[k] * z[k - 1] : z[k];
   double zn = 0.0;
 #pragma unroll
   for (int k = 0; k < 9; ++k) zn = fma(z[k], z[k], zn);
@@ -399,9 +412,15 @@ struct W8Coop {
 // kernel is bound by the issue of its 21 000 instructions per wavefront, not by the 4.6 TB/s of re-reads it generates.  Reverted.)
 // xch: 36 doubles of LDS owned by this pair.
 // PLAIN: none of the textbook-solver variant flags is set (the hot instantiation carries no test for them).
-template <int IT, bool RAW, bool PLAIN, int ROWS = 1>
+// LEAN (IT > 0, one row per pair): the <= 256-register build for batches of >= 8192 pairs, where a SIMD holds two wavefronts if they
+// fit (round 5).  The coordinates of the lane's correspondences and their 1 / |p| are NOT kept from the moments phase to the output
+// phase -- the stretch that holds the eigen solve and the rank-2 step, the kernel's register peak -- but fetched again (an L2 hit:
+// this very wavefront read them at its start) and re-derived by the same expressions: bit-identical outputs, ~120 more instructions,
+// 45 registers fewer.  (A register cap alone makes the compiler spill exactly these values to scratch memory and back.)
+template <int IT, bool RAW, bool PLAIN, int ROWS = 1, bool LEAN = false>
 __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair, double* xch, W8Coop* co = nullptr, const int rowid = 0) {
   static_assert(ROWS == 1 || (ROWS == 16 && IT > 0), "one row per pair, or the 16 rows of a workgroup with the correspondences in registers");
+  static_assert(!LEAN || (IT > 0 && ROWS == 1), "the lean build is a variant of the registers-resident row kernel");
   constexpr int S = 16 * ROWS;  // lanes per pair
   const int l = rg_lane();
   const int L = rowid * 16 + l;  // lane within the pair
@@ -588,7 +607,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     // (w / max(|p|, 1e-12))^2; a dropped or padding correspondence has w = 0 and contributes exact zeros.  1 / |p| is kept
     // for the residual of phase 6 when the correspondences live in registers.
     const double inv = fmin(rsqrt_nr<1, !RAW>(n2), 1e12);  // ~2e-14: it only scales a weight; RAW: n2 >= 1
-    if constexpr (IT > 0) invs[it] = inv;
+    if constexpr (IT > 0 && !LEAN) invs[it] = inv;
     const double wi = (variant & DFEPE_W8PT_NO_ROWNORM) ? w : w * inv;
     const double k2 = wi * wi;
     const double aa[6] = {a0 * a0, a0 * a1, a0 * a2, a1 * a1, a1 * a2, a2 * a2};
@@ -669,6 +688,37 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   double z[9], td[9], te[8], hv[7], hb[7], lam;
   int twist;
   eig9_select(Ar, l, kth, f, z, twist, lam, td, te, hv, hb);
+  // The `save` record: everything but the reflector components is uniform over the row, and lane s of {0, 1, 2, 8..15} assembles
+  // floats 8 s .. 8 s + 7 of it with one select per float (see the stores below).  The pieces are folded into the lane's slice AS
+  // SOON AS THEY ARE FINAL (round 5) -- the tridiagonal, the eigenvalue and the reflector scales right here, z and f after the
+  // orientation, the singular triplet after the rank-2 step -- so that 9 + 8 + 1 + 7 doubles stop being live across the rank-2 step:
+  // the peak of the kernel's register use was there (289 -> <= 256 registers: two wavefronts per SIMD for batches >= 8192 pairs).
+  const bool saving = A.save != nullptr;
+  float slice[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) slice[c] = 0.0f;
+  auto put = [&](const int idx, const float v) {  // idx is a literal after unrolling: slice[] is indexed at compile time
+    slice[idx & 7] = ((idx >> 3) == l) ? v : slice[idx & 7];
+  };
+  auto put2 = [&](const int idx, const double v) {  // a double in two consecutive floats
+    typedef float f32x2 __attribute__((vector_size(8)));
+    const f32x2 h = __builtin_bit_cast(f32x2, v);
+    put(idx, h[0]);
+    put(idx + 1, h[1]);
+  };
+  float hvf[7];
+  if (saving) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) put2(S16_TD + 2 * c, td[c]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) put2(S16_TE + 2 * c, te[c]);
+    put2(S16_LAM, lam);
+    put(S16_TWIST, (float)twist);
+#pragma unroll
+    for (int c = 0; c < 7; ++c) { put(S16_HB + c, (float)hb[c]); hvf[c] = (float)hv[c]; }
+    put(S16_INVTR, (float)inv_tr);
+    put(S16_TAG, S16_TAG_VALUE);
+  }
 
   DFEPE_MARK("P5");
   // ---- phase 5: orientation, rank-2 projection, de-normalisation (uniform over the row) -------------------------
@@ -683,6 +733,10 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   const double fscale = sgn * rsqrt_nr<2, false>(fn2);  // a unit vector up to rounding
 #pragma unroll
   for (int c = 0; c < 9; ++c) f[c] *= fscale;
+  if (saving) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { put(S16_F + c, (float)f[c]); put(S16_Z + c, (float)(sgn * z[c])); }
+  }
 
   DFEPE_MARK("P5b_rank2");
   // rank-2 step: F' = F - s3 u3 v3^T with the smallest singular triplet in closed form (fp64)
@@ -731,42 +785,17 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   }
 
   DFEPE_MARK("P5s_save");
-  if (A.save != nullptr) {
+  if (saving) {
     float* sv = static_cast<float*>(__builtin_assume_aligned(A.save, 16)) + (size_t)pair * DFEPE_SAVE_FLOATS;
-    // Everything but the reflector components is uniform over the row.  Under load a global store INSTRUCTION costs this lone
-    // wavefront 50-70 cycles whatever its width or the number of lanes behind it (scripts/ubench/lat2.hip), a select 5: so the
-    // uniform part (floats 0..23 and 64..127 of the record) leaves in TWO instructions -- lane s of {0, 1, 2, 8..15} assembles
-    // floats 8 s .. 8 s + 7 with one select per float (~95 v_cndmask) and stores them as two 16-byte pieces -- instead of the
-    // 26 stores a lane per piece needed (rounds 2-3).  Floats 24..63 hold only reflector components, which live in their lanes.
-    float slice[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) slice[c] = 0.0f;
-    auto put = [&](const int idx, const float v) {  // idx is a literal after unrolling: slice[] is indexed at compile time
-      slice[idx & 7] = ((idx >> 3) == l) ? v : slice[idx & 7];
-    };
-    auto put2 = [&](const int idx, const double v) {  // a double in two consecutive floats
-      typedef float f32x2 __attribute__((vector_size(8)));
-      const f32x2 h = __builtin_bit_cast(f32x2, v);
-      put(idx, h[0]);
-      put(idx + 1, h[1]);
-    };
+    // Under load a global store INSTRUCTION costs this lone wavefront 50-70 cycles whatever its width or the number of lanes behind
+    // it (scripts/ubench/lat2.hip), a select 5: so the uniform part (floats 0..23 and 64..127 of the record) leaves in TWO
+    // instructions -- each lane's slice as two 16-byte pieces -- instead of the 26 stores a lane per piece needed (rounds 2-3).
+    // Floats 24..63 hold only reflector components, which live in their lanes.
     put(S16_T1 + 0, (float)s1); put(S16_T1 + 1, (float)c1x); put(S16_T1 + 2, (float)c1y);
     put(S16_T2 + 0, (float)s2); put(S16_T2 + 1, (float)c2x); put(S16_T2 + 2, (float)c2y);
 #pragma unroll
-    for (int c = 0; c < 9; ++c) { put(S16_F + c, (float)f[c]); put(S16_Z + c, (float)(sgn * z[c])); }
-#pragma unroll
-    for (int c = 0; c < 9; ++c) put2(S16_TD + 2 * c, td[c]);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) put2(S16_TE + 2 * c, te[c]);
-    put2(S16_LAM, lam);
-#pragma unroll
     for (int c = 0; c < 3; ++c) { put(S16_U3 + c, (float)u3[c]); put(S16_V3 + c, (float)v3[c]); }
     put(S16_S3, (float)s3);
-    put(S16_TWIST, (float)twist);
-#pragma unroll
-    for (int c = 0; c < 7; ++c) put(S16_HB + c, (float)hb[c]);
-    put(S16_INVTR, (float)inv_tr);
-    put(S16_TAG, S16_TAG_VALUE);
     static_assert(S16_Z + 9 <= 24 && S16_HV >= 24 && S16_HV + 35 <= 64 && S16_HB >= 64 && S16_TD >= 64, "slices 3..7 of the record hold reflector components only");
     if (l < 3 || l >= 8) {
       float4* dst = reinterpret_cast<float4*>(sv + 8 * l);
@@ -778,7 +807,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     }
 #pragma unroll
     for (int k = 0; k < 7; ++k)  // lanes that hold no component of reflector k write a scratch slot: no branch per reflector
-      sv[(l > k && l < 9) ? S16_HV + s16_hv_off(k) + (l - k - 1) : 24] = (float)hv[k];
+      sv[(l > k && l < 9) ? S16_HV + s16_hv_off(k) + (l - k - 1) : 24] = hvf[k];
   }
   if constexpr (ROWS > 1) {
     if (l < 9) { co->f[l] = f[l]; co->of[l] = of[l]; }
@@ -794,16 +823,37 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   // ---- phase 6: per-correspondence outputs ----------------------------------------------------------------------
   float* rdst = A.residual + (size_t)pair * N;
   float* edst = (A.epi_res != nullptr) ? A.epi_res + (size_t)pair * N : nullptr;
-  for_points<IT>(nit, point_load, point, [&](int it, const PRec& rec) {
+  // LEAN: the correspondence is fetched and decoded again; its weight in X is still in the lane's registers
+  auto reload = [&](int it) {
+    RawRec r;
+    if constexpr (LEAN) load_point_raw<RAW>(A.pts1, A.pts2, mp, N, it * S + L, r);
+    return r;
+  };
+  auto point_out = [&](int it, const RawRec& raw) {
+    if constexpr (LEAN) {
+      PRec r;
+      decode_point<RAW>(raw, N, it * S + L, A.hw_sx, A.hw_sy, r.p, r.valid, r.keep);
+      r.w = r.ws = wv[it];
+      return r;
+    } else {
+      return point(it, raw);
+    }
+  };
+  auto out_load = [&](int it) { if constexpr (LEAN) return reload(it); else return point_load(it); };
+  for_points<IT>(nit, out_load, point_out, [&](int it, const PRec& rec) {
     const int i = it * S + L;
     const Pt& p = rec.p;
     const float wf = rec.w;
     const bool valid = rec.valid;
     // residual_i = w_i p^_i . f  (DeepFNet.py:203-214,251); straight-line, only the stores are guarded
     double ra[3], rb[2], inv;
-    if constexpr (IT > 0) {
+    if constexpr (IT > 0 && !LEAN) {
       row_ab(p, s1, c1x, c1y, s2, c2x, c2y, ra, rb);
       inv = invs[it];
+    } else if constexpr (LEAN) {  // the expressions of phase 2, so that 1 / |p| comes out bit-identical
+      row_ab(p, s1, c1x, c1y, s2, c2x, c2y, ra, rb);
+      const double n2 = (ra[0] * ra[0] + ra[1] * ra[1] + ra[2] * ra[2]) * (rb[0] * rb[0] + rb[1] * rb[1] + 1.0);
+      inv = fmin(rsqrt_nr<1, !RAW>(n2), 1e12);
     } else {
       row_factors(p, s1, c1x, c1y, s2, c2x, c2y, ra, rb, inv);
     }

@@ -73,9 +73,16 @@ int dispatch(const Args& A, int B, int N, bool raw) {
   return 0;
 }
 
+bool g_lean = false;  // emu_set_lean: run the <= 256-register build of the forward fit (w8pt16_body.h: LEAN) where the library would
 template <int IT, bool RAW>
 struct FwdBody {
   static void run(const W8Args& A, int pair, double* xch) {
+    if constexpr (IT == 7 || IT == 8) {
+      if (g_lean) {
+        if (A.variant == 0) w8pt16_fwd_pair<IT, RAW, true, 1, true>(A, pair, xch); else w8pt16_fwd_pair<IT, RAW, false, 1, true>(A, pair, xch);
+        return;
+      }
+    }
     if (A.variant == 0) w8pt16_fwd_pair<IT, RAW, true>(A, pair, xch); else w8pt16_fwd_pair<IT, RAW, false>(A, pair, xch);
   }
 };
@@ -84,6 +91,8 @@ struct BwdBody {
   static void run(const W8BwdArgs& A, int pair, double* xch) { w8pt16_bwd_pair<IT, RAW>(A, pair, xch); }
 };
 }  // namespace
+
+extern "C" void emu_set_lean(int on) { g_lean = on != 0; }
 
 extern "C" int emu_w8pt16_fwd(const float* pts1, const float* pts2, const float* weights, int B, int N, int n_weight_sets,
                               unsigned flags, float image_w, float image_h, float clamp_at, float* F_out, float* residual,

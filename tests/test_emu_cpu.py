@@ -30,6 +30,8 @@ def emu():
     P, I, U, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_float
     L.emu_w8pt16_fwd.restype = I
     L.emu_w8pt16_fwd.argtypes = [P, P, P, I, I, I, U, F, F, F, P, P, P, P, P]
+    L.emu_set_lean.restype = None
+    L.emu_set_lean.argtypes = [I]
     L.emu_w8pt16_bwd.restype = I
     L.emu_w8pt16_bwd.argtypes = [P, P, P, I, I, I, U, F, F, F, P, P, P, P, P, P, P, P, P, P]
     return L
@@ -99,6 +101,36 @@ def test_forward_body_matches_fp64_oracle(emu, dfepe, oracle, B, N, outl, noise)
     o2, _, _ = oracle.fit_forward(p1f.double(), p2f.double(), wout.double().unsqueeze(1))  # same fp32-rounded points
     a2, r2, _ = unit_align(F2, o2)
     assert (a2 - r2).norm(dim=1).max().item() < tol
+
+
+@pytest.mark.parametrize("N", [100, 128, 113, 65, 112])
+@pytest.mark.parametrize("flags", [RAW | LOGITS, RAW, 0])
+def test_lean_forward_body_is_bit_identical(emu, dfepe, oracle, N, flags):
+    """The <= 256-register build of the forward fit (w8pt16_body.h: LEAN -- the lane's correspondences and their 1 / |p| are fetched /
+    derived again for the output phase instead of being held across the eigen solve; the library takes it from 8192 pairs on) against
+    the resident build: every output and the whole `save` record bit for bit, with logits or weights, pixel matches or homogeneous
+    points, dropped (non-finite) correspondences and a ragged last group."""
+    B = 6
+    sc = dfepe.synth.make_scene(B, N, seed=50 + N, outlier_ratio=0.2, noise_px=0.5)
+    m = sc["matches_xy_ori"].clone().contiguous()
+    m[1, 3, 2] = float("nan")   # dropped correspondences: they keep their softmax weight in weights_out, zero in X
+    m[2, N - 1, 0] = float("inf")
+    w = sc["logits_layers"][0].contiguous() if flags & LOGITS else torch.softmax(sc["logits_layers"][0], 1).contiguous()
+    if flags & RAW:
+        a, b = m, None
+    else:
+        p1, p2, _ = oracle.normalize_hw(torch.nan_to_num(m, nan=1e30, posinf=1e30), IMAGE_SIZE)
+        a, b = p1.float().contiguous(), p2.float().contiguous()
+    emu.emu_set_lean(0)
+    ref = emu_fwd(emu, a, b, w, flags)
+    emu.emu_set_lean(1)
+    try:
+        lean = emu_fwd(emu, a, b, w, flags)
+    finally:
+        emu.emu_set_lean(0)
+    for x, y in zip(ref, lean):
+        if x is not None:
+            assert torch.equal(torch.nan_to_num(x), torch.nan_to_num(y)) and torch.equal(torch.isnan(x), torch.isnan(y))
 
 
 def relerr(a, b):
