@@ -15,7 +15,7 @@ the caching allocator -- but train_good.py never builds a graph.  This helper do
     step = compat.CapturedStep(forward_and_loss, net.parameters())   # forward_and_loss(batch) -> (loss, aux): the lines above
     for batch in loader:                                             # up to, NOT including, loss.backward()
         optimizer.zero_grad()
-        loss, aux = step(batch)      # forward + loss + backward; .grad of every parameter is filled
+        loss, aux = step(batch)      # forward + loss + backward; .grad of every parameter is (over)written
         optimizer.step()
 
 The first ``warmup`` calls of a batch signature (shapes, dtypes, non-tensor values) run eagerly -- they are real steps, their
@@ -122,8 +122,16 @@ class CapturedStep:
             p.grad = None
 
     def _run(self, batch):
+        """forward + loss + backward.  The parameter gradients are taken with torch.autograd.grad and ASSIGNED to .grad, not
+        accumulated by loss.backward(): an AccumulateGrad node runs on the stream it was created on -- the default stream if the
+        model ever ran a step outside this helper -- and the engine's hop to that stream and back, harmless in eager mode, pulls the
+        legacy default stream into a capture: hipStreamEndCapture then segfaults (scripts/capture_probe2.py).  autograd.grad stays on
+        the stream of the forward."""
         loss, aux = self.fn(batch)
-        loss.backward()
+        if self.params:
+            grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+            for p, g in zip(self.params, grads):
+                p.grad = g
         return loss, aux
 
     def _eager(self, batch):

@@ -20,9 +20,11 @@ constexpr int kCoopMaxN = 2048;  // cooperative workgroup per pair: N / 256 corr
 constexpr int kCoopMaxPairs = 3072;
 // the forward and the backward agree on this by construction (same N, same pair count, same flag), and the `save` record is the
 // same either way
-// the lean forward fit (<= 256 registers) from this many pairs on: 8192 pairs are two wavefronts per SIMD.  DFEPE_FIT_LEAN = 0 / 1 in the
+// the lean forward fit (<= 256 registers) from this many pairs on.  Measured against the resident build (scripts/ab_fit_sizes.py, us per
+// 4096 pairs, N = 100): 4096 pairs 14.5 vs 12.5 (one wavefront per SIMD: the extra instructions only cost), 8192 11.4 vs 11.2, 16384
+// 9.9 vs 10.9, 32768 9.1 vs 10.4 (issue floor of its 4 140 instructions at the sustained clock: ~8.1).  DFEPE_FIT_LEAN = 0 / 1 in the
 // environment forces it off / on (A/B timing; the outputs are bit-identical either way)
-constexpr int kLeanMinPairs = 8192;
+constexpr int kLeanMinPairs = 12288;
 static bool use_lean(int pairs) {
   static const int forced = [] { const char* e = getenv("DFEPE_FIT_LEAN"); return e ? atoi(e) : -1; }();
   return forced < 0 ? pairs >= kLeanMinPairs : forced != 0;
@@ -57,7 +59,7 @@ w8pt16_fwd_kernel(const float* pts1, const float* pts2, const float* wts, int B,
 }
 
 // The same kernel in <= 256 registers (w8pt16_body.h: LEAN): two wavefronts per SIMD.  Taken from kLeanMinPairs pairs on, where a
-// SIMD has a second wavefront to hold (at 4096 pairs = one wavefront per SIMD the few extra instructions would only cost).
+// SIMD has wavefronts queueing for it (at 4096 pairs = one wavefront per SIMD the few extra instructions would only cost).
 template <int IT, bool RAW, bool PLAIN>
 __global__ void __launch_bounds__(256, 2)
 w8pt16_fwd_lean_kernel(const float* pts1, const float* pts2, const float* wts, int B, int Bm, int N, float hw_sx, float hw_sy,

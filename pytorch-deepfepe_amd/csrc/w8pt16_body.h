@@ -261,6 +261,8 @@ __device__ __forceinline__ double pivot_guard(double q) { return (fabs(q) < 1e-3
 // In: Ar = row `l` of M / trace(M) (lanes 0..8; zeros elsewhere), kth = number of eigenvalues to pass over.
 // Out (uniform over the row): f[9] unit eigenvector (unoriented), z[9] its tridiagonal-space image, twist, lam, td, te;
 //      per lane: hv[k] = component l of reflector k; hb[k] uniform.
+// FUSED_SWEEPS (the lean build): the twisted factorisation keeps ~18 instead of 36 doubles live, same operations in the same order.
+template <bool FUSED_SWEEPS = false>
 __device__ __forceinline__ void eig9_select(double* Ar, const int l, const int kth, double* f, double* z, int& twist,
                                             double& lam, double* td, double* te, double* hv, double* hb) {
   // Householder tridiagonalisation, lower form: step k annihilates column k below the sub-diagonal
@@ -331,6 +333,36 @@ __device__ __forceinline__ void eig9_select(double* Ar, const int l, const int k
   DFEPE_MARK("P4c_twisted");
   // eigenvector of T by twisted factorisation: pivots from the top (dp) and from the bottom (dm), twist where
   // gamma_k = dp_k + dm_k - (d_k - lam) is smallest in magnitude
+  if constexpr (!FUSED_SWEEPS) {
+  double dp[9], dm[9], rp[9], rm[9];
+  dp[0] = td[0] - lam;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    dp[k] = pivot_guard(dp[k]);
+    rp[k] = rcp_nr<1, false>(dp[k]);  // one Newton step from the fp32 seed: ~2e-14, far inside what the eigenvector needs
+    dp[k + 1] = (td[k + 1] - lam) - te2[k] * rp[k];
+  }
+  dm[8] = td[8] - lam;
+#pragma unroll
+  for (int k = 7; k >= 0; --k) {
+    dm[k + 1] = pivot_guard(dm[k + 1]);
+    rm[k + 1] = rcp_nr<1, false>(dm[k + 1]);
+    dm[k] = (td[k] - lam) - te2[k] * rm[k + 1];
+  }
+  twist = 0;
+  double gbest = fabs(dp[0] + dm[0] - (td[0] - lam));
+#pragma unroll
+  for (int k = 1; k < 9; ++k) {
+    const double g = fabs(dp[k] + dm[k] - (td[k] - lam));
+    if (g < gbest) { gbest = g; twist = k; }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) z[k] = (k == twist) ? 1.0 : 0.0;
+#pragma unroll
+  for (int k = 7; k >= 0; --k) z[k] = (k < twist) ? -(te[k] * rp[k]) * z[k + 1] : z[k];
+#pragma unroll
+  for (int k = 1; k < 9; ++k) z[k] = (k > twist) ? -(te[k - 1] * rm[k]) * z[k - 1] : z[k];
+  } else {
   // The bottom-up sweep first, keeping only what the rest needs of it: its pivots (for the twist search) and the products
   // te[k-1] / dm[k] (for z below the twist).  The top-down sweep then runs FUSED with the twist search -- gamma_k is formed the
   // moment dp_k exists, after which that pivot of the bottom-up sweep is dead -- and keeps te[k] / dp[k] only: ~18 live doubles at
@@ -372,6 +404,7 @@ __device__ __forceinline__ void eig9_select(double* Ar, const int l, const int k
   for (int k = 7; k >= 0; --k) z[k] = (k < twist) ? -cp[k] * z[k + 1] : z[k];
 #pragma unroll
   for (int k = 1; k < 9; ++k) z[k] = (k > twist) ? -cm[k] * z[k - 1] : z[k];
+  }
   double zn = 0.0;
 #pragma unroll
   for (int k = 0; k < 9; ++k) zn = fma(z[k], z[k], zn);
@@ -687,12 +720,13 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   const int kth = (N >= 9) ? 0 : 9 - N;
   double z[9], td[9], te[8], hv[7], hb[7], lam;
   int twist;
-  eig9_select(Ar, l, kth, f, z, twist, lam, td, te, hv, hb);
+  eig9_select<LEAN>(Ar, l, kth, f, z, twist, lam, td, te, hv, hb);
   // The `save` record: everything but the reflector components is uniform over the row, and lane s of {0, 1, 2, 8..15} assembles
-  // floats 8 s .. 8 s + 7 of it with one select per float (see the stores below).  The pieces are folded into the lane's slice AS
-  // SOON AS THEY ARE FINAL (round 5) -- the tridiagonal, the eigenvalue and the reflector scales right here, z and f after the
-  // orientation, the singular triplet after the rank-2 step -- so that 9 + 8 + 1 + 7 doubles stop being live across the rank-2 step:
-  // the peak of the kernel's register use was there (289 -> <= 256 registers: two wavefronts per SIMD for batches >= 8192 pairs).
+  // floats 8 s .. 8 s + 7 of it with one select per float (see the stores below).  In the LEAN build the pieces are folded into the
+  // lane's slice AS SOON AS THEY ARE FINAL -- the tridiagonal, the eigenvalue and the reflector scales right here, z and f after the
+  // orientation, the singular triplet after the rank-2 step -- so that 9 + 8 + 1 + 7 doubles stop being live across the rank-2 step
+  // (part of what takes that build from 289 to <= 256 registers).  The resident build assembles the whole record at the end: at one
+  // wavefront per SIMD the early selects measured 4 % slower (12.5 -> 13.1 us at 4096 pairs, scripts/ab_fit_sizes.py).
   const bool saving = A.save != nullptr;
   float slice[8];
 #pragma unroll
@@ -707,7 +741,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     put(idx + 1, h[1]);
   };
   float hvf[7];
-  if (saving) {
+  auto put_eigen = [&]() {
 #pragma unroll
     for (int c = 0; c < 9; ++c) put2(S16_TD + 2 * c, td[c]);
 #pragma unroll
@@ -718,6 +752,9 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     for (int c = 0; c < 7; ++c) { put(S16_HB + c, (float)hb[c]); hvf[c] = (float)hv[c]; }
     put(S16_INVTR, (float)inv_tr);
     put(S16_TAG, S16_TAG_VALUE);
+  };
+  if constexpr (LEAN) {
+    if (saving) put_eigen();
   }
 
   DFEPE_MARK("P5");
@@ -733,9 +770,12 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   const double fscale = sgn * rsqrt_nr<2, false>(fn2);  // a unit vector up to rounding
 #pragma unroll
   for (int c = 0; c < 9; ++c) f[c] *= fscale;
-  if (saving) {
+  auto put_fz = [&]() {
 #pragma unroll
     for (int c = 0; c < 9; ++c) { put(S16_F + c, (float)f[c]); put(S16_Z + c, (float)(sgn * z[c])); }
+  };
+  if constexpr (LEAN) {
+    if (saving) put_fz();
   }
 
   DFEPE_MARK("P5b_rank2");
@@ -793,6 +833,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     // Floats 24..63 hold only reflector components, which live in their lanes.
     put(S16_T1 + 0, (float)s1); put(S16_T1 + 1, (float)c1x); put(S16_T1 + 2, (float)c1y);
     put(S16_T2 + 0, (float)s2); put(S16_T2 + 1, (float)c2x); put(S16_T2 + 2, (float)c2y);
+    if constexpr (!LEAN) { put_fz(); put_eigen(); }
 #pragma unroll
     for (int c = 0; c < 3; ++c) { put(S16_U3 + c, (float)u3[c]); put(S16_V3 + c, (float)v3[c]); }
     put(S16_S3, (float)s3);

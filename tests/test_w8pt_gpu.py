@@ -209,3 +209,24 @@ def test_cooperative_workgroup_per_pair(dfepe, oracle, B, N):
     # the least-squares solution is well conditioned here (N >= 130 noisy correspondences): gradients agree to the record's fp32 entries
     scale = gc.abs().max().item()
     assert (ga - gc).abs().max().item() < 2e-3 * scale and (gb - gc).abs().max().item() < 2e-3 * scale
+
+
+@pytest.mark.parametrize("N", [100, 128])
+def test_lean_forward_fit_of_large_batches_is_bit_identical(dfepe, N):
+    """From 12288 pairs on the library launches the <= 256-register build of the forward fit (csrc/w8pt16_body.h: LEAN, two wavefronts
+    per SIMD; the correspondences are fetched again for the output phase instead of held across the eigen solve).  Same arithmetic:
+    a 16384-pair launch must return, for every pair, exactly what four 4096-pair launches of the resident build return -- F,
+    residual, epipolar residual, softmax weights and the whole `save` record -- and its backward must accept that record."""
+    B = 16384
+    sc = dfepe.synth.make_scene(B, N, seed=5, outlier_ratio=0.2, noise_px=0.5)
+    m = sc["matches_xy_ori"].to(DEV).contiguous()
+    lg = sc["logits_layers"][0].to(DEV).contiguous()
+    big = dfepe.ops.w8pt_forward(m, None, lg, True, 1241.0, 376.0, 0.5, True, True, logits=True)
+    for c in range(0, B, 4096):
+        part = dfepe.ops.w8pt_forward(m[c:c + 4096].contiguous(), None, lg[c:c + 4096].contiguous(), True, 1241.0, 376.0, 0.5, True, True, logits=True)
+        for x, y in zip(big, part):
+            a, b = torch.nan_to_num(x[c:c + 4096]), torch.nan_to_num(y)  # float 24 of the record is a scratch slot
+            assert torch.equal(a, b)
+    F, res, epi, save, wout = big
+    g = dfepe.ops.w8pt_backward(m, None, wout, True, 1241.0, 376.0, 0.5, save, F, torch.ones_like(F), None, None, logits=True)
+    assert torch.isfinite(g).all()
