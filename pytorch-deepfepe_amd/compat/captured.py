@@ -12,7 +12,7 @@ Behind this package's mirrors that sequence is ~50 kernel launches of 5-13 us ea
 the host (~1.7 ms at B = 4096 against 0.24 ms of GPU work).  It is capturable -- no host synchronisation, no allocation outside
 the caching allocator -- but train_good.py never builds a graph.  This helper does it for the caller, in three lines:
 
-    step = compat.CapturedStep(forward_and_loss, net.parameters())   # forward_and_loss(batch) -> (loss, aux): the lines above
+    step = compat.CapturedStep(forward_and_loss, net)                # forward_and_loss(batch) -> (loss, aux): the lines above
     for batch in loader:                                             # up to, NOT including, loss.backward()
         optimizer.zero_grad()
         loss, aux = step(batch)      # forward + loss + backward; .grad of every parameter is (over)written
@@ -93,10 +93,18 @@ class _Entry:
 
 
 class CapturedStep:
-    def __init__(self, forward_and_loss: Callable[[Any], Tuple[torch.Tensor, Any]], parameters: Iterable[torch.nn.Parameter] = (),
+    def __init__(self, forward_and_loss: Callable[[Any], Tuple[torch.Tensor, Any]], parameters=(),
                  device: Optional[torch.device] = None, warmup: int = 2, max_graphs: int = 8, enabled: bool = True):
+        """``parameters``: the nn.Module whose parameters the step trains (preferred), or an iterable of leaf tensors.
+        With a module the step runs its forward over fresh VIEWS of the parameters (torch.nn.utils.stateless): gradients are then
+        taken at nodes created on the capture stream.  With bare leaves they are taken at the leaves' AccumulateGrad nodes, which
+        live on the stream of the model's first backward -- if that was the default stream (a step run outside this helper whose
+        graph is still alive) the autograd engine's hop to it pulls the legacy stream into the capture and hipStreamEndCapture
+        crashes (scripts/capture_probe2.py): pass the module."""
         self.fn = forward_and_loss
-        self.params = [p for p in parameters]
+        self.module = parameters if isinstance(parameters, torch.nn.Module) else None
+        self.params = [p for p in (parameters.parameters() if self.module is not None else parameters)]
+        self._names = [n for n, _ in self.module.named_parameters()] if self.module is not None else None
         self.device = torch.device(device) if device is not None else (self.params[0].device if self.params else torch.device("cuda", torch.cuda.current_device()))
         if self.device.type != "cuda":
             raise _lib.DfepeError("CapturedStep: the step runs on the GPU (this package has no CPU path)")
@@ -127,9 +135,18 @@ class CapturedStep:
         model ever ran a step outside this helper -- and the engine's hop to that stream and back, harmless in eager mode, pulls the
         legacy default stream into a capture: hipStreamEndCapture then segfaults (scripts/capture_probe2.py).  autograd.grad stays on
         the stream of the forward."""
-        loss, aux = self.fn(batch)
-        if self.params:
-            grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+        if self.module is not None:
+            from torch.nn.utils import stateless
+
+            views = [p.view_as(p) for p in self.params]  # non-leaf aliases: their grad_fn is created here, on this stream
+            with stateless._reparametrize_module(self.module, dict(zip(self._names, views))):
+                loss, aux = self.fn(batch)
+            targets = views
+        else:
+            loss, aux = self.fn(batch)
+            targets = self.params
+        if targets:
+            grads = torch.autograd.grad(loss, targets, allow_unused=True)
             for p, g in zip(self.params, grads):
                 p.grad = g
         return loss, aux

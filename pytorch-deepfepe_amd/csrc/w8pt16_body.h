@@ -721,18 +721,19 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   double z[9], td[9], te[8], hv[7], hb[7], lam;
   int twist;
   eig9_select<LEAN>(Ar, l, kth, f, z, twist, lam, td, te, hv, hb);
-  // The `save` record: everything but the reflector components is uniform over the row, and lane s of {0, 1, 2, 8..15} assembles
-  // floats 8 s .. 8 s + 7 of it with one select per float (see the stores below).  In the LEAN build the pieces are folded into the
-  // lane's slice AS SOON AS THEY ARE FINAL -- the tridiagonal, the eigenvalue and the reflector scales right here, z and f after the
-  // orientation, the singular triplet after the rank-2 step -- so that 9 + 8 + 1 + 7 doubles stop being live across the rank-2 step
-  // (part of what takes that build from 289 to <= 256 registers).  The resident build assembles the whole record at the end: at one
-  // wavefront per SIMD the early selects measured 4 % slower (12.5 -> 13.1 us at 4096 pairs, scripts/ab_fit_sizes.py).
-  const bool saving = A.save != nullptr;
-  float slice[8];
+  // The `save` record in the LEAN build: everything but the reflector components is uniform over the row, and lane s of
+  // {0, 1, 2, 8..15} assembles floats 8 s .. 8 s + 7 of it with one select per float (see the stores at the end of the solver phases).
+  // Here the pieces are folded into the lane's slice AS SOON AS THEY ARE FINAL -- the tridiagonal, the eigenvalue and the reflector
+  // scales right now, z and f after the orientation, the singular triplet after the rank-2 step -- so that 9 + 8 + 1 + 7 doubles stop
+  // being live across the rank-2 step (part of what takes that build from 289 to <= 256 registers).  The resident build keeps
+  // round 4's code, which assembles the whole record at the end: at one wavefront per SIMD the early selects measured 3-4 % slower
+  // (12.5 -> 13.0 us at 4096 pairs, scripts/ab_fit_sizes.py).
+  const bool saving = LEAN && A.save != nullptr;
+  float slice[LEAN ? 8 : 1];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) slice[c] = 0.0f;
+  for (int c = 0; c < (LEAN ? 8 : 1); ++c) slice[c] = 0.0f;
   auto put = [&](const int idx, const float v) {  // idx is a literal after unrolling: slice[] is indexed at compile time
-    slice[idx & 7] = ((idx >> 3) == l) ? v : slice[idx & 7];
+    if constexpr (LEAN) slice[idx & 7] = ((idx >> 3) == l) ? v : slice[idx & 7];
   };
   auto put2 = [&](const int idx, const double v) {  // a double in two consecutive floats
     typedef float f32x2 __attribute__((vector_size(8)));
@@ -741,20 +742,19 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     put(idx + 1, h[1]);
   };
   float hvf[7];
-  auto put_eigen = [&]() {
-#pragma unroll
-    for (int c = 0; c < 9; ++c) put2(S16_TD + 2 * c, td[c]);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) put2(S16_TE + 2 * c, te[c]);
-    put2(S16_LAM, lam);
-    put(S16_TWIST, (float)twist);
-#pragma unroll
-    for (int c = 0; c < 7; ++c) { put(S16_HB + c, (float)hb[c]); hvf[c] = (float)hv[c]; }
-    put(S16_INVTR, (float)inv_tr);
-    put(S16_TAG, S16_TAG_VALUE);
-  };
   if constexpr (LEAN) {
-    if (saving) put_eigen();
+    if (saving) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) put2(S16_TD + 2 * c, td[c]);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) put2(S16_TE + 2 * c, te[c]);
+      put2(S16_LAM, lam);
+      put(S16_TWIST, (float)twist);
+#pragma unroll
+      for (int c = 0; c < 7; ++c) { put(S16_HB + c, (float)hb[c]); hvf[c] = (float)hv[c]; }
+      put(S16_INVTR, (float)inv_tr);
+      put(S16_TAG, S16_TAG_VALUE);
+    }
   }
 
   DFEPE_MARK("P5");
@@ -770,12 +770,11 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   const double fscale = sgn * rsqrt_nr<2, false>(fn2);  // a unit vector up to rounding
 #pragma unroll
   for (int c = 0; c < 9; ++c) f[c] *= fscale;
-  auto put_fz = [&]() {
-#pragma unroll
-    for (int c = 0; c < 9; ++c) { put(S16_F + c, (float)f[c]); put(S16_Z + c, (float)(sgn * z[c])); }
-  };
   if constexpr (LEAN) {
-    if (saving) put_fz();
+    if (saving) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) { put(S16_F + c, (float)f[c]); put(S16_Z + c, (float)(sgn * z[c])); }
+    }
   }
 
   DFEPE_MARK("P5b_rank2");
@@ -825,6 +824,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   }
 
   DFEPE_MARK("P5s_save");
+  if constexpr (LEAN) {
   if (saving) {
     float* sv = static_cast<float*>(__builtin_assume_aligned(A.save, 16)) + (size_t)pair * DFEPE_SAVE_FLOATS;
     // Under load a global store INSTRUCTION costs this lone wavefront 50-70 cycles whatever its width or the number of lanes behind
@@ -833,7 +833,6 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     // Floats 24..63 hold only reflector components, which live in their lanes.
     put(S16_T1 + 0, (float)s1); put(S16_T1 + 1, (float)c1x); put(S16_T1 + 2, (float)c1y);
     put(S16_T2 + 0, (float)s2); put(S16_T2 + 1, (float)c2x); put(S16_T2 + 2, (float)c2y);
-    if constexpr (!LEAN) { put_fz(); put_eigen(); }
 #pragma unroll
     for (int c = 0; c < 3; ++c) { put(S16_U3 + c, (float)u3[c]); put(S16_V3 + c, (float)v3[c]); }
     put(S16_S3, (float)s3);
@@ -849,6 +848,57 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
 #pragma unroll
     for (int k = 0; k < 7; ++k)  // lanes that hold no component of reflector k write a scratch slot: no branch per reflector
       sv[(l > k && l < 9) ? S16_HV + s16_hv_off(k) + (l - k - 1) : 24] = hvf[k];
+  }
+  } else {
+  if (A.save != nullptr) {
+    float* sv = static_cast<float*>(__builtin_assume_aligned(A.save, 16)) + (size_t)pair * DFEPE_SAVE_FLOATS;
+    // Everything but the reflector components is uniform over the row.  Under load a global store INSTRUCTION costs this lone
+    // wavefront 50-70 cycles whatever its width or the number of lanes behind it (scripts/ubench/lat2.hip), a select 5: so the
+    // uniform part (floats 0..23 and 64..127 of the record) leaves in TWO instructions -- lane s of {0, 1, 2, 8..15} assembles
+    // floats 8 s .. 8 s + 7 with one select per float (~95 v_cndmask) and stores them as two 16-byte pieces -- instead of the
+    // 26 stores a lane per piece needed (rounds 2-3).  Floats 24..63 hold only reflector components, which live in their lanes.
+    float slice[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) slice[c] = 0.0f;
+    auto put = [&](const int idx, const float v) {  // idx is a literal after unrolling: slice[] is indexed at compile time
+      slice[idx & 7] = ((idx >> 3) == l) ? v : slice[idx & 7];
+    };
+    auto put2 = [&](const int idx, const double v) {  // a double in two consecutive floats
+      typedef float f32x2 __attribute__((vector_size(8)));
+      const f32x2 h = __builtin_bit_cast(f32x2, v);
+      put(idx, h[0]);
+      put(idx + 1, h[1]);
+    };
+    put(S16_T1 + 0, (float)s1); put(S16_T1 + 1, (float)c1x); put(S16_T1 + 2, (float)c1y);
+    put(S16_T2 + 0, (float)s2); put(S16_T2 + 1, (float)c2x); put(S16_T2 + 2, (float)c2y);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { put(S16_F + c, (float)f[c]); put(S16_Z + c, (float)(sgn * z[c])); }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) put2(S16_TD + 2 * c, td[c]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) put2(S16_TE + 2 * c, te[c]);
+    put2(S16_LAM, lam);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { put(S16_U3 + c, (float)u3[c]); put(S16_V3 + c, (float)v3[c]); }
+    put(S16_S3, (float)s3);
+    put(S16_TWIST, (float)twist);
+#pragma unroll
+    for (int c = 0; c < 7; ++c) put(S16_HB + c, (float)hb[c]);
+    put(S16_INVTR, (float)inv_tr);
+    put(S16_TAG, S16_TAG_VALUE);
+    static_assert(S16_Z + 9 <= 24 && S16_HV >= 24 && S16_HV + 35 <= 64 && S16_HB >= 64 && S16_TD >= 64, "slices 3..7 of the record hold reflector components only");
+    if (l < 3 || l >= 8) {
+      float4* dst = reinterpret_cast<float4*>(sv + 8 * l);
+      float4 q0, q1;
+      q0.x = slice[0]; q0.y = slice[1]; q0.z = slice[2]; q0.w = slice[3];
+      q1.x = slice[4]; q1.y = slice[5]; q1.z = slice[6]; q1.w = slice[7];
+      dst[0] = q0;
+      dst[1] = q1;
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k)  // lanes that hold no component of reflector k write a scratch slot: no branch per reflector
+      sv[(l > k && l < 9) ? S16_HV + s16_hv_off(k) + (l - k - 1) : 24] = (float)hv[k];
+  }
   }
   if constexpr (ROWS > 1) {
     if (l < 9) { co->f[l] = f[l]; co->of[l] = of[l]; }
@@ -871,17 +921,14 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     return r;
   };
   auto point_out = [&](int it, const RawRec& raw) {
+    PRec r;
     if constexpr (LEAN) {
-      PRec r;
       decode_point<RAW>(raw, N, it * S + L, A.hw_sx, A.hw_sy, r.p, r.valid, r.keep);
       r.w = r.ws = wv[it];
-      return r;
-    } else {
-      return point(it, raw);
     }
+    return r;
   };
-  auto out_load = [&](int it) { if constexpr (LEAN) return reload(it); else return point_load(it); };
-  for_points<IT>(nit, out_load, point_out, [&](int it, const PRec& rec) {
+  auto out_body = [&](int it, const PRec& rec) {
     const int i = it * S + L;
     const Pt& p = rec.p;
     const float wf = rec.w;
@@ -917,6 +964,8 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
         if (A.logits_mode && A.weights_out != nullptr) A.weights_out[(size_t)pair * N + i] = wsm[it];
       }
     }
-  });
+  };
+  if constexpr (LEAN) for_points<IT>(nit, reload, point_out, out_body);
+  else for_points<IT>(nit, point_load, point, out_body);
   DFEPE_MARK("Pend");
 }

@@ -24,7 +24,7 @@ if v.startswith("full_test"):
 net = d.compat.DeepFNet.DeepFNet(depth=depth, image_size=[376, 1241, 3], if_quality=False).to(DEV)
 d.synth.fill_params_deterministic(net, 3)
 fn = t._make_step(d, net, depth, False)
-step = d.compat.CapturedStep(fn, net.parameters(), warmup=2)
+step = d.compat.CapturedStep(fn, net if os.environ.get('PROBE_MODULE', '1') == '1' else net.parameters(), warmup=2)
 if v == "gc_disabled":
     gc.disable()
 batches = [t._batch(d, 48, N, 100 + k, host_gt=(v == "with_host_gt" and k == 1)) for k in range(3)]
