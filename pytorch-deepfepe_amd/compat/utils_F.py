@@ -4,6 +4,7 @@ import numpy as np
 import torch
 
 from .. import _lib, ops
+from . import _autograd_paths as _ap
 from . import utils_misc
 
 
@@ -53,17 +54,23 @@ def _normalize_XY_batch(X, Y):
 
 
 def compute_epi_residual(pts1, pts2, F, clamp_at=0.5):
-    """Symmetric epipolar residual, [B,N] (utils_F.py:400-413); differentiable w.r.t. F only (what the F-loss needs;
-    the recurrent model's in-loop residual with point gradients comes out of the fit itself, ops.w8pt)."""
-    _no_grad_here("compute_epi_residual (w.r.t. the points)", pts1, pts2)
+    """Symmetric epipolar residual, [B,N] (utils_F.py:400-413).  The kernel (with its adjoint w.r.t. F: what the F-loss needs; the
+    recurrent model's in-loop residual with point gradients comes out of the fit itself, ops.w8pt); when the POINTS require grad,
+    the same formula through torch autograd (_autograd_paths)."""
+    if _ap.wants_grad(pts1, pts2):
+        return _ap.epi_residual(_gpu(pts1), _gpu(pts2), _gpu(F), clamp_at)
     return ops.epi_residual(_gpu(pts1), _gpu(pts2), _gpu(F), clamp_at)
 
 
 def _get_M2s(E):
     """E [3,3] -> (R2s, t2s, M2s) like utils_F.py:478-498 (two rotations, +-t, the four [R|t]).
-    The candidate *set* equals the reference's; the order within each pair follows this library's SVD gauge.
-    Not differentiable here (the pose loss has its own adjoint, ops.pose_errors)."""
-    _no_grad_here("_get_M2s", E)
+    The candidate *set* equals the reference's; the order within each pair follows this library's SVD gauge (with an E that
+    requires grad: torch.linalg.svd's, through the differentiable evaluation of _autograd_paths -- the pose loss on the hot path has
+    its own adjoint, ops.pose_errors)."""
+    if _ap.wants_grad(E):
+        R1, R2, t = _ap.decompose_essential(_gpu(E))
+        R2s, t2s = [R1, R2], [t, -t]
+        return R2s, t2s, [torch.cat((R, tt), 1) for R in R2s for tt in t2s]
     R1, R2, t = ops.decompose_essential(_gpu(E).reshape(1, 3, 3))
     R2s = [R1[0], R2[0]]
     t2s = [t[0].reshape(3, 1), -t[0].reshape(3, 1)]
@@ -130,16 +137,7 @@ def E_F_from_Rt_np(R, t, K):
     return E_gt, F_gt
 
 
-def _no_grad_here(what, *tensors):
-    """These mirrors are raw kernel launches outside autograd (the reference's versions are differentiable torch code but
-    nothing on the hot path differentiates through them); asking for a gradient is an error rather than a silent zero."""
-    if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors):
-        raise _lib.DfepeError(f"compat.utils_F.{what}: not differentiable in this library (an input requires grad); "
-                              "use compute_epi_residual (gradient w.r.t. F) or detach the inputs")
-
-
 def _epi_args(what, F, X, Y, if_homo):
-    _no_grad_here(what, F, X, Y)
     F, X, Y = _gpu(F), _gpu(X), _gpu(Y)
     single = X.dim() == 2
     if single:
@@ -152,12 +150,16 @@ def _epi_args(what, F, X, Y, if_homo):
 
 def _sym_epi_dist(F, X, Y, if_homo=False, clamp_at=None):
     """Squared symmetric epipolar distance (utils_F.py:310-339); the 1e-10 guard only in the batched form (:329)."""
+    if _ap.wants_grad(F, X, Y):  # the reference's gradients (legacy callers: train_good_utils.py:55-61), see _autograd_paths
+        return _ap.sym_epi_dist(_gpu(F), _gpu(X), _gpu(Y), if_homo, clamp_at, eps=0.0 if torch.as_tensor(X).dim() == 2 else 1e-10)
     F, X, Y, single = _epi_args("_sym_epi_dist", F, X, Y, if_homo)
     out = ops.epi_metrics(0, F, X, Y, clamp_at=clamp_at, eps=0.0 if single else 1e-10)
     return out[0] if single else out
 
 
 def _sampson_dist(F, X, Y, if_homo=False):
+    if _ap.wants_grad(F, X, Y):  # dsac_tools/dsac.py:138-176 differentiates the soft inlier count through this
+        return _ap.sampson_dist(_gpu(F), _gpu(X), _gpu(Y), if_homo)
     F, X, Y, single = _epi_args("_sampson_dist", F, X, Y, if_homo)
     out = ops.epi_metrics(1, F, X, Y)
     return out[0] if single else out
@@ -165,6 +167,8 @@ def _sampson_dist(F, X, Y, if_homo=False):
 
 def _epi_distance(F, X, Y, if_homo=False):
     """Returns ((d1+d2)/2, d1, d2) (utils_F.py:341-361)."""
+    if _ap.wants_grad(F, X, Y):
+        return _ap.epi_distance(_gpu(F), _gpu(X), _gpu(Y), if_homo)
     F, X, Y, single = _epi_args("_epi_distance", F, X, Y, if_homo)
     out = ops.epi_metrics(2, F, X, Y)
     return (out[0, 0], out[1, 0], out[2, 0]) if single else (out[0], out[1], out[2])
@@ -289,8 +293,11 @@ def _dense_w_solve(X, Y, W, essential, normalize):
 
 
 def _F_from_XY(X, Y, W=None, normalize=True, show_debug=False):
-    """Normalised 8-point fundamental matrix from X, Y [N,2] (utils_F.py:223-275); sign follows this library's gauge."""
+    """Normalised 8-point fundamental matrix from X, Y [N,2] (utils_F.py:223-275); sign follows this library's gauge (with inputs
+    that require grad: torch.linalg.svd's, through the differentiable evaluation of _autograd_paths)."""
     X, Y = _gpu(X), _gpu(Y)
+    if _ap.wants_grad(X, Y, W):
+        return _ap.eight_point(X, Y, None if W is None else _gpu(W), essential=False, normalize=normalize)
     w = None if W is None else _diag_weights(W, X.shape[0])
     if W is not None and w is None:
         return _dense_w_solve(X, Y, W, False, normalize)
@@ -321,6 +328,8 @@ def _E_from_XY(X, Y, K, W=None, if_normzliedK=False, normalize=True, show_debug=
         ones = torch.ones(X.shape[0], 1, device=X.device)
         Xh, Yh = torch.cat((X, ones), 1) @ Ki.t(), torch.cat((Y, ones), 1) @ Ki.t()
         X, Y = Xh[:, :2] / (Xh[:, 2:3] + 1e-10), Yh[:, :2] / (Yh[:, 2:3] + 1e-10)  # _de_homo (utils_misc.py:69-78)
+    if _ap.wants_grad(X, Y, W):  # the reference's own differentiable route (legacy callers, dsac.py:138-176)
+        return _ap.eight_point(X, Y, None if W is None else _gpu(W), essential=True, normalize=normalize)
     w = None if W is None else _diag_weights(W, X.shape[0])
     if W is not None and w is None:
         return _dense_w_solve(X, Y, W, True, normalize)

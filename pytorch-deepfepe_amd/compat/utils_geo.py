@@ -14,9 +14,10 @@ def _as_batch(x, shape):
 
 def _R_to_q(R):
     """R [3,3] (or [B,3,3]) -> unit quaternion [4,1] (or [B,4,1]), q0 >= 0, trace method on R^T (utils_geo.py:58-86)."""
-    if torch.is_grad_enabled() and R.requires_grad:
-        from .. import _lib
-        raise _lib.DfepeError("compat.utils_geo._R_to_q: not differentiable in this library (the pose loss has its own adjoint, ops.pose_errors)")
+    if torch.is_grad_enabled() and R.requires_grad:  # the reference's is differentiable torch code: same formula through autograd
+        from . import _autograd_paths as _ap
+
+        return _ap.rot_to_quat(R).unsqueeze(-1)
     single = R.dim() == 2
     q = ops.rot_to_quat(_as_batch(R, (3, 3)))
     return q[0].unsqueeze(-1) if single else q.unsqueeze(-1)

@@ -145,9 +145,8 @@ def test_deepfnet_sign_gauge_departure_is_bounded_and_documented(dfepe, golden):
           f"max unit-Frobenius departure of the later layers' F: {max(dep):.3e}")
 
 
-def test_shape_validation_and_nondifferentiable_mirrors(dfepe):
-    """Wrong layouts raise ValueError before anything is launched (the kernels index raw pointers); mirrors that are raw
-    launches refuse inputs that require grad instead of silently dropping the gradient."""
+def test_shape_validation(dfepe):
+    """Wrong layouts raise ValueError before anything is launched (the kernels index raw pointers)."""
     B, N = 3, 20
     w = torch.rand(B, N, device=DEV)
     with pytest.raises(ValueError):
@@ -166,15 +165,70 @@ def test_shape_validation_and_nondifferentiable_mirrors(dfepe):
         dfepe.ops.cheirality(torch.rand(B, 3, 3, device=DEV), torch.rand(1, 3, 3, device=DEV), torch.rand(B, N, 4, device=DEV))
     with pytest.raises(ValueError):
         dfepe.ops.epi_residual(torch.rand(B, N, 3, device=DEV), torch.rand(B, N, 3, device=DEV), torch.rand(B + 1, 3, 3, device=DEV))
-    uF = dfepe.compat.utils_F
-    F = torch.rand(B, 3, 3, device=DEV, requires_grad=True)
-    X, Y = torch.rand(B, N, 2, device=DEV), torch.rand(B, N, 2, device=DEV)
-    for fn in (uF._sym_epi_dist, uF._sampson_dist, uF._epi_distance):
-        with pytest.raises(dfepe.DfepeError):
-            fn(F, X, Y)
-        fn(F.detach(), X, Y)
-    with pytest.raises(dfepe.DfepeError):
-        uF.compute_epi_residual(torch.rand(B, N, 3, device=DEV, requires_grad=True), torch.rand(B, N, 3, device=DEV), F.detach())
+
+
+def test_legacy_helpers_are_differentiable_like_the_references(dfepe, oracle):
+    """The reference's _sym_epi_dist, _sampson_dist, _epi_distance, compute_epi_residual, _get_M2s, _R_to_q, _F_from_XY, _E_from_XY
+    are differentiable torch code (utils_F.py:104-155,223-275,291-361,400-413,478-498; utils_geo.py:58-86; used with gradients by
+    train_good_utils.py:55-61 and dsac_tools/dsac.py:138-176).  The mirrors launch kernels without an adjoint, so a call whose
+    inputs require grad is evaluated by compat._autograd_paths instead (VERDICT r4 missing #3): its VALUES must equal the kernels'
+    and its GRADIENTS float64 autograd of the oracle."""
+    uF, uG = dfepe.compat.utils_F, dfepe.compat.utils_geo
+    sc = dfepe.synth.make_scene(4, 60, seed=12, outlier_ratio=0.1, noise_px=0.5)
+    m, K = sc["matches_xy_ori"], sc["Ks"]
+    Fgt = sc["F_gt"] / sc["F_gt"].flatten(1).norm(dim=1)[:, None, None]
+
+    def both(fn_dev, fn_ref, args, pick=lambda o: o):
+        """fn(*args) on the device with every arg requiring grad vs the oracle in float64: values and all gradients."""
+        dev_args = [a.float().to(DEV).requires_grad_(True) for a in args]
+        ref_args = [a.double().requires_grad_(True) for a in args]
+        od, orf = pick(fn_dev(*dev_args)), pick(fn_ref(*ref_args))
+        plain = pick(fn_dev(*[a.detach() for a in dev_args]))  # the kernel path
+        scale = float(orf.detach().abs().max()) + 1e-30
+        assert float((od.detach().cpu().double() - orf.detach()).abs().max()) < 2e-4 * scale
+        assert float((plain.cpu().double() - orf.detach()).abs().max()) < 2e-4 * scale
+        gen = torch.Generator().manual_seed(3)
+        wgt = torch.rand(orf.shape, generator=gen, dtype=torch.float64)
+        (od * wgt.float().to(DEV)).sum().backward()
+        (orf * wgt).sum().backward()
+        for a, b in zip(dev_args, ref_args):
+            assert a.grad is not None
+            gs = float(b.grad.abs().max()) + 1e-30
+            assert float((a.grad.cpu().double() - b.grad).abs().max()) < 2e-3 * gs, (fn_dev.__name__, float((a.grad.cpu().double() - b.grad).abs().max()), gs)
+
+    X, Y = m[..., :2], m[..., 2:]
+    both(uF._sym_epi_dist, oracle.sym_epi_dist, [Fgt, X, Y])
+    both(uF._sampson_dist, oracle.sampson_dist, [Fgt, X, Y])
+    both(uF._epi_distance, oracle.epi_distance, [Fgt, X, Y], pick=lambda o: o[0])
+    both(uF._sym_epi_dist, oracle.sym_epi_dist, [Fgt[0], X[0], Y[0]])
+    p1, p2, _ = oracle.normalize_hw(m.double(), IMAGE_SIZE)
+    both(lambda a, b, F: uF.compute_epi_residual(a, b, F, 0.5), lambda a, b, F: oracle.compute_epi_residual(a, b, F, 0.5), [p1, p2, Fgt])
+    # decomposition / quaternion: the torch gauge on both sides (the reference's own)
+    E = sc["E_gt"][0]
+    both(lambda e: torch.stack(uF._get_M2s(e)[2]), lambda e: torch.stack([torch.cat((R, t), 1) for R in oracle.get_M2s(e)[0] for t in oracle.get_M2s(e)[1]]), [E])
+    R = torch.linalg.inv(sc["delta_Rtijs_4_4"].double())[0, :3, :3]
+    both(uG._R_to_q, oracle.R_to_q, [R])
+    # textbook solvers, gradients w.r.t. the points (sign gauge: torch.linalg.svd on both sides)
+    Ki = torch.linalg.inv(K[0].double())
+    xn = (torch.cat((X[0].double(), torch.ones(60, 1, dtype=torch.float64)), 1) @ Ki.T)[:, :2]
+    yn = (torch.cat((Y[0].double(), torch.ones(60, 1, dtype=torch.float64)), 1) @ Ki.T)[:, :2]
+
+    def unit(Mx):
+        Mx = Mx / Mx.norm()
+        return Mx * torch.sign(Mx.flatten()[Mx.abs().flatten().argmax()])
+
+    dev_x = xn.float().to(DEV).requires_grad_(True)
+    ref_x = xn.clone().requires_grad_(True)
+    Fd = unit(uF._F_from_XY(dev_x, yn.float().to(DEV)))
+    Fr = unit(oracle.F_from_XY(ref_x, yn))
+    assert float((Fd.detach().cpu().double() - Fr.detach()).abs().max()) < 1e-3
+    Fk = unit(uF._F_from_XY(dev_x.detach(), yn.float().to(DEV)))  # the kernel
+    assert float((Fk.cpu().double() - Fr.detach()).abs().max()) < 1e-3
+    Fd[0, 1].backward()
+    Fr[0, 1].backward()
+    assert float((dev_x.grad.cpu().double() - ref_x.grad).abs().max()) < 2e-2 * float(ref_x.grad.abs().max())
+    Ed = uF._E_from_XY(dev_x.detach().requires_grad_(True), yn.float().to(DEV), K[0].to(DEV), if_normzliedK=True)
+    assert Ed.requires_grad and torch.isfinite(Ed).all()
 
 
 def test_epipolar_metrics_on_homogeneous_points(dfepe, oracle):
