@@ -23,6 +23,10 @@ import argparse
 import importlib
 import json
 import os
+
+# before the HIP runtime initialises: see pytorch-deepfepe_amd/__init__.py (ROCm 7.2 hipGraph replays are wrong for the full model's
+# captured step with the runtime's graph packet capture, and 3 % slower for the timed step); logged in config.env
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 import statistics
 import sys
 import time
@@ -758,7 +762,7 @@ def main():
                                          "overlap": "double-buffered asynchronous all_reduce (dist.OverlappedLossExchange)",
                                          "none": None}[exchange_mode],
                        "loss_exchange_fallback": exchange_fallback,
-                       "env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "DFEPE_BENCH_EXCHANGE", "NCCL_DEBUG")}},
+                       "env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "DEBUG_CLR_GRAPH_PACKET_CAPTURE", "DFEPE_BENCH_EXCHANGE", "NCCL_DEBUG")}},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "accuracy": acc,

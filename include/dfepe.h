@@ -418,6 +418,11 @@ int dfepe_inorm_lrelu_bwd(const float *Y, const float *gA, const float *gamma, c
  *                        chip): each pair's rows over `splits` workgroups in two launches (partial mean / squared deviations, merged
  *                        pairwise; then the normalisation), part = workspace of n_pairs * splits * 2 * C floats
  *   dfepe_est_in_bwd_n   dfepe_est_in_bwd for any N (ncols = n_pairs * N)
+ *   dfepe_est_dgamma_zero  the two adjoints above recover x^ as (z - beta) / gamma and take it as 0 where gamma is exactly 0 (their
+ *                        d beta and dY are right there, d gamma is not): this launch, run after them, overwrites dgamma_part[pair][ch]
+ *                        of every channel with |gamma| < 1e-30 from a recomputation of the layer's product (input planes [3] of
+ *                        [ncols][K-blocked], fp32 weights W [C][ldw], Ci input channels); channels with gamma != 0 cost an idle
+ *                        workgroup each.  N <= 4096
  *   dfepe_est_head_fwd   logits[col] = sum_c w[c] a[col][c] + bias[0]   (the last Conv1d(C -> 1))
  *   dfepe_est_head_dw    part[blocks][C] = partial sums of d w = sum_col dlogit[col] a[col][c]
  */
@@ -431,6 +436,9 @@ int dfepe_est_gemm_nt(const void *A, size_t a_plane, const void *B, size_t b_pla
                       float *out, int ldc, void *stream);
 int dfepe_est_gemm_tn(const void *dY, size_t dy_plane, int Cout, const void *X, size_t x_plane, int Cin, int ncols, int slices,
                       float *part, void *stream);
+int dfepe_est_dgamma_zero(const float *dA, const float *dlogit, const float *w_head, const void *out_planes, size_t out_plane,
+                          const void *in_planes, size_t in_plane, const float *W, int ldw, int Ci, const float *rstd, const float *gamma,
+                          float slope, int C, int N, long n_pairs, float *dgamma_part, void *stream);
 int dfepe_est_in_bwd(const float *dA, const float *dlogit, const float *w_head, const void *planes, size_t plane_stride,
                      const float *rstd, const float *gamma, const float *beta, float slope, int C, int ncols, void *dY,
                      size_t dy_plane, float *dgamma_part, float *dbeta_part, void *stream);

@@ -28,7 +28,7 @@ signature gets a graph of its own (all graphs share one memory pool).  Contract 
   * the optimizer updates parameters in place (every torch.optim one does); gradients are OVERWRITTEN by every replay, not
     accumulated, and ``optimizer.zero_grad(set_to_none=True)`` is harmless: the step re-attaches its static .grad tensors.
   * ``loss`` / ``aux`` are rewritten by the next call: copy what must outlive it.  Host-side metrics of get_Rt_loss found in
-    ``aux`` are lazy while captured (no device synchronisation inside the step); ``step.realise(aux)`` turns them into the
+    ``aux`` are lazy while captured (no device synchronisation inside the step); ``step.realise(aux)`` returns a copy with the
     reference's numpy arrays / floats, read from the buffers as they are after the latest replay.
 """
 from __future__ import annotations
@@ -165,6 +165,15 @@ class CapturedStep:
 
     def _capture(self, ent: _Entry, batch):
         from . import train_good_utils as tgu
+        import sys
+        import warnings
+
+        pkg = sys.modules[__name__.rsplit(".", 2)[0]]
+        if not getattr(pkg, "HIP_GRAPH_PACKET_CAPTURE_OFF", False):
+            warnings.warn("CapturedStep: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 is not in effect (the HIP runtime was initialised before this "
+                          "package was imported, or the environment sets it to another value); on ROCm 7.2 a captured step of the full "
+                          "model then replays with wrong parameter gradients from its second launch on (see the package __init__)",
+                          RuntimeWarning, stacklevel=3)
 
         cur = torch.cuda.current_stream(self.device)
         self._stream.wait_stream(cur)
@@ -254,19 +263,15 @@ class CapturedStep:
 
     @staticmethod
     def realise(aux):
-        """Every get_Rt_loss dict inside ``aux`` (or ``aux`` itself) -> the reference's numpy / float types, read now (one device
-        synchronisation); returns ``aux``."""
-        seen = [aux] if hasattr(aux, "realise") else []
-        if isinstance(aux, (dict, list, tuple)):
-            stack = [aux]
-            while stack:
-                cur = stack.pop()
-                vals = cur.values() if isinstance(cur, dict) else cur
-                for v in vals:
-                    if hasattr(v, "realise") and hasattr(v, "host_metrics"):
-                        seen.append(v)
-                    elif isinstance(v, (dict, list, tuple)) and not hasattr(v, "realise"):
-                        stack.append(v)
-        for g in seen:
-            g.realise()
-        return aux
+        """A copy of ``aux`` in which every get_Rt_loss dict (``aux`` itself may be one) carries the reference's host types -- numpy
+        arrays / python floats read from the device buffers as they are NOW (one device synchronisation).  The step's own ``aux``
+        stays lazy: it is static, the next replay rewrites the buffers behind it."""
+        def conv(x):
+            if hasattr(x, "realised") and hasattr(x, "host_metrics"):
+                return x.realised()
+            if isinstance(x, dict):
+                return type(x)((k, conv(v)) for k, v in x.items())
+            if isinstance(x, (list, tuple)) and not hasattr(x, "_fields"):
+                return type(x)(conv(v) for v in x)
+            return x
+        return conv(aux)

@@ -144,15 +144,28 @@ class _GeoErrors(dict):
         """Replace every lazy value by the reference's own type (python float / numpy array / list of numpy arrays), read from
         the device buffer as it is now: one device-to-host copy.  Returns self.  A capturing caller runs this after a replay
         (host_metrics.refresh() first) when it wants to log or pickle the dict."""
-        for k in self._LAZY_KEYS:
-            v = self[k]
-            if isinstance(v, list):
-                self[k] = [np.asarray(x._v()) if isinstance(x, _Lazy) else x for x in v]
-            elif isinstance(v, _LazyScalar):
-                self[k] = float(v._v())
-            elif isinstance(v, _Lazy):
-                self[k] = np.asarray(v._v())
+        self.update(self._realised_items())
         return self
+
+    def _realised_items(self):
+        out = {}
+        for k in self._LAZY_KEYS:
+            v = self.get(k)
+            if isinstance(v, list):
+                out[k] = [np.asarray(x._v()) if isinstance(x, _Lazy) else x for x in v]
+            elif isinstance(v, _LazyScalar):
+                out[k] = float(v._v())
+            elif isinstance(v, _Lazy):
+                out[k] = np.asarray(v._v())
+        return out
+
+    def realised(self):
+        """A NEW dict with the reference's host types, this one left lazy: what a replayed graph's (static) dict needs -- it is
+        rewritten by the next replay and must keep following the device buffer."""
+        new = _GeoErrors(self)
+        new.update(self._realised_items())
+        new.host_metrics = None
+        return new
 
 
 _dense_T_cache = {}

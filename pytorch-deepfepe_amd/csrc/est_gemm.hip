@@ -885,6 +885,71 @@ extern "C" int dfepe_est_gemm_tn(const void* dY, size_t dy_plane, int Cout, cons
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
+// ---- d gamma of a channel whose gamma is EXACTLY zero (ADVICE r3 / VERDICT r4 7d) ---------------------------------------------------
+// The adjoints above recover x^ from the stored activation as (z - beta) / gamma.  With gamma = 0 the activation is the constant
+// lrelu(beta) and x^ is gone: they take it as 0, which leaves d beta and dY right (dY = 0 there anyway) and d gamma = sum dz x^ wrong.
+// This kernel -- one workgroup per channel, leaving at once unless |gamma| < 1e-30, i.e. a handful of idle workgroups in any trained
+// network -- recomputes that channel's pre-normalisation product y = W[ch] . x from the layer's INPUT planes and fp32 weights, forms
+// x^ = (y - mean) rstd per pair and overwrites the channel's per-pair d gamma.  Slow (a serial GEMV per pair) and rare by construction.
+constexpr int kFixMaxN = 4096;
+__global__ void __launch_bounds__(256)
+est_dgamma_zero_kernel(const float* __restrict__ dA, const float* __restrict__ dlogit, const float* __restrict__ w_head,
+                       const bf16_t* __restrict__ out_planes, size_t out_stride, const bf16_t* __restrict__ in_planes, size_t in_stride,
+                       const float* __restrict__ W, int ldw, int Ci, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                       float slope, int C, int N, long n_pairs, float* __restrict__ dgamma_part) {
+  const int ch = (int)blockIdx.x;
+  if (fabsf(gamma[ch]) > 1e-30f) return;
+  __shared__ float y[kFixMaxN];
+  __shared__ float red[4];
+  const int t = (int)threadIdx.x;
+  const size_t ncols = (size_t)n_pairs * N;
+  auto plane3 = [&](const bf16_t* P, size_t stride, size_t at) {
+    return (__uint_as_float((unsigned)P[at] << 16) + __uint_as_float((unsigned)P[stride + at] << 16)) + __uint_as_float((unsigned)P[2 * stride + at] << 16);
+  };
+  auto block_sum = [&](float v) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((t & 63) == 0) red[t >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+  };
+  for (long pair = 0; pair < n_pairs; ++pair) {
+    const size_t col0 = (size_t)pair * N;
+    float s = 0.f;
+    for (int r = t; r < N; r += 256) {
+      float acc = 0.f;
+      for (int k = 0; k < Ci; ++k) acc = fmaf(W[(size_t)ch * ldw + k], plane3(in_planes, in_stride, kb_index(col0 + r, k, ncols)), acc);
+      y[r] = acc;
+      s += acc;
+    }
+    const float mean = block_sum(s) / (float)N;
+    const float rs = rstd[(size_t)pair * C + ch];
+    float g = 0.f;
+    for (int r = t; r < N; r += 256) {
+      const size_t col = col0 + r;
+      const size_t at = kb_index(col, ch, ncols);
+      const float a = __uint_as_float((unsigned)out_planes[at] << 16) + __uint_as_float((unsigned)out_planes[out_stride + at] << 16);
+      const float d = (dA != nullptr) ? dA[col * C + ch] : dlogit[col] * w_head[ch];
+      const float dz = (a > 0.f) ? d : d * slope;
+      g = fmaf(dz, (y[r] - mean) * rs, g);
+    }
+    const float G = block_sum(g);
+    if (t == 0) dgamma_part[(size_t)pair * C + ch] = G;
+  }
+}
+
+extern "C" int dfepe_est_dgamma_zero(const float* dA, const float* dlogit, const float* w_head, const void* out_planes, size_t out_plane,
+                                     const void* in_planes, size_t in_plane, const float* W, int ldw, int Ci, const float* rstd,
+                                     const float* gamma, float slope, int C, int N, long n_pairs, float* dgamma_part, void* stream) {
+  if ((!dA && !(dlogit && w_head)) || !out_planes || !in_planes || !W || !rstd || !gamma || !dgamma_part) return DFEPE_ERR_INVALID_ARG;
+  if (C <= 0 || N <= 0 || N > kFixMaxN || n_pairs < 0 || Ci <= 0 || ldw < Ci || !(slope > 0.f)) return DFEPE_ERR_INVALID_ARG;
+  if (n_pairs == 0) return DFEPE_OK;
+  hipLaunchKernelGGL(est_dgamma_zero_kernel, dim3(C), dim3(256), 0, static_cast<hipStream_t>(stream), dA, dlogit, w_head,
+                     static_cast<const bf16_t*>(out_planes), out_plane, static_cast<const bf16_t*>(in_planes), in_plane, W, ldw, Ci, rstd, gamma,
+                     slope, C, N, n_pairs, dgamma_part);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
 extern "C" int dfepe_est_in_bwd(const float* dA, const float* dlogit, const float* w_head, const void* planes, size_t plane_stride,
                                 const float* rstd, const float* gamma, const float* beta, float slope, int C, int ncols, void* dY,
                                 size_t dy_plane, float* dgamma_part, float* dbeta_part, void* stream) {

@@ -19,6 +19,15 @@ from .ops import _on, _ptr, _stream
 Tensor = torch.Tensor
 BF16 = torch.bfloat16
 
+import os as _os
+
+_DEBUG_ZERO = set(filter(None, _os.environ.get("DFEPE_EST_DEBUG_ZERO", "").split(",")))
+
+
+def _buf(name, *shape, **kw):
+    """torch.empty, or torch.zeros for the buffers named in DFEPE_EST_DEBUG_ZERO (diagnostics: hunting reads of unwritten memory)."""
+    return (torch.zeros if (name in _DEBUG_ZERO or "all" in _DEBUG_ZERO) else torch.empty)(*shape, **kw)
+
 
 def supported(x: Tensor) -> bool:
     """Any [B, C, N] on the GPU with B >= 1, N >= 2 (N = dfepe_est_points() takes the fused epilogue, see _fused; a single point
@@ -36,7 +45,7 @@ def _pad32(c: int) -> int:
 
 def _split(src: Tensor, rows: int, c_src: int, c: int, n_planes: int) -> Tensor:
     """fp32 [rows, c_src] (contiguous) -> bf16 planes [n_planes, rows, c], channels past c_src zero."""
-    out = torch.empty(n_planes, rows, c, device=src.device, dtype=BF16)
+    out = _buf("split", n_planes, rows, c, device=src.device, dtype=BF16)
     rc = _lib.lib().dfepe_est_split(_ptr(src), rows, c_src, c_src, c, n_planes, _ptr(out), rows * c, _stream())
     _lib.check(rc, "dfepe_est_split")
     return out
@@ -82,19 +91,19 @@ class _EstimatorFunction(torch.autograd.Function):
                 Co, Ci = W.shape[0], W.shape[1]
                 K = acts[-1].shape[2]
                 Wp = _split(W.detach().float().reshape(Co, Ci).contiguous(), Co, Ci, K, 3)
-                out = torch.empty(3, cols, Co, device=dev, dtype=BF16)
-                rstd = torch.empty(B, Co, device=dev, dtype=torch.float32)
+                out = _buf("out", 3, cols, Co, device=dev, dtype=BF16)
+                rstd = _buf("rstd", B, Co, device=dev, dtype=torch.float32)
                 g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
                 if _fused(N):
                     rc = lib.dfepe_est_layer_fwd(_ptr(Wp), Co * K, _ptr(acts[-1]), cols * K, Co, cols, K, _ptr(g32), _ptr(b32), float(eps),
                                                  float(slope), _ptr(out), cols * Co, _ptr(rstd), st)
                     _lib.check(rc, "dfepe_est_layer_fwd")
                 else:  # the plain product (six bf16 products, fp32 out), then the statistics over each pair's N columns
-                    Y = torch.empty(cols, Co, device=dev, dtype=torch.float32)
+                    Y = _buf("Y", cols, Co, device=dev, dtype=torch.float32)
                     rc = lib.dfepe_est_gemm_nt(_ptr(Wp), Co * K, _ptr(acts[-1]), cols * K, Co, cols, K, 3, _ptr(Y), Co, st)
                     _lib.check(rc, "dfepe_est_gemm_nt")
                     sp = _row_splits(B, Co, N)
-                    part = torch.empty(B * sp * 2 * Co, device=dev, dtype=torch.float32) if sp > 1 else None
+                    part = _buf("npart", B * sp * 2 * Co, device=dev, dtype=torch.float32) if sp > 1 else None
                     rc = lib.dfepe_est_norm_fwd(_ptr(Y), Co, Co, B, N, _ptr(g32), _ptr(b32), float(eps), float(slope), _ptr(out), cols * Co,
                                                 _ptr(rstd), sp, _ptr(part), st)
                     _lib.check(rc, "dfepe_est_norm_fwd")
@@ -106,7 +115,7 @@ class _EstimatorFunction(torch.autograd.Function):
             n_out = Wh.shape[0]  # 1: the weight heads; 4: update_offsets (if_learn_offsets, models/DeepFNet.py:330,342)
             wh = Wh.detach().float().reshape(n_out, C).contiguous()
             bh32 = None if bh is None else bh.detach().float().contiguous()
-            logits = torch.empty(n_out, cols, device=dev, dtype=torch.float32)
+            logits = _buf("logits", n_out, cols, device=dev, dtype=torch.float32)
             for o in range(n_out):  # a GEMV per output channel over the same planes
                 rc = lib.dfepe_est_head_fwd(_ptr(acts[-1]), cols * C, C, cols, _ptr(wh[o]), _ptr(None if bh32 is None else bh32[o:o + 1]),
                                             _ptr(logits[o]), st)
@@ -143,7 +152,7 @@ class _EstimatorFunction(torch.autograd.Function):
             dl = g_logits.detach().float().permute(1, 0, 2).reshape(n_out, cols).contiguous()  # [n_out, cols]
             wh = Wh.detach().float().reshape(n_out, C).contiguous()
             nblk = 512
-            part = torch.empty(n_out, nblk, C, device=dev, dtype=torch.float32)
+            part = _buf("hpart", n_out, nblk, C, device=dev, dtype=torch.float32)
             for o in range(n_out):
                 rc = lib.dfepe_est_head_dw(_ptr(acts[-1]), cols * C, C, cols, nblk, _ptr(dl[o]), _ptr(part[o]), st)
                 _lib.check(rc, "dfepe_est_head_dw")
@@ -160,9 +169,9 @@ class _EstimatorFunction(torch.autograd.Function):
                 Co, Ci = W.shape[0], W.shape[1]
                 a_out, a_in = acts[l + 1], acts[l]
                 K = a_in.shape[2]
-                dY = torch.empty(2, cols, Co, device=dev, dtype=BF16)
-                dg = torch.empty(B, Co, device=dev, dtype=torch.float32)
-                db = torch.empty(B, Co, device=dev, dtype=torch.float32)
+                dY = _buf("dY", 2, cols, Co, device=dev, dtype=BF16)
+                dg = _buf("dg", B, Co, device=dev, dtype=torch.float32)
+                db = _buf("db", B, Co, device=dev, dtype=torch.float32)
                 g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
                 if _fused(N):
                     rc = lib.dfepe_est_in_bwd(_ptr(dA), _ptr(dl if dA is None else None), _ptr(wh if dA is None else None), _ptr(a_out), cols * Co,
@@ -171,33 +180,44 @@ class _EstimatorFunction(torch.autograd.Function):
                     _lib.check(rc, "dfepe_est_in_bwd")
                 else:
                     sp = _row_splits(B, Co, N)
-                    part = torch.empty(B * sp * 2 * Co, device=dev, dtype=torch.float32) if sp > 1 else None
+                    part = _buf("npart", B * sp * 2 * Co, device=dev, dtype=torch.float32) if sp > 1 else None
                     rc = lib.dfepe_est_in_bwd_n(_ptr(dA), _ptr(dl if dA is None else None), _ptr(wh if dA is None else None), _ptr(a_out),
                                                 cols * Co, _ptr(rstds[l]), _ptr(g32), _ptr(b32), float(slope), Co, B, N, _ptr(dY), cols * Co,
                                                 _ptr(dg), _ptr(db), sp, _ptr(part), st)
                     _lib.check(rc, "dfepe_est_in_bwd_n")
+                # channels whose gamma is exactly 0: x^ cannot be recovered from the stored activation; their d gamma is recomputed from
+                # the layer's input (idle workgroups otherwise; N beyond the fix kernel's 4096 keeps the documented zero)
+                if N <= 4096:
+                    W32 = W.detach().float().reshape(Co, Ci).contiguous()
+                    rc = lib.dfepe_est_dgamma_zero(_ptr(dA), _ptr(dl if dA is None else None), _ptr(wh if dA is None else None), _ptr(a_out),
+                                                   cols * Co, _ptr(a_in), cols * K, _ptr(W32), Ci, Ci, _ptr(rstds[l]), _ptr(g32), float(slope), Co, N, B,
+                                                   _ptr(dg), st)
+                    _lib.check(rc, "dfepe_est_dgamma_zero")
                 grads[4 * l + 2] = dg.sum(0).to(gamma.dtype)
                 grads[4 * l + 3] = db.sum(0).to(beta.dtype)
-                grads[4 * l + 1] = torch.zeros_like(bconv)  # the bias cancels in the instance normalisation: exact zero, like the reference's autograd
+                grads[4 * l + 1] = (torch.empty_like(bconv).fill_(0.0) if "nomemset" in _DEBUG_ZERO else torch.zeros_like(bconv))  # the bias cancels in the instance normalisation: exact zero, like the reference's autograd
                 # dW = dY^T X (split-K over the columns, partials summed here: deterministic)
                 slices = _slices_for(Co, K)
-                partw = torch.empty(slices, Co, K, device=dev, dtype=torch.float32)
+                partw = _buf("partw", slices, Co, K, device=dev, dtype=torch.float32)
                 rc = lib.dfepe_est_gemm_tn(_ptr(dY), cols * Co, Co, _ptr(a_in), cols * K, K, cols, slices, _ptr(partw), st)
                 _lib.check(rc, "dfepe_est_gemm_tn")
                 grads[4 * l] = partw.sum(0)[:, :Ci].reshape(W.shape).to(W.dtype)
                 need_dx = l > 0 or ctx.needs_input_grad[1]
                 if need_dx:
                     Mp = (K + 7) // 8 * 8
-                    WT = torch.zeros(Mp, Co, device=dev, dtype=torch.float32)
+                    WT = (torch.empty(Mp, Co, device=dev, dtype=torch.float32).fill_(0.0) if "nomemset" in _DEBUG_ZERO else
+                          torch.zeros(Mp, Co, device=dev, dtype=torch.float32))
                     WT[:Ci] = W.detach().float().reshape(Co, Ci).t()
                     WTp = _split(WT, Mp, Co, Co, 2)
-                    dA = torch.empty(cols, Mp, device=dev, dtype=torch.float32)
+                    dA = _buf("dA", cols, Mp, device=dev, dtype=torch.float32)
                     rc = lib.dfepe_est_gemm_nt(_ptr(WTp), Mp * Co, _ptr(dY), cols * Co, Mp, cols, Co, 2, _ptr(dA), Mp, st)
                     _lib.check(rc, "dfepe_est_gemm_nt")
                 del dY
             gx = None
             if ctx.needs_input_grad[1]:
                 gx = dA[:, :C0].reshape(B, N, C0).permute(0, 2, 1).contiguous()
+        if "clone" in _DEBUG_ZERO:
+            grads = [None if g is None else g.clone() for g in grads]
         return (None, gx, *grads)
 
 

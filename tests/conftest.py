@@ -3,6 +3,9 @@ import importlib
 import os
 import sys
 
+# before anything touches the HIP runtime (pytorch-deepfepe_amd/__init__.py explains; the package sets it too, on import)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import numpy as np
 import pytest
 

@@ -69,9 +69,9 @@ def test_captured_step_equals_the_eager_sequence_over_batches(dfepe, pose_gt):
                 assert p.grad is not None
                 torch.testing.assert_close(p.grad, g, rtol=1e-5, atol=1e-7 * float(g.abs().max()) + 1e-12)
                 worst = max(worst, float((p.grad - g).abs().max() / g.abs().max().clamp_min(1e-30)))
-            dfepe.compat.CapturedStep.realise(aux)
-            got_R = aux["geo"]["R_angle_error_layers_list"][-1]
-            assert isinstance(got_R, np.ndarray) and isinstance(aux["geo"]["R_angle_error_mean"], float)
+            host = dfepe.compat.CapturedStep.realise(aux)
+            got_R = host["geo"]["R_angle_error_layers_list"][-1]
+            assert isinstance(got_R, np.ndarray) and isinstance(host["geo"]["R_angle_error_mean"], float)
             np.testing.assert_allclose(got_R, ref_R, atol=1e-5)
     # two signatures (device ground truth: batches 0 and 2; host ground truth: batch 1), each: two eager steps, then its graph
     assert (step.n_eager, step.n_captures, step.n_replays) == (4, 2, 5), (step.n_eager, step.n_captures, step.n_replays)
