@@ -229,13 +229,17 @@ class CapturedStep:
 
     @staticmethod
     def _refresh(aux):
-        for _, x in _flatten(aux):
+        """Forget the cached host copies of every get_Rt_loss dict inside ``aux``: the replay rewrote the device buffers."""
+        stack = [aux]
+        while stack:
+            x = stack.pop()
             hm = getattr(x, "host_metrics", None)
             if hm is not None and hasattr(hm, "refresh"):
                 hm.refresh()
-        hm = getattr(aux, "host_metrics", None)  # aux itself may be get_Rt_loss's dict
-        if hm is not None and hasattr(hm, "refresh"):
-            hm.refresh()
+            if isinstance(x, dict):
+                stack.extend(x.values())
+            elif isinstance(x, (list, tuple)):
+                stack.extend(x)
 
     # ------------------------------------------------------------------------------------------------------------------
     def __call__(self, batch):
