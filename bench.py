@@ -776,6 +776,14 @@ def main():
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
     if dist is not None:
         dist.barrier()
+        # the captured graphs hold the communicator's collective as a node: they go first, and the device is idle, before the process
+        # group is torn down (a watchdog thread that still sees work on a destroyed communicator aborts the process)
+        graph = None
+        state.clear()
+        import gc
+
+        gc.collect()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 
