@@ -21,6 +21,20 @@ __device__ __forceinline__ double hw_rcp64(double x) { return __builtin_amdgcn_r
 
 __device__ __forceinline__ int rg_lane() { return (int)(threadIdx.x & 15u); }
 
+// value of the same lane of the NEIGHBOURING row (lane ^ 16) -- for kernels that give a pair two rows of one wavefront; a DPP
+// operand cannot cross a row, so this goes through the LDS crossbar (ds_bpermute, no LDS memory)
+__device__ __forceinline__ float rg_xrow(float v) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 63u) ^ 16u) << 2), __float_as_int(v)));
+}
+__device__ __forceinline__ double rg_xrow(double v) {
+  union { double d; int i[2]; } a, r;
+  a.d = v;
+  const int addr = (int)(((threadIdx.x & 63u) ^ 16u) << 2);
+  r.i[0] = __builtin_amdgcn_ds_bpermute(addr, a.i[0]);
+  r.i[1] = __builtin_amdgcn_ds_bpermute(addr, a.i[1]);
+  return r.d;
+}
+
 template <int CTRL>
 __device__ __forceinline__ int rg_dpp_i32(int v) {
   return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, true);

@@ -29,6 +29,13 @@ static bool use_lean(int pairs) {
   static const int forced = [] { const char* e = getenv("DFEPE_FIT_LEAN"); return e ? atoi(e) : -1; }();
   return forced < 0 ? pairs >= kLeanMinPairs : forced != 0;
 }
+// N > 128, one row per pair: below this many pairs a SIMD holds a single wavefront, and two rows per pair (twice the wavefronts, each
+// with half the per-correspondence work) are faster.  DFEPE_FIT_PAIR2 = 0 / 1 forces it off / on (A/B timing).
+constexpr int kPair2MaxPairs = 8192;
+static bool use_pair2(int pairs) {
+  static const int forced = [] { const char* e = getenv("DFEPE_FIT_PAIR2"); return e ? atoi(e) : -1; }();
+  return forced < 0 ? pairs < kPair2MaxPairs : forced != 0;
+}
 static bool use_coop(int N, int pairs, bool row_per_pair) { return N > 128 && N <= kCoopMaxN && pairs <= kCoopMaxPairs && !row_per_pair; }
 
 // Kernel arguments (forward and backward alike): what a wavefront needs before it can issue its global loads comes first, as plain scalars / pointers --
@@ -73,6 +80,26 @@ w8pt16_fwd_lean_kernel(const float* pts1, const float* pts2, const float* wts, i
   A.clamp_at = clamp_at; A.F_out = F_out; A.residual = residual; A.epi_res = R.epi_res; A.save = R.save;
   A.weights_out = R.weights_out; A.logits_mode = R.logits_mode; A.variant = R.variant; A.row_per_pair = false;
   w8pt16_fwd_pair<IT, RAW, PLAIN, 1, true>(A, pair, xch + row * 36);
+}
+
+// N > 128 at a few thousand pairs: TWO rows of a wavefront per pair (w8pt16_body.h: ROWS = 2).  One row per pair is one wavefront per
+// SIMD at 4096 pairs -- a lone in-order stream of 21 000 instructions at N = 1000 --; with two rows a pair's correspondences are
+// walked by 32 lanes (half the per-correspondence instructions per wavefront), the eigen phases run once per wavefront as before,
+// and the 2048 wavefronts are two per SIMD (236 registers) that fill each other's issue bubbles.
+constexpr int kPairsPerBlock2 = 8;
+template <bool RAW, bool PLAIN>
+__global__ void __launch_bounds__(256, 2)  // instantiated for pixel matches only
+w8pt16_pair2_fwd_kernel(const float* pts1, const float* pts2, const float* wts, int B, int Bm, int N, float hw_sx, float hw_sy,
+                        float clamp_at, float* F_out, float* residual, const W8FwdRest R) {
+  __shared__ double xch[kPairsPerBlock2 * 36];
+  const int prow = (int)(threadIdx.x >> 5);  // pair within the workgroup
+  const int pair = (int)blockIdx.x * kPairsPerBlock2 + prow;
+  if (pair >= B) return;  // both rows of a pair leave together
+  W8Args A;
+  A.pts1 = pts1; A.pts2 = pts2; A.wts = wts; A.B = B; A.Bm = Bm; A.N = N; A.hw_sx = hw_sx; A.hw_sy = hw_sy;
+  A.clamp_at = clamp_at; A.F_out = F_out; A.residual = residual; A.epi_res = R.epi_res; A.save = R.save;
+  A.weights_out = R.weights_out; A.logits_mode = R.logits_mode; A.variant = R.variant; A.row_per_pair = false;
+  w8pt16_fwd_pair<0, RAW, PLAIN, 2>(A, pair, xch + prow * 36, nullptr, (int)(threadIdx.x >> 4) & 1);
 }
 
 // Cooperative variant: one 256-thread workgroup (16 rows) per pair, for N > 128 (w8pt16_body.h: W8Coop).
@@ -210,6 +237,12 @@ void launch_fwd(const W8Args& A, hipStream_t st) {
     else if (N <= 1024) DFEPE_CFWD(4);
     else DFEPE_CFWD(8);
 #undef DFEPE_CFWD
+  } else if (RAW && N > 128 && use_pair2(A.B)) {  // two rows of a wavefront per pair (pixel matches: the homogeneous-point
+    if constexpr (RAW) {                         // instantiations need 300 registers and keep the row kernel)
+      const dim3 grid2((A.B + kPairsPerBlock2 - 1) / kPairsPerBlock2);
+      hipLaunchKernelGGL((w8pt16_pair2_fwd_kernel<true, PLAIN>), grid2, block, 0, st, A.pts1, A.pts2, A.wts, A.B, A.Bm, A.N, A.hw_sx, A.hw_sy,
+                         A.clamp_at, A.F_out, A.residual, R);
+    }
   } else if (N > 128) DFEPE_FWD(0);  // any N: correspondences re-read per phase
   else if (N <= 16) DFEPE_FWD(1);
   else if (N <= 32) DFEPE_FWD(2);

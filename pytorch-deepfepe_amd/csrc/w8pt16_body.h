@@ -452,7 +452,8 @@ struct W8Coop {
 // 45 registers fewer.  (A register cap alone makes the compiler spill exactly these values to scratch memory and back.)
 template <int IT, bool RAW, bool PLAIN, int ROWS = 1, bool LEAN = false>
 __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair, double* xch, W8Coop* co = nullptr, const int rowid = 0) {
-  static_assert(ROWS == 1 || (ROWS == 16 && IT > 0), "one row per pair, or the 16 rows of a workgroup with the correspondences in registers");
+  static_assert(ROWS == 1 || (ROWS == 16 && IT > 0) || (ROWS == 2 && IT == 0),
+                "one row per pair, the 16 rows of a workgroup with the correspondences in registers, or two rows of one wavefront (looped)");
   static_assert(!LEAN || (IT > 0 && ROWS == 1), "the lean build is a variant of the registers-resident row kernel");
   constexpr int S = 16 * ROWS;  // lanes per pair
   const int l = rg_lane();
@@ -462,16 +463,25 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   // slot[r], re-read as lane r's operand of a second row reduction).  Every call site has its own slot: one barrier per reduction.
   auto psum = [&](double v, int slot) {
     v = rg_sum(v);
-    if constexpr (ROWS > 1) {
+    if constexpr (ROWS == 2) {
+      v += rg_xrow(v);  // the pair's other row sits 16 lanes away in the same wavefront: one exchange, no LDS, no barrier
+    } else if constexpr (ROWS > 1) {
       if (l == 0) co->red[slot][rowid] = v;
       DFEPE_BLOCK_SYNC();
       v = rg_sum(co->red[slot][l]);
     }
     return v;
   };
+  auto psumf = [&](float v) {  // looped kernels only (ROWS <= 2): the sum of the exponentials, in fp32 like the row kernel's
+    v = rg_sum(v);
+    if constexpr (ROWS == 2) v += rg_xrow(v);
+    return v;
+  };
   auto pmaxf = [&](float v, int slot) {
     v = rg_max(v);
-    if constexpr (ROWS > 1) {
+    if constexpr (ROWS == 2) {
+      v = fmaxf(v, rg_xrow(v));
+    } else if constexpr (ROWS > 1) {
       if (l == 0) co->red[slot][rowid] = (double)v;
       DFEPE_BLOCK_SYNC();
       v = rg_max((float)co->red[slot][l]);
@@ -599,7 +609,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
       sx1 += (double)p.x1; sy1 += (double)p.y1; sx2 += (double)p.x2; sy2 += (double)p.y2;
       sme += r.ws;
     });
-    if (IT == 0 && A.logits_mode) linv = 1.0f / rg_sum(sme);
+    if (IT == 0 && A.logits_mode) linv = 1.0f / psumf(sme);
     c1x = psum(sx1, 2) * invN; c1y = psum(sy1, 3) * invN; c2x = psum(sx2, 4) * invN; c2y = psum(sy2, 5) * invN;
   DFEPE_MARK("P1");
     // ---- phase 1: Hartley scale (mean distance to the centroid) -------------------------------------------------
@@ -621,7 +631,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   if (IT == 0 && A.logits_mode && !hartley) {
     float sme = 0.0f;
     for_points<IT>(nit, point_load, point, [&](int it, const PRec& r) { sme += r.ws; });
-    linv = 1.0f / rg_sum(sme);
+    linv = 1.0f / psumf(sme);
   }
   wstage = 1;
   DFEPE_MARK("P2");
@@ -669,7 +679,13 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
       if (l & m) { idx += h; cnt -= h; } else { cnt = (cnt < h) ? cnt : h; }
       width = h;
     }
-    if constexpr (ROWS > 1) {
+    if constexpr (ROWS == 2) {  // both rows end up with the pair's totals and write the same values
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acc[k] += rg_xrow(acc[k]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (k < cnt) xch[idx + k] = acc[k];
+    } else if constexpr (ROWS > 1) {
 #pragma unroll
       for (int k = 0; k < 3; ++k)
         if (k < cnt) co->part[rowid][idx + k] = acc[k];
@@ -687,11 +703,14 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
         if (k < cnt) xch[idx + k] = acc[k];
     }
   }
-  if constexpr (ROWS > 1) xch = co->xch;
+  if constexpr (ROWS > 2) xch = co->xch;
   else rg_sync();
   double f[9];
   float of[9];
-  if (ROWS == 1 || rowid == 0) {  // the solver phases: one row per pair
+  // ROWS = 2: BOTH rows run the solver phases on the same numbers (they share the wavefront's instruction stream: nothing is saved
+  // by masking one of them off); row 0 alone stores
+  const bool storer = ROWS != 2 || rowid == 0;
+  if (ROWS <= 2 || rowid == 0) {  // the solver phases: one row per pair
   // sum (u, v) is M[3r+c][3r'+c'] for (r, r') = symmetric pair u, (c, c') = symmetric pair v.  Lane i < 9 fetches row i.
   double Ar[9];
   double tr;
@@ -820,7 +839,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     float mine = of[0];
 #pragma unroll
     for (int c = 1; c < 9; ++c) mine = (l == c) ? of[c] : mine;
-    if (l < 9) A.F_out[(size_t)pair * 9 + l] = mine;
+    if (l < 9 && storer) A.F_out[(size_t)pair * 9 + l] = mine;
   }
 
   DFEPE_MARK("P5s_save");
@@ -850,7 +869,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
       sv[(l > k && l < 9) ? S16_HV + s16_hv_off(k) + (l - k - 1) : 24] = hvf[k];
   }
   } else {
-  if (A.save != nullptr) {
+  if (A.save != nullptr && storer) {
     float* sv = static_cast<float*>(__builtin_assume_aligned(A.save, 16)) + (size_t)pair * DFEPE_SAVE_FLOATS;
     // Everything but the reflector components is uniform over the row.  Under load a global store INSTRUCTION costs this lone
     // wavefront 50-70 cycles whatever its width or the number of lanes behind it (scripts/ubench/lat2.hip), a select 5: so the
@@ -900,11 +919,11 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
       sv[(l > k && l < 9) ? S16_HV + s16_hv_off(k) + (l - k - 1) : 24] = (float)hv[k];
   }
   }
-  if constexpr (ROWS > 1) {
+  if constexpr (ROWS > 2) {
     if (l < 9) { co->f[l] = f[l]; co->of[l] = of[l]; }
   }
   }  // solver row
-  if constexpr (ROWS > 1) {
+  if constexpr (ROWS > 2) {
     DFEPE_BLOCK_SYNC();
 #pragma unroll
     for (int c = 0; c < 9; ++c) { f[c] = co->f[c]; of[c] = co->of[c]; }

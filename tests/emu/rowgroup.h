@@ -25,6 +25,9 @@
 // the cooperative (16 rows per pair) variant of the bodies is device-only: the emulation runs one row per pair, where the
 // block-level barrier is never reached
 #define DFEPE_BLOCK_SYNC() abort()
+// likewise the two-rows-of-a-wavefront variant (ROWS = 2): never instantiated here
+inline float rg_xrow(float) { abort(); }
+inline double rg_xrow(double) { abort(); }
 
 struct float4 {
   float x, y, z, w;

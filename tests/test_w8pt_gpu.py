@@ -224,9 +224,13 @@ def test_lean_forward_fit_of_large_batches_is_bit_identical(dfepe, N):
     big = dfepe.ops.w8pt_forward(m, None, lg, True, 1241.0, 376.0, 0.5, True, True, logits=True)
     for c in range(0, B, 4096):
         part = dfepe.ops.w8pt_forward(m[c:c + 4096].contiguous(), None, lg[c:c + 4096].contiguous(), True, 1241.0, 376.0, 0.5, True, True, logits=True)
-        for x, y in zip(big, part):
-            a, b = torch.nan_to_num(x[c:c + 4096]), torch.nan_to_num(y)  # float 24 of the record is a scratch slot
-            assert torch.equal(a, b)
+        for k, (x, y) in enumerate(zip(big, part)):
+            a, b = x[c:c + 4096].clone(), y.clone()
+            if k == 3:  # the `save` record: float 24 is the scratch slot of the reflector lanes' stray stores, 25 and 61..63 are never
+                for col in (24, 25, 61, 62, 63):  # written (the reflector components occupy 26..60): memory as it was
+                    a[:, col] = 0.0
+                    b[:, col] = 0.0
+            assert torch.equal(a, b), k
     F, res, epi, save, wout = big
     g = dfepe.ops.w8pt_backward(m, None, wout, True, 1241.0, 376.0, 0.5, save, F, torch.ones_like(F), None, None, logits=True)
     assert torch.isfinite(g).all()
