@@ -37,6 +37,13 @@ static bool use_pair2(int pairs) {
   return forced < 0 ? pairs < kPair2MaxPairs : forced != 0;
 }
 static bool use_coop(int N, int pairs, bool row_per_pair) { return N > 128 && N <= kCoopMaxN && pairs <= kCoopMaxPairs && !row_per_pair; }
+// the FORWARD fit leaves the cooperative workgroup earlier since round 5: two rows of a wavefront per pair (w8pt16_pair2_fwd_kernel) beat it
+// from ~1300 pairs on (N = 1000, scripts/fit_n1000_sizes.py: 1024 pairs 29.7 vs 34.1 us, 2048 54.7 vs 37.7, 3072 78.3 vs 57.0); the `save`
+// record is the same whichever kernel wrote it, so the backward keeps its own threshold
+constexpr int kCoopFwdMaxPairs = 1280;
+static bool use_coop_fwd(int N, int pairs, bool row_per_pair, bool raw) {
+  return use_coop(N, pairs, row_per_pair) && (pairs <= kCoopFwdMaxPairs || !raw);
+}
 
 // Kernel arguments (forward and backward alike): what a wavefront needs before it can issue its global loads comes first, as plain scalars / pointers --
 // with -amdgpu-kernarg-preload-count=16 (build.py) the command processor hands those 16 dwords over in SGPRs at wave launch,
@@ -228,7 +235,7 @@ void launch_fwd(const W8Args& A, hipStream_t st) {
 #define DFEPE_FWD(IT_)                                                                                                     \
   hipLaunchKernelGGL((w8pt16_fwd_kernel<IT_, RAW, PLAIN>), grid, block, 0, st, A.pts1, A.pts2, A.wts, A.B, A.Bm, A.N, A.hw_sx, \
                      A.hw_sy, A.clamp_at, A.F_out, A.residual, R)
-  if (use_coop(N, A.B, A.row_per_pair)) {  // one workgroup per pair: 16 rows x IT correspondences per lane
+  if (use_coop_fwd(N, A.B, A.row_per_pair, RAW)) {  // one workgroup per pair: 16 rows x IT correspondences per lane
     const dim3 cgrid(A.B);
 #define DFEPE_CFWD(IT_)                                                                                                    \
   hipLaunchKernelGGL((w8pt16_coop_fwd_kernel<IT_, RAW, PLAIN>), cgrid, block, 0, st, A.pts1, A.pts2, A.wts, A.B, A.Bm, A.N, A.hw_sx, \
@@ -375,7 +382,7 @@ extern "C" int dfepe_w8pt_pose_fwd(const float* matches, const float* weights, i
   if (reinterpret_cast<uintptr_t>(matches) & 15u) return DFEPE_ERR_INVALID_ARG;
   // A/B switch (measurement only, read once): DFEPE_POSE_LAUNCHES=2 forces the two launches, =1 the fused one where it exists
   static const int forced_launches = [] { const char* e = getenv("DFEPE_POSE_LAUNCHES"); return e ? atoi(e) : 0; }();
-  if (forced_launches == 2 || !use_coop(N, B, (flags & DFEPE_W8PT_ROW_PER_PAIR) != 0)) {  // any other shape: the two launches this one replaces
+  if (forced_launches == 2 || !use_coop_fwd(N, B, (flags & DFEPE_W8PT_ROW_PER_PAIR) != 0, true)) {  // any other shape: the two launches this one replaces
     const int rc = dfepe_w8pt_fwd(matches, nullptr, weights, B, N, 1, flags, image_w, image_h, clamp_at, F_out, residual, epi_res, nullptr,
                                   weights_out, stream);
     if (rc != DFEPE_OK) return rc;

@@ -230,7 +230,8 @@ def test_lean_forward_fit_of_large_batches_is_bit_identical(dfepe, N):
                 for col in (24, 25, 61, 62, 63):  # written (the reflector components occupy 26..60): memory as it was
                     a[:, col] = 0.0
                     b[:, col] = 0.0
-            assert torch.equal(a, b), k
+            # bit patterns: the record carries doubles as float pairs, whose halves may read as NaN
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), k
     F, res, epi, save, wout = big
     g = dfepe.ops.w8pt_backward(m, None, wout, True, 1241.0, 376.0, 0.5, save, F, torch.ones_like(F), None, None, logits=True)
     assert torch.isfinite(g).all()
