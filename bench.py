@@ -489,12 +489,13 @@ def main():
         row_kernel = True
         kname = ("w8pt16_fwd_kernel<raw> (one 16-lane row per pair, correspondences in registers)" if N <= dfepe._lib.W8PT16_MAX_N
                  else "w8pt16_fwd_kernel<0, raw> (one 16-lane row per pair, correspondences re-read per phase)")
-        traffic = issue = None
+        traffic = issue = rocprof_us = rocprof_src = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get(f"fit_fwd_B{B}_N{N}")
+                rocprof_us, rocprof_src = tj.get(f"fit_fwd_rocprof_avg_us_B{B}_N{N}"), tj.get("fit_fwd_rocprof_source")
                 valu = tj.get(f"fit_fwd_valu_insts_per_wave_B{B}_N{N}")
                 if valu and row_kernel:
                     # what actually limits this kernel: four pairs per wavefront, ceil(B / 4 / 1024 SIMDs) wavefronts per SIMD,
@@ -531,6 +532,10 @@ def main():
         roofline = {"bound": "hbm", "kernel": kname, "alu": alu, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                     "avg_kernel_us": round(kdur_us, 2), "algorithmic_bytes_per_launch": alg_bytes,
+                    # the same kernel's average in the committed rocprofv3 kernel trace (another box, under the profiler): the two
+                    # methods differ by a few per cent ("say so in the line") -- `frac` is the live HIP-event one
+                    "rocprof_avg_kernel_us": rocprof_us, "rocprof_source": rocprof_src,
+                    "frac_from_rocprof_avg": (round(alg_bytes / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5) if rocprof_us else None),
                     "launches_per_step": L, "vector_issue": issue,
                     "traffic_note": "profiles/traffic.json: PMC FETCH_SIZE/WRITE_SIZE of this probe launch, which in the training configs "
                                     "also writes the 512-B save record per pair on top of the 28N+36 algorithmic bytes",

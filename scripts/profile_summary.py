@@ -159,6 +159,9 @@ if valu and fwd_avg_us:
     traffic[f"fit_fwd_valu_insts_per_wave_B{B}_N{N}"] = round(valu, 1)
 if clk_ghz:
     traffic["fit_fwd_sustained_clock_ghz"] = round(clk_ghz, 3)
+if fwd_avg_us:
+    traffic[f"fit_fwd_rocprof_avg_us_B{B}_N{N}"] = round(fwd_avg_us, 3)
+    traffic["fit_fwd_rocprof_source"] = f"profiles/{tag}_bench_kernel_stats.csv (rocprofv3 --kernel-trace average at the hot-path grid)"
 json.dump(traffic, open(os.path.join(P, "traffic.json"), "w"), indent=1)
 open(os.path.join(P, f"{tag}_rocprof_summary.md"), "w").write("\n".join(md) + "\n")
 print("\n".join(md))
