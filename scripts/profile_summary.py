@@ -87,8 +87,11 @@ for (k, g), ds in groups.items():
 md += ["", f"bench line of the same (profiled) run: `value` = {line['value']:.0f} pairs/s, ms_per_step = {line['ms_per_step']}, "
        f"roofline.avg_kernel_us = {line['roofline']['avg_kernel_us']} (HIP events around a hipGraph of 50 back-to-back stand-alone fits, "
        f"i.e. kernel + the dispatch gap between dependent launches).  The rocprof average of the forward fit at the hot-path grid is "
-       f"{fwd_avg_us:.2f} us.  Sum of the step's kernel averages: {step_sum:.1f} us of the {1e3*line['ms_per_step']:.1f} us step; the rest is "
-       "dispatch gaps between the 11 dependent launches.", ""]
+       f"{fwd_avg_us:.2f} us.  Sum of the step's kernel averages: {step_sum:.1f} us against the {1e3*line['ms_per_step']:.1f} us step"
+       + ("; the rest is dispatch gaps between the 11 dependent launches." if step_sum < 1e3 * line['ms_per_step'] else
+          " -- the averages pool every launch of the run (roofline probe, block repeats, the informational variants, all under the profiler's "
+          "per-dispatch instrumentation), the step is timed on the graph replays alone: since round 5 (HIP graph packet capture off, "
+          "pytorch-deepfepe_amd/__init__.py) the replayed step shows no measurable gap between its 11 dependent launches."), ""]
 
 fetch, write = counters("pmc_fetch"), counters("pmc_write")
 alg = {  # algorithmic bytes per launch in the fused step (SURVEY.md 8d + what the step additionally writes)
