@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFEPE_VERSION 150 /* 0.5.0 */
+#define DFEPE_VERSION 151 /* 0.5.0 */
 
 #define DFEPE_OK 0
 #define DFEPE_ERR_INVALID_ARG (-1) /* null pointer, non-positive size, bad flag combination   */
@@ -400,19 +400,32 @@ int dfepe_inorm_lrelu_bwd(const float *Y, const float *gA, const float *gamma, c
  * The weight estimator on the matrix cores, N = dfepe_est_points() = 100 points per pair.
  * Replaces: ErrorEstimator.forward, the Conv1d(k=1) -> InstanceNorm1d(affine) -> LeakyReLU stack and its autograd backward
  *           (deepFEPE/models/ErrorEstimators.py:47-64, called at deepFEPE/models/DeepFNet.py:441,510).
- * Every fp32 operand travels as bf16 PLANES (a = a0 + a1 + a2, exact), a forward product = six bf16 MFMAs (fp32-class accuracy),
- * a backward product = three.  Plane buffers are bf16, POINT-major and K-blocked: element (row, ch) of a plane with `rows` rows
+ * Every fp32 operand travels as 16-bit PLANES, exact remainders of each other.  Forward products (round 5): TWO fp16 planes per
+ * operand (22 mantissa bits), three MFMAs (a0 b0 + a0 b1 + a1 b0, fp32 accumulate): fp32-class accuracy at half the matrix work of
+ * the six bf16 products of rounds 3-4; a layer's weights are split scaled by the power of two that brings max |W| into [8, 16)
+ * (their low plane would otherwise sit in fp16's subnormal range), the accumulators are scaled back before the statistics.
+ * Backward products: two bf16 planes each (three MFMAs, ~2^-16; gradients keep bf16's range without any loss scaling), so a
+ * forward layer that will be differentiated also leaves its activation as two bf16 planes.  Domain: |activation| <= 65504 (fp16;
+ * InstanceNorm bounds it by |gamma| sqrt(N - 1) + |beta|) -- beyond it the logits are NaN, not silently wrong.
+ * Plane buffers are 16-bit, POINT-major and K-blocked: element (row, ch) of a plane with `rows` rows
  * lives at ((ch / 32) * rows + row) * 32 + ch % 32; `*_plane` arguments are the element strides between planes; ncols = pairs * 100.
- *   dfepe_est_split      fp32 [rows][C_src] (ld = src_ld) -> n_planes planes with C (% 32 == 0) channels, the tail zero
- *   dfepe_est_layer_fwd  planes_out[3][...M] = split(leaky_relu(instance_norm(W X) * gamma + beta)); rstd [pairs][M];
- *                        W planes [3] of [M][K], X planes [3] of [ncols][K]; the convolution bias cancels in the normalisation
- *   dfepe_est_gemm_nt    out[col][m] (fp32, ld = ldc) = sum_k A[m][k] B[col][k] on n_planes (2 or 3) planes: the data gradient
- *                        dA = W^T dY
+ *   dfepe_est_split      fp32 [rows][C_src] (ld = src_ld) -> n_planes bf16 planes with C (% 32 == 0) channels, the tail zero
+ *   dfepe_est_absmax     *word = max(*word, bit pattern of max |src[i]|) -- the caller zeroes the word first; the scale of
+ *                        dfepe_est_split_f16 / dfepe_est_layer_fwd / dfepe_est_gemm_nt_f16 is derived from it on the device
+ *   dfepe_est_split_f16  the same into two fp16 planes, the values multiplied by the scale of `absmax` (null: unscaled)
+ *   dfepe_est_layer_fwd  planes_out[2][...M] (fp16) = split(leaky_relu(instance_norm(W X) * gamma + beta)), planes_bwd[2][...M]
+ *                        (bf16; null when no gradient is wanted) the same activation for the backward; rstd [pairs][M];
+ *                        W planes [2] of [M][K] split with `absmax` (or null), X planes [2] of [ncols][K], both fp16; the
+ *                        convolution bias cancels in the normalisation
+ *   dfepe_est_gemm_nt    out[col][m] (fp32, ld = ldc) = sum_k A[m][k] B[col][k] on n_planes (2 or 3) bf16 planes: the data
+ *                        gradient dA = W^T dY
+ *   dfepe_est_gemm_nt_f16  the forward's plain product on two fp16 planes each, A split with `absmax` (or null)
  *   dfepe_est_gemm_tn    part[slices][Cout][Cin] = split-K partial sums of dW = dY^T X (two planes each; the caller adds the slices)
  *   dfepe_est_in_bwd     dY planes [2] = adjoint of InstanceNorm + LeakyReLU given dA [ncols][C] fp32 (or its rank-one head form
- *                        dlogit[col] * w_head[c]), the layer's output planes [3], rstd, gamma, beta; per-pair d gamma / d beta
- *   dfepe_est_norm_fwd   any N points per pair (the reference's SIFT configurations: up to 2000): planes [3] and rstd from the
- *                        plain product Y fp32 [n_pairs * N][ldy] of dfepe_est_gemm_nt -- InstanceNorm (biased variance, two-pass),
+ *                        dlogit[col] * w_head[c]), the layer's output planes [2] (bf16), rstd, gamma, beta; per-pair d gamma / d beta
+ *   dfepe_est_norm_fwd   any N points per pair (the reference's SIFT configurations: up to 2000): planes_out [2] (fp16), planes_bwd
+ *                        [2] (bf16, or null) and rstd from the plain product Y fp32 [n_pairs * N][ldy] of dfepe_est_gemm_nt_f16 --
+ *                        InstanceNorm (biased variance, two-pass),
  *                        affine, LeakyReLU, split; dfepe_est_layer_fwd is this fused into the product for N = dfepe_est_points().
  *                        splits = 1: one launch, a workgroup per (pair, 64 channels); splits in 2..64 (a dozen pairs do not fill the
  *                        chip): each pair's rows over `splits` workgroups in two launches (partial mean / squared deviations, merged
@@ -420,18 +433,23 @@ int dfepe_inorm_lrelu_bwd(const float *Y, const float *gA, const float *gamma, c
  *   dfepe_est_in_bwd_n   dfepe_est_in_bwd for any N (ncols = n_pairs * N)
  *   dfepe_est_dgamma_zero  the two adjoints above recover x^ as (z - beta) / gamma and take it as 0 where gamma is exactly 0 (their
  *                        d beta and dY are right there, d gamma is not): this launch, run after them, overwrites dgamma_part[pair][ch]
- *                        of every channel with |gamma| < 1e-30 from a recomputation of the layer's product (input planes [3] of
+ *                        of every channel with |gamma| < 1e-30 from a recomputation of the layer's product (input planes [2], bf16, of
  *                        [ncols][K-blocked], fp32 weights W [C][ldw], Ci input channels); channels with gamma != 0 cost an idle
  *                        workgroup each.  N <= 4096
- *   dfepe_est_head_fwd   logits[col] = sum_c w[c] a[col][c] + bias[0]   (the last Conv1d(C -> 1))
- *   dfepe_est_head_dw    part[blocks][C] = partial sums of d w = sum_col dlogit[col] a[col][c]
+ *   dfepe_est_head_fwd   logits[col] = sum_c w[c] a[col][c] + bias[0]   (the last Conv1d(C -> 1)); a: the forward's planes [2] (fp16)
+ *   dfepe_est_head_dw    part[blocks][C] = partial sums of d w = sum_col dlogit[col] a[col][c]; a: the backward's planes [2] (bf16)
  */
 int dfepe_est_points(void);
 int dfepe_est_split(const float *src, long rows, int C_src, int src_ld, int C, int n_planes, void *planes, size_t plane_stride,
                     void *stream);
+int dfepe_est_absmax(const float *src, long n, unsigned *word, void *stream);
+int dfepe_est_split_f16(const float *src, long rows, int C_src, int src_ld, int C, const unsigned *absmax, void *planes,
+                        size_t plane_stride, void *stream);
 int dfepe_est_layer_fwd(const void *W, size_t w_plane, const void *X, size_t x_plane, int M, int ncols, int K,
-                        const float *gamma, const float *beta, float eps, float slope, void *planes_out, size_t out_plane,
-                        float *rstd, void *stream);
+                        const unsigned *absmax, const float *gamma, const float *beta, float eps, float slope, void *planes_out,
+                        size_t out_plane, void *planes_bwd, size_t bwd_plane, float *rstd, void *stream);
+int dfepe_est_gemm_nt_f16(const void *A, size_t a_plane, const void *B, size_t b_plane, int M, int ncols, int K,
+                          const unsigned *absmax, float *out, int ldc, void *stream);
 int dfepe_est_gemm_nt(const void *A, size_t a_plane, const void *B, size_t b_plane, int M, int ncols, int K, int n_planes,
                       float *out, int ldc, void *stream);
 int dfepe_est_gemm_tn(const void *dY, size_t dy_plane, int Cout, const void *X, size_t x_plane, int Cin, int ncols, int slices,
@@ -443,7 +461,8 @@ int dfepe_est_in_bwd(const float *dA, const float *dlogit, const float *w_head, 
                      const float *rstd, const float *gamma, const float *beta, float slope, int C, int ncols, void *dY,
                      size_t dy_plane, float *dgamma_part, float *dbeta_part, void *stream);
 int dfepe_est_norm_fwd(const float *Y, int ldy, int C, long n_pairs, int N, const float *gamma, const float *beta, float eps,
-                       float slope, void *planes_out, size_t out_plane, float *rstd, int splits, float *part, void *stream);
+                       float slope, void *planes_out, size_t out_plane, void *planes_bwd, size_t bwd_plane, float *rstd, int splits,
+                       float *part, void *stream);
 int dfepe_est_in_bwd_n(const float *dA, const float *dlogit, const float *w_head, const void *planes, size_t plane_stride,
                        const float *rstd, const float *gamma, const float *beta, float slope, int C, long n_pairs, int N, void *dY,
                        size_t dy_plane, float *dgamma_part, float *dbeta_part, int splits, float *part, void *stream);

@@ -43,7 +43,17 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef unsigned short bf16_t;  // storage type of a plane element
+typedef unsigned short bf16_t;  // storage type of a plane element (bf16 or fp16 bits)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(8))) short frag8;  // an MFMA operand fragment: eight 16-bit values of either format
+enum { FMT_BF16 = 0, FMT_F16 = 1 };
+
+template <int FMT>
+__device__ __forceinline__ f32x4 mfma16(const frag8& a, const frag8& b, const f32x4& c) {
+  if constexpr (FMT == FMT_F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
 #define DFEPE_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define DFEPE_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -80,6 +90,26 @@ __device__ __forceinline__ void split2(float x, float y, unsigned& p0, unsigned&
   const bf16x2 m = __builtin_convertvector(v, bf16x2);
   p0 = __builtin_bit_cast(unsigned, h); p1 = __builtin_bit_cast(unsigned, m);
 }
+// fp32 -> two fp16 planes (round-to-nearest-even each; 22 mantissa bits while the low plane stays in fp16's normal range,
+// an absolute 2^-25 below it; |x| > 65504 overflows to inf / NaN -- loudly)
+__device__ __forceinline__ void split2h(float x, float y, unsigned& p0, unsigned& p1) {
+  f32x2 v = {x, y};
+  const f16x2 h = __builtin_convertvector(v, f16x2);
+  v -= __builtin_convertvector(h, f32x2);
+  const f16x2 m = __builtin_convertvector(v, f16x2);
+  p0 = __builtin_bit_cast(unsigned, h); p1 = __builtin_bit_cast(unsigned, m);
+}
+__device__ __forceinline__ float f16_lo(unsigned u) { return (float)__builtin_bit_cast(f16x2, u)[0]; }
+__device__ __forceinline__ float f16_hi(unsigned u) { return (float)__builtin_bit_cast(f16x2, u)[1]; }
+// The forward products run on fp16 planes.  Weights are small (1 / sqrt(fan-in)): unscaled, their low plane would sit in fp16's
+// subnormal range and lose bits, so a layer's weights are split as W * s with s the power of two that brings max |W| into [8, 16)
+// (exact), and the product's accumulators are scaled back before anything else reads them.  `bits` = the fp32 bit pattern of max |W|
+// (est_absmax_kernel); exponent clamped so that s and 1 / s^2 stay normal fp32 numbers.
+__device__ __forceinline__ float wscale(unsigned bits, bool inverse) {
+  int eb = (int)((bits >> 23) & 255u);
+  eb = eb < 100 ? 100 : (eb > 150 ? 150 : eb);
+  return __uint_as_float((unsigned)(inverse ? eb - 3 : 257 - eb) << 23);
+}
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
@@ -93,6 +123,10 @@ enum { EPI_F32 = 0, EPI_IN = 1 };
 #ifndef DFEPE_NT2_BLOCKS
 #define DFEPE_NT2_BLOCKS 3  // workgroups per CU the two-plane (data-gradient) product is compiled for
 #endif
+#ifndef DFEPE_FWD_BLOCKS
+#define DFEPE_FWD_BLOCKS 3  // workgroups per CU the two-plane forward layer (fused epilogue) is compiled for: 168 registers, 43 KB of LDS each;
+                            // measured at B = 4096: forward 2.49 ms against 2.67 with two (one fragment set then, fetched per tile, like the data gradient)
+#endif
 
 struct EpiArgs {
   // EPI_F32: out[col][m] fp32, ld = ldc
@@ -102,9 +136,13 @@ struct EpiArgs {
   const float* gamma;
   const float* beta;
   float eps, slope;
-  bf16_t* planes;        // [3][ncols][M]
+  bf16_t* planes;        // [3][ncols][M] bf16 (FMT_BF16) or [2][ncols][M] fp16 (FMT_F16): the next layer's operand
   size_t plane_stride;   // elements between planes
   float* rstd;           // [npairs][M]
+  // FMT_F16
+  const unsigned* absmax;  // bits of max |W| (the weights were split scaled, see wscale); null: unscaled
+  bf16_t* planes_bwd;      // [2][ncols][M] bf16: what the backward reads (est_in_bwd, est_gemm_tn); null: not kept (no gradient wanted)
+  size_t bwd_stride;
 };
 
 // C[m][n] = sum over plane pairs (i, j), i + j <= ORDER, of A_i[m][:] . B_j[n][:]
@@ -117,8 +155,8 @@ struct EpiArgs {
 // weights straight from global memory into a second register set + two LDS stages of the activations only, still two workgroups
 // per CU: 1.47 vs 1.43 ms with two planes (206 registers), spills with three.  The step is bound by instruction issue around the
 // MFMAs (DMA setup, fragment reads, barriers), not by an exposed load latency.
-template <int NPA, int NPB, int ORDER, int EPI>
-__global__ void __launch_bounds__(256, (NPA == 2 && NPB == 2) ? DFEPE_NT2_BLOCKS : 2)
+template <int NPA, int NPB, int ORDER, int EPI, int FMT = FMT_BF16>
+__global__ void __launch_bounds__(256, (NPA == 2 && NPB == 2 && EPI == EPI_F32) ? DFEPE_NT2_BLOCKS : ((NPA == 2 && NPB == 2) ? DFEPE_FWD_BLOCKS : 2))
 est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* __restrict__ B, size_t b_plane, int M, int ncols, int K,
                    const EpiArgs E) {
   constexpr int kABytes = NPA * BM * 64, kBBytes = NPB * BN * 64;
@@ -175,23 +213,23 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
       }
     }
   };
-  auto a_from_lds = [&](const unsigned char* lds, bf16x8 (&a)[2][NPA]) {
+  auto a_from_lds = [&](const unsigned char* lds, frag8 (&a)[2][NPA]) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int p = 0; p < NPA; ++p)
-        a[mt][p] = *reinterpret_cast<const bf16x8*>(lds + ((p * BM + wave * 32 + 8 * (c >> 2) + 4 * mt + (c & 3)) * 4 + (g ^ fswA[mt])) * 16);
+        a[mt][p] = *reinterpret_cast<const frag8*>(lds + ((p * BM + wave * 32 + 8 * (c >> 2) + 4 * mt + (c & 3)) * 4 + (g ^ fswA[mt])) * 16);
   };
-  auto mfma_phase = [&](const unsigned char* lds, const bf16x8 (&a)[2][NPA]) {
+  auto mfma_phase = [&](const unsigned char* lds, const frag8 (&a)[2][NPA]) {
     // the column tile's B fragments are fetched one tile ahead of the MFMAs that consume them (two register sets): the LDS
     // latency of tile nt + 1 hides behind the twelve MFMAs of tile nt instead of stalling every tile
     // (the two-plane product compiled for three workgroups per CU has 168 registers: one fragment set, fetched per tile -- the
     // third wavefront on the SIMD covers the LDS latency the second set would)
-    constexpr bool kAhead = !(NPA == 2 && NPB == 2 && DFEPE_NT2_BLOCKS > 2);
-    bf16x8 b[kAhead ? 2 : 1][NPB];
+    constexpr bool kAhead = !(NPA == 2 && NPB == 2 && (EPI == EPI_F32 ? DFEPE_NT2_BLOCKS : DFEPE_FWD_BLOCKS) > 2);
+    frag8 b[kAhead ? 2 : 1][NPB];
     if (kAhead) {
 #pragma unroll
-      for (int p = 0; p < NPB; ++p) b[0][p] = *reinterpret_cast<const bf16x8*>(lds + kABytes + ((p * BN + c) * 4 + (g ^ fsw)) * 16);
+      for (int p = 0; p < NPB; ++p) b[0][p] = *reinterpret_cast<const frag8*>(lds + kABytes + ((p * BN + c) * 4 + (g ^ fsw)) * 16);
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -199,11 +237,11 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
         if (nt + 1 < NT) {
 #pragma unroll
           for (int p = 0; p < NPB; ++p)
-            b[(nt + 1) & (kAhead ? 1 : 0)][p] = *reinterpret_cast<const bf16x8*>(lds + kABytes + ((p * BN + (nt + 1) * 16 + c) * 4 + (g ^ fsw)) * 16);
+            b[(nt + 1) & (kAhead ? 1 : 0)][p] = *reinterpret_cast<const frag8*>(lds + kABytes + ((p * BN + (nt + 1) * 16 + c) * 4 + (g ^ fsw)) * 16);
         }
       } else {
 #pragma unroll
-        for (int p = 0; p < NPB; ++p) b[0][p] = *reinterpret_cast<const bf16x8*>(lds + kABytes + ((p * BN + nt * 16 + c) * 4 + (g ^ fsw)) * 16);
+        for (int p = 0; p < NPB; ++p) b[0][p] = *reinterpret_cast<const frag8*>(lds + kABytes + ((p * BN + nt * 16 + c) * 4 + (g ^ fsw)) * 16);
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this tile's MFMAs (the scheduler would sink it to its first use)
       // smallest terms first; the two row tiles alternate, so that no MFMA waits for the one issued just before it
@@ -215,7 +253,7 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
           if (i < NPA && j < NPB) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][i], b[kAhead ? (nt & 1) : 0][j], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = mfma16<FMT>(a[mt][i], b[kAhead ? (nt & 1) : 0][j], acc[mt][nt]);
           }
         }
       __builtin_amdgcn_sched_barrier(0);
@@ -226,7 +264,7 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
     stage_issue(ks, lds_all);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    bf16x8 a[2][NPA];
+    frag8 a[2][NPA];
     a_from_lds(lds_all, a);
     mfma_phase(lds_all, a);
     __syncthreads();
@@ -235,20 +273,28 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
   // ---- epilogue: lane holds, per column n0 + 16 nt + c, channels ch8 + 4 mt + r (mt = 0, 1; r = 0..3): eight in a row --------
   const int ch8 = m0 + wave * 32 + 8 * g;
   const bool chok = ch8 < M;  // M % 8 == 0
+  float unscale = 1.0f;  // FMT_F16: the weights were split scaled by a power of two
+  if constexpr (FMT == FMT_F16) unscale = E.absmax ? wscale(*E.absmax, true) : 1.0f;
   if constexpr (EPI == EPI_F32) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int cl = nt * 16 + c, col = n0 + cl;
       if (cl < BSTEP && col < ncols && chok) {
         float* dst = E.out + (size_t)col * E.ldc + ch8;
-        *reinterpret_cast<f32x4*>(dst) = acc[0][nt];
-        *reinterpret_cast<f32x4*>(dst + 4) = acc[1][nt];
+        if constexpr (FMT == FMT_F16) {
+          *reinterpret_cast<f32x4*>(dst) = acc[0][nt] * unscale;
+          *reinterpret_cast<f32x4*>(dst + 4) = acc[1][nt] * unscale;
+        } else {
+          *reinterpret_cast<f32x4*>(dst) = acc[0][nt];
+          *reinterpret_cast<f32x4*>(dst + 4) = acc[1][nt];
+        }
       }
     }
   } else {
     // pair 0 = columns 0..99 (tiles 0..5 and lanes 0..3 of tile 6), pair 1 = 100..199 (lanes 4..15 of tile 6, tiles 7..11,
     // lanes 0..7 of tile 12); lanes 8..15 of tile 12 belong to the next block
     const float inv_n = 1.0f / (float)kPts;
+    const float inv_n2 = inv_n * unscale * unscale;
     const bool t6p0 = c < 4, t12ok = c < 8;
     const int pair0 = 2 * bx;
     const int chc = chok ? ch8 : 0;
@@ -276,8 +322,10 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
         for (int nt = 7; nt < 12; ++nt) { const float d = acc[mt][nt][r] - mu1; q1 = fmaf(d, d, q1); }
         { const float d = acc[mt][12][r] - mu1; q1 += t12ok ? d * d : 0.f; }
         mean0[mt][r] = mu0; mean1[mt][r] = mu1;
-        rs0[mt][r] = 1.0f / sqrtf(row16_sum(q0) * inv_n + E.eps);  // biased variance, like F.instance_norm
-        rs1[mt][r] = 1.0f / sqrtf(row16_sum(q1) * inv_n + E.eps);
+        // biased variance, like F.instance_norm.  FMT_F16: the accumulators are s x the product (s a power of two: mean and
+        // deviations scale exactly), so the variance is q / s^2 and the normalised value (acc - mean) (rstd / s)
+        rs0[mt][r] = 1.0f / sqrtf(row16_sum(q0) * inv_n2 + E.eps);
+        rs1[mt][r] = 1.0f / sqrtf(row16_sum(q1) * inv_n2 + E.eps);
       }
       if (chok && c == 0) {
         if ((size_t)(pair0) * kPts < (size_t)ncols) *reinterpret_cast<f32x4*>(E.rstd + (size_t)pair0 * M + ch8 + 4 * mt) = rs0[mt];
@@ -285,13 +333,13 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
       }
       // z = (v - mean) * (rstd gamma) + beta  (the difference first: no cancellation against a large mean)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { rs0[mt][r] *= gam[mt][r]; rs1[mt][r] *= gam[mt][r]; }
+      for (int r = 0; r < 4; ++r) { rs0[mt][r] *= gam[mt][r] * unscale; rs1[mt][r] *= gam[mt][r] * unscale; }
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const bool first = (nt < 6) || (nt == 6 && t6p0);
       const int cl = nt * 16 + c, col = n0 + cl;
-      unsigned pl[3][4];
+      unsigned pl[4][4];  // FMT_BF16: three bf16 planes; FMT_F16: two fp16 planes (forward) + two bf16 planes (backward)
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         float v[4];
@@ -300,13 +348,30 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
           const float z = fmaf(acc[mt][nt][r] - (first ? mean0[mt][r] : mean1[mt][r]), first ? rs0[mt][r] : rs1[mt][r], bet[mt][r]);
           v[r] = (z > 0.f) ? z : z * E.slope;
         }
-        split3(v[0], v[1], pl[0][2 * mt], pl[1][2 * mt], pl[2][2 * mt]);
-        split3(v[2], v[3], pl[0][2 * mt + 1], pl[1][2 * mt + 1], pl[2][2 * mt + 1]);
+        if constexpr (FMT == FMT_F16) {
+          split2h(v[0], v[1], pl[0][2 * mt], pl[1][2 * mt]);
+          split2h(v[2], v[3], pl[0][2 * mt + 1], pl[1][2 * mt + 1]);
+          if (E.planes_bwd) {  // uniform
+            split2(v[0], v[1], pl[2][2 * mt], pl[3][2 * mt]);
+            split2(v[2], v[3], pl[2][2 * mt + 1], pl[3][2 * mt + 1]);
+          }
+        } else {
+          split3(v[0], v[1], pl[0][2 * mt], pl[1][2 * mt], pl[2][2 * mt]);
+          split3(v[2], v[3], pl[0][2 * mt + 1], pl[1][2 * mt + 1], pl[2][2 * mt + 1]);
+        }
       }
       if (cl < BSTEP && col < ncols && chok) {
-        bf16_t* dst = E.planes + kb_index((size_t)col, ch8, (size_t)ncols);
+        const size_t at = kb_index((size_t)col, ch8, (size_t)ncols);
+        bf16_t* dst = E.planes + at;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(dst + p * E.plane_stride) = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
+        for (int p = 0; p < (FMT == FMT_F16 ? 2 : 3); ++p) *reinterpret_cast<uint4*>(dst + p * E.plane_stride) = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
+        if constexpr (FMT == FMT_F16) {
+          if (E.planes_bwd) {
+            bf16_t* bw = E.planes_bwd + at;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) *reinterpret_cast<uint4*>(bw + p * E.bwd_stride) = make_uint4(pl[2 + p][0], pl[2 + p][1], pl[2 + p][2], pl[2 + p][3]);
+          }
+        }
       }
     }
   }
@@ -537,7 +602,7 @@ template <int MODE>
 __global__ void __launch_bounds__(1024)
 est_norm_fwd_n_kernel(const float* __restrict__ Y, int ldy, int C, int N, size_t ncols, const float* __restrict__ gamma,
                       const float* __restrict__ beta, float eps, float slope, bf16_t* __restrict__ planes, size_t plane_stride,
-                      float* __restrict__ rstd, float* __restrict__ part) {
+                      bf16_t* __restrict__ planes_bwd, size_t bwd_stride, float* __restrict__ rstd, float* __restrict__ part) {
   __shared__ float red[kRG][64];
   const int pair = (int)blockIdx.x, cb = (int)blockIdx.y * 64;
   const int S = (int)gridDim.z, sp = (int)blockIdx.z;
@@ -614,12 +679,17 @@ est_norm_fwd_n_kernel(const float* __restrict__ Y, int ldy, int C, int N, size_t
       const int rl = rb + kRG * u;
       if (rl >= r1) break;
       const float z0 = fmaf(y[u][0] - mu0, k0, b0), z1 = fmaf(y[u][1] - mu1, k1, b1);
-      unsigned p0, p1, p2;
-      split3((z0 > 0.f) ? z0 : z0 * slope, (z1 > 0.f) ? z1 : z1 * slope, p0, p1, p2);
+      const float a0 = (z0 > 0.f) ? z0 : z0 * slope, a1 = (z1 > 0.f) ? z1 : z1 * slope;
+      unsigned p0, p1;
+      split2h(a0, a1, p0, p1);  // two fp16 planes: the next layer's operand
       const size_t at = kb_index(col0 + rl, ch, ncols);
       *reinterpret_cast<unsigned*>(planes + at) = p0;
       *reinterpret_cast<unsigned*>(planes + plane_stride + at) = p1;
-      *reinterpret_cast<unsigned*>(planes + 2 * plane_stride + at) = p2;
+      if (planes_bwd) {  // two bf16 planes: what the backward reads
+        split2(a0, a1, p0, p1);
+        *reinterpret_cast<unsigned*>(planes_bwd + at) = p0;
+        *reinterpret_cast<unsigned*>(planes_bwd + bwd_stride + at) = p1;
+      }
     }
   }
 }
@@ -745,9 +815,8 @@ est_head_fwd_kernel(const bf16_t* __restrict__ planes, size_t plane_stride, int 
     const size_t at = kb_index((size_t)cc, ch, (size_t)ncols);
     const unsigned u0 = *reinterpret_cast<const unsigned*>(planes + at);
     const unsigned u1 = *reinterpret_cast<const unsigned*>(planes + plane_stride + at);
-    const unsigned u2 = *reinterpret_cast<const unsigned*>(planes + 2 * plane_stride + at);
-    s = fmaf((bf16_lo(u0) + bf16_lo(u1)) + bf16_lo(u2), w[ch], s);
-    s = fmaf((bf16_hi(u0) + bf16_hi(u1)) + bf16_hi(u2), w[ch + 1], s);
+    s = fmaf(f16_lo(u0) + f16_lo(u1), w[ch], s);  // the forward's two fp16 planes
+    s = fmaf(f16_hi(u0) + f16_hi(u1), w[ch + 1], s);
   }
   s = row16_sum(s);
   if (l == 0 && col < ncols) logits[col] = s + (bias ? bias[0] : 0.f);
@@ -822,9 +891,58 @@ est_split_kernel(const float* __restrict__ src, long rows, int C_src, int src_ld
   if (NP > 2) *reinterpret_cast<unsigned*>(planes + 2 * plane_stride + at) = p2;
 }
 
+// the same into two fp16 planes, optionally scaled by the layer's power of two (weights: see wscale)
+__global__ void __launch_bounds__(256)
+est_split_f16_kernel(const float* __restrict__ src, long rows, int C_src, int src_ld, int C, const unsigned* __restrict__ absmax,
+                     bf16_t* __restrict__ planes, size_t plane_stride) {
+  const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (e >= rows * C) return;
+  const float sc = absmax ? wscale(*absmax, false) : 1.0f;
+  const long r = e / C;
+  const int ch = (int)(e - r * C);
+  const float x = (ch < C_src) ? src[r * src_ld + ch] * sc : 0.f, y = (ch + 1 < C_src) ? src[r * src_ld + ch + 1] * sc : 0.f;
+  unsigned p0, p1;
+  split2h(x, y, p0, p1);
+  const size_t at = kb_index((size_t)r, ch, (size_t)rows);
+  *reinterpret_cast<unsigned*>(planes + at) = p0;
+  *reinterpret_cast<unsigned*>(planes + plane_stride + at) = p1;
+}
+// *word = max(*word, bits of max |src[i]|)  (non-negative floats order like their bit patterns; NaN / inf sort above: the clamp in
+// wscale keeps the scale finite and the NaN travels in the data)
+__global__ void __launch_bounds__(256)
+est_absmax_kernel(const float* __restrict__ src, long n, unsigned* __restrict__ word) {
+  unsigned m = 0u;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const unsigned b = __float_as_uint(src[i]) & 0x7fffffffu;
+    m = b > m ? b : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o, 64); m = t > m ? t : m; }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(word, m);
+}
+
 }  // namespace
 
 extern "C" int dfepe_est_points(void) { return kPts; }
+
+extern "C" int dfepe_est_absmax(const float* src, long n, unsigned* word, void* stream) {
+  if (!src || !word || n < 0) return DFEPE_ERR_INVALID_ARG;
+  if (n == 0) return DFEPE_OK;
+  long blocks = (n + 2047) / 2048;
+  blocks = blocks > 256 ? 256 : blocks;
+  hipLaunchKernelGGL(est_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, n, word);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+extern "C" int dfepe_est_split_f16(const float* src, long rows, int C_src, int src_ld, int C, const unsigned* absmax, void* planes,
+                                   size_t plane_stride, void* stream) {
+  if (!src || !planes || rows < 0 || C <= 0 || (C & 31) || C_src <= 0 || C_src > C) return DFEPE_ERR_INVALID_ARG;
+  if (rows == 0) return DFEPE_OK;
+  const unsigned blocks = (unsigned)((rows * C / 2 + 255) / 256);
+  hipLaunchKernelGGL(est_split_f16_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, rows, C_src, src_ld, C, absmax,
+                     static_cast<bf16_t*>(planes), plane_stride);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
 
 extern "C" int dfepe_est_split(const float* src, long rows, int C_src, int src_ld, int C, int n_planes, void* planes, size_t plane_stride,
                                void* stream) {
@@ -839,19 +957,34 @@ extern "C" int dfepe_est_split(const float* src, long rows, int C_src, int src_l
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
-// forward layer: planes_out[3][ncols][M] = split(lrelu(IN(W X))), rstd[npairs][M]
+// forward layer: planes_out[2][ncols][M] (fp16) = split(lrelu(IN(W X))) for the next layer, planes_bwd[2][ncols][M] (bf16, or
+// null) = the same activation as the backward reads it, rstd[npairs][M].  W, X: two fp16 planes each (three products); W split
+// scaled with `absmax` (dfepe_est_absmax + dfepe_est_split_f16), or unscaled with absmax = null.
 extern "C" int dfepe_est_layer_fwd(const void* W, size_t w_plane, const void* X, size_t x_plane, int M, int ncols, int K,
-                                   const float* gamma, const float* beta, float eps, float slope, void* planes_out,
-                                   size_t out_plane, float* rstd, void* stream) {
+                                   const unsigned* absmax, const float* gamma, const float* beta, float eps, float slope,
+                                   void* planes_out, size_t out_plane, void* planes_bwd, size_t bwd_plane, float* rstd, void* stream) {
   if (!W || !X || !gamma || !beta || !planes_out || !rstd || M <= 0 || (M & 31) || ncols <= 0 || (ncols % kPts) || K <= 0 || (K % BK))
     return DFEPE_ERR_INVALID_ARG;
   if (!(slope > 0.f)) return DFEPE_ERR_UNSUPPORTED;  // the backward inverts the activation
   EpiArgs E{};
   E.gamma = gamma; E.beta = beta; E.eps = eps; E.slope = slope; E.planes = static_cast<bf16_t*>(planes_out); E.plane_stride = out_plane;
-  E.rstd = rstd;
+  E.rstd = rstd; E.absmax = absmax; E.planes_bwd = static_cast<bf16_t*>(planes_bwd); E.bwd_stride = bwd_plane;
   const dim3 grid((ncols + BSTEP - 1) / BSTEP, (M + BM - 1) / BM), block(256);
-  hipLaunchKernelGGL((est_gemm_nt_kernel<3, 3, 2, EPI_IN>), grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(W),
-                     w_plane, static_cast<const bf16_t*>(X), x_plane, M, ncols, K, E);
+  hipLaunchKernelGGL((est_gemm_nt_kernel<2, 2, 1, EPI_IN, FMT_F16>), grid, block, 0, static_cast<hipStream_t>(stream),
+                     static_cast<const bf16_t*>(W), w_plane, static_cast<const bf16_t*>(X), x_plane, M, ncols, K, E);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+// the forward's plain product (any number of points per pair): out[col][m] fp32 = (1 / s) sum_terms A_i[m][:] . B_j[col][:] on two
+// fp16 planes each, A split scaled by s (absmax as above, or null)
+extern "C" int dfepe_est_gemm_nt_f16(const void* A, size_t a_plane, const void* B, size_t b_plane, int M, int ncols, int K,
+                                     const unsigned* absmax, float* out, int ldc, void* stream) {
+  if (!A || !B || !out || M <= 0 || (M & 7) || ncols <= 0 || K <= 0 || (K % BK) || ldc < M || (ldc & 3)) return DFEPE_ERR_INVALID_ARG;
+  EpiArgs E{};
+  E.out = out; E.ldc = ldc; E.absmax = absmax;
+  const dim3 grid((ncols + BSTEP - 1) / BSTEP, (M + BM - 1) / BM), block(256);
+  hipLaunchKernelGGL((est_gemm_nt_kernel<2, 2, 1, EPI_F32, FMT_F16>), grid, block, 0, static_cast<hipStream_t>(stream),
+                     static_cast<const bf16_t*>(A), a_plane, static_cast<const bf16_t*>(B), b_plane, M, ncols, K, E);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
@@ -903,8 +1036,8 @@ est_dgamma_zero_kernel(const float* __restrict__ dA, const float* __restrict__ d
   __shared__ float red[4];
   const int t = (int)threadIdx.x;
   const size_t ncols = (size_t)n_pairs * N;
-  auto plane3 = [&](const bf16_t* P, size_t stride, size_t at) {
-    return (__uint_as_float((unsigned)P[at] << 16) + __uint_as_float((unsigned)P[stride + at] << 16)) + __uint_as_float((unsigned)P[2 * stride + at] << 16);
+  auto plane2 = [&](const bf16_t* P, size_t stride, size_t at) {  // the backward's two bf16 planes (2^-17: a gradient)
+    return __uint_as_float((unsigned)P[at] << 16) + __uint_as_float((unsigned)P[stride + at] << 16);
   };
   auto block_sum = [&](float v) {
     v = wave_sum(v);
@@ -918,7 +1051,7 @@ est_dgamma_zero_kernel(const float* __restrict__ dA, const float* __restrict__ d
     float s = 0.f;
     for (int r = t; r < N; r += 256) {
       float acc = 0.f;
-      for (int k = 0; k < Ci; ++k) acc = fmaf(W[(size_t)ch * ldw + k], plane3(in_planes, in_stride, kb_index(col0 + r, k, ncols)), acc);
+      for (int k = 0; k < Ci; ++k) acc = fmaf(W[(size_t)ch * ldw + k], plane2(in_planes, in_stride, kb_index(col0 + r, k, ncols)), acc);
       y[r] = acc;
       s += acc;
     }
@@ -966,7 +1099,8 @@ extern "C" int dfepe_est_in_bwd(const float* dA, const float* dlogit, const floa
 // one launch, a workgroup per (pair, 64 channels); splits = 2..64 (few pairs): the pair's rows over `splits` workgroups, two
 // launches, part = workspace of n_pairs * splits * 2 * C floats.
 extern "C" int dfepe_est_norm_fwd(const float* Y, int ldy, int C, long n_pairs, int N, const float* gamma, const float* beta, float eps,
-                                  float slope, void* planes_out, size_t out_plane, float* rstd, int splits, float* part, void* stream) {
+                                  float slope, void* planes_out, size_t out_plane, void* planes_bwd, size_t bwd_plane, float* rstd,
+                                  int splits, float* part, void* stream) {
   if (!Y || !gamma || !beta || !planes_out || !rstd || C <= 0 || (C & 31) || ldy < C || (ldy & 1) || n_pairs < 0 || N <= 0)
     return DFEPE_ERR_INVALID_ARG;
   if (splits < 1 || splits > 64 || (splits > 1 && !part)) return DFEPE_ERR_INVALID_ARG;
@@ -977,11 +1111,12 @@ extern "C" int dfepe_est_norm_fwd(const float* Y, int ldy, int C, long n_pairs, 
   const dim3 grid((unsigned)n_pairs, (C + 63) / 64, splits), block(kRG * 32);
   const size_t ncols = (size_t)n_pairs * N;
   bf16_t* P = static_cast<bf16_t*>(planes_out);
+  bf16_t* Q = static_cast<bf16_t*>(planes_bwd);
   if (splits == 1) {
-    hipLaunchKernelGGL(est_norm_fwd_n_kernel<0>, grid, block, 0, st, Y, ldy, C, N, ncols, gamma, beta, eps, slope, P, out_plane, rstd, part);
+    hipLaunchKernelGGL(est_norm_fwd_n_kernel<0>, grid, block, 0, st, Y, ldy, C, N, ncols, gamma, beta, eps, slope, P, out_plane, Q, bwd_plane, rstd, part);
   } else {
-    hipLaunchKernelGGL(est_norm_fwd_n_kernel<1>, grid, block, 0, st, Y, ldy, C, N, ncols, gamma, beta, eps, slope, P, out_plane, rstd, part);
-    hipLaunchKernelGGL(est_norm_fwd_n_kernel<2>, grid, block, 0, st, Y, ldy, C, N, ncols, gamma, beta, eps, slope, P, out_plane, rstd, part);
+    hipLaunchKernelGGL(est_norm_fwd_n_kernel<1>, grid, block, 0, st, Y, ldy, C, N, ncols, gamma, beta, eps, slope, P, out_plane, Q, bwd_plane, rstd, part);
+    hipLaunchKernelGGL(est_norm_fwd_n_kernel<2>, grid, block, 0, st, Y, ldy, C, N, ncols, gamma, beta, eps, slope, P, out_plane, Q, bwd_plane, rstd, part);
   }
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }

@@ -2,11 +2,15 @@
 
 ``estimator_forward(x, layers, head)`` evaluates the Conv1d(k=1) -> InstanceNorm1d(affine) -> LeakyReLU stack of
 ErrorEstimator (deepFEPE/models/ErrorEstimators.py:47-64) with the kernels of csrc/est_gemm.hip: every fp32 operand travels as
-three bf16 planes (a = a0 + a1 + a2, exact), a forward product is six bf16 MFMAs with fp32 accumulation (fp32-class accuracy),
-a backward product three; InstanceNorm + LeakyReLU + the split into planes are the forward GEMM's epilogue for N = 100 points per
-pair, and a kernel of their own behind the plain product for any other N (the SIFT configurations' 1000-2000).  One autograd
-node for the whole stack; parameters and inputs are the module's own fp32 tensors.  PyTorch is plumbing here (allocation, the
-tiny weight transposes, the sums over split-K / per-pair partials)."""
+16-bit planes.  Forward (round 5): two fp16 planes per operand (a = a0 + a1 to 22 bits), three MFMAs per product with fp32
+accumulation -- fp32-class accuracy at half the matrix work of the six bf16 products of rounds 3-4; each layer's weights are split
+scaled by a power of two found on the device (dfepe_est_absmax) so that their low plane stays out of fp16's subnormal range.
+Backward: two bf16 planes, three MFMAs (gradients keep bf16's range, no loss scaling) -- a forward that will be differentiated
+also leaves each activation as two bf16 planes, one that will not (torch.no_grad(), nothing requires grad) skips them.
+InstanceNorm + LeakyReLU + the split into planes are the forward GEMM's epilogue for N = 100 points per pair, and a kernel of
+their own behind the plain product for any other N (the SIFT configurations' 1000-2000).  One autograd node for the whole stack;
+parameters and inputs are the module's own fp32 tensors.  PyTorch is plumbing here (allocation, the tiny weight transposes, the
+sums over split-K / per-pair partials)."""
 from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
@@ -18,6 +22,7 @@ from .ops import _on, _ptr, _stream
 
 Tensor = torch.Tensor
 BF16 = torch.bfloat16
+F16 = torch.float16
 
 import os as _os
 
@@ -51,6 +56,14 @@ def _split(src: Tensor, rows: int, c_src: int, c: int, n_planes: int) -> Tensor:
     return out
 
 
+def _split_f16(src: Tensor, rows: int, c_src: int, c: int, absmax: Optional[Tensor] = None) -> Tensor:
+    """fp32 [rows, c_src] (contiguous) -> two fp16 planes [2, rows, c], scaled by the power of two of `absmax` (weights) if given."""
+    out = _buf("split", 2, rows, c, device=src.device, dtype=F16)
+    rc = _lib.lib().dfepe_est_split_f16(_ptr(src), rows, c_src, c_src, c, _ptr(absmax), _ptr(out), rows * c, _stream())
+    _lib.check(rc, "dfepe_est_split_f16")
+    return out
+
+
 def _row_splits(pairs: int, c: int, n: int) -> int:
     """Workgroups a pair's rows are spread over in the N-generic normalisation kernels: 1 when (pair, 64-channel) workgroups
     alone fill the chip, otherwise enough to reach ~1024 workgroups with at least 128 rows (one unrolled trip) each."""
@@ -72,11 +85,11 @@ def _slices_for(cout: int, cin: int) -> int:
 
 class _EstimatorFunction(torch.autograd.Function):
     """args: x [B, C0, N], then per hidden layer (conv weight [Co,Ci,1], conv bias [Co], gamma [Co], beta [Co]), then the head's
-    (weight [O,C,1], bias [O] or None; O = 1 for the weight heads, 4 for update_offsets); cfg = (n_hidden, eps, slope)."""
+    (weight [O,C,1], bias [O] or None; O = 1 for the weight heads, 4 for update_offsets); cfg = (n_hidden, eps, slope, keep)."""
 
     @staticmethod
     def forward(ctx, cfg, x, *params):
-        n_hidden, eps, slope = cfg
+        n_hidden, eps, slope, keep = cfg
         lib = _lib.lib()
         B, C0, N = x.shape
         cols = B * N
@@ -84,40 +97,49 @@ class _EstimatorFunction(torch.autograd.Function):
         with _on(dev):
             st = _stream()  # the current stream of x's device, read under its guard
             xin = x.detach().float().permute(0, 2, 1).reshape(cols, C0).contiguous()
-            acts = [_split(xin, cols, C0, _pad32(C0), 3)]  # planes of every layer's input, point-major [3, cols, C]
+            # keep: a backward may come (estimator_forward: grad mode on and something requires grad); without one the bf16 planes
+            # the backward reads are neither computed nor stored
+            act = _split_f16(xin, cols, C0, _pad32(C0))  # the layer's input as the forward reads it: two fp16 planes [2, cols, C]
+            acts = [_split(xin, cols, C0, _pad32(C0), 2)] if keep else []  # ... and as the backward reads it: two bf16 planes
             rstds = []
+            wmax = torch.zeros(max(n_hidden, 1), device=dev, dtype=torch.int32)  # bit patterns of max |W| per layer (dfepe_est_absmax)
             for l in range(n_hidden):
                 W, _b, gamma, beta = params[4 * l:4 * l + 4]
                 Co, Ci = W.shape[0], W.shape[1]
-                K = acts[-1].shape[2]
-                Wp = _split(W.detach().float().reshape(Co, Ci).contiguous(), Co, Ci, K, 3)
-                out = _buf("out", 3, cols, Co, device=dev, dtype=BF16)
+                K = act.shape[2]
+                W32 = W.detach().float().reshape(Co, Ci).contiguous()
+                _lib.check(lib.dfepe_est_absmax(_ptr(W32), Co * Ci, _ptr(wmax[l:l + 1]), st), "dfepe_est_absmax")
+                Wp = _split_f16(W32, Co, Ci, K, wmax[l:l + 1])
+                out = _buf("out", 2, cols, Co, device=dev, dtype=F16)
+                out_b = _buf("out_b", 2, cols, Co, device=dev, dtype=BF16) if keep else None
                 rstd = _buf("rstd", B, Co, device=dev, dtype=torch.float32)
                 g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
                 if _fused(N):
-                    rc = lib.dfepe_est_layer_fwd(_ptr(Wp), Co * K, _ptr(acts[-1]), cols * K, Co, cols, K, _ptr(g32), _ptr(b32), float(eps),
-                                                 float(slope), _ptr(out), cols * Co, _ptr(rstd), st)
+                    rc = lib.dfepe_est_layer_fwd(_ptr(Wp), Co * K, _ptr(act), cols * K, Co, cols, K, _ptr(wmax[l:l + 1]), _ptr(g32), _ptr(b32),
+                                                 float(eps), float(slope), _ptr(out), cols * Co, _ptr(out_b), cols * Co, _ptr(rstd), st)
                     _lib.check(rc, "dfepe_est_layer_fwd")
-                else:  # the plain product (six bf16 products, fp32 out), then the statistics over each pair's N columns
+                else:  # the plain product (three fp16 products, fp32 out), then the statistics over each pair's N columns
                     Y = _buf("Y", cols, Co, device=dev, dtype=torch.float32)
-                    rc = lib.dfepe_est_gemm_nt(_ptr(Wp), Co * K, _ptr(acts[-1]), cols * K, Co, cols, K, 3, _ptr(Y), Co, st)
-                    _lib.check(rc, "dfepe_est_gemm_nt")
+                    rc = lib.dfepe_est_gemm_nt_f16(_ptr(Wp), Co * K, _ptr(act), cols * K, Co, cols, K, _ptr(wmax[l:l + 1]), _ptr(Y), Co, st)
+                    _lib.check(rc, "dfepe_est_gemm_nt_f16")
                     sp = _row_splits(B, Co, N)
                     part = _buf("npart", B * sp * 2 * Co, device=dev, dtype=torch.float32) if sp > 1 else None
                     rc = lib.dfepe_est_norm_fwd(_ptr(Y), Co, Co, B, N, _ptr(g32), _ptr(b32), float(eps), float(slope), _ptr(out), cols * Co,
-                                                _ptr(rstd), sp, _ptr(part), st)
+                                                _ptr(out_b), cols * Co, _ptr(rstd), sp, _ptr(part), st)
                     _lib.check(rc, "dfepe_est_norm_fwd")
                     del Y
-                acts.append(out)
-                rstds.append(rstd)
+                act = out  # the previous layer's fp16 planes are dropped here: only the bf16 pair lives on to the backward
+                if keep:
+                    acts.append(out_b)
+                    rstds.append(rstd)
             Wh, bh = params[4 * n_hidden], params[4 * n_hidden + 1]
-            C = acts[-1].shape[2]
+            C = act.shape[2]
             n_out = Wh.shape[0]  # 1: the weight heads; 4: update_offsets (if_learn_offsets, models/DeepFNet.py:330,342)
             wh = Wh.detach().float().reshape(n_out, C).contiguous()
             bh32 = None if bh is None else bh.detach().float().contiguous()
             logits = _buf("logits", n_out, cols, device=dev, dtype=torch.float32)
             for o in range(n_out):  # a GEMV per output channel over the same planes
-                rc = lib.dfepe_est_head_fwd(_ptr(acts[-1]), cols * C, C, cols, _ptr(wh[o]), _ptr(None if bh32 is None else bh32[o:o + 1]),
+                rc = lib.dfepe_est_head_fwd(_ptr(act), cols * C, C, cols, _ptr(wh[o]), _ptr(None if bh32 is None else bh32[o:o + 1]),
                                             _ptr(logits[o]), st)
                 _lib.check(rc, "dfepe_est_head_fwd")
         ctx.cfg = cfg
@@ -133,7 +155,7 @@ class _EstimatorFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_logits):
-        n_hidden, eps, slope = ctx.cfg
+        n_hidden, eps, slope, _keep = ctx.cfg
         lib = _lib.lib()
         B, C0, N = ctx.shape
         cols = B * N
@@ -231,4 +253,5 @@ def estimator_forward(x: Tensor, hidden: Sequence[Tuple[Tensor, Tensor, Tensor, 
     for layer in hidden:
         flat.extend(layer)
     flat.extend(head)
-    return _EstimatorFunction.apply((len(hidden), float(eps), float(slope)), x, *flat)
+    keep = torch.is_grad_enabled() and (x.requires_grad or any(p is not None and p.requires_grad for p in flat))
+    return _EstimatorFunction.apply((len(hidden), float(eps), float(slope), bool(keep)), x, *flat)

@@ -1,7 +1,8 @@
 """Row f-1 on the matrix cores (csrc/est_gemm.hip): each kernel against a float64 restatement of
 deepFEPE/models/ErrorEstimators.py:47-64 (Conv1d(k=1) = matrix product, F.instance_norm, F.leaky_relu), then the whole
-estimator against the stock PyTorch module run in float64.  Tolerances: forward products carry three bf16 planes per operand
-(six MFMAs, ~2^-24 per product: the fp32 class), backward products two (three MFMAs, ~2^-16).  GPU box only."""
+estimator against the stock PyTorch module run in float64.  Tolerances: forward products carry two fp16 planes per operand
+(three MFMAs, ~2^-22 per product: the fp32 class; weights split scaled by a power of two), backward products two bf16 planes
+(three MFMAs, ~2^-16).  GPU box only."""
 import ctypes
 
 import pytest
@@ -23,6 +24,56 @@ def planes_to_f64(P):
 
 def _split(dfepe, src, c, n_planes=3):
     return dfepe.estimator._split(src.contiguous(), src.shape[0], src.shape[1], c, n_planes)
+
+
+def _split_f16(dfepe, src, c, scaled=False):
+    """Two fp16 planes; scaled: by the power of two of max |src| (the weights' path: dfepe_est_absmax + dfepe_est_split_f16).
+    Returns (planes, absmax word or None, scale)."""
+    src = src.contiguous()
+    word, scale = None, 1.0
+    if scaled:
+        word = torch.zeros(1, device=src.device, dtype=torch.int32)
+        assert dfepe._lib.lib().dfepe_est_absmax(src.data_ptr(), src.numel(), word.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        assert word.view(torch.float32).item() == src.abs().max().item()
+        scale = 2.0 ** (3 - int(torch.floor(torch.log2(src.abs().max())).item()))
+    return dfepe.estimator._split_f16(src, src.shape[0], src.shape[1], c, word), word, scale
+
+
+def test_fp16_planes_hold_22_bits_and_the_weight_scale_is_a_power_of_two(dfepe):
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(500, 40, generator=g) * 3).to(DEV)  # activations: O(1), unscaled
+    P, _, _ = _split_f16(dfepe, x, 64)
+    assert P.shape == (2, 500, 64) and P.dtype == torch.float16
+    rec = planes_to_f64(P)
+    assert float((rec[:, :40] - x.double()).abs().max()) <= 2.0 ** -22 * float(x.abs().max())
+    assert rec[:, 40:].abs().max().item() == 0.0
+    w = (torch.randn(64, 40, generator=g) * 0.02).to(DEV)  # weights: small, split scaled into [8, 16)
+    Pw, word, scale = _split_f16(dfepe, w, 64, scaled=True)
+    recw = planes_to_f64(Pw)[:, :40] / scale
+    assert 8.0 <= float(planes_to_f64(Pw).abs().max()) < 16.0
+    assert float((recw - w.double()).abs().max()) <= 2.0 ** -21 * float(w.abs().max())
+
+
+@pytest.mark.parametrize("M,K,pairs,scaled", [(128, 32, 4, True), (64, 64, 3, False), (256, 1024, 5, True)])
+def test_gemm_nt_f16_matches_float64(dfepe, M, K, pairs, scaled):
+    """The forward's plain product on two fp16 planes (three products), weights split scaled and the result scaled back."""
+    lib = dfepe._lib.lib()
+    cols = pairs * 100
+    g = torch.Generator().manual_seed(M + K)
+    A = (torch.randn(M, K, generator=g) / K ** 0.5).to(DEV)
+    Bm = torch.randn(cols, K, generator=g).to(DEV)
+    Ap, word, _ = _split_f16(dfepe, A, K, scaled)
+    Bp, _, _ = _split_f16(dfepe, Bm, K)
+    out = torch.full((cols, M), float("nan"), device=DEV)
+    rc = lib.dfepe_est_gemm_nt_f16(Ap.data_ptr(), M * K, Bp.data_ptr(), cols * K, M, cols, K, None if word is None else word.data_ptr(),
+                                   out.data_ptr(), M, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = Bm.double() @ A.double().t()
+    scale = (Bm.double().abs() @ A.double().abs().t()).max()
+    err = float((out.double() - ref).abs().max() / scale)
+    assert err < (4e-7 if scaled else 1.5e-6), err  # unscaled small weights: their low plane is subnormal fp16
 
 
 def test_split_planes_are_exact(dfepe):
@@ -66,19 +117,27 @@ def test_layer_forward_matches_float64(dfepe, Cout, K, pairs):
     X = torch.randn(cols, K, generator=g).to(DEV)
     gamma = (1 + 0.2 * torch.randn(Cout, generator=g)).to(DEV)
     beta = (0.3 * torch.randn(Cout, generator=g)).to(DEV)
-    Wp, Xp = _split(dfepe, W, K), _split(dfepe, X, K)
-    out = torch.zeros(3, cols, Cout, device=DEV, dtype=torch.bfloat16)
-    rstd = torch.zeros(pairs, Cout, device=DEV)
-    rc = lib.dfepe_est_layer_fwd(Wp.data_ptr(), Cout * K, Xp.data_ptr(), cols * K, Cout, cols, K, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.01,
-                                 out.data_ptr(), cols * Cout, rstd.data_ptr(), None)
-    assert rc == 0
-    torch.cuda.synchronize()
+    (Wp, word, _), (Xp, _, _) = _split_f16(dfepe, W, K, scaled=True), _split_f16(dfepe, X, K)
     Y = (X.double() @ W.double().t()).view(pairs, 100, Cout).permute(0, 2, 1)  # [pairs, C, N]
     ref = torch.nn.functional.leaky_relu(torch.nn.functional.instance_norm(Y, weight=gamma.double(), bias=beta.double(), eps=1e-5), 0.01)
-    got = planes_to_f64(out).view(pairs, 100, Cout).permute(0, 2, 1)
-    assert relerr(got, ref) < 2e-6
     ref_rstd = 1.0 / torch.sqrt(Y.var(2, unbiased=False) + 1e-5)
-    assert relerr(rstd, ref_rstd) < 2e-6
+    for keep in (True, False):  # with and without the backward's bf16 planes
+        out = torch.zeros(2, cols, Cout, device=DEV, dtype=torch.float16)
+        out_b = torch.zeros(2, cols, Cout, device=DEV, dtype=torch.bfloat16)
+        rstd = torch.zeros(pairs, Cout, device=DEV)
+        rc = lib.dfepe_est_layer_fwd(Wp.data_ptr(), Cout * K, Xp.data_ptr(), cols * K, Cout, cols, K, word.data_ptr(), gamma.data_ptr(),
+                                     beta.data_ptr(), 1e-5, 0.01, out.data_ptr(), cols * Cout, out_b.data_ptr() if keep else None, cols * Cout,
+                                     rstd.data_ptr(), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        got = planes_to_f64(out).view(pairs, 100, Cout).permute(0, 2, 1)
+        assert relerr(got, ref) < 2e-6
+        assert relerr(rstd, ref_rstd) < 2e-6
+        got_b = planes_to_f64(out_b).view(pairs, 100, Cout).permute(0, 2, 1)
+        if keep:
+            assert float((got_b - got).abs().max()) <= 2.0 ** -16 * float(ref.abs().max())  # the same activation, to two bf16 planes
+        else:
+            assert got_b.abs().max().item() == 0.0
 
 
 @pytest.mark.parametrize("C,pairs,head", [(64, 3, False), (256, 2, True), (1024, 2, False)])
@@ -145,9 +204,10 @@ def test_head_forward_and_weight_gradient(dfepe):
     g = torch.Generator().manual_seed(9)
     a = torch.randn(cols, C, generator=g).to(DEV)
     w, b = torch.randn(C, generator=g).to(DEV), torch.randn(1, generator=g).to(DEV)
-    P = _split(dfepe, a, C)
+    P = _split(dfepe, a, C, 2)  # the backward's planes
+    Ph, _, _ = _split_f16(dfepe, a, C)  # the forward's
     logits = torch.zeros(cols, device=DEV)
-    assert lib.dfepe_est_head_fwd(P.data_ptr(), cols * C, C, cols, w.data_ptr(), b.data_ptr(), logits.data_ptr(), None) == 0
+    assert lib.dfepe_est_head_fwd(Ph.data_ptr(), cols * C, C, cols, w.data_ptr(), b.data_ptr(), logits.data_ptr(), None) == 0
     assert relerr(logits, a.double() @ w.double() + b.double()) < 1e-6
     dl = torch.randn(cols, generator=g).to(DEV)
     part = torch.zeros(8, C, device=DEV)
@@ -225,11 +285,12 @@ def test_norm_forward_any_points_matches_float64(dfepe, C, N, pairs, splits):
     Yd = (torch.randn(cols, ld, generator=g) * 3 + 40.0).to(DEV)  # a mean far above the deviation: the two-pass variance matters
     gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV)
     beta = (0.3 * torch.randn(C, generator=g)).to(DEV)
-    out = torch.zeros(3, cols, C, device=DEV, dtype=torch.bfloat16)
+    out = torch.zeros(2, cols, C, device=DEV, dtype=torch.float16)
+    out_b = torch.zeros(2, cols, C, device=DEV, dtype=torch.bfloat16)
     rstd = torch.zeros(pairs, C, device=DEV)
     part = torch.full((pairs * splits * 2 * C,), float("nan"), device=DEV)
     rc = lib.dfepe_est_norm_fwd(Yd.data_ptr(), ld, C, pairs, N, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.01, out.data_ptr(), cols * C,
-                                rstd.data_ptr(), splits, part.data_ptr() if splits > 1 else None, None)
+                                out_b.data_ptr(), cols * C, rstd.data_ptr(), splits, part.data_ptr() if splits > 1 else None, None)
     assert rc == 0
     torch.cuda.synchronize()
     Y = Yd[:, :C].double().view(pairs, N, C).permute(0, 2, 1)
@@ -238,6 +299,7 @@ def test_norm_forward_any_points_matches_float64(dfepe, C, N, pairs, splits):
                                          + beta.double()[None, :, None], 0.01)  # F.instance_norm refuses N = 1
     got = planes_to_f64(out).view(pairs, N, C).permute(0, 2, 1)
     assert float((got - ref).abs().max()) < 2e-5 * float(ref.abs().max())  # fp32 rounding of (y - mean) at |y| ~ 40: 4e-6 of the deviation
+    assert float((planes_to_f64(out_b) - planes_to_f64(out)).abs().max()) <= 2.0 ** -16 * float(ref.abs().max())
     assert relerr(rstd, 1.0 / torch.sqrt(var + 1e-5)) < 5e-6
 
 
@@ -339,12 +401,21 @@ def test_four_output_head_matches_float64(dfepe, N, B):
     fused = EE.FusedErrorEstimator(7, output_size=4).to(DEV)
     fused.load_state_dict(stock.state_dict())
     stock = stock.double()
-    g = torch.Generator().manual_seed(N)
+    # input seeds whose float64 run keeps every pre-activation > 2e-6 away from the LeakyReLU kink (found on the CPU over sixty
+    # seeds each): closer than that ANY fp32 evaluation may take the other branch, and with only B x N columns one flipped element
+    # is up to 1e-2 of the input gradient (seed N = 300 has |z| = 5e-7 in the third and fourth layer)
+    margin = [float("inf")]
+    hooks = [m.register_forward_hook(lambda _m, _i, o: margin.__setitem__(0, min(margin[0], float(o.detach().abs().min()))))
+             for m in stock.fw if isinstance(m, torch.nn.InstanceNorm1d)]
+    g = torch.Generator().manual_seed({100: 122, 300: 326}[N])
     x = torch.rand(B, 7, N, generator=g)
     G = torch.randn(B, 4, N, generator=g)
     xa = x.double().requires_grad_(True)
     xb = x.to(DEV).requires_grad_(True)
     ya, yb = stock(xa), fused(xb)
+    for h in hooks:
+        h.remove()
+    assert margin[0] > 2e-6, margin
     assert yb.shape == (B, 4, N) and yb.is_contiguous()
     assert float((yb.detach().cpu().double() - ya.detach()).abs().max()) < 1e-5
     (ya * G.double()).sum().backward()
@@ -354,7 +425,7 @@ def test_four_output_head_matches_float64(dfepe, N, B):
         if float(ref.norm()) < 1e-9:
             assert float(got.abs().max()) < 1e-6, name
             continue
-        assert float((got - ref).norm() / ref.norm()) < 2e-3, name  # a LeakyReLU branch flip at most (see the N != 100 test); typically 1e-5
+        assert float((got - ref).norm() / ref.norm()) < 1e-4, name  # the two-plane class; typically 1e-5
     # and it is the matrix-core path that ran, not the stock stack: the native-fp32 switch gives the same numbers to fp32 rounding
     fused.split_bf16 = False
     assert float((fused(x.to(DEV)).detach() - yb.detach()).abs().max()) < 1e-4
@@ -376,7 +447,10 @@ def test_zero_gamma_channels_get_their_gradient(dfepe, N, B):
     fused = EE.FusedErrorEstimator(7).to(DEV)
     fused.load_state_dict(stock.state_dict())
     stock = stock.double()
-    g = torch.Generator().manual_seed(2)
+    # input seeds whose float64 run keeps every pre-activation of a gamma != 0 channel > 4e-6 (N = 100) / 1.9e-5 (N = 37) away
+    # from the LeakyReLU kink (searched on the CPU; seed 2 has |z| = 1.3e-7 in the third layer at N = 100, where any fp32
+    # evaluation may take the other branch)
+    g = torch.Generator().manual_seed({100: 21, 37: 52}[N])
     x = torch.rand(B, 7, N, generator=g)
     G = torch.randn(B, 1, N, generator=g)
     (stock(x.double()) * G.double()).sum().backward()
