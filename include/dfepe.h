@@ -423,6 +423,11 @@ int dfepe_inorm_lrelu_bwd(const float *Y, const float *gA, const float *gamma, c
  *   dfepe_est_gemm_tn    part[slices][Cout][Cin] = split-K partial sums of dW = dY^T X (two planes each; the caller adds the slices)
  *   dfepe_est_in_bwd     dY planes [2] = adjoint of InstanceNorm + LeakyReLU given dA [ncols][C] fp32 (or its rank-one head form
  *                        dlogit[col] * w_head[c]), the layer's output planes [2] (bf16), rstd, gamma, beta; per-pair d gamma / d beta
+ *   dfepe_est_dgrad_in_bwd  (round 5) the data gradient dA = dY_next W_next (WT = W_next^T planes [2] of [M][K], dY_next planes [2] of
+ *                        [ncols][K], bf16) and dfepe_est_in_bwd of the layer below in ONE launch: dA stays in the accumulators (two
+ *                        whole pairs x 128 channels per workgroup), the layer's output planes are read twice (statistics, then dY),
+ *                        dY planes [2], per-pair d gamma / d beta out.  dA never reaches memory: 8 of the 20 bytes per element the
+ *                        two launches moved.  N = dfepe_est_points() only
  *   dfepe_est_norm_fwd   any N points per pair (the reference's SIFT configurations: up to 2000): planes_out [2] (fp16), planes_bwd
  *                        [2] (bf16, or null) and rstd from the plain product Y fp32 [n_pairs * N][ldy] of dfepe_est_gemm_nt_f16 --
  *                        InstanceNorm (biased variance, two-pass),
@@ -435,7 +440,9 @@ int dfepe_inorm_lrelu_bwd(const float *Y, const float *gA, const float *gamma, c
  *                        d beta and dY are right there, d gamma is not): this launch, run after them, overwrites dgamma_part[pair][ch]
  *                        of every channel with |gamma| < 1e-30 from a recomputation of the layer's product (input planes [2], bf16, of
  *                        [ncols][K-blocked], fp32 weights W [C][ldw], Ci input channels); channels with gamma != 0 cost an idle
- *                        workgroup each.  N <= 4096
+ *                        workgroup each.  N <= 4096.  The upstream gradient comes from dA, from the head's rank-one form, or -- behind
+ *                        dfepe_est_dgrad_in_bwd, which never writes dA -- is recomputed for the channel from dY_next planes [2] of
+ *                        [ncols][C_next] and the next layer's fp32 weights W_next [C_next][ldw_next]
  *   dfepe_est_head_fwd   logits[col] = sum_c w[c] a[col][c] + bias[0]   (the last Conv1d(C -> 1)); a: the forward's planes [2] (fp16)
  *   dfepe_est_head_dw    part[blocks][C] = partial sums of d w = sum_col dlogit[col] a[col][c]; a: the backward's planes [2] (bf16)
  */
@@ -456,7 +463,11 @@ int dfepe_est_gemm_tn(const void *dY, size_t dy_plane, int Cout, const void *X, 
                       float *part, void *stream);
 int dfepe_est_dgamma_zero(const float *dA, const float *dlogit, const float *w_head, const void *out_planes, size_t out_plane,
                           const void *in_planes, size_t in_plane, const float *W, int ldw, int Ci, const float *rstd, const float *gamma,
-                          float slope, int C, int N, long n_pairs, float *dgamma_part, void *stream);
+                          float slope, int C, int N, long n_pairs, float *dgamma_part, const void *dY_next, size_t dyn_plane,
+                          const float *W_next, int ldw_next, int C_next, void *stream);
+int dfepe_est_dgrad_in_bwd(const void *WT, size_t wt_plane, const void *dY_next, size_t dyn_plane, int M, int ncols, int K,
+                           const void *aout, size_t aout_plane, const float *rstd, const float *gamma, const float *beta, float slope,
+                           void *dY, size_t dy_plane, float *dgamma_part, float *dbeta_part, void *stream);
 int dfepe_est_in_bwd(const float *dA, const float *dlogit, const float *w_head, const void *planes, size_t plane_stride,
                      const float *rstd, const float *gamma, const float *beta, float slope, int C, int ncols, void *dY,
                      size_t dy_plane, float *dgamma_part, float *dbeta_part, void *stream);

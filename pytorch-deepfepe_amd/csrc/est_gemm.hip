@@ -119,7 +119,7 @@ __device__ __forceinline__ size_t kb_index(size_t row, int ch, size_t rows) { re
 // f = (0, 2, 3, 1): each of the four 16-lane service groups of a ds_read_b128 then covers all 16 slots of the bank row
 __device__ __forceinline__ int chunk_swz(int rowgroup) { return (0x78 >> (2 * (rowgroup & 3))) & 3; }
 
-enum { EPI_F32 = 0, EPI_IN = 1 };
+enum { EPI_F32 = 0, EPI_IN = 1, EPI_INBWD = 2 };
 #ifndef DFEPE_NT2_BLOCKS
 #define DFEPE_NT2_BLOCKS 3  // workgroups per CU the two-plane (data-gradient) product is compiled for
 #endif
@@ -143,6 +143,13 @@ struct EpiArgs {
   const unsigned* absmax;  // bits of max |W| (the weights were split scaled, see wscale); null: unscaled
   bf16_t* planes_bwd;      // [2][ncols][M] bf16: what the backward reads (est_in_bwd, est_gemm_tn); null: not kept (no gradient wanted)
   size_t bwd_stride;
+  // EPI_INBWD (the data gradient dA = dY_next W_next stays in the accumulators and goes straight through the InstanceNorm + LeakyReLU
+  // adjoint of the layer below): gamma, beta, slope as above; planes / plane_stride = dY out [2][ncols][M] bf16
+  const bf16_t* aout;      // that layer's output as the backward reads it, [2][ncols][M] bf16
+  size_t aout_stride;
+  const float* rstd_in;    // [npairs][M]
+  float* dgamma_part;      // [npairs][M] each
+  float* dbeta_part;
 };
 
 // C[m][n] = sum over plane pairs (i, j), i + j <= ORDER, of A_i[m][:] . B_j[n][:]
@@ -156,7 +163,7 @@ struct EpiArgs {
 // per CU: 1.47 vs 1.43 ms with two planes (206 registers), spills with three.  The step is bound by instruction issue around the
 // MFMAs (DMA setup, fragment reads, barriers), not by an exposed load latency.
 template <int NPA, int NPB, int ORDER, int EPI, int FMT = FMT_BF16>
-__global__ void __launch_bounds__(256, (NPA == 2 && NPB == 2 && EPI == EPI_F32) ? DFEPE_NT2_BLOCKS : ((NPA == 2 && NPB == 2) ? DFEPE_FWD_BLOCKS : 2))
+__global__ void __launch_bounds__(256, (NPA == 2 && NPB == 2 && EPI == EPI_F32) ? DFEPE_NT2_BLOCKS : ((NPA == 2 && NPB == 2 && EPI == EPI_IN) ? DFEPE_FWD_BLOCKS : 2))
 est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* __restrict__ B, size_t b_plane, int M, int ncols, int K,
                    const EpiArgs E) {
   constexpr int kABytes = NPA * BM * 64, kBBytes = NPB * BN * 64;
@@ -225,7 +232,7 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
     // latency of tile nt + 1 hides behind the twelve MFMAs of tile nt instead of stalling every tile
     // (the two-plane product compiled for three workgroups per CU has 168 registers: one fragment set, fetched per tile -- the
     // third wavefront on the SIMD covers the LDS latency the second set would)
-    constexpr bool kAhead = !(NPA == 2 && NPB == 2 && (EPI == EPI_F32 ? DFEPE_NT2_BLOCKS : DFEPE_FWD_BLOCKS) > 2);
+    constexpr bool kAhead = !(NPA == 2 && NPB == 2 && (EPI == EPI_F32 ? DFEPE_NT2_BLOCKS : (EPI == EPI_IN ? DFEPE_FWD_BLOCKS : 2)) > 2);
     frag8 b[kAhead ? 2 : 1][NPB];
     if (kAhead) {
 #pragma unroll
@@ -289,6 +296,156 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
           *reinterpret_cast<f32x4*>(dst + 4) = acc[1][nt];
         }
       }
+    }
+  } else if constexpr (EPI == EPI_INBWD) {
+    // The accumulators hold dA[col][ch] of TWO whole pairs x this lane's eight channels: est_in_bwd_kernel's arithmetic on them in
+    // place.  Pass A: a = the layer's output (two bf16 planes, one 16-byte load per plane and column tile), dz = dA lrelu'(a) written
+    // back into the accumulator, x^ = (z - beta) / gamma recovered from a, the two sums per (channel, pair) accumulated over the
+    // pair's column tiles and then over the 16 lanes of the DPP row.  Pass B: x^ recomputed from the same planes (L2), dY = rstd gamma
+    // (dz - mean(dz) - x^ mean(dz x^)), two bf16 planes, 16-byte stores.  dA never reaches memory.
+    const bool t6p0 = c < 4, t12ok = c < 8;
+    const int npairs = ncols / kPts;
+    const int pair0 = 2 * bx, pair1 = (pair0 + 1 < npairs) ? pair0 + 1 : pair0;
+    const int chc = chok ? ch8 : 0;
+    const float islope = 1.0f / E.slope;
+    // z from a = lrelu(z) without a compare (a mask per element kept for a second use is what spilled the first build of this
+    // epilogue): a slope below one makes the pre-activation the smaller of a and a / slope, one above it the larger
+    // (the median of a, a / slope and -inf resp. +inf: one instruction)
+    const float med_lim = (E.slope <= 1.0f) ? -__builtin_inff() : __builtin_inff();
+    auto unrelu = [&](float a) { return __builtin_amdgcn_fmed3f(a, a * islope, med_lim); };
+    float ig[8], bt[8];
+    {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(E.gamma + chc), g1 = *reinterpret_cast<const f32x4*>(E.gamma + chc + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(E.beta + chc), b1 = *reinterpret_cast<const f32x4*>(E.beta + chc + 4);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float gj = j < 4 ? g0[j & 3] : g1[j & 3];
+        ig[j] = (fabsf(gj) > 1e-30f) ? 1.0f / gj : 0.0f;
+        bt[j] = j < 4 ? b0[j & 3] : b1[j & 3];
+      }
+    }
+    // the raw words of one column tile (two planes x 16 bytes), fetched one tile ahead of their use; the scheduling barriers keep the
+    // compiler from hoisting all thirteen tiles' loads (104 registers) above the loop
+    struct Raw { uint4 u0, u1; };
+    size_t plane_at = kb_index(0, chc, (size_t)ncols);  // of this lane's channel group, column 0
+    auto fetch = [&](int nt) {
+      int cc = c;
+      asm volatile("" : "+v"(cc));  // the address arithmetic stays with its tile (hoisted, the 26 addresses are 52 registers)
+      int col = n0 + nt * 16 + cc;
+      col = (col < ncols) ? col : ncols - 1;
+      const size_t at = plane_at + (size_t)col * 32;
+      Raw r;
+      r.u0 = *reinterpret_cast<const uint4*>(E.aout + at);
+      r.u1 = *reinterpret_cast<const uint4*>(E.aout + E.aout_stride + at);
+      return r;
+    };
+    auto unpack = [&](const Raw& r, float (&a)[8]) {
+      const unsigned w0[4] = {r.u0.x, r.u0.y, r.u0.z, r.u0.w}, w1[4] = {r.u1.x, r.u1.y, r.u1.z, r.u1.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a[2 * q] = bf16_lo(w0[q]) + bf16_lo(w1[q]);
+        a[2 * q + 1] = bf16_hi(w0[q]) + bf16_hi(w1[q]);
+      }
+    };
+    float s1[2][8], s2[2][8];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s1[p][j] = 0.f; s2[p][j] = 0.f; }
+    Raw nxt = fetch(0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const Raw cur = nxt;
+      if (nt + 1 < NT) nxt = fetch(nt + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      float a[8];
+      unpack(cur, a);
+      const bool live = (nt < 12) || t12ok;  // lanes 8..15 of tile 12 belong to the next block
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = acc[j >> 2][nt][j & 3];
+        const float e = live ? ((a[j] > 0.f) ? d : d * E.slope) : 0.f;
+        const float x = (unrelu(a[j]) - bt[j]) * ig[j];
+        acc[j >> 2][nt][j & 3] = e;
+        if (nt < 6) { s1[0][j] += e; s2[0][j] = fmaf(e, x, s2[0][j]); }
+        else if (nt > 6) { s1[1][j] += e; s2[1][j] = fmaf(e, x, s2[1][j]); }
+        else {
+          const float e0 = t6p0 ? e : 0.f, e1 = t6p0 ? 0.f : e;
+          s1[0][j] += e0; s2[0][j] = fmaf(e0, x, s2[0][j]);
+          s1[1][j] += e1; s2[1][j] = fmaf(e1, x, s2[1][j]);
+        }
+      }
+      // pin the sums to this iteration: left free, instruction selection orders the pure accumulation chains after ALL thirteen
+      // tiles' x^ (104 more live values), and the scheduling barriers then keep them there
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        if ((p == 0 && nt <= 6) || (p == 1 && nt >= 6))
+          asm volatile("" : "+v"(s1[p][0]), "+v"(s1[p][1]), "+v"(s1[p][2]), "+v"(s1[p][3]), "+v"(s1[p][4]), "+v"(s1[p][5]), "+v"(s1[p][6]), "+v"(s1[p][7]),
+                            "+v"(s2[p][0]), "+v"(s2[p][1]), "+v"(s2[p][2]), "+v"(s2[p][3]), "+v"(s2[p][4]), "+v"(s2[p][5]), "+v"(s2[p][6]), "+v"(s2[p][7]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s1[p][j] = row16_sum(s1[p][j]); s2[p][j] = row16_sum(s2[p][j]); }
+    if (chok && c == 0) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int pr = pair0 + p;
+        if (pr < npairs) {
+          float* db = E.dbeta_part + (size_t)pr * M + ch8;
+          float* dg = E.dgamma_part + (size_t)pr * M + ch8;
+          *reinterpret_cast<f32x4*>(db) = f32x4{s1[p][0], s1[p][1], s1[p][2], s1[p][3]};
+          *reinterpret_cast<f32x4*>(db + 4) = f32x4{s1[p][4], s1[p][5], s1[p][6], s1[p][7]};
+          *reinterpret_cast<f32x4*>(dg) = f32x4{s2[p][0], s2[p][1], s2[p][2], s2[p][3]};
+          *reinterpret_cast<f32x4*>(dg + 4) = f32x4{s2[p][4], s2[p][5], s2[p][6], s2[p][7]};
+        }
+      }
+    }
+    float kk[2][8];
+    {
+      const float inv_n = 1.0f / (float)kPts;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(E.gamma + chc), g1 = *reinterpret_cast<const f32x4*>(E.gamma + chc + 4);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const float* rp = E.rstd_in + (size_t)(p ? pair1 : pair0) * M + chc;
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          kk[p][j] = (j < 4 ? r0[j & 3] : r1[j & 3]) * (j < 4 ? g0[j & 3] : g1[j & 3]);
+          s1[p][j] *= inv_n; s2[p][j] *= inv_n;
+        }
+      }
+    }
+    // the planes are read AGAIN for pass B (L2): without the compiler barrier the second loads are merged with the first and all
+    // 104 values of a stay live across the row sums (the first build spilled 130 registers that way)
+    asm volatile("" : "+v"(plane_at) :: "memory");  // (and the addresses formed again: kept, they were 52 registers, spilled)
+    nxt = fetch(0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const Raw cur = nxt;
+      if (nt + 1 < NT) nxt = fetch(nt + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      float a[8];
+      unpack(cur, a);
+      const bool first = (nt < 6) || (nt == 6 && t6p0);
+      float y[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = (unrelu(a[j]) - bt[j]) * ig[j];
+        const float m1 = first ? s1[0][j] : s1[1][j], m2 = first ? s2[0][j] : s2[1][j], k = first ? kk[0][j] : kk[1][j];
+        y[j] = k * (acc[j >> 2][nt][j & 3] - m1 - x * m2);
+      }
+      unsigned pl[2][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) split2(y[2 * q], y[2 * q + 1], pl[0][q], pl[1][q]);
+      const int cl = nt * 16 + c, col = n0 + cl;
+      if (cl < BSTEP && col < ncols && chok) {
+        bf16_t* dst = E.planes + kb_index((size_t)col, ch8, (size_t)ncols);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(pl[0][0], pl[0][1], pl[0][2], pl[0][3]);
+        *reinterpret_cast<uint4*>(dst + E.plane_stride) = make_uint4(pl[1][0], pl[1][1], pl[1][2], pl[1][3]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   } else {
     // pair 0 = columns 0..99 (tiles 0..5 and lanes 0..3 of tile 6), pair 1 = 100..199 (lanes 4..15 of tile 6, tiles 7..11,
@@ -1006,6 +1163,23 @@ extern "C" int dfepe_est_gemm_nt(const void* A, size_t a_plane, const void* B, s
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
+// data gradient + the adjoint of the layer below in one launch (N = dfepe_est_points()):
+//   dA[col][m] = sum_k WT[m][k] dY_next[col][k]  (two bf16 planes each, three products; never written),
+//   dY[2][ncols][M] = InstanceNorm + LeakyReLU adjoint of the layer whose output planes are `aout`, and its per-pair d gamma / d beta
+extern "C" int dfepe_est_dgrad_in_bwd(const void* WT, size_t wt_plane, const void* dY_next, size_t dyn_plane, int M, int ncols, int K,
+                                      const void* aout, size_t aout_plane, const float* rstd, const float* gamma, const float* beta,
+                                      float slope, void* dY, size_t dy_plane, float* dgamma_part, float* dbeta_part, void* stream) {
+  if (!WT || !dY_next || !aout || !rstd || !gamma || !beta || !dY || !dgamma_part || !dbeta_part) return DFEPE_ERR_INVALID_ARG;
+  if (M <= 0 || (M & 31) || ncols <= 0 || (ncols % kPts) || K <= 0 || (K % BK) || !(slope > 0.f)) return DFEPE_ERR_INVALID_ARG;
+  EpiArgs E{};
+  E.gamma = gamma; E.beta = beta; E.slope = slope; E.planes = static_cast<bf16_t*>(dY); E.plane_stride = dy_plane;
+  E.aout = static_cast<const bf16_t*>(aout); E.aout_stride = aout_plane; E.rstd_in = rstd; E.dgamma_part = dgamma_part; E.dbeta_part = dbeta_part;
+  const dim3 grid((ncols + BSTEP - 1) / BSTEP, (M + BM - 1) / BM), block(256);
+  hipLaunchKernelGGL((est_gemm_nt_kernel<2, 2, 1, EPI_INBWD>), grid, block, 0, static_cast<hipStream_t>(stream),
+                     static_cast<const bf16_t*>(WT), wt_plane, static_cast<const bf16_t*>(dY_next), dyn_plane, M, ncols, K, E);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
 // weight gradient partials: part[slices][Cout][Cin]
 extern "C" int dfepe_est_gemm_tn(const void* dY, size_t dy_plane, int Cout, const void* X, size_t x_plane, int Cin, int ncols,
                                  int slices, float* part, void* stream) {
@@ -1029,7 +1203,8 @@ __global__ void __launch_bounds__(256)
 est_dgamma_zero_kernel(const float* __restrict__ dA, const float* __restrict__ dlogit, const float* __restrict__ w_head,
                        const bf16_t* __restrict__ out_planes, size_t out_stride, const bf16_t* __restrict__ in_planes, size_t in_stride,
                        const float* __restrict__ W, int ldw, int Ci, const float* __restrict__ rstd, const float* __restrict__ gamma,
-                       float slope, int C, int N, long n_pairs, float* __restrict__ dgamma_part) {
+                       float slope, int C, int N, long n_pairs, float* __restrict__ dgamma_part,
+                       const bf16_t* __restrict__ dYn, size_t dyn_stride, const float* __restrict__ Wn, int ldwn, int Cn) {
   const int ch = (int)blockIdx.x;
   if (fabsf(gamma[ch]) > 1e-30f) return;
   __shared__ float y[kFixMaxN];
@@ -1062,7 +1237,13 @@ est_dgamma_zero_kernel(const float* __restrict__ dA, const float* __restrict__ d
       const size_t col = col0 + r;
       const size_t at = kb_index(col, ch, ncols);
       const float a = __uint_as_float((unsigned)out_planes[at] << 16) + __uint_as_float((unsigned)out_planes[out_stride + at] << 16);
-      const float d = (dA != nullptr) ? dA[col * C + ch] : dlogit[col] * w_head[ch];
+      float d;
+      if (dA != nullptr) d = dA[col * C + ch];
+      else if (dlogit != nullptr) d = dlogit[col] * w_head[ch];
+      else {  // the fused data gradient never wrote dA: this channel's column of dY_next W_next again (Cn terms per point)
+        d = 0.f;
+        for (int k = 0; k < Cn; ++k) d = fmaf(plane2(dYn, dyn_stride, kb_index(col, k, ncols)), Wn[(size_t)k * ldwn + ch], d);
+      }
       const float dz = (a > 0.f) ? d : d * slope;
       g = fmaf(dz, (y[r] - mean) * rs, g);
     }
@@ -1073,13 +1254,15 @@ est_dgamma_zero_kernel(const float* __restrict__ dA, const float* __restrict__ d
 
 extern "C" int dfepe_est_dgamma_zero(const float* dA, const float* dlogit, const float* w_head, const void* out_planes, size_t out_plane,
                                      const void* in_planes, size_t in_plane, const float* W, int ldw, int Ci, const float* rstd,
-                                     const float* gamma, float slope, int C, int N, long n_pairs, float* dgamma_part, void* stream) {
-  if ((!dA && !(dlogit && w_head)) || !out_planes || !in_planes || !W || !rstd || !gamma || !dgamma_part) return DFEPE_ERR_INVALID_ARG;
+                                     const float* gamma, float slope, int C, int N, long n_pairs, float* dgamma_part,
+                                     const void* dY_next, size_t dyn_plane, const float* W_next, int ldw_next, int C_next, void* stream) {
+  const bool from_next = dY_next && W_next && C_next > 0 && ldw_next >= C;
+  if ((!dA && !(dlogit && w_head) && !from_next) || !out_planes || !in_planes || !W || !rstd || !gamma || !dgamma_part) return DFEPE_ERR_INVALID_ARG;
   if (C <= 0 || N <= 0 || N > kFixMaxN || n_pairs < 0 || Ci <= 0 || ldw < Ci || !(slope > 0.f)) return DFEPE_ERR_INVALID_ARG;
   if (n_pairs == 0) return DFEPE_OK;
   hipLaunchKernelGGL(est_dgamma_zero_kernel, dim3(C), dim3(256), 0, static_cast<hipStream_t>(stream), dA, dlogit, w_head,
                      static_cast<const bf16_t*>(out_planes), out_plane, static_cast<const bf16_t*>(in_planes), in_plane, W, ldw, Ci, rstd, gamma,
-                     slope, C, N, n_pairs, dgamma_part);
+                     slope, C, N, n_pairs, dgamma_part, static_cast<const bf16_t*>(dY_next), dyn_plane, W_next, ldw_next, C_next);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 

@@ -73,6 +73,8 @@ def _row_splits(pairs: int, c: int, n: int) -> int:
     return max(1, min(64, n // 128, (1024 + blocks - 1) // blocks))
 
 
+FUSE_DGRAD = _os.environ.get("DFEPE_EST_FUSE_DGRAD", "1") != "0"  # A/B switch: the data gradient fused with the adjoint below it
+
 TN_BLOCKS = 768  # workgroups of a weight-gradient launch: three per CU in one residency round (130 registers, 32 KB of LDS each);
 # measured: 1024 (the kernel compiled for four per CU, 128 registers) 10.67 against 10.55 ms per estimator call
 
@@ -186,35 +188,47 @@ class _EstimatorFunction(torch.autograd.Function):
             dA = None if n_out == 1 else torch.mm(dl.t(), wh)
             if n_out == 1:
                 dl, wh = dl[0], wh[0]
+            # (dY, d gamma / d beta partials) of layer l when the fused data gradient of layer l + 1 already went through this layer's
+            # InstanceNorm + LeakyReLU adjoint (dfepe_est_dgrad_in_bwd), plus what the gamma == 0 fix needs in place of dA
+            pending = None
             for l in range(n_hidden - 1, -1, -1):
                 W, bconv, gamma, beta = params[4 * l:4 * l + 4]
                 Co, Ci = W.shape[0], W.shape[1]
                 a_out, a_in = acts[l + 1], acts[l]
                 K = a_in.shape[2]
-                dY = _buf("dY", 2, cols, Co, device=dev, dtype=BF16)
-                dg = _buf("dg", B, Co, device=dev, dtype=torch.float32)
-                db = _buf("db", B, Co, device=dev, dtype=torch.float32)
                 g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-                if _fused(N):
-                    rc = lib.dfepe_est_in_bwd(_ptr(dA), _ptr(dl if dA is None else None), _ptr(wh if dA is None else None), _ptr(a_out), cols * Co,
-                                              _ptr(rstds[l]), _ptr(g32), _ptr(b32), float(slope), Co, cols, _ptr(dY), cols * Co, _ptr(dg), _ptr(db),
-                                              st)
-                    _lib.check(rc, "dfepe_est_in_bwd")
+                W32 = W.detach().float().reshape(Co, Ci).contiguous()
+                if pending is None:
+                    dY = _buf("dY", 2, cols, Co, device=dev, dtype=BF16)
+                    dg = _buf("dg", B, Co, device=dev, dtype=torch.float32)
+                    db = _buf("db", B, Co, device=dev, dtype=torch.float32)
+                    if _fused(N):
+                        rc = lib.dfepe_est_in_bwd(_ptr(dA), _ptr(dl if dA is None else None), _ptr(wh if dA is None else None), _ptr(a_out),
+                                                  cols * Co, _ptr(rstds[l]), _ptr(g32), _ptr(b32), float(slope), Co, cols, _ptr(dY), cols * Co,
+                                                  _ptr(dg), _ptr(db), st)
+                        _lib.check(rc, "dfepe_est_in_bwd")
+                    else:
+                        sp = _row_splits(B, Co, N)
+                        part = _buf("npart", B * sp * 2 * Co, device=dev, dtype=torch.float32) if sp > 1 else None
+                        rc = lib.dfepe_est_in_bwd_n(_ptr(dA), _ptr(dl if dA is None else None), _ptr(wh if dA is None else None), _ptr(a_out),
+                                                    cols * Co, _ptr(rstds[l]), _ptr(g32), _ptr(b32), float(slope), Co, B, N, _ptr(dY), cols * Co,
+                                                    _ptr(dg), _ptr(db), sp, _ptr(part), st)
+                        _lib.check(rc, "dfepe_est_in_bwd_n")
+                    zero_src = (_ptr(dA), _ptr(dl if dA is None else None), _ptr(wh if dA is None else None), None, 0, None, 0, 0)
+                    keep_alive = None
                 else:
-                    sp = _row_splits(B, Co, N)
-                    part = _buf("npart", B * sp * 2 * Co, device=dev, dtype=torch.float32) if sp > 1 else None
-                    rc = lib.dfepe_est_in_bwd_n(_ptr(dA), _ptr(dl if dA is None else None), _ptr(wh if dA is None else None), _ptr(a_out),
-                                                cols * Co, _ptr(rstds[l]), _ptr(g32), _ptr(b32), float(slope), Co, B, N, _ptr(dY), cols * Co,
-                                                _ptr(dg), _ptr(db), sp, _ptr(part), st)
-                    _lib.check(rc, "dfepe_est_in_bwd_n")
+                    dY, dg, db, dY_up, W_up = pending  # dA was never written: the fix recomputes its channel from dY_up W_up
+                    zero_src = (None, None, None, _ptr(dY_up), cols * W_up.shape[0], _ptr(W_up), W_up.shape[1], W_up.shape[0])
+                    keep_alive = (dY_up, W_up)
                 # channels whose gamma is exactly 0: x^ cannot be recovered from the stored activation; their d gamma is recomputed from
                 # the layer's input (idle workgroups otherwise; N beyond the fix kernel's 4096 keeps the documented zero)
                 if N <= 4096:
-                    W32 = W.detach().float().reshape(Co, Ci).contiguous()
-                    rc = lib.dfepe_est_dgamma_zero(_ptr(dA), _ptr(dl if dA is None else None), _ptr(wh if dA is None else None), _ptr(a_out),
-                                                   cols * Co, _ptr(a_in), cols * K, _ptr(W32), Ci, Ci, _ptr(rstds[l]), _ptr(g32), float(slope), Co, N, B,
-                                                   _ptr(dg), st)
+                    rc = lib.dfepe_est_dgamma_zero(zero_src[0], zero_src[1], zero_src[2], _ptr(a_out), cols * Co, _ptr(a_in), cols * K, _ptr(W32),
+                                                   Ci, Ci, _ptr(rstds[l]), _ptr(g32), float(slope), Co, N, B, _ptr(dg), zero_src[3], zero_src[4],
+                                                   zero_src[5], zero_src[6], zero_src[7], st)
                     _lib.check(rc, "dfepe_est_dgamma_zero")
+                del keep_alive
+                pending = None
                 grads[4 * l + 2] = dg.sum(0).to(gamma.dtype)
                 grads[4 * l + 3] = db.sum(0).to(beta.dtype)
                 grads[4 * l + 1] = (torch.empty_like(bconv).fill_(0.0) if "nomemset" in _DEBUG_ZERO else torch.zeros_like(bconv))  # the bias cancels in the instance normalisation: exact zero, like the reference's autograd
@@ -229,11 +243,24 @@ class _EstimatorFunction(torch.autograd.Function):
                     Mp = (K + 7) // 8 * 8
                     WT = (torch.empty(Mp, Co, device=dev, dtype=torch.float32).fill_(0.0) if "nomemset" in _DEBUG_ZERO else
                           torch.zeros(Mp, Co, device=dev, dtype=torch.float32))
-                    WT[:Ci] = W.detach().float().reshape(Co, Ci).t()
+                    WT[:Ci] = W32.t()
                     WTp = _split(WT, Mp, Co, Co, 2)
-                    dA = _buf("dA", cols, Mp, device=dev, dtype=torch.float32)
-                    rc = lib.dfepe_est_gemm_nt(_ptr(WTp), Mp * Co, _ptr(dY), cols * Co, Mp, cols, Co, 2, _ptr(dA), Mp, st)
-                    _lib.check(rc, "dfepe_est_gemm_nt")
+                    if l > 0 and _fused(N) and Ci == K and FUSE_DGRAD:
+                        # the data gradient dA = dY W stays in the GEMM's accumulators and goes straight through the adjoint of the layer
+                        # below: dY, d gamma / d beta partials of layer l - 1 out, dA never written (8 of 20 bytes per element)
+                        gl, bl = params[4 * (l - 1) + 2].detach().float().contiguous(), params[4 * (l - 1) + 3].detach().float().contiguous()
+                        dYd = _buf("dY", 2, cols, K, device=dev, dtype=BF16)
+                        dgd = _buf("dg", B, K, device=dev, dtype=torch.float32)
+                        dbd = _buf("db", B, K, device=dev, dtype=torch.float32)
+                        rc = lib.dfepe_est_dgrad_in_bwd(_ptr(WTp), Mp * Co, _ptr(dY), cols * Co, K, cols, Co, _ptr(a_in), cols * K, _ptr(rstds[l - 1]),
+                                                        _ptr(gl), _ptr(bl), float(slope), _ptr(dYd), cols * K, _ptr(dgd), _ptr(dbd), st)
+                        _lib.check(rc, "dfepe_est_dgrad_in_bwd")
+                        pending = (dYd, dgd, dbd, dY, W32)
+                        dA = None
+                    else:
+                        dA = _buf("dA", cols, Mp, device=dev, dtype=torch.float32)
+                        rc = lib.dfepe_est_gemm_nt(_ptr(WTp), Mp * Co, _ptr(dY), cols * Co, Mp, cols, Co, 2, _ptr(dA), Mp, st)
+                        _lib.check(rc, "dfepe_est_gemm_nt")
                 del dY
             gx = None
             if ctx.needs_input_grad[1]:

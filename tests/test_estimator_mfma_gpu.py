@@ -178,6 +178,38 @@ def test_instance_norm_adjoint_matches_autograd(dfepe, C, pairs, head):
     assert relerr(db.sum(0).cpu(), beta.grad) < 5e-5
 
 
+@pytest.mark.parametrize("M,K,pairs", [(64, 128, 3), (128, 1024, 2), (1024, 512, 5), (512, 256, 4)])
+def test_fused_data_gradient_and_adjoint_equals_the_two_launches(dfepe, M, K, pairs):
+    """dfepe_est_dgrad_in_bwd (dA = dY_next W_next kept in the accumulators, straight through the InstanceNorm + LeakyReLU adjoint of
+    the layer below) against dfepe_est_gemm_nt + dfepe_est_in_bwd on the same planes: the same arithmetic, sums in another order.
+    Odd pair counts: the half-empty last block."""
+    lib = dfepe._lib.lib()
+    cols = pairs * 100
+    g = torch.Generator().manual_seed(M + K + pairs)
+    WT = (torch.randn(M, K, generator=g) / K ** 0.5).to(DEV)     # W_next^T [C of this layer][C of the next]
+    dYn = torch.randn(cols, K, generator=g).to(DEV)
+    a = torch.nn.functional.leaky_relu(torch.randn(cols, M, generator=g) * 1.5 + 0.2, 0.01).to(DEV)  # this layer's output
+    rstd = (0.5 + torch.rand(pairs, M, generator=g)).to(DEV)
+    gamma = (1 + 0.2 * torch.randn(M, generator=g)).to(DEV)
+    gamma[5] = 0.0  # a dead channel: x^ taken as 0 by both
+    beta = (0.3 * torch.randn(M, generator=g)).to(DEV)
+    WTp, dYp, ap = _split(dfepe, WT, K, 2), _split(dfepe, dYn, K, 2), _split(dfepe, a, M, 2)
+    dA = torch.full((cols, M), float("nan"), device=DEV)
+    assert lib.dfepe_est_gemm_nt(WTp.data_ptr(), M * K, dYp.data_ptr(), cols * K, M, cols, K, 2, dA.data_ptr(), M, None) == 0
+    ref_dY = torch.zeros(2, cols, M, device=DEV, dtype=torch.bfloat16)
+    ref_dg, ref_db = torch.zeros(pairs, M, device=DEV), torch.zeros(pairs, M, device=DEV)
+    assert lib.dfepe_est_in_bwd(dA.data_ptr(), None, None, ap.data_ptr(), cols * M, rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 0.01, M,
+                                cols, ref_dY.data_ptr(), cols * M, ref_dg.data_ptr(), ref_db.data_ptr(), None) == 0
+    dY = torch.full((2, cols, M), float("nan"), device=DEV, dtype=torch.bfloat16)
+    dg, db = torch.full((pairs, M), float("nan"), device=DEV), torch.full((pairs, M), float("nan"), device=DEV)
+    rc = lib.dfepe_est_dgrad_in_bwd(WTp.data_ptr(), M * K, dYp.data_ptr(), cols * K, M, cols, K, ap.data_ptr(), cols * M, rstd.data_ptr(),
+                                    gamma.data_ptr(), beta.data_ptr(), 0.01, dY.data_ptr(), cols * M, dg.data_ptr(), db.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert relerr(planes_to_f64(dY), planes_to_f64(ref_dY)) < 2e-5   # two bf16 planes of values that agree to fp32 rounding
+    assert relerr(dg, ref_dg) < 1e-5 and relerr(db, ref_db) < 1e-5
+
+
 @pytest.mark.parametrize("Cout,Cin,pairs,slices", [(64, 32, 3, 4), (128, 64, 7, 3), (1024, 128, 5, 8), (256, 512, 4, 1)])
 def test_gemm_tn_weight_gradient(dfepe, Cout, Cin, pairs, slices):
     """dW[co][ci] = sum_cols dY[col][co] X[col][ci] through the transposing LDS reads, split-K partials."""
