@@ -4,12 +4,18 @@
 // (deepFEPE/models/ErrorEstimators.py:47-64), called depth times per step (deepFEPE/models/DeepFNet.py:441,510), forward and
 // backward.  Every 1x1 convolution is a GEMM  Y[C_out, cols] = W[C_out, C_in] X[C_in, cols]  over cols = pairs x N points.
 //
-// Precision: the reference trains this stack in fp32.  bf16 MFMA is 16x the fp32 MFMA rate, so every fp32 operand is
-// carried as a sum of bf16 PLANES  a = a0 + a1 + a2  (a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1): 24 mantissa
-// bits, the split is exact) and a product is the sum of the plane products of order i + j <= 2 (six bf16 MFMAs, fp32
-// accumulate): error ~2^-24 per product, the fp32 class (scripts/proto_split_bf16.py: logits 2.7e-7 from the fp64 truth
-// against 2.9e-6 for stock fp32 and 6.6e-5 for two planes).  The backward products use two planes (i + j <= 1, three MFMAs,
-// ~2^-16): gradients need far less than the activations the next fit is sensitive to.
+// Precision: the reference trains this stack in fp32.  16-bit MFMA is 16x the fp32 MFMA rate, so every fp32 operand is carried as a
+// sum of 16-bit PLANES, exact remainders of each other.
+//   forward (round 5): TWO fp16 planes, a = a0 + a1 (a0 = fp16(a), a1 = fp16(a - a0): 22 mantissa bits), a product = a0 b0 + a0 b1 +
+//     a1 b0 -- three MFMAs, fp32 accumulate, error ~2^-22 per product: the fp32 class (scripts/proto_split_fp16.py: logits 1e-6 from
+//     the fp64 truth against 2.4-3.5e-6 for stock fp32; measured on the GPU 2.0-2.4e-6 with the fp32 accumulation).  Rounds 3-4 used
+//     three bf16 planes and six products for the same accuracy: twice the matrix work, 6 instead of 4 bytes per element read.  fp16's
+//     narrow exponent is handled where it bites: weights (1 / sqrt(fan-in): their low plane would be subnormal) are split scaled by a
+//     power of two found on the device (est_absmax_kernel, wscale) and the accumulators scaled back; activations are O(1) behind an
+//     InstanceNorm, |a| <= |gamma| sqrt(N - 1) + |beta| must stay below 65504 (beyond it the result is inf / NaN, loudly).
+//   backward: two bf16 planes (i + j <= 1, three MFMAs, ~2^-16): gradients need far less than the activations the next fit is
+//     sensitive to, and bf16 keeps fp32's exponent range -- no loss scaling.  A forward that will be differentiated therefore also
+//     leaves each activation as two bf16 planes (est_in_bwd / est_gemm_tn read those); one that will not skips them.
 //
 // Layout: activations POINT-major and K-BLOCKED:  P[plane][C/32][col][32]  (the 32 channels of a K step are contiguous per
 // column, and the columns of a K step are contiguous: the 208 x 32 operand tile of a block is ONE contiguous 13 KB run, so
@@ -27,9 +33,10 @@
 //   est_gemm_tn   dW[co][ci] = sum_cols dY[col][co] X[col][ci]: both operands are K-major here, fragments come from
 //                 ds_read_b64_tr_b16 (the LDS transpose read) of an XOR-swizzled [k][128 channels] image, split-K over columns.
 //   est_in_bwd    InstanceNorm + LeakyReLU adjoint in the point-major layout (x^ and the activation sign recovered from the
-//                 stored planes), writes dY as two planes.  (Run as the data-gradient GEMM's epilogue instead -- dA kept in the
-//                 accumulators -- it needs x^ or a second pass over the planes on top of 104 accumulator registers: it spilled
-//                 and measured 12.05 against 11.95 ms per call for the two kernels; this kernel streams at 5 TB/s.)
+//                 stored planes), writes dY as two planes; streams at 5 TB/s.  Since round 5 only the layer under the head (and any
+//                 N != 100) runs it as a launch of its own: below that the adjoint is the data-gradient GEMM's epilogue (EPI_INBWD:
+//                 dA stays in the accumulators, the layer's output planes are read twice -- sums, then dY -- 228 registers, no
+//                 scratch; round 3's first attempt held x^ and spilled).  dA never reaches memory: 8 of the 20 bytes per element.
 //   est_norm_fwd_n / est_in_bwd_n   the same normalisation + activation + split, and its adjoint, for ANY number of points per
 //                 pair behind the plain product (EPI_F32): a workgroup per (pair, 64 channels), or the pair's rows over several
 //                 workgroups in two launches when a dozen pairs would not fill the chip.
@@ -122,6 +129,9 @@ __device__ __forceinline__ int chunk_swz(int rowgroup) { return (0x78 >> (2 * (r
 enum { EPI_F32 = 0, EPI_IN = 1, EPI_INBWD = 2 };
 #ifndef DFEPE_NT2_BLOCKS
 #define DFEPE_NT2_BLOCKS 3  // workgroups per CU the two-plane (data-gradient) product is compiled for
+#endif
+#ifndef DFEPE_INBWD_DEPTH
+#define DFEPE_INBWD_DEPTH 4  // column tiles of the layer's output in flight in the fused adjoint's two passes
 #endif
 #ifndef DFEPE_FWD_BLOCKS
 #define DFEPE_FWD_BLOCKS 3  // workgroups per CU the two-plane forward layer (fused epilogue) is compiled for: 168 registers, 43 KB of LDS each;
@@ -352,11 +362,15 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
     for (int p = 0; p < 2; ++p)
 #pragma unroll
       for (int j = 0; j < 8; ++j) { s1[p][j] = 0.f; s2[p][j] = 0.f; }
-    Raw nxt = fetch(0);
+    // kDepth tiles in flight: one iteration is ~80 vector instructions, a miss to HBM an order of magnitude more
+    constexpr int kDepth = DFEPE_INBWD_DEPTH;
+    Raw ring[kDepth];
+#pragma unroll
+    for (int i = 0; i < kDepth; ++i) ring[i] = fetch(i);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const Raw cur = nxt;
-      if (nt + 1 < NT) nxt = fetch(nt + 1);
+      const Raw cur = ring[nt % kDepth];
+      if (nt + kDepth < NT) ring[nt % kDepth] = fetch(nt + kDepth);
       __builtin_amdgcn_sched_barrier(0);
       float a[8];
       unpack(cur, a);
@@ -420,11 +434,12 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
     // the planes are read AGAIN for pass B (L2): without the compiler barrier the second loads are merged with the first and all
     // 104 values of a stay live across the row sums (the first build spilled 130 registers that way)
     asm volatile("" : "+v"(plane_at) :: "memory");  // (and the addresses formed again: kept, they were 52 registers, spilled)
-    nxt = fetch(0);
+#pragma unroll
+    for (int i = 0; i < kDepth; ++i) ring[i] = fetch(i);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const Raw cur = nxt;
-      if (nt + 1 < NT) nxt = fetch(nt + 1);
+      const Raw cur = ring[nt % kDepth];
+      if (nt + kDepth < NT) ring[nt % kDepth] = fetch(nt + kDepth);
       __builtin_amdgcn_sched_barrier(0);
       float a[8];
       unpack(cur, a);
