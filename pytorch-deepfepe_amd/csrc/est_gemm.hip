@@ -130,12 +130,34 @@ enum { EPI_F32 = 0, EPI_IN = 1, EPI_INBWD = 2 };
 #ifndef DFEPE_NT2_BLOCKS
 #define DFEPE_NT2_BLOCKS 3  // workgroups per CU the two-plane (data-gradient) product is compiled for
 #endif
+#ifndef DFEPE_NT_SPLIT
+#define DFEPE_NT_SPLIT 0  // 1: est_gemm_nt fills its LDS stage in two halves, each under the other half's MFMAs, instead of issue / wait /
+                          // multiply.  Measured (round 5, same box, twice): 8.18-8.20 against 8.15-8.16 ms per estimator call, forward alone
+                          // 2.42 against 2.45 ms -- the cycles between DMA issue and barrier (half of the K loop by the phase stamps of
+                          // scripts/ubench/est_phases.hip) are not an exposed load latency a wavefront could hide by itself
+#endif
 #ifndef DFEPE_INBWD_DEPTH
 #define DFEPE_INBWD_DEPTH 4  // column tiles of the layer's output in flight in the fused adjoint's two passes
 #endif
 #ifndef DFEPE_FWD_BLOCKS
 #define DFEPE_FWD_BLOCKS 3  // workgroups per CU the two-plane forward layer (fused epilogue) is compiled for: 168 registers, 43 KB of LDS each;
                             // measured at B = 4096: forward 2.49 ms against 2.67 with two (one fragment set then, fetched per tile, like the data gradient)
+#endif
+
+// -DDFEPE_EST_PHASE_CLOCKS (scripts/ubench/est_phases.hip only): lane 0 of every wavefront stamps the shader clock at the phase
+// boundaries of est_gemm_nt_kernel and sums its waits in the K loop
+#ifdef DFEPE_EST_PHASE_CLOCKS
+__device__ unsigned long long* g_est_phase_clk;  // [workgroup * 4 + wavefront][8]
+#define EST_STAMP(slot)                                                                                                  \
+  do {                                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    const unsigned long long t_ = __builtin_readcyclecounter();                                                          \
+    if ((threadIdx.x & 63u) == 0u)                                                                                       \
+      g_est_phase_clk[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 8 + (slot)] = t_;      \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  } while (0)
+#else
+#define EST_STAMP(slot) do {} while (0)
 #endif
 
 struct EpiArgs {
@@ -208,25 +230,43 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
   // lane and plane, 64 contiguous bytes per column, one contiguous KiB per store instruction
   const int fswA[2] = {chunk_swz(2 * (c >> 2)), chunk_swz(2 * (c >> 2) + 1)};
   const int nk = K / BK;
+  // The stage is filled in two groups -- group 0: the A rows and the column tiles [0, kHalf) of B; group 1: the column tiles
+  // [kHalf, NT) -- so that the DMA of one half runs under the MFMAs of the other (DFEPE_NT_SPLIT, below).
+  constexpr int kHalf = 7;
+  auto issue_task_a = [&](int ks, unsigned char* lds, int t) {
+    const int p = t / (BM / 16), rb = t % (BM / 16);
+    int row = m0 + rb * 16 + drow;
+    row = (row < M) ? row : M - 1;
+    const bf16_t* src = A + (size_t)p * a_plane + ((size_t)ks * M + row) * 32 + dchunk * 8;
+    unsigned char* dst = lds + (p * BM + rb * 16) * 64;
+    __builtin_amdgcn_global_load_lds(DFEPE_GLOBAL_PTR(src), DFEPE_LDS_PTR(dst), 16, 0, 0);
+  };
+  auto issue_task_b = [&](int ks, unsigned char* lds, int p, int rb) {
+    int row = n0 + rb * 16 + drow;
+    row = (row < ncols) ? row : ncols - 1;
+    const bf16_t* src = B + (size_t)p * b_plane + ((size_t)ks * ncols + row) * 32 + dchunk * 8;
+    unsigned char* dst = lds + kABytes + (p * BN + rb * 16) * 64;
+    __builtin_amdgcn_global_load_lds(DFEPE_GLOBAL_PTR(src), DFEPE_LDS_PTR(dst), 16, 0, 0);
+  };
   auto stage_issue = [&](int ks, unsigned char* lds) {
 #pragma unroll
     for (int i = 0; i < kPerWave; ++i) {
       const int t = wave + 4 * i;  // wave-uniform
-      if (t < kATasks) {
-        const int p = t / (BM / 16), rb = t % (BM / 16);
-        int row = m0 + rb * 16 + drow;
-        row = (row < M) ? row : M - 1;
-        const bf16_t* src = A + (size_t)p * a_plane + ((size_t)ks * M + row) * 32 + dchunk * 8;
-        unsigned char* dst = lds + (p * BM + rb * 16) * 64;
-        __builtin_amdgcn_global_load_lds(DFEPE_GLOBAL_PTR(src), DFEPE_LDS_PTR(dst), 16, 0, 0);
-      } else if (t < kTasks) {
-        const int u = t - kATasks;
-        const int p = u / NT, rb = u % NT;
-        int row = n0 + rb * 16 + drow;
-        row = (row < ncols) ? row : ncols - 1;
-        const bf16_t* src = B + (size_t)p * b_plane + ((size_t)ks * ncols + row) * 32 + dchunk * 8;
-        unsigned char* dst = lds + kABytes + (p * BN + rb * 16) * 64;
-        __builtin_amdgcn_global_load_lds(DFEPE_GLOBAL_PTR(src), DFEPE_LDS_PTR(dst), 16, 0, 0);
+      if (t < kATasks) issue_task_a(ks, lds, t);
+      else if (t < kTasks) issue_task_b(ks, lds, (t - kATasks) / NT, (t - kATasks) % NT);
+    }
+  };
+  auto group_issue = [&](int ks, unsigned char* lds, auto grp) {
+    constexpr int G = decltype(grp)::value;
+    constexpr int kTiles = G == 0 ? kHalf : NT - kHalf, kFirst = G == 0 ? 0 : kHalf;
+    constexpr int kN = (G == 0 ? kATasks : 0) + NPB * kTiles;
+#pragma unroll
+    for (int i = 0; i < (kN + 3) / 4; ++i) {
+      const int t = wave + 4 * i;
+      if (G == 0 && t < kATasks) issue_task_a(ks, lds, t);
+      else if (t < kN) {
+        const int u = t - (G == 0 ? kATasks : 0);
+        issue_task_b(ks, lds, u / kTiles, kFirst + u % kTiles);
       }
     }
   };
@@ -237,7 +277,8 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
       for (int p = 0; p < NPA; ++p)
         a[mt][p] = *reinterpret_cast<const frag8*>(lds + ((p * BM + wave * 32 + 8 * (c >> 2) + 4 * mt + (c & 3)) * 4 + (g ^ fswA[mt])) * 16);
   };
-  auto mfma_phase = [&](const unsigned char* lds, const frag8 (&a)[2][NPA]) {
+  auto mfma_phase = [&](const unsigned char* lds, const frag8 (&a)[2][NPA], auto first_tile, auto end_tile) {
+    constexpr int kT0 = decltype(first_tile)::value, kT1 = decltype(end_tile)::value;
     // the column tile's B fragments are fetched one tile ahead of the MFMAs that consume them (two register sets): the LDS
     // latency of tile nt + 1 hides behind the twelve MFMAs of tile nt instead of stalling every tile
     // (the two-plane product compiled for three workgroups per CU has 168 registers: one fragment set, fetched per tile -- the
@@ -246,12 +287,12 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
     frag8 b[kAhead ? 2 : 1][NPB];
     if (kAhead) {
 #pragma unroll
-      for (int p = 0; p < NPB; ++p) b[0][p] = *reinterpret_cast<const frag8*>(lds + kABytes + ((p * BN + c) * 4 + (g ^ fsw)) * 16);
+      for (int p = 0; p < NPB; ++p) b[kAhead ? (kT0 & 1) : 0][p] = *reinterpret_cast<const frag8*>(lds + kABytes + ((p * BN + kT0 * 16 + c) * 4 + (g ^ fsw)) * 16);
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
+    for (int nt = kT0; nt < kT1; ++nt) {
       if (kAhead) {
-        if (nt + 1 < NT) {
+        if (nt + 1 < kT1) {
 #pragma unroll
           for (int p = 0; p < NPB; ++p)
             b[(nt + 1) & (kAhead ? 1 : 0)][p] = *reinterpret_cast<const frag8*>(lds + kABytes + ((p * BN + (nt + 1) * 16 + c) * 4 + (g ^ fsw)) * 16);
@@ -277,15 +318,77 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
     }
   };
 
+  EST_STAMP(0);
+#ifdef DFEPE_EST_PHASE_CLOCKS
+  unsigned long long wait_cycles = 0, mfma_cycles = 0;
+#endif
+  using T0 = std::integral_constant<int, 0>;
+  using TH = std::integral_constant<int, kHalf>;
+  using TN = std::integral_constant<int, NT>;
+  if constexpr (DFEPE_NT_SPLIT) {
+    // One LDS stage, filled in two halves: while the MFMAs of column tiles [0, 7) run, the DMA of tiles [7, 13) of the same K step is
+    // in flight; while those of [7, 13) run, the DMA of the NEXT step's A rows and tiles [0, 7).  Two barriers per step, as before
+    // (each one both releases a half for overwriting and publishes the other half's arrival).
+    group_issue(0, lds_all, T0{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    group_issue(0, lds_all, std::integral_constant<int, 1>{});
+    for (int ks = 0; ks < nk; ++ks) {
+#ifdef DFEPE_EST_PHASE_CLOCKS
+      const unsigned long long t0_ = __builtin_readcyclecounter();
+#endif
+      frag8 a[2][NPA];
+      a_from_lds(lds_all, a);
+      mfma_phase(lds_all, a, T0{}, TH{});
+#ifdef DFEPE_EST_PHASE_CLOCKS
+      const unsigned long long t1_ = __builtin_readcyclecounter();
+#endif
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tiles [7, 13) of this step
+      __syncthreads();
+#ifdef DFEPE_EST_PHASE_CLOCKS
+      const unsigned long long t2_ = __builtin_readcyclecounter();
+#endif
+      if (ks + 1 < nk) group_issue(ks + 1, lds_all, T0{});
+      mfma_phase(lds_all, a, TH{}, TN{});
+#ifdef DFEPE_EST_PHASE_CLOCKS
+      const unsigned long long t3_ = __builtin_readcyclecounter();
+#endif
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next step's first half
+      __syncthreads();
+      if (ks + 1 < nk) group_issue(ks + 1, lds_all, std::integral_constant<int, 1>{});
+#ifdef DFEPE_EST_PHASE_CLOCKS
+      const unsigned long long t4_ = __builtin_readcyclecounter();
+      wait_cycles += (t2_ - t1_) + (t4_ - t3_); mfma_cycles += (t1_ - t0_) + (t3_ - t2_);
+#endif
+    }
+  } else {
   for (int ks = 0; ks < nk; ++ks) {
+#ifdef DFEPE_EST_PHASE_CLOCKS
+    const unsigned long long t0_ = __builtin_readcyclecounter();
+#endif
     stage_issue(ks, lds_all);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef DFEPE_EST_PHASE_CLOCKS
+    const unsigned long long t1_ = __builtin_readcyclecounter();
+#endif
     frag8 a[2][NPA];
     a_from_lds(lds_all, a);
-    mfma_phase(lds_all, a);
+    mfma_phase(lds_all, a, T0{}, TN{});
+#ifdef DFEPE_EST_PHASE_CLOCKS
+    const unsigned long long t2_ = __builtin_readcyclecounter();
+    wait_cycles += t1_ - t0_; mfma_cycles += t2_ - t1_;
+#endif
     __syncthreads();
   }
+  }
+  EST_STAMP(1);
+#ifdef DFEPE_EST_PHASE_CLOCKS
+  if ((threadIdx.x & 63u) == 0u) {
+    unsigned long long* q = g_est_phase_clk + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 8;
+    q[5] = wait_cycles; q[6] = mfma_cycles;
+  }
+#endif
 
   // ---- epilogue: lane holds, per column n0 + 16 nt + c, channels ch8 + 4 mt + r (mt = 0, 1; r = 0..3): eight in a row --------
   const int ch8 = m0 + wave * 32 + 8 * g;
@@ -398,6 +501,7 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
                             "+v"(s2[p][0]), "+v"(s2[p][1]), "+v"(s2[p][2]), "+v"(s2[p][3]), "+v"(s2[p][4]), "+v"(s2[p][5]), "+v"(s2[p][6]), "+v"(s2[p][7]));
       __builtin_amdgcn_sched_barrier(0);
     }
+    EST_STAMP(2);
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -433,6 +537,7 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
     }
     // the planes are read AGAIN for pass B (L2): without the compiler barrier the second loads are merged with the first and all
     // 104 values of a stay live across the row sums (the first build spilled 130 registers that way)
+    EST_STAMP(3);
     asm volatile("" : "+v"(plane_at) :: "memory");  // (and the addresses formed again: kept, they were 52 registers, spilled)
 #pragma unroll
     for (int i = 0; i < kDepth; ++i) ring[i] = fetch(i);
@@ -462,6 +567,7 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    EST_STAMP(4);
   } else {
     // pair 0 = columns 0..99 (tiles 0..5 and lanes 0..3 of tile 6), pair 1 = 100..199 (lanes 4..15 of tile 6, tiles 7..11,
     // lanes 0..7 of tile 12); lanes 8..15 of tile 12 belong to the next block
@@ -507,6 +613,7 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
 #pragma unroll
       for (int r = 0; r < 4; ++r) { rs0[mt][r] *= gam[mt][r] * unscale; rs1[mt][r] *= gam[mt][r] * unscale; }
     }
+    EST_STAMP(2);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const bool first = (nt < 6) || (nt == 6 && t6p0);
@@ -546,6 +653,7 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
         }
       }
     }
+    EST_STAMP(4);
   }
 }
 
