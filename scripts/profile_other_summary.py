@@ -43,7 +43,7 @@ fetch, write, sq, mf = counters("pmc_fetch"), counters("pmc_write"), counters("p
 md = [f"# {tag} — kernels outside the bench line (rocprofv3 on one MI355X)", "",
       "`scripts/profile_other.sh` (kernel trace, then FETCH_SIZE / WRITE_SIZE / SQ counters in separate `--pmc` passes) over "
       "`scripts/pmc_probe_other.py`: BASELINE config 5 (N = 1000: one fit + E-from-F + cheirality) at 4096 and at 512 pairs, and one "
-      "split-bf16 estimator call forward + backward at B = 4096, N = 100 (fused epilogue) and one at 12 pairs x 2000 points (plain product + `est_norm_fwd_n` / `est_in_bwd_n`; the GEMM rows of the two calls differ by their grids).  HBM-side bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB.", "",
+      "split-bf16 estimator call forward + backward at B = 4096, N = 100 (fused epilogue) and one at 12 pairs x 2000 points (plain product + `est_norm_fwd_n` / `est_in_bwd_n`; the GEMM rows of the two calls differ by their grids).  HBM-side bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB.  `est_gemm_nt_kernel<planes of A, planes of B, order, epilogue, format>`: epilogue 0 = plain fp32 store, 1 = InstanceNorm + LeakyReLU + split (the forward layer), 2 = the adjoint of the layer below (the fused data gradient); format 0 = bf16 planes, 1 = fp16 planes.", "",
       "| kernel | grid (threads) | launches | avg us | min us | HBM-side MB / launch | GB/s | VALU inst / wave | active % | wait % | MFMA busy % of CU-busy | LDS conflict % |",
       "|---|---|---|---|---|---|---|---|---|---|---|---|"]
 for (k, g), ds in dur.items():
