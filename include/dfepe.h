@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFEPE_VERSION 151 /* 0.5.0 */
+#define DFEPE_VERSION 152 /* 0.5.0 */
 
 #define DFEPE_OK 0
 #define DFEPE_ERR_INVALID_ARG (-1) /* null pointer, non-positive size, bad flag combination   */
@@ -412,6 +412,17 @@ int dfepe_inorm_lrelu_bwd(const float *Y, const float *gA, const float *gamma, c
  *   dfepe_est_split      fp32 [rows][C_src] (ld = src_ld) -> n_planes bf16 planes with C (% 32 == 0) channels, the tail zero
  *   dfepe_est_absmax     *word = max(*word, bit pattern of max |src[i]|) -- the caller zeroes the word first; the scale of
  *                        dfepe_est_split_f16 / dfepe_est_layer_fwd / dfepe_est_gemm_nt_f16 is derived from it on the device
+ *   dfepe_est_wprep      (version 152) the weights of n_layers <= 8 layers (host arrays of device pointers W[l] [Co[l]][Ci[l]]) in two
+ *                        launches: words[l] = bit pattern of max |W[l]| (partial maxima in `workspace`, dfepe_est_wprep_workspace_bytes
+ *                        bytes, contents irrelevant: no atomics, no zeroing), then
+ *                        planes_f16[l] = two fp16 planes [Co][K = Ci rounded up to 32] of W[l] scaled as in dfepe_est_split_f16 and,
+ *                        where planes_wt (and planes_wt[l]) is not null, two bf16 planes of W[l]^T [K][Co] (Co % 32 == 0) -- what
+ *                        dfepe_est_gemm_nt / dfepe_est_dgrad_in_bwd multiply dY by.  At the reference's batch sizes (4-32 pairs) a
+ *                        call's bookkeeping launches (per layer: maximum, split, transposed split, reductions, fills) cost more
+ *                        than its GEMMs; this and dfepe_est_colsum take one estimator call from ~75 launches to ~30
+ *   dfepe_est_colsum     dst[s][c] = sum_r src[s][r * cols[s] + c], r < rows[s], for n_seg <= 32 segments in ONE launch, additions in a
+ *                        fixed order (rows[s] = 0: zeros, src[s] may be null): all reductions of one backward -- per-pair d gamma /
+ *                        d beta partials, split-K partials of the weight gradients -- and the zero gradients of the cancelled biases
  *   dfepe_est_split_f16  the same into two fp16 planes, the values multiplied by the scale of `absmax` (null: unscaled)
  *   dfepe_est_layer_fwd  planes_out[2][...M] (fp16) = split(leaky_relu(instance_norm(W X) * gamma + beta)), planes_bwd[2][...M]
  *                        (bf16; null when no gradient is wanted) the same activation for the backward; rstd [pairs][M];
@@ -450,6 +461,10 @@ int dfepe_est_points(void);
 int dfepe_est_split(const float *src, long rows, int C_src, int src_ld, int C, int n_planes, void *planes, size_t plane_stride,
                     void *stream);
 int dfepe_est_absmax(const float *src, long n, unsigned *word, void *stream);
+size_t dfepe_est_wprep_workspace_bytes(int n_layers);
+int dfepe_est_wprep(int n_layers, const float *const *W, const int *Co, const int *Ci, void *const *planes_f16,
+                    void *const *planes_wt, unsigned *words, void *workspace, void *stream);
+int dfepe_est_colsum(int n_seg, const float *const *src, const int *rows, const int *cols, float *const *dst, void *stream);
 int dfepe_est_split_f16(const float *src, long rows, int C_src, int src_ld, int C, const unsigned *absmax, void *planes,
                         size_t plane_stride, void *stream);
 int dfepe_est_layer_fwd(const void *W, size_t w_plane, const void *X, size_t x_plane, int M, int ncols, int K,

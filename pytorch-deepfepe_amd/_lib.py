@@ -65,6 +65,9 @@ _SIGNATURES = {
     "dfepe_est_points": (c_int, []),
     "dfepe_est_split": (c_int, [_P, c_long, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "dfepe_est_absmax": (c_int, [_P, c_long, _P, _P]),
+    "dfepe_est_wprep_workspace_bytes": (c_size_t, [c_int]),
+    "dfepe_est_wprep": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dfepe_est_colsum": (c_int, [c_int, _P, _P, _P, _P, _P]),
     "dfepe_est_split_f16": (c_int, [_P, c_long, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
     "dfepe_est_layer_fwd": (c_int, [_P, c_size_t, _P, c_size_t, c_int, c_int, c_int, _P, _P, _P, c_float, c_float, _P, c_size_t, _P, c_size_t, _P, _P]),
     "dfepe_est_gemm_nt_f16": (c_int, [_P, c_size_t, _P, c_size_t, c_int, c_int, c_int, _P, _P, c_int, _P]),

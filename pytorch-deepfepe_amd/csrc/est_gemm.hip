@@ -1201,6 +1201,123 @@ est_absmax_kernel(const float* __restrict__ src, long n, unsigned* __restrict__ 
   if ((threadIdx.x & 63) == 0 && m) atomicMax(word, m);
 }
 
+// ---- table-driven launches (round 5): at the reference's batch sizes (4-32 pairs) one estimator call is ~75 launches of which ~60
+// are a few microseconds of bookkeeping each -- per layer a maximum, a split, a transposed split, three reductions, three fills.  These
+// kernels do a call's worth of each in ONE launch, the per-layer pointers travelling in the kernel arguments.
+constexpr int kTabMax = 8;    // hidden layers per table (the reference's estimator has five)
+constexpr int kSegMax = 32;   // reduction segments per launch
+struct WprepTab {
+  int n;
+  const float* W[kTabMax];   // [Co][Ci] fp32
+  int Co[kTabMax], Ci[kTabMax], K[kTabMax];  // K = Ci rounded up to 32
+  bf16_t* pf[kTabMax];       // two fp16 planes of W * s, [K/32][Co][32] each
+  bf16_t* pt[kTabMax];       // two bf16 planes of W^T (rows = K, channels = Co: [Co/32][K][32]) for the data gradient, or null
+  unsigned* words;           // [n] bit patterns of max |W|
+};
+// kAbsBlocks workgroups per layer leave their partial maxima in part[layer][block] (no atomics, no zeroing beforehand); the split
+// kernel merges them (and its first workgroup of a layer publishes words[layer] for the GEMM epilogues that follow)
+constexpr int kAbsBlocks = 32;
+__global__ void __launch_bounds__(256) est_wprep_absmax_kernel(const WprepTab T, unsigned* __restrict__ part) {
+  __shared__ unsigned red[4];
+  const int layer = (int)blockIdx.y;
+  const float* W = T.W[layer];
+  const long n = (long)T.Co[layer] * T.Ci[layer];
+  unsigned m = 0u;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)kAbsBlocks * 256) {
+    const unsigned b = __float_as_uint(W[i]) & 0x7fffffffu;
+    m = b > m ? b : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o, 64); m = t > m ? t : m; }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < 4; ++w) m = red[w] > m ? red[w] : m;
+    part[layer * kAbsBlocks + blockIdx.x] = m;
+  }
+}
+__global__ void __launch_bounds__(256) est_wprep_split_kernel(const WprepTab T, const unsigned* __restrict__ part) {
+  const int layer = (int)blockIdx.y;
+  const float* W = T.W[layer];
+  const int Co = T.Co[layer], Ci = T.Ci[layer], K = T.K[layer];
+  unsigned mx = part[layer * kAbsBlocks + (threadIdx.x & (kAbsBlocks - 1))];
+#pragma unroll
+  for (int o = kAbsBlocks / 2; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)mx, o, 64); mx = t > mx ? t : mx; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) T.words[layer] = mx;
+  const float sc = wscale(mx, false);
+  const long nf = (long)Co * K / 2, nt = T.pt[layer] ? (long)K * Co / 2 : 0;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < nf + nt; idx += (long)gridDim.x * 256) {
+    unsigned p0, p1;
+    if (idx < nf) {  // the forward's operand: row = output channel, channel = input channel
+      const long e = idx * 2;
+      const int r = (int)(e / K), ch = (int)(e - (long)r * K);
+      const float x = (ch < Ci) ? W[(size_t)r * Ci + ch] * sc : 0.f, y = (ch + 1 < Ci) ? W[(size_t)r * Ci + ch + 1] * sc : 0.f;
+      split2h(x, y, p0, p1);
+      const size_t at = kb_index((size_t)r, ch, (size_t)Co);
+      *reinterpret_cast<unsigned*>(T.pf[layer] + at) = p0;
+      *reinterpret_cast<unsigned*>(T.pf[layer] + (size_t)Co * K + at) = p1;
+    } else {         // the data gradient's: row = input channel (zero rows up to K), channel = output channel
+      const long e = (idx - nf) * 2;
+      const int r = (int)(e / Co), ch = (int)(e - (long)r * Co);
+      const float x = (r < Ci) ? W[(size_t)ch * Ci + r] : 0.f, y = (r < Ci) ? W[(size_t)(ch + 1) * Ci + r] : 0.f;
+      split2(x, y, p0, p1);
+      const size_t at = kb_index((size_t)r, ch, (size_t)K);
+      *reinterpret_cast<unsigned*>(T.pt[layer] + at) = p0;
+      *reinterpret_cast<unsigned*>(T.pt[layer] + (size_t)K * Co + at) = p1;
+    }
+  }
+}
+
+// dst[c] = sum over r < rows of src[r * cols + c] for up to kSegMax independent segments (rows = 0: zeros): every reduction of one
+// backward -- per-pair d gamma / d beta partials, split-K partials of the weight gradients, the head's -- and the exact-zero
+// gradients of the cancelled convolution biases.  Fixed order of additions.  Two shapes of segment: TALL (rows > 32: the per-pair
+// partials, thousands of rows x <= 1024 columns): a workgroup = 64 columns x 16 row groups, thread (column, group g) adds rows g,
+// g + 16, ... and the sixteen partial sums are added in order; WIDE (rows <= 32: split-K partials, up to 2^19 columns): a workgroup
+// = 1024 columns, a thread adds its column's rows in order.
+struct ColSumTab {
+  int n;
+  const float* src[kSegMax];
+  float* dst[kSegMax];
+  int rows[kSegMax], cols[kSegMax];
+  int first_block[kSegMax + 1];  // prefix sums of the segments' workgroup counts
+};
+__host__ __device__ inline int colsum_blocks(int rows, int cols) { return rows > 32 ? (cols + 63) / 64 : (cols + 1023) / 1024; }
+__global__ void __launch_bounds__(1024) est_colsum_kernel(const ColSumTab T) {
+  __shared__ float red[16][64];
+  int seg = 0;
+  while (seg + 1 < T.n && (int)blockIdx.x >= T.first_block[seg + 1]) ++seg;
+  const int rows = T.rows[seg], cols = T.cols[seg], blk = (int)blockIdx.x - T.first_block[seg];
+  const float* src = T.src[seg];
+  if (rows <= 32) {  // WIDE (uniform per workgroup)
+    const int c = blk * 1024 + (int)threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += src[(size_t)r * cols + c];
+    T.dst[seg][c] = s;
+    return;
+  }
+  const int c = blk * 64 + (int)(threadIdx.x & 63), g = (int)(threadIdx.x >> 6);
+  float s = 0.f;
+  if (c < cols) {
+    int r = g;
+    for (; r + 48 < rows; r += 64) {  // four loads in flight
+      const float a0 = src[(size_t)r * cols + c], a1 = src[(size_t)(r + 16) * cols + c], a2 = src[(size_t)(r + 32) * cols + c],
+                  a3 = src[(size_t)(r + 48) * cols + c];
+      s = (((s + a0) + a1) + a2) + a3;
+    }
+    for (; r < rows; r += 16) s += src[(size_t)r * cols + c];
+  }
+  red[g][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (g == 0 && c < cols) {
+    float t = red[0][threadIdx.x];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += red[q][threadIdx.x];
+    T.dst[seg][c] = t;
+  }
+}
+
 }  // namespace
 
 extern "C" int dfepe_est_points(void) { return kPts; }
@@ -1211,6 +1328,45 @@ extern "C" int dfepe_est_absmax(const float* src, long n, unsigned* word, void* 
   long blocks = (n + 2047) / 2048;
   blocks = blocks > 256 ? 256 : blocks;
   hipLaunchKernelGGL(est_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, n, word);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+// every layer's weights in two launches: the maxima (one workgroup per layer), then the two fp16 planes of W * s for the forward
+// and -- where planes_wt[l] is given -- the two bf16 planes of W^T the data gradient multiplies by
+extern "C" size_t dfepe_est_wprep_workspace_bytes(int n_layers) { return (size_t)(n_layers > 0 ? n_layers : 0) * kAbsBlocks * sizeof(unsigned); }
+
+extern "C" int dfepe_est_wprep(int n_layers, const float* const* W, const int* Co, const int* Ci, void* const* planes_f16,
+                               void* const* planes_wt, unsigned* words, void* workspace, void* stream) {
+  if (n_layers <= 0 || n_layers > kTabMax || !W || !Co || !Ci || !planes_f16 || !words || !workspace) return DFEPE_ERR_INVALID_ARG;
+  WprepTab T{};
+  T.n = n_layers; T.words = words;
+  for (int l = 0; l < n_layers; ++l) {
+    if (!W[l] || !planes_f16[l] || Co[l] <= 0 || Ci[l] <= 0) return DFEPE_ERR_INVALID_ARG;
+    if (planes_wt && planes_wt[l] && (Co[l] & 31)) return DFEPE_ERR_INVALID_ARG;
+    T.W[l] = W[l]; T.Co[l] = Co[l]; T.Ci[l] = Ci[l]; T.K[l] = (Ci[l] + 31) / 32 * 32;
+    T.pf[l] = static_cast<bf16_t*>(planes_f16[l]); T.pt[l] = planes_wt ? static_cast<bf16_t*>(planes_wt[l]) : nullptr;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  unsigned* part = static_cast<unsigned*>(workspace);
+  hipLaunchKernelGGL(est_wprep_absmax_kernel, dim3(kAbsBlocks, n_layers), dim3(256), 0, st, T, part);
+  hipLaunchKernelGGL(est_wprep_split_kernel, dim3(256, n_layers), dim3(256), 0, st, T, static_cast<const unsigned*>(part));
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+// dst[s][c] = sum_r src[s][r][c] for n_seg <= 32 segments in one launch (rows[s] = 0: zeros; src[s] may then be null)
+extern "C" int dfepe_est_colsum(int n_seg, const float* const* src, const int* rows, const int* cols, float* const* dst, void* stream) {
+  if (n_seg <= 0 || n_seg > kSegMax || !src || !rows || !cols || !dst) return DFEPE_ERR_INVALID_ARG;
+  ColSumTab T{};
+  T.n = n_seg;
+  int blocks = 0;
+  for (int s = 0; s < n_seg; ++s) {
+    if (rows[s] < 0 || cols[s] <= 0 || !dst[s] || (rows[s] > 0 && !src[s])) return DFEPE_ERR_INVALID_ARG;
+    T.src[s] = src[s]; T.dst[s] = dst[s]; T.rows[s] = rows[s]; T.cols[s] = cols[s];
+    T.first_block[s] = blocks;
+    blocks += colsum_blocks(rows[s], cols[s]);
+  }
+  T.first_block[n_seg] = blocks;
+  hipLaunchKernelGGL(est_colsum_kernel, dim3(blocks), dim3(1024), 0, static_cast<hipStream_t>(stream), T);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 

@@ -13,6 +13,7 @@ parameters and inputs are the module's own fp32 tensors.  PyTorch is plumbing he
 sums over split-K / per-pair partials)."""
 from __future__ import annotations
 
+import ctypes
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -64,6 +65,47 @@ def _split_f16(src: Tensor, rows: int, c_src: int, c: int, absmax: Optional[Tens
     return out
 
 
+def _ptr_array(ts):
+    return (ctypes.c_void_p * len(ts))(*[_ptr(t) for t in ts])
+
+
+def _int_array(vs):
+    return (ctypes.c_int * len(vs))(*vs)
+
+
+_TAB = 8    # layers per dfepe_est_wprep launch pair
+_SEG = 32   # segments per dfepe_est_colsum launch
+
+
+def _wprep(Ws: Sequence[Tensor], want_wt: Sequence[bool], dev) -> Tuple[List[Tensor], List[Optional[Tensor]], Tensor]:
+    """Every hidden layer's weights [Co, Ci] (fp32, contiguous) in two launches (per eight layers): the device-side power-of-two
+    scales, the scaled fp16 planes [2, Co, K] the forward multiplies by, and -- where wanted -- the bf16 planes of W^T [2, K, Co]
+    the data gradient multiplies by (the weights a backward sees are the ones its forward saw: autograd's version check)."""
+    n = len(Ws)
+    words = torch.empty(max(n, 1), device=dev, dtype=torch.int32)
+    Co, Ci = [int(W.shape[0]) for W in Ws], [int(W.shape[1]) for W in Ws]
+    pf = [_buf("split", 2, Co[l], _pad32(Ci[l]), device=dev, dtype=F16) for l in range(n)]
+    pt = [(_buf("split", 2, _pad32(Ci[l]), Co[l], device=dev, dtype=BF16) if want_wt[l] else None) for l in range(n)]
+    ws = torch.empty(max(1, _lib.lib().dfepe_est_wprep_workspace_bytes(min(n, _TAB)) // 4), device=dev, dtype=torch.int32)
+    for a in range(0, n, _TAB):
+        b = min(n, a + _TAB)
+        rc = _lib.lib().dfepe_est_wprep(b - a, _ptr_array(Ws[a:b]), _int_array(Co[a:b]), _int_array(Ci[a:b]), _ptr_array(pf[a:b]),
+                                        _ptr_array(pt[a:b]), _ptr(words[a:b]), _ptr(ws), _stream())
+        _lib.check(rc, "dfepe_est_wprep")
+    return pf, pt, words
+
+
+def _colsum(segs: List[Tuple[Optional[Tensor], int, int]], dev) -> List[Tensor]:
+    """[(src [rows, cols] or None, rows, cols)] -> the column sums, one launch per 32 segments (rows = 0: zeros), fixed order."""
+    outs = [torch.empty(c, device=dev, dtype=torch.float32) for _, _, c in segs]
+    for a in range(0, len(segs), _SEG):
+        b = min(len(segs), a + _SEG)
+        rc = _lib.lib().dfepe_est_colsum(b - a, _ptr_array([t for t, _, _ in segs[a:b]]), _int_array([r for _, r, _ in segs[a:b]]),
+                                         _int_array([c for _, _, c in segs[a:b]]), _ptr_array(outs[a:b]), _stream())
+        _lib.check(rc, "dfepe_est_colsum")
+    return outs
+
+
 def _row_splits(pairs: int, c: int, n: int) -> int:
     """Workgroups a pair's rows are spread over in the N-generic normalisation kernels: 1 when (pair, 64-channel) workgroups
     alone fill the chip, otherwise enough to reach ~1024 workgroups with at least 128 rows (one unrolled trip) each."""
@@ -79,9 +121,9 @@ TN_BLOCKS = 768  # workgroups of a weight-gradient launch: three per CU in one r
 # measured: 1024 (the kernel compiled for four per CU, 128 registers) 10.67 against 10.55 ms per estimator call
 
 
-def _slices_for(cout: int, cin: int) -> int:
+def _slices_for(cout: int, cin: int, cols: int = 1 << 30) -> int:
     tiles = ((cout + 127) // 128) * ((cin + 127) // 128)
-    s = max(1, min(512, TN_BLOCKS // tiles))
+    s = max(1, min(512, TN_BLOCKS // tiles, cols // 256))  # at the reference's batch sizes a slice keeps >= 256 columns (8 K steps)
     return s - s % 8 if s >= 8 else s  # a multiple of eight: one slice group per XCD (est_gemm_tn's block order needs it)
 
 
@@ -104,14 +146,15 @@ class _EstimatorFunction(torch.autograd.Function):
             act = _split_f16(xin, cols, C0, _pad32(C0))  # the layer's input as the forward reads it: two fp16 planes [2, cols, C]
             acts = [_split(xin, cols, C0, _pad32(C0), 2)] if keep else []  # ... and as the backward reads it: two bf16 planes
             rstds = []
-            wmax = torch.zeros(max(n_hidden, 1), device=dev, dtype=torch.int32)  # bit patterns of max |W| per layer (dfepe_est_absmax)
+            W32s = [params[4 * l].detach().float().reshape(params[4 * l].shape[0], params[4 * l].shape[1]).contiguous() for l in range(n_hidden)]
+            # all layers' weights in two launches: scales, fp16 planes, and the transposed bf16 planes of every layer whose data
+            # gradient the backward will form (all but the first, unless the input wants a gradient)
+            Wps, WTps, wmax = _wprep(W32s, [keep and (l > 0 or ctx.needs_input_grad[1]) for l in range(n_hidden)], dev)
             for l in range(n_hidden):
                 W, _b, gamma, beta = params[4 * l:4 * l + 4]
                 Co, Ci = W.shape[0], W.shape[1]
                 K = act.shape[2]
-                W32 = W.detach().float().reshape(Co, Ci).contiguous()
-                _lib.check(lib.dfepe_est_absmax(_ptr(W32), Co * Ci, _ptr(wmax[l:l + 1]), st), "dfepe_est_absmax")
-                Wp = _split_f16(W32, Co, Ci, K, wmax[l:l + 1])
+                Wp = Wps[l]
                 out = _buf("out", 2, cols, Co, device=dev, dtype=F16)
                 out_b = _buf("out_b", 2, cols, Co, device=dev, dtype=BF16) if keep else None
                 rstd = _buf("rstd", B, Co, device=dev, dtype=torch.float32)
@@ -151,7 +194,9 @@ class _EstimatorFunction(torch.autograd.Function):
         # through a freed graph raises autograd's own error instead of a TypeError on a cleared attribute)
         kept = [p for p in params if p is not None]
         ctx.n_params = len(kept)
-        ctx.save_for_backward(*kept, *acts, *rstds)
+        wts = [t for t in WTps if t is not None] if keep else []
+        ctx.wt_layers = [l for l in range(n_hidden) if keep and WTps[l] is not None]
+        ctx.save_for_backward(*kept, *acts, *rstds, *wts)
         ctx.has_head_bias = bh is not None
         return logits.view(B, 1, N) if n_out == 1 else logits.view(n_out, B, N).permute(1, 0, 2).contiguous()
 
@@ -164,7 +209,8 @@ class _EstimatorFunction(torch.autograd.Function):
         everything = list(ctx.saved_tensors)
         saved = everything[:ctx.n_params]
         acts = everything[ctx.n_params:ctx.n_params + n_hidden + 1]
-        rstds = everything[ctx.n_params + n_hidden + 1:]
+        rstds = everything[ctx.n_params + n_hidden + 1:ctx.n_params + 2 * n_hidden + 1]
+        WTps = dict(zip(ctx.wt_layers, everything[ctx.n_params + 2 * n_hidden + 1:]))
         params = saved if ctx.has_head_bias else saved + [None]
         dev = g_logits.device
         grads: List[Optional[Tensor]] = [None] * len(params)
@@ -180,7 +226,10 @@ class _EstimatorFunction(torch.autograd.Function):
             for o in range(n_out):
                 rc = lib.dfepe_est_head_dw(_ptr(acts[-1]), cols * C, C, cols, nblk, _ptr(dl[o]), _ptr(part[o]), st)
                 _lib.check(rc, "dfepe_est_head_dw")
-            grads[4 * n_hidden] = part.sum(1).reshape(Wh.shape).to(Wh.dtype)
+            # every reduction of this backward is a segment of ONE dfepe_est_colsum launch at the end: (source [rows, cols], rows, cols)
+            # and what to do with the sum
+            segs: List[Tuple[Optional[Tensor], int, int]] = [(part[o], nblk, C) for o in range(n_out)]
+            sinks = [None] * n_out  # the head's: gathered below
             if ctx.has_head_bias:
                 grads[4 * n_hidden + 1] = dl.sum(1).to(params[4 * n_hidden + 1].dtype)
             # fp32 [cols, C_l]: gradient w.r.t. the output of hidden layer l.  None under a one-channel head: est_in_bwd forms the
@@ -229,22 +278,19 @@ class _EstimatorFunction(torch.autograd.Function):
                     _lib.check(rc, "dfepe_est_dgamma_zero")
                 del keep_alive
                 pending = None
-                grads[4 * l + 2] = dg.sum(0).to(gamma.dtype)
-                grads[4 * l + 3] = db.sum(0).to(beta.dtype)
-                grads[4 * l + 1] = (torch.empty_like(bconv).fill_(0.0) if "nomemset" in _DEBUG_ZERO else torch.zeros_like(bconv))  # the bias cancels in the instance normalisation: exact zero, like the reference's autograd
-                # dW = dY^T X (split-K over the columns, partials summed here: deterministic)
-                slices = _slices_for(Co, K)
+                # dW = dY^T X (split-K over the columns; the partials are a segment of the final reduction: deterministic)
+                slices = _slices_for(Co, K, cols)
                 partw = _buf("partw", slices, Co, K, device=dev, dtype=torch.float32)
                 rc = lib.dfepe_est_gemm_tn(_ptr(dY), cols * Co, Co, _ptr(a_in), cols * K, K, cols, slices, _ptr(partw), st)
                 _lib.check(rc, "dfepe_est_gemm_tn")
-                grads[4 * l] = partw.sum(0)[:, :Ci].reshape(W.shape).to(W.dtype)
+                # d gamma, d beta (per-pair partials), dW (split-K partials), and the convolution bias: it cancels in the instance
+                # normalisation -- an exact zero (rows = 0), like the reference's autograd up to its 1e-16 noise
+                segs += [(dg, B, Co), (db, B, Co), (partw, slices, Co * K), (None, 0, Co)]
+                sinks += [(4 * l + 2, gamma), (4 * l + 3, beta), (4 * l, W), (4 * l + 1, bconv)]
                 need_dx = l > 0 or ctx.needs_input_grad[1]
                 if need_dx:
-                    Mp = (K + 7) // 8 * 8
-                    WT = (torch.empty(Mp, Co, device=dev, dtype=torch.float32).fill_(0.0) if "nomemset" in _DEBUG_ZERO else
-                          torch.zeros(Mp, Co, device=dev, dtype=torch.float32))
-                    WT[:Ci] = W32.t()
-                    WTp = _split(WT, Mp, Co, Co, 2)
+                    Mp = K  # a multiple of 32
+                    WTp = WTps[l]  # two bf16 planes of W^T [K, Co], made with the forward's weight planes (dfepe_est_wprep)
                     if l > 0 and _fused(N) and Ci == K and FUSE_DGRAD:
                         # the data gradient dA = dY W stays in the GEMM's accumulators and goes straight through the adjoint of the layer
                         # below: dY, d gamma / d beta partials of layer l - 1 out, dA never written (8 of 20 bytes per element)
@@ -262,6 +308,14 @@ class _EstimatorFunction(torch.autograd.Function):
                         rc = lib.dfepe_est_gemm_nt(_ptr(WTp), Mp * Co, _ptr(dY), cols * Co, Mp, cols, Co, 2, _ptr(dA), Mp, st)
                         _lib.check(rc, "dfepe_est_gemm_nt")
                 del dY
+            sums = _colsum(segs, dev)
+            grads[4 * n_hidden] = torch.stack(sums[:n_out]).reshape(Wh.shape).to(Wh.dtype) if n_out > 1 else sums[0].reshape(Wh.shape).to(Wh.dtype)
+            for (slot, like), v in zip(sinks[n_out:], sums[n_out:]):
+                if slot % 4 == 0:  # a weight gradient [Co, K]: the K - Ci zero-padded input channels dropped
+                    Co_, Ci_ = like.shape[0], like.shape[1]
+                    v = v.view(Co_, -1)
+                    v = v if v.shape[1] == Ci_ else v[:, :Ci_]
+                grads[slot] = v.reshape(like.shape).to(like.dtype)
             gx = None
             if ctx.needs_input_grad[1]:
                 gx = dA[:, :C0].reshape(B, N, C0).permute(0, 2, 1).contiguous()

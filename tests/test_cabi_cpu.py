@@ -31,7 +31,7 @@ def test_library_builds_and_exports_every_declared_symbol(dfepe):
 
 def test_version_strerror_and_save_layout(dfepe):
     L = dfepe._lib.lib()
-    assert L.dfepe_version() == 151
+    assert L.dfepe_version() == 152
     assert L.dfepe_save_floats() == 128
     assert L.dfepe_strerror(0) == b"ok"
     assert b"invalid" in L.dfepe_strerror(-1)
@@ -75,6 +75,10 @@ def test_argument_validation_without_launching(dfepe):
     assert L.dfepe_est_absmax(None, 4, None, None) == -1 and L.dfepe_est_split_f16(None, 4, 32, 32, 32, None, None, 0, None) == -1
     assert L.dfepe_est_layer_fwd(None, 0, None, 0, 64, 200, 32, None, None, None, 1e-5, 0.01, None, 0, None, 0, None, None) == -1
     assert L.dfepe_est_gemm_nt_f16(None, 0, None, 0, 64, 200, 32, None, None, 64, None) == -1
+    assert L.dfepe_est_wprep(0, None, None, None, None, None, None, None, None) == -1 and L.dfepe_est_wprep(9, None, None, None, None, None, None, None, None) == -1
+    assert L.dfepe_est_wprep_workspace_bytes(5) >= 5 * 4 and L.dfepe_est_wprep_workspace_bytes(0) == 0
+    assert L.dfepe_est_colsum(0, None, None, None, None, None) == -1 and L.dfepe_est_colsum(33, None, None, None, None, None) == -1
+    assert L.dfepe_est_dgrad_in_bwd(None, 0, None, 0, 64, 200, 32, None, 0, None, None, None, 0.01, None, 0, None, None, None) == -1
     assert L.dfepe_est_in_bwd_n(None, None, None, None, 0, None, None, None, 0.01, 64, 2, 1000, None, 0, None, None, 1, None, None) == -1
 
 

@@ -76,6 +76,35 @@ def test_gemm_nt_f16_matches_float64(dfepe, M, K, pairs, scaled):
     assert err < (4e-7 if scaled else 1.5e-6), err  # unscaled small weights: their low plane is subnormal fp16
 
 
+def test_weight_preparation_and_column_sums_in_one_launch_each(dfepe):
+    """dfepe_est_wprep (all layers' scales, fp16 planes and transposed bf16 planes in two launches) against the per-layer calls it
+    replaces, and dfepe_est_colsum (every reduction of a backward in one launch, rows = 0 -> zeros) against float64 sums."""
+    est = dfepe.estimator
+    g = torch.Generator().manual_seed(4)
+    shapes = [(64, 7), (128, 64), (1024, 128), (32, 40)]
+    Ws = [(torch.randn(co, ci, generator=g) * (0.5 / ci ** 0.5)).to(DEV) for co, ci in shapes]
+    pf, pt, words = est._wprep(Ws, [False, True, True, True], torch.device(DEV))
+    torch.cuda.synchronize()
+    for W, f, t, wd in zip(Ws, pf, pt, words):
+        co, ci = W.shape
+        K = (ci + 31) // 32 * 32
+        ref_f, word, scale = _split_f16(dfepe, W, K, scaled=True)
+        assert int(wd) == int(word) and torch.equal(f.view(torch.int16), ref_f.view(torch.int16))
+        if t is not None:
+            WT = torch.zeros(K, co, device=DEV)
+            WT[:ci] = W.t()
+            assert torch.equal(t.view(torch.int16), _split(dfepe, WT, co, 2).view(torch.int16))
+    assert pt[0] is None
+    srcs = [torch.randn(r, c, generator=g).to(DEV) for r, c in [(5, 64), (4096, 1024), (24, 70000), (1, 33), (17, 100)]]
+    segs = [(s_, s_.shape[0], s_.shape[1]) for s_ in srcs] + [(None, 0, 256)]
+    outs = est._colsum(segs, torch.device(DEV))
+    torch.cuda.synchronize()
+    for s_, o in zip(srcs, outs):
+        ref = s_.double().sum(0)
+        assert float((o.double() - ref).abs().max()) <= 1e-6 * float(s_.abs().sum(0).max())
+    assert outs[-1].shape == (256,) and outs[-1].abs().max().item() == 0.0
+
+
 def test_split_planes_are_exact(dfepe):
     g = torch.Generator().manual_seed(0)
     x = (torch.randn(1000, 7, generator=g) * torch.logspace(-6, 3, 7)).to(DEV)
