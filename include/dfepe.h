@@ -453,7 +453,8 @@ int dfepe_inorm_lrelu_bwd(const float *Y, const float *gA, const float *gamma, c
  *                        [ncols][K-blocked], fp32 weights W [C][ldw], Ci input channels); channels with gamma != 0 cost an idle
  *                        workgroup each.  N <= 4096.  The upstream gradient comes from dA, from the head's rank-one form, or -- behind
  *                        dfepe_est_dgrad_in_bwd, which never writes dA -- is recomputed for the channel from dY_next planes [2] of
- *                        [ncols][C_next] and the next layer's fp32 weights W_next [C_next][ldw_next]
+ *                        [ncols][C_next] and the next layer's fp32 weights W_next [C_next][ldw_next].  dfepe_est_dgamma_zero_multi: the
+ *                        same for n_layers <= 8 layers in ONE launch (host arrays indexed by layer; ldw = Ci, ldw_next = C)
  *   dfepe_est_head_fwd   logits[col] = sum_c w[c] a[col][c] + bias[0]   (the last Conv1d(C -> 1)); a: the forward's planes [2] (fp16)
  *   dfepe_est_head_dw    part[blocks][C] = partial sums of d w = sum_col dlogit[col] a[col][c]; a: the backward's planes [2] (bf16)
  */
@@ -480,6 +481,12 @@ int dfepe_est_dgamma_zero(const float *dA, const float *dlogit, const float *w_h
                           const void *in_planes, size_t in_plane, const float *W, int ldw, int Ci, const float *rstd, const float *gamma,
                           float slope, int C, int N, long n_pairs, float *dgamma_part, const void *dY_next, size_t dyn_plane,
                           const float *W_next, int ldw_next, int C_next, void *stream);
+int dfepe_est_dgamma_zero_multi(int n_layers, const float *const *dA, const float *const *dlogit, const float *const *w_head,
+                                const void *const *out_planes, const size_t *out_plane, const void *const *in_planes,
+                                const size_t *in_plane, const float *const *W, const int *Ci, const float *const *rstd,
+                                const float *const *gamma, const int *C, float *const *dgamma_part, const void *const *dY_next,
+                                const size_t *dyn_plane, const float *const *W_next, const int *C_next, float slope, int N, long n_pairs,
+                                void *stream);
 int dfepe_est_dgrad_in_bwd(const void *WT, size_t wt_plane, const void *dY_next, size_t dyn_plane, int M, int ncols, int K,
                            const void *aout, size_t aout_plane, const float *rstd, const float *gamma, const float *beta, float slope,
                            void *dY, size_t dy_plane, float *dgamma_part, float *dbeta_part, void *stream);

@@ -76,6 +76,7 @@ _SIGNATURES = {
     "dfepe_est_in_bwd": (c_int, [_P, _P, _P, _P, c_size_t, _P, _P, _P, c_float, c_int, c_int, _P, c_size_t, _P, _P, _P]),
     "dfepe_est_dgamma_zero": (c_int, [_P, _P, _P, _P, c_size_t, _P, c_size_t, _P, c_int, c_int, _P, _P, c_float, c_int, c_int, c_long, _P, _P,
                                       c_size_t, _P, c_int, c_int, _P]),
+    "dfepe_est_dgamma_zero_multi": (c_int, [c_int] + [_P] * 17 + [c_float, c_int, c_long, _P]),
     "dfepe_est_dgrad_in_bwd": (c_int, [_P, c_size_t, _P, c_size_t, c_int, c_int, c_int, _P, c_size_t, _P, _P, _P, c_float, _P, c_size_t, _P, _P, _P]),
     "dfepe_est_norm_fwd": (c_int, [_P, c_int, c_int, c_long, c_int, _P, _P, c_float, c_float, _P, c_size_t, _P, c_size_t, _P, c_int, _P, _P]),
     "dfepe_est_in_bwd_n": (c_int, [_P, _P, _P, _P, c_size_t, _P, _P, _P, c_float, c_int, c_long, c_int, _P, c_size_t, _P, _P, c_int, _P, _P]),

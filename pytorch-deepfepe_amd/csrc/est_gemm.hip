@@ -1216,14 +1216,22 @@ struct WprepTab {
 };
 // kAbsBlocks workgroups per layer leave their partial maxima in part[layer][block] (no atomics, no zeroing beforehand); the split
 // kernel merges them (and its first workgroup of a layer publishes words[layer] for the GEMM epilogues that follow)
-constexpr int kAbsBlocks = 32;
+constexpr int kAbsBlocks = 64;  // (a wavefront merges them with shuffles: <= 64)
 __global__ void __launch_bounds__(256) est_wprep_absmax_kernel(const WprepTab T, unsigned* __restrict__ part) {
   __shared__ unsigned red[4];
   const int layer = (int)blockIdx.y;
   const float* W = T.W[layer];
   const long n = (long)T.Co[layer] * T.Ci[layer];
   unsigned m = 0u;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)kAbsBlocks * 256) {
+  constexpr long kStride = (long)kAbsBlocks * 256;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * kStride < n; i += 4 * kStride) {  // four loads in flight
+    const unsigned b0 = __float_as_uint(W[i]) & 0x7fffffffu, b1 = __float_as_uint(W[i + kStride]) & 0x7fffffffu,
+                   b2 = __float_as_uint(W[i + 2 * kStride]) & 0x7fffffffu, b3 = __float_as_uint(W[i + 3 * kStride]) & 0x7fffffffu;
+    const unsigned c0 = b0 > b1 ? b0 : b1, c1 = b2 > b3 ? b2 : b3, c = c0 > c1 ? c0 : c1;
+    m = c > m ? c : m;
+  }
+  for (; i < n; i += kStride) {
     const unsigned b = __float_as_uint(W[i]) & 0x7fffffffu;
     m = b > m ? b : m;
   }
@@ -1478,14 +1486,25 @@ extern "C" int dfepe_est_gemm_tn(const void* dY, size_t dy_plane, int Cout, cons
 // network -- recomputes that channel's pre-normalisation product y = W[ch] . x from the layer's INPUT planes and fp32 weights, forms
 // x^ = (y - mean) rstd per pair and overwrites the channel's per-pair d gamma.  Slow (a serial GEMV per pair) and rare by construction.
 constexpr int kFixMaxN = 4096;
-__global__ void __launch_bounds__(256)
-est_dgamma_zero_kernel(const float* __restrict__ dA, const float* __restrict__ dlogit, const float* __restrict__ w_head,
-                       const bf16_t* __restrict__ out_planes, size_t out_stride, const bf16_t* __restrict__ in_planes, size_t in_stride,
-                       const float* __restrict__ W, int ldw, int Ci, const float* __restrict__ rstd, const float* __restrict__ gamma,
-                       float slope, int C, int N, long n_pairs, float* __restrict__ dgamma_part,
-                       const bf16_t* __restrict__ dYn, size_t dyn_stride, const float* __restrict__ Wn, int ldwn, int Cn) {
+struct ZeroFix {  // one layer's arguments
+  const float* dA; const float* dlogit; const float* w_head;
+  const bf16_t* out_planes; size_t out_stride;
+  const bf16_t* in_planes; size_t in_stride;
+  const float* W; int ldw, Ci;
+  const float* rstd; const float* gamma;
+  int C;
+  float* dgamma_part;
+  const bf16_t* dYn; size_t dyn_stride; const float* Wn; int ldwn, Cn;
+};
+struct ZeroFixTab { int n; float slope; int N; long n_pairs; ZeroFix L[kTabMax]; };
+// grid (max C, layers): a launch covers every layer of a backward when their dY are still alive (few columns), one layer otherwise
+__global__ void __launch_bounds__(256) est_dgamma_zero_kernel(const ZeroFixTab T) {
+  const ZeroFix& A = T.L[blockIdx.y];
   const int ch = (int)blockIdx.x;
-  if (fabsf(gamma[ch]) > 1e-30f) return;
+  if (ch >= A.C || fabsf(A.gamma[ch]) > 1e-30f) return;
+  const float slope = T.slope;
+  const int N = T.N, C = A.C, Ci = A.Ci;
+  const long n_pairs = T.n_pairs;
   __shared__ float y[kFixMaxN];
   __shared__ float red[4];
   const int t = (int)threadIdx.x;
@@ -1505,43 +1524,83 @@ est_dgamma_zero_kernel(const float* __restrict__ dA, const float* __restrict__ d
     float s = 0.f;
     for (int r = t; r < N; r += 256) {
       float acc = 0.f;
-      for (int k = 0; k < Ci; ++k) acc = fmaf(W[(size_t)ch * ldw + k], plane2(in_planes, in_stride, kb_index(col0 + r, k, ncols)), acc);
+      for (int k = 0; k < Ci; ++k) acc = fmaf(A.W[(size_t)ch * A.ldw + k], plane2(A.in_planes, A.in_stride, kb_index(col0 + r, k, ncols)), acc);
       y[r] = acc;
       s += acc;
     }
     const float mean = block_sum(s) / (float)N;
-    const float rs = rstd[(size_t)pair * C + ch];
+    const float rs = A.rstd[(size_t)pair * C + ch];
     float g = 0.f;
     for (int r = t; r < N; r += 256) {
       const size_t col = col0 + r;
       const size_t at = kb_index(col, ch, ncols);
-      const float a = __uint_as_float((unsigned)out_planes[at] << 16) + __uint_as_float((unsigned)out_planes[out_stride + at] << 16);
+      const float a = __uint_as_float((unsigned)A.out_planes[at] << 16) + __uint_as_float((unsigned)A.out_planes[A.out_stride + at] << 16);
       float d;
-      if (dA != nullptr) d = dA[col * C + ch];
-      else if (dlogit != nullptr) d = dlogit[col] * w_head[ch];
+      if (A.dA != nullptr) d = A.dA[col * C + ch];
+      else if (A.dlogit != nullptr) d = A.dlogit[col] * A.w_head[ch];
       else {  // the fused data gradient never wrote dA: this channel's column of dY_next W_next again (Cn terms per point)
         d = 0.f;
-        for (int k = 0; k < Cn; ++k) d = fmaf(plane2(dYn, dyn_stride, kb_index(col, k, ncols)), Wn[(size_t)k * ldwn + ch], d);
+        for (int k = 0; k < A.Cn; ++k) d = fmaf(plane2(A.dYn, A.dyn_stride, kb_index(col, k, ncols)), A.Wn[(size_t)k * A.ldwn + ch], d);
       }
       const float dz = (a > 0.f) ? d : d * slope;
       g = fmaf(dz, (y[r] - mean) * rs, g);
     }
     const float G = block_sum(g);
-    if (t == 0) dgamma_part[(size_t)pair * C + ch] = G;
+    if (t == 0) A.dgamma_part[(size_t)pair * C + ch] = G;
   }
+}
+
+static int zero_fix_fill(ZeroFix& Z, const float* dA, const float* dlogit, const float* w_head, const void* out_planes, size_t out_plane,
+                         const void* in_planes, size_t in_plane, const float* W, int ldw, int Ci, const float* rstd, const float* gamma, int C,
+                         float* dgamma_part, const void* dY_next, size_t dyn_plane, const float* W_next, int ldw_next, int C_next) {
+  const bool from_next = dY_next && W_next && C_next > 0 && ldw_next >= C;
+  if ((!dA && !(dlogit && w_head) && !from_next) || !out_planes || !in_planes || !W || !rstd || !gamma || !dgamma_part) return DFEPE_ERR_INVALID_ARG;
+  if (C <= 0 || Ci <= 0 || ldw < Ci) return DFEPE_ERR_INVALID_ARG;
+  Z.dA = dA; Z.dlogit = dlogit; Z.w_head = w_head; Z.out_planes = static_cast<const bf16_t*>(out_planes); Z.out_stride = out_plane;
+  Z.in_planes = static_cast<const bf16_t*>(in_planes); Z.in_stride = in_plane; Z.W = W; Z.ldw = ldw; Z.Ci = Ci; Z.rstd = rstd; Z.gamma = gamma;
+  Z.C = C; Z.dgamma_part = dgamma_part; Z.dYn = static_cast<const bf16_t*>(dY_next); Z.dyn_stride = dyn_plane; Z.Wn = W_next; Z.ldwn = ldw_next;
+  Z.Cn = C_next;
+  return DFEPE_OK;
 }
 
 extern "C" int dfepe_est_dgamma_zero(const float* dA, const float* dlogit, const float* w_head, const void* out_planes, size_t out_plane,
                                      const void* in_planes, size_t in_plane, const float* W, int ldw, int Ci, const float* rstd,
                                      const float* gamma, float slope, int C, int N, long n_pairs, float* dgamma_part,
                                      const void* dY_next, size_t dyn_plane, const float* W_next, int ldw_next, int C_next, void* stream) {
-  const bool from_next = dY_next && W_next && C_next > 0 && ldw_next >= C;
-  if ((!dA && !(dlogit && w_head) && !from_next) || !out_planes || !in_planes || !W || !rstd || !gamma || !dgamma_part) return DFEPE_ERR_INVALID_ARG;
-  if (C <= 0 || N <= 0 || N > kFixMaxN || n_pairs < 0 || Ci <= 0 || ldw < Ci || !(slope > 0.f)) return DFEPE_ERR_INVALID_ARG;
+  if (N <= 0 || N > kFixMaxN || n_pairs < 0 || !(slope > 0.f)) return DFEPE_ERR_INVALID_ARG;
+  ZeroFixTab T{};
+  T.n = 1; T.slope = slope; T.N = N; T.n_pairs = n_pairs;
+  const int rc = zero_fix_fill(T.L[0], dA, dlogit, w_head, out_planes, out_plane, in_planes, in_plane, W, ldw, Ci, rstd, gamma, C, dgamma_part,
+                               dY_next, dyn_plane, W_next, ldw_next, C_next);
+  if (rc != DFEPE_OK) return rc;
   if (n_pairs == 0) return DFEPE_OK;
-  hipLaunchKernelGGL(est_dgamma_zero_kernel, dim3(C), dim3(256), 0, static_cast<hipStream_t>(stream), dA, dlogit, w_head,
-                     static_cast<const bf16_t*>(out_planes), out_plane, static_cast<const bf16_t*>(in_planes), in_plane, W, ldw, Ci, rstd, gamma,
-                     slope, C, N, n_pairs, dgamma_part, static_cast<const bf16_t*>(dY_next), dyn_plane, W_next, ldw_next, C_next);
+  hipLaunchKernelGGL(est_dgamma_zero_kernel, dim3(C, 1), dim3(256), 0, static_cast<hipStream_t>(stream), T);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+// the same for n_layers <= 8 layers in one launch (arrays indexed by layer; ldw = Ci, ldw_next = C): what a backward over few columns
+// does, where keeping every layer's dY alive to the end costs nothing
+extern "C" int dfepe_est_dgamma_zero_multi(int n_layers, const float* const* dA, const float* const* dlogit, const float* const* w_head,
+                                           const void* const* out_planes, const size_t* out_plane, const void* const* in_planes,
+                                           const size_t* in_plane, const float* const* W, const int* Ci, const float* const* rstd,
+                                           const float* const* gamma, const int* C, float* const* dgamma_part, const void* const* dY_next,
+                                           const size_t* dyn_plane, const float* const* W_next, const int* C_next, float slope, int N,
+                                           long n_pairs, void* stream) {
+  if (n_layers <= 0 || n_layers > kTabMax || N <= 0 || N > kFixMaxN || n_pairs < 0 || !(slope > 0.f)) return DFEPE_ERR_INVALID_ARG;
+  if (!dA || !dlogit || !w_head || !out_planes || !out_plane || !in_planes || !in_plane || !W || !Ci || !rstd || !gamma || !C || !dgamma_part ||
+      !dY_next || !dyn_plane || !W_next || !C_next)
+    return DFEPE_ERR_INVALID_ARG;
+  ZeroFixTab T{};
+  T.n = n_layers; T.slope = slope; T.N = N; T.n_pairs = n_pairs;
+  int cmax = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    const int rc = zero_fix_fill(T.L[l], dA[l], dlogit[l], w_head[l], out_planes[l], out_plane[l], in_planes[l], in_plane[l], W[l], Ci[l], Ci[l],
+                                 rstd[l], gamma[l], C[l], dgamma_part[l], dY_next[l], dyn_plane[l], W_next[l], C[l], C_next[l]);
+    if (rc != DFEPE_OK) return rc;
+    cmax = C[l] > cmax ? C[l] : cmax;
+  }
+  if (n_pairs == 0) return DFEPE_OK;
+  hipLaunchKernelGGL(est_dgamma_zero_kernel, dim3(cmax, n_layers), dim3(256), 0, static_cast<hipStream_t>(stream), T);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 

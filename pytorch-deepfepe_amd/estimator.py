@@ -95,6 +95,25 @@ def _wprep(Ws: Sequence[Tensor], want_wt: Sequence[bool], dev) -> Tuple[List[Ten
     return pf, pt, words
 
 
+def _dgamma_zero(fixes, slope: float, N: int, B: int) -> None:
+    """fixes: per layer (dA, dlogit, w_head, dY_next, dyn_plane, W_next, C_next, out_planes, out_plane, in_planes, in_plane, W32, Ci,
+    rstd, gamma, C, dgamma_part).  One layer: dfepe_est_dgamma_zero; several: dfepe_est_dgamma_zero_multi, one launch."""
+    lib = _lib.lib()
+    if len(fixes) == 1:
+        dA, dlg, wh, dYn, dynp, Wn, Cn, outp, outs, inp, ins, W32, Ci, rstd, g32, C, dg = fixes[0]
+        rc = lib.dfepe_est_dgamma_zero(_ptr(dA), _ptr(dlg), _ptr(wh), _ptr(outp), outs, _ptr(inp), ins, _ptr(W32), Ci, Ci, _ptr(rstd), _ptr(g32),
+                                       float(slope), C, N, B, _ptr(dg), _ptr(dYn), dynp, _ptr(Wn), C, Cn, _stream())
+        _lib.check(rc, "dfepe_est_dgamma_zero")
+        return
+    col = lambda i: [f[i] for f in fixes]
+    sizes = lambda i: (ctypes.c_size_t * len(fixes))(*col(i))
+    rc = lib.dfepe_est_dgamma_zero_multi(len(fixes), _ptr_array(col(0)), _ptr_array(col(1)), _ptr_array(col(2)), _ptr_array(col(7)), sizes(8),
+                                         _ptr_array(col(9)), sizes(10), _ptr_array(col(11)), _int_array(col(12)), _ptr_array(col(13)),
+                                         _ptr_array(col(14)), _int_array(col(15)), _ptr_array(col(16)), _ptr_array(col(3)), sizes(4),
+                                         _ptr_array(col(5)), _int_array(col(6)), float(slope), N, B, _stream())
+    _lib.check(rc, "dfepe_est_dgamma_zero_multi")
+
+
 def _colsum(segs: List[Tuple[Optional[Tensor], int, int]], dev) -> List[Tensor]:
     """[(src [rows, cols] or None, rows, cols)] -> the column sums, one launch per 32 segments (rows = 0: zeros), fixed order."""
     outs = [torch.empty(c, device=dev, dtype=torch.float32) for _, _, c in segs]
@@ -116,6 +135,8 @@ def _row_splits(pairs: int, c: int, n: int) -> int:
 
 
 FUSE_DGRAD = _os.environ.get("DFEPE_EST_FUSE_DGRAD", "1") != "0"  # A/B switch: the data gradient fused with the adjoint below it
+
+FIX_AT_END_BYTES = int(_os.environ.get("DFEPE_EST_FIX_AT_END_BYTES", 64 << 20))  # a backward whose dY planes together stay below this keeps them for one gamma == 0 launch at its end
 
 TN_BLOCKS = 768  # workgroups of a weight-gradient launch: three per CU in one residency round (130 registers, 32 KB of LDS each);
 # measured: 1024 (the kernel compiled for four per CU, 128 registers) 10.67 against 10.55 ms per estimator call
@@ -240,6 +261,8 @@ class _EstimatorFunction(torch.autograd.Function):
             # (dY, d gamma / d beta partials) of layer l when the fused data gradient of layer l + 1 already went through this layer's
             # InstanceNorm + LeakyReLU adjoint (dfepe_est_dgrad_in_bwd), plus what the gamma == 0 fix needs in place of dA
             pending = None
+            fixes: list = []
+            fix_at_end = n_hidden <= _TAB and cols * sum(int(a.shape[2]) for a in acts[1:]) * 4 <= FIX_AT_END_BYTES
             for l in range(n_hidden - 1, -1, -1):
                 W, bconv, gamma, beta = params[4 * l:4 * l + 4]
                 Co, Ci = W.shape[0], W.shape[1]
@@ -263,20 +286,20 @@ class _EstimatorFunction(torch.autograd.Function):
                                                     cols * Co, _ptr(rstds[l]), _ptr(g32), _ptr(b32), float(slope), Co, B, N, _ptr(dY), cols * Co,
                                                     _ptr(dg), _ptr(db), sp, _ptr(part), st)
                         _lib.check(rc, "dfepe_est_in_bwd_n")
-                    zero_src = (_ptr(dA), _ptr(dl if dA is None else None), _ptr(wh if dA is None else None), None, 0, None, 0, 0)
-                    keep_alive = None
+                    zero_src = (dA, dl if dA is None else None, wh if dA is None else None, None, 0, None, 0)
                 else:
                     dY, dg, db, dY_up, W_up = pending  # dA was never written: the fix recomputes its channel from dY_up W_up
-                    zero_src = (None, None, None, _ptr(dY_up), cols * W_up.shape[0], _ptr(W_up), W_up.shape[1], W_up.shape[0])
-                    keep_alive = (dY_up, W_up)
+                    zero_src = (None, None, None, dY_up, cols * W_up.shape[0], W_up, W_up.shape[0])
                 # channels whose gamma is exactly 0: x^ cannot be recovered from the stored activation; their d gamma is recomputed from
-                # the layer's input (idle workgroups otherwise; N beyond the fix kernel's 4096 keeps the documented zero)
+                # the layer's input (idle workgroups otherwise; N beyond the fix kernel's 4096 keeps the documented zero).  Over few
+                # columns (the reference's batch sizes) every layer's fix waits for ONE launch at the end -- its inputs, dY among
+                # them, stay alive until then; over many they are released layer by layer
                 if N <= 4096:
-                    rc = lib.dfepe_est_dgamma_zero(zero_src[0], zero_src[1], zero_src[2], _ptr(a_out), cols * Co, _ptr(a_in), cols * K, _ptr(W32),
-                                                   Ci, Ci, _ptr(rstds[l]), _ptr(g32), float(slope), Co, N, B, _ptr(dg), zero_src[3], zero_src[4],
-                                                   zero_src[5], zero_src[6], zero_src[7], st)
-                    _lib.check(rc, "dfepe_est_dgamma_zero")
-                del keep_alive
+                    fix = zero_src + (a_out, cols * Co, a_in, cols * K, W32, Ci, rstds[l], g32, Co, dg)
+                    if fix_at_end:
+                        fixes.append(fix)
+                    else:
+                        _dgamma_zero([fix], slope, N, B)
                 pending = None
                 # dW = dY^T X (split-K over the columns; the partials are a segment of the final reduction: deterministic)
                 slices = _slices_for(Co, K, cols)
@@ -308,6 +331,9 @@ class _EstimatorFunction(torch.autograd.Function):
                         rc = lib.dfepe_est_gemm_nt(_ptr(WTp), Mp * Co, _ptr(dY), cols * Co, Mp, cols, Co, 2, _ptr(dA), Mp, st)
                         _lib.check(rc, "dfepe_est_gemm_nt")
                 del dY
+            if fixes:
+                _dgamma_zero(fixes, slope, N, B)
+            del fixes
             sums = _colsum(segs, dev)
             grads[4 * n_hidden] = torch.stack(sums[:n_out]).reshape(Wh.shape).to(Wh.dtype) if n_out > 1 else sums[0].reshape(Wh.shape).to(Wh.dtype)
             for (slot, like), v in zip(sinks[n_out:], sums[n_out:]):

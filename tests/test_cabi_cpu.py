@@ -77,6 +77,7 @@ def test_argument_validation_without_launching(dfepe):
     assert L.dfepe_est_gemm_nt_f16(None, 0, None, 0, 64, 200, 32, None, None, 64, None) == -1
     assert L.dfepe_est_wprep(0, None, None, None, None, None, None, None, None) == -1 and L.dfepe_est_wprep(9, None, None, None, None, None, None, None, None) == -1
     assert L.dfepe_est_wprep_workspace_bytes(5) >= 5 * 4 and L.dfepe_est_wprep_workspace_bytes(0) == 0
+    assert L.dfepe_est_dgamma_zero_multi(0, *([None] * 17), 0.01, 100, 4, None) == -1 and L.dfepe_est_dgamma_zero_multi(2, *([None] * 17), 0.01, 100, 4, None) == -1
     assert L.dfepe_est_colsum(0, None, None, None, None, None) == -1 and L.dfepe_est_colsum(33, None, None, None, None, None) == -1
     assert L.dfepe_est_dgrad_in_bwd(None, 0, None, 0, 64, 200, 32, None, 0, None, None, None, 0.01, None, 0, None, None, None) == -1
     assert L.dfepe_est_in_bwd_n(None, None, None, None, 0, None, None, None, 0.01, 64, 2, 1000, None, 0, None, None, 1, None, None) == -1

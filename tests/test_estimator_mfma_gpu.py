@@ -492,12 +492,15 @@ def test_four_output_head_matches_float64(dfepe, N, B):
     assert float((fused(x.to(DEV)).detach() - yb.detach()).abs().max()) < 1e-4
 
 
-@pytest.mark.parametrize("N,B", [(100, 5), (37, 4)])
-def test_zero_gamma_channels_get_their_gradient(dfepe, N, B):
+@pytest.mark.parametrize("N,B,at_end", [(100, 5, True), (37, 4, True), (100, 5, False), (37, 4, False)])
+def test_zero_gamma_channels_get_their_gradient(dfepe, N, B, at_end, monkeypatch):
     """ADVICE r3 / VERDICT r4 7d: the adjoints recover x^ from the stored activation as (z - beta) / gamma, which an InstanceNorm
     weight of EXACTLY zero makes impossible (they take x^ = 0: d beta and dY right, d gamma wrong).  dfepe_est_dgamma_zero
     recomputes that channel's product from the layer's input; with it every gradient of a network with zeroed gammas -- in the first,
-    a middle and the last hidden layer -- meets the float64 stock module like any other (N = 100: fused epilogue; 37: generic)."""
+    a middle and the last hidden layer -- meets the float64 stock module like any other (N = 100: fused epilogue; 37: generic).
+    at_end: all layers' fixes in one launch at the end of the backward (what few columns get) / layer by layer (many columns)."""
+    if not at_end:
+        monkeypatch.setattr(dfepe.estimator, "FIX_AT_END_BYTES", 0)
     EE = dfepe.compat.ErrorEstimators
     stock = EE.ErrorEstimator(7)
     dfepe.synth.fill_params_deterministic(stock, seed=6)
