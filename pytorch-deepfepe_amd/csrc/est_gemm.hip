@@ -132,9 +132,15 @@ enum { EPI_F32 = 0, EPI_IN = 1, EPI_INBWD = 2 };
 #endif
 #ifndef DFEPE_NT_SPLIT
 #define DFEPE_NT_SPLIT 0  // 1: est_gemm_nt fills its LDS stage in two halves, each under the other half's MFMAs, instead of issue / wait /
-                          // multiply.  Measured (round 5, same box, twice): 8.18-8.20 against 8.15-8.16 ms per estimator call, forward alone
-                          // 2.42 against 2.45 ms -- the cycles between DMA issue and barrier (half of the K loop by the phase stamps of
-                          // scripts/ubench/est_phases.hip) are not an exposed load latency a wavefront could hide by itself
+                          // multiply -- in EVERY build.  Measured at full grids (round 5, B = 4096, same box, twice): 8.18-8.20 against
+                          // 8.15-8.16 ms per estimator call, forward alone 2.42 against 2.45 ms -- with two or three workgroups per CU
+                          // the cycles between DMA issue and barrier (half of the K loop by the phase stamps of
+                          // scripts/ubench/est_phases.hip) are already covered by the other workgroups' MFMAs.  At SMALL grids
+                          // (DFEPE_NT_SPLIT_SMALL: the AHEAD = 2 builds) it is worth 15-20 %: B = 8, rocprofv3 --stats: forward layers
+                          // 26.8 -> 22.7 us on average (1024 -> 512: 59.6 -> 47.0), the fused data gradient 31.2 -> 28.8
+#endif
+#ifndef DFEPE_NT_SPLIT_SMALL
+#define DFEPE_NT_SPLIT_SMALL 1  // ... in the small-grid builds (AHEAD = 2), where a workgroup has its CU to itself
 #endif
 #ifndef DFEPE_INBWD_DEPTH
 #define DFEPE_INBWD_DEPTH 4  // column tiles of the layer's output in flight in the fused adjoint's two passes
@@ -194,8 +200,15 @@ struct EpiArgs {
 // weights straight from global memory into a second register set + two LDS stages of the activations only, still two workgroups
 // per CU: 1.47 vs 1.43 ms with two planes (206 registers), spills with three.  The step is bound by instruction issue around the
 // MFMAs (DMA setup, fragment reads, barriers), not by an exposed load latency.
-template <int NPA, int NPB, int ORDER, int EPI, int FMT = FMT_BF16>
-__global__ void __launch_bounds__(256, (NPA == 2 && NPB == 2 && EPI == EPI_F32) ? DFEPE_NT2_BLOCKS : ((NPA == 2 && NPB == 2 && EPI == EPI_IN) ? DFEPE_FWD_BLOCKS : 2))
+// AHEAD: column tiles whose B fragments are fetched ahead of the MFMAs that consume them.  -1: what the (planes, epilogue) combination
+// is tuned for at a full grid -- 0 for the two-plane products compiled for three workgroups per CU (the third wavefront on the SIMD
+// covers the LDS latency), 1 otherwise.  2: the build for SMALL grids (the reference's batch sizes: 16-64 workgroups on 256 CUs):
+// a wavefront alone on its SIMD sees every LDS round trip (13 tiles x ~120 cycles against 96 cycles of MFMAs per tile with AHEAD = 0).
+constexpr int nt_blocks(int NPA, int NPB, int EPI, int AHEAD) {
+  return (AHEAD >= 0) ? 2 : ((NPA == 2 && NPB == 2 && EPI == EPI_F32) ? DFEPE_NT2_BLOCKS : ((NPA == 2 && NPB == 2 && EPI == EPI_IN) ? DFEPE_FWD_BLOCKS : 2));
+}
+template <int NPA, int NPB, int ORDER, int EPI, int FMT = FMT_BF16, int AHEAD = -1>
+__global__ void __launch_bounds__(256, nt_blocks(NPA, NPB, EPI, AHEAD))
 est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* __restrict__ B, size_t b_plane, int M, int ncols, int K,
                    const EpiArgs E) {
   constexpr int kABytes = NPA * BM * 64, kBBytes = NPB * BN * 64;
@@ -283,24 +296,18 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
     // latency of tile nt + 1 hides behind the twelve MFMAs of tile nt instead of stalling every tile
     // (the two-plane product compiled for three workgroups per CU has 168 registers: one fragment set, fetched per tile -- the
     // third wavefront on the SIMD covers the LDS latency the second set would)
-    constexpr bool kAhead = !(NPA == 2 && NPB == 2 && (EPI == EPI_F32 ? DFEPE_NT2_BLOCKS : (EPI == EPI_IN ? DFEPE_FWD_BLOCKS : 2)) > 2);
-    frag8 b[kAhead ? 2 : 1][NPB];
-    if (kAhead) {
+    constexpr int kD = (AHEAD >= 0) ? AHEAD : ((nt_blocks(NPA, NPB, EPI, AHEAD) > 2) ? 0 : 1);  // tiles fetched ahead
+    frag8 b[kD + 1][NPB];
+    auto fetch_b = [&](int nt, frag8 (&dst)[NPB]) {
 #pragma unroll
-      for (int p = 0; p < NPB; ++p) b[kAhead ? (kT0 & 1) : 0][p] = *reinterpret_cast<const frag8*>(lds + kABytes + ((p * BN + kT0 * 16 + c) * 4 + (g ^ fsw)) * 16);
-    }
+      for (int p = 0; p < NPB; ++p) dst[p] = *reinterpret_cast<const frag8*>(lds + kABytes + ((p * BN + nt * 16 + c) * 4 + (g ^ fsw)) * 16);
+    };
+#pragma unroll
+    for (int d = 0; d < kD; ++d)
+      if (kT0 + d < kT1) fetch_b(kT0 + d, b[(kT0 + d) % (kD + 1)]);
 #pragma unroll
     for (int nt = kT0; nt < kT1; ++nt) {
-      if (kAhead) {
-        if (nt + 1 < kT1) {
-#pragma unroll
-          for (int p = 0; p < NPB; ++p)
-            b[(nt + 1) & (kAhead ? 1 : 0)][p] = *reinterpret_cast<const frag8*>(lds + kABytes + ((p * BN + (nt + 1) * 16 + c) * 4 + (g ^ fsw)) * 16);
-        }
-      } else {
-#pragma unroll
-        for (int p = 0; p < NPB; ++p) b[0][p] = *reinterpret_cast<const frag8*>(lds + kABytes + ((p * BN + nt * 16 + c) * 4 + (g ^ fsw)) * 16);
-      }
+      if (nt + kD < kT1) fetch_b(nt + kD, b[(nt + kD) % (kD + 1)]);
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this tile's MFMAs (the scheduler would sink it to its first use)
       // smallest terms first; the two row tiles alternate, so that no MFMA waits for the one issued just before it
 #pragma unroll
@@ -311,7 +318,7 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
           if (i < NPA && j < NPB) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
-              acc[mt][nt] = mfma16<FMT>(a[mt][i], b[kAhead ? (nt & 1) : 0][j], acc[mt][nt]);
+              acc[mt][nt] = mfma16<FMT>(a[mt][i], b[nt % (kD + 1)][j], acc[mt][nt]);
           }
         }
       __builtin_amdgcn_sched_barrier(0);
@@ -325,7 +332,7 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
   using T0 = std::integral_constant<int, 0>;
   using TH = std::integral_constant<int, kHalf>;
   using TN = std::integral_constant<int, NT>;
-  if constexpr (DFEPE_NT_SPLIT) {
+  if constexpr (DFEPE_NT_SPLIT || (DFEPE_NT_SPLIT_SMALL && AHEAD == 2)) {
     // One LDS stage, filled in two halves: while the MFMAs of column tiles [0, 7) run, the DMA of tiles [7, 13) of the same K step is
     // in flight; while those of [7, 13) run, the DMA of the NEXT step's A rows and tiles [0, 7).  Two barriers per step, as before
     // (each one both releases a half for overwriting and publishes the other half's arrival).
@@ -1330,6 +1337,14 @@ __global__ void __launch_bounds__(1024) est_colsum_kernel(const ColSumTab T) {
 
 extern "C" int dfepe_est_points(void) { return kPts; }
 
+// fewer than two workgroups per CU: a wavefront is alone on its SIMD and the GEMM kernels take their AHEAD = 2 build (B fragments two
+// column tiles ahead of the MFMAs); DFEPE_EST_SMALL_GRID=0 / 1 forces the choice (A/B timing)
+static bool small_grid(const dim3& grid) {
+  static const char* force = getenv("DFEPE_EST_SMALL_GRID");
+  if (force) return force[0] == '1';
+  return (size_t)grid.x * grid.y < 512;
+}
+
 extern "C" int dfepe_est_absmax(const float* src, long n, unsigned* word, void* stream) {
   if (!src || !word || n < 0) return DFEPE_ERR_INVALID_ARG;
   if (n == 0) return DFEPE_OK;
@@ -1414,8 +1429,12 @@ extern "C" int dfepe_est_layer_fwd(const void* W, size_t w_plane, const void* X,
   E.gamma = gamma; E.beta = beta; E.eps = eps; E.slope = slope; E.planes = static_cast<bf16_t*>(planes_out); E.plane_stride = out_plane;
   E.rstd = rstd; E.absmax = absmax; E.planes_bwd = static_cast<bf16_t*>(planes_bwd); E.bwd_stride = bwd_plane;
   const dim3 grid((ncols + BSTEP - 1) / BSTEP, (M + BM - 1) / BM), block(256);
-  hipLaunchKernelGGL((est_gemm_nt_kernel<2, 2, 1, EPI_IN, FMT_F16>), grid, block, 0, static_cast<hipStream_t>(stream),
-                     static_cast<const bf16_t*>(W), w_plane, static_cast<const bf16_t*>(X), x_plane, M, ncols, K, E);
+  if (small_grid(grid))
+    hipLaunchKernelGGL((est_gemm_nt_kernel<2, 2, 1, EPI_IN, FMT_F16, 2>), grid, block, 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16_t*>(W), w_plane, static_cast<const bf16_t*>(X), x_plane, M, ncols, K, E);
+  else
+    hipLaunchKernelGGL((est_gemm_nt_kernel<2, 2, 1, EPI_IN, FMT_F16>), grid, block, 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16_t*>(W), w_plane, static_cast<const bf16_t*>(X), x_plane, M, ncols, K, E);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
@@ -1427,8 +1446,12 @@ extern "C" int dfepe_est_gemm_nt_f16(const void* A, size_t a_plane, const void* 
   EpiArgs E{};
   E.out = out; E.ldc = ldc; E.absmax = absmax;
   const dim3 grid((ncols + BSTEP - 1) / BSTEP, (M + BM - 1) / BM), block(256);
-  hipLaunchKernelGGL((est_gemm_nt_kernel<2, 2, 1, EPI_F32, FMT_F16>), grid, block, 0, static_cast<hipStream_t>(stream),
-                     static_cast<const bf16_t*>(A), a_plane, static_cast<const bf16_t*>(B), b_plane, M, ncols, K, E);
+  if (small_grid(grid))
+    hipLaunchKernelGGL((est_gemm_nt_kernel<2, 2, 1, EPI_F32, FMT_F16, 2>), grid, block, 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16_t*>(A), a_plane, static_cast<const bf16_t*>(B), b_plane, M, ncols, K, E);
+  else
+    hipLaunchKernelGGL((est_gemm_nt_kernel<2, 2, 1, EPI_F32, FMT_F16>), grid, block, 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16_t*>(A), a_plane, static_cast<const bf16_t*>(B), b_plane, M, ncols, K, E);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
@@ -1443,6 +1466,9 @@ extern "C" int dfepe_est_gemm_nt(const void* A, size_t a_plane, const void* B, s
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (n_planes == 3)
     hipLaunchKernelGGL((est_gemm_nt_kernel<3, 3, 2, EPI_F32>), grid, block, 0, st, static_cast<const bf16_t*>(A), a_plane,
+                       static_cast<const bf16_t*>(B), b_plane, M, ncols, K, E);
+  else if (small_grid(grid))
+    hipLaunchKernelGGL((est_gemm_nt_kernel<2, 2, 1, EPI_F32, FMT_BF16, 2>), grid, block, 0, st, static_cast<const bf16_t*>(A), a_plane,
                        static_cast<const bf16_t*>(B), b_plane, M, ncols, K, E);
   else
     hipLaunchKernelGGL((est_gemm_nt_kernel<2, 2, 1, EPI_F32>), grid, block, 0, st, static_cast<const bf16_t*>(A), a_plane,
@@ -1462,8 +1488,12 @@ extern "C" int dfepe_est_dgrad_in_bwd(const void* WT, size_t wt_plane, const voi
   E.gamma = gamma; E.beta = beta; E.slope = slope; E.planes = static_cast<bf16_t*>(dY); E.plane_stride = dy_plane;
   E.aout = static_cast<const bf16_t*>(aout); E.aout_stride = aout_plane; E.rstd_in = rstd; E.dgamma_part = dgamma_part; E.dbeta_part = dbeta_part;
   const dim3 grid((ncols + BSTEP - 1) / BSTEP, (M + BM - 1) / BM), block(256);
-  hipLaunchKernelGGL((est_gemm_nt_kernel<2, 2, 1, EPI_INBWD>), grid, block, 0, static_cast<hipStream_t>(stream),
-                     static_cast<const bf16_t*>(WT), wt_plane, static_cast<const bf16_t*>(dY_next), dyn_plane, M, ncols, K, E);
+  if (small_grid(grid))
+    hipLaunchKernelGGL((est_gemm_nt_kernel<2, 2, 1, EPI_INBWD, FMT_BF16, 2>), grid, block, 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16_t*>(WT), wt_plane, static_cast<const bf16_t*>(dY_next), dyn_plane, M, ncols, K, E);
+  else
+    hipLaunchKernelGGL((est_gemm_nt_kernel<2, 2, 1, EPI_INBWD>), grid, block, 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16_t*>(WT), wt_plane, static_cast<const bf16_t*>(dY_next), dyn_plane, M, ncols, K, E);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
