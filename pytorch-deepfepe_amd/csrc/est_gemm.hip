@@ -489,7 +489,7 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
       for (int j = 0; j < 8; ++j) {
         const float d = acc[j >> 2][nt][j & 3];
         const float e = live ? ((a[j] > 0.f) ? d : d * E.slope) : 0.f;
-        const float x = (unrelu(a[j]) - bt[j]) * ig[j];
+        const float x = unrelu(a[j]);  // z; x^ = (z - beta) / gamma is affine in it: sum dz x^ = (sum dz z - beta sum dz) / gamma, below
         acc[j >> 2][nt][j & 3] = e;
         if (nt < 6) { s1[0][j] += e; s2[0][j] = fmaf(e, x, s2[0][j]); }
         else if (nt > 6) { s1[1][j] += e; s2[1][j] = fmaf(e, x, s2[1][j]); }
@@ -512,7 +512,10 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { s1[p][j] = row16_sum(s1[p][j]); s2[p][j] = row16_sum(s2[p][j]); }
+      for (int j = 0; j < 8; ++j) {
+        s1[p][j] = row16_sum(s1[p][j]);
+        s2[p][j] = (row16_sum(s2[p][j]) - bt[j] * s1[p][j]) * ig[j];  // sum dz x^  (0 where gamma == 0, like est_in_bwd)
+      }
     if (chok && c == 0) {
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
@@ -537,8 +540,12 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
         const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          kk[p][j] = (j < 4 ? r0[j & 3] : r1[j & 3]) * (j < 4 ? g0[j & 3] : g1[j & 3]);
-          s1[p][j] *= inv_n; s2[p][j] *= inv_n;
+          // dY = k (dz - m1 - x^ m2), x^ = (z - beta) / gamma:  dY = k dz + c1 z + c0 -- two FMAs per element in pass B
+          const float k = (j < 4 ? r0[j & 3] : r1[j & 3]) * (j < 4 ? g0[j & 3] : g1[j & 3]);
+          const float m1 = s1[p][j] * inv_n, m2g = s2[p][j] * inv_n * ig[j];
+          kk[p][j] = k;
+          s2[p][j] = -k * m2g;                   // c1
+          s1[p][j] = k * (m2g * bt[j] - m1);     // c0
         }
       }
     }
@@ -559,9 +566,8 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
       float y[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float x = (unrelu(a[j]) - bt[j]) * ig[j];
-        const float m1 = first ? s1[0][j] : s1[1][j], m2 = first ? s2[0][j] : s2[1][j], k = first ? kk[0][j] : kk[1][j];
-        y[j] = k * (acc[j >> 2][nt][j & 3] - m1 - x * m2);
+        const float c0 = first ? s1[0][j] : s1[1][j], c1 = first ? s2[0][j] : s2[1][j], k = first ? kk[0][j] : kk[1][j];
+        y[j] = fmaf(k, acc[j >> 2][nt][j & 3], fmaf(c1, unrelu(a[j]), c0));
       }
       unsigned pl[2][4];
 #pragma unroll
