@@ -1,0 +1,60 @@
+"""Randomized sweep of the matrix-core estimator (csrc/est_gemm.hip through compat.FusedErrorEstimator) against the stock module in
+float64: batch sizes 1-40 (odd pair counts: the half-empty last block of the 200-column tiles; small grids: the AHEAD = 2 builds),
+N = 100 (fused epilogues, fused data gradient) and other N (plain product + norm kernels), 4 / 7 input channels, one- and
+four-channel heads, with and without an input gradient.  A case counts as a FAILURE when the float64 run keeps every pre-activation
+> 3e-6 away from the LeakyReLU kink (closer, any fp32 evaluation may take the other branch) and still the logits are > 1e-5 or a
+gradient > 2e-4 (relative 2-norm) from it.   python scripts/stress_estimator.py [cases [seed]]"""
+import importlib, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+d = importlib.import_module("pytorch-deepfepe_amd")
+EE = d.compat.ErrorEstimators
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+g = torch.Generator().manual_seed(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+fails, flips, worst_l, worst_g = 0, 0, 0.0, 0.0
+for it in range(cases):
+    cin = [4, 7][int(torch.randint(0, 2, (1,), generator=g))]
+    n_out = [1, 1, 1, 4][int(torch.randint(0, 4, (1,), generator=g))]
+    N = [100, 100, 100, 37, 250, 1000][int(torch.randint(0, 6, (1,), generator=g))]
+    B = int(torch.randint(1, 41 if N <= 250 else 7, (1,), generator=g))
+    xgrad = bool(torch.randint(0, 2, (1,), generator=g))
+    pseed = int(torch.randint(0, 1000, (1,), generator=g))
+    stock = EE.ErrorEstimator(cin, output_size=n_out)
+    d.synth.fill_params_deterministic(stock, seed=pseed)
+    fused = EE.FusedErrorEstimator(cin, output_size=n_out).cuda()
+    fused.load_state_dict(stock.state_dict())
+    stock = stock.double()
+    margin = [float("inf")]
+    hooks = [m.register_forward_hook(lambda _m, _i, o: margin.__setitem__(0, min(margin[0], float(o.detach().abs().min()))))
+             for m in stock.fw if isinstance(m, torch.nn.InstanceNorm1d)]
+    x = torch.rand(B, cin, N, generator=g) * 2 - 0.5
+    G = torch.randn(B, n_out, N, generator=g)
+    xa = x.double().requires_grad_(xgrad)
+    xb = x.cuda().requires_grad_(xgrad)
+    ya, yb = stock(xa), fused(xb)
+    (ya * G.double()).sum().backward()
+    (yb * G.cuda()).sum().backward()
+    el = float((yb.detach().cpu().double() - ya.detach()).abs().max())
+    pa, pb = dict(stock.named_parameters()), dict(fused.named_parameters())
+    pairs = [(n, pb[n].grad.cpu().double(), pa[n].grad) for n in pa] + ([("input", xb.grad.cpu().double(), xa.grad)] if xgrad else [])
+    eg, who = 0.0, ""
+    for n, got, ref in pairs:
+        if float(ref.norm()) < 1e-9:
+            continue
+        e = float((got - ref).norm() / ref.norm())
+        if e > eg: eg, who = e, n
+    safe = margin[0] > 3e-6
+    bad = (el > 1e-5 or eg > 2e-4 or not torch.isfinite(yb).all())
+    if bad and safe: fails += 1
+    if bad and not safe: flips += 1
+    if safe: worst_l, worst_g = max(worst_l, el), max(worst_g, eg)
+    ref32 = ""
+    if bad:  # what the STOCK module evaluated in fp32 on the same GPU does on this case (the kink is not this library's)
+        s32 = EE.ErrorEstimator(cin, output_size=n_out).cuda()
+        s32.load_state_dict({k: v.float() for k, v in stock.state_dict().items()})
+        xc = x.cuda().requires_grad_(xgrad)
+        (s32(xc) * G.cuda()).sum().backward()
+        p32 = dict(s32.named_parameters())
+        e32 = max(float((p32[n].grad.cpu().double() - pa[n].grad).norm() / pa[n].grad.norm()) for n in pa if float(pa[n].grad.norm()) >= 1e-9)
+        ref32 = f"; stock fp32 parameter gradients: {e32:.1e}"
+    if bad: print(f"case {it}: cin {cin} out {n_out} B {B} N {N} xgrad {xgrad} pseed {pseed}: logits {el:.1e} grad {eg:.1e} ({who}) margin {margin[0]:.1e} {'FAIL' if safe else 'kink'}{ref32}", flush=True)
+print(f"{cases} cases: {fails} failures, {flips} kink cases (margin <= 3e-6) beyond the bounds; worst over the safe cases: logits {worst_l:.1e}, gradient {worst_g:.1e}")
