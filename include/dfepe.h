@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFEPE_VERSION 152 /* 0.5.0 */
+#define DFEPE_VERSION 153 /* 0.5.0 */
 
 #define DFEPE_OK 0
 #define DFEPE_ERR_INVALID_ARG (-1) /* null pointer, non-positive size, bad flag combination   */
@@ -455,6 +455,18 @@ int dfepe_inorm_lrelu_bwd(const float *Y, const float *gA, const float *gamma, c
  *                        dfepe_est_dgrad_in_bwd, which never writes dA -- is recomputed for the channel from dY_next planes [2] of
  *                        [ncols][C_next] and the next layer's fp32 weights W_next [C_next][ldw_next].  dfepe_est_dgamma_zero_multi: the
  *                        same for n_layers <= 8 layers in ONE launch (host arrays indexed by layer; ldw = Ci, ldw_next = C)
+ *   dfepe_est_forward / dfepe_est_backward  (version 153) ONE call per estimator pass: the whole stack of n_hidden <= 8 layers and its
+ *                        one-channel head through the entry points above, in the order the host code used to issue them (bit-identical
+ *                        results).  x [B][C0][N], W[l] [Co[l]][Ci[l]] (Ci[l] = Co[l-1], Ci[0] = C0; Co % 32 == 0), gamma / beta [l]
+ *                        [Co[l]], w_head [Co of the last layer], b_head [1] or null: fp32, contiguous, host arrays of device pointers.
+ *                        The caller brings the memory: `saved` (dfepe_est_saved_bytes; null for a forward no backward will follow; what
+ *                        the backward reads: every layer's bf16 planes, reciprocal deviations, transposed weight planes -- need_gx also
+ *                        the first layer's, for the gradient w.r.t. x), a transient workspace per pass (dfepe_est_*_workspace_bytes;
+ *                        16-byte aligned, contents irrelevant) and the outputs: logits [B * N]; g_W[l] [Co][Ci], g_bias[l] [Co] (exact
+ *                        zeros: the convolution bias cancels in the normalisation), g_gamma[l], g_beta[l] [Co], g_w_head, g_b_head
+ *                        (or null), gx [B][C0][N] (or null).  N = dfepe_est_points() takes the fused epilogues, any other N >= 2 the
+ *                        plain products.  Why: at the reference's batch sizes the HOST was the limiter of the eager training step
+ *                        (~30 launches and ~40 allocations per pass from Python)
  *   dfepe_est_head_fwd   logits[col] = sum_c w[c] a[col][c] + bias[0]   (the last Conv1d(C -> 1)); a: the forward's planes [2] (fp16)
  *   dfepe_est_head_dw    part[blocks][C] = partial sums of d w = sum_col dlogit[col] a[col][c]; a: the backward's planes [2] (bf16)
  */
@@ -499,6 +511,16 @@ int dfepe_est_norm_fwd(const float *Y, int ldy, int C, long n_pairs, int N, cons
 int dfepe_est_in_bwd_n(const float *dA, const float *dlogit, const float *w_head, const void *planes, size_t plane_stride,
                        const float *rstd, const float *gamma, const float *beta, float slope, int C, long n_pairs, int N, void *dY,
                        size_t dy_plane, float *dgamma_part, float *dbeta_part, int splits, float *part, void *stream);
+size_t dfepe_est_saved_bytes(int n_hidden, const int *Co, const int *Ci, long B, int C0, int N, int need_gx);
+size_t dfepe_est_forward_workspace_bytes(int n_hidden, const int *Co, const int *Ci, long B, int C0, int N, int keep);
+size_t dfepe_est_backward_workspace_bytes(int n_hidden, const int *Co, const int *Ci, long B, int C0, int N, int need_gx);
+int dfepe_est_forward(const float *x, long B, int C0, int N, int n_hidden, const float *const *W, const float *const *gamma,
+                      const float *const *beta, const int *Co, const int *Ci, const float *w_head, const float *b_head, float eps,
+                      float slope, void *saved, int need_gx, void *workspace, float *logits, void *stream);
+int dfepe_est_backward(const float *g_logits, long B, int C0, int N, int n_hidden, const float *const *W, const float *const *gamma,
+                       const float *const *beta, const int *Co, const int *Ci, const float *w_head, float slope, const void *saved,
+                       void *workspace, float *const *g_W, float *const *g_bias, float *const *g_gamma, float *const *g_beta,
+                       float *g_w_head, float *g_b_head, float *gx, void *stream);
 int dfepe_est_head_fwd(const void *planes, size_t plane_stride, int C, int ncols, const float *w, const float *bias, float *logits,
                        void *stream);
 int dfepe_est_head_dw(const void *planes, size_t plane_stride, int C, int ncols, int blocks, const float *dlogit, float *part,

@@ -1720,3 +1720,359 @@ extern "C" int dfepe_est_head_dw(const void* planes, size_t plane_stride, int C,
                      plane_stride, C, ncols, cpb, dlogit, part);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
+
+// =====================================================================================================================================
+// One estimator pass per call (round 5): dfepe_est_forward / dfepe_est_backward run the whole Conv1d -> InstanceNorm -> LeakyReLU stack and
+// its head (one output channel) through the entry points above, in the order the host code of estimator.py used to issue them -- the
+// same kernels on the same data, so the results are bit-identical.  Why: at the reference's batch sizes the HOST is the limiter of the
+// eager training step (Python spent ~0.27 ms per forward and more per backward on ~30 launches, ~40 allocations and their bookkeeping:
+// more than the GPU needs for the whole model's step).  The caller brings three buffers -- `saved` (what the backward reads: the layers'
+// bf16 planes, reciprocal deviations, transposed weight planes), a transient workspace per pass, the outputs -- whose sizes the
+// *_bytes functions give; nothing is allocated here.
+namespace {
+
+constexpr size_t kAlign = 256;
+inline size_t up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
+inline int pad32(int c) { return (c + 31) / 32 * 32; }
+
+struct PassDims {
+  int n;              // hidden layers
+  int Co[kTabMax], Ci[kTabMax], K[kTabMax];
+  long B; int N; long cols;
+  int C0, K0, Cmax, Kmax;
+  bool fused;         // N == kPts
+};
+int pass_dims(PassDims& D, int n_hidden, const int* Co, const int* Ci, long B, int C0, int N) {
+  if (n_hidden <= 0 || n_hidden > kTabMax || !Co || !Ci || B <= 0 || N < 2 || C0 <= 0 || B * (long)N >= (1L << 31)) return DFEPE_ERR_INVALID_ARG;
+  D.n = n_hidden; D.B = B; D.N = N; D.cols = B * (long)N; D.C0 = C0; D.K0 = pad32(C0); D.Cmax = 0; D.Kmax = 0; D.fused = (N == kPts);
+  for (int l = 0; l < n_hidden; ++l) {
+    if (Co[l] <= 0 || (Co[l] & 31) || Ci[l] != (l ? Co[l - 1] : C0)) return DFEPE_ERR_INVALID_ARG;
+    D.Co[l] = Co[l]; D.Ci[l] = Ci[l]; D.K[l] = pad32(Ci[l]);
+    D.Cmax = Co[l] > D.Cmax ? Co[l] : D.Cmax; D.Kmax = D.K[l] > D.Kmax ? D.K[l] : D.Kmax;
+  }
+  return DFEPE_OK;
+}
+int row_splits(long pairs, int c, int n) {  // estimator.py: _row_splits
+  const long blocks = pairs * ((c + 63) / 64);
+  if (blocks >= 512 || n < 256) return 1;
+  long s = (1024 + blocks - 1) / blocks;
+  s = s < n / 128 ? s : n / 128;
+  s = s < 64 ? s : 64;
+  return (int)(s > 1 ? s : 1);
+}
+int slices_for(int cout, int cin, long cols) {  // estimator.py: _slices_for (TN_BLOCKS = 768)
+  const int tiles = ((cout + 127) / 128) * ((cin + 127) / 128);
+  long s = 768 / tiles;
+  s = s < 512 ? s : 512;
+  s = s < cols / 256 ? s : cols / 256;
+  s = s > 1 ? s : 1;
+  return (int)(s >= 8 ? s - s % 8 : s);
+}
+
+// what the backward reads, laid out in `saved`
+struct SavedLayout {
+  size_t words, act[kTabMax + 1], rstd[kTabMax], wt[kTabMax], total;
+};
+SavedLayout saved_layout(const PassDims& D, bool need_gx) {
+  SavedLayout S{};
+  size_t at = 0;
+  S.words = at; at += up(sizeof(unsigned) * kTabMax);
+  S.act[0] = at; at += up((size_t)2 * D.cols * D.K0 * 2);
+  for (int l = 0; l < D.n; ++l) { S.act[l + 1] = at; at += up((size_t)2 * D.cols * D.Co[l] * 2); }
+  for (int l = 0; l < D.n; ++l) { S.rstd[l] = at; at += up((size_t)D.B * D.Co[l] * 4); }
+  for (int l = 0; l < D.n; ++l) {
+    S.wt[l] = at;
+    if (l > 0 || need_gx) at += up((size_t)2 * D.K[l] * D.Co[l] * 2);
+  }
+  S.total = at;
+  return S;
+}
+struct FwdLayout {
+  size_t absws, wf[kTabMax], xh, ping, pong, rstd_scratch, Y, npart, words, total;
+};
+FwdLayout fwd_layout(const PassDims& D, bool keep) {
+  FwdLayout F{};
+  size_t at = 0;
+  F.absws = at; at += up(dfepe_est_wprep_workspace_bytes(D.n));
+  F.words = at; at += up(sizeof(unsigned) * kTabMax);  // used when nothing is kept (no `saved`)
+  for (int l = 0; l < D.n; ++l) { F.wf[l] = at; at += up((size_t)2 * D.Co[l] * D.K[l] * 2); }
+  F.xh = at; at += up((size_t)2 * D.cols * D.K0 * 2);
+  F.ping = at; at += up((size_t)2 * D.cols * D.Cmax * 2);
+  F.pong = at; at += up((size_t)2 * D.cols * D.Cmax * 2);
+  F.rstd_scratch = at; if (!keep) at += up((size_t)D.B * D.Cmax * 4);
+  F.Y = at; F.npart = at;
+  if (!D.fused) { at += up((size_t)D.cols * D.Cmax * 4); F.npart = at; at += up((size_t)D.B * 64 * 2 * D.Cmax * 4); }
+  F.total = at;
+  return F;
+}
+struct BwdLayout {
+  size_t hpart, bpart, dY[kTabMax], dg[kTabMax], db[kTabMax], partw[kTabMax], dA, npart, wtmp, total;
+  int slices[kTabMax];
+  bool fix_at_end;
+};
+BwdLayout bwd_layout(const PassDims& D, bool need_gx) {
+  BwdLayout L{};
+  size_t at = 0;
+  L.hpart = at; at += up((size_t)512 * D.Co[D.n - 1] * 4);
+  L.bpart = at; at += up((size_t)512 * 4);
+  size_t dy_total = 0;
+  for (int l = 0; l < D.n; ++l) dy_total += (size_t)D.cols * D.Co[l] * 4;
+  // (fused path only: the plain data gradients of the generic path share ONE dA buffer, which a fix deferred to the end would find overwritten)
+  L.fix_at_end = D.fused && dy_total <= ((size_t)64 << 20);
+  if (L.fix_at_end) {
+    for (int l = 0; l < D.n; ++l) { L.dY[l] = at; at += up((size_t)2 * D.cols * D.Co[l] * 2); }
+  } else {  // two buffers taking turns: dY of layer l is read while dY of layer l - 1 is written
+    const size_t a = at, b = at + up((size_t)2 * D.cols * D.Cmax * 2);
+    at = b + up((size_t)2 * D.cols * D.Cmax * 2);
+    for (int l = D.n - 1, k = 0; l >= 0; --l, ++k) L.dY[l] = (k & 1) ? b : a;
+  }
+  for (int l = 0; l < D.n; ++l) {
+    L.dg[l] = at; at += up((size_t)D.B * D.Co[l] * 4);
+    L.db[l] = at; at += up((size_t)D.B * D.Co[l] * 4);
+    L.slices[l] = slices_for(D.Co[l], D.K[l], D.cols);
+    L.partw[l] = at; at += up((size_t)L.slices[l] * D.Co[l] * D.K[l] * 4);
+  }
+  L.dA = at;
+  if (!D.fused || need_gx) at += up((size_t)D.cols * (D.fused ? D.K0 : D.Kmax) * 4);
+  L.npart = at; if (!D.fused) at += up((size_t)D.B * 64 * 2 * D.Cmax * 4);
+  L.wtmp = at; if (D.K0 != D.C0) at += up((size_t)D.Co[0] * D.K0 * 4);
+  L.total = at;
+  return L;
+}
+
+// x [B][C0][N] fp32 -> planes [cols = B N][K0]: two fp16 (what the first layer multiplies by) and, if wanted, two bf16 (what its
+// weight gradient multiplies by); channels C0..K0 zero
+__global__ void __launch_bounds__(256)
+est_input_split_kernel(const float* __restrict__ x, long B, int C0, int N, int K0, bf16_t* __restrict__ ph, size_t h_stride,
+                       bf16_t* __restrict__ pb, size_t b_stride) {
+  const long cols = B * (long)N;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;  // (channel pair, column), column fastest: the reads of x coalesce
+  const long col = t % cols;
+  const int ch = (int)(t / cols) * 2;
+  if (ch >= K0) return;
+  const long b = col / N, n = col - b * N;
+  const float v0 = (ch < C0) ? x[((size_t)b * C0 + ch) * N + n] : 0.f, v1 = (ch + 1 < C0) ? x[((size_t)b * C0 + ch + 1) * N + n] : 0.f;
+  unsigned p0, p1;
+  split2h(v0, v1, p0, p1);
+  const size_t at = kb_index((size_t)col, ch, (size_t)cols);
+  *reinterpret_cast<unsigned*>(ph + at) = p0;
+  *reinterpret_cast<unsigned*>(ph + h_stride + at) = p1;
+  if (pb) {
+    split2(v0, v1, p0, p1);
+    *reinterpret_cast<unsigned*>(pb + at) = p0;
+    *reinterpret_cast<unsigned*>(pb + b_stride + at) = p1;
+  }
+}
+// gx[b][c][n] = dA[(b N + n) ld + c], c < C0
+__global__ void __launch_bounds__(256) est_gx_kernel(const float* __restrict__ dA, int ld, long B, int C0, int N, float* __restrict__ gx) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * (long)C0 * N) return;
+  const long n = i % N, c = (i / N) % C0, b = i / ((long)N * C0);
+  gx[i] = dA[((size_t)b * N + n) * ld + c];
+}
+// part[block] = sum of dlogit over the block's columns (the head bias gradient's partial sums, same blocks as est_head_dw)
+__global__ void __launch_bounds__(256) est_head_db_kernel(const float* __restrict__ dlogit, int ncols, int cols_per_block, float* __restrict__ part) {
+  __shared__ float red[4];
+  const int c0 = (int)blockIdx.x * cols_per_block;
+  int c1 = c0 + cols_per_block;
+  c1 = c1 < ncols ? c1 : ncols;
+  float s = 0.f;
+  for (int c = c0 + (int)threadIdx.x; c < c1; c += 256) s += dlogit[c];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+}  // namespace
+
+#define EST_TRY(call) do { const int rc_ = (call); if (rc_ != DFEPE_OK) return rc_; } while (0)
+
+extern "C" size_t dfepe_est_saved_bytes(int n_hidden, const int* Co, const int* Ci, long B, int C0, int N, int need_gx) {
+  PassDims D;
+  if (pass_dims(D, n_hidden, Co, Ci, B, C0, N) != DFEPE_OK) return 0;
+  return saved_layout(D, need_gx != 0).total;
+}
+extern "C" size_t dfepe_est_forward_workspace_bytes(int n_hidden, const int* Co, const int* Ci, long B, int C0, int N, int keep) {
+  PassDims D;
+  if (pass_dims(D, n_hidden, Co, Ci, B, C0, N) != DFEPE_OK) return 0;
+  return fwd_layout(D, keep != 0).total;
+}
+extern "C" size_t dfepe_est_backward_workspace_bytes(int n_hidden, const int* Co, const int* Ci, long B, int C0, int N, int need_gx) {
+  PassDims D;
+  if (pass_dims(D, n_hidden, Co, Ci, B, C0, N) != DFEPE_OK) return 0;
+  return bwd_layout(D, need_gx != 0).total;
+}
+
+// logits [cols] = head(stack(x)); saved != null: everything dfepe_est_backward needs is left there (need_gx: also the first layer's
+// transposed weight planes).  x [B][C0][N], W[l] [Co][Ci], gamma / beta [l] [Co], w_head [Co of the last layer], b_head [1] or null: fp32.
+extern "C" int dfepe_est_forward(const float* x, long B, int C0, int N, int n_hidden, const float* const* W, const float* const* gamma,
+                                 const float* const* beta, const int* Co, const int* Ci, const float* w_head, const float* b_head, float eps,
+                                 float slope, void* saved, int need_gx, void* workspace, float* logits, void* stream) {
+  PassDims D;
+  EST_TRY(pass_dims(D, n_hidden, Co, Ci, B, C0, N));
+  if (!x || !W || !gamma || !beta || !w_head || !workspace || !logits) return DFEPE_ERR_INVALID_ARG;
+  if (((uintptr_t)workspace & 15) || ((uintptr_t)saved & 15)) return DFEPE_ERR_INVALID_ARG;
+  const bool keep = saved != nullptr;
+  const SavedLayout S = saved_layout(D, need_gx != 0);
+  const FwdLayout F = fwd_layout(D, keep);
+  char* ws = static_cast<char*>(workspace);
+  char* sv = static_cast<char*>(saved);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long cols = D.cols;
+  unsigned* words = reinterpret_cast<unsigned*>(keep ? sv + S.words : ws + F.words);
+  // the input's planes
+  {
+    const long threads = cols * (D.K0 / 2);
+    hipLaunchKernelGGL(est_input_split_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, x, B, C0, N, D.K0,
+                       reinterpret_cast<bf16_t*>(ws + F.xh), (size_t)cols * D.K0, keep ? reinterpret_cast<bf16_t*>(sv + S.act[0]) : nullptr,
+                       (size_t)cols * D.K0);
+    if (hipGetLastError() != hipSuccess) return DFEPE_ERR_HIP;
+  }
+  // every layer's weights: scales, fp16 planes, transposed bf16 planes for the backward
+  {
+    void* pf[kTabMax]; void* pt[kTabMax];
+    for (int l = 0; l < D.n; ++l) { pf[l] = ws + F.wf[l]; pt[l] = (keep && (l > 0 || need_gx)) ? sv + S.wt[l] : nullptr; }
+    EST_TRY(dfepe_est_wprep(D.n, W, Co, Ci, pf, pt, words, ws + F.absws, stream));
+  }
+  const char* act = ws + F.xh;
+  for (int l = 0; l < D.n; ++l) {
+    const int C = D.Co[l], K = D.K[l];
+    char* out = ws + ((l & 1) ? F.pong : F.ping);
+    void* out_b = keep ? sv + S.act[l + 1] : nullptr;
+    float* rstd = reinterpret_cast<float*>(keep ? sv + S.rstd[l] : ws + F.rstd_scratch);
+    if (D.fused) {
+      EST_TRY(dfepe_est_layer_fwd(ws + F.wf[l], (size_t)C * K, act, (size_t)cols * K, C, (int)cols, K, words + l, gamma[l], beta[l], eps, slope, out,
+                                  (size_t)cols * C, out_b, (size_t)cols * C, rstd, stream));
+    } else {
+      float* Y = reinterpret_cast<float*>(ws + F.Y);
+      EST_TRY(dfepe_est_gemm_nt_f16(ws + F.wf[l], (size_t)C * K, act, (size_t)cols * K, C, (int)cols, K, words + l, Y, C, stream));
+      const int sp = row_splits(B, C, N);
+      EST_TRY(dfepe_est_norm_fwd(Y, C, C, B, N, gamma[l], beta[l], eps, slope, out, (size_t)cols * C, out_b, (size_t)cols * C, rstd, sp,
+                                 sp > 1 ? reinterpret_cast<float*>(ws + F.npart) : nullptr, stream));
+    }
+    act = out;
+  }
+  return dfepe_est_head_fwd(act, (size_t)cols * D.Co[D.n - 1], D.Co[D.n - 1], (int)cols, w_head, b_head, logits, stream);
+}
+
+// every gradient of one dfepe_est_forward(saved != null): g_W[l] [Co][Ci], g_bias[l] [Co] (zeros: the bias cancels in the
+// normalisation), g_gamma[l], g_beta[l] [Co], g_w_head [C], g_b_head [1] or null, gx [B][C0][N] or null (needs need_gx at the forward)
+extern "C" int dfepe_est_backward(const float* g_logits, long B, int C0, int N, int n_hidden, const float* const* W, const float* const* gamma,
+                                  const float* const* beta, const int* Co, const int* Ci, const float* w_head, float slope, const void* saved,
+                                  void* workspace, float* const* g_W, float* const* g_bias, float* const* g_gamma, float* const* g_beta,
+                                  float* g_w_head, float* g_b_head, float* gx, void* stream) {
+  PassDims D;
+  EST_TRY(pass_dims(D, n_hidden, Co, Ci, B, C0, N));
+  if (!g_logits || !W || !gamma || !beta || !w_head || !saved || !workspace || !g_W || !g_bias || !g_gamma || !g_beta || !g_w_head)
+    return DFEPE_ERR_INVALID_ARG;
+  if (((uintptr_t)workspace & 15) || ((uintptr_t)saved & 15)) return DFEPE_ERR_INVALID_ARG;
+  const bool need_gx = gx != nullptr;
+  const SavedLayout S = saved_layout(D, need_gx);
+  const BwdLayout L = bwd_layout(D, need_gx);
+  char* ws = static_cast<char*>(workspace);
+  const char* sv = static_cast<const char*>(saved);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long cols = D.cols;
+  const int n = D.n, Clast = D.Co[n - 1];
+  const float* src[kSegMax]; float* dst[kSegMax]; int rows[kSegMax], ccols[kSegMax];
+  int nseg = 0;
+  auto seg = [&](const float* s, int r, int c, float* d) { src[nseg] = s; rows[nseg] = r; ccols[nseg] = c; dst[nseg] = d; ++nseg; };
+  auto flush = [&]() -> int {
+    if (nseg == 0) return DFEPE_OK;
+    const int rc = dfepe_est_colsum(nseg, src, rows, ccols, dst, stream);
+    nseg = 0;
+    return rc;
+  };
+  // head
+  const int nblk = 512;
+  float* hpart = reinterpret_cast<float*>(ws + L.hpart);
+  EST_TRY(dfepe_est_head_dw(sv + S.act[n], (size_t)cols * Clast, Clast, (int)cols, nblk, g_logits, hpart, stream));
+  seg(hpart, nblk, Clast, g_w_head);
+  if (g_b_head) {
+    float* bpart = reinterpret_cast<float*>(ws + L.bpart);
+    hipLaunchKernelGGL(est_head_db_kernel, dim3(nblk), dim3(256), 0, st, g_logits, (int)cols, (int)((cols + nblk - 1) / nblk), bpart);
+    if (hipGetLastError() != hipSuccess) return DFEPE_ERR_HIP;
+    seg(bpart, nblk, 1, g_b_head);
+  }
+  // gamma == 0 fixes: gathered for one launch at the end, or issued layer by layer (see bwd_layout)
+  const float* f_dA[kTabMax]; const float* f_dl[kTabMax]; const float* f_wh[kTabMax]; const void* f_out[kTabMax]; size_t f_outs[kTabMax];
+  const void* f_in[kTabMax]; size_t f_ins[kTabMax]; const float* f_W[kTabMax]; int f_Ci[kTabMax]; const float* f_rstd[kTabMax];
+  const float* f_gamma[kTabMax]; int f_C[kTabMax]; float* f_dg[kTabMax]; const void* f_dYn[kTabMax]; size_t f_dyns[kTabMax];
+  const float* f_Wn[kTabMax]; int f_Cn[kTabMax];
+  int nfix = 0;
+  float* dA = reinterpret_cast<float*>(ws + L.dA);
+  bool pending = false;  // dY / dg / db of the current layer already written by the fused data gradient of the layer above
+  bool have_dA = false;
+  for (int l = n - 1; l >= 0; --l) {
+    const int C = D.Co[l], K = D.K[l];
+    const void* a_out = sv + S.act[l + 1];
+    const void* a_in = sv + S.act[l];
+    const float* rstd = reinterpret_cast<const float*>(sv + S.rstd[l]);
+    char* dY = ws + L.dY[l];
+    float* dg = reinterpret_cast<float*>(ws + L.dg[l]);
+    float* db = reinterpret_cast<float*>(ws + L.db[l]);
+    const float* up_dA = have_dA ? dA : nullptr;
+    const float* up_dl = (l == n - 1) ? g_logits : nullptr;
+    const float* up_wh = (l == n - 1) ? w_head : nullptr;
+    if (!pending) {
+      if (D.fused) {
+        EST_TRY(dfepe_est_in_bwd(up_dA, up_dl, up_wh, a_out, (size_t)cols * C, rstd, gamma[l], beta[l], slope, C, (int)cols, dY, (size_t)cols * C, dg,
+                                 db, stream));
+      } else {
+        const int sp = row_splits(B, C, N);
+        EST_TRY(dfepe_est_in_bwd_n(up_dA, up_dl, up_wh, a_out, (size_t)cols * C, rstd, gamma[l], beta[l], slope, C, B, N, dY, (size_t)cols * C, dg, db,
+                                   sp, sp > 1 ? reinterpret_cast<float*>(ws + L.npart) : nullptr, stream));
+      }
+    }
+    if (N <= kFixMaxN) {
+      const int i = nfix;
+      f_dA[i] = pending ? nullptr : up_dA; f_dl[i] = pending ? nullptr : up_dl; f_wh[i] = pending ? nullptr : up_wh;
+      f_out[i] = a_out; f_outs[i] = (size_t)cols * C; f_in[i] = a_in; f_ins[i] = (size_t)cols * K; f_W[i] = W[l]; f_Ci[i] = D.Ci[l];
+      f_rstd[i] = rstd; f_gamma[i] = gamma[l]; f_C[i] = C; f_dg[i] = dg;
+      f_dYn[i] = pending ? ws + L.dY[l + 1] : nullptr; f_dyns[i] = pending ? (size_t)cols * D.Co[l + 1] : 0;
+      f_Wn[i] = pending ? W[l + 1] : nullptr; f_Cn[i] = pending ? D.Co[l + 1] : 0;
+      if (L.fix_at_end && n > 1) ++nfix;
+      else
+        EST_TRY(dfepe_est_dgamma_zero(f_dA[i], f_dl[i], f_wh[i], f_out[i], f_outs[i], f_in[i], f_ins[i], f_W[i], f_Ci[i], f_Ci[i], f_rstd[i],
+                                      f_gamma[i], slope, C, N, B, dg, f_dYn[i], f_dyns[i], f_Wn[i], C, f_Cn[i], stream));
+    }
+    pending = false; have_dA = false;
+    // dW = dY^T X
+    float* partw = reinterpret_cast<float*>(ws + L.partw[l]);
+    EST_TRY(dfepe_est_gemm_tn(dY, (size_t)cols * C, C, a_in, (size_t)cols * K, K, (int)cols, L.slices[l], partw, stream));
+    if (nseg + 4 > kSegMax) EST_TRY(flush());
+    seg(dg, (int)B, C, g_gamma[l]);
+    seg(db, (int)B, C, g_beta[l]);
+    seg(partw, L.slices[l], C * K, (K == D.Ci[l]) ? g_W[l] : reinterpret_cast<float*>(ws + L.wtmp));
+    seg(nullptr, 0, C, g_bias[l]);
+    if (l > 0 || need_gx) {
+      const void* WT = sv + S.wt[l];
+      if (l > 0 && D.fused && D.Ci[l] == K) {
+        EST_TRY(dfepe_est_dgrad_in_bwd(WT, (size_t)K * C, dY, (size_t)cols * C, K, (int)cols, C, a_in, (size_t)cols * K,
+                                       reinterpret_cast<const float*>(sv + S.rstd[l - 1]), gamma[l - 1], beta[l - 1], slope, ws + L.dY[l - 1],
+                                       (size_t)cols * K, reinterpret_cast<float*>(ws + L.dg[l - 1]), reinterpret_cast<float*>(ws + L.db[l - 1]),
+                                       stream));
+        pending = true;
+      } else {
+        EST_TRY(dfepe_est_gemm_nt(WT, (size_t)K * C, dY, (size_t)cols * C, K, (int)cols, C, 2, dA, K, stream));
+        have_dA = true;
+      }
+    }
+  }
+  if (nfix > 0)
+    EST_TRY(dfepe_est_dgamma_zero_multi(nfix, f_dA, f_dl, f_wh, f_out, f_outs, f_in, f_ins, f_W, f_Ci, f_rstd, f_gamma, f_C, f_dg, f_dYn, f_dyns, f_Wn,
+                                        f_Cn, slope, N, B, stream));
+  EST_TRY(flush());
+  if (D.K0 != D.C0) {  // the first layer's weight gradient without its K0 - C0 zero-padded input channels
+    if (hipMemcpy2DAsync(g_W[0], (size_t)D.C0 * 4, ws + L.wtmp, (size_t)D.K0 * 4, (size_t)D.C0 * 4, (size_t)D.Co[0], hipMemcpyDeviceToDevice, st) !=
+        hipSuccess)
+      return DFEPE_ERR_HIP;
+  }
+  if (need_gx) {
+    const long total = B * (long)C0 * N;
+    hipLaunchKernelGGL(est_gx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dA, D.K0, B, C0, N, gx);
+    if (hipGetLastError() != hipSuccess) return DFEPE_ERR_HIP;
+  }
+  return DFEPE_OK;
+}

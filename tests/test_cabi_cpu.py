@@ -31,7 +31,7 @@ def test_library_builds_and_exports_every_declared_symbol(dfepe):
 
 def test_version_strerror_and_save_layout(dfepe):
     L = dfepe._lib.lib()
-    assert L.dfepe_version() == 152
+    assert L.dfepe_version() == 153
     assert L.dfepe_save_floats() == 128
     assert L.dfepe_strerror(0) == b"ok"
     assert b"invalid" in L.dfepe_strerror(-1)
@@ -78,9 +78,31 @@ def test_argument_validation_without_launching(dfepe):
     assert L.dfepe_est_wprep(0, None, None, None, None, None, None, None, None) == -1 and L.dfepe_est_wprep(9, None, None, None, None, None, None, None, None) == -1
     assert L.dfepe_est_wprep_workspace_bytes(5) >= 5 * 4 and L.dfepe_est_wprep_workspace_bytes(0) == 0
     assert L.dfepe_est_dgamma_zero_multi(0, *([None] * 17), 0.01, 100, 4, None) == -1 and L.dfepe_est_dgamma_zero_multi(2, *([None] * 17), 0.01, 100, 4, None) == -1
+    assert L.dfepe_est_saved_bytes(0, None, None, 4, 7, 100, 0) == 0 and L.dfepe_est_forward_workspace_bytes(9, None, None, 4, 7, 100, 1) == 0
+    assert L.dfepe_est_forward(None, 4, 7, 100, 5, None, None, None, None, None, None, None, 1e-5, 0.01, None, 0, None, None, None) == -1
+    assert L.dfepe_est_backward(None, 4, 7, 100, 5, None, None, None, None, None, None, 0.01, None, None, None, None, None, None, None, None, None, None) == -1
     assert L.dfepe_est_colsum(0, None, None, None, None, None) == -1 and L.dfepe_est_colsum(33, None, None, None, None, None) == -1
     assert L.dfepe_est_dgrad_in_bwd(None, 0, None, 0, 64, 200, 32, None, 0, None, None, None, 0.01, None, 0, None, None, None) == -1
     assert L.dfepe_est_in_bwd_n(None, None, None, None, 0, None, None, None, 0.01, 64, 2, 1000, None, 0, None, None, 1, None, None) == -1
+
+
+def test_estimator_pass_buffer_sizes(dfepe):
+    """The caller-owned buffers of dfepe_est_forward / dfepe_est_backward: sizes for the reference's estimator (7 -> 64 -> 128 -> 1024 ->
+    512 -> 256) grow with the batch, need_gx adds the first layer's transposed weight planes, a forward that keeps nothing needs no
+    `saved` at all; widths off the 32 grid or a broken chain of widths are refused (size 0)."""
+    import ctypes
+    L = dfepe._lib.lib()
+    arr = lambda v: (ctypes.c_int * len(v))(*v)
+    Co, Ci = arr([64, 128, 1024, 512, 256]), arr([7, 64, 128, 1024, 512])
+    s8, s16 = L.dfepe_est_saved_bytes(5, Co, Ci, 8, 7, 100, 0), L.dfepe_est_saved_bytes(5, Co, Ci, 16, 7, 100, 0)
+    assert 0 < s8 < s16 and L.dfepe_est_saved_bytes(5, Co, Ci, 8, 7, 100, 1) > s8
+    # per column: two bf16 planes of 32 + 64 + 128 + 1024 + 512 + 256 channels
+    assert s8 >= 8 * 100 * (32 + 64 + 128 + 1024 + 512 + 256) * 4
+    assert L.dfepe_est_forward_workspace_bytes(5, Co, Ci, 8, 7, 100, 1) > 0 and L.dfepe_est_backward_workspace_bytes(5, Co, Ci, 8, 7, 100, 1) > 0
+    assert L.dfepe_est_forward_workspace_bytes(5, Co, Ci, 8, 7, 37, 0) > L.dfepe_est_forward_workspace_bytes(5, Co, Ci, 8, 7, 37, 1) * 0  # generic N: sized too
+    assert L.dfepe_est_saved_bytes(5, arr([64, 100, 1024, 512, 256]), Ci, 8, 7, 100, 0) == 0   # 100 % 32 != 0
+    assert L.dfepe_est_saved_bytes(5, Co, arr([7, 64, 128, 1000, 512]), 8, 7, 100, 0) == 0     # Ci[3] != Co[2]
+    assert L.dfepe_est_saved_bytes(5, Co, Ci, 8, 7, 1, 0) == 0                                   # one point per pair: the stock stack's error
 
 
 def test_no_cpu_fallback(dfepe):

@@ -315,6 +315,45 @@ def test_whole_estimator_matches_the_stock_module_in_float64(dfepe, cin, B, seed
     assert float((yc.detach() - yb.detach()).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("cin,B,N,xgrad", [(4, 6, 100, False), (7, 5, 100, True), (7, 3, 37, True), (4, 2, 1000, False), (7, 41, 100, True)])
+def test_one_call_per_pass_is_bit_identical_to_the_per_launch_host_code(dfepe, cin, B, N, xgrad, monkeypatch):
+    """dfepe_est_forward / dfepe_est_backward issue the launches of the per-launch host code from C, in the same order, on three
+    caller-owned buffers: logits and every gradient must come out bit for bit the same (fused epilogues at N = 100, plain products
+    elsewhere; with and without a gradient for x; 41 pairs: the gamma == 0 guard layer by layer instead of at the end), and a
+    forward under no_grad (nothing saved) must give the same logits."""
+    est = dfepe.estimator
+    EE = dfepe.compat.ErrorEstimators
+    net = EE.FusedErrorEstimator(cin).to(DEV)
+    dfepe.synth.fill_params_deterministic(net, seed=11)
+    g = torch.Generator().manual_seed(B + N)
+    x0 = torch.rand(B, cin, N, generator=g).to(DEV)
+    G = torch.randn(B, 1, N, generator=g).to(DEV)
+    if B == 41:
+        monkeypatch.setattr(est, "FIX_AT_END_BYTES", 0)  # (the C side decides by the same 64 MB: 41 x 100 columns stay below it, so
+        # this only moves the host code to its layer-by-layer form; both orders of the fixes write the same values)
+    outs = {}
+    for use in (True, False):
+        monkeypatch.setattr(est, "USE_PASS", use)
+        net.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(xgrad)
+        y = net(x)
+        assert type(y.grad_fn).__name__.startswith("_EstimatorPassFunction" if use else "_EstimatorFunction")
+        (y * G).sum().backward()
+        with torch.no_grad():
+            y0 = net(x0)
+        outs[use] = (y.detach().clone(), y0.clone(), None if not xgrad else x.grad.clone(), [p.grad.clone() for p in net.parameters()])
+    a, b = outs[True], outs[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[0], a[1])
+    if xgrad:
+        assert torch.equal(a[2], b[2])
+    names = [n for n, _ in net.named_parameters()]
+    for name, ga, gb in zip(names, a[3], b[3]):
+        if name == names[-1]:  # the head's bias: sum of dlogit -- torch.sum there, 512 partial sums + the common reduction launch here
+            assert float((ga - gb).abs().max()) <= 1e-6 * float(G.abs().sum()), name
+        else:
+            assert torch.equal(ga, gb), name
+
+
 def test_backward_twice_with_retain_graph_and_the_standard_error_without(dfepe):
     """the node's bf16 planes live in save_for_backward, so a retained graph can be walked twice (separate
     loss_F / loss_qt backward calls, repeated torch.autograd.grad) with identical gradients, and a second walk through a freed
