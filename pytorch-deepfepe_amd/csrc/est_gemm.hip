@@ -1797,8 +1797,10 @@ FwdLayout fwd_layout(const PassDims& D, bool keep) {
   F.words = at; at += up(sizeof(unsigned) * kTabMax);  // used when nothing is kept (no `saved`)
   for (int l = 0; l < D.n; ++l) { F.wf[l] = at; at += up((size_t)2 * D.Co[l] * D.K[l] * 2); }
   F.xh = at; at += up((size_t)2 * D.cols * D.K0 * 2);
-  F.ping = at; at += up((size_t)2 * D.cols * D.Cmax * 2);
-  F.pong = at; at += up((size_t)2 * D.cols * D.Cmax * 2);
+  int c_even = 0, c_odd = 0;  // the layers' fp16 outputs take turns in two buffers: even layers in one, odd ones in the other
+  for (int l = 0; l < D.n; ++l) { int& c = (l & 1) ? c_odd : c_even; c = D.Co[l] > c ? D.Co[l] : c; }
+  F.ping = at; at += up((size_t)2 * D.cols * c_even * 2);
+  F.pong = at; at += up((size_t)2 * D.cols * c_odd * 2);
   F.rstd_scratch = at; if (!keep) at += up((size_t)D.B * D.Cmax * 4);
   F.Y = at; F.npart = at;
   if (!D.fused) { at += up((size_t)D.cols * D.Cmax * 4); F.npart = at; at += up((size_t)D.B * 64 * 2 * D.Cmax * 4); }
@@ -1822,8 +1824,10 @@ BwdLayout bwd_layout(const PassDims& D, bool need_gx) {
   if (L.fix_at_end) {
     for (int l = 0; l < D.n; ++l) { L.dY[l] = at; at += up((size_t)2 * D.cols * D.Co[l] * 2); }
   } else {  // two buffers taking turns: dY of layer l is read while dY of layer l - 1 is written
-    const size_t a = at, b = at + up((size_t)2 * D.cols * D.Cmax * 2);
-    at = b + up((size_t)2 * D.cols * D.Cmax * 2);
+    int ca = 0, cb = 0;
+    for (int l = D.n - 1, k = 0; l >= 0; --l, ++k) { int& c = (k & 1) ? cb : ca; c = D.Co[l] > c ? D.Co[l] : c; }
+    const size_t a = at, b = at + up((size_t)2 * D.cols * ca * 2);
+    at = b + up((size_t)2 * D.cols * cb * 2);
     for (int l = D.n - 1, k = 0; l >= 0; --l, ++k) L.dY[l] = (k & 1) ? b : a;
   }
   for (int l = 0; l < D.n; ++l) {
@@ -1841,27 +1845,45 @@ BwdLayout bwd_layout(const PassDims& D, bool need_gx) {
 }
 
 // x [B][C0][N] fp32 -> planes [cols = B N][K0]: two fp16 (what the first layer multiplies by) and, if wanted, two bf16 (what its
-// weight gradient multiplies by); channels C0..K0 zero
+// weight gradient multiplies by); channels C0..K0 zero.  A thread = one column x one block of 32 channels: its reads of x run along n
+// with its neighbours' (coalesced), its 64 bytes per plane are contiguous with theirs.
 __global__ void __launch_bounds__(256)
 est_input_split_kernel(const float* __restrict__ x, long B, int C0, int N, int K0, bf16_t* __restrict__ ph, size_t h_stride,
                        bf16_t* __restrict__ pb, size_t b_stride) {
   const long cols = B * (long)N;
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;  // (channel pair, column), column fastest: the reads of x coalesce
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;  // (channel block, column), column fastest
   const long col = t % cols;
-  const int ch = (int)(t / cols) * 2;
-  if (ch >= K0) return;
+  const int cb = (int)(t / cols) * 32;
+  if (cb >= K0) return;
   const long b = col / N, n = col - b * N;
-  const float v0 = (ch < C0) ? x[((size_t)b * C0 + ch) * N + n] : 0.f, v1 = (ch + 1 < C0) ? x[((size_t)b * C0 + ch + 1) * N + n] : 0.f;
-  unsigned p0, p1;
-  split2h(v0, v1, p0, p1);
-  const size_t at = kb_index((size_t)col, ch, (size_t)cols);
-  *reinterpret_cast<unsigned*>(ph + at) = p0;
-  *reinterpret_cast<unsigned*>(ph + h_stride + at) = p1;
-  if (pb) {
-    split2(v0, v1, p0, p1);
-    *reinterpret_cast<unsigned*>(pb + at) = p0;
-    *reinterpret_cast<unsigned*>(pb + b_stride + at) = p1;
+  unsigned h0[16], h1[16], q0[16], q1[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int ch = cb + 2 * i;
+    const float v0 = (ch < C0) ? x[((size_t)b * C0 + ch) * N + n] : 0.f, v1 = (ch + 1 < C0) ? x[((size_t)b * C0 + ch + 1) * N + n] : 0.f;
+    split2h(v0, v1, h0[i], h1[i]);
+    split2(v0, v1, q0[i], q1[i]);
   }
+  const size_t at = kb_index((size_t)col, cb, (size_t)cols);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    *reinterpret_cast<uint4*>(ph + at + 8 * i) = make_uint4(h0[4 * i], h0[4 * i + 1], h0[4 * i + 2], h0[4 * i + 3]);
+    *reinterpret_cast<uint4*>(ph + h_stride + at + 8 * i) = make_uint4(h1[4 * i], h1[4 * i + 1], h1[4 * i + 2], h1[4 * i + 3]);
+  }
+  if (pb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<uint4*>(pb + at + 8 * i) = make_uint4(q0[4 * i], q0[4 * i + 1], q0[4 * i + 2], q0[4 * i + 3]);
+      *reinterpret_cast<uint4*>(pb + b_stride + at + 8 * i) = make_uint4(q1[4 * i], q1[4 * i + 1], q1[4 * i + 2], q1[4 * i + 3]);
+    }
+  }
+}
+// dst[r][c] = src[r][c], c < width (rows of ld_src floats into rows of `width`): the first layer's weight gradient without its padding
+__global__ void __launch_bounds__(256) est_crop_kernel(const float* __restrict__ src, int ld_src, int rows, int width, float* __restrict__ dst) {
+  const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (i >= rows * width) return;
+  const int r = i / width, c = i - r * width;
+  dst[i] = src[(size_t)r * ld_src + c];
 }
 // gx[b][c][n] = dA[(b N + n) ld + c], c < C0
 __global__ void __launch_bounds__(256) est_gx_kernel(const float* __restrict__ dA, int ld, long B, int C0, int N, float* __restrict__ gx) {
@@ -1923,7 +1945,7 @@ extern "C" int dfepe_est_forward(const float* x, long B, int C0, int N, int n_hi
   unsigned* words = reinterpret_cast<unsigned*>(keep ? sv + S.words : ws + F.words);
   // the input's planes
   {
-    const long threads = cols * (D.K0 / 2);
+    const long threads = cols * (D.K0 / 32);
     hipLaunchKernelGGL(est_input_split_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, x, B, C0, N, D.K0,
                        reinterpret_cast<bf16_t*>(ws + F.xh), (size_t)cols * D.K0, keep ? reinterpret_cast<bf16_t*>(sv + S.act[0]) : nullptr,
                        (size_t)cols * D.K0);
@@ -2065,9 +2087,10 @@ extern "C" int dfepe_est_backward(const float* g_logits, long B, int C0, int N, 
                                         f_Cn, slope, N, B, stream));
   EST_TRY(flush());
   if (D.K0 != D.C0) {  // the first layer's weight gradient without its K0 - C0 zero-padded input channels
-    if (hipMemcpy2DAsync(g_W[0], (size_t)D.C0 * 4, ws + L.wtmp, (size_t)D.K0 * 4, (size_t)D.C0 * 4, (size_t)D.Co[0], hipMemcpyDeviceToDevice, st) !=
-        hipSuccess)
-      return DFEPE_ERR_HIP;
+    const int total = D.Co[0] * D.C0;
+    hipLaunchKernelGGL(est_crop_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float*>(ws + L.wtmp), D.K0,
+                       D.Co[0], D.C0, g_W[0]);
+    if (hipGetLastError() != hipSuccess) return DFEPE_ERR_HIP;
   }
   if (need_gx) {
     const long total = B * (long)C0 * N;
