@@ -14,6 +14,7 @@ sums over split-K / per-pair partials)."""
 from __future__ import annotations
 
 import ctypes
+import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -428,6 +429,24 @@ def _pass_ok(x: Tensor, flat: Sequence[Optional[Tensor]], n_hidden: int) -> bool
     parameters; everything else keeps the per-launch host code of _EstimatorFunction."""
     if not USE_PASS or n_hidden < 1 or n_hidden > _TAB or flat[4 * n_hidden].shape[0] != 1:
         return False
+    # the answer for THESE parameter objects is remembered (module.to() / .half() keep the Parameter objects and swap their data:
+    # dtype and device of the first one are re-checked every time)
+    key = (tuple(map(id, flat)), x.shape[1])
+    hit = _PASS_OK.get(key)
+    if (hit is not None and flat[0].dtype == torch.float32 and flat[0].device == x.device and flat[0].is_contiguous()
+            and all((r is None and p is None) or (r is not None and r() is p) for r, p in zip(hit[1], flat))):  # ids are reused: the objects
+        return hit[0]
+    ok = _pass_ok_uncached(x, flat, n_hidden)
+    if len(_PASS_OK) > 256:
+        _PASS_OK.clear()
+    _PASS_OK[key] = (ok, tuple(None if p is None else weakref.ref(p) for p in flat))
+    return ok
+
+
+_PASS_OK: dict = {}
+
+
+def _pass_ok_uncached(x: Tensor, flat: Sequence[Optional[Tensor]], n_hidden: int) -> bool:
     for i, p in enumerate(flat):
         if p is None:
             if i != 4 * n_hidden + 1:
