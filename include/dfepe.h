@@ -460,8 +460,8 @@ int dfepe_inorm_lrelu_bwd(const float *Y, const float *gA, const float *gamma, c
  *                        results).  x [B][C0][N], W[l] [Co[l]][Ci[l]] (Ci[l] = Co[l-1], Ci[0] = C0; Co % 32 == 0), gamma / beta [l]
  *                        [Co[l]], w_head [Co of the last layer], b_head [1] or null: fp32, contiguous, host arrays of device pointers.
  *                        The caller brings the memory: `saved` (dfepe_est_saved_bytes; null for a forward no backward will follow; what
- *                        the backward reads: every layer's bf16 planes, reciprocal deviations, transposed weight planes -- need_gx also
- *                        the first layer's, for the gradient w.r.t. x), a transient workspace per pass (dfepe_est_*_workspace_bytes;
+ *                        the backward reads: every layer's bf16 planes, reciprocal deviations, transposed weight planes; need_gx does not
+ *                        change its layout -- a backward may ask for gx or not), a transient workspace per pass (dfepe_est_*_workspace_bytes;
  *                        16-byte aligned, contents irrelevant) and the outputs: logits [B * N]; g_W[l] [Co][Ci], g_bias[l] [Co] (exact
  *                        zeros: the convolution bias cancels in the normalisation), g_gamma[l], g_beta[l] [Co], g_w_head, g_b_head
  *                        (or null), gx [B][C0][N] (or null).  N = dfepe_est_points() takes the fused epilogues, any other N >= 2 the

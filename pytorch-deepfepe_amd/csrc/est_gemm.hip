@@ -1780,10 +1780,8 @@ SavedLayout saved_layout(const PassDims& D, bool need_gx) {
   S.act[0] = at; at += up((size_t)2 * D.cols * D.K0 * 2);
   for (int l = 0; l < D.n; ++l) { S.act[l + 1] = at; at += up((size_t)2 * D.cols * D.Co[l] * 2); }
   for (int l = 0; l < D.n; ++l) { S.rstd[l] = at; at += up((size_t)D.B * D.Co[l] * 4); }
-  for (int l = 0; l < D.n; ++l) {
-    S.wt[l] = at;
-    if (l > 0 || need_gx) at += up((size_t)2 * D.K[l] * D.Co[l] * 2);
-  }
+  (void)need_gx;  // the first layer's transposed planes (a few KB) are always there: the layout must not depend on what the caller
+  for (int l = 0; l < D.n; ++l) { S.wt[l] = at; at += up((size_t)2 * D.K[l] * D.Co[l] * 2); }  // later asks the backward for
   S.total = at;
   return S;
 }
@@ -1926,8 +1924,9 @@ extern "C" size_t dfepe_est_backward_workspace_bytes(int n_hidden, const int* Co
   return bwd_layout(D, need_gx != 0).total;
 }
 
-// logits [cols] = head(stack(x)); saved != null: everything dfepe_est_backward needs is left there (need_gx: also the first layer's
-// transposed weight planes).  x [B][C0][N], W[l] [Co][Ci], gamma / beta [l] [Co], w_head [Co of the last layer], b_head [1] or null: fp32.
+// logits [cols] = head(stack(x)); saved != null: everything dfepe_est_backward needs is left there (need_gx is accepted for symmetry with
+// the size functions and ignored: the first layer's transposed weight planes are a few KB and always kept, so that a backward may ask
+// for gx or not).  x [B][C0][N], W[l] [Co][Ci], gamma / beta [l] [Co], w_head [Co of the last layer], b_head [1] or null: fp32.
 extern "C" int dfepe_est_forward(const float* x, long B, int C0, int N, int n_hidden, const float* const* W, const float* const* gamma,
                                  const float* const* beta, const int* Co, const int* Ci, const float* w_head, const float* b_head, float eps,
                                  float slope, void* saved, int need_gx, void* workspace, float* logits, void* stream) {
@@ -1954,7 +1953,7 @@ extern "C" int dfepe_est_forward(const float* x, long B, int C0, int N, int n_hi
   // every layer's weights: scales, fp16 planes, transposed bf16 planes for the backward
   {
     void* pf[kTabMax]; void* pt[kTabMax];
-    for (int l = 0; l < D.n; ++l) { pf[l] = ws + F.wf[l]; pt[l] = (keep && (l > 0 || need_gx)) ? sv + S.wt[l] : nullptr; }
+    for (int l = 0; l < D.n; ++l) { pf[l] = ws + F.wf[l]; pt[l] = keep ? sv + S.wt[l] : nullptr; }
     EST_TRY(dfepe_est_wprep(D.n, W, Co, Ci, pf, pt, words, ws + F.absws, stream));
   }
   const char* act = ws + F.xh;
