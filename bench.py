@@ -713,12 +713,10 @@ def main():
                 fdt = (time.perf_counter() - f0) / nfull
                 full_model = {"value": round(B / fdt, 1), "unit": "pairs/s", "ms_per_step": round(fdt * 1e3, 2),
                               "what": "compat.DeepFNet (seeded random weights) forward + F-loss + qt loss + backward to the estimator parameters; the estimator runs "
-                                      "on the bf16 matrix cores with fp32-accurate split operands (csrc/est_gemm.hip, SURVEY row f-1); not part of `value`"}
+                                      "on the 16-bit matrix cores with fp32-accurate split operands (csrc/est_gemm.hip, SURVEY row f-1); not part of `value`"}
                 # the same model at a loader-sized batch, where the step is launch-bound: the reference's eager sequence against
                 # compat.CapturedStep (the whole step -- estimators, solver, losses, backward -- as one replayed hipGraph)
-                Bs = 64
                 keys = ("matches_xy_ori", "pts1_virt_ori", "pts2_virt_ori", "Ks", "delta_Rtijs_4_4", "qs_cam", "ts_cam")
-                small = [{k: scene[k][i * Bs:(i + 1) * Bs].contiguous() for k in keys} for i in range(2)]
 
                 def fwd_loss(b):
                     outs = net({"matches_xy_ori": b["matches_xy_ori"], "matches_good_unique_nums": None, "t_scene_scale": None})
@@ -732,27 +730,32 @@ def main():
                     net.zero_grad(set_to_none=True)
                     fwd_loss(b)[0].backward()
 
-                for k in range(3):
-                    eager_small(small[k & 1])
-                torch.cuda.synchronize()
-                f0 = time.perf_counter()
-                for k in range(10):
-                    eager_small(small[k & 1])
-                torch.cuda.synchronize()
-                eager_small_ms = (time.perf_counter() - f0) * 1e2
-                helper = dfepe.compat.CapturedStep(fwd_loss, net, warmup=2)
-                for k in range(6):
-                    helper(small[k & 1])
-                torch.cuda.synchronize()
-                f0 = time.perf_counter()
-                for k in range(20):
-                    helper(small[k & 1])
-                torch.cuda.synchronize()
-                full_model["small_batch"] = {"B": Bs, "eager_ms_per_step": round(eager_small_ms, 3),
-                                             "captured_step_ms_per_step": round((time.perf_counter() - f0) * 50.0, 3),
-                                             "captures": helper.n_captures, "replays": helper.n_replays,
-                                             "note": "compat.CapturedStep(forward_and_loss, net): copy-in of a fresh batch + one hipGraph replay per step"}
-                del helper, net
+                def small_batch(Bs):
+                    small = [{k: scene[k][i * Bs:(i + 1) * Bs].contiguous() for k in keys} for i in range(2)]
+                    for k in range(3):
+                        eager_small(small[k & 1])
+                    torch.cuda.synchronize()
+                    f0 = time.perf_counter()
+                    for k in range(10):
+                        eager_small(small[k & 1])
+                    torch.cuda.synchronize()
+                    eager_small_ms = (time.perf_counter() - f0) * 1e2
+                    helper = dfepe.compat.CapturedStep(fwd_loss, net, warmup=2)
+                    for k in range(6):
+                        helper(small[k & 1])
+                    torch.cuda.synchronize()
+                    f0 = time.perf_counter()
+                    for k in range(20):
+                        helper(small[k & 1])
+                    torch.cuda.synchronize()
+                    return {"B": Bs, "eager_ms_per_step": round(eager_small_ms, 3),
+                            "captured_step_ms_per_step": round((time.perf_counter() - f0) * 50.0, 3),
+                            "captures": helper.n_captures, "replays": helper.n_replays,
+                            "note": "compat.CapturedStep(forward_and_loss, net): copy-in of a fresh batch + one hipGraph replay per step"}
+
+                full_model["small_batch"] = small_batch(64)
+                full_model["reference_batch"] = small_batch(8)  # the reference's own configurations train with 4-32 pairs per batch
+                del net
             except Exception as e:  # never let the secondary measurement break the contract line
                 full_model = {"error": repr(e)[:200]} if full_model is None else dict(full_model, small_batch={"error": repr(e)[:200]})
 
