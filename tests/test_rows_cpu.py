@@ -195,6 +195,46 @@ def test_estimator_launch_geometry_helpers(dfepe):
         assert 1 <= s <= 64 and (s == 1 or n // s >= 128)
 
 
+def test_estimator_small_batch_slices_and_the_one_call_per_pass_decision(dfepe):
+    """Host-side choices added in round 5: over few columns a split-K slice keeps >= 256 of them (the reference's batch sizes: the
+    partial sums would otherwise outweigh the product); and which estimators take ONE library call per pass -- a one-channel head,
+    <= 8 hidden layers of widths on the 32 grid, fp32 contiguous parameters -- everything else the per-launch host code."""
+    est = dfepe.estimator
+    assert est._slices_for(512, 1024, 800) == 3 and est._slices_for(512, 1024, 100) == 1
+    assert est._slices_for(512, 1024, 409600) == est._slices_for(512, 1024)
+    for cols in (200, 800, 3200, 6400, 409600):
+        for cout, cin in [(64, 32), (1024, 128), (512, 1024)]:
+            s = est._slices_for(cout, cin, cols)
+            assert s == 1 or cols // s >= 256
+    EE = dfepe.compat.ErrorEstimators
+
+    def flat_of(net):
+        mods, out, i = list(net.fw), [], 0
+        while i + 2 < len(mods):
+            out += [mods[i].weight, mods[i].bias, mods[i + 1].weight, mods[i + 1].bias]
+            i += 3
+        return out + [mods[i].weight, mods[i].bias], (len(mods) - 1) // 3
+
+    x = torch.zeros(2, 7, 100)
+    flat, n = flat_of(EE.ErrorEstimator(7))
+    assert est._pass_ok(x, flat, n) and est._pass_ok(x, flat, n)            # (the second answer comes from the cache)
+    flat4, n4 = flat_of(EE.ErrorEstimator(7, output_size=4))
+    assert not est._pass_ok(x, flat4, n4)                                    # four head channels: the per-launch host code
+    half, nh = flat_of(EE.ErrorEstimator(7).half())
+    assert not est._pass_ok(x, half, nh)                                     # not fp32
+    assert not est._pass_ok(torch.zeros(2, 4, 100), flat, n)                 # the first layer does not take these inputs
+    odd = [p for p in flat]
+    odd[0] = torch.nn.Parameter(torch.zeros(64, 14, 1)[:, ::2])              # non-contiguous weight
+    assert not est._pass_ok(x, odd, n)
+    net = EE.ErrorEstimator(7)
+    net.half()
+    net.float()                                                              # same Parameter objects, dtype back: the cached answer holds
+    flat2, n2 = flat_of(net)
+    assert est._pass_ok(x, flat2, n2)
+    net.half()
+    assert not est._pass_ok(x, flat_of(net)[0], n2)                          # ... and is not trusted once the dtype changed
+
+
 def test_fused_tail_is_reused_only_for_the_announced_ground_truth(dfepe):
     """get_Rt_loss takes the pose errors of get_all_loss_DeepF's fused launch only when it is handed the very objects that launch
     was given (or device tensors over the same memory): equal VALUES in other objects recompute -- slower, never wrong."""
