@@ -139,6 +139,14 @@ enum { EPI_F32 = 0, EPI_IN = 1, EPI_INBWD = 2 };
                           // (DFEPE_NT_SPLIT_SMALL: the AHEAD = 2 builds) it is worth 15-20 %: B = 8, rocprofv3 --stats: forward layers
                           // 26.8 -> 22.7 us on average (1024 -> 512: 59.6 -> 47.0), the fused data gradient 31.2 -> 28.8
 #endif
+#ifndef DFEPE_NT_PAIR_TILES
+#define DFEPE_NT_PAIR_TILES 0  // 1: the small-grid builds walk the column tiles in pairs (four accumulators in rotation, four fragment sets).
+                               // Measured at B = 8 (rocprofv3 --stats, same box): no better than tile by tile for the fused layers and 70 % WORSE for
+                               // the plain data gradient (17.8 vs 10.6 us): a lone wavefront's MFMAs are not waiting for their accumulators
+#endif
+#ifndef DFEPE_NT_TWO_STAGE
+#define DFEPE_NT_TWO_STAGE 1  // the small-grid builds (AHEAD = 2: at most one workgroup per CU) double-buffer the whole LDS stage (86 KB)
+#endif
 #ifndef DFEPE_NT_SPLIT_SMALL
 #define DFEPE_NT_SPLIT_SMALL 1  // ... in the small-grid builds (AHEAD = 2), where a workgroup has its CU to itself
 #endif
@@ -212,7 +220,9 @@ __global__ void __launch_bounds__(256, nt_blocks(NPA, NPB, EPI, AHEAD))
 est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* __restrict__ B, size_t b_plane, int M, int ncols, int K,
                    const EpiArgs E) {
   constexpr int kABytes = NPA * BM * 64, kBBytes = NPB * BN * 64;
-  __shared__ __attribute__((aligned(16))) unsigned char lds_all[kABytes + kBBytes];
+  // the small-grid builds (AHEAD = 2) own their CU: TWO stages, the next K step's DMA under the whole MFMA phase of this one
+  constexpr bool kTwoStage = (AHEAD == 2) && (DFEPE_NT_TWO_STAGE != 0);
+  __shared__ __attribute__((aligned(16))) unsigned char lds_all[(kTwoStage ? 2 : 1) * (kABytes + kBBytes)];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
   // XCD-aware order: consecutive workgroup ids go round-robin to the 8 XCDs; the channel blocks of one column block share its
@@ -296,15 +306,42 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
     // latency of tile nt + 1 hides behind the twelve MFMAs of tile nt instead of stalling every tile
     // (the two-plane product compiled for three workgroups per CU has 168 registers: one fragment set, fetched per tile -- the
     // third wavefront on the SIMD covers the LDS latency the second set would)
-    constexpr int kD = (AHEAD >= 0) ? AHEAD : ((nt_blocks(NPA, NPB, EPI, AHEAD) > 2) ? 0 : 1);  // tiles fetched ahead
+    constexpr bool kPairs = (AHEAD == 2) && (DFEPE_NT_PAIR_TILES != 0);
+    constexpr int kD = kPairs ? 3 : ((AHEAD >= 0) ? AHEAD : ((nt_blocks(NPA, NPB, EPI, AHEAD) > 2) ? 0 : 1));  // tiles fetched ahead
     frag8 b[kD + 1][NPB];
     auto fetch_b = [&](int nt, frag8 (&dst)[NPB]) {
 #pragma unroll
       for (int p = 0; p < NPB; ++p) dst[p] = *reinterpret_cast<const frag8*>(lds + kABytes + ((p * BN + nt * 16 + c) * 4 + (g ^ fsw)) * 16);
     };
 #pragma unroll
-    for (int d = 0; d < kD; ++d)
+    for (int d = 0; d < (kPairs ? 2 : kD); ++d)
       if (kT0 + d < kT1) fetch_b(kT0 + d, b[(kT0 + d) % (kD + 1)]);
+    if constexpr (kPairs) {
+      // a wavefront alone on its SIMD: two column tiles at a time, FOUR accumulators in rotation (an accumulator comes round every
+      // fourth MFMA instead of every second)
+#pragma unroll
+      for (int nt = kT0; nt < kT1; nt += 2) {
+        const bool two = nt + 1 < kT1;
+        if (nt + 2 < kT1) fetch_b(nt + 2, b[(nt + 2) % 4]);  // the next pair's fragments, into the two sets this pair does not use
+        if (nt + 3 < kT1) fetch_b(nt + 3, b[(nt + 3) % 4]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ord = ORDER; ord >= 0; --ord)
+#pragma unroll
+          for (int i = 0; i <= ord; ++i) {
+            const int j = ord - i;
+            if (i < NPA && j < NPB) {
+#pragma unroll
+              for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = mfma16<FMT>(a[mt][i], b[nt % (kD + 1)][j], acc[mt][nt]);
+              if (two) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[mt][nt + 1] = mfma16<FMT>(a[mt][i], b[(nt + 1) % (kD + 1)][j], acc[mt][nt + 1]);
+              }
+            }
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
     for (int nt = kT0; nt < kT1; ++nt) {
       if (nt + kD < kT1) fetch_b(nt + kD, b[(nt + kD) % (kD + 1)]);
@@ -323,6 +360,7 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
         }
       __builtin_amdgcn_sched_barrier(0);
     }
+    }
   };
 
   EST_STAMP(0);
@@ -332,7 +370,19 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
   using T0 = std::integral_constant<int, 0>;
   using TH = std::integral_constant<int, kHalf>;
   using TN = std::integral_constant<int, NT>;
-  if constexpr (DFEPE_NT_SPLIT || (DFEPE_NT_SPLIT_SMALL && AHEAD == 2)) {
+  if constexpr (kTwoStage) {
+    constexpr int kStage = kABytes + kBBytes;
+    stage_issue(0, lds_all);
+    for (int ks = 0; ks < nk; ++ks) {
+      unsigned char* cur = lds_all + (ks & 1) * kStage;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this step's stage
+      __syncthreads();                                  // ... everyone's, and everyone is done reading the other buffer (step ks - 1)
+      if (ks + 1 < nk) stage_issue(ks + 1, lds_all + ((ks + 1) & 1) * kStage);
+      frag8 a[2][NPA];
+      a_from_lds(cur, a);
+      mfma_phase(cur, a, T0{}, TN{});
+    }
+  } else if constexpr (DFEPE_NT_SPLIT || (DFEPE_NT_SPLIT_SMALL && AHEAD == 2)) {
     // One LDS stage, filled in two halves: while the MFMAs of column tiles [0, 7) run, the DMA of tiles [7, 13) of the same K step is
     // in flight; while those of [7, 13) run, the DMA of the NEXT step's A rows and tiles [0, 7).  Two barriers per step, as before
     // (each one both releases a half for overwriting and publishes the other half's arrival).
@@ -1343,12 +1393,12 @@ __global__ void __launch_bounds__(1024) est_colsum_kernel(const ColSumTab T) {
 
 extern "C" int dfepe_est_points(void) { return kPts; }
 
-// fewer than two workgroups per CU: a wavefront is alone on its SIMD and the GEMM kernels take their AHEAD = 2 build (B fragments two
-// column tiles ahead of the MFMAs); DFEPE_EST_SMALL_GRID=0 / 1 forces the choice (A/B timing)
+// at most one workgroup per CU: a wavefront is alone on its SIMD and the GEMM kernels take their AHEAD = 2 build (B fragments two
+// column tiles ahead of the MFMAs, two LDS stages); DFEPE_EST_SMALL_GRID=0 / 1 forces the choice (A/B timing)
 static bool small_grid(const dim3& grid) {
   static const char* force = getenv("DFEPE_EST_SMALL_GRID");
   if (force) return force[0] == '1';
-  return (size_t)grid.x * grid.y < 512;
+  return (size_t)grid.x * grid.y <= 256;  // one workgroup per CU at most: the two-stage build's 86 KB of LDS admit no second one
 }
 
 extern "C" int dfepe_est_absmax(const float* src, long n, unsigned* word, void* stream) {
