@@ -148,7 +148,8 @@ enum { EPI_F32 = 0, EPI_IN = 1, EPI_INBWD = 2 };
 #define DFEPE_NT_TWO_STAGE 1  // the small-grid builds (AHEAD = 2: at most one workgroup per CU) double-buffer the whole LDS stage (86 KB)
 #endif
 #ifndef DFEPE_NT_SPLIT_SMALL
-#define DFEPE_NT_SPLIT_SMALL 1  // ... in the small-grid builds (AHEAD = 2), where a workgroup has its CU to itself
+#define DFEPE_NT_SPLIT_SMALL 1  // ... in the small-grid builds (AHEAD = 2), where a workgroup has its CU to itself -- superseded there by
+                                // DFEPE_NT_TWO_STAGE (two whole stages: 22.0 / 27.3 us); this is what they fall back to with it off
 #endif
 #ifndef DFEPE_INBWD_DEPTH
 #define DFEPE_INBWD_DEPTH 4  // column tiles of the layer's output in flight in the fused adjoint's two passes
