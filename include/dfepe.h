@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFEPE_VERSION 153 /* 0.5.0 */
+#define DFEPE_VERSION 154 /* 0.6.0 */
 
 #define DFEPE_OK 0
 #define DFEPE_ERR_INVALID_ARG (-1) /* null pointer, non-positive size, bad flag combination   */
@@ -420,7 +420,7 @@ int dfepe_inorm_lrelu_bwd(const float *Y, const float *gA, const float *gamma, c
  *                        dfepe_est_gemm_nt / dfepe_est_dgrad_in_bwd multiply dY by.  At the reference's batch sizes (4-32 pairs) a
  *                        call's bookkeeping launches (per layer: maximum, split, transposed split, reductions, fills) cost more
  *                        than its GEMMs; this and dfepe_est_colsum take one estimator call from ~75 launches to ~30
- *   dfepe_est_colsum     dst[s][c] = sum_r src[s][r * cols[s] + c], r < rows[s], for n_seg <= 32 segments in ONE launch, additions in a
+ *   dfepe_est_colsum     dst[s][c] = sum_r src[s][r * cols[s] + c], r < rows[s], for n_seg <= 40 segments in ONE launch, additions in a
  *                        fixed order (rows[s] = 0: zeros, src[s] may be null): all reductions of one backward -- per-pair d gamma /
  *                        d beta partials, split-K partials of the weight gradients -- and the zero gradients of the cancelled biases
  *   dfepe_est_split_f16  the same into two fp16 planes, the values multiplied by the scale of `absmax` (null: unscaled)
@@ -468,7 +468,27 @@ int dfepe_inorm_lrelu_bwd(const float *Y, const float *gA, const float *gamma, c
  *                        plain products.  Why: at the reference's batch sizes the HOST was the limiter of the eager training step
  *                        (~30 launches and ~40 allocations per pass from Python)
  *   dfepe_est_head_fwd   logits[col] = sum_c w[c] a[col][c] + bias[0]   (the last Conv1d(C -> 1)); a: the forward's planes [2] (fp16)
- *   dfepe_est_head_dw    part[blocks][C] = partial sums of d w = sum_col dlogit[col] a[col][c]; a: the backward's planes [2] (bf16)
+ *   dfepe_est_head_dw    part[blocks][C] = partial sums of d w = sum_col dlogit[col] a[col][c]; a: the backward's planes [2] (bf16);
+ *                        bias_part [blocks] (or null; version 154) = partial sums of dlogit: the head bias gradient's, in the same launch
+ * Version 154 (round 6) -- the reference's own shapes (N = 1000-2000 points, 4-12 pairs per batch, deepFEPE/configs/kitti_corr_baseline.yaml:12-13)
+ * and an estimator that one model forward calls several times (DeepFNet.update_weights, deepFEPE/models/DeepFNet.py:510):
+ *   dfepe_est_gemm_nt_f16_splitk / dfepe_est_gemm_nt_splitk   the plain products with their K steps shared by `splits` workgroups per tile:
+ *                        partial products out[z][col][m], z < splits <= K / 32, split_stride (>= ncols * ldc) floats apart.  With a few
+ *                        pairs per batch a K-heavy layer is a dozen 128 x 208 tiles: a chain of 16-32 K steps on 5 % of the chip
+ *   dfepe_est_norm_fwd_r / dfepe_est_in_bwd_r   dfepe_est_norm_fwd / dfepe_est_in_bwd_n for N <= 2048 with the pair's block RESIDENT IN
+ *                        REGISTERS: one launch, one read of the product, given as `splits` partials (added in slice order); a workgroup =
+ *                        one pair x 32 channels
+ *   dfepe_est_gemm_nt_gx the data gradient of the FIRST layer stored as the estimator's input gradient gx [pairs][C0][N] (was: a
+ *                        transposing launch behind the plain product)
+ *   dfepe_est_gemm_tn_multi   dfepe_est_gemm_tn for n_layers <= 8 layers over the same columns in ONE launch (host arrays indexed by layer)
+ *   dfepe_est_prep_bytes / dfepe_est_prepare   the weights' planes of one estimator (power-of-two scales, scaled fp16 planes, transposed
+ *                        bf16 planes) into a caller-owned buffer `prep`, two launches; dfepe_est_forward / dfepe_est_backward given
+ *                        `prep` read them instead of making their own per call.  The weights must not change between dfepe_est_prepare
+ *                        and the last backward handed `prep` (one optimizer step apart at the earliest)
+ *   dfepe_est_forward / dfepe_est_backward   take `prep` (or null); per layer they run the fused epilogue (N = dfepe_est_points(), enough
+ *                        tiles) or plain product -> dfepe_est_norm_fwd_r / dfepe_est_in_bwd_r (any other N <= 2048, and K-heavy layers
+ *                        on few tiles, split over K) -- or the strided kernels beyond N = 2048; over few columns the weight gradients of
+ *                        all layers are one dfepe_est_gemm_tn_multi launch at the end of the backward
  */
 int dfepe_est_points(void);
 int dfepe_est_split(const float *src, long rows, int C_src, int src_ld, int C, int n_planes, void *planes, size_t plane_stride,
@@ -489,6 +509,22 @@ int dfepe_est_gemm_nt(const void *A, size_t a_plane, const void *B, size_t b_pla
                       float *out, int ldc, void *stream);
 int dfepe_est_gemm_tn(const void *dY, size_t dy_plane, int Cout, const void *X, size_t x_plane, int Cin, int ncols, int slices,
                       float *part, void *stream);
+int dfepe_est_gemm_nt_f16_splitk(const void *A, size_t a_plane, const void *B, size_t b_plane, int M, int ncols, int K,
+                                 const unsigned *absmax, float *out, int ldc, int splits, size_t split_stride, void *stream);
+int dfepe_est_gemm_nt_splitk(const void *A, size_t a_plane, const void *B, size_t b_plane, int M, int ncols, int K, float *out, int ldc,
+                             int splits, size_t split_stride, void *stream);
+int dfepe_est_gemm_nt_gx(const void *A, size_t a_plane, const void *B, size_t b_plane, int M, int ncols, int K, float *gx, int C0, int N,
+                         void *stream);
+int dfepe_est_gemm_tn_multi(int n_layers, const void *const *dY, const size_t *dy_plane, const int *Cout, const void *const *X,
+                            const size_t *x_plane, const int *Cin, int ncols, const int *slices, float *const *part, void *stream);
+int dfepe_est_norm_fwd_r(const float *Y, int ldy, int splits, size_t split_stride, int C, long n_pairs, int N, const float *gamma,
+                         const float *beta, float eps, float slope, void *planes_out, size_t out_plane, void *planes_bwd,
+                         size_t bwd_plane, float *rstd, void *stream);
+int dfepe_est_in_bwd_r(const float *dA, int ldd, int splits, size_t split_stride, const float *dlogit, const float *w_head,
+                       const void *planes, size_t plane_stride, const float *rstd, const float *gamma, const float *beta, float slope,
+                       int C, long n_pairs, int N, void *dY, size_t dy_plane, float *dgamma_part, float *dbeta_part, void *stream);
+size_t dfepe_est_prep_bytes(int n_hidden, const int *Co, const int *Ci);
+int dfepe_est_prepare(int n_hidden, const float *const *W, const int *Co, const int *Ci, void *prep, void *stream);
 int dfepe_est_dgamma_zero(const float *dA, const float *dlogit, const float *w_head, const void *out_planes, size_t out_plane,
                           const void *in_planes, size_t in_plane, const float *W, int ldw, int Ci, const float *rstd, const float *gamma,
                           float slope, int C, int N, long n_pairs, float *dgamma_part, const void *dY_next, size_t dyn_plane,
@@ -516,15 +552,15 @@ size_t dfepe_est_forward_workspace_bytes(int n_hidden, const int *Co, const int 
 size_t dfepe_est_backward_workspace_bytes(int n_hidden, const int *Co, const int *Ci, long B, int C0, int N, int need_gx);
 int dfepe_est_forward(const float *x, long B, int C0, int N, int n_hidden, const float *const *W, const float *const *gamma,
                       const float *const *beta, const int *Co, const int *Ci, const float *w_head, const float *b_head, float eps,
-                      float slope, void *saved, int need_gx, void *workspace, float *logits, void *stream);
+                      float slope, void *saved, int need_gx, void *workspace, const void *prep, float *logits, void *stream);
 int dfepe_est_backward(const float *g_logits, long B, int C0, int N, int n_hidden, const float *const *W, const float *const *gamma,
                        const float *const *beta, const int *Co, const int *Ci, const float *w_head, float slope, const void *saved,
-                       void *workspace, float *const *g_W, float *const *g_bias, float *const *g_gamma, float *const *g_beta,
-                       float *g_w_head, float *g_b_head, float *gx, void *stream);
+                       void *workspace, const void *prep, float *const *g_W, float *const *g_bias, float *const *g_gamma,
+                       float *const *g_beta, float *g_w_head, float *g_b_head, float *gx, void *stream);
 int dfepe_est_head_fwd(const void *planes, size_t plane_stride, int C, int ncols, const float *w, const float *bias, float *logits,
                        void *stream);
 int dfepe_est_head_dw(const void *planes, size_t plane_stride, int C, int ncols, int blocks, const float *dlogit, float *part,
-                      void *stream);
+                      float *bias_part, void *stream);
 
 /*
  * Match construction: what produces the [B,N,4] correspondences of dfepe_w8pt_fwd.

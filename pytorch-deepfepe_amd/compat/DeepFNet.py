@@ -156,6 +156,14 @@ class DeepFNet(nn.Module):
         return outs[:-1] + (outs[-1].unsqueeze(1),)
 
     def forward(self, data_batch):
+        # update_weights is evaluated depth - 1 times on the same parameters (:510): they are packed and split into planes once
+        shared = getattr(self.update_weights, "shared_parameters", None)
+        if shared is None or self.depth < 3:
+            return self._forward(data_batch)
+        with shared():
+            return self._forward(data_batch)
+
+    def _forward(self, data_batch):
         matches = data_batch["matches_xy_ori"]
         _require_gpu(matches, "DeepFNet")
         plain = not self.if_learn_offsets and not self.if_img_w

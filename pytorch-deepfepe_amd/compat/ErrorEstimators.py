@@ -3,6 +3,8 @@
 Stock PyTorch-ROCm (MIOpen / rocBLAS): SURVEY.md §8 row a18 keeps it outside the hand-written hot path.
 The layer stack is restated so that ``state_dict`` keys (``fw.<idx>.weight`` ...) match the reference and its
 checkpoints load unchanged."""
+import contextlib
+
 import torch
 import torch.nn as nn
 
@@ -50,6 +52,38 @@ class FusedErrorEstimator(ErrorEstimator):
     always takes the stock path, and so does the native-fp32 evaluation for N not a multiple of 4 or above 512."""
 
     split_bf16 = True
+    _prepared = None  # estimator.Prepared of the current shared_parameters() scope
+
+    def _stack(self):
+        """(hidden, head, eps, slope) of the Conv1d -> InstanceNorm1d(affine) -> LeakyReLU stack, or None for another architecture."""
+        mods = list(self.fw)
+        if any(isinstance(m, nn.BatchNorm1d) for m in mods):
+            return None
+        hidden, i = [], 0
+        while i + 2 < len(mods) and isinstance(mods[i + 1], nn.InstanceNorm1d):
+            hidden.append((mods[i].weight, mods[i].bias, mods[i + 1].weight, mods[i + 1].bias))
+            i += 3
+        if not hidden or i != len(mods) - 1:
+            return None
+        head, inorm, act = mods[i], mods[1], mods[2]
+        if not (act.negative_slope > 0 and all(m.affine for m in mods if isinstance(m, nn.InstanceNorm1d))):
+            return None
+        return hidden, (head.weight, head.bias), inorm.eps, act.negative_slope
+
+    @contextlib.contextmanager
+    def shared_parameters(self):
+        """Scope in which every forward() of this module uses ONE preparation of its parameters (estimator.prepare: the packed
+        parameter vector + the weights' 16-bit planes): for a caller that evaluates the estimator several times on unchanged
+        parameters -- DeepFNet.forward's recurrent loop (deepFEPE/models/DeepFNet.py:510).  The parameters must not be modified
+        inside the scope.  Per module OBJECT, so the replicas nn.DataParallel runs in threads each have their own."""
+        from .. import estimator
+
+        st = self._stack() if self.split_bf16 else None
+        self._prepared = estimator.prepare(st[0], st[1]) if (st is not None and st[0][0][0].is_cuda) else None
+        try:
+            yield self
+        finally:
+            self._prepared = None
 
     def forward(self, data):
         from .. import estimator, ops
@@ -58,13 +92,10 @@ class FusedErrorEstimator(ErrorEstimator):
         mods = list(self.fw)
         has_bn = any(isinstance(m, nn.BatchNorm1d) for m in mods)
         if self.split_bf16 and not has_bn and estimator.supported(data):
-            hidden, i = [], 0
-            while i + 2 < len(mods) and isinstance(mods[i + 1], nn.InstanceNorm1d):
-                hidden.append((mods[i].weight, mods[i].bias, mods[i + 1].weight, mods[i + 1].bias))
-                i += 3
-            head, inorm, act = mods[i], mods[1], mods[2]
-            if i == len(mods) - 1 and act.negative_slope > 0 and all(m.affine for m in mods if isinstance(m, nn.InstanceNorm1d)):
-                return estimator.estimator_forward(data, hidden, (head.weight, head.bias), eps=inorm.eps, slope=act.negative_slope)
+            st = self._stack()
+            if st is not None:
+                hidden, head, eps, slope = st
+                return estimator.estimator_forward(data, hidden, head, eps=eps, slope=slope, prepared=self._prepared)
         if has_bn or (N % 4) or N > 512 or not data.is_cuda:
             return super().forward(data)
         x = data.permute(1, 0, 2).reshape(C0, B * N)  # channel-major

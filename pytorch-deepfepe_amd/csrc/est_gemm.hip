@@ -176,9 +176,13 @@ __device__ unsigned long long* g_est_phase_clk;  // [workgroup * 4 + wavefront][
 #endif
 
 struct EpiArgs {
-  // EPI_F32: out[col][m] fp32, ld = ldc
+  // EPI_F32: out[col][m] fp32, ld = ldc; with gridDim.z = S > 1 (split-K) slice z of the K steps goes to out + z * split_stride
   float* out;
   int ldc;
+  size_t split_stride;
+  // EPI_F32, gx != null: the product is the gradient w.r.t. the estimator's input -- stored as gx[pair][ch][n], ch < gx_C0, col = pair * gx_N + n
+  float* gx;
+  int gx_C0, gx_N;
   // EPI_IN
   const float* gamma;
   const float* beta;
@@ -253,7 +257,9 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
   // (row group g) then owns the EIGHT consecutive channels 8 g .. 8 g + 7 across its two tiles, so the epilogue stores 16 bytes per
   // lane and plane, 64 contiguous bytes per column, one contiguous KiB per store instruction
   const int fswA[2] = {chunk_swz(2 * (c >> 2)), chunk_swz(2 * (c >> 2) + 1)};
-  const int nk = K / BK;
+  // split-K (EPI_F32 only): workgroup z of gridDim.z walks the K steps [ks_begin, ks_end)
+  const int nk_all = K / BK, kz = (int)blockIdx.z, nz = (int)gridDim.z;
+  const int ks_begin = (nk_all * kz) / nz, nk = (nk_all * (kz + 1)) / nz;
   // The stage is filled in two groups -- group 0: the A rows and the column tiles [0, kHalf) of B; group 1: the column tiles
   // [kHalf, NT) -- so that the DMA of one half runs under the MFMAs of the other (DFEPE_NT_SPLIT, below).
   constexpr int kHalf = 7;
@@ -373,12 +379,12 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
   using TN = std::integral_constant<int, NT>;
   if constexpr (kTwoStage) {
     constexpr int kStage = kABytes + kBBytes;
-    stage_issue(0, lds_all);
-    for (int ks = 0; ks < nk; ++ks) {
-      unsigned char* cur = lds_all + (ks & 1) * kStage;
+    stage_issue(ks_begin, lds_all);
+    for (int ks = ks_begin; ks < nk; ++ks) {
+      unsigned char* cur = lds_all + ((ks - ks_begin) & 1) * kStage;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this step's stage
       __syncthreads();                                  // ... everyone's, and everyone is done reading the other buffer (step ks - 1)
-      if (ks + 1 < nk) stage_issue(ks + 1, lds_all + ((ks + 1) & 1) * kStage);
+      if (ks + 1 < nk) stage_issue(ks + 1, lds_all + ((ks + 1 - ks_begin) & 1) * kStage);
       frag8 a[2][NPA];
       a_from_lds(cur, a);
       mfma_phase(cur, a, T0{}, TN{});
@@ -387,11 +393,11 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
     // One LDS stage, filled in two halves: while the MFMAs of column tiles [0, 7) run, the DMA of tiles [7, 13) of the same K step is
     // in flight; while those of [7, 13) run, the DMA of the NEXT step's A rows and tiles [0, 7).  Two barriers per step, as before
     // (each one both releases a half for overwriting and publishes the other half's arrival).
-    group_issue(0, lds_all, T0{});
+    group_issue(ks_begin, lds_all, T0{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    group_issue(0, lds_all, std::integral_constant<int, 1>{});
-    for (int ks = 0; ks < nk; ++ks) {
+    group_issue(ks_begin, lds_all, std::integral_constant<int, 1>{});
+    for (int ks = ks_begin; ks < nk; ++ks) {
 #ifdef DFEPE_EST_PHASE_CLOCKS
       const unsigned long long t0_ = __builtin_readcyclecounter();
 #endif
@@ -420,7 +426,7 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
 #endif
     }
   } else {
-  for (int ks = 0; ks < nk; ++ks) {
+  for (int ks = ks_begin; ks < nk; ++ks) {
 #ifdef DFEPE_EST_PHASE_CLOCKS
     const unsigned long long t0_ = __builtin_readcyclecounter();
 #endif
@@ -454,11 +460,26 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
   float unscale = 1.0f;  // FMT_F16: the weights were split scaled by a power of two
   if constexpr (FMT == FMT_F16) unscale = E.absmax ? wscale(*E.absmax, true) : 1.0f;
   if constexpr (EPI == EPI_F32) {
+    if (E.gx != nullptr) {  // (uniform) the input gradient, channel-major per pair like x itself: 16 consecutive points per channel and store
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int cl = nt * 16 + c, col = n0 + cl;
+        if (cl < BSTEP && col < ncols) {
+          const int pr = col / E.gx_N, pt = col - pr * E.gx_N;
+          float* dst = E.gx + ((size_t)pr * E.gx_C0 + ch8) * E.gx_N + pt;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (ch8 + j < E.gx_C0) dst[(size_t)j * E.gx_N] = acc[j >> 2][nt][j & 3] * unscale;
+        }
+      }
+      return;
+    }
+    float* const out_z = E.out + (size_t)kz * E.split_stride;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int cl = nt * 16 + c, col = n0 + cl;
       if (cl < BSTEP && col < ncols && chok) {
-        float* dst = E.out + (size_t)col * E.ldc + ch8;
+        float* dst = out_z + (size_t)col * E.ldc + ch8;
         if constexpr (FMT == FMT_F16) {
           *reinterpret_cast<f32x4*>(dst) = acc[0][nt] * unscale;
           *reinterpret_cast<f32x4*>(dst + 4) = acc[1][nt] * unscale;
@@ -728,9 +749,11 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
 // LDS-DMA instruction copies one contiguous KiB: 16 columns of one channel block); chunk position q of column k holds channel
 // chunk q ^ 2 ((k >> 2) & 1)  (the swizzle lives on the SOURCE address, the image itself is lane-linear), so that the eight
 // columns a ds_read_b64_tr_b16 half-wave touches fall on all 64 banks.
-__global__ void __launch_bounds__(256, 2)
-est_gemm_tn_kernel(const bf16_t* __restrict__ dY, size_t dy_plane, int Cout, const bf16_t* __restrict__ X, size_t x_plane, int Cin,
-                   int ncols, int cols_per_slice, float* __restrict__ part) {
+// (the body is shared by the one-problem launch and the table-driven one of round 6: `id` = the workgroup's linear index among the
+// nx * ny * nslices of its problem)
+__device__ __forceinline__ void est_gemm_tn_body(const bf16_t* __restrict__ dY, size_t dy_plane, int Cout, const bf16_t* __restrict__ X,
+                                                 size_t x_plane, int Cin, int ncols, int cols_per_slice, float* __restrict__ part, int id,
+                                                 int nx, int ny, int nslices) {
   constexpr int kOpBytes = 2 * BK * 256;  // two planes of [32][256 B]
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kOpBytes];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -738,11 +761,10 @@ est_gemm_tn_kernel(const bf16_t* __restrict__ dY, size_t dy_plane, int Cout, con
   // XCD-aware order (-DDFEPE_TN_NO_XCD builds the launch-order variant for A/B timing): consecutive workgroup ids go round-robin to the 8 XCDs; all output tiles of one column slice
   // stream the same columns of dY and X, so a slice's tiles are given consecutive slots of ONE XCD and its L2 serves the re-reads
   // (in launch order the eight Cout tiles of a (Cin tile, slice) sat on eight different XCDs: X crossed the fabric eight times)
-  int bx = (int)blockIdx.x, by = (int)blockIdx.y, slice = (int)blockIdx.z;
+  int bx = id % nx, by = (id / nx) % ny, slice = id / (nx * ny);
 #ifndef DFEPE_TN_NO_XCD
-  if ((gridDim.z & 7) == 0) {
-    const int nx = (int)gridDim.x, tiles = nx * (int)gridDim.y;
-    const int id = bx + nx * (by + (int)gridDim.y * slice);
+  if ((nslices & 7) == 0) {
+    const int tiles = nx * ny;
     const int xcd = id & 7, j = id >> 3, t = j % tiles;
     slice = (j / tiles) * 8 + xcd;
     bx = t % nx; by = t / nx;
@@ -833,6 +855,30 @@ est_gemm_tn_kernel(const bf16_t* __restrict__ dY, size_t dy_plane, int Cout, con
         if (co < Cout && ci < Cin) dst[(size_t)co * Cin + ci] = acc[mt][nt][r];
       }
     }
+}
+__global__ void __launch_bounds__(256, 2)
+est_gemm_tn_kernel(const bf16_t* __restrict__ dY, size_t dy_plane, int Cout, const bf16_t* __restrict__ X, size_t x_plane, int Cin,
+                   int ncols, int cols_per_slice, float* __restrict__ part) {
+  const int nx = (int)gridDim.x, ny = (int)gridDim.y;
+  est_gemm_tn_body(dY, dy_plane, Cout, X, x_plane, Cin, ncols, cols_per_slice, part, (int)blockIdx.x + nx * ((int)blockIdx.y + ny * (int)blockIdx.z),
+                   nx, ny, (int)gridDim.z);
+}
+// every layer's weight gradient of one backward in ONE launch (round 6): over few columns a backward keeps all its dY alive to the end
+// anyway (the gamma == 0 fix), and five launches of 1-32 tiles each become one grid that fills the chip
+struct TnTab {
+  int n;
+  const bf16_t* dY[8]; const bf16_t* X[8];
+  size_t dy_plane[8], x_plane[8];
+  int Cout[8], Cin[8], nx[8], ny[8], slices[8], cps[8];
+  float* part[8];
+  int first_block[9];  // multiples of 8: a problem's linear ids keep their XCD phase
+};
+__global__ void __launch_bounds__(256, 2) est_gemm_tn_multi_kernel(const TnTab T, int ncols) {
+  int l = 0;
+  while (l + 1 < T.n && (int)blockIdx.x >= T.first_block[l + 1]) ++l;
+  const int id = (int)blockIdx.x - T.first_block[l];
+  if (id >= T.nx[l] * T.ny[l] * T.slices[l]) return;  // padding up to the next multiple of 8
+  est_gemm_tn_body(T.dY[l], T.dy_plane[l], T.Cout[l], T.X[l], T.x_plane[l], T.Cin[l], ncols, T.cps[l], T.part[l], id, T.nx[l], T.ny[l], T.slices[l]);
 }
 
 // ---- InstanceNorm + LeakyReLU adjoint, point-major ----------------------------------------------------------------------------
@@ -1148,6 +1194,215 @@ est_in_bwd_n_kernel(const float* __restrict__ dA, const float* __restrict__ dlog
   }
 }
 
+// ---- round 6: the same two kernels with the pair's block RESIDENT IN REGISTERS, summing split-K partials on the way in ----------
+// What the reference's own configurations need (N = 1000-2000 points, 4-12 pairs per batch, deepFEPE/configs/kitti_corr_baseline.yaml:
+// 12-13) and what the K-heavy layers need at ANY N once a batch is so small that one 128 x 208 tile per workgroup leaves most CUs idle:
+// the product is the plain GEMM (EPI_F32), optionally split over S slices of K (S partial products [S][cols][ld] fp32), and ONE more
+// launch does everything else.  A workgroup = one pair x 32 channels (one K block of the plane layout) = 16 channel pairs x 64 row
+// groups; thread (cp, rg) owns rows rg, rg + 64, ... (RPT = ceil(N / 64) of them, template: N <= 128 / 512 / 1024 / 2048) of its two
+// channels: ONE pass over the fp32 block -- the partials added in slice order --, the values stay in registers for the two-pass
+// statistics (mean, then squared deviations: the same arithmetic as the fused epilogue and est_norm_fwd_n) and the normalise +
+// activate + split.  Against est_norm_fwd_n (three passes, two launches when the pair's rows are spread): one launch, one read.
+// Geometry: CP channel pairs x RG = 1024 / CP row groups per workgroup; RPT rows per thread.  (CP, RPT) = (16, 2 / 8 / 16) serves
+// N <= 128 / 512 / 1024 with 32 channels per workgroup; N <= 2048 takes (8, 16): 16 channels, because 1024 threads hold 128 registers
+// each and the adjoint keeps four values per (row, channel pair).
+// sums over the workgroup's row groups of NV values per thread (each channel pair's own): a wavefront holds 64 / CP row groups --
+// cross-lane exchanges --, then sixteen partials per channel pair through LDS
+template <int NV, int CP>
+__device__ __forceinline__ void rg_all_sum(float (&red)[16][NV][CP], float (&v)[NV]) {
+  const int cp = threadIdx.x & (CP - 1), w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+#pragma unroll
+    for (int o = CP; o < 64; o <<= 1) v[i] += __shfl_xor(v[i], o, 64);
+  }
+  __syncthreads();  // the previous reduction's readers are done
+  if ((threadIdx.x & 63) < CP) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[w][i][cp] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    float t = red[0][i][cp];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += red[q][i][cp];
+    v[i] = t;
+  }
+}
+
+template <int RPT, int CP>
+__global__ void __launch_bounds__(1024)
+est_norm_fwd_r_kernel(const float* __restrict__ Y, int ldy, size_t split_stride, int S, int C, int N, size_t ncols,
+                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float slope, bf16_t* __restrict__ planes,
+                      size_t plane_stride, bf16_t* __restrict__ planes_bwd, size_t bwd_stride, float* __restrict__ rstd) {
+  constexpr int RG = 1024 / CP;
+  __shared__ float red[16][2][CP];
+  const int pair = (int)blockIdx.x, cb = (int)blockIdx.y * (2 * CP);
+  const int cp = threadIdx.x & (CP - 1), rg = threadIdx.x / CP;
+  const int ch = cb + 2 * cp;  // C % 32 == 0: every channel of the workgroup exists
+  const size_t col0 = (size_t)pair * N;
+  const float* Yc = Y + col0 * ldy + ch;
+  f32x2 v[RPT];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int rl = rg + RG * i;
+    v[i] = *reinterpret_cast<const f32x2*>(Yc + (size_t)(rl < N ? rl : 0) * ldy);
+  }
+  for (int s = 1; s < S; ++s) {
+    const float* Ys = Yc + (size_t)s * split_stride;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int rl = rg + RG * i;
+      v[i] += *reinterpret_cast<const f32x2*>(Ys + (size_t)(rl < N ? rl : 0) * ldy);
+    }
+  }
+  const float inv_N = 1.0f / (float)N;
+  float a[2] = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) { const bool live = rg + RG * i < N; a[0] += live ? v[i][0] : 0.f; a[1] += live ? v[i][1] : 0.f; }
+  rg_all_sum<2, CP>(red, a);
+  const float mu0 = a[0] * inv_N, mu1 = a[1] * inv_N;
+  float q[2] = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const bool live = rg + RG * i < N;
+    const float d0 = v[i][0] - mu0, d1 = v[i][1] - mu1;
+    q[0] += live ? d0 * d0 : 0.f; q[1] += live ? d1 * d1 : 0.f;
+  }
+  rg_all_sum<2, CP>(red, q);
+  const float rs0 = 1.0f / sqrtf(q[0] * inv_N + eps), rs1 = 1.0f / sqrtf(q[1] * inv_N + eps);  // biased variance, like F.instance_norm
+  if (rg == 0) { rstd[(size_t)pair * C + ch] = rs0; rstd[(size_t)pair * C + ch + 1] = rs1; }
+  const float k0 = rs0 * gamma[ch], k1 = rs1 * gamma[ch + 1], b0 = beta[ch], b1 = beta[ch + 1];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int rl = rg + RG * i;
+    if (rl < N) {
+      const float z0 = fmaf(v[i][0] - mu0, k0, b0), z1 = fmaf(v[i][1] - mu1, k1, b1);
+      const float a0 = (z0 > 0.f) ? z0 : z0 * slope, a1 = (z1 > 0.f) ? z1 : z1 * slope;
+      unsigned p0, p1;
+      split2h(a0, a1, p0, p1);  // two fp16 planes: the next layer's operand
+      const size_t at = kb_index(col0 + rl, ch, ncols);
+      *reinterpret_cast<unsigned*>(planes + at) = p0;
+      *reinterpret_cast<unsigned*>(planes + plane_stride + at) = p1;
+      if (planes_bwd) {  // two bf16 planes: what the backward reads
+        split2(a0, a1, p0, p1);
+        *reinterpret_cast<unsigned*>(planes_bwd + at) = p0;
+        *reinterpret_cast<unsigned*>(planes_bwd + bwd_stride + at) = p1;
+      }
+    }
+  }
+}
+
+// the adjoint, same geometry: dz and x^ of the thread's rows stay in registers between the two sums and the dY they feed (the rows come
+// in four at a time: with all of a thread's raw words in flight at once the 128 registers of a 1024-thread workgroup spill)
+template <int RPT, int CP>
+__global__ void __launch_bounds__(1024)
+est_in_bwd_r_kernel(const float* __restrict__ dA, int ldd, size_t split_stride, int S, const float* __restrict__ dlogit,
+                    const float* __restrict__ w_head, const bf16_t* __restrict__ planes, size_t plane_stride, const float* __restrict__ rstd,
+                    const float* __restrict__ gamma, const float* __restrict__ beta, float slope, int C, int N, size_t ncols,
+                    bf16_t* __restrict__ dYp, size_t dy_plane, float* __restrict__ dgamma_part, float* __restrict__ dbeta_part) {
+  constexpr int RG = 1024 / CP;
+  constexpr int CHUNK = RPT < 4 ? RPT : 4;
+  __shared__ float red[16][4][CP];
+  const int pair = (int)blockIdx.x, cb = (int)blockIdx.y * (2 * CP);
+  const int cp = threadIdx.x & (CP - 1), rg = threadIdx.x / CP;
+  const int ch = cb + 2 * cp;
+  const size_t col0 = (size_t)pair * N;
+  const float g0 = gamma[ch], g1 = gamma[ch + 1], b0 = beta[ch], b1 = beta[ch + 1];
+  const float ig0 = (fabsf(g0) > 1e-30f) ? 1.0f / g0 : 0.0f, ig1 = (fabsf(g1) > 1e-30f) ? 1.0f / g1 : 0.0f;
+  const float islope = 1.0f / slope;
+  const float wh0 = dA ? 0.f : w_head[ch], wh1 = dA ? 0.f : w_head[ch + 1];
+  // RPT >= 16: x^ is not kept but formed again from a second read of the planes (L2) for the output pass -- dz alone is 32 registers
+  constexpr bool kKeepX = RPT < 16;
+  f32x2 dz[RPT], xh[kKeepX ? RPT : 1];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i0 = 0; i0 < RPT; i0 += CHUNK) {
+    unsigned u0[CHUNK], u1[CHUNK];
+    f32x2 d[CHUNK];
+    int rgx = rg;
+    asm volatile("" : "+v"(rgx));  // the address arithmetic stays with its chunk (hoisted, the thread's 3 x RPT addresses are what spills)
+#pragma unroll
+    for (int k = 0; k < CHUNK; ++k) {
+      const int rl = rgx + RG * (i0 + k);
+      const size_t col = col0 + (rl < N ? rl : 0);
+      const size_t at = kb_index(col, ch, ncols);
+      u0[k] = *reinterpret_cast<const unsigned*>(planes + at);
+      u1[k] = *reinterpret_cast<const unsigned*>(planes + plane_stride + at);
+      if (dA != nullptr) d[k] = *reinterpret_cast<const f32x2*>(dA + col * ldd + ch);
+      else { const float dl = dlogit[col]; d[k] = f32x2{dl * wh0, dl * wh1}; }
+    }
+    if (dA != nullptr)
+      for (int s = 1; s < S; ++s) {
+        const float* Ds = dA + (size_t)s * split_stride;
+#pragma unroll
+        for (int k = 0; k < CHUNK; ++k) {
+          const int rl = rgx + RG * (i0 + k);
+          d[k] += *reinterpret_cast<const f32x2*>(Ds + (col0 + (rl < N ? rl : 0)) * ldd + ch);
+        }
+      }
+#pragma unroll
+    for (int k = 0; k < CHUNK; ++k) {
+      const bool live = rg + RG * (i0 + k) < N;
+      const float a0 = bf16_lo(u0[k]) + bf16_lo(u1[k]), a1 = bf16_hi(u0[k]) + bf16_hi(u1[k]);
+      const float z0 = (a0 > 0.f) ? a0 : a0 * islope, z1 = (a1 > 0.f) ? a1 : a1 * islope;
+      const float e0 = live ? ((a0 > 0.f) ? d[k][0] : d[k][0] * slope) : 0.f, e1 = live ? ((a1 > 0.f) ? d[k][1] : d[k][1] * slope) : 0.f;
+      dz[i0 + k] = f32x2{e0, e1};
+      const float x0 = (z0 - b0) * ig0, x1 = (z1 - b1) * ig1;
+      if constexpr (kKeepX) xh[i0 + k] = f32x2{x0, x1};
+      s[0] += e0; s[1] += e1;
+      s[2] = fmaf(e0, x0, s[2]); s[3] = fmaf(e1, x1, s[3]);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // one chunk's raw words at a time
+  }
+  rg_all_sum<4, CP>(red, s);
+  if (rg == 0) {
+    dbeta_part[(size_t)pair * C + ch] = s[0]; dbeta_part[(size_t)pair * C + ch + 1] = s[1];
+    dgamma_part[(size_t)pair * C + ch] = s[2]; dgamma_part[(size_t)pair * C + ch + 1] = s[3];
+  }
+  const float inv_n = 1.0f / (float)N;
+  const float k0 = rstd[(size_t)pair * C + ch] * g0, k1 = rstd[(size_t)pair * C + ch + 1] * g1;
+  const float m10 = s[0] * inv_n, m11 = s[1] * inv_n, m20 = s[2] * inv_n, m21 = s[3] * inv_n;
+#pragma unroll
+  for (int i0 = 0; i0 < RPT; i0 += CHUNK) {
+    f32x2 x[CHUNK];
+    int rgx = rg;
+    asm volatile("" : "+v"(rgx));
+    if constexpr (kKeepX) {
+#pragma unroll
+      for (int k = 0; k < CHUNK; ++k) x[k] = xh[i0 + k];
+    } else {
+      unsigned u0[CHUNK], u1[CHUNK];
+#pragma unroll
+      for (int k = 0; k < CHUNK; ++k) {
+        const int rl = rgx + RG * (i0 + k);
+        const size_t at = kb_index(col0 + (rl < N ? rl : 0), ch, ncols);
+        u0[k] = *reinterpret_cast<const unsigned*>(planes + at);
+        u1[k] = *reinterpret_cast<const unsigned*>(planes + plane_stride + at);
+      }
+#pragma unroll
+      for (int k = 0; k < CHUNK; ++k) {
+        const float a0 = bf16_lo(u0[k]) + bf16_lo(u1[k]), a1 = bf16_hi(u0[k]) + bf16_hi(u1[k]);
+        const float z0 = (a0 > 0.f) ? a0 : a0 * islope, z1 = (a1 > 0.f) ? a1 : a1 * islope;
+        x[k] = f32x2{(z0 - b0) * ig0, (z1 - b1) * ig1};
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < CHUNK; ++k) {
+      const int rl = rgx + RG * (i0 + k);
+      if (rl < N) {
+        unsigned p0, p1;
+        split2(k0 * (dz[i0 + k][0] - m10 - x[k][0] * m20), k1 * (dz[i0 + k][1] - m11 - x[k][1] * m21), p0, p1);
+        const size_t at = kb_index(col0 + rl, ch, ncols);
+        *reinterpret_cast<unsigned*>(dYp + at) = p0;
+        *reinterpret_cast<unsigned*>(dYp + dy_plane + at) = p1;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // ---- head: logits[col] = sum_c w[c] a[col][c] + b (Conv1d(256 -> 1)); one 16-lane row per column ----------------------------
 __global__ void __launch_bounds__(256)
 est_head_fwd_kernel(const bf16_t* __restrict__ planes, size_t plane_stride, int C, int ncols, const float* __restrict__ w,
@@ -1169,8 +1424,10 @@ est_head_fwd_kernel(const bf16_t* __restrict__ planes, size_t plane_stride, int 
 // eight column groups): the 16 channel pairs of a K block read one contiguous 64-byte row per column.
 __global__ void __launch_bounds__(256)
 est_head_dw_kernel(const bf16_t* __restrict__ planes, size_t plane_stride, int C, int ncols, int cols_per_block,
-                   const float* __restrict__ dlogit, float* __restrict__ part) {
+                   const float* __restrict__ dlogit, float* __restrict__ part, float* __restrict__ bias_part) {
   __shared__ float red[8][64];
+  __shared__ float redb[8];
+  float sd = 0.f;  // bias_part[block] = sum of dlogit over the block's columns (the head bias gradient's partials; round 6: was a launch of its own)
   const int c0 = (int)blockIdx.x * cols_per_block;
   int c1 = c0 + cols_per_block;
   c1 = (c1 < ncols) ? c1 : ncols;
@@ -1196,6 +1453,7 @@ est_head_dw_kernel(const bf16_t* __restrict__ planes, size_t plane_stride, int C
           s0 = fmaf(bf16_lo(u0[u]) + bf16_lo(u1[u]), d[u], s0);
           s1 = fmaf(bf16_hi(u0[u]) + bf16_hi(u1[u]), d[u], s1);
         }
+        if (cb == 0) sd += (d[0] + d[1]) + (d[2] + d[3]);
       }
       for (; col < c1; col += 8) {
         const size_t at = kb_index((size_t)col, ch, (size_t)ncols);
@@ -1204,10 +1462,14 @@ est_head_dw_kernel(const bf16_t* __restrict__ planes, size_t plane_stride, int C
         const float d = dlogit[col];
         s0 = fmaf(bf16_lo(u0) + bf16_lo(u1), d, s0);
         s1 = fmaf(bf16_hi(u0) + bf16_hi(u1), d, s1);
+        if (cb == 0) sd += d;
       }
     }
     red[cg][2 * cp] = s0; red[cg][2 * cp + 1] = s1;
+    if (cb == 0 && cp == 0) redb[cg] = sd;  // (C >= 32: channel pair 0 exists and saw every column of its group)
     __syncthreads();
+    if (cb == 0 && bias_part != nullptr && threadIdx.x == 0)
+      bias_part[blockIdx.x] = ((redb[0] + redb[1]) + (redb[2] + redb[3])) + ((redb[4] + redb[5]) + (redb[6] + redb[7]));
     if (threadIdx.x < 64 && cb + (int)threadIdx.x < C) {
       float t = 0.f;
 #pragma unroll
@@ -1269,7 +1531,7 @@ est_absmax_kernel(const float* __restrict__ src, long n, unsigned* __restrict__ 
 // are a few microseconds of bookkeeping each -- per layer a maximum, a split, a transposed split, three reductions, three fills.  These
 // kernels do a call's worth of each in ONE launch, the per-layer pointers travelling in the kernel arguments.
 constexpr int kTabMax = 8;    // hidden layers per table (the reference's estimator has five)
-constexpr int kSegMax = 32;   // reduction segments per launch
+constexpr int kSegMax = 40;   // reduction segments per launch (>= 2 + 4 kTabMax: one backward never needs a second launch)
 struct WprepTab {
   int n;
   const float* W[kTabMax];   // [Co][Ci] fp32
@@ -1352,8 +1614,16 @@ struct ColSumTab {
   const float* src[kSegMax];
   float* dst[kSegMax];
   int rows[kSegMax], cols[kSegMax];
+  int ld_src[kSegMax], ld_dst[kSegMax];  // ld_dst > 0: the sums are a [cols / ld_src][ld_src] matrix of which the first ld_dst columns are kept, densely
+                                         // (the first layer's weight gradient without its zero-padded input channels; round 6: was a launch of its own)
   int first_block[kSegMax + 1];  // prefix sums of the segments' workgroup counts
 };
+__device__ __forceinline__ void colsum_store(const ColSumTab& T, int seg, int c, float v) {
+  const int ls = T.ld_src[seg], ld = T.ld_dst[seg];
+  if (ld <= 0) { T.dst[seg][c] = v; return; }
+  const int r = c / ls, k = c - r * ls;
+  if (k < ld) T.dst[seg][(size_t)r * ld + k] = v;
+}
 __host__ __device__ inline int colsum_blocks(int rows, int cols) { return rows > 32 ? (cols + 63) / 64 : (cols + 1023) / 1024; }
 __global__ void __launch_bounds__(1024) est_colsum_kernel(const ColSumTab T) {
   __shared__ float red[16][64];
@@ -1366,7 +1636,7 @@ __global__ void __launch_bounds__(1024) est_colsum_kernel(const ColSumTab T) {
     if (c >= cols) return;
     float s = 0.f;
     for (int r = 0; r < rows; ++r) s += src[(size_t)r * cols + c];
-    T.dst[seg][c] = s;
+    colsum_store(T, seg, c, s);
     return;
   }
   const int c = blk * 64 + (int)(threadIdx.x & 63), g = (int)(threadIdx.x >> 6);
@@ -1386,7 +1656,7 @@ __global__ void __launch_bounds__(1024) est_colsum_kernel(const ColSumTab T) {
     float t = red[0][threadIdx.x];
 #pragma unroll
     for (int q = 1; q < 16; ++q) t += red[q][threadIdx.x];
-    T.dst[seg][c] = t;
+    colsum_store(T, seg, c, t);
   }
 }
 
@@ -1399,7 +1669,7 @@ extern "C" int dfepe_est_points(void) { return kPts; }
 static bool small_grid(const dim3& grid) {
   static const char* force = getenv("DFEPE_EST_SMALL_GRID");
   if (force) return force[0] == '1';
-  return (size_t)grid.x * grid.y <= 256;  // one workgroup per CU at most: the two-stage build's 86 KB of LDS admit no second one
+  return (size_t)grid.x * grid.y * grid.z <= 256;  // one workgroup per CU at most: the two-stage build's 86 KB of LDS admit no second one
 }
 
 extern "C" int dfepe_est_absmax(const float* src, long n, unsigned* word, void* stream) {
@@ -1433,8 +1703,10 @@ extern "C" int dfepe_est_wprep(int n_layers, const float* const* W, const int* C
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
-// dst[s][c] = sum_r src[s][r][c] for n_seg <= 32 segments in one launch (rows[s] = 0: zeros; src[s] may then be null)
-extern "C" int dfepe_est_colsum(int n_seg, const float* const* src, const int* rows, const int* cols, float* const* dst, void* stream) {
+// dst[s][c] = sum_r src[s][r][c] for n_seg <= kSegMax segments in one launch (rows[s] = 0: zeros; src[s] may then be null); ld_src / ld_dst
+// (null: plain): segment s is a [cols / ld_src][ld_src] matrix of which the first ld_dst columns are stored densely
+static int colsum_launch(int n_seg, const float* const* src, const int* rows, const int* cols, float* const* dst, const int* ld_src,
+                         const int* ld_dst, void* stream) {
   if (n_seg <= 0 || n_seg > kSegMax || !src || !rows || !cols || !dst) return DFEPE_ERR_INVALID_ARG;
   ColSumTab T{};
   T.n = n_seg;
@@ -1442,12 +1714,17 @@ extern "C" int dfepe_est_colsum(int n_seg, const float* const* src, const int* r
   for (int s = 0; s < n_seg; ++s) {
     if (rows[s] < 0 || cols[s] <= 0 || !dst[s] || (rows[s] > 0 && !src[s])) return DFEPE_ERR_INVALID_ARG;
     T.src[s] = src[s]; T.dst[s] = dst[s]; T.rows[s] = rows[s]; T.cols[s] = cols[s];
+    T.ld_src[s] = ld_src ? ld_src[s] : 0; T.ld_dst[s] = ld_dst ? ld_dst[s] : 0;
+    if (T.ld_dst[s] > 0 && (T.ld_src[s] < T.ld_dst[s] || cols[s] % T.ld_src[s])) return DFEPE_ERR_INVALID_ARG;
     T.first_block[s] = blocks;
     blocks += colsum_blocks(rows[s], cols[s]);
   }
   T.first_block[n_seg] = blocks;
   hipLaunchKernelGGL(est_colsum_kernel, dim3(blocks), dim3(1024), 0, static_cast<hipStream_t>(stream), T);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+extern "C" int dfepe_est_colsum(int n_seg, const float* const* src, const int* rows, const int* cols, float* const* dst, void* stream) {
+  return colsum_launch(n_seg, src, rows, cols, dst, nullptr, nullptr, stream);
 }
 
 extern "C" int dfepe_est_split_f16(const float* src, long rows, int C_src, int src_ld, int C, const unsigned* absmax, void* planes,
@@ -1496,13 +1773,15 @@ extern "C" int dfepe_est_layer_fwd(const void* W, size_t w_plane, const void* X,
 }
 
 // the forward's plain product (any number of points per pair): out[col][m] fp32 = (1 / s) sum_terms A_i[m][:] . B_j[col][:] on two
-// fp16 planes each, A split scaled by s (absmax as above, or null)
-extern "C" int dfepe_est_gemm_nt_f16(const void* A, size_t a_plane, const void* B, size_t b_plane, int M, int ncols, int K,
-                                     const unsigned* absmax, float* out, int ldc, void* stream) {
+// fp16 planes each, A split scaled by s (absmax as above, or null).  splits = S > 1 (round 6): S workgroups share a tile's K steps and leave
+// S partial products out[z][col][m], z < S, split_stride floats apart -- summed by dfepe_est_norm_fwd_r
+static int nt_f16_launch(const void* A, size_t a_plane, const void* B, size_t b_plane, int M, int ncols, int K, const unsigned* absmax,
+                         float* out, int ldc, int splits, size_t split_stride, void* stream) {
   if (!A || !B || !out || M <= 0 || (M & 7) || ncols <= 0 || K <= 0 || (K % BK) || ldc < M || (ldc & 3)) return DFEPE_ERR_INVALID_ARG;
+  if (splits < 1 || splits > K / BK || (splits > 1 && split_stride < (size_t)ncols * ldc)) return DFEPE_ERR_INVALID_ARG;
   EpiArgs E{};
-  E.out = out; E.ldc = ldc; E.absmax = absmax;
-  const dim3 grid((ncols + BSTEP - 1) / BSTEP, (M + BM - 1) / BM), block(256);
+  E.out = out; E.ldc = ldc; E.absmax = absmax; E.split_stride = split_stride;
+  const dim3 grid((ncols + BSTEP - 1) / BSTEP, (M + BM - 1) / BM, splits), block(256);
   if (small_grid(grid))
     hipLaunchKernelGGL((est_gemm_nt_kernel<2, 2, 1, EPI_F32, FMT_F16, 2>), grid, block, 0, static_cast<hipStream_t>(stream),
                        static_cast<const bf16_t*>(A), a_plane, static_cast<const bf16_t*>(B), b_plane, M, ncols, K, E);
@@ -1511,15 +1790,28 @@ extern "C" int dfepe_est_gemm_nt_f16(const void* A, size_t a_plane, const void* 
                        static_cast<const bf16_t*>(A), a_plane, static_cast<const bf16_t*>(B), b_plane, M, ncols, K, E);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
+extern "C" int dfepe_est_gemm_nt_f16(const void* A, size_t a_plane, const void* B, size_t b_plane, int M, int ncols, int K,
+                                     const unsigned* absmax, float* out, int ldc, void* stream) {
+  return nt_f16_launch(A, a_plane, B, b_plane, M, ncols, K, absmax, out, ldc, 1, 0, stream);
+}
+extern "C" int dfepe_est_gemm_nt_f16_splitk(const void* A, size_t a_plane, const void* B, size_t b_plane, int M, int ncols, int K,
+                                            const unsigned* absmax, float* out, int ldc, int splits, size_t split_stride, void* stream) {
+  return nt_f16_launch(A, a_plane, B, b_plane, M, ncols, K, absmax, out, ldc, splits, split_stride, stream);
+}
 
-// plain product: out[col][m] (fp32, ld = ldc) = sum_terms A_i[m][:] . B_j[col][:]; n_planes = 2 (three products) or 3 (six)
-extern "C" int dfepe_est_gemm_nt(const void* A, size_t a_plane, const void* B, size_t b_plane, int M, int ncols, int K, int n_planes,
-                                 float* out, int ldc, void* stream) {
-  if (!A || !B || !out || M <= 0 || (M & 7) || ncols <= 0 || K <= 0 || (K % BK) || ldc < M || (ldc & 3)) return DFEPE_ERR_INVALID_ARG;
+// plain product: out[col][m] (fp32, ld = ldc) = sum_terms A_i[m][:] . B_j[col][:]; n_planes = 2 (three products) or 3 (six); splits as above
+// (two planes only); gx != null (two planes, splits = 1): the product is the gradient w.r.t. the estimator's input and is stored as
+// gx[pair][ch][n], ch < gx_C0, col = pair * gx_N + n, instead of out (round 6: was a transposing launch of its own)
+static int nt_bf16_launch(const void* A, size_t a_plane, const void* B, size_t b_plane, int M, int ncols, int K, int n_planes, float* out,
+                          int ldc, int splits, size_t split_stride, float* gx, int gx_C0, int gx_N, void* stream) {
+  if (!A || !B || (!out && !gx) || M <= 0 || (M & 7) || ncols <= 0 || K <= 0 || (K % BK)) return DFEPE_ERR_INVALID_ARG;
+  if (!gx && (ldc < M || (ldc & 3))) return DFEPE_ERR_INVALID_ARG;
+  if (gx && (gx_C0 <= 0 || gx_C0 > M || gx_N <= 0 || (ncols % gx_N) || splits != 1 || n_planes != 2)) return DFEPE_ERR_INVALID_ARG;
   if (n_planes != 2 && n_planes != 3) return DFEPE_ERR_INVALID_ARG;
+  if (splits < 1 || splits > K / BK || (splits > 1 && (n_planes != 2 || split_stride < (size_t)ncols * ldc))) return DFEPE_ERR_INVALID_ARG;
   EpiArgs E{};
-  E.out = out; E.ldc = ldc;
-  const dim3 grid((ncols + BSTEP - 1) / BSTEP, (M + BM - 1) / BM), block(256);
+  E.out = out; E.ldc = ldc; E.split_stride = split_stride; E.gx = gx; E.gx_C0 = gx_C0; E.gx_N = gx_N;
+  const dim3 grid((ncols + BSTEP - 1) / BSTEP, (M + BM - 1) / BM, splits), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (n_planes == 3)
     hipLaunchKernelGGL((est_gemm_nt_kernel<3, 3, 2, EPI_F32>), grid, block, 0, st, static_cast<const bf16_t*>(A), a_plane,
@@ -1531,6 +1823,18 @@ extern "C" int dfepe_est_gemm_nt(const void* A, size_t a_plane, const void* B, s
     hipLaunchKernelGGL((est_gemm_nt_kernel<2, 2, 1, EPI_F32>), grid, block, 0, st, static_cast<const bf16_t*>(A), a_plane,
                        static_cast<const bf16_t*>(B), b_plane, M, ncols, K, E);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+extern "C" int dfepe_est_gemm_nt(const void* A, size_t a_plane, const void* B, size_t b_plane, int M, int ncols, int K, int n_planes,
+                                 float* out, int ldc, void* stream) {
+  return nt_bf16_launch(A, a_plane, B, b_plane, M, ncols, K, n_planes, out, ldc, 1, 0, nullptr, 0, 0, stream);
+}
+extern "C" int dfepe_est_gemm_nt_splitk(const void* A, size_t a_plane, const void* B, size_t b_plane, int M, int ncols, int K, float* out,
+                                        int ldc, int splits, size_t split_stride, void* stream) {
+  return nt_bf16_launch(A, a_plane, B, b_plane, M, ncols, K, 2, out, ldc, splits, split_stride, nullptr, 0, 0, stream);
+}
+extern "C" int dfepe_est_gemm_nt_gx(const void* A, size_t a_plane, const void* B, size_t b_plane, int M, int ncols, int K, float* gx, int C0,
+                                    int N, void* stream) {
+  return nt_bf16_launch(A, a_plane, B, b_plane, M, ncols, K, 2, nullptr, 0, 1, 0, gx, C0, N, stream);
 }
 
 // data gradient + the adjoint of the layer below in one launch (N = dfepe_est_points()):
@@ -1563,6 +1867,29 @@ extern "C" int dfepe_est_gemm_tn(const void* dY, size_t dy_plane, int Cout, cons
   const dim3 grid((Cout + 127) / 128, (Cin + 127) / 128, slices), block(256);
   hipLaunchKernelGGL(est_gemm_tn_kernel, grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(dY), dy_plane, Cout,
                      static_cast<const bf16_t*>(X), x_plane, Cin, ncols, cps, part);
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
+// the weight-gradient partials of n_layers <= 8 layers over the same ncols columns in ONE launch (host arrays indexed by layer)
+extern "C" int dfepe_est_gemm_tn_multi(int n_layers, const void* const* dY, const size_t* dy_plane, const int* Cout, const void* const* X,
+                                       const size_t* x_plane, const int* Cin, int ncols, const int* slices, float* const* part, void* stream) {
+  if (n_layers <= 0 || n_layers > 8 || !dY || !dy_plane || !Cout || !X || !x_plane || !Cin || !slices || !part || ncols <= 0)
+    return DFEPE_ERR_INVALID_ARG;
+  TnTab T{};
+  T.n = n_layers;
+  int blocks = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    if (!dY[l] || !X[l] || !part[l] || Cout[l] <= 0 || Cin[l] <= 0 || (Cout[l] & 31) || (Cin[l] & 31) || slices[l] <= 0) return DFEPE_ERR_INVALID_ARG;
+    int cps = (ncols + slices[l] - 1) / slices[l];
+    cps = ((cps + BK - 1) / BK) * BK;
+    T.dY[l] = static_cast<const bf16_t*>(dY[l]); T.X[l] = static_cast<const bf16_t*>(X[l]); T.dy_plane[l] = dy_plane[l]; T.x_plane[l] = x_plane[l];
+    T.Cout[l] = Cout[l]; T.Cin[l] = Cin[l]; T.nx[l] = (Cout[l] + 127) / 128; T.ny[l] = (Cin[l] + 127) / 128; T.slices[l] = slices[l]; T.cps[l] = cps;
+    T.part[l] = part[l];
+    T.first_block[l] = blocks;
+    blocks += (T.nx[l] * T.ny[l] * slices[l] + 7) / 8 * 8;
+  }
+  T.first_block[n_layers] = blocks;
+  hipLaunchKernelGGL(est_gemm_tn_multi_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), T, ncols);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
@@ -1755,6 +2082,54 @@ extern "C" int dfepe_est_in_bwd_n(const float* dA, const float* dlogit, const fl
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
+// round 6: InstanceNorm + LeakyReLU + split of a plain product held in registers (N <= 2048), the product given as `splits` partials
+// Y[z][n_pairs * N][ldy] (split_stride floats apart; splits = 1: the plain product).  One launch, one read of Y.
+extern "C" int dfepe_est_norm_fwd_r(const float* Y, int ldy, int splits, size_t split_stride, int C, long n_pairs, int N, const float* gamma,
+                                    const float* beta, float eps, float slope, void* planes_out, size_t out_plane, void* planes_bwd,
+                                    size_t bwd_plane, float* rstd, void* stream) {
+  if (!Y || !gamma || !beta || !planes_out || !rstd || C <= 0 || (C & 31) || ldy < C || (ldy & 1) || n_pairs < 0 || N <= 0 || N > 2048)
+    return DFEPE_ERR_INVALID_ARG;
+  if (splits < 1 || splits > 64) return DFEPE_ERR_INVALID_ARG;
+  if (!(slope > 0.f)) return DFEPE_ERR_UNSUPPORTED;
+  if (n_pairs == 0) return DFEPE_OK;
+  if (n_pairs > 0x7fffffffL) return DFEPE_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)n_pairs, N <= 1024 ? C / 32 : C / 16), block(1024);
+  const size_t ncols = (size_t)n_pairs * N;
+  bf16_t* P = static_cast<bf16_t*>(planes_out);
+  bf16_t* Q = static_cast<bf16_t*>(planes_bwd);
+#define DFEPE_NORM_R(R, CP) hipLaunchKernelGGL((est_norm_fwd_r_kernel<R, CP>), grid, block, 0, st, Y, ldy, split_stride, splits, C, N, ncols, gamma, beta, eps, slope, P, out_plane, Q, bwd_plane, rstd)
+  if (N <= 128) DFEPE_NORM_R(2, 16);
+  else if (N <= 512) DFEPE_NORM_R(8, 16);
+  else if (N <= 1024) DFEPE_NORM_R(16, 16);
+  else DFEPE_NORM_R(16, 8);
+#undef DFEPE_NORM_R
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+// ... and its adjoint: dA given as `splits` partials [z][n_pairs * N][ldd] (or the head's rank-one form: dA null)
+extern "C" int dfepe_est_in_bwd_r(const float* dA, int ldd, int splits, size_t split_stride, const float* dlogit, const float* w_head,
+                                  const void* planes, size_t plane_stride, const float* rstd, const float* gamma, const float* beta,
+                                  float slope, int C, long n_pairs, int N, void* dY, size_t dy_plane, float* dgamma_part, float* dbeta_part,
+                                  void* stream) {
+  if ((!dA && !(dlogit && w_head)) || !planes || !rstd || !gamma || !beta || !dY || !dgamma_part || !dbeta_part) return DFEPE_ERR_INVALID_ARG;
+  if (C <= 0 || (C & 31) || n_pairs < 0 || N <= 0 || N > 2048 || !(slope > 0.f)) return DFEPE_ERR_INVALID_ARG;
+  if (dA && (ldd < C || (ldd & 1) || splits < 1 || splits > 64)) return DFEPE_ERR_INVALID_ARG;
+  if (n_pairs == 0) return DFEPE_OK;
+  if (n_pairs > 0x7fffffffL) return DFEPE_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)n_pairs, N <= 1024 ? C / 32 : C / 16), block(1024);
+  const size_t ncols = (size_t)n_pairs * N;
+  const bf16_t* P = static_cast<const bf16_t*>(planes);
+  bf16_t* D = static_cast<bf16_t*>(dY);
+#define DFEPE_INBWD_R(R, CP) hipLaunchKernelGGL((est_in_bwd_r_kernel<R, CP>), grid, block, 0, st, dA, ldd, split_stride, splits, dlogit, w_head, P, plane_stride, rstd, gamma, beta, slope, C, N, ncols, D, dy_plane, dgamma_part, dbeta_part)
+  if (N <= 128) DFEPE_INBWD_R(2, 16);
+  else if (N <= 512) DFEPE_INBWD_R(8, 16);
+  else if (N <= 1024) DFEPE_INBWD_R(16, 16);
+  else DFEPE_INBWD_R(16, 8);
+#undef DFEPE_INBWD_R
+  return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
+}
+
 extern "C" int dfepe_est_head_fwd(const void* planes, size_t plane_stride, int C, int ncols, const float* w, const float* bias,
                                   float* logits, void* stream) {
   if (!planes || !w || !logits || C <= 0 || (C & 31) || ncols <= 0) return DFEPE_ERR_INVALID_ARG;
@@ -1764,22 +2139,32 @@ extern "C" int dfepe_est_head_fwd(const void* planes, size_t plane_stride, int C
 }
 
 extern "C" int dfepe_est_head_dw(const void* planes, size_t plane_stride, int C, int ncols, int blocks, const float* dlogit, float* part,
-                                 void* stream) {
+                                 float* bias_part, void* stream) {
   if (!planes || !dlogit || !part || C <= 0 || (C & 31) || ncols <= 0 || blocks <= 0) return DFEPE_ERR_INVALID_ARG;
   const int cpb = (ncols + blocks - 1) / blocks;
   hipLaunchKernelGGL(est_head_dw_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(planes),
-                     plane_stride, C, ncols, cpb, dlogit, part);
+                     plane_stride, C, ncols, cpb, dlogit, part, bias_part);
   return (hipGetLastError() == hipSuccess) ? DFEPE_OK : DFEPE_ERR_HIP;
 }
 
 // =====================================================================================================================================
 // One estimator pass per call (round 5): dfepe_est_forward / dfepe_est_backward run the whole Conv1d -> InstanceNorm -> LeakyReLU stack and
-// its head (one output channel) through the entry points above, in the order the host code of estimator.py used to issue them -- the
-// same kernels on the same data, so the results are bit-identical.  Why: at the reference's batch sizes the HOST is the limiter of the
-// eager training step (Python spent ~0.27 ms per forward and more per backward on ~30 launches, ~40 allocations and their bookkeeping:
-// more than the GPU needs for the whole model's step).  The caller brings three buffers -- `saved` (what the backward reads: the layers'
-// bf16 planes, reciprocal deviations, transposed weight planes), a transient workspace per pass, the outputs -- whose sizes the
-// *_bytes functions give; nothing is allocated here.
+// its head (one output channel) through the entry points above.  Why: at the reference's batch sizes the HOST is the limiter of the eager
+// training step (Python spent ~0.27 ms per forward and more per backward on ~30 launches, ~40 allocations and their bookkeeping: more than
+// the GPU needs for the whole model's step).  The caller brings three buffers -- `saved` (what the backward reads: the layers' bf16
+// planes, reciprocal deviations, transposed weight planes), a transient workspace per pass, the outputs -- whose sizes the *_bytes
+// functions give; nothing is allocated here.
+//
+// Round 6 -- the step a train_good.py user runs (N = 1000-2000 points, 4-12 pairs: deepFEPE/configs/kitti_corr_baseline.yaml:12-13):
+//   * every layer has a PLAN (fwd_plan / dgrad_plan): the fused epilogue (N = 100, grid large enough), or the plain product -- split over
+//     S slices of K where a batch of a few pairs leaves a K-heavy layer on a dozen workgroups -- followed by ONE register-resident
+//     normalisation launch that adds the slices (est_norm_fwd_r / est_in_bwd_r: N <= 2048; beyond, the strided kernels of round 4);
+//   * `prep` (dfepe_est_prepare): the weights' planes made ONCE per model forward for an estimator that is called several times in it
+//     (DeepFNet.update_weights: depth - 1 calls, deepFEPE/models/DeepFNet.py:510) instead of once per call;
+//   * over few columns (all dY of a backward alive together: the gamma == 0 fix already wanted that) the five weight-gradient GEMMs are
+//     ONE table-driven launch at the end (est_gemm_tn_multi);
+//   * the head bias partials ride in est_head_dw, the first layer's cropped weight gradient in est_colsum, the input gradient's
+//     transposition in its GEMM's epilogue: three launches per call gone.
 namespace {
 
 constexpr size_t kAlign = 256;
@@ -1791,11 +2176,13 @@ struct PassDims {
   int Co[kTabMax], Ci[kTabMax], K[kTabMax];
   long B; int N; long cols;
   int C0, K0, Cmax, Kmax;
-  bool fused;         // N == kPts
+  bool fusable;       // N == kPts: the fused epilogues exist
+  bool resident;      // N <= 2048: the register-resident normalisation kernels serve the plain products
 };
 int pass_dims(PassDims& D, int n_hidden, const int* Co, const int* Ci, long B, int C0, int N) {
   if (n_hidden <= 0 || n_hidden > kTabMax || !Co || !Ci || B <= 0 || N < 2 || C0 <= 0 || B * (long)N >= (1L << 31)) return DFEPE_ERR_INVALID_ARG;
-  D.n = n_hidden; D.B = B; D.N = N; D.cols = B * (long)N; D.C0 = C0; D.K0 = pad32(C0); D.Cmax = 0; D.Kmax = 0; D.fused = (N == kPts);
+  D.n = n_hidden; D.B = B; D.N = N; D.cols = B * (long)N; D.C0 = C0; D.K0 = pad32(C0); D.Cmax = 0; D.Kmax = 0;
+  D.fusable = (N == kPts); D.resident = (N <= 2048);
   for (int l = 0; l < n_hidden; ++l) {
     if (Co[l] <= 0 || (Co[l] & 31) || Ci[l] != (l ? Co[l - 1] : C0)) return DFEPE_ERR_INVALID_ARG;
     D.Co[l] = Co[l]; D.Ci[l] = Ci[l]; D.K[l] = pad32(Ci[l]);
@@ -1818,6 +2205,48 @@ int slices_for(int cout, int cin, long cols) {  // estimator.py: _slices_for (TN
   s = s < cols / 256 ? s : cols / 256;
   s = s > 1 ? s : 1;
   return (int)(s >= 8 ? s - s % 8 : s);
+}
+
+// How one GEMM of a pass runs: through its fused epilogue, or as S partial products + a normalisation launch.
+// DFEPE_EST_SPLITK = 0: fused wherever it exists and never split (round 5's behaviour); 2: the plain product wherever it can serve (A/B timing)
+struct Plan { bool fused; int S; };
+int splitk_mode() {
+  static const char* e = getenv("DFEPE_EST_SPLITK");
+  return e ? (e[0] - '0') : 1;
+}
+Plan gemm_plan(const PassDims& D, int M, int K, bool fusable) {
+  const long tiles = ((D.cols + BSTEP - 1) / BSTEP) * ((M + BM - 1) / BM);
+  const int nk = K / BK, mode = splitk_mode();
+  Plan P{fusable, 1};
+  if (!D.resident || mode == 0) return P;  // the strided kernels of round 4 take one plain product
+  // a K-heavy product on a few workgroups is a chain of K steps with most of the chip idle: slices of >= 4 K steps each, up to ~256
+  // workgroups, at most eight partials for the normalisation launch to add
+  long S = 1;
+  if (tiles < 128 && nk >= 8) {
+    S = 256 / tiles;
+    S = S < nk / 4 ? S : nk / 4;
+    S = S < 8 ? S : 8;
+    S = S > 1 ? S : 1;
+  }
+  if (fusable && mode != 2 && !(tiles <= 64 && nk >= 8)) return P;  // the fused epilogue: one launch, nothing written twice
+  P.fused = false; P.S = (int)S;
+  return P;
+}
+Plan fwd_plan(const PassDims& D, int l) { return gemm_plan(D, D.Co[l], D.K[l], D.fusable); }
+// the data gradient of layer l (>= 1) = the upstream gradient of layer l - 1: M = K[l] rows (= Co[l - 1]), contraction over Co[l]
+Plan dgrad_plan(const PassDims& D, int l) { return gemm_plan(D, D.K[l], D.Co[l], D.fusable && D.Ci[l] == D.K[l]); }
+
+// the weights' planes of one estimator, made once and shared by its calls: words | fp16 planes per layer | transposed bf16 planes per layer
+struct PrepLayout { size_t words, absws, wf[kTabMax], wt[kTabMax], total; };
+PrepLayout prep_layout(int n, const int* Co, const int* Ci) {
+  PrepLayout P{};
+  size_t at = 0;
+  P.words = at; at += up(sizeof(unsigned) * kTabMax);
+  P.absws = at; at += up(dfepe_est_wprep_workspace_bytes(n));
+  for (int l = 0; l < n; ++l) { P.wf[l] = at; at += up((size_t)2 * Co[l] * pad32(Ci[l]) * 2); }
+  for (int l = 0; l < n; ++l) { P.wt[l] = at; at += up((size_t)2 * pad32(Ci[l]) * Co[l] * 2); }
+  P.total = at;
+  return P;
 }
 
 // what the backward reads, laid out in `saved`
@@ -1851,15 +2280,20 @@ FwdLayout fwd_layout(const PassDims& D, bool keep) {
   F.ping = at; at += up((size_t)2 * D.cols * c_even * 2);
   F.pong = at; at += up((size_t)2 * D.cols * c_odd * 2);
   F.rstd_scratch = at; if (!keep) at += up((size_t)D.B * D.Cmax * 4);
-  F.Y = at; F.npart = at;
-  if (!D.fused) { at += up((size_t)D.cols * D.Cmax * 4); F.npart = at; at += up((size_t)D.B * 64 * 2 * D.Cmax * 4); }
+  size_t ybytes = 0;  // the largest plain product of the pass, its split-K partials included
+  for (int l = 0; l < D.n; ++l) {
+    const Plan P = fwd_plan(D, l);
+    if (!P.fused) { const size_t b = (size_t)P.S * D.cols * D.Co[l] * 4; ybytes = b > ybytes ? b : ybytes; }
+  }
+  F.Y = at; at += up(ybytes);
+  F.npart = at; if (!D.resident) at += up((size_t)D.B * 64 * 2 * D.Cmax * 4);
   F.total = at;
   return F;
 }
 struct BwdLayout {
-  size_t hpart, bpart, dY[kTabMax], dg[kTabMax], db[kTabMax], partw[kTabMax], dA, npart, wtmp, total;
+  size_t hpart, bpart, dY[kTabMax], dg[kTabMax], db[kTabMax], partw[kTabMax], dA, npart, total;
   int slices[kTabMax];
-  bool fix_at_end;
+  bool keep_all;  // every layer's dY stays alive to the end of the backward: one gamma == 0 launch and one weight-gradient launch there
 };
 BwdLayout bwd_layout(const PassDims& D, bool need_gx) {
   BwdLayout L{};
@@ -1868,9 +2302,9 @@ BwdLayout bwd_layout(const PassDims& D, bool need_gx) {
   L.bpart = at; at += up((size_t)512 * 4);
   size_t dy_total = 0;
   for (int l = 0; l < D.n; ++l) dy_total += (size_t)D.cols * D.Co[l] * 4;
-  // (fused path only: the plain data gradients of the generic path share ONE dA buffer, which a fix deferred to the end would find overwritten)
-  L.fix_at_end = D.fused && dy_total <= ((size_t)64 << 20);
-  if (L.fix_at_end) {
+  L.keep_all = dy_total <= ((size_t)64 << 20);
+  if (const char* e = getenv("DFEPE_EST_KEEP_ALL")) L.keep_all = e[0] == '1';  // tests: both branches at any size
+  if (L.keep_all) {
     for (int l = 0; l < D.n; ++l) { L.dY[l] = at; at += up((size_t)2 * D.cols * D.Co[l] * 2); }
   } else {  // two buffers taking turns: dY of layer l is read while dY of layer l - 1 is written
     int ca = 0, cb = 0;
@@ -1885,10 +2319,14 @@ BwdLayout bwd_layout(const PassDims& D, bool need_gx) {
     L.slices[l] = slices_for(D.Co[l], D.K[l], D.cols);
     L.partw[l] = at; at += up((size_t)L.slices[l] * D.Co[l] * D.K[l] * 4);
   }
-  L.dA = at;
-  if (!D.fused || need_gx) at += up((size_t)D.cols * (D.fused ? D.K0 : D.Kmax) * 4);
-  L.npart = at; if (!D.fused) at += up((size_t)D.B * 64 * 2 * D.Cmax * 4);
-  L.wtmp = at; if (D.K0 != D.C0) at += up((size_t)D.Co[0] * D.K0 * 4);
+  size_t dabytes = 0;  // the largest data gradient that is written (not fused, not the input's: that one goes straight to gx)
+  for (int l = 1; l < D.n; ++l) {
+    const Plan P = dgrad_plan(D, l);
+    if (!P.fused) { const size_t b = (size_t)P.S * D.cols * D.K[l] * 4; dabytes = b > dabytes ? b : dabytes; }
+  }
+  (void)need_gx;
+  L.dA = at; at += up(dabytes);
+  L.npart = at; if (!D.resident) at += up((size_t)D.B * 64 * 2 * D.Cmax * 4);
   L.total = at;
   return L;
 }
@@ -1927,33 +2365,6 @@ est_input_split_kernel(const float* __restrict__ x, long B, int C0, int N, int K
     }
   }
 }
-// dst[r][c] = src[r][c], c < width (rows of ld_src floats into rows of `width`): the first layer's weight gradient without its padding
-__global__ void __launch_bounds__(256) est_crop_kernel(const float* __restrict__ src, int ld_src, int rows, int width, float* __restrict__ dst) {
-  const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
-  if (i >= rows * width) return;
-  const int r = i / width, c = i - r * width;
-  dst[i] = src[(size_t)r * ld_src + c];
-}
-// gx[b][c][n] = dA[(b N + n) ld + c], c < C0
-__global__ void __launch_bounds__(256) est_gx_kernel(const float* __restrict__ dA, int ld, long B, int C0, int N, float* __restrict__ gx) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= B * (long)C0 * N) return;
-  const long n = i % N, c = (i / N) % C0, b = i / ((long)N * C0);
-  gx[i] = dA[((size_t)b * N + n) * ld + c];
-}
-// part[block] = sum of dlogit over the block's columns (the head bias gradient's partial sums, same blocks as est_head_dw)
-__global__ void __launch_bounds__(256) est_head_db_kernel(const float* __restrict__ dlogit, int ncols, int cols_per_block, float* __restrict__ part) {
-  __shared__ float red[4];
-  const int c0 = (int)blockIdx.x * cols_per_block;
-  int c1 = c0 + cols_per_block;
-  c1 = c1 < ncols ? c1 : ncols;
-  float s = 0.f;
-  for (int c = c0 + (int)threadIdx.x; c < c1; c += 256) s += dlogit[c];
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-}
 
 }  // namespace
 
@@ -1974,25 +2385,47 @@ extern "C" size_t dfepe_est_backward_workspace_bytes(int n_hidden, const int* Co
   if (pass_dims(D, n_hidden, Co, Ci, B, C0, N) != DFEPE_OK) return 0;
   return bwd_layout(D, need_gx != 0).total;
 }
+extern "C" size_t dfepe_est_prep_bytes(int n_hidden, const int* Co, const int* Ci) {
+  if (n_hidden <= 0 || n_hidden > kTabMax || !Co || !Ci) return 0;
+  for (int l = 0; l < n_hidden; ++l)
+    if (Co[l] <= 0 || (Co[l] & 31) || Ci[l] <= 0) return 0;
+  return prep_layout(n_hidden, Co, Ci).total;
+}
+// the weights' planes (scales, scaled fp16 planes for the forward, transposed bf16 planes for the data gradients) of one estimator into
+// `prep` (dfepe_est_prep_bytes, 16-byte aligned): two launches, once per model forward; dfepe_est_forward / _backward given `prep`
+// read them instead of making their own.  The weights must not change between this call and the last backward that is handed `prep`.
+extern "C" int dfepe_est_prepare(int n_hidden, const float* const* W, const int* Co, const int* Ci, void* prep, void* stream) {
+  if (n_hidden <= 0 || n_hidden > kTabMax || !W || !Co || !Ci || !prep || ((uintptr_t)prep & 15)) return DFEPE_ERR_INVALID_ARG;
+  for (int l = 0; l < n_hidden; ++l)
+    if (Co[l] <= 0 || (Co[l] & 31) || Ci[l] <= 0) return DFEPE_ERR_INVALID_ARG;
+  const PrepLayout P = prep_layout(n_hidden, Co, Ci);
+  char* pp = static_cast<char*>(prep);
+  void* pf[kTabMax]; void* pt[kTabMax];
+  for (int l = 0; l < n_hidden; ++l) { pf[l] = pp + P.wf[l]; pt[l] = pp + P.wt[l]; }
+  return dfepe_est_wprep(n_hidden, W, Co, Ci, pf, pt, reinterpret_cast<unsigned*>(pp + P.words), pp + P.absws, stream);
+}
 
 // logits [cols] = head(stack(x)); saved != null: everything dfepe_est_backward needs is left there (need_gx is accepted for symmetry with
 // the size functions and ignored: the first layer's transposed weight planes are a few KB and always kept, so that a backward may ask
 // for gx or not).  x [B][C0][N], W[l] [Co][Ci], gamma / beta [l] [Co], w_head [Co of the last layer], b_head [1] or null: fp32.
+// prep: null, or the planes dfepe_est_prepare made of these very weights.
 extern "C" int dfepe_est_forward(const float* x, long B, int C0, int N, int n_hidden, const float* const* W, const float* const* gamma,
                                  const float* const* beta, const int* Co, const int* Ci, const float* w_head, const float* b_head, float eps,
-                                 float slope, void* saved, int need_gx, void* workspace, float* logits, void* stream) {
+                                 float slope, void* saved, int need_gx, void* workspace, const void* prep, float* logits, void* stream) {
   PassDims D;
   EST_TRY(pass_dims(D, n_hidden, Co, Ci, B, C0, N));
   if (!x || !W || !gamma || !beta || !w_head || !workspace || !logits) return DFEPE_ERR_INVALID_ARG;
-  if (((uintptr_t)workspace & 15) || ((uintptr_t)saved & 15)) return DFEPE_ERR_INVALID_ARG;
+  if (((uintptr_t)workspace & 15) || ((uintptr_t)saved & 15) || ((uintptr_t)prep & 15)) return DFEPE_ERR_INVALID_ARG;
   const bool keep = saved != nullptr;
   const SavedLayout S = saved_layout(D, need_gx != 0);
   const FwdLayout F = fwd_layout(D, keep);
+  const PrepLayout P = prep_layout(D.n, Co, Ci);
   char* ws = static_cast<char*>(workspace);
   char* sv = static_cast<char*>(saved);
+  const char* pp = static_cast<const char*>(prep);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long cols = D.cols;
-  unsigned* words = reinterpret_cast<unsigned*>(keep ? sv + S.words : ws + F.words);
+  const unsigned* words = pp ? reinterpret_cast<const unsigned*>(pp + P.words) : reinterpret_cast<unsigned*>(keep ? sv + S.words : ws + F.words);
   // the input's planes
   {
     const long threads = cols * (D.K0 / 32);
@@ -2001,27 +2434,35 @@ extern "C" int dfepe_est_forward(const float* x, long B, int C0, int N, int n_hi
                        (size_t)cols * D.K0);
     if (hipGetLastError() != hipSuccess) return DFEPE_ERR_HIP;
   }
-  // every layer's weights: scales, fp16 planes, transposed bf16 planes for the backward
-  {
+  // every layer's weights: scales, fp16 planes, transposed bf16 planes for the backward -- unless the caller prepared them
+  if (!pp) {
     void* pf[kTabMax]; void* pt[kTabMax];
     for (int l = 0; l < D.n; ++l) { pf[l] = ws + F.wf[l]; pt[l] = keep ? sv + S.wt[l] : nullptr; }
-    EST_TRY(dfepe_est_wprep(D.n, W, Co, Ci, pf, pt, words, ws + F.absws, stream));
+    EST_TRY(dfepe_est_wprep(D.n, W, Co, Ci, pf, pt, const_cast<unsigned*>(words), ws + F.absws, stream));
   }
   const char* act = ws + F.xh;
   for (int l = 0; l < D.n; ++l) {
     const int C = D.Co[l], K = D.K[l];
+    const void* wf = pp ? static_cast<const void*>(pp + P.wf[l]) : static_cast<const void*>(ws + F.wf[l]);
     char* out = ws + ((l & 1) ? F.pong : F.ping);
     void* out_b = keep ? sv + S.act[l + 1] : nullptr;
     float* rstd = reinterpret_cast<float*>(keep ? sv + S.rstd[l] : ws + F.rstd_scratch);
-    if (D.fused) {
-      EST_TRY(dfepe_est_layer_fwd(ws + F.wf[l], (size_t)C * K, act, (size_t)cols * K, C, (int)cols, K, words + l, gamma[l], beta[l], eps, slope, out,
+    const Plan pl = fwd_plan(D, l);
+    if (pl.fused) {
+      EST_TRY(dfepe_est_layer_fwd(wf, (size_t)C * K, act, (size_t)cols * K, C, (int)cols, K, words + l, gamma[l], beta[l], eps, slope, out,
                                   (size_t)cols * C, out_b, (size_t)cols * C, rstd, stream));
     } else {
       float* Y = reinterpret_cast<float*>(ws + F.Y);
-      EST_TRY(dfepe_est_gemm_nt_f16(ws + F.wf[l], (size_t)C * K, act, (size_t)cols * K, C, (int)cols, K, words + l, Y, C, stream));
-      const int sp = row_splits(B, C, N);
-      EST_TRY(dfepe_est_norm_fwd(Y, C, C, B, N, gamma[l], beta[l], eps, slope, out, (size_t)cols * C, out_b, (size_t)cols * C, rstd, sp,
-                                 sp > 1 ? reinterpret_cast<float*>(ws + F.npart) : nullptr, stream));
+      const size_t ystride = (size_t)cols * C;
+      EST_TRY(nt_f16_launch(wf, (size_t)C * K, act, (size_t)cols * K, C, (int)cols, K, words + l, Y, C, pl.S, ystride, stream));
+      if (D.resident) {
+        EST_TRY(dfepe_est_norm_fwd_r(Y, C, pl.S, ystride, C, B, N, gamma[l], beta[l], eps, slope, out, (size_t)cols * C, out_b, (size_t)cols * C, rstd,
+                                     stream));
+      } else {
+        const int sp = row_splits(B, C, N);
+        EST_TRY(dfepe_est_norm_fwd(Y, C, C, B, N, gamma[l], beta[l], eps, slope, out, (size_t)cols * C, out_b, (size_t)cols * C, rstd, sp,
+                                   sp > 1 ? reinterpret_cast<float*>(ws + F.npart) : nullptr, stream));
+      }
     }
     act = out;
   }
@@ -2029,53 +2470,56 @@ extern "C" int dfepe_est_forward(const float* x, long B, int C0, int N, int n_hi
 }
 
 // every gradient of one dfepe_est_forward(saved != null): g_W[l] [Co][Ci], g_bias[l] [Co] (zeros: the bias cancels in the
-// normalisation), g_gamma[l], g_beta[l] [Co], g_w_head [C], g_b_head [1] or null, gx [B][C0][N] or null (needs need_gx at the forward)
+// normalisation), g_gamma[l], g_beta[l] [Co], g_w_head [C], g_b_head [1] or null, gx [B][C0][N] or null (needs need_gx at the forward);
+// prep: what the forward was given (null: the transposed weight planes are in `saved`)
 extern "C" int dfepe_est_backward(const float* g_logits, long B, int C0, int N, int n_hidden, const float* const* W, const float* const* gamma,
                                   const float* const* beta, const int* Co, const int* Ci, const float* w_head, float slope, const void* saved,
-                                  void* workspace, float* const* g_W, float* const* g_bias, float* const* g_gamma, float* const* g_beta,
-                                  float* g_w_head, float* g_b_head, float* gx, void* stream) {
+                                  void* workspace, const void* prep, float* const* g_W, float* const* g_bias, float* const* g_gamma,
+                                  float* const* g_beta, float* g_w_head, float* g_b_head, float* gx, void* stream) {
   PassDims D;
   EST_TRY(pass_dims(D, n_hidden, Co, Ci, B, C0, N));
   if (!g_logits || !W || !gamma || !beta || !w_head || !saved || !workspace || !g_W || !g_bias || !g_gamma || !g_beta || !g_w_head)
     return DFEPE_ERR_INVALID_ARG;
-  if (((uintptr_t)workspace & 15) || ((uintptr_t)saved & 15)) return DFEPE_ERR_INVALID_ARG;
+  if (((uintptr_t)workspace & 15) || ((uintptr_t)saved & 15) || ((uintptr_t)prep & 15)) return DFEPE_ERR_INVALID_ARG;
   const bool need_gx = gx != nullptr;
   const SavedLayout S = saved_layout(D, need_gx);
   const BwdLayout L = bwd_layout(D, need_gx);
+  const PrepLayout P = prep_layout(D.n, Co, Ci);
   char* ws = static_cast<char*>(workspace);
   const char* sv = static_cast<const char*>(saved);
-  hipStream_t st = static_cast<hipStream_t>(stream);
+  const char* pp = static_cast<const char*>(prep);
   const long cols = D.cols;
   const int n = D.n, Clast = D.Co[n - 1];
-  const float* src[kSegMax]; float* dst[kSegMax]; int rows[kSegMax], ccols[kSegMax];
+  const float* src[kSegMax]; float* dst[kSegMax]; int rows[kSegMax], ccols[kSegMax], lds_[kSegMax], ldd_[kSegMax];
   int nseg = 0;
-  auto seg = [&](const float* s, int r, int c, float* d) { src[nseg] = s; rows[nseg] = r; ccols[nseg] = c; dst[nseg] = d; ++nseg; };
+  auto seg = [&](const float* s, int r, int c, float* d, int ld_src = 0, int ld_dst = 0) {
+    src[nseg] = s; rows[nseg] = r; ccols[nseg] = c; dst[nseg] = d; lds_[nseg] = ld_src; ldd_[nseg] = ld_dst; ++nseg;
+  };
   auto flush = [&]() -> int {
     if (nseg == 0) return DFEPE_OK;
-    const int rc = dfepe_est_colsum(nseg, src, rows, ccols, dst, stream);
+    const int rc = colsum_launch(nseg, src, rows, ccols, dst, lds_, ldd_, stream);
     nseg = 0;
     return rc;
   };
-  // head
+  // head (the bias gradient's partial sums ride in the same launch)
   const int nblk = 512;
   float* hpart = reinterpret_cast<float*>(ws + L.hpart);
-  EST_TRY(dfepe_est_head_dw(sv + S.act[n], (size_t)cols * Clast, Clast, (int)cols, nblk, g_logits, hpart, stream));
+  float* bpart = reinterpret_cast<float*>(ws + L.bpart);
+  EST_TRY(dfepe_est_head_dw(sv + S.act[n], (size_t)cols * Clast, Clast, (int)cols, nblk, g_logits, hpart, g_b_head ? bpart : nullptr, stream));
   seg(hpart, nblk, Clast, g_w_head);
-  if (g_b_head) {
-    float* bpart = reinterpret_cast<float*>(ws + L.bpart);
-    hipLaunchKernelGGL(est_head_db_kernel, dim3(nblk), dim3(256), 0, st, g_logits, (int)cols, (int)((cols + nblk - 1) / nblk), bpart);
-    if (hipGetLastError() != hipSuccess) return DFEPE_ERR_HIP;
-    seg(bpart, nblk, 1, g_b_head);
-  }
-  // gamma == 0 fixes: gathered for one launch at the end, or issued layer by layer (see bwd_layout)
+  if (g_b_head) seg(bpart, nblk, 1, g_b_head);
+  // gamma == 0 fixes (one launch at the end, or layer by layer) and the weight gradients (likewise): see bwd_layout
   const float* f_dA[kTabMax]; const float* f_dl[kTabMax]; const float* f_wh[kTabMax]; const void* f_out[kTabMax]; size_t f_outs[kTabMax];
   const void* f_in[kTabMax]; size_t f_ins[kTabMax]; const float* f_W[kTabMax]; int f_Ci[kTabMax]; const float* f_rstd[kTabMax];
   const float* f_gamma[kTabMax]; int f_C[kTabMax]; float* f_dg[kTabMax]; const void* f_dYn[kTabMax]; size_t f_dyns[kTabMax];
   const float* f_Wn[kTabMax]; int f_Cn[kTabMax];
   int nfix = 0;
+  const void* t_dY[kTabMax]; size_t t_dys[kTabMax]; int t_Co[kTabMax]; const void* t_X[kTabMax]; size_t t_xs[kTabMax]; int t_K[kTabMax];
+  int t_sl[kTabMax]; float* t_part[kTabMax];
+  int ntn = 0;
   float* dA = reinterpret_cast<float*>(ws + L.dA);
   bool pending = false;  // dY / dg / db of the current layer already written by the fused data gradient of the layer above
-  bool have_dA = false;
+  Plan up{true, 1};      // how the data gradient above this layer left dA (fused = false: `S` partials in dA)
   for (int l = n - 1; l >= 0; --l) {
     const int C = D.Co[l], K = D.K[l];
     const void* a_out = sv + S.act[l + 1];
@@ -2084,13 +2528,17 @@ extern "C" int dfepe_est_backward(const float* g_logits, long B, int C0, int N, 
     char* dY = ws + L.dY[l];
     float* dg = reinterpret_cast<float*>(ws + L.dg[l]);
     float* db = reinterpret_cast<float*>(ws + L.db[l]);
-    const float* up_dA = have_dA ? dA : nullptr;
-    const float* up_dl = (l == n - 1) ? g_logits : nullptr;
-    const float* up_wh = (l == n - 1) ? w_head : nullptr;
+    const bool under_head = (l == n - 1);
     if (!pending) {
-      if (D.fused) {
-        EST_TRY(dfepe_est_in_bwd(up_dA, up_dl, up_wh, a_out, (size_t)cols * C, rstd, gamma[l], beta[l], slope, C, (int)cols, dY, (size_t)cols * C, dg,
+      const float* up_dA = under_head ? nullptr : dA;
+      const float* up_dl = under_head ? g_logits : nullptr;
+      const float* up_wh = under_head ? w_head : nullptr;
+      if (under_head && D.fusable) {
+        EST_TRY(dfepe_est_in_bwd(nullptr, up_dl, up_wh, a_out, (size_t)cols * C, rstd, gamma[l], beta[l], slope, C, (int)cols, dY, (size_t)cols * C, dg,
                                  db, stream));
+      } else if (D.resident) {
+        EST_TRY(dfepe_est_in_bwd_r(up_dA, C, up.S, (size_t)cols * C, up_dl, up_wh, a_out, (size_t)cols * C, rstd, gamma[l], beta[l], slope, C, B, N, dY,
+                                   (size_t)cols * C, dg, db, stream));
       } else {
         const int sp = row_splits(B, C, N);
         EST_TRY(dfepe_est_in_bwd_n(up_dA, up_dl, up_wh, a_out, (size_t)cols * C, rstd, gamma[l], beta[l], slope, C, B, N, dY, (size_t)cols * C, dg, db,
@@ -2098,54 +2546,56 @@ extern "C" int dfepe_est_backward(const float* g_logits, long B, int C0, int N, 
       }
     }
     if (N <= kFixMaxN) {
+      // the upstream gradient of the fix: the head's rank-one form, else recomputed for the channel from dY of the layer above (alive in
+      // both layouts until the layer below has been written) -- dA is transient (split-K partials, one buffer for all layers) or never existed
       const int i = nfix;
-      f_dA[i] = pending ? nullptr : up_dA; f_dl[i] = pending ? nullptr : up_dl; f_wh[i] = pending ? nullptr : up_wh;
+      f_dA[i] = nullptr; f_dl[i] = under_head ? g_logits : nullptr; f_wh[i] = under_head ? w_head : nullptr;
       f_out[i] = a_out; f_outs[i] = (size_t)cols * C; f_in[i] = a_in; f_ins[i] = (size_t)cols * K; f_W[i] = W[l]; f_Ci[i] = D.Ci[l];
       f_rstd[i] = rstd; f_gamma[i] = gamma[l]; f_C[i] = C; f_dg[i] = dg;
-      f_dYn[i] = pending ? ws + L.dY[l + 1] : nullptr; f_dyns[i] = pending ? (size_t)cols * D.Co[l + 1] : 0;
-      f_Wn[i] = pending ? W[l + 1] : nullptr; f_Cn[i] = pending ? D.Co[l + 1] : 0;
-      if (L.fix_at_end && n > 1) ++nfix;
+      f_dYn[i] = under_head ? nullptr : ws + L.dY[l + 1]; f_dyns[i] = under_head ? 0 : (size_t)cols * D.Co[l + 1];
+      f_Wn[i] = under_head ? nullptr : W[l + 1]; f_Cn[i] = under_head ? 0 : D.Co[l + 1];
+      if (L.keep_all) ++nfix;
       else
-        EST_TRY(dfepe_est_dgamma_zero(f_dA[i], f_dl[i], f_wh[i], f_out[i], f_outs[i], f_in[i], f_ins[i], f_W[i], f_Ci[i], f_Ci[i], f_rstd[i],
+        EST_TRY(dfepe_est_dgamma_zero(nullptr, f_dl[i], f_wh[i], f_out[i], f_outs[i], f_in[i], f_ins[i], f_W[i], f_Ci[i], f_Ci[i], f_rstd[i],
                                       f_gamma[i], slope, C, N, B, dg, f_dYn[i], f_dyns[i], f_Wn[i], C, f_Cn[i], stream));
     }
-    pending = false; have_dA = false;
+    pending = false;
     // dW = dY^T X
     float* partw = reinterpret_cast<float*>(ws + L.partw[l]);
-    EST_TRY(dfepe_est_gemm_tn(dY, (size_t)cols * C, C, a_in, (size_t)cols * K, K, (int)cols, L.slices[l], partw, stream));
-    if (nseg + 4 > kSegMax) EST_TRY(flush());
+    if (L.keep_all) {
+      t_dY[ntn] = dY; t_dys[ntn] = (size_t)cols * C; t_Co[ntn] = C; t_X[ntn] = a_in; t_xs[ntn] = (size_t)cols * K; t_K[ntn] = K; t_sl[ntn] = L.slices[l];
+      t_part[ntn] = partw; ++ntn;
+    } else {
+      EST_TRY(dfepe_est_gemm_tn(dY, (size_t)cols * C, C, a_in, (size_t)cols * K, K, (int)cols, L.slices[l], partw, stream));
+    }
+    if (nseg + 4 > kSegMax) EST_TRY(flush());  // (never with <= 8 layers: kSegMax >= 2 + 4 kTabMax; a flush before the fixes at the end
+                                               // would sum uncorrected d gamma partials)
     seg(dg, (int)B, C, g_gamma[l]);
     seg(db, (int)B, C, g_beta[l]);
-    seg(partw, L.slices[l], C * K, (K == D.Ci[l]) ? g_W[l] : reinterpret_cast<float*>(ws + L.wtmp));
+    if (K == D.Ci[l]) seg(partw, L.slices[l], C * K, g_W[l]);
+    else seg(partw, L.slices[l], C * K, g_W[l], K, D.Ci[l]);  // the first layer: its K - C0 zero-padded input channels dropped
     seg(nullptr, 0, C, g_bias[l]);
     if (l > 0 || need_gx) {
-      const void* WT = sv + S.wt[l];
-      if (l > 0 && D.fused && D.Ci[l] == K) {
-        EST_TRY(dfepe_est_dgrad_in_bwd(WT, (size_t)K * C, dY, (size_t)cols * C, K, (int)cols, C, a_in, (size_t)cols * K,
-                                       reinterpret_cast<const float*>(sv + S.rstd[l - 1]), gamma[l - 1], beta[l - 1], slope, ws + L.dY[l - 1],
-                                       (size_t)cols * K, reinterpret_cast<float*>(ws + L.dg[l - 1]), reinterpret_cast<float*>(ws + L.db[l - 1]),
-                                       stream));
-        pending = true;
+      const void* WT = pp ? static_cast<const void*>(pp + P.wt[l]) : static_cast<const void*>(sv + S.wt[l]);
+      if (l == 0) {
+        EST_TRY(nt_bf16_launch(WT, (size_t)K * C, dY, (size_t)cols * C, K, (int)cols, C, 2, nullptr, 0, 1, 0, gx, C0, N, stream));
       } else {
-        EST_TRY(dfepe_est_gemm_nt(WT, (size_t)K * C, dY, (size_t)cols * C, K, (int)cols, C, 2, dA, K, stream));
-        have_dA = true;
+        up = dgrad_plan(D, l);
+        if (up.fused) {
+          EST_TRY(dfepe_est_dgrad_in_bwd(WT, (size_t)K * C, dY, (size_t)cols * C, K, (int)cols, C, a_in, (size_t)cols * K,
+                                         reinterpret_cast<const float*>(sv + S.rstd[l - 1]), gamma[l - 1], beta[l - 1], slope, ws + L.dY[l - 1],
+                                         (size_t)cols * K, reinterpret_cast<float*>(ws + L.dg[l - 1]), reinterpret_cast<float*>(ws + L.db[l - 1]),
+                                         stream));
+          pending = true;
+        } else {
+          EST_TRY(nt_bf16_launch(WT, (size_t)K * C, dY, (size_t)cols * C, K, (int)cols, C, 2, dA, K, up.S, (size_t)cols * K, nullptr, 0, 0, stream));
+        }
       }
     }
   }
+  if (ntn > 0) EST_TRY(dfepe_est_gemm_tn_multi(ntn, t_dY, t_dys, t_Co, t_X, t_xs, t_K, (int)cols, t_sl, t_part, stream));
   if (nfix > 0)
     EST_TRY(dfepe_est_dgamma_zero_multi(nfix, f_dA, f_dl, f_wh, f_out, f_outs, f_in, f_ins, f_W, f_Ci, f_rstd, f_gamma, f_C, f_dg, f_dYn, f_dyns, f_Wn,
                                         f_Cn, slope, N, B, stream));
-  EST_TRY(flush());
-  if (D.K0 != D.C0) {  // the first layer's weight gradient without its K0 - C0 zero-padded input channels
-    const int total = D.Co[0] * D.C0;
-    hipLaunchKernelGGL(est_crop_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float*>(ws + L.wtmp), D.K0,
-                       D.Co[0], D.C0, g_W[0]);
-    if (hipGetLastError() != hipSuccess) return DFEPE_ERR_HIP;
-  }
-  if (need_gx) {
-    const long total = B * (long)C0 * N;
-    hipLaunchKernelGGL(est_gx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dA, D.K0, B, C0, N, gx);
-    if (hipGetLastError() != hipSuccess) return DFEPE_ERR_HIP;
-  }
-  return DFEPE_OK;
+  return flush();
 }

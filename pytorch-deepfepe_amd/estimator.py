@@ -14,7 +14,6 @@ sums over split-K / per-pair partials)."""
 from __future__ import annotations
 
 import ctypes
-import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -75,7 +74,7 @@ def _int_array(vs):
 
 
 _TAB = 8    # layers per dfepe_est_wprep launch pair
-_SEG = 32   # segments per dfepe_est_colsum launch
+_SEG = 40   # segments per dfepe_est_colsum launch (kSegMax)
 
 
 def _wprep(Ws: Sequence[Tensor], want_wt: Sequence[bool], dev) -> Tuple[List[Tensor], List[Optional[Tensor]], Tensor]:
@@ -248,7 +247,7 @@ class _EstimatorFunction(torch.autograd.Function):
             nblk = 512
             part = _buf("hpart", n_out, nblk, C, device=dev, dtype=torch.float32)
             for o in range(n_out):
-                rc = lib.dfepe_est_head_dw(_ptr(acts[-1]), cols * C, C, cols, nblk, _ptr(dl[o]), _ptr(part[o]), st)
+                rc = lib.dfepe_est_head_dw(_ptr(acts[-1]), cols * C, C, cols, nblk, _ptr(dl[o]), _ptr(part[o]), None, st)
                 _lib.check(rc, "dfepe_est_head_dw")
             # every reduction of this backward is a segment of ONE dfepe_est_colsum launch at the end: (source [rows, cols], rows, cols)
             # and what to do with the sum
@@ -353,126 +352,166 @@ class _EstimatorFunction(torch.autograd.Function):
         return (None, gx, *grads)
 
 
-class _EstimatorPassFunction(torch.autograd.Function):
-    """The same stack through ONE library call per pass (dfepe_est_forward / dfepe_est_backward: the launches of _EstimatorFunction
-    issued from C in the same order -- bit-identical results --, on three caller-owned buffers instead of ~40 allocations).  At the
-    reference's batch sizes the host was the limiter of the eager step; this is ~0.2 ms less of it per estimator call and pass.
-    For: one head channel, <= 8 hidden layers, fp32 contiguous parameters (estimator_forward decides).  args as _EstimatorFunction."""
+class Prepared:
+    """One estimator's parameters as the library wants them, made ONCE per model forward (round 6):
+      packed   every parameter in one fp32 vector (torch.cat: differentiable, its backward hands each parameter a VIEW of the packed
+               gradient) -- an estimator called k times in a forward (DeepFNet.update_weights: depth - 1 calls,
+               deepFEPE/models/DeepFNet.py:510) then costs autograd k - 1 additions of one vector instead of k - 1 per parameter
+               (66 `add` launches per step at depth 5), and every call writes ALL its parameter gradients into one buffer;
+      prep     the weights' planes (dfepe_est_prepare: power-of-two scales, scaled fp16 planes, transposed bf16 planes): two
+               launches per forward instead of two per call.
+    Holds the parameter objects it was made of: estimator_forward uses it only for exactly those."""
 
-    @staticmethod
-    def forward(ctx, cfg, x, *params):
-        n_hidden, eps, slope, keep = cfg
-        lib = _lib.lib()
-        B, C0, N = x.shape
-        dev = x.device
-        with _on(dev):
-            st = _stream()
-            xin = x.detach()
-            xin = xin if (xin.dtype == torch.float32 and xin.is_contiguous()) else xin.float().contiguous()
-            Ws = [params[4 * l] for l in range(n_hidden)]
-            Co, Ci = _int_array([int(w.shape[0]) for w in Ws]), _int_array([int(w.shape[1]) for w in Ws])
-            need_gx = bool(keep and ctx.needs_input_grad[1])
-            saved = None
-            if keep:
-                saved = torch.empty(lib.dfepe_est_saved_bytes(n_hidden, Co, Ci, B, C0, N, int(need_gx)), device=dev, dtype=torch.uint8)
-            ws = torch.empty(lib.dfepe_est_forward_workspace_bytes(n_hidden, Co, Ci, B, C0, N, int(keep)), device=dev, dtype=torch.uint8)
-            logits = torch.empty(B, 1, N, device=dev, dtype=torch.float32)
-            Wh, bh = params[4 * n_hidden], params[4 * n_hidden + 1]
-            rc = lib.dfepe_est_forward(_ptr(xin), B, C0, N, n_hidden, _ptr_array(Ws), _ptr_array([params[4 * l + 2] for l in range(n_hidden)]),
-                                       _ptr_array([params[4 * l + 3] for l in range(n_hidden)]), Co, Ci, _ptr(Wh), _ptr(bh), float(eps), float(slope),
-                                       _ptr(saved), int(need_gx), _ptr(ws), _ptr(logits), st)
-            _lib.check(rc, "dfepe_est_forward")
-        ctx.cfg = cfg
-        ctx.shape = (B, C0, N)
-        ctx.need_gx = need_gx
-        ctx.has_head_bias = bh is not None
-        kept = [p for p in params if p is not None]
-        ctx.save_for_backward(*kept, *([saved] if keep else []))
-        return logits
+    __slots__ = ("params", "packed", "prep", "n_hidden", "Co", "Ci", "W", "gamma", "beta", "w_head", "b_head", "off", "numel", "device")
 
-    @staticmethod
-    def backward(ctx, g_logits):
-        n_hidden, eps, slope, _keep = ctx.cfg
-        lib = _lib.lib()
-        B, C0, N = ctx.shape
-        everything = list(ctx.saved_tensors)
-        saved = everything[-1]
-        params = everything[:-1] if ctx.has_head_bias else everything[:-1] + [None]
-        dev = g_logits.device
-        with _on(dev):
-            st = _stream()
-            gl = g_logits.detach()
-            gl = gl if (gl.dtype == torch.float32 and gl.is_contiguous()) else gl.float().contiguous()
-            Ws = [params[4 * l] for l in range(n_hidden)]
-            Co, Ci = _int_array([int(w.shape[0]) for w in Ws]), _int_array([int(w.shape[1]) for w in Ws])
-            ws = torch.empty(lib.dfepe_est_backward_workspace_bytes(n_hidden, Co, Ci, B, C0, N, int(ctx.need_gx)), device=dev, dtype=torch.uint8)
-            # every parameter gradient in one buffer, handed out as views in parameter order
-            sizes = [0 if p is None else p.numel() for p in params]
-            flat = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
-            grads, at = [], 0
-            for p, k in zip(params, sizes):
-                grads.append(None if p is None else flat[at:at + k].view(p.shape))
-                at += k
-            gx = torch.empty(B, C0, N, device=dev, dtype=torch.float32) if ctx.need_gx else None
-            Wh = params[4 * n_hidden]
-            rc = lib.dfepe_est_backward(_ptr(gl), B, C0, N, n_hidden, _ptr_array(Ws), _ptr_array([params[4 * l + 2] for l in range(n_hidden)]),
-                                        _ptr_array([params[4 * l + 3] for l in range(n_hidden)]), Co, Ci, _ptr(Wh), float(slope), _ptr(saved), _ptr(ws),
-                                        _ptr_array([grads[4 * l] for l in range(n_hidden)]), _ptr_array([grads[4 * l + 1] for l in range(n_hidden)]),
-                                        _ptr_array([grads[4 * l + 2] for l in range(n_hidden)]), _ptr_array([grads[4 * l + 3] for l in range(n_hidden)]),
-                                        _ptr(grads[4 * n_hidden]), _ptr(grads[4 * n_hidden + 1]), _ptr(gx), st)
-            _lib.check(rc, "dfepe_est_backward")
-        return (None, gx, *grads)
+    def matches(self, flat: Sequence[Optional[Tensor]]) -> bool:
+        return len(flat) == len(self.params) and all(a is b for a, b in zip(self.params, flat))
+
+    def pointers(self, base: int):
+        """(W[], bias[], gamma[], beta[], w_head, b_head) as ctypes pointer arrays / ints into a packed vector that starts at `base`."""
+        n = self.n_hidden
+        arr = lambda k: (ctypes.c_void_p * n)(*[base + 4 * self.off[4 * l + k] for l in range(n)])
+        bh = self.off[4 * n + 1]
+        return arr(0), arr(1), arr(2), arr(3), base + 4 * self.off[4 * n], (None if bh is None else base + 4 * bh)
 
 
-def _pass_ok(x: Tensor, flat: Sequence[Optional[Tensor]], n_hidden: int) -> bool:
-    """One library call per pass serves: a one-channel head, <= 8 hidden layers whose widths are multiples of 32, fp32 contiguous
-    parameters; everything else keeps the per-launch host code of _EstimatorFunction."""
-    if not USE_PASS or n_hidden < 1 or n_hidden > _TAB or flat[4 * n_hidden].shape[0] != 1:
+def _prepare_ok(flat: Sequence[Optional[Tensor]], n_hidden: int) -> bool:
+    """One library call per pass serves: a one-channel head, <= 8 hidden layers whose widths are multiples of 32, fp32 parameters on
+    one GPU; everything else keeps the per-launch host code of _EstimatorFunction.  Every tensor is looked at on every call (ADVICE r5:
+    a cached answer keyed on object identity went stale when one parameter's .data was swapped)."""
+    if not USE_PASS or n_hidden < 1 or n_hidden > _TAB or len(flat) != 4 * n_hidden + 2:
         return False
-    # the answer for THESE parameter objects is remembered (module.to() / .half() keep the Parameter objects and swap their data:
-    # dtype and device of the first one are re-checked every time)
-    key = (tuple(map(id, flat)), x.shape[1])
-    hit = _PASS_OK.get(key)
-    if (hit is not None and flat[0].dtype == torch.float32 and flat[0].device == x.device and flat[0].is_contiguous()
-            and all((r is None and p is None) or (r is not None and r() is p) for r, p in zip(hit[1], flat))):  # ids are reused: the objects
-        return hit[0]
-    ok = _pass_ok_uncached(x, flat, n_hidden)
-    if len(_PASS_OK) > 256:
-        _PASS_OK.clear()
-    _PASS_OK[key] = (ok, tuple(None if p is None else weakref.ref(p) for p in flat))
-    return ok
-
-
-_PASS_OK: dict = {}
-
-
-def _pass_ok_uncached(x: Tensor, flat: Sequence[Optional[Tensor]], n_hidden: int) -> bool:
+    dev = None
     for i, p in enumerate(flat):
         if p is None:
             if i != 4 * n_hidden + 1:
                 return False
             continue
-        if p.dtype != torch.float32 or not p.is_contiguous() or p.device != x.device:
+        if p.dtype != torch.float32 or (dev is not None and p.device != dev):
             return False
-    prev = x.shape[1]
+        dev = p.device
+    prev = None
     for l in range(n_hidden):
         W = flat[4 * l]
-        if W.dim() != 3 or W.shape[2] != 1 or W.shape[1] != prev or W.shape[0] % 32 or any(flat[4 * l + k] is None for k in (1, 2, 3)):
+        if W.dim() != 3 or W.shape[2] != 1 or (prev is not None and W.shape[1] != prev) or W.shape[0] % 32:
             return False
         prev = W.shape[0]
-    return flat[4 * n_hidden].shape[1] == prev
+        if any(flat[4 * l + k].numel() != prev for k in (1, 2, 3)):
+            return False
+    Wh, bh = flat[4 * n_hidden], flat[4 * n_hidden + 1]
+    return Wh.dim() == 3 and Wh.shape[0] == 1 and Wh.shape[1] == prev and Wh.shape[2] == 1 and (bh is None or bh.numel() == 1)
+
+
+def prepare(hidden: Sequence[Tuple[Tensor, Tensor, Tensor, Tensor]], head: Tuple[Tensor, Optional[Tensor]]) -> Optional[Prepared]:
+    """The Prepared form of an estimator's parameters (None when the one-call-per-pass path does not serve them: estimator_forward then
+    takes its per-launch host code).  Three launches: the cat, and the two of dfepe_est_prepare."""
+    flat: List[Optional[Tensor]] = []
+    for layer in hidden:
+        flat.extend(layer)
+    flat.extend(head)
+    n = len(hidden)
+    if not _prepare_ok(flat, n) or not flat[0].is_cuda:
+        return None
+    lib = _lib.lib()
+    P = Prepared()
+    P.params = tuple(flat)
+    P.n_hidden = n
+    P.device = flat[0].device
+    off, at = [], 0
+    for p in flat:
+        off.append(None if p is None else at)
+        at += 0 if p is None else p.numel()
+    P.off, P.numel = off, at
+    with _on(P.device):
+        P.packed = torch.cat([p.reshape(-1) for p in flat if p is not None])
+        P.Co = _int_array([int(flat[4 * l].shape[0]) for l in range(n)])
+        P.Ci = _int_array([int(flat[4 * l].shape[1]) for l in range(n)])
+        P.W, _, P.gamma, P.beta, P.w_head, P.b_head = P.pointers(P.packed.data_ptr())
+        P.prep = torch.empty(lib.dfepe_est_prep_bytes(n, P.Co, P.Ci), device=P.device, dtype=torch.uint8)
+        rc = lib.dfepe_est_prepare(n, P.W, P.Co, P.Ci, _ptr(P.prep), _stream())
+        _lib.check(rc, "dfepe_est_prepare")
+    return P
+
+
+class _EstimatorPackedFunction(torch.autograd.Function):
+    """The whole stack through ONE library call per pass (dfepe_est_forward / dfepe_est_backward) on the PACKED parameters of a Prepared:
+    args (cfg, prepared, x, packed); the backward returns ONE gradient vector for `packed`.  At the reference's batch sizes the host was
+    the limiter of the eager step (round 5: one call instead of ~30 launches and ~40 allocations from Python); round 6 moved the weights'
+    preparation out of the call and the parameter gradients into one buffer."""
+
+    @staticmethod
+    def forward(ctx, cfg, P, x, packed):
+        eps, slope, keep = cfg
+        lib = _lib.lib()
+        B, C0, N = x.shape
+        dev = x.device
+        n = P.n_hidden
+        with _on(dev):
+            st = _stream()
+            xin = x.detach()
+            xin = xin if (xin.dtype == torch.float32 and xin.is_contiguous()) else xin.float().contiguous()
+            need_gx = bool(keep and ctx.needs_input_grad[2])
+            saved = None
+            if keep:
+                saved = torch.empty(lib.dfepe_est_saved_bytes(n, P.Co, P.Ci, B, C0, N, int(need_gx)), device=dev, dtype=torch.uint8)
+            ws = torch.empty(lib.dfepe_est_forward_workspace_bytes(n, P.Co, P.Ci, B, C0, N, int(keep)), device=dev, dtype=torch.uint8)
+            logits = torch.empty(B, 1, N, device=dev, dtype=torch.float32)
+            rc = lib.dfepe_est_forward(_ptr(xin), B, C0, N, n, P.W, P.gamma, P.beta, P.Co, P.Ci, P.w_head, P.b_head, float(eps), float(slope),
+                                       _ptr(saved), int(need_gx), _ptr(ws), _ptr(P.prep), _ptr(logits), st)
+            _lib.check(rc, "dfepe_est_forward")
+        ctx.cfg = cfg
+        ctx.P = P  # keeps `prep` alive until the backward has read it
+        ctx.shape = (B, C0, N)
+        ctx.need_gx = need_gx
+        ctx.save_for_backward(*([packed, saved] if keep else []))
+        return logits
+
+    @staticmethod
+    def backward(ctx, g_logits):
+        eps, slope, _keep = ctx.cfg
+        lib = _lib.lib()
+        B, C0, N = ctx.shape
+        P = ctx.P
+        n = P.n_hidden
+        packed, saved = ctx.saved_tensors
+        dev = g_logits.device
+        with _on(dev):
+            st = _stream()
+            gl = g_logits.detach()
+            gl = gl if (gl.dtype == torch.float32 and gl.is_contiguous()) else gl.float().contiguous()
+            ws = torch.empty(lib.dfepe_est_backward_workspace_bytes(n, P.Co, P.Ci, B, C0, N, int(ctx.need_gx)), device=dev, dtype=torch.uint8)
+            flat = torch.empty_like(packed)  # every parameter gradient, laid out like `packed`: each element is written by the call
+            gW, gb, gg, gbt, gwh, gbh = P.pointers(flat.data_ptr())
+            gx = torch.empty(B, C0, N, device=dev, dtype=torch.float32) if ctx.need_gx else None
+            rc = lib.dfepe_est_backward(_ptr(gl), B, C0, N, n, P.W, P.gamma, P.beta, P.Co, P.Ci, P.w_head, float(slope), _ptr(saved), _ptr(ws),
+                                        _ptr(P.prep), gW, gb, gg, gbt, gwh, gbh, _ptr(gx), st)
+            _lib.check(rc, "dfepe_est_backward")
+        return (None, None, gx, flat if ctx.needs_input_grad[3] else None)
+
+
+def _pass_ok(x: Tensor, flat: Sequence[Optional[Tensor]], n_hidden: int) -> bool:
+    """Does the one-call-per-pass path serve these parameters for this input?  (_prepare_ok plus: same device, matching width.)"""
+    return _prepare_ok(flat, n_hidden) and x.dim() == 3 and flat[0].device == x.device and flat[0].shape[1] == x.shape[1]
 
 
 def estimator_forward(x: Tensor, hidden: Sequence[Tuple[Tensor, Tensor, Tensor, Tensor]], head: Tuple[Tensor, Optional[Tensor]],
-                      eps: float = 1e-5, slope: float = 0.01) -> Tensor:
+                      eps: float = 1e-5, slope: float = 0.01, prepared: Optional[Prepared] = None) -> Tensor:
     """x [B, C0, N] fp32 on the GPU -> logits [B, O, N].  hidden: per layer (conv weight, conv bias, InstanceNorm weight,
-    InstanceNorm bias); head: (conv weight [O,C,1], bias [O] or None)."""
+    InstanceNorm bias); head: (conv weight [O,C,1], bias [O] or None).  prepared: prepare(hidden, head) of THESE parameter objects, made
+    once by a caller that evaluates the estimator several times per forward; without it (or with one made of other objects) the call
+    prepares its own."""
     if not supported(x):
         raise _lib.DfepeError(f"estimator_forward: needs a GPU tensor [B >= 1, C, N >= 2], got {tuple(x.shape)} on {x.device}")
     flat: List[Optional[Tensor]] = []
     for layer in hidden:
         flat.extend(layer)
     flat.extend(head)
+    if prepared is not None and not (prepared.matches(flat) and prepared.device == x.device and _prepare_ok(flat, len(hidden))):
+        prepared = None
+    if prepared is None and _pass_ok(x, flat, len(hidden)):
+        prepared = prepare(hidden, head)
+    if prepared is not None and prepared.params[0].shape[1] == x.shape[1]:
+        keep = torch.is_grad_enabled() and (x.requires_grad or prepared.packed.requires_grad)
+        return _EstimatorPackedFunction.apply((float(eps), float(slope), bool(keep)), prepared, x, prepared.packed)
     keep = torch.is_grad_enabled() and (x.requires_grad or any(p is not None and p.requires_grad for p in flat))
-    fn = _EstimatorPassFunction if _pass_ok(x, flat, len(hidden)) else _EstimatorFunction
-    return fn.apply((len(hidden), float(eps), float(slope), bool(keep)), x, *flat)
+    return _EstimatorFunction.apply((len(hidden), float(eps), float(slope), bool(keep)), x, *flat)

@@ -31,7 +31,7 @@ def test_library_builds_and_exports_every_declared_symbol(dfepe):
 
 def test_version_strerror_and_save_layout(dfepe):
     L = dfepe._lib.lib()
-    assert L.dfepe_version() == 153
+    assert L.dfepe_version() == 154
     assert L.dfepe_save_floats() == 128
     assert L.dfepe_strerror(0) == b"ok"
     assert b"invalid" in L.dfepe_strerror(-1)
@@ -79,9 +79,19 @@ def test_argument_validation_without_launching(dfepe):
     assert L.dfepe_est_wprep_workspace_bytes(5) >= 5 * 4 and L.dfepe_est_wprep_workspace_bytes(0) == 0
     assert L.dfepe_est_dgamma_zero_multi(0, *([None] * 17), 0.01, 100, 4, None) == -1 and L.dfepe_est_dgamma_zero_multi(2, *([None] * 17), 0.01, 100, 4, None) == -1
     assert L.dfepe_est_saved_bytes(0, None, None, 4, 7, 100, 0) == 0 and L.dfepe_est_forward_workspace_bytes(9, None, None, 4, 7, 100, 1) == 0
-    assert L.dfepe_est_forward(None, 4, 7, 100, 5, None, None, None, None, None, None, None, 1e-5, 0.01, None, 0, None, None, None) == -1
-    assert L.dfepe_est_backward(None, 4, 7, 100, 5, None, None, None, None, None, None, 0.01, None, None, None, None, None, None, None, None, None, None) == -1
-    assert L.dfepe_est_colsum(0, None, None, None, None, None) == -1 and L.dfepe_est_colsum(33, None, None, None, None, None) == -1
+    assert L.dfepe_est_forward(None, 4, 7, 100, 5, None, None, None, None, None, None, None, 1e-5, 0.01, None, 0, None, None, None, None) == -1
+    assert L.dfepe_est_backward(None, 4, 7, 100, 5, None, None, None, None, None, None, 0.01, None, None, None, None, None, None, None, None, None, None, None) == -1
+    assert L.dfepe_est_colsum(0, None, None, None, None, None) == -1 and L.dfepe_est_colsum(41, None, None, None, None, None) == -1
+    # version 154: split-K products, the register-resident normalisations, the table-driven weight gradient, prepared parameters
+    assert L.dfepe_est_gemm_nt_f16_splitk(None, 0, None, 0, 64, 200, 256, None, None, 64, 2, 0, None) == -1
+    assert L.dfepe_est_gemm_nt_splitk(None, 0, None, 0, 64, 200, 256, None, 64, 2, 0, None) == -1
+    assert L.dfepe_est_gemm_nt_gx(None, 0, None, 0, 32, 200, 64, None, 7, 100, None) == -1
+    assert L.dfepe_est_gemm_tn_multi(0, None, None, None, None, None, None, 800, None, None, None) == -1
+    assert L.dfepe_est_gemm_tn_multi(9, None, None, None, None, None, None, 800, None, None, None) == -1
+    assert L.dfepe_est_norm_fwd_r(None, 64, 1, 0, 64, 2, 1000, None, None, 1e-5, 0.01, None, 0, None, 0, None, None) == -1
+    assert L.dfepe_est_in_bwd_r(None, 64, 1, 0, None, None, None, 0, None, None, None, 0.01, 64, 2, 1000, None, 0, None, None, None) == -1
+    assert L.dfepe_est_prepare(5, None, None, None, None, None) == -1 and L.dfepe_est_prep_bytes(0, None, None) == 0
+    assert L.dfepe_est_head_dw(None, 0, 256, 800, 512, None, None, None, None) == -1
     assert L.dfepe_est_dgrad_in_bwd(None, 0, None, 0, 64, 200, 32, None, 0, None, None, None, 0.01, None, 0, None, None, None) == -1
     assert L.dfepe_est_in_bwd_n(None, None, None, None, 0, None, None, None, 0.01, 64, 2, 1000, None, 0, None, None, 1, None, None) == -1
 
@@ -103,6 +113,12 @@ def test_estimator_pass_buffer_sizes(dfepe):
     assert L.dfepe_est_saved_bytes(5, arr([64, 100, 1024, 512, 256]), Ci, 8, 7, 100, 0) == 0   # 100 % 32 != 0
     assert L.dfepe_est_saved_bytes(5, Co, arr([7, 64, 128, 1000, 512]), 8, 7, 100, 0) == 0     # Ci[3] != Co[2]
     assert L.dfepe_est_saved_bytes(5, Co, Ci, 8, 7, 1, 0) == 0                                   # one point per pair: the stock stack's error
+    # the reference's own shape (8 pairs x 1000 points): plain products, a K-heavy layer's partials included; prepared parameters
+    assert L.dfepe_est_forward_workspace_bytes(5, Co, Ci, 8, 7, 1000, 1) >= 8 * 1000 * 1024 * 4
+    assert L.dfepe_est_backward_workspace_bytes(5, Co, Ci, 8, 7, 1000, 1) >= 8 * 1000 * 1024 * 4
+    pb = L.dfepe_est_prep_bytes(5, Co, Ci)
+    assert pb >= 2 * 2 * 2 * (64 * 32 + 128 * 64 + 1024 * 128 + 512 * 1024 + 256 * 512)       # two formats x two planes x two bytes
+    assert L.dfepe_est_prep_bytes(5, arr([64, 100, 1024, 512, 256]), Ci) == 0
 
 
 def test_no_cpu_fallback(dfepe):

@@ -315,12 +315,14 @@ def test_whole_estimator_matches_the_stock_module_in_float64(dfepe, cin, B, seed
     assert float((yc.detach() - yb.detach()).abs().max()) < 1e-4
 
 
-@pytest.mark.parametrize("cin,B,N,xgrad", [(4, 6, 100, False), (7, 5, 100, True), (7, 3, 37, True), (4, 2, 1000, False), (7, 41, 100, True)])
-def test_one_call_per_pass_is_bit_identical_to_the_per_launch_host_code(dfepe, cin, B, N, xgrad, monkeypatch):
-    """dfepe_est_forward / dfepe_est_backward issue the launches of the per-launch host code from C, in the same order, on three
-    caller-owned buffers: logits and every gradient must come out bit for bit the same (fused epilogues at N = 100, plain products
-    elsewhere; with and without a gradient for x; 41 pairs: the gamma == 0 guard layer by layer instead of at the end), and a
-    forward under no_grad (nothing saved) must give the same logits."""
+@pytest.mark.parametrize("cin,B,N,xgrad", [(4, 6, 100, False), (7, 5, 100, True), (7, 3, 37, True), (4, 2, 1000, False), (7, 41, 100, True), (7, 64, 100, True)])
+def test_one_call_per_pass_against_the_per_launch_host_code(dfepe, cin, B, N, xgrad, monkeypatch):
+    """dfepe_est_forward / dfepe_est_backward against the per-launch host code of round 4-5 (estimator._EstimatorFunction: fused epilogues
+    at N = 100, plain product + strided normalisation elsewhere).  From 41 pairs x 100 points on, every layer of the pass takes its fused
+    epilogue too -- the same kernels on the same data -- and logits and gradients must come out BIT FOR BIT the same (only the
+    weight gradients' launch differs: five or one, same partials); below, the pass runs K-heavy layers as split-K products + the
+    register-resident normalisation (another order of the same fp32 sums: the fp32 class).  A forward under no_grad (nothing saved)
+    must give the same logits as one that keeps its planes."""
     est = dfepe.estimator
     EE = dfepe.compat.ErrorEstimators
     net = EE.FusedErrorEstimator(cin).to(DEV)
@@ -328,30 +330,38 @@ def test_one_call_per_pass_is_bit_identical_to_the_per_launch_host_code(dfepe, c
     g = torch.Generator().manual_seed(B + N)
     x0 = torch.rand(B, cin, N, generator=g).to(DEV)
     G = torch.randn(B, 1, N, generator=g).to(DEV)
-    if B == 41:
-        monkeypatch.setattr(est, "FIX_AT_END_BYTES", 0)  # (the C side decides by the same 64 MB: 41 x 100 columns stay below it, so
-        # this only moves the host code to its layer-by-layer form; both orders of the fixes write the same values)
     outs = {}
     for use in (True, False):
         monkeypatch.setattr(est, "USE_PASS", use)
         net.zero_grad(set_to_none=True)
         x = x0.clone().requires_grad_(xgrad)
         y = net(x)
-        assert type(y.grad_fn).__name__.startswith("_EstimatorPassFunction" if use else "_EstimatorFunction")
+        assert type(y.grad_fn).__name__.startswith("_EstimatorPackedFunction" if use else "_EstimatorFunction")
         (y * G).sum().backward()
         with torch.no_grad():
             y0 = net(x0)
         outs[use] = (y.detach().clone(), y0.clone(), None if not xgrad else x.grad.clone(), [p.grad.clone() for p in net.parameters()])
     a, b = outs[True], outs[False]
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[0], a[1])
-    if xgrad:
-        assert torch.equal(a[2], b[2])
+    assert torch.equal(a[0], a[1]) and torch.equal(b[0], b[1])
     names = [n for n, _ in net.named_parameters()]
+    exact = N == 100 and B >= 41
+    if exact:
+        assert torch.equal(a[0], b[0])
+        if xgrad:
+            assert torch.equal(a[2], b[2])
+    else:
+        assert float((a[0] - b[0]).abs().max()) < 3e-6 * max(1.0, float(b[0].abs().max()))
+        if xgrad:
+            assert float((a[2] - b[2]).norm() / b[2].norm()) < 1e-4
     for name, ga, gb in zip(names, a[3], b[3]):
         if name == names[-1]:  # the head's bias: sum of dlogit -- torch.sum there, 512 partial sums + the common reduction launch here
             assert float((ga - gb).abs().max()) <= 1e-6 * float(G.abs().sum()), name
-        else:
+        elif exact:
             assert torch.equal(ga, gb), name
+        elif float(gb.abs().max()) == 0.0:
+            assert float(ga.abs().max()) == 0.0, name
+        else:
+            assert float((ga - gb).norm() / gb.norm()) < 1e-4, name
 
 
 def test_backward_twice_with_retain_graph_and_the_standard_error_without(dfepe):
@@ -531,13 +541,18 @@ def test_four_output_head_matches_float64(dfepe, N, B):
     assert float((fused(x.to(DEV)).detach() - yb.detach()).abs().max()) < 1e-4
 
 
-@pytest.mark.parametrize("N,B,at_end", [(100, 5, True), (37, 4, True), (100, 5, False), (37, 4, False)])
-def test_zero_gamma_channels_get_their_gradient(dfepe, N, B, at_end, monkeypatch):
+@pytest.mark.parametrize("use_pass", [True, False])
+@pytest.mark.parametrize("N,B,at_end", [(100, 5, True), (37, 4, True), (100, 5, False), (37, 4, False), (100, 48, True), (100, 48, False)])
+def test_zero_gamma_channels_get_their_gradient(dfepe, N, B, at_end, use_pass, monkeypatch):
     """ADVICE r3 / VERDICT r4 7d: the adjoints recover x^ from the stored activation as (z - beta) / gamma, which an InstanceNorm
     weight of EXACTLY zero makes impossible (they take x^ = 0: d beta and dY right, d gamma wrong).  dfepe_est_dgamma_zero
     recomputes that channel's product from the layer's input; with it every gradient of a network with zeroed gammas -- in the first,
-    a middle and the last hidden layer -- meets the float64 stock module like any other (N = 100: fused epilogue; 37: generic).
-    at_end: all layers' fixes in one launch at the end of the backward (what few columns get) / layer by layer (many columns)."""
+    a middle and the last hidden layer -- meets the float64 stock module like any other (N = 100 at 5 pairs: fused epilogues + split-K
+    layers; at 48 pairs: fused epilogues throughout; N = 37: plain products).
+    at_end: all layers' fixes in one launch at the end of the backward (what few columns get) / layer by layer (many columns) -- in BOTH
+    host paths: the one-call-per-pass C code (DFEPE_EST_KEEP_ALL, read per call) and the per-launch Python code."""
+    monkeypatch.setattr(dfepe.estimator, "USE_PASS", use_pass)
+    monkeypatch.setenv("DFEPE_EST_KEEP_ALL", "1" if at_end else "0")
     if not at_end:
         monkeypatch.setattr(dfepe.estimator, "FIX_AT_END_BYTES", 0)
     EE = dfepe.compat.ErrorEstimators
@@ -567,6 +582,52 @@ def test_zero_gamma_channels_get_their_gradient(dfepe, N, B, at_end, monkeypatch
     for name in pa:
         if pb[name].grad.abs().max().item() > 0.0:
             assert relerr(pb[name].grad.cpu(), pa[name].grad) < 2e-4, name
+
+
+def test_eight_hidden_layers_with_zero_gammas(dfepe):
+    """the table limit of the one-call-per-pass path (8 hidden layers = 2 + 4 x 8 = 34 reduction segments: more than round
+    5's 32 per launch, whose mid-loop flush summed the d gamma partials of layers 7..1 BEFORE the gamma == 0 fix at the end had
+    corrected them).  Eight layers, a zeroed gamma in every one of them, against float64."""
+    est = dfepe.estimator
+    widths = [7, 32, 64, 32, 96, 64, 32, 64, 32]
+    g = torch.Generator().manual_seed(12)
+    hidden = []
+    for ci, co in zip(widths[:-1], widths[1:]):
+        W = (torch.randn(co, ci, 1, generator=g) / ci ** 0.5)
+        gam = 1 + 0.2 * torch.randn(co, generator=g)
+        gam[co // 3] = 0.0
+        hidden.append([W, 0.1 * torch.randn(co, generator=g), gam, 0.3 * torch.randn(co, generator=g)])
+    head = [torch.randn(1, widths[-1], 1, generator=g) / widths[-1] ** 0.5, torch.randn(1, generator=g)]
+    B, N = 6, 100
+    x = torch.rand(B, 7, N, generator=g)
+    G = torch.randn(B, 1, N, generator=g)
+
+    def reference():
+        ps = [[t.double().requires_grad_(True) for t in layer] for layer in hidden]
+        hd = [t.double().requires_grad_(True) for t in head]
+        a = x.double()
+        for W, b, gam, bet in ps:
+            a = torch.nn.functional.leaky_relu(torch.nn.functional.instance_norm(torch.nn.functional.conv1d(a, W, b), weight=gam, bias=bet, eps=1e-5), 0.01)
+        y = torch.nn.functional.conv1d(a, hd[0], hd[1])
+        (y * G.double()).sum().backward()
+        return y.detach(), [t.grad for layer in ps for t in layer] + [t.grad for t in hd]
+
+    ps = [[t.to(DEV).requires_grad_(True) for t in layer] for layer in hidden]
+    hd = [t.to(DEV).requires_grad_(True) for t in head]
+    y = est.estimator_forward(x.to(DEV), [tuple(l) for l in ps], tuple(hd))
+    assert type(y.grad_fn).__name__.startswith("_EstimatorPackedFunction")
+    (y * G.to(DEV)).sum().backward()
+    yr, gr = reference()
+    assert float((y.detach().cpu().double() - yr).abs().max()) < 5e-6
+    got = [t.grad for layer in ps for t in layer] + [t.grad for t in hd]
+    for i, (a, b) in enumerate(zip(got, gr)):
+        if float(a.abs().max()) == 0.0:
+            assert i % 4 == 1 and float(b.abs().max()) < 1e-9, i  # a convolution bias in front of an InstanceNorm
+            continue
+        assert relerr(a.cpu(), b) < 2e-4, i
+        if i % 4 == 2:  # a gamma vector: its zeroed channel's gradient is not zero, and is right
+            z = (hidden[i // 4][2] == 0).nonzero().flatten().tolist()
+            assert float(b[z].abs().min()) > 1e-7 * float(b.abs().max()), i
 
 
 def test_estimator_backward_survives_graph_replays(dfepe):

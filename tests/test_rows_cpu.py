@@ -198,7 +198,7 @@ def test_estimator_launch_geometry_helpers(dfepe):
 def test_estimator_small_batch_slices_and_the_one_call_per_pass_decision(dfepe):
     """Host-side choices added in round 5: over few columns a split-K slice keeps >= 256 of them (the reference's batch sizes: the
     partial sums would otherwise outweigh the product); and which estimators take ONE library call per pass -- a one-channel head,
-    <= 8 hidden layers of widths on the 32 grid, fp32 contiguous parameters -- everything else the per-launch host code."""
+    <= 8 hidden layers of widths on the 32 grid, fp32 parameters -- everything else the per-launch host code."""
     est = dfepe.estimator
     assert est._slices_for(512, 1024, 800) == 3 and est._slices_for(512, 1024, 100) == 1
     assert est._slices_for(512, 1024, 409600) == est._slices_for(512, 1024)
@@ -217,22 +217,29 @@ def test_estimator_small_batch_slices_and_the_one_call_per_pass_decision(dfepe):
 
     x = torch.zeros(2, 7, 100)
     flat, n = flat_of(EE.ErrorEstimator(7))
-    assert est._pass_ok(x, flat, n) and est._pass_ok(x, flat, n)            # (the second answer comes from the cache)
+    assert est._pass_ok(x, flat, n)
     flat4, n4 = flat_of(EE.ErrorEstimator(7, output_size=4))
     assert not est._pass_ok(x, flat4, n4)                                    # four head channels: the per-launch host code
     half, nh = flat_of(EE.ErrorEstimator(7).half())
     assert not est._pass_ok(x, half, nh)                                     # not fp32
     assert not est._pass_ok(torch.zeros(2, 4, 100), flat, n)                 # the first layer does not take these inputs
     odd = [p for p in flat]
-    odd[0] = torch.nn.Parameter(torch.zeros(64, 14, 1)[:, ::2])              # non-contiguous weight
-    assert not est._pass_ok(x, odd, n)
+    odd[0] = torch.nn.Parameter(torch.zeros(64, 14, 1)[:, ::2])              # non-contiguous weight: fine since round 6 (the
+    assert est._pass_ok(x, odd, n)                                           # parameters are packed into one dense vector first)
+    broken = [p for p in flat]
+    broken[4] = torch.nn.Parameter(torch.zeros(128, 32, 1))                  # a chain of widths that does not close
+    assert not est._pass_ok(x, broken, n)
     net = EE.ErrorEstimator(7)
     net.half()
-    net.float()                                                              # same Parameter objects, dtype back: the cached answer holds
+    net.float()                                                              # same Parameter objects, dtype back
     flat2, n2 = flat_of(net)
     assert est._pass_ok(x, flat2, n2)
     net.half()
-    assert not est._pass_ok(x, flat_of(net)[0], n2)                          # ... and is not trusted once the dtype changed
+    assert not est._pass_ok(x, flat_of(net)[0], n2)                          # every tensor is looked at on every call: no stale answer
+    flat3, n3 = flat_of(EE.ErrorEstimator(7))
+    flat3[6].data = flat3[6].data.half()                                     # ONE parameter's data swapped under the same object
+    assert not est._pass_ok(x, flat3, n3)
+    assert est.prepare([tuple(flat[4 * l:4 * l + 4]) for l in range(n)], (flat[-2], flat[-1])) is None  # CPU parameters: nothing to prepare
 
 
 def test_fused_tail_is_reused_only_for_the_announced_ground_truth(dfepe):
