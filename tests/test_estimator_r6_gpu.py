@@ -263,17 +263,25 @@ def test_parameters_prepared_once_serve_every_call_of_a_forward(dfepe, B, N, cal
             assert torch.equal(other(xs[0]), alone(xs[0]))
 
 
-def test_whole_model_at_1000_points_through_the_fused_estimators(dfepe):
-    """compat.DeepFNet (depth 3, 4 pairs x 1000 points: the shape of deepFEPE/configs/kitti_corr_baseline.yaml) + F-loss + pose loss +
-    backward with the matrix-core estimators against the SAME model on the stock PyTorch estimators (identical parameters, both fp32):
-    logits, F per layer, loss and every parameter gradient agree to the fp32 reordering noise the N = 100 golden test documents."""
-    depth, B, N = 3, 4, 1000
+@pytest.mark.parametrize("B,N", [(4, 1000), (6, 2000)])
+def test_whole_model_at_the_reference_point_counts_through_the_fused_estimators(dfepe, B, N):
+    """compat.DeepFNet (depth 3, the shapes of deepFEPE/configs/kitti_corr_baseline.yaml: 1000-2000 points, a few pairs) + F-loss + pose
+    loss + backward with the matrix-core estimators against the SAME model on the stock PyTorch estimators (identical parameters, both
+    fp32): logits, F per layer, both losses, and every parameter gradient.  The estimators' heads are scaled down (near-uniform
+    weights on an outlier-free scene): with the deterministic random parameters as they are the fits are garbage whose eigenvector
+    adjoints amplify the 1e-4 distance between two fp32 evaluations of the logits to percents of a gradient
+    (scripts/whole_model_fd_check.py: the objective's own central differences then sit closer to this package's gradient than to the
+    stock path's) -- no yardstick.  The N = 100 golden test pins the same code path to the reference's gradients."""
+    depth = 3
     D = dfepe.compat.DeepFNet
     net = D.DeepFNet(depth=depth, image_size=[376, 1241, 3], if_quality=False).to(DEV)
     dfepe.synth.fill_params_deterministic(net, seed=5)
+    with torch.no_grad():
+        for est in (net.input_weights, net.update_weights):
+            est.fw[-1].weight.mul_(0.05)
     ref = D.DeepFNet(depth=depth, image_size=[376, 1241, 3], if_quality=False, fused_estimator=False).to(DEV)
     ref.load_state_dict(net.state_dict())
-    sc = dfepe.synth.make_scene(B, N, seed=3, outlier_ratio=0.2, noise_px=0.5)
+    sc = dfepe.synth.make_scene(B, N, seed=3, outlier_ratio=0.0, noise_px=0.5)
     b = {k: sc[k].to(DEV) for k in ("matches_xy_ori", "pts1_virt_ori", "pts2_virt_ori", "Ks", "delta_Rtijs_4_4", "qs_cam", "ts_cam")}
     tg = dfepe.compat.train_good_utils
 
@@ -286,20 +294,26 @@ def test_whole_model_at_1000_points_through_the_fused_estimators(dfepe):
         lt = torch.clamp(torch.stack(geo["t_l2_error_layers_list"]), 0.0, 0.5).mean()
         loss = losses["loss_F"] + lq + 0.1 * lt
         loss.backward()
-        return outs, loss.detach()
+        return outs, (float(losses["loss_F"].detach()), float(lq.detach()), float(lt.detach()))
 
     oa, la = step(net)
     assert type(oa["logits_layers"][1].grad_fn).__name__.startswith("_EstimatorPackedFunction")
     ob, lb = step(ref)
     for l in range(depth):
-        assert float((oa["logits_layers"][l].detach() - ob["logits_layers"][l].detach()).abs().max()) < 1e-3, l
+        assert float((oa["logits_layers"][l].detach() - ob["logits_layers"][l].detach()).abs().max()) < 1e-4, l
         Fa, Fb = oa["out_layers"][l].detach().flatten(1), ob["out_layers"][l].detach().flatten(1)
         Fa, Fb = Fa / Fa.norm(dim=1, keepdim=True), Fb / Fb.norm(dim=1, keepdim=True)
         s = torch.sign((Fa * Fb).sum(1, keepdim=True))
-        assert float((Fa * s - Fb).norm(dim=1).max()) < 2e-4, l
-    assert abs(float(la) - float(lb)) < 1e-4 * abs(float(lb)) + 1e-7
+        assert float((Fa * s - Fb).norm(dim=1).max()) < 2e-5, l
+    for x, y in zip(la, lb):
+        assert abs(x - y) < 1e-4 * abs(y) + 1e-7, (la, lb)
+    top = max(float(p.grad.norm()) for p in ref.parameters())
+    worst = 0.0
     for (name, pa), (_, pb) in zip(net.named_parameters(), ref.named_parameters()):
         if float(pa.grad.abs().max()) == 0.0:  # biases that cancel in an InstanceNorm: exact zero here, rounding noise there
-            assert name.endswith(".bias") and float(pb.grad.abs().max()) < 1e-6 * float(lb) + 1e-9, name
+            assert name.endswith(".bias") and float(pb.grad.norm()) < 1e-5 * top, name
             continue
-        assert float((pa.grad - pb.grad).norm() / pb.grad.norm()) < 5e-3, name
+        dist = float((pa.grad - pb.grad).norm())
+        worst = max(worst, dist / max(float(pb.grad.norm()), 1e-3 * top))
+        assert dist < 1e-2 * float(pb.grad.norm()) + 1e-4 * top, (name, dist, float(pb.grad.norm()), top)
+    print(f"whole model at {B} x {N}: worst parameter-gradient distance between the fused and the stock estimators {worst:.1e}")
