@@ -478,8 +478,10 @@ int dfepe_inorm_lrelu_bwd(const float *Y, const float *gA, const float *gamma, c
  *   dfepe_est_norm_fwd_r / dfepe_est_in_bwd_r   dfepe_est_norm_fwd / dfepe_est_in_bwd_n for N <= 2048 with the pair's block RESIDENT IN
  *                        REGISTERS: one launch, one read of the product, given as `splits` partials (added in slice order); a workgroup =
  *                        one pair x 32 channels
- *   dfepe_est_gemm_nt_gx the data gradient of the FIRST layer stored as the estimator's input gradient gx [pairs][C0][N] (was: a
- *                        transposing launch behind the plain product)
+ *   dfepe_est_gemm_nt_gx the data gradient of the FIRST layer stored as the estimator's input gradient: element (pair, ch, n) at
+ *                        pair * gx_stride_pair + ch * gx_stride_ch + n (was: a transposing launch behind the plain product).  x and gx of
+ *                        dfepe_est_forward / dfepe_est_backward take the same two strides: dense [B][C0][N] (C0 N, N) or a view of the
+ *                        channel-major [C0][B][N] buffers compat.DeepFNet keeps its estimator inputs in (N, B N) -- no copies
  *   dfepe_est_gemm_tn_multi   dfepe_est_gemm_tn for n_layers <= 8 layers over the same columns in ONE launch (host arrays indexed by layer)
  *   dfepe_est_prep_bytes / dfepe_est_prepare   the weights' planes of one estimator (power-of-two scales, scaled fp16 planes, transposed
  *                        bf16 planes) into a caller-owned buffer `prep`, two launches; dfepe_est_forward / dfepe_est_backward given
@@ -514,7 +516,7 @@ int dfepe_est_gemm_nt_f16_splitk(const void *A, size_t a_plane, const void *B, s
 int dfepe_est_gemm_nt_splitk(const void *A, size_t a_plane, const void *B, size_t b_plane, int M, int ncols, int K, float *out, int ldc,
                              int splits, size_t split_stride, void *stream);
 int dfepe_est_gemm_nt_gx(const void *A, size_t a_plane, const void *B, size_t b_plane, int M, int ncols, int K, float *gx, int C0, int N,
-                         void *stream);
+                         long gx_stride_pair, long gx_stride_ch, void *stream);
 int dfepe_est_gemm_tn_multi(int n_layers, const void *const *dY, const size_t *dy_plane, const int *Cout, const void *const *X,
                             const size_t *x_plane, const int *Cin, int ncols, const int *slices, float *const *part, void *stream);
 int dfepe_est_norm_fwd_r(const float *Y, int ldy, int splits, size_t split_stride, int C, long n_pairs, int N, const float *gamma,
@@ -550,13 +552,13 @@ int dfepe_est_in_bwd_n(const float *dA, const float *dlogit, const float *w_head
 size_t dfepe_est_saved_bytes(int n_hidden, const int *Co, const int *Ci, long B, int C0, int N, int need_gx);
 size_t dfepe_est_forward_workspace_bytes(int n_hidden, const int *Co, const int *Ci, long B, int C0, int N, int keep);
 size_t dfepe_est_backward_workspace_bytes(int n_hidden, const int *Co, const int *Ci, long B, int C0, int N, int need_gx);
-int dfepe_est_forward(const float *x, long B, int C0, int N, int n_hidden, const float *const *W, const float *const *gamma,
+int dfepe_est_forward(const float *x, long x_stride_b, long x_stride_c, long B, int C0, int N, int n_hidden, const float *const *W, const float *const *gamma,
                       const float *const *beta, const int *Co, const int *Ci, const float *w_head, const float *b_head, float eps,
                       float slope, void *saved, int need_gx, void *workspace, const void *prep, float *logits, void *stream);
 int dfepe_est_backward(const float *g_logits, long B, int C0, int N, int n_hidden, const float *const *W, const float *const *gamma,
                        const float *const *beta, const int *Co, const int *Ci, const float *w_head, float slope, const void *saved,
                        void *workspace, const void *prep, float *const *g_W, float *const *g_bias, float *const *g_gamma,
-                       float *const *g_beta, float *g_w_head, float *g_b_head, float *gx, void *stream);
+                       float *const *g_beta, float *g_w_head, float *g_b_head, float *gx, long gx_stride_b, long gx_stride_c, void *stream);
 int dfepe_est_head_fwd(const void *planes, size_t plane_stride, int C, int ncols, const float *w, const float *bias, float *logits,
                        void *stream);
 int dfepe_est_head_dw(const void *planes, size_t plane_stride, int C, int ncols, int blocks, const float *dlogit, float *part,

@@ -83,13 +83,13 @@ _SIGNATURES = {
     "dfepe_est_saved_bytes": (c_size_t, [c_int, _P, _P, c_long, c_int, c_int, c_int]),
     "dfepe_est_forward_workspace_bytes": (c_size_t, [c_int, _P, _P, c_long, c_int, c_int, c_int]),
     "dfepe_est_backward_workspace_bytes": (c_size_t, [c_int, _P, _P, c_long, c_int, c_int, c_int]),
-    "dfepe_est_forward": (c_int, [_P, c_long, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P, _P, _P, _P]),
-    "dfepe_est_backward": (c_int, [_P, c_long, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dfepe_est_forward": (c_int, [_P, c_long, c_long, c_long, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P, _P, _P, _P]),
+    "dfepe_est_backward": (c_int, [_P, c_long, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_long, c_long, _P]),
     "dfepe_est_head_fwd": (c_int, [_P, c_size_t, c_int, c_int, _P, _P, _P, _P]),
     "dfepe_est_head_dw": (c_int, [_P, c_size_t, c_int, c_int, c_int, _P, _P, _P, _P]),
     "dfepe_est_gemm_nt_f16_splitk": (c_int, [_P, c_size_t, _P, c_size_t, c_int, c_int, c_int, _P, _P, c_int, c_int, c_size_t, _P]),
     "dfepe_est_gemm_nt_splitk": (c_int, [_P, c_size_t, _P, c_size_t, c_int, c_int, c_int, _P, c_int, c_int, c_size_t, _P]),
-    "dfepe_est_gemm_nt_gx": (c_int, [_P, c_size_t, _P, c_size_t, c_int, c_int, c_int, _P, c_int, c_int, _P]),
+    "dfepe_est_gemm_nt_gx": (c_int, [_P, c_size_t, _P, c_size_t, c_int, c_int, c_int, _P, c_int, c_int, c_long, c_long, _P]),
     "dfepe_est_gemm_tn_multi": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P]),
     "dfepe_est_norm_fwd_r": (c_int, [_P, c_int, c_int, c_size_t, c_int, c_long, c_int, _P, _P, c_float, c_float, _P, c_size_t, _P, c_size_t, _P, _P]),
     "dfepe_est_in_bwd_r": (c_int, [_P, c_int, c_int, c_size_t, _P, _P, _P, c_size_t, _P, _P, _P, c_float, c_int, c_long, c_int, _P, c_size_t, _P, _P, _P]),

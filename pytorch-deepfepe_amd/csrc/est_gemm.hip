@@ -183,6 +183,8 @@ struct EpiArgs {
   // EPI_F32, gx != null: the product is the gradient w.r.t. the estimator's input -- stored as gx[pair][ch][n], ch < gx_C0, col = pair * gx_N + n
   float* gx;
   int gx_C0, gx_N;
+  long gx_sb, gx_sc;  // element strides of gx between pairs / channels (points are contiguous): [pairs][C0][N] dense, or the channel-major
+                      // [C0][pairs][N] buffer the model keeps its estimator inputs in
   // EPI_IN
   const float* gamma;
   const float* beta;
@@ -466,10 +468,10 @@ est_gemm_nt_kernel(const bf16_t* __restrict__ A, size_t a_plane, const bf16_t* _
         const int cl = nt * 16 + c, col = n0 + cl;
         if (cl < BSTEP && col < ncols) {
           const int pr = col / E.gx_N, pt = col - pr * E.gx_N;
-          float* dst = E.gx + ((size_t)pr * E.gx_C0 + ch8) * E.gx_N + pt;
+          float* dst = E.gx + (size_t)pr * E.gx_sb + (size_t)ch8 * E.gx_sc + pt;
 #pragma unroll
           for (int j = 0; j < 8; ++j)
-            if (ch8 + j < E.gx_C0) dst[(size_t)j * E.gx_N] = acc[j >> 2][nt][j & 3] * unscale;
+            if (ch8 + j < E.gx_C0) dst[(size_t)j * E.gx_sc] = acc[j >> 2][nt][j & 3] * unscale;
         }
       }
       return;
@@ -1801,16 +1803,16 @@ extern "C" int dfepe_est_gemm_nt_f16_splitk(const void* A, size_t a_plane, const
 
 // plain product: out[col][m] (fp32, ld = ldc) = sum_terms A_i[m][:] . B_j[col][:]; n_planes = 2 (three products) or 3 (six); splits as above
 // (two planes only); gx != null (two planes, splits = 1): the product is the gradient w.r.t. the estimator's input and is stored as
-// gx[pair][ch][n], ch < gx_C0, col = pair * gx_N + n, instead of out (round 6: was a transposing launch of its own)
+// gx[pair * gx_sb + ch * gx_sc + n], ch < gx_C0, col = pair * gx_N + n, instead of out (round 6: was a transposing launch of its own)
 static int nt_bf16_launch(const void* A, size_t a_plane, const void* B, size_t b_plane, int M, int ncols, int K, int n_planes, float* out,
-                          int ldc, int splits, size_t split_stride, float* gx, int gx_C0, int gx_N, void* stream) {
+                          int ldc, int splits, size_t split_stride, float* gx, int gx_C0, int gx_N, long gx_sb, long gx_sc, void* stream) {
   if (!A || !B || (!out && !gx) || M <= 0 || (M & 7) || ncols <= 0 || K <= 0 || (K % BK)) return DFEPE_ERR_INVALID_ARG;
   if (!gx && (ldc < M || (ldc & 3))) return DFEPE_ERR_INVALID_ARG;
-  if (gx && (gx_C0 <= 0 || gx_C0 > M || gx_N <= 0 || (ncols % gx_N) || splits != 1 || n_planes != 2)) return DFEPE_ERR_INVALID_ARG;
+  if (gx && (gx_C0 <= 0 || gx_C0 > M || gx_N <= 0 || (ncols % gx_N) || splits != 1 || n_planes != 2 || gx_sb <= 0 || gx_sc <= 0)) return DFEPE_ERR_INVALID_ARG;
   if (n_planes != 2 && n_planes != 3) return DFEPE_ERR_INVALID_ARG;
   if (splits < 1 || splits > K / BK || (splits > 1 && (n_planes != 2 || split_stride < (size_t)ncols * ldc))) return DFEPE_ERR_INVALID_ARG;
   EpiArgs E{};
-  E.out = out; E.ldc = ldc; E.split_stride = split_stride; E.gx = gx; E.gx_C0 = gx_C0; E.gx_N = gx_N;
+  E.out = out; E.ldc = ldc; E.split_stride = split_stride; E.gx = gx; E.gx_C0 = gx_C0; E.gx_N = gx_N; E.gx_sb = gx_sb; E.gx_sc = gx_sc;
   const dim3 grid((ncols + BSTEP - 1) / BSTEP, (M + BM - 1) / BM, splits), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (n_planes == 3)
@@ -1826,15 +1828,15 @@ static int nt_bf16_launch(const void* A, size_t a_plane, const void* B, size_t b
 }
 extern "C" int dfepe_est_gemm_nt(const void* A, size_t a_plane, const void* B, size_t b_plane, int M, int ncols, int K, int n_planes,
                                  float* out, int ldc, void* stream) {
-  return nt_bf16_launch(A, a_plane, B, b_plane, M, ncols, K, n_planes, out, ldc, 1, 0, nullptr, 0, 0, stream);
+  return nt_bf16_launch(A, a_plane, B, b_plane, M, ncols, K, n_planes, out, ldc, 1, 0, nullptr, 0, 0, 0, 0, stream);
 }
 extern "C" int dfepe_est_gemm_nt_splitk(const void* A, size_t a_plane, const void* B, size_t b_plane, int M, int ncols, int K, float* out,
                                         int ldc, int splits, size_t split_stride, void* stream) {
-  return nt_bf16_launch(A, a_plane, B, b_plane, M, ncols, K, 2, out, ldc, splits, split_stride, nullptr, 0, 0, stream);
+  return nt_bf16_launch(A, a_plane, B, b_plane, M, ncols, K, 2, out, ldc, splits, split_stride, nullptr, 0, 0, 0, 0, stream);
 }
 extern "C" int dfepe_est_gemm_nt_gx(const void* A, size_t a_plane, const void* B, size_t b_plane, int M, int ncols, int K, float* gx, int C0,
-                                    int N, void* stream) {
-  return nt_bf16_launch(A, a_plane, B, b_plane, M, ncols, K, 2, nullptr, 0, 1, 0, gx, C0, N, stream);
+                                    int N, long gx_stride_pair, long gx_stride_ch, void* stream) {
+  return nt_bf16_launch(A, a_plane, B, b_plane, M, ncols, K, 2, nullptr, 0, 1, 0, gx, C0, N, gx_stride_pair, gx_stride_ch, stream);
 }
 
 // data gradient + the adjoint of the layer below in one launch (N = dfepe_est_points()):
@@ -2331,11 +2333,11 @@ BwdLayout bwd_layout(const PassDims& D, bool need_gx) {
   return L;
 }
 
-// x [B][C0][N] fp32 -> planes [cols = B N][K0]: two fp16 (what the first layer multiplies by) and, if wanted, two bf16 (what its
+// x [B][C0][N] fp32 (element (b, c, n) at b * x_sb + c * x_sc + n: dense, or a view of the channel-major [C0][B][N] buffer) -> planes [cols = B N][K0]: two fp16 (what the first layer multiplies by) and, if wanted, two bf16 (what its
 // weight gradient multiplies by); channels C0..K0 zero.  A thread = one column x one block of 32 channels: its reads of x run along n
 // with its neighbours' (coalesced), its 64 bytes per plane are contiguous with theirs.
 __global__ void __launch_bounds__(256)
-est_input_split_kernel(const float* __restrict__ x, long B, int C0, int N, int K0, bf16_t* __restrict__ ph, size_t h_stride,
+est_input_split_kernel(const float* __restrict__ x, long x_sb, long x_sc, long B, int C0, int N, int K0, bf16_t* __restrict__ ph, size_t h_stride,
                        bf16_t* __restrict__ pb, size_t b_stride) {
   const long cols = B * (long)N;
   const long t = (long)blockIdx.x * 256 + threadIdx.x;  // (channel block, column), column fastest
@@ -2347,7 +2349,7 @@ est_input_split_kernel(const float* __restrict__ x, long B, int C0, int N, int K
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int ch = cb + 2 * i;
-    const float v0 = (ch < C0) ? x[((size_t)b * C0 + ch) * N + n] : 0.f, v1 = (ch + 1 < C0) ? x[((size_t)b * C0 + ch + 1) * N + n] : 0.f;
+    const float v0 = (ch < C0) ? x[(size_t)b * x_sb + (size_t)ch * x_sc + n] : 0.f, v1 = (ch + 1 < C0) ? x[(size_t)b * x_sb + (size_t)(ch + 1) * x_sc + n] : 0.f;
     split2h(v0, v1, h0[i], h1[i]);
     split2(v0, v1, q0[i], q1[i]);
   }
@@ -2407,14 +2409,15 @@ extern "C" int dfepe_est_prepare(int n_hidden, const float* const* W, const int*
 
 // logits [cols] = head(stack(x)); saved != null: everything dfepe_est_backward needs is left there (need_gx is accepted for symmetry with
 // the size functions and ignored: the first layer's transposed weight planes are a few KB and always kept, so that a backward may ask
-// for gx or not).  x [B][C0][N], W[l] [Co][Ci], gamma / beta [l] [Co], w_head [Co of the last layer], b_head [1] or null: fp32.
+// for gx or not).  x [B][C0][N] with element (b, c, n) at b * x_stride_b + c * x_stride_c + n (dense: C0 N, N; the model's channel-major input
+// buffers [C0][B][N]: N, B N -- no copy either way), W[l] [Co][Ci], gamma / beta [l] [Co], w_head [Co of the last layer], b_head [1] or null: fp32.
 // prep: null, or the planes dfepe_est_prepare made of these very weights.
-extern "C" int dfepe_est_forward(const float* x, long B, int C0, int N, int n_hidden, const float* const* W, const float* const* gamma,
+extern "C" int dfepe_est_forward(const float* x, long x_stride_b, long x_stride_c, long B, int C0, int N, int n_hidden, const float* const* W, const float* const* gamma,
                                  const float* const* beta, const int* Co, const int* Ci, const float* w_head, const float* b_head, float eps,
                                  float slope, void* saved, int need_gx, void* workspace, const void* prep, float* logits, void* stream) {
   PassDims D;
   EST_TRY(pass_dims(D, n_hidden, Co, Ci, B, C0, N));
-  if (!x || !W || !gamma || !beta || !w_head || !workspace || !logits) return DFEPE_ERR_INVALID_ARG;
+  if (!x || !W || !gamma || !beta || !w_head || !workspace || !logits || x_stride_b <= 0 || x_stride_c <= 0) return DFEPE_ERR_INVALID_ARG;
   if (((uintptr_t)workspace & 15) || ((uintptr_t)saved & 15) || ((uintptr_t)prep & 15)) return DFEPE_ERR_INVALID_ARG;
   const bool keep = saved != nullptr;
   const SavedLayout S = saved_layout(D, need_gx != 0);
@@ -2429,7 +2432,7 @@ extern "C" int dfepe_est_forward(const float* x, long B, int C0, int N, int n_hi
   // the input's planes
   {
     const long threads = cols * (D.K0 / 32);
-    hipLaunchKernelGGL(est_input_split_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, x, B, C0, N, D.K0,
+    hipLaunchKernelGGL(est_input_split_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, x, x_stride_b, x_stride_c, B, C0, N, D.K0,
                        reinterpret_cast<bf16_t*>(ws + F.xh), (size_t)cols * D.K0, keep ? reinterpret_cast<bf16_t*>(sv + S.act[0]) : nullptr,
                        (size_t)cols * D.K0);
     if (hipGetLastError() != hipSuccess) return DFEPE_ERR_HIP;
@@ -2470,17 +2473,19 @@ extern "C" int dfepe_est_forward(const float* x, long B, int C0, int N, int n_hi
 }
 
 // every gradient of one dfepe_est_forward(saved != null): g_W[l] [Co][Ci], g_bias[l] [Co] (zeros: the bias cancels in the
-// normalisation), g_gamma[l], g_beta[l] [Co], g_w_head [C], g_b_head [1] or null, gx [B][C0][N] or null (needs need_gx at the forward);
+// normalisation), g_gamma[l], g_beta[l] [Co], g_w_head [C], g_b_head [1] or null, gx or null (needs need_gx at the forward; element
+// (b, c, n) at b * gx_stride_b + c * gx_stride_c + n, like x);
 // prep: what the forward was given (null: the transposed weight planes are in `saved`)
 extern "C" int dfepe_est_backward(const float* g_logits, long B, int C0, int N, int n_hidden, const float* const* W, const float* const* gamma,
                                   const float* const* beta, const int* Co, const int* Ci, const float* w_head, float slope, const void* saved,
                                   void* workspace, const void* prep, float* const* g_W, float* const* g_bias, float* const* g_gamma,
-                                  float* const* g_beta, float* g_w_head, float* g_b_head, float* gx, void* stream) {
+                                  float* const* g_beta, float* g_w_head, float* g_b_head, float* gx, long gx_stride_b, long gx_stride_c, void* stream) {
   PassDims D;
   EST_TRY(pass_dims(D, n_hidden, Co, Ci, B, C0, N));
   if (!g_logits || !W || !gamma || !beta || !w_head || !saved || !workspace || !g_W || !g_bias || !g_gamma || !g_beta || !g_w_head)
     return DFEPE_ERR_INVALID_ARG;
   if (((uintptr_t)workspace & 15) || ((uintptr_t)saved & 15) || ((uintptr_t)prep & 15)) return DFEPE_ERR_INVALID_ARG;
+  if (gx && (gx_stride_b <= 0 || gx_stride_c <= 0)) return DFEPE_ERR_INVALID_ARG;
   const bool need_gx = gx != nullptr;
   const SavedLayout S = saved_layout(D, need_gx);
   const BwdLayout L = bwd_layout(D, need_gx);
@@ -2578,7 +2583,7 @@ extern "C" int dfepe_est_backward(const float* g_logits, long B, int C0, int N, 
     if (l > 0 || need_gx) {
       const void* WT = pp ? static_cast<const void*>(pp + P.wt[l]) : static_cast<const void*>(sv + S.wt[l]);
       if (l == 0) {
-        EST_TRY(nt_bf16_launch(WT, (size_t)K * C, dY, (size_t)cols * C, K, (int)cols, C, 2, nullptr, 0, 1, 0, gx, C0, N, stream));
+        EST_TRY(nt_bf16_launch(WT, (size_t)K * C, dY, (size_t)cols * C, K, (int)cols, C, 2, nullptr, 0, 1, 0, gx, C0, N, gx_stride_b, gx_stride_c, stream));
       } else {
         up = dgrad_plan(D, l);
         if (up.fused) {
@@ -2588,7 +2593,7 @@ extern "C" int dfepe_est_backward(const float* g_logits, long B, int C0, int N, 
                                          stream));
           pending = true;
         } else {
-          EST_TRY(nt_bf16_launch(WT, (size_t)K * C, dY, (size_t)cols * C, K, (int)cols, C, 2, dA, K, up.S, (size_t)cols * K, nullptr, 0, 0, stream));
+          EST_TRY(nt_bf16_launch(WT, (size_t)K * C, dY, (size_t)cols * C, K, (int)cols, C, 2, dA, K, up.S, (size_t)cols * K, nullptr, 0, 0, 0, 0, stream));
         }
       }
     }

@@ -449,20 +449,25 @@ class _EstimatorPackedFunction(torch.autograd.Function):
         with _on(dev):
             st = _stream()
             xin = x.detach()
-            xin = xin if (xin.dtype == torch.float32 and xin.is_contiguous()) else xin.float().contiguous()
+            # any fp32 layout whose points are contiguous is read in place: the model hands over [B, C, N] VIEWS of its channel-major
+            # [C, B, N] input buffers (ops.estimator_input), and the input gradient goes back in the same layout (its rows are then
+            # the dense [B, N] blocks the fit's adjoint wants) -- round 5 copied both ways
+            if not (xin.dtype == torch.float32 and (xin.stride(2) == 1 or N == 1) and xin.stride(0) > 0 and xin.stride(1) > 0):
+                xin = xin.float().contiguous()
             need_gx = bool(keep and ctx.needs_input_grad[2])
             saved = None
             if keep:
                 saved = torch.empty(lib.dfepe_est_saved_bytes(n, P.Co, P.Ci, B, C0, N, int(need_gx)), device=dev, dtype=torch.uint8)
             ws = torch.empty(lib.dfepe_est_forward_workspace_bytes(n, P.Co, P.Ci, B, C0, N, int(keep)), device=dev, dtype=torch.uint8)
             logits = torch.empty(B, 1, N, device=dev, dtype=torch.float32)
-            rc = lib.dfepe_est_forward(_ptr(xin), B, C0, N, n, P.W, P.gamma, P.beta, P.Co, P.Ci, P.w_head, P.b_head, float(eps), float(slope),
+            rc = lib.dfepe_est_forward(_ptr(xin), xin.stride(0), xin.stride(1), B, C0, N, n, P.W, P.gamma, P.beta, P.Co, P.Ci, P.w_head, P.b_head, float(eps), float(slope),
                                        _ptr(saved), int(need_gx), _ptr(ws), _ptr(P.prep), _ptr(logits), st)
             _lib.check(rc, "dfepe_est_forward")
         ctx.cfg = cfg
         ctx.P = P  # keeps `prep` alive until the backward has read it
         ctx.shape = (B, C0, N)
         ctx.need_gx = need_gx
+        ctx.x_strides = (xin.stride(0), xin.stride(1))
         ctx.save_for_backward(*([packed, saved] if keep else []))
         return logits
 
@@ -482,9 +487,15 @@ class _EstimatorPackedFunction(torch.autograd.Function):
             ws = torch.empty(lib.dfepe_est_backward_workspace_bytes(n, P.Co, P.Ci, B, C0, N, int(ctx.need_gx)), device=dev, dtype=torch.uint8)
             flat = torch.empty_like(packed)  # every parameter gradient, laid out like `packed`: each element is written by the call
             gW, gb, gg, gbt, gwh, gbh = P.pointers(flat.data_ptr())
-            gx = torch.empty(B, C0, N, device=dev, dtype=torch.float32) if ctx.need_gx else None
+            gx = None
+            if ctx.need_gx:
+                if ctx.x_strides == (N, B * N):  # x was a view of a channel-major buffer: so is its gradient
+                    gx = torch.empty(C0, B, N, device=dev, dtype=torch.float32).permute(1, 0, 2)
+                else:
+                    gx = torch.empty(B, C0, N, device=dev, dtype=torch.float32)
             rc = lib.dfepe_est_backward(_ptr(gl), B, C0, N, n, P.W, P.gamma, P.beta, P.Co, P.Ci, P.w_head, float(slope), _ptr(saved), _ptr(ws),
-                                        _ptr(P.prep), gW, gb, gg, gbt, gwh, gbh, _ptr(gx), st)
+                                        _ptr(P.prep), gW, gb, gg, gbt, gwh, gbh, _ptr(gx), 0 if gx is None else gx.stride(0),
+                                        0 if gx is None else gx.stride(1), st)
             _lib.check(rc, "dfepe_est_backward")
         return (None, None, gx, flat if ctx.needs_input_grad[3] else None)
 

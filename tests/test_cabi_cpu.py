@@ -79,13 +79,13 @@ def test_argument_validation_without_launching(dfepe):
     assert L.dfepe_est_wprep_workspace_bytes(5) >= 5 * 4 and L.dfepe_est_wprep_workspace_bytes(0) == 0
     assert L.dfepe_est_dgamma_zero_multi(0, *([None] * 17), 0.01, 100, 4, None) == -1 and L.dfepe_est_dgamma_zero_multi(2, *([None] * 17), 0.01, 100, 4, None) == -1
     assert L.dfepe_est_saved_bytes(0, None, None, 4, 7, 100, 0) == 0 and L.dfepe_est_forward_workspace_bytes(9, None, None, 4, 7, 100, 1) == 0
-    assert L.dfepe_est_forward(None, 4, 7, 100, 5, None, None, None, None, None, None, None, 1e-5, 0.01, None, 0, None, None, None, None) == -1
-    assert L.dfepe_est_backward(None, 4, 7, 100, 5, None, None, None, None, None, None, 0.01, None, None, None, None, None, None, None, None, None, None, None) == -1
+    assert L.dfepe_est_forward(None, 700, 100, 4, 7, 100, 5, None, None, None, None, None, None, None, 1e-5, 0.01, None, 0, None, None, None, None) == -1
+    assert L.dfepe_est_backward(None, 4, 7, 100, 5, None, None, None, None, None, None, 0.01, None, None, None, None, None, None, None, None, None, None, 700, 100, None) == -1
     assert L.dfepe_est_colsum(0, None, None, None, None, None) == -1 and L.dfepe_est_colsum(41, None, None, None, None, None) == -1
     # version 154: split-K products, the register-resident normalisations, the table-driven weight gradient, prepared parameters
     assert L.dfepe_est_gemm_nt_f16_splitk(None, 0, None, 0, 64, 200, 256, None, None, 64, 2, 0, None) == -1
     assert L.dfepe_est_gemm_nt_splitk(None, 0, None, 0, 64, 200, 256, None, 64, 2, 0, None) == -1
-    assert L.dfepe_est_gemm_nt_gx(None, 0, None, 0, 32, 200, 64, None, 7, 100, None) == -1
+    assert L.dfepe_est_gemm_nt_gx(None, 0, None, 0, 32, 200, 64, None, 7, 100, 700, 100, None) == -1
     assert L.dfepe_est_gemm_tn_multi(0, None, None, None, None, None, None, 800, None, None, None) == -1
     assert L.dfepe_est_gemm_tn_multi(9, None, None, None, None, None, None, 800, None, None, None) == -1
     assert L.dfepe_est_norm_fwd_r(None, 64, 1, 0, 64, 2, 1000, None, None, 1e-5, 0.01, None, 0, None, 0, None, None) == -1

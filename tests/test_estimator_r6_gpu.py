@@ -157,8 +157,8 @@ def test_weight_gradients_of_all_layers_in_one_launch(dfepe):
 
 @pytest.mark.parametrize("C0,pairs,N", [(7, 5, 100), (4, 3, 37), (7, 2, 1000)])
 def test_input_gradient_is_stored_by_the_gemm_epilogue(dfepe, C0, pairs, N):
-    """dfepe_est_gemm_nt_gx writes the first layer's data gradient as gx [pairs][C0][N]: bit for bit the plain product transposed and
-    cropped to the C0 real input channels."""
+    """dfepe_est_gemm_nt_gx writes the first layer's data gradient as gx [pairs][C0][N] (or channel-major [C0][pairs][N]): bit for bit
+    the plain product transposed and cropped to the C0 real input channels."""
     lib = dfepe._lib.lib()
     cols, K0, Co = pairs * N, 32, 64
     g = torch.Generator().manual_seed(C0 + N)
@@ -167,9 +167,38 @@ def test_input_gradient_is_stored_by_the_gemm_epilogue(dfepe, C0, pairs, N):
     dA = torch.zeros(cols, K0, device=DEV)
     assert lib.dfepe_est_gemm_nt(WT.data_ptr(), K0 * Co, dY.data_ptr(), cols * Co, K0, cols, Co, 2, dA.data_ptr(), K0, None) == 0
     gx = torch.full((pairs, C0, N), float("nan"), device=DEV)
-    assert lib.dfepe_est_gemm_nt_gx(WT.data_ptr(), K0 * Co, dY.data_ptr(), cols * Co, K0, cols, Co, gx.data_ptr(), C0, N, None) == 0
+    assert lib.dfepe_est_gemm_nt_gx(WT.data_ptr(), K0 * Co, dY.data_ptr(), cols * Co, K0, cols, Co, gx.data_ptr(), C0, N, C0 * N, N, None) == 0
+    gxc = torch.full((C0, pairs, N), float("nan"), device=DEV)  # the model's channel-major layout: same values, other strides
+    assert lib.dfepe_est_gemm_nt_gx(WT.data_ptr(), K0 * Co, dY.data_ptr(), cols * Co, K0, cols, Co, gxc.data_ptr(), C0, N, N, pairs * N, None) == 0
     torch.cuda.synchronize()
     assert torch.equal(gx, dA[:, :C0].reshape(pairs, N, C0).permute(0, 2, 1).contiguous())
+    assert torch.equal(gxc.permute(1, 0, 2), gx)
+
+
+def test_channel_major_input_views_are_read_and_differentiated_in_place(dfepe):
+    """The model hands the estimator [B, C, N] VIEWS of channel-major [C, B, N] buffers (ops.estimator_input): logits and parameter
+    gradients equal those of the dense copy bit for bit, and the input gradient comes back in the view's own layout (its rows dense)."""
+    EE = dfepe.compat.ErrorEstimators
+    net = EE.FusedErrorEstimator(7).to(DEV)
+    dfepe.synth.fill_params_deterministic(net, seed=4)
+    g = torch.Generator().manual_seed(3)
+    B, N = 6, 100
+    store = torch.rand(7, B, N, generator=g).to(DEV)
+    G = torch.randn(B, 1, N, generator=g).to(DEV)
+    outs = []
+    for dense in (False, True):
+        net.zero_grad(set_to_none=True)
+        x = store.permute(1, 0, 2)
+        x = (x.contiguous() if dense else x).detach().requires_grad_(True)
+        assert x.is_contiguous() == dense
+        y = net(x)
+        (y * G).sum().backward()
+        outs.append((y.detach().clone(), x.grad, [p.grad.clone() for p in net.parameters()]))
+    (ya, ga, pa), (yb, gb, pb) = outs
+    assert torch.equal(ya, yb) and torch.equal(ga, gb)
+    assert ga.stride() == (N, B * N, 1) and ga[:, 4, :].is_contiguous() and gb.is_contiguous()
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)
 
 
 def _fused_and_stock(dfepe, cin, seed):
