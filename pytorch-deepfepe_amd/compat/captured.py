@@ -27,6 +27,11 @@ signature gets a graph of its own (all graphs share one memory pool).  Contract 
     values, no .item() / .cpu(); python-side state it mutates is not replayed.
   * the optimizer updates parameters in place (every torch.optim one does); gradients are OVERWRITTEN by every replay, not
     accumulated, and ``optimizer.zero_grad(set_to_none=True)`` is harmless: the step re-attaches its static .grad tensors.
+  * every new graph VERIFIES ITSELF before it is trusted (round 6): the capture call runs the step eagerly on the static batch, then
+    replays the fresh graph twice and requires loss and every parameter gradient of both replays to equal the eager ones (ROCm 7.2's
+    graph packet capture replays a full-model step correctly once and wrongly ever after, see the package __init__); a graph that
+    fails is dropped, its signature stays eager and ONE error is logged.  Without the runtime workaround in effect
+    (``dfepe.HIP_GRAPH_PACKET_CAPTURE_OFF`` False) the helper does not capture at all unless ``allow_unsafe_graph=True``.
   * ``loss`` / ``aux`` are rewritten by the next call: copy what must outlive it.  Host-side metrics of get_Rt_loss found in
     ``aux`` are lazy while captured (no device synchronisation inside the step); ``step.realise(aux)`` returns a copy with the
     reference's numpy arrays / floats, read from the buffers as they are after the latest replay.
@@ -81,10 +86,11 @@ def _leaf_key(x):
 class _Entry:
     """One captured signature: static inputs, graph, static outputs, static gradients."""
 
-    __slots__ = ("seen", "static", "graph", "out", "grads", "batch")
+    __slots__ = ("seen", "static", "graph", "out", "grads", "batch", "eager_only")
 
     def __init__(self):
         self.seen = 0
+        self.eager_only = False  # its graph failed the self-check (or graphs are not allowed): every call of this signature runs eagerly
         self.static: Dict[tuple, torch.Tensor] = {}
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.out = None
@@ -94,7 +100,8 @@ class _Entry:
 
 class CapturedStep:
     def __init__(self, forward_and_loss: Callable[[Any], Tuple[torch.Tensor, Any]], parameters=(),
-                 device: Optional[torch.device] = None, warmup: int = 2, max_graphs: int = 8, enabled: bool = True):
+                 device: Optional[torch.device] = None, warmup: int = 2, max_graphs: int = 8, enabled: bool = True,
+                 allow_unsafe_graph: bool = False, verify: bool = True):
         """``parameters``: the nn.Module whose parameters the step trains (preferred), or an iterable of leaf tensors.
         With a module the step runs its forward over fresh VIEWS of the parameters (torch.nn.utils.stateless): gradients are then
         taken at nodes created on the capture stream.  With bare leaves they are taken at the leaves' AccumulateGrad nodes, which
@@ -111,6 +118,10 @@ class CapturedStep:
         self.warmup = max(1, int(warmup))  # at least one eager step: it sizes the allocator and runs every lazy initialisation
         self.max_graphs = int(max_graphs)
         self.enabled = bool(enabled)
+        self.allow_unsafe_graph = bool(allow_unsafe_graph)
+        self.verify = bool(verify)
+        self.n_rejected = 0  # graphs dropped by the self-check
+        self._complained = False
         self._entries: Dict[tuple, _Entry] = {}
         self._pool = None
         self._stream = torch.cuda.Stream(device=self.device)
@@ -127,7 +138,8 @@ class CapturedStep:
 
     def _zero_grads(self):
         for p in self.params:
-            p.grad = None
+            if p.requires_grad:  # a frozen parameter's .grad is none of this helper's business
+                p.grad = None
 
     def _run(self, batch):
         """forward + loss + backward.  The parameter gradients are taken with torch.autograd.grad and ASSIGNED to .grad, not
@@ -145,10 +157,12 @@ class CapturedStep:
         else:
             loss, aux = self.fn(batch)
             targets = self.params
-        if targets:
-            grads = torch.autograd.grad(loss, targets, allow_unused=True)
-            for p, g in zip(self.params, grads):
-                p.grad = g
+        # only what trains: autograd.grad raises for a target that does not require grad (allow_unused covers unused ones only)
+        idx = [i for i, p in enumerate(self.params) if p.requires_grad]
+        if idx:
+            grads = torch.autograd.grad(loss, [targets[i] for i in idx], allow_unused=True)
+            for i, g in zip(idx, grads):
+                self.params[i].grad = g
         return loss, aux
 
     def _eager(self, batch):
@@ -163,18 +177,42 @@ class CapturedStep:
         self.n_eager += 1
         return out
 
-    def _capture(self, ent: _Entry, batch):
-        from . import train_good_utils as tgu
+    def _complain(self, msg: str):
+        """One error-level message per helper: a training loop must not scroll it, and must not miss it."""
+        if not self._complained:
+            import logging
+
+            logging.getLogger("dfepe.CapturedStep").error(msg)
+            self._complained = True
+
+    def _graphs_allowed(self) -> bool:
         import sys
-        import warnings
 
         pkg = sys.modules[__name__.rsplit(".", 2)[0]]
-        if not getattr(pkg, "HIP_GRAPH_PACKET_CAPTURE_OFF", False):
-            warnings.warn("CapturedStep: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 is not in effect (the HIP runtime was initialised before this "
-                          "package was imported, or the environment sets it to another value); on ROCm 7.2 a captured step of the full "
-                          "model then replays with wrong parameter gradients from its second launch on (see the package __init__)",
-                          RuntimeWarning, stacklevel=3)
+        if getattr(pkg, "HIP_GRAPH_PACKET_CAPTURE_OFF", False) or self.allow_unsafe_graph:
+            return True
+        self._complain("CapturedStep: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 is not in effect (the HIP runtime was initialised before this package "
+                       "was imported, or the environment sets another value); on ROCm 7.2 a captured step of the full model then replays "
+                       "with wrong parameter gradients from its second launch on -- staying on the eager path "
+                       "(allow_unsafe_graph=True captures anyway, behind the self-check)")
+        return False
 
+    @staticmethod
+    def _same(a: Optional[torch.Tensor], b: Optional[torch.Tensor]) -> bool:
+        """Equal as a replay of the same kernels on the same inputs must be: bit for bit, or -- a caller's own atomics may reorder
+        sums -- to 1e-5 of the largest entry.  What the runtime bug leaves behind is stale or unwritten memory: nowhere near."""
+        if a is None or b is None:
+            return a is None and b is None
+        if a.shape != b.shape:
+            return False
+        if torch.equal(a, b):
+            return True
+        a64, b64 = a.detach().double(), b.detach().double()
+        return bool(torch.isfinite(a64).all()) and float((a64 - b64).abs().max()) <= 1e-5 * float(b64.abs().max()) + 1e-30
+
+    def _capture(self, ent: _Entry, batch) -> bool:
+        """Capture the step for this entry.  Returns False (entry marked eager-only, ent.out = the eager result on this batch) when
+        graphs are not allowed or the new graph fails its self-check."""
         cur = torch.cuda.current_stream(self.device)
         self._stream.wait_stream(cur)
         with torch.cuda.stream(self._stream):
@@ -186,21 +224,37 @@ class CapturedStep:
                         buf.requires_grad_(True)
                     ent.static[path] = buf
             ent.batch = _rebuild(batch, ent.static)
+            ref = None
+            if self.verify:  # the yardstick: this very step, eagerly, on the static batch
+                self._zero_grads()
+                ref_loss, _ = self._run(ent.batch)
+                ref = (ref_loss.detach().clone(), [None if p.grad is None else p.grad.detach().clone() for p in self.params])
             self._zero_grads()  # the captured backward then WRITES each gradient into memory of the graph's pool
         torch.cuda.synchronize(self.device)
         ent.graph = torch.cuda.CUDAGraph()
-        lazy = tgu.LAZY_HOST_METRICS
-        tgu.LAZY_HOST_METRICS = True
-        try:
-            with torch.cuda.graph(ent.graph, pool=self._pool, stream=self._stream):
-                ent.out = self._run(ent.batch)
-        finally:
-            tgu.LAZY_HOST_METRICS = lazy
+        # (get_Rt_loss hands out lazy host metrics by itself while its stream is being captured: no module-global is flipped here --
+        # round 5 toggled train_good_utils.LAZY_HOST_METRICS around the capture, under the feet of other threads)
+        with torch.cuda.graph(ent.graph, pool=self._pool, stream=self._stream):
+            ent.out = self._run(ent.batch)
         if self._pool is None:
             self._pool = ent.graph.pool()
         ent.grads = [p.grad for p in self.params]
         cur.wait_stream(self._stream)  # the static inputs were filled on the helper's stream; the replays run on the caller's
         self.n_captures += 1
+        if ref is not None:
+            ok = True
+            for _ in range(3 if self.allow_unsafe_graph else 2):  # the packet-capture bug shows from the SECOND launch of a graph on
+                ent.graph.replay()
+                torch.cuda.synchronize(self.device)
+                ok = ok and self._same(ent.out[0], ref[0]) and all(self._same(g, r) for g, r in zip(ent.grads, ref[1]))
+            if not ok:
+                self.n_rejected += 1
+                self._complain("CapturedStep: the captured step does not reproduce the eager step on its own batch (loss or parameter "
+                               "gradients differ after a replay) -- the graph is dropped and this batch signature stays on the eager path")
+                ent.graph, ent.grads, ent.out = None, [], None
+                ent.eager_only = True
+                return False
+        return True
 
     def _replay(self, ent: _Entry, batch, fresh: bool):
         # on the CALLER's current stream: a captured graph replays on any stream, and a hop to the helper's stream and back would
@@ -222,7 +276,8 @@ class CapturedStep:
                         dst.copy_(src, non_blocking=True)
         ent.graph.replay()
         for p, g in zip(self.params, ent.grads):
-            p.grad = g  # survives the caller's zero_grad(set_to_none=True)
+            if p.requires_grad:
+                p.grad = g  # survives the caller's zero_grad(set_to_none=True)
         self._refresh(ent.out[1])
         self.n_replays += 1
         return ent.out
@@ -252,10 +307,14 @@ class CapturedStep:
                 return self._eager(batch)
             ent = self._entries[key] = _Entry()
         if ent.graph is None:
-            if ent.seen < self.warmup:
+            if ent.eager_only or ent.seen < self.warmup:
                 ent.seen += 1
                 return self._eager(batch)
-            self._capture(ent, batch)
+            if not self._graphs_allowed():
+                ent.eager_only = True
+                return self._eager(batch)
+            if not self._capture(ent, batch):
+                return self._eager(batch)
             return self._replay(ent, batch, fresh=True)
         return self._replay(ent, batch, fresh=False)
 
