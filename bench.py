@@ -486,9 +486,17 @@ def main():
         kdur_us = event_time_us(fit_call)
         alg_bytes = B * (28 * N + 36)  # read 16N matches + 4N weights; write 36 F + 4N residual + 4N epi  
         achieved = alg_bytes / (kdur_us * 1e-6) / 1e9
-        row_kernel = True
-        kname = ("w8pt16_fwd_kernel<raw> (one 16-lane row per pair, correspondences in registers)" if N <= dfepe._lib.W8PT16_MAX_N
-                 else "w8pt16_fwd_kernel<0, raw> (one 16-lane row per pair, correspondences re-read per phase)")
+        # which kernel of the family the library launches for this shape (csrc/w8pt16.hip: use_coop / use_pair2 / LEAN)
+        if N <= dfepe._lib.W8PT16_MAX_N:
+            kname = ("w8pt16_fwd_lean_kernel<raw> (one 16-lane row per pair, 234 registers: two wavefronts per SIMD)" if B >= 12288
+                     else "w8pt16_fwd_kernel<raw> (one 16-lane row per pair, correspondences in registers)")
+        elif N <= 2048 and B <= 1280:
+            kname = "w8pt16_coop_fwd_kernel (a four-wavefront workgroup per pair, correspondences in registers)"
+        elif N <= 2048 and B < 8192:
+            kname = "w8pt16_pair2_fwd_kernel (two 16-lane rows of one wavefront per pair, correspondences re-read per phase)"
+        else:
+            kname = "w8pt16_fwd_kernel<0, raw> (one 16-lane row per pair, correspondences re-read per phase)"
+        row_kernel = N <= dfepe._lib.W8PT16_MAX_N
         traffic = issue = rocprof_us = rocprof_src = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -730,8 +738,14 @@ def main():
                     net.zero_grad(set_to_none=True)
                     fwd_loss(b)[0].backward()
 
-                def small_batch(Bs):
-                    small = [{k: scene[k][i * Bs:(i + 1) * Bs].contiguous() for k in keys} for i in range(2)]
+                def small_batch(Bs, Ns=None):
+                    if Ns is None or Ns == N:
+                        small = [{k: scene[k][i * Bs:(i + 1) * Bs].contiguous() for k in keys} for i in range(2)]
+                    else:  # another number of points per pair: scenes of its own (the same generator and seeds family)
+                        small = []
+                        for i in range(2):
+                            sc_ = dfepe.synth.make_scene(Bs, Ns, seed=2000 + i, outlier_ratio=outl, noise_px=0.5)
+                            small.append({k: sc_[k].to(dev) for k in keys})
                     for k in range(3):
                         eager_small(small[k & 1])
                     torch.cuda.synchronize()
@@ -748,13 +762,18 @@ def main():
                     for k in range(20):
                         helper(small[k & 1])
                     torch.cuda.synchronize()
-                    return {"B": Bs, "eager_ms_per_step": round(eager_small_ms, 3),
-                            "captured_step_ms_per_step": round((time.perf_counter() - f0) * 50.0, 3),
-                            "captures": helper.n_captures, "replays": helper.n_replays,
-                            "note": "compat.CapturedStep(forward_and_loss, net): copy-in of a fresh batch + one hipGraph replay per step"}
+                    cap_ms = (time.perf_counter() - f0) * 50.0
+                    nl = count_launches(lambda: eager_small(small[0]))
+                    return {"B": Bs, "N": Ns or N, "eager_ms_per_step": round(eager_small_ms, 3),
+                            "captured_step_ms_per_step": round(cap_ms, 3),
+                            "captures": helper.n_captures, "replays": helper.n_replays, "graphs_rejected_by_self_check": helper.n_rejected,
+                            "kernel_launches_per_step": None if nl is None else nl["total"],
+                            "note": "compat.CapturedStep(forward_and_loss, net): copy-in of a fresh batch + one hipGraph replay per step (no optimizer in either figure)"}
 
                 full_model["small_batch"] = small_batch(64)
-                full_model["reference_batch"] = small_batch(8)  # the reference's own configurations train with 4-32 pairs per batch
+                full_model["reference_batch"] = small_batch(8)  # the reference's own configurations train with 4-32 pairs per batch ...
+                # ... and 1000-2000 points per pair (deepFEPE/configs/kitti_corr_baseline.yaml:12-13: good_num 1000, batch_size 8)
+                full_model["reference_batch_n1000"] = small_batch(8, 1000)
                 del net
             except Exception as e:  # never let the secondary measurement break the contract line
                 full_model = {"error": repr(e)[:200]} if full_model is None else dict(full_model, small_batch={"error": repr(e)[:200]})
@@ -808,7 +827,9 @@ def main():
                                          "overlap": "double-buffered asynchronous all_reduce (dist.OverlappedLossExchange)",
                                          "none": None}[exchange_mode],
                        "loss_exchange_fallback": exchange_fallback,
-                       "env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "DEBUG_CLR_GRAPH_PACKET_CAPTURE", "DFEPE_BENCH_EXCHANGE", "NCCL_DEBUG")}},
+                       "env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "DEBUG_CLR_GRAPH_PACKET_CAPTURE", "DFEPE_BENCH_EXCHANGE", "NCCL_DEBUG")},
+                       # whether the hipGraph packet-capture workaround took effect in THIS process (set before the HIP runtime initialised)
+                       "hip_graph_packet_capture_off": bool(getattr(dfepe, "HIP_GRAPH_PACKET_CAPTURE_OFF", False))},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "accuracy": acc,

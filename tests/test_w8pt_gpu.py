@@ -116,13 +116,14 @@ def test_invalid_arguments_raise(dfepe):
         dfepe.ops.w8pt(torch.zeros(2, 10, 3), torch.zeros(2, 10, 3), torch.zeros(2, 10))  # CPU tensors: no CPU path
 
 
-@pytest.mark.parametrize("outl,noise", [(0.2, 0.5), (0.4, 0.5), (0.0, 0.0)])
-def test_full_batch_error_vs_fp64_oracle(dfepe, oracle, outl, noise):
-    """BASELINE sizes (B=4096, N=100): the north-star bound |F - F_ref|_F <= 1e-5 (unit norm, sign aligned) against the
+@pytest.mark.parametrize("B,outl,noise", [(4096, 0.2, 0.5), (4096, 0.4, 0.5), (4096, 0.0, 0.0), (1024, 0.2, 0.5)])
+def test_full_batch_error_vs_fp64_oracle(dfepe, oracle, B, outl, noise):
+    """BASELINE sizes (B=4096, N=100; B=1024: config 2 at its own size, one launch of 256 wavefronts): the north-star bound
+    |F - F_ref|_F <= 1e-5 (unit norm, sign aligned) against the
     fp64 oracle for EVERY pair, plus E = K^T T^T F T K.  Pairs whose 8th and 9th singular values are closer than 1e-4
     relative (the solution itself is ill-defined there) are held to the bound scaled by that gap."""
-    B, N = 4096, 100
-    sc = dfepe.synth.make_scene(B, N, seed=77, outlier_ratio=outl, noise_px=noise)
+    N = 100
+    sc = dfepe.synth.make_scene(B, N, seed=77 if B == 4096 else B, outlier_ratio=outl, noise_px=noise)
     m = sc["matches_xy_ori"]
     w = torch.softmax(sc["logits_layers"][0], dim=1)
     # same fp32 image-size-normalised points on both sides (the reference forms them in fp32 too, DeepFNet.py:111-113);
