@@ -74,8 +74,8 @@ struct W8Args {
 #if defined(DFEPE_ISA_MARKS)
 #define DFEPE_MARK(name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; MARK " name); __builtin_amdgcn_sched_barrier(0); } while (0)
 #elif defined(DFEPE_PHASE_CLOCKS)
-constexpr int dfepe_phase_id(const char* s) {  // P0 P1 P2 P3 P4 P4b P4c P4d P5 P5b P5s P6 Pend -> 0..12
-  return (s[1] == '0') ? 0 : (s[1] == '1') ? 1 : (s[1] == '2') ? 2 : (s[1] == '3') ? 3
+constexpr int dfepe_phase_id(const char* s) {  // P0 P1 P2 P3 P4 P4b P4c P4d P5 P5b P5s P6 Pend -> 0..12; the backward's B0 .. B7 -> 0..7
+  return (s[0] == 'B') ? (s[1] - '0') : (s[1] == '0') ? 0 : (s[1] == '1') ? 1 : (s[1] == '2') ? 2 : (s[1] == '3') ? 3
        : (s[1] == '4') ? ((s[2] == 0) ? 4 : (s[2] == 'b') ? 5 : (s[2] == 'c') ? 6 : 7)
        : (s[1] == '5') ? ((s[2] == 0) ? 8 : (s[2] == 'b') ? 9 : 10) : (s[1] == '6') ? 11 : 12;
 }
@@ -472,6 +472,26 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     }
     return v;
   };
+  // several sums behind ONE barrier (round 6; scripts/ubench/bwd_phases.hip <pairs>: at one pair per workgroup the cooperative kernel is a
+  // chain of eleven block barriers of ~600 cycles each around 4 correspondences per lane of work): the same additions in the same order
+  // as K separate psum calls on slots slot0 .. slot0 + K - 1, so the results are bit-identical
+  auto psumk = [&](auto& vals, int slot0) {
+    constexpr int K = sizeof(vals) / sizeof(vals[0]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) vals[k] = rg_sum(vals[k]);
+    if constexpr (ROWS == 2) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) vals[k] += rg_xrow(vals[k]);
+    } else if constexpr (ROWS > 1) {
+      if (l == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) co->red[slot0 + k][rowid] = vals[k];
+      }
+      DFEPE_BLOCK_SYNC();
+#pragma unroll
+      for (int k = 0; k < K; ++k) vals[k] = rg_sum(co->red[slot0 + k][l]);
+    }
+  };
   auto psumf = [&](float v) {  // looped kernels only (ROWS <= 2): the sum of the exponentials, in fp32 like the row kernel's
     v = rg_sum(v);
     if constexpr (ROWS == 2) v += rg_xrow(v);
@@ -610,7 +630,9 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
       sme += r.ws;
     });
     if (IT == 0 && A.logits_mode) linv = 1.0f / psumf(sme);
-    c1x = psum(sx1, 2) * invN; c1y = psum(sy1, 3) * invN; c2x = psum(sx2, 4) * invN; c2y = psum(sy2, 5) * invN;
+    double cs[4] = {sx1, sy1, sx2, sy2};
+    psumk(cs, 2);
+    c1x = cs[0] * invN; c1y = cs[1] * invN; c2x = cs[2] * invN; c2y = cs[3] * invN;
   DFEPE_MARK("P1");
     // ---- phase 1: Hartley scale (mean distance to the centroid) -------------------------------------------------
     double d1 = 0, d2 = 0;
@@ -624,8 +646,10 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     });
     // Fit.normalize uses the literal 1.4142, not sqrt(2) (DeepFNet.py:168); utils_F._normalize_XY uses np.sqrt(2)
     const double hscale = (variant & DFEPE_W8PT_SQRT2) ? 1.4142135623730951 : 1.4142;
-    s1 = hscale * rcp_nr<2>(psum(d1, 6) * invN);
-    s2 = hscale * rcp_nr<2>(psum(d2, 7) * invN);
+    double ds[2] = {d1, d2};
+    psumk(ds, 6);
+    s1 = hscale * rcp_nr<2>(ds[0] * invN);
+    s2 = hscale * rcp_nr<2>(ds[1] * invN);
   }
 
   if (IT == 0 && A.logits_mode && !hartley) {

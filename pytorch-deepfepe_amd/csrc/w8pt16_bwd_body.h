@@ -182,6 +182,10 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A0, const 
   const float* gepi_p = has_epi ? A.g_epi + (size_t)pair * N : wsrc;
   const float* gwx_p = has_wx ? A.g_w_extra + (size_t)pair * N : wsrc;
   float gres_r[ITR], gepi_r[ITR], gwx_r[ITR];  // IT > 0: in registers from the start
+  // (round 6, scripts/ubench/bwd_phases.hip: this block -- ~50 load instructions, no wait inside it -- is 23 % of the g_F-only kernel:
+  // a lone wavefront pays ~60 cycles per VMEM instruction it ISSUES while every CU is loading.  Keeping the correspondences raw until
+  // pass B, so that the uniform part runs under their arrival, changed nothing: 3059 vs 3064 cycles, same 250 registers -- the data
+  // is back long before the rank-2 adjoint needs it; what costs is the instruction issue itself.)
   if constexpr (IT > 0) {
     static_for<0, IT>([&](auto c) {
       constexpr int it = decltype(c)::value;
@@ -592,6 +596,7 @@ __device__ __forceinline__ void w8pt16_bwd_pair_impl(const W8BwdArgs& A0, const 
       }
     });
   }
+  DFEPE_MARK("B7_end");
 }
 
 template <int IT, bool RAW>
