@@ -10,6 +10,11 @@
 #define DFEPE_TAIL_KL 2  // layers a lone F-loss wavefront walks together (A/B: -DDFEPE_TAIL_KL=3)
 #endif
 
+#ifndef DFEPE_TAIL_STAGGER
+#define DFEPE_TAIL_STAGGER 0  // A/B switch: F-loss wavefront w of a workgroup starts w x 64 x this many cycles late (w8pt16.hip: DFEPE_FWD_STAGGER
+                              // is worth 3 % there); measured here at 64 / 128 / 256 cycles: +-0 (0.1023-0.1028 vs 0.1025-0.1030 ms per step)
+#endif
+
 namespace {
 
 constexpr int kPairsPerBlock = 16;
@@ -48,6 +53,9 @@ loss_tail_kernel(const float* F_layers, int L, int B, int M, int t_stride, const
   }
   const bool floss_wave = threadIdx.x < 256u;  // uniform per wavefront
   const int row = (int)(threadIdx.x >> 4) & 15;
+#if DFEPE_TAIL_STAGGER
+  if (floss_wave) for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) __builtin_amdgcn_s_sleep(DFEPE_TAIL_STAGGER);
+#endif
   if (floss_wave) {
     if (pair0 + row < B) tail_floss_row<IT, JAC, DFEPE_TAIL_KL>(A, pair0 + row, lds[row], part[row], lds[row] + kTailMaxLayers * 9);
   } else {

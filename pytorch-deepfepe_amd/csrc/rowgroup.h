@@ -21,6 +21,18 @@ __device__ __forceinline__ double hw_rcp64(double x) { return __builtin_amdgcn_r
 
 __device__ __forceinline__ int rg_lane() { return (int)(threadIdx.x & 15u); }
 
+// Two fp32 values in a register pair, for arithmetic that treats two correspondences of a lane alike: v_pk_fma_f32 / v_pk_mul_f32 /
+// v_pk_add_f32 do both in ONE full-rate instruction (gfx950), each half rounded exactly like the scalar instruction -- results are
+// bit-identical to the unpacked code, a kernel bound by the issue of a lone wavefront just issues half as many of these.
+typedef float pk2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk2 pk_make(float a, float b) { pk2 r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ pk2 pk_splat(float a) { pk2 r; r.x = a; r.y = a; return r; }
+__device__ __forceinline__ pk2 pk_fma(pk2 a, pk2 b, pk2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ pk2 pk_mul(pk2 a, pk2 b) { return a * b; }
+__device__ __forceinline__ pk2 pk_add(pk2 a, pk2 b) { return a + b; }
+__device__ __forceinline__ float pk_lo(pk2 a) { return a.x; }
+__device__ __forceinline__ float pk_hi(pk2 a) { return a.y; }
+
 // value of the same lane of the NEIGHBOURING row (lane ^ 16) -- for kernels that give a pair two rows of one wavefront; a DPP
 // operand cannot cross a row, so this goes through the LDS crossbar (ds_bpermute, no LDS memory)
 __device__ __forceinline__ float rg_xrow(float v) {

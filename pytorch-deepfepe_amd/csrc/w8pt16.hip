@@ -57,6 +57,28 @@ struct W8FwdRest {
   unsigned variant;
 };
 
+// Start offsets (round 6).  At 4096 pairs a CU holds ONE workgroup whose four wavefronts -- one per SIMD -- start in the same cycle and
+// run the same straight-line instruction stream in lockstep, so they reach every shared unit of the CU (instruction fetch, the texture
+// addresser with its loads and stores, the LDS exchange of the moments) in the same cycles.  Wavefront w waits w x DFEPE_*_STAGGER
+// cycles first.  Measured on one box (scripts/ab_fit.sh, captured step at B = 4096, N = 100, ms): none 0.1058-0.1062; 8 / 16 cycles
+// per wavefront 0.1029-0.1034; 32: 0.1041-0.1044; 64: 0.1034-0.1038; 128: 0.1034-0.1037; 192: 0.1041-0.1044; 512: 0.1051-0.1060 -- the
+// gain is in not being aligned, more distance only delays the last wavefront.  Also measured and dropped: offsets between the
+// workgroups of an XCD (+0.5 ... +1.5 us per step), repeating the offset at the phase boundaries of the body (+1.5 ... +6 us: the loop
+// in the middle of the stream costs more than it spreads), the same on the loss tail's F-loss wavefronts (+-0).
+#define DFEPE_STAGGER_WAIT(X)                                              \
+  do {                                                                     \
+    if constexpr ((X) >= 64) __builtin_amdgcn_s_sleep((X) / 64);           \
+    else {                                                                 \
+      if constexpr ((X) > 16) asm volatile("s_nop 15");                    \
+      asm volatile("s_nop %0" ::"n"(((X) - 1) & 15));                      \
+    }                                                                      \
+  } while (0)
+#ifndef DFEPE_FWD_STAGGER
+#define DFEPE_FWD_STAGGER 16  // cycles per wavefront index, forward fit (0: off)
+#endif
+#ifndef DFEPE_BWD_STAGGER
+#define DFEPE_BWD_STAGGER 16  // ... backward fit
+#endif
 template <int IT, bool RAW, bool PLAIN>
 __global__ void __launch_bounds__(256)
 w8pt16_fwd_kernel(const float* pts1, const float* pts2, const float* wts, int B, int Bm, int N, float hw_sx, float hw_sy,
@@ -65,6 +87,9 @@ w8pt16_fwd_kernel(const float* pts1, const float* pts2, const float* wts, int B,
   const int row = (int)(threadIdx.x >> 4);
   const int pair = (int)blockIdx.x * kPairsPerBlock + row;
   if (pair >= B) return;  // a whole row leaves; rows never wait for each other
+#if DFEPE_FWD_STAGGER
+  for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) DFEPE_STAGGER_WAIT(DFEPE_FWD_STAGGER);
+#endif
   W8Args A;
   A.pts1 = pts1; A.pts2 = pts2; A.wts = wts; A.B = B; A.Bm = Bm; A.N = N; A.hw_sx = hw_sx; A.hw_sy = hw_sy;
   A.clamp_at = clamp_at; A.F_out = F_out; A.residual = residual; A.epi_res = R.epi_res; A.save = R.save;
@@ -173,6 +198,9 @@ w8pt16_bwd_kernel(const float* pts1, const float* pts2, const float* wts, int B,
   const int row = (int)(threadIdx.x >> 4);
   const int pair = (int)blockIdx.x * kPairsPerBlock + row;
   if (pair >= B) return;
+#if DFEPE_BWD_STAGGER
+  for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) DFEPE_STAGGER_WAIT(DFEPE_BWD_STAGGER);
+#endif
   W8BwdArgs A;
   A.pts1 = pts1; A.pts2 = pts2; A.wts = wts; A.B = B; A.Bm = Bm; A.N = N; A.hw_sx = hw_sx; A.hw_sy = hw_sy;
   A.clamp_at = clamp_at; A.save = save; A.F_out = R.F_out; A.g_F = R.g_F; A.g_res = R.g_res; A.g_epi = R.g_epi;
@@ -218,6 +246,9 @@ w8pt16_bwd_head_kernel(const float* pts1, const float* pts2, const float* wts, i
   const int row = (int)(threadIdx.x >> 4);
   const int pair = (int)blockIdx.x * kPairsPerBlock + row;
   if (pair >= B) return;
+#if DFEPE_BWD_STAGGER
+  for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) DFEPE_STAGGER_WAIT(DFEPE_BWD_STAGGER);
+#endif
   W8BwdArgs A;
   A.pts1 = pts1; A.pts2 = pts2; A.wts = wts; A.B = B; A.Bm = Bm; A.N = N; A.hw_sx = hw_sx; A.hw_sy = hw_sy;
   A.clamp_at = clamp_at; A.save = save; A.F_out = R.F_out; A.g_F = R.g_F; A.g_res = R.g_res; A.g_epi = R.g_epi;

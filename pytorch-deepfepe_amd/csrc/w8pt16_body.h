@@ -91,6 +91,10 @@ extern __device__ unsigned long long* g_dfepe_phase_clk;  // [wavefront][16]
 #define DFEPE_MARK(name)
 #endif
 
+#ifndef DFEPE_P6_FAST
+#define DFEPE_P6_FAST 1  // the output phase of the registers-resident kernels: unguarded stores where the guards are known to hold (round 6)
+#endif
+
 template <int I, int E, class Fn>
 __device__ __forceinline__ void static_for(Fn&& fn) {
   if constexpr (I < E) {
@@ -957,6 +961,7 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
   // ---- phase 6: per-correspondence outputs ----------------------------------------------------------------------
   float* rdst = A.residual + (size_t)pair * N;
   float* edst = (A.epi_res != nullptr) ? A.epi_res + (size_t)pair * N : nullptr;
+  float* wdst = A.weights_out + (size_t)pair * N;  // only dereferenced where weights_out was tested
   // LEAN: the correspondence is fetched and decoded again; its weight in X is still in the lane's registers
   auto reload = [&](int it) {
     RawRec r;
@@ -971,7 +976,29 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     }
     return r;
   };
-  auto out_body = [&](int it, const PRec& rec) {
+  // the symmetric epipolar residual of TWO correspondences in packed fp32 (DFEPE_P6_FAST): each half is the scalar expression of
+  // out_body below, operation for operation, so the outputs are bit-identical -- a lone wavefront just issues half as many instructions
+  auto epi2 = [&](const pk2 x1, const pk2 y1, const pk2 z1, const pk2 x2, const pk2 y2, const pk2 z2, float& da, float& db) {
+    auto zmul = [](pk2 z, pk2 v) { return RAW ? v : pk_mul(z, v); };  // pixel matches: z = 1, and 1 * v = v exactly
+    const pk2 l1x = pk_fma(x2, pk_splat(of[0]), pk_fma(y2, pk_splat(of[3]), zmul(z2, pk_splat(of[6]))));
+    const pk2 l1y = pk_fma(x2, pk_splat(of[1]), pk_fma(y2, pk_splat(of[4]), zmul(z2, pk_splat(of[7]))));
+    const pk2 l1z = pk_fma(x2, pk_splat(of[2]), pk_fma(y2, pk_splat(of[5]), zmul(z2, pk_splat(of[8]))));
+    const pk2 l2x = pk_fma(x1, pk_splat(of[0]), pk_fma(y1, pk_splat(of[1]), zmul(z1, pk_splat(of[2]))));
+    const pk2 l2y = pk_fma(x1, pk_splat(of[3]), pk_fma(y1, pk_splat(of[4]), zmul(z1, pk_splat(of[5]))));
+    const pk2 dd = pk_fma(x1, l1x, pk_fma(y1, l1y, zmul(z1, l1z)));
+    const pk2 q1 = pk_fma(l1x, l1x, pk_mul(l1y, l1y)), q2 = pk_fma(l2x, l2x, pk_mul(l2y, l2y));
+    const pk2 n1 = pk_add(pk_make(hw_sqrt(pk_lo(q1)), hw_sqrt(pk_hi(q1))), pk_splat(1e-6f));
+    const pk2 m2 = pk_add(pk_make(hw_sqrt(pk_lo(q2)), hw_sqrt(pk_hi(q2))), pk_splat(1e-6f));
+    const pk2 rr = pk_add(pk_make(hw_rcp(pk_lo(n1)), hw_rcp(pk_hi(n1))), pk_make(hw_rcp(pk_lo(m2)), hw_rcp(pk_hi(m2))));
+    da = fminf(fabsf(pk_lo(dd)) * pk_lo(rr), A.clamp_at);
+    db = fminf(fabsf(pk_hi(dd)) * pk_hi(rr), A.clamp_at);
+  };
+  // GUARD = false (DFEPE_P6_FAST, the registers-resident kernels): the caller has established that this correspondence exists and that
+  // the training outputs (epi_res, weights_out) are wanted -- straight-line stores, no exec region and no pointer test per correspondence
+  // d_given: the epipolar residual of this correspondence was computed by epi2 (d_in)
+  auto out_body = [&](int it, const PRec& rec, auto guard_c, auto d_given, const float d_in) {
+    constexpr bool GUARD = decltype(guard_c)::value;
+    constexpr bool DGIVEN = decltype(d_given)::value;
     const int i = it * S + L;
     const Pt& p = rec.p;
     const float wf = rec.w;
@@ -991,6 +1018,8 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     if (!PLAIN) inv = (variant & DFEPE_W8PT_NO_ROWNORM) ? 1.0 : inv;  // X_i = w_i p_i
     const float r = (float)(row_bilinear(ra, rb, f) * inv * (double)wf);
     // l1 = F^T x2 (row form x2 F), l2 = F x1, dd = x2^T F x1 = x1 . l1     (utils_F.py:402-411), fp32 like the reference
+    float d = d_in;
+    if constexpr (!DGIVEN) {
     const float l1x = fmaf(p.x2, of[0], fmaf(p.y2, of[3], p.z2 * of[6]));
     const float l1y = fmaf(p.x2, of[1], fmaf(p.y2, of[4], p.z2 * of[7]));
     const float l1z = fmaf(p.x2, of[2], fmaf(p.y2, of[5], p.z2 * of[8]));
@@ -999,7 +1028,13 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
     const float dd = fmaf(p.x1, l1x, fmaf(p.y1, l1y, p.z1 * l1z));
     const float n1 = hw_sqrt(fmaf(l1x, l1x, l1y * l1y)) + 1e-6f;  // v_sqrt_f32 / v_rcp_f32: 1 ulp, far inside the tolerance
     const float m2 = hw_sqrt(fmaf(l2x, l2x, l2y * l2y)) + 1e-6f;
-    const float d = fminf(fabsf(dd) * (hw_rcp(n1) + hw_rcp(m2)), A.clamp_at);
+    d = fminf(fabsf(dd) * (hw_rcp(n1) + hw_rcp(m2)), A.clamp_at);
+    }
+    if constexpr (!GUARD) {
+      rdst[i] = r;
+      edst[i] = d;
+      if constexpr (IT > 0) wdst[i] = wsm[it];
+    } else {
     if (valid) {
       rdst[i] = r;
       if (edst != nullptr) edst[i] = d;
@@ -1007,8 +1042,27 @@ __device__ __forceinline__ void w8pt16_fwd_pair(const W8Args& A, const int pair,
         if (A.logits_mode && A.weights_out != nullptr) A.weights_out[(size_t)pair * N + i] = wsm[it];
       }
     }
+    }
   };
-  if constexpr (LEAN) for_points<IT>(nit, reload, point_out, out_body);
-  else for_points<IT>(nit, point_load, point, out_body);
+  auto out_guarded = [&](int it, const PRec& rec) { out_body(it, rec, std::true_type{}, std::false_type{}, 0.0f); };
+  if constexpr (LEAN) for_points<IT>(nit, reload, point_out, out_guarded);
+  else if constexpr (DFEPE_P6_FAST != 0 && IT > 1) {
+    // all of the lane's correspondences but its last one exist whenever N > S (IT - 1) -- the shape the instantiation was chosen for
+    // (N = 100: IT = 7, 96 < N) -- and the training call wants every per-correspondence output: 3 IT stores in a row
+    if (N > S * (IT - 1) && edst != nullptr && A.logits_mode && A.weights_out != nullptr) {
+      static_for<0, (IT - 1) / 2>([&](auto c) {
+        constexpr int it = 2 * decltype(c)::value;
+        float da, db;
+        epi2(pk_make(pt[it].x1, pt[it + 1].x1), pk_make(pt[it].y1, pt[it + 1].y1), pk_make(pt[it].z1, pt[it + 1].z1),
+             pk_make(pt[it].x2, pt[it + 1].x2), pk_make(pt[it].y2, pt[it + 1].y2), pk_make(pt[it].z2, pt[it + 1].z2), da, db);
+        out_body(it, point(it, RawRec{}), std::false_type{}, std::true_type{}, da);
+        out_body(it + 1, point(it + 1, RawRec{}), std::false_type{}, std::true_type{}, db);
+      });
+      if constexpr (((IT - 1) & 1) != 0) out_body(IT - 2, point(IT - 2, RawRec{}), std::false_type{}, std::false_type{}, 0.0f);
+      out_body(IT - 1, point(IT - 1, RawRec{}), std::true_type{}, std::false_type{}, 0.0f);
+    } else {
+      for_points<IT>(nit, point_load, point, out_guarded);
+    }
+  } else for_points<IT>(nit, point_load, point, out_guarded);
   DFEPE_MARK("Pend");
 }

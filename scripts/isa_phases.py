@@ -41,7 +41,7 @@ def main():
         src = os.path.join(d, "one.hip")
         open(src, "w").write(SRC[which] % (it, raw))
         out = os.path.join(d, "one.s")
-        subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-fast-math", "-ffp-contract=on", "-DDFEPE_ISA_MARKS",
+        subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-fast-math", "-ffp-contract=on", "-DDFEPE_ISA_MARKS", *os.environ.get("DFEPE_EXTRA_DEFS", "").split(),
                         f"-I{REPO}/include", f"-I{CSRC}", "-S", "--cuda-device-only", src, "-o", out,
                         "-Rpass-analysis=kernel-resource-usage"], check=True, stderr=subprocess.PIPE)
         lines = open(out).read().split("\n")

@@ -33,6 +33,16 @@ struct float4 {
   float x, y, z, w;
 };
 
+// two fp32 values handled alike (the device packs them into one v_pk_* instruction; each half rounds like the scalar operation)
+struct pk2 { float x, y; };
+inline pk2 pk_make(float a, float b) { return pk2{a, b}; }
+inline pk2 pk_splat(float a) { return pk2{a, a}; }
+inline pk2 pk_fma(pk2 a, pk2 b, pk2 c) { return pk2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+inline pk2 pk_mul(pk2 a, pk2 b) { return pk2{a.x * b.x, a.y * b.y}; }
+inline pk2 pk_add(pk2 a, pk2 b) { return pk2{a.x + b.x, a.y + b.y}; }
+inline float pk_lo(pk2 a) { return a.x; }
+inline float pk_hi(pk2 a) { return a.y; }
+
 inline float hw_rsq(float x) { return 1.0f / sqrtf(x); }
 inline float hw_rcp(float x) { return 1.0f / x; }
 inline float hw_sqrt(float x) { return sqrtf(x); }
