@@ -83,6 +83,14 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
+def capture_mode():
+    """"thread_local" once an RCCL group exists (its watchdog thread must be free to poll events while this thread captures:
+    pytorch-deepfepe_amd/dist.py graph_capture_mode), torch's default otherwise."""
+    import torch.distributed as dist
+
+    return "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+
+
 def _free_port():
     import socket
 
@@ -164,7 +172,7 @@ def event_time_us(fn, reps=50, rounds=5, warm=5, graph=True):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode=capture_mode()):
             for _ in range(reps):
                 fn()
         g.replay()
@@ -192,14 +200,18 @@ def count_launches(fn):
 
         fn()
         torch.cuda.synchronize()
-        with profile(activities=[ProfilerActivity.CUDA]) as prof:
-            fn()
-            torch.cuda.synchronize()
-        names = {}
-        for ev in prof.events():
-            if str(getattr(ev, "device_type", "")).endswith("CUDA") and "memcpy" not in ev.name.lower() and "memset" not in ev.name.lower():
-                names[ev.name] = names.get(ev.name, 0) + 1
-        n = sum(names.values())
+        names, n = {}, 0
+        for _ in range(3):  # the ROCm tracer behind torch.profiler drops records now and then (round 6: 164, 94 and 17 "launches" for the
+            # same step on three boxes): a count can only come out too LOW, so the largest of three passes is kept
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                fn()
+                torch.cuda.synchronize()
+            seen = {}
+            for ev in prof.events():
+                if str(getattr(ev, "device_type", "")).endswith("CUDA") and "memcpy" not in ev.name.lower() and "memset" not in ev.name.lower():
+                    seen[ev.name] = seen.get(ev.name, 0) + 1
+            if sum(seen.values()) > n:
+                names, n = seen, sum(seen.values())
         ours = sum(c for k, c in names.items() if any(t in k for t in ("w8pt", "loss_tail", "loss_stats", "floss", "pose_", "geo_misc", "deepf_input", "row_dot")))
         return {"total": n, "hip_kernels_of_this_library": ours, "torch_glue": n - ours} if n else None
     except Exception:
@@ -284,7 +296,7 @@ def measure_api_path(dfepe, scene, logits, L, balance_F, args, B, fused_ms, fuse
         finally:
             tgu.LAZY_HOST_METRICS = False
         gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr):
+        with torch.cuda.graph(gr, capture_error_mode=capture_mode()):
             body()
         for _ in range(args.warmup + 20):
             gr.replay()
@@ -399,7 +411,7 @@ def main():
         captured = 1
         try:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode=capture_mode()):
                 last = step_body()
         except Exception as exc:  # only a captured collective is allowed to fail: the step then keeps it outside the graph
             if exchange_mode not in ("graph", "branch"):
@@ -415,7 +427,7 @@ def main():
                 exchange_fallback = exchange_fallback or "another rank failed to capture the all-reduce"
                 exchange_mode, loss_exchange = "sync", None  # step_body reads loss_exchange at call time
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode=capture_mode()):
                     last = step_body()
     log("graph captured" if graph is not None else "eager mode")
 
@@ -595,7 +607,7 @@ def main():
                 torch.cuda.synchronize()
                 same = bool(torch.equal(gb, state["grad_logits"]))
                 gr_b = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gr_b):
+                with torch.cuda.graph(gr_b, capture_error_mode=capture_mode()):
                     gb = body_b()
                 for _ in range(args.warmup):
                     gr_b.replay()

@@ -44,6 +44,7 @@ import numpy as np
 import torch
 
 from .. import _lib
+from .. import dist as _dist
 
 
 def _flatten(obj, path=()):
@@ -234,7 +235,7 @@ class CapturedStep:
         ent.graph = torch.cuda.CUDAGraph()
         # (get_Rt_loss hands out lazy host metrics by itself while its stream is being captured: no module-global is flipped here --
         # round 5 toggled train_good_utils.LAZY_HOST_METRICS around the capture, under the feet of other threads)
-        with torch.cuda.graph(ent.graph, pool=self._pool, stream=self._stream):
+        with torch.cuda.graph(ent.graph, pool=self._pool, stream=self._stream, capture_error_mode=_dist.graph_capture_mode()):
             ent.out = self._run(ent.batch)
         if self._pool is None:
             self._pool = ent.graph.pool()

@@ -16,6 +16,15 @@ import torch.distributed as dist
 Tensor = torch.Tensor
 
 
+def graph_capture_mode() -> str:
+    """``capture_error_mode`` for ``torch.cuda.graph`` in a process that holds an RCCL process group: "thread_local".  The group's
+    watchdog thread polls the events of earlier collectives with hipEventQuery; in the default "global" mode that call is illegal
+    while ANY thread captures, the watchdog dies of "operation not permitted when stream is capturing" and takes the process with
+    it (seen in round 6 as `Fatal Python error: Aborted` in the middle of a capture that held an all-reduce -- a race: the poll has
+    to fall inside the capture).  Without a process group: "global", torch's default."""
+    return "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+
+
 def shard_range(B: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous [start, stop) of rank's pairs; the first B % world ranks get one extra pair."""
     if not (0 <= rank < world):
