@@ -236,3 +236,33 @@ def test_lean_forward_fit_of_large_batches_is_bit_identical(dfepe, N):
     F, res, epi, save, wout = big
     g = dfepe.ops.w8pt_backward(m, None, wout, True, 1241.0, 376.0, 0.5, save, F, torch.ones_like(F), None, None, logits=True)
     assert torch.isfinite(g).all()
+
+
+@pytest.mark.parametrize("N", [100, 97, 112, 96, 128, 113, 65, 33, 17])
+def test_training_call_output_phase_equals_the_guarded_one(dfepe, N):
+    """Round 6 (w8pt16_body.h: DFEPE_P6_FAST): a call that wants every per-correspondence output (logits in, epi_res, weights_out)
+    and whose N fills all but the lane's last correspondence takes an output phase without per-correspondence guards and with the
+    epipolar residual of two correspondences per packed-fp32 instruction.  It must write bit for bit what the guarded phase writes:
+    the same launch WITHOUT epi_res (guarded), and the softmax weights fed back as plain weights (guarded, no weights_out), agree
+    with it in every shared output (ragged last group, dropped correspondences included)."""
+    B = 37
+    sc = dfepe.synth.make_scene(B, N, seed=900 + N, outlier_ratio=0.3, noise_px=0.5)
+    m = sc["matches_xy_ori"].clone()
+    m[1, N // 2, 2] = float("nan")
+    m[2, N - 1, 0] = float("inf")
+    m = m.to(DEV).contiguous()
+    logits = sc["logits_layers"][0].to(DEV).contiguous()
+    F1, r1, e1, s1, w1 = dfepe.ops.w8pt_forward(m, None, logits, True, 1241.0, 376.0, 0.5, True, True, logits=True)
+    F2, r2, e2, s2, w2 = dfepe.ops.w8pt_forward(m, None, logits, True, 1241.0, 376.0, 0.5, False, True, logits=True)  # no epi_res: guarded phase
+    F3, r3, e3, _, _ = dfepe.ops.w8pt_forward(m, None, w1, True, 1241.0, 376.0, 0.5, True, False)  # plain weights: guarded phase
+    torch.cuda.synchronize()
+
+    def same(a, b):
+        return bool((a.view(torch.int32) == b.view(torch.int32)).all())
+
+    assert same(F1, F2) and same(r1, r2) and same(w1, w2)
+    s1[:, 24:26] = 0; s2[:, 24:26] = 0; s1[:, 61:64] = 0; s2[:, 61:64] = 0  # scratch slots of the record
+    assert same(s1, s2)
+    assert same(F1, F3)  # the softmax weights as plain weights are the same rows of X
+    assert same(e1, e3) and same(r1, r3)
+    assert torch.isfinite(r1).all() and torch.isfinite(e1).all() and torch.isfinite(w1).all()
