@@ -73,6 +73,12 @@ struct W8FwdRest {
       asm volatile("s_nop %0" ::"n"(((X) - 1) & 15));                      \
     }                                                                      \
   } while (0)
+#ifndef DFEPE_PAIR2_STAGGER
+#define DFEPE_PAIR2_STAGGER 16  // the N = 1000 fit with two rows per pair (two wavefronts per SIMD at 4096 pairs): wavefront w of a workgroup, and
+                                // the workgroups a CU receives second (ids 256 apart), start 16 (w [+ 4]) cycles late: bench.py --config 5
+                                // 0.1586-0.1588 -> 0.1561-0.1569 ms (same box, twice).  The same on the lean fit (config 4 as one 32768-pair
+                                // batch: workgroups queue for the CUs, only the first wave of them starts together): +-0, not kept
+#endif
 #ifndef DFEPE_FWD_STAGGER
 #define DFEPE_FWD_STAGGER 16  // cycles per wavefront index, forward fit (0: off)
 #endif
@@ -127,6 +133,9 @@ w8pt16_pair2_fwd_kernel(const float* pts1, const float* pts2, const float* wts, 
   const int prow = (int)(threadIdx.x >> 5);  // pair within the workgroup
   const int pair = (int)blockIdx.x * kPairsPerBlock2 + prow;
   if (pair >= B) return;  // both rows of a pair leave together
+#if DFEPE_PAIR2_STAGGER
+  for (int k = 0; k < (int)(threadIdx.x >> 6) + 4 * (int)((blockIdx.x >> 8) & 1u); ++k) DFEPE_STAGGER_WAIT(DFEPE_PAIR2_STAGGER);
+#endif
   W8Args A;
   A.pts1 = pts1; A.pts2 = pts2; A.wts = wts; A.B = B; A.Bm = Bm; A.N = N; A.hw_sx = hw_sx; A.hw_sy = hw_sy;
   A.clamp_at = clamp_at; A.F_out = F_out; A.residual = residual; A.epi_res = R.epi_res; A.save = R.save;
