@@ -452,8 +452,13 @@ def main():
 
     # untimed spin-up in front of the W warm-up steps: a few ms of the same step so that clocks and caches are those of a running
     # job whatever W and K the caller picked (reported as "spinup_steps"; the timed region is exactly K steps of full work)
-    for _ in range(args.spinup):
+    # (synchronised every 20 steps: a host that has queued all of them and then sleeps 20 ms in the barrier below comes back slow --
+    # with the driver's K = 20 the timed 2 ms then measured 0.104-0.114 ms per step on one box where the ten 20-step blocks behind
+    # it, identical code after a 2 ms wait, all gave 0.103: scripts/bench_jitter.sh)
+    for i in range(args.spinup):
         run_step()
+        if i % 20 == 19 and os.environ.get("DFEPE_BENCH_SPINUP_SYNC", "1") != "0":
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         run_step()
     barrier()
