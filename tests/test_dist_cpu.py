@@ -147,6 +147,30 @@ def test_overlapped_loss_exchange_without_process_group():
     np.testing.assert_allclose(ex.drain().numpy(), [1.0, 2.0, 3.0])
 
 
+def _capture_mode_worker(port, q):
+    sys.path.insert(0, REPO)
+    dfepe = importlib.import_module("pytorch-deepfepe_amd")
+    bench = importlib.import_module("bench")
+    before = (dfepe.dist.graph_capture_mode(), bench.capture_mode())
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    during = (dfepe.dist.graph_capture_mode(), bench.capture_mode())
+    dist.destroy_process_group()
+    q.put((before, during, (dfepe.dist.graph_capture_mode(), bench.capture_mode())))
+
+
+def test_graph_capture_mode_follows_the_process_group():
+    """Round 6: a hipGraph capture next to a process group must be thread-local -- the group's watchdog thread polls events, which the
+    default global mode forbids while any thread captures (the process aborted on the GPU box) -- and torch's default otherwise.  The
+    library's helper and bench.py's agree."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_capture_mode_worker, args=(_free_port(), q))
+    p.start()
+    before, during, after = q.get(timeout=120)
+    p.join(60)
+    assert before == ("global", "global") and during == ("thread_local", "thread_local") and after == ("global", "global")
+
+
 def test_bench_self_launch_command_is_the_drivers_invocation():
     """`python bench.py --gpus N` (no RANK in the environment) re-executes under torch.distributed.run with N ranks on 127.0.0.1
     -- the command the driver uses for N > 1 -- and the ranks are told not to launch again."""
