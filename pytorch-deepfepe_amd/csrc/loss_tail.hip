@@ -11,8 +11,8 @@
 #endif
 
 #ifndef DFEPE_TAIL_STAGGER
-#define DFEPE_TAIL_STAGGER 0  // A/B switch: F-loss wavefront w of a workgroup starts w x 64 x this many cycles late (w8pt16.hip: DFEPE_FWD_STAGGER
-                              // is worth 3 % there); measured here at 64 / 128 / 256 cycles: +-0 (0.1023-0.1028 vs 0.1025-0.1030 ms per step)
+#define DFEPE_TAIL_STAGGER 0  // A/B switch: F-loss wavefront w of a workgroup starts w x this many cycles late (w8pt16.hip: DFEPE_FWD_STAGGER
+                              // is worth 3 % there); measured here at 8 / 16 / 24 / 64 / 128 / 256 cycles: +-0 (0.1022-0.1038 vs 0.1023-0.1035 ms per step)
 #endif
 
 namespace {
@@ -54,7 +54,15 @@ loss_tail_kernel(const float* F_layers, int L, int B, int M, int t_stride, const
   const bool floss_wave = threadIdx.x < 256u;  // uniform per wavefront
   const int row = (int)(threadIdx.x >> 4) & 15;
 #if DFEPE_TAIL_STAGGER
-  if (floss_wave) for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) __builtin_amdgcn_s_sleep(DFEPE_TAIL_STAGGER);
+  if (floss_wave) {
+    for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) {
+      if constexpr (DFEPE_TAIL_STAGGER >= 64) __builtin_amdgcn_s_sleep(DFEPE_TAIL_STAGGER / 64);
+      else {
+        if constexpr (DFEPE_TAIL_STAGGER > 16) asm volatile("s_nop 15");
+        asm volatile("s_nop %0" ::"n"((DFEPE_TAIL_STAGGER - 1) & 15));
+      }
+    }
+  }
 #endif
   if (floss_wave) {
     if (pair0 + row < B) tail_floss_row<IT, JAC, DFEPE_TAIL_KL>(A, pair0 + row, lds[row], part[row], lds[row] + kTailMaxLayers * 9);
